@@ -1,0 +1,212 @@
+"""Synthetic problem instances for the energies this backend accelerates.
+
+Host-side numpy only.  Every generator returns a `Problem` whose `params` list is ordered by the binding
+index each array / scalar has in the energy's .t file (what a caller puts in Opt_ProblemSolve's void**).
+The shapes mirror the reference example harnesses (cited per generator); there is no network, so image /
+mesh payloads are procedural.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+# examples/data/cat512.constraints (public-domain marker list: source x,y -> target x,y on a 512^2 image)
+CAT512_MARKERS = [
+    (30, 132, 59, 44), (229, 51, 157, 91), (430, 124, 379, 42), (281, 369, 326, 323), (197, 407, 163, 418),
+    (64, 386, 26, 300), (311, 168, 253, 182), (89, 228, 56, 255), (92, 192, 84, 192),
+]
+
+
+@dataclass
+class Problem:
+    energy: str                 # .t file stem
+    dims: tuple                 # Opt_ProblemPlan dimensions
+    params: list                # host arrays / scalars by binding index
+    unknown_slots: tuple        # which entries of `params` are unknowns (updated in place by a solve)
+    double: bool = False
+    meta: dict = field(default_factory=dict)
+
+    def clone(self):
+        return Problem(self.energy, self.dims, [np.array(p, copy=True) for p in self.params], self.unknown_slots,
+                       self.double, dict(self.meta))
+
+
+def image_warping(W, H=None, double=False, random_state=None, mask_fraction=0.0, perturb=0.0):
+    """examples/image_warping/src/CombinedSolver.h:110-207 + main.cpp:98-108, constraint ramp alpha=1.
+
+    random_state/mask_fraction/perturb > 0 give the randomised variant used by the parity tests
+    (masked pixels, non-zero angles, perturbed offsets) so every branch of the energy is exercised.
+    """
+    H = H or W
+    ft = np.float64 if double else np.float32
+    xs, ys = np.meshgrid(np.arange(W, dtype=ft), np.arange(H, dtype=ft))
+    urshape = np.stack([xs, ys], axis=-1).astype(ft)                  # (H,W,2), x fastest
+    offset = urshape.copy()
+    angle = np.zeros((H, W), dtype=ft)
+    mask = np.zeros((H, W), dtype=ft)
+    constraints = np.full((H, W, 2), -1.0, dtype=ft)
+    # border pixels pinned to themselves (main.cpp:98-108)
+    constraints[0, :, :] = urshape[0, :, :]
+    constraints[-1, :, :] = urshape[-1, :, :]
+    constraints[:, 0, :] = urshape[:, 0, :]
+    constraints[:, -1, :] = urshape[:, -1, :]
+    sx, sy = W / 512.0, H / 512.0
+    for (x0, y0, x1, y1) in CAT512_MARKERS:
+        x, y = int(x0 * sx), int(y0 * sy)
+        if 0 <= x < W and 0 <= y < H:
+            constraints[y, x] = (int(x1 * sx), int(y1 * sy))
+    if random_state is not None:
+        rng = np.random.default_rng(random_state)
+        if mask_fraction > 0:
+            mask[rng.random((H, W)) < mask_fraction] = 255.0
+        if perturb > 0:
+            offset += (perturb * rng.standard_normal((H, W, 2))).astype(ft)
+            angle += (0.3 * perturb * rng.standard_normal((H, W))).astype(ft)
+            extra = rng.random((H, W)) < 0.05
+            constraints[extra] = (urshape[extra] + 3.0 * rng.standard_normal((int(extra.sum()), 2))).astype(ft)
+            constraints[extra] = np.abs(constraints[extra])
+    w_fit = np.array(np.sqrt(np.float32(100.0)), dtype=np.float32)     # CombinedSolver.h:126-130
+    w_reg = np.array(np.sqrt(np.float32(0.01)), dtype=np.float32)
+    return Problem("image_warping", (W, H), [offset, angle, urshape, constraints, mask, w_fit, w_reg], (0, 1), double)
+
+
+def poisson_image_editing(W, H=None, double=False, seed=0):
+    """examples/poisson_image_editing/src/CombinedSolver.h:29-50, 66-90: float4 base image X, inserted image T,
+    mask M = 0 inside the pasted region (solved), 255 outside (kept)."""
+    H = H or W
+    ft = np.float64 if double else np.float32
+    rng = np.random.default_rng(seed)
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H))
+    base = np.stack([128 + 100 * np.sin(xs / 17.0), 128 + 100 * np.cos(ys / 23.0), 0.5 * (xs + ys) % 255, np.full_like(xs, 255.0, dtype=float)], -1)
+    ins = rng.uniform(0, 255, size=(H, W, 4))
+    ins[..., 3] = 255.0
+    M = np.full((H, W), 255.0)
+    M[H // 4: H // 4 + H // 2, W // 4: W // 4 + W // 2] = 0.0
+    return Problem("poisson_image_editing", (W, H), [base.astype(ft), ins.astype(ft), M.astype(ft)], (0,), double)
+
+
+def laplacian(W, H=None, seed=0):
+    """tests/minimal/main.cpp:44-56: random target in [0,1], unknown initialised to the target."""
+    H = H or W
+    rng = np.random.default_rng(seed)
+    A = rng.random((H, W)).astype(np.float32)
+    return Problem("laplacian", (W, H), [A.copy(), A], (0,), False)
+
+
+def curve_fitting(n=512, double=True):
+    """tests/minimal_graph_only/main.cpp:43-90: y = a cos(bx) + b sin(ax), (a,b) = (100,102), start (99.7,101.6)."""
+    ft = np.float64 if double else np.float32
+    a, b = 100.0, 102.0
+    x = (np.arange(n, dtype=np.float32).astype(np.float64) * 2.0 * 3.141592653589 / n)
+    y = a * np.cos(b * x) + b * np.sin(a * x)
+    data = np.stack([x, y], -1).astype(ft)
+    unknown = np.array([[np.float32(99.7), np.float32(101.6)]], dtype=ft)
+    n_edges = np.array(n, dtype=np.int32)
+    end_nodes = np.arange(n, dtype=np.int32)      # "d": data index
+    start_nodes = np.zeros(n, dtype=np.int32)     # "p": parameter index
+    return Problem("curveFitting", (n, 1), [unknown, data, n_edges, end_nodes, start_nodes], (0,), double,
+                   {"goal": (a, b)})
+
+
+def grid_mesh_edges(nx, ny):
+    """Directed half-edges of a regular triangulated grid, grouped by head vertex exactly like
+    createGraphFromNeighborLists (examples/shared/OptGraph.h:64-76)."""
+    idx = np.arange(nx * ny).reshape(ny, nx)
+    nbr = [(1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (-1, -1)]      # 6-valence interior
+    heads, tails = [], []
+    ys, xs = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+    cols = []
+    for dx, dy in nbr:
+        tx, ty = xs + dx, ys + dy
+        ok = (tx >= 0) & (tx < nx) & (ty >= 0) & (ty < ny)
+        t = np.where(ok, idx[np.clip(ty, 0, ny - 1), np.clip(tx, 0, nx - 1)], -1)
+        cols.append(t.reshape(-1))
+    T = np.stack(cols, 1)                                            # (N,6), -1 where absent
+    h = np.repeat(np.arange(nx * ny), 6).reshape(-1, 6)
+    keep = T >= 0
+    heads = h[keep].astype(np.int32)
+    tails = T[keep].astype(np.int32)
+    return heads, tails
+
+
+def arap_mesh_deformation(nx, ny=None, double=False, seed=0, perturb=0.0):
+    """examples/arap_mesh_deformation/src/CombinedSolver.h:62-164 on a procedural grid mesh (the reference's
+    mesh blobs are not shipped): UrShape = Offset = rest pose, Angle = 0, Constraints = -inf except handles."""
+    ny = ny or nx
+    ft = np.float64 if double else np.float32
+    N = nx * ny
+    ys, xs = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+    rest = np.stack([xs.reshape(-1) * 0.01, ys.reshape(-1) * 0.01, 0.02 * np.sin(xs.reshape(-1) * 0.1) * np.cos(ys.reshape(-1) * 0.13)], -1).astype(ft)
+    offset = rest.copy()
+    angle = np.zeros((N, 3), dtype=ft)
+    cons = np.full((N, 3), -np.inf, dtype=ft)
+    # handles: pin the left column, displace the right column (like the .mrk marker files)
+    left = (xs.reshape(-1) == 0)
+    right = (xs.reshape(-1) == nx - 1)
+    cons[left] = rest[left]
+    cons[right] = rest[right] + np.array([0.0, 0.05 * ny * 0.01, 0.1 * nx * 0.01], dtype=ft)
+    if perturb > 0:
+        rng = np.random.default_rng(seed)
+        offset += (perturb * rng.standard_normal((N, 3))).astype(ft)
+        angle += (perturb * 5 * rng.standard_normal((N, 3))).astype(ft)
+    heads, tails = grid_mesh_edges(nx, ny)
+    w_fit = np.array(np.sqrt(np.float32(4.0)), dtype=np.float32)      # main.cpp:103-104
+    w_reg = np.array(np.sqrt(np.float32(1.0)), dtype=np.float32)
+    n_edges = np.array(len(heads), dtype=np.int32)
+    return Problem("arap_mesh_deformation", (N,), [w_fit, w_reg, offset, angle, rest, cons, n_edges, heads, tails], (2, 3), double,
+                   {"n_edges": int(len(heads))})
+
+
+# decoded from examples/data/shape_from_shading/default.SFSSolverParameters (struct layout TerraSolverParameters.h:7-44)
+SFS_FIXTURE = dict(w_p=100.0, w_s=100.0, w_g=1.0, fx=574.0529, fy=574.0528, ux=320.0, uy=240.0,
+                   L=[0.6908, 0.0446, 0.0181, -0.1773, -0.0407, 0.1447, 0.0239, -0.2466, 0.0058])
+
+
+def _sfs_render(depth, fx, fy, ux, uy, L):
+    """Shading B of shape_from_shading.t:32-54 evaluated on a depth map (numpy, float64)."""
+    H, W = depth.shape
+    j, i = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    d1 = depth
+    d0 = np.roll(depth, 1, axis=1)     # X(-1,0)
+    d2 = np.roll(depth, 1, axis=0)     # X(0,-1)
+    nx = d2 * (d1 - d0) / fy
+    ny = d0 * (d1 - d2) / fx
+    nz = nx * (ux - i) / fx + ny * (uy - j) / fy - d0 * d2 / (fx * fy)
+    sq = nx * nx + ny * ny + nz * nz
+    inv = np.where(sq > 0, 1.0 / np.sqrt(np.where(sq > 0, sq, 1.0)), 1.0)
+    nx, ny, nz = nx * inv, ny * inv, nz * inv
+    return (L[0] + L[1] * ny + L[2] * nz + L[3] * nx + L[4] * nx * ny + L[5] * ny * nz +
+            L[6] * (-nx * nx - ny * ny + 2 * nz * nz) + L[7] * nz * nx + L[8] * (nx * nx - ny * ny))
+
+
+def shape_from_shading(W, H=None, double=True, seed=0, holes=False, noise=1e-3):
+    """examples/shape_from_shading/src/SFSSolverInput.h:22-47 binding order; synthetic smooth depth,
+    intensity rendered from it with the fixture's SH lighting, intrinsics scaled from the 640x480 fixture."""
+    H = H or W
+    ft = np.float64 if double else np.float32
+    rng = np.random.default_rng(seed)
+    j, i = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    depth = 0.45 + 0.05 * np.sin(i / W * 6.0) * np.cos(j / H * 5.0)
+    fx = SFS_FIXTURE["fx"] * W / 640.0
+    fy = SFS_FIXTURE["fy"] * W / 640.0
+    ux, uy = W / 2.0, H / 2.0
+    L = SFS_FIXTURE["L"]
+    shading = _sfs_render(depth, fx, fy, ux, uy, L)
+    # target intensity: rendered shading of a slightly different (detail-carrying) surface
+    detail = depth + 0.002 * np.sin(i * 0.7) * np.sin(j * 0.9)
+    Im = _sfs_render(detail, fx, fy, ux, uy, L)
+    D_i = depth.copy()
+    if holes:
+        hole = rng.random((H, W)) < 0.03
+        D_i[hole] = -10000.0          # SimpleBuffer.cpp:30-41 clamps -inf depths to a large negative
+    X = depth + noise * rng.standard_normal((H, W))
+    X = np.where(D_i > 0, X, D_i)
+    edgeR = np.ones((H, W), dtype=np.uint8)
+    edgeC = np.ones((H, W), dtype=np.uint8)
+    if holes:
+        edgeR[rng.random((H, W)) < 0.05] = 0
+        edgeC[rng.random((H, W)) < 0.05] = 0
+    f32 = lambda v: np.array(v, dtype=np.float32)
+    params = [f32(SFS_FIXTURE["w_p"]), f32(SFS_FIXTURE["w_s"]), f32(SFS_FIXTURE["w_g"]), f32(fx), f32(fy), f32(ux), f32(uy)]
+    params += [f32(v) for v in L]
+    params += [X.astype(ft), D_i.astype(ft), Im.astype(ft), edgeR, edgeC]
+    return Problem("shape_from_shading", (W, H), params, (16,), double)

@@ -1,0 +1,44 @@
+// TEST INFRASTRUCTURE ONLY (CPU oracle) -- never linked into, imported by, or called from the product path.
+//
+// Forward-mode dual numbers: the oracle's stand-in for Opt's symbolic differentiation
+// (reference API/src/ad.t:612-660 `Exp:d`, op partials ad.t:747-797).  A residual written once
+// against Dual<T,N> yields its value and its partials w.r.t. the N unknowns of its support,
+// which is exactly what the reference generator consumes (o.t:2029-2316).
+#pragma once
+#include <cmath>
+
+namespace oracle {
+
+template <class T, int N>
+struct Dual {
+    T v;
+    T d[N];
+    Dual() : v(0) { for (int i = 0; i < N; ++i) d[i] = 0; }
+    Dual(T c) : v(c) { for (int i = 0; i < N; ++i) d[i] = 0; }
+    static Dual var(T value, int slot) { Dual r(value); r.d[slot] = T(1); return r; }
+};
+
+template <class T, int N> Dual<T,N> operator+(const Dual<T,N>& a, const Dual<T,N>& b) { Dual<T,N> r; r.v = a.v + b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <class T, int N> Dual<T,N> operator-(const Dual<T,N>& a, const Dual<T,N>& b) { Dual<T,N> r; r.v = a.v - b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <class T, int N> Dual<T,N> operator-(const Dual<T,N>& a) { Dual<T,N> r; r.v = -a.v; for (int i = 0; i < N; ++i) r.d[i] = -a.d[i]; return r; }
+template <class T, int N> Dual<T,N> operator*(const Dual<T,N>& a, const Dual<T,N>& b) { Dual<T,N> r; r.v = a.v * b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+template <class T, int N> Dual<T,N> operator/(const Dual<T,N>& a, const Dual<T,N>& b) { Dual<T,N> r; T inv = T(1) / b.v; r.v = a.v * inv; for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv; return r; }
+
+template <class T, int N> Dual<T,N> operator+(const Dual<T,N>& a, T b) { Dual<T,N> r = a; r.v += b; return r; }
+template <class T, int N> Dual<T,N> operator+(T a, const Dual<T,N>& b) { return b + a; }
+template <class T, int N> Dual<T,N> operator-(const Dual<T,N>& a, T b) { Dual<T,N> r = a; r.v -= b; return r; }
+template <class T, int N> Dual<T,N> operator-(T a, const Dual<T,N>& b) { return (-b) + a; }
+template <class T, int N> Dual<T,N> operator*(const Dual<T,N>& a, T b) { Dual<T,N> r; r.v = a.v * b; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b; return r; }
+template <class T, int N> Dual<T,N> operator*(T a, const Dual<T,N>& b) { return b * a; }
+template <class T, int N> Dual<T,N> operator/(const Dual<T,N>& a, T b) { return a * (T(1) / b); }
+template <class T, int N> Dual<T,N> operator/(T a, const Dual<T,N>& b) { return Dual<T,N>(a) / b; }
+
+// ad.t:795 sin -> cos ; ad.t:787 cos -> -sin ; ad.t:797 sqrt -> 1/(2 sqrt)
+template <class T, int N> Dual<T,N> sin(const Dual<T,N>& a) { Dual<T,N> r; r.v = std::sin(a.v); T c = std::cos(a.v); for (int i = 0; i < N; ++i) r.d[i] = c * a.d[i]; return r; }
+template <class T, int N> Dual<T,N> cos(const Dual<T,N>& a) { Dual<T,N> r; r.v = std::cos(a.v); T s = -std::sin(a.v); for (int i = 0; i < N; ++i) r.d[i] = s * a.d[i]; return r; }
+template <class T, int N> Dual<T,N> sqrt(const Dual<T,N>& a) { Dual<T,N> r; r.v = std::sqrt(a.v); T k = T(1) / (T(2) * r.v); for (int i = 0; i < N; ++i) r.d[i] = k * a.d[i]; return r; }
+
+// ad.t:765-775: select(c,a,b) picks a branch; its partials are (0, c, not c) -> the chosen branch's partials.
+template <class T, int N> Dual<T,N> select(bool c, const Dual<T,N>& a, const Dual<T,N>& b) { return c ? a : b; }
+
+}  // namespace oracle
