@@ -1,0 +1,161 @@
+#!/usr/bin/env python
+"""bench.py -- PCG iterations/s of the Gauss-Newton solve of image_warping 4096^2 (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one Opt_ProblemStep: one Gauss-Newton iteration = evalJTF + `lIterations` (400, the
+reference's examples/image_warping/src/main.cpp:113-114) matrix-free PCG iterations + update + cost.
+value = K * lIterations / wall time of the K timed steps (max over ranks), inputs resident in HBM.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the 4096^2 image is split into row slabs,
+1-row halo exchange of p + scalar all-reduces over RCCL -- total work fixed => "strong" scaling.
+
+The same JSON line carries
+  roofline     : the dominant kernel (PCGStep1 = applyJTJ) timed with hipEvents on the solver's stream,
+                 achieved = 48 B/pixel * pixels / average launch time, against 8 TB/s;
+  cpu_baseline : the CPU oracle (a port, not the reference) timed on a bounded sample on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_PIXEL_STEP1 = 48       # (2C + A_in) * 4 B, C = 3, A_in = 6  
+HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--liters", type=int, default=400)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=4096)
+    ap.add_argument("--cpu-liters", type=int, default=5)
+    return ap.parse_args()
+
+
+def cpu_baseline(size, liters):
+    """Oracle (CPU restatement, single thread) on a bounded sample of the same workload."""
+    from oracle.binding import OracleSolver
+    from opt_amd import workloads as wl
+    P = wl.image_warping(size, size)
+    s = OracleSolver("image_warping", "gaussNewtonGPU", False, P.dims)
+    s.set("nIterations", 1); s.set("lIterations", liters)
+    s.init(P.params)
+    t0 = time.perf_counter()
+    s.step(P.params)
+    dt = time.perf_counter() - t0
+    rate = liters / dt * (size * size) / (4096.0 * 4096.0)     # scaled to 4096^2-equivalent PCG iterations/s
+    return {"value": rate, "unit": "PCG iters/s", "cores": 1, "kind": "port",
+            "sample": f"oracle (scalar C++ port of solverGPUGaussNewton.t), image_warping {size}x{size} float, 1 GN step x {liters} PCG iterations, "
+                      f"{dt:.1f} s wall incl. the step's evalJTF/update/cost; host has {os.cpu_count()} cores, 1 used"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from opt_amd import api, build, workloads as wl
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not os.path.exists(api.LIB_PATH):
+        if rank == 0:
+            build.build()
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+
+    W = H = args.size
+    total_steps = args.warmup + args.steps
+
+    if distributed:
+        from opt_amd import slab
+        job = slab.SlabJob("image_warping", W, H, rank, world)
+        solver, dev = job.solver, job.params
+        comm_keep = job
+    else:
+        P = wl.image_warping(W, H)
+        dev = api.to_device(P)
+        solver = api.Solver(api.energy_file("image_warping"), "gaussNewtonGPU", (W, H))
+    solver.set_parameter("nIterations", total_steps)
+    solver.set_parameter("lIterations", args.liters)
+
+    def sync():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    solver.init(dev)
+    cost0 = solver.cost()
+    for _ in range(args.warmup):
+        solver.step(dev)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.step(dev)
+    sync()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    cost1 = solver.cost()
+    value = args.steps * args.liters / dt
+
+    # ---- roofline leg: per-kernel hipEvent timing of PCGStep1 (applyJTJ) on the solver's stream ----------
+    roofline = None
+    if not distributed:
+        solver.close()
+        P2 = wl.image_warping(W, H)
+        dev2 = api.to_device(P2)
+        ts = api.Solver(api.energy_file("image_warping"), "gaussNewtonGPU", (W, H), timing=True)
+        ts.set_parameter("nIterations", 2); ts.set_parameter("lIterations", 100)
+        ts.init(dev2); ts.step(dev2); ts.step(dev2)
+        torch.cuda.synchronize()
+        kt = ts.kernel_timings()
+        cnt, tot = kt["PCGStep1"]
+        avg_ms = tot / cnt
+        achieved = ALGO_BYTES_PER_PIXEL_STEP1 * W * H / (avg_ms * 1e-3) / 1e9
+        per_iter = {k: v[1] / v[0] for k, v in kt.items()}
+        roofline = {"bound": "hbm", "kernel": "PCGStep1 (applyJTJ)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": avg_ms, "launches": cnt,
+                    "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PIXEL_STEP1 * W * H,
+                    "kernel_avg_ms": per_iter}
+        ts.close()
+
+    cpu = None
+    if rank == 0 and not distributed and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_size, args.cpu_liters)
+
+    if rank == 0:
+        out = {"metric": "PCG iters/s, GN solve of image_warping 4096^2", "value": value, "unit": "PCG iters/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"image_warping {W}x{H} float, gaussNewtonGPU, {args.liters} PCG iterations per GN step "
+                                      "(synthetic cat512-style constraints, border pinned)",
+                          "parallelism": f"row-slabs x{world}" if distributed else "single GPU",
+                          "step": "one Opt_ProblemStep (1 GN iteration)"},
+               "gn_solve_ms_8_steps": dt / args.steps * 8 * 1e3,
+               "cost_initial": cost0, "cost_final": cost1,
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

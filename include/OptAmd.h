@@ -1,0 +1,86 @@
+/* OptAmd.h -- extensions of libOpt.so beyond the reference's Opt.h.
+ *
+ * The reference has no equivalent of these: its only per-vector probe is the hand-written comparator's
+ * dump kernels (examples/shape_from_shading/src/SFSSolver.cu:409-463) and its only timing output is the
+ * printed table (API/src/util.t:451-511).  They exist so that (a) parity tests can compare every
+ * intermediate vector of the HIP solver with the CPU oracle, (b) bench.py can read per-kernel hipEvent
+ * timings for the roofline figure, (c) a multi-process launcher can tile an image problem over the GPUs
+ * of a node.  A caller that only needs the reference behaviour never touches this header.
+ */
+#pragma once
+#include "Opt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Library identification; the string names the compile target ("gfx950"). */
+const char* OptAmd_Version(void);
+/* Kernel registry: energies (".t" file stems) this build has hand-written kernel sets for. */
+int OptAmd_EnergyCount(void);
+const char* OptAmd_EnergyName(int i);
+
+/* Host-only check of a .t file against the registry (what Opt_ProblemPlan does before touching the GPU):
+ * returns 1 and "ok: <energy>" in `message`, or 0 and the reason Opt_ProblemPlan would print. */
+int OptAmd_CheckProblemFile(const char* filename, char* message, int messageLen);
+
+/* Length of the solver's unknown vector: unknown images in declaration order, each AoS, concatenated
+ * (the reference's UnknownType iteration order, API/src/o.t:675-687). */
+long OptAmd_PlanNumUnknownScalars(Opt_Plan* plan);
+/* Device pointer of a solver vector owned by the plan: "delta","r","b","Adelta","z","p","Ap_X","CtC",
+ * "preconditioner","SSq","prevX" (reference PlanData fields, solverGPUGaussNewton.t:173-185).
+ * NULL for an unknown name. */
+void* OptAmd_PlanVector(Opt_Plan* plan, const char* name);
+
+/* Kernel-level entry points.  Each binds `problemparams` exactly like Opt_ProblemInit, launches the
+ * energy's kernel(s) and synchronises.  Outputs are DEVICE buffers of OptAmd_PlanNumUnknownScalars
+ * opt_float elements.
+ *   EvalJTF : jtf = J^T F (gradient without the factor 2), diag = diag(J^T J); rows of excluded
+ *             unknowns are 0 (reference evalJTF, o.t:2129-2172, 2228-2253).
+ *   ApplyJTJ: out = J^T J v on non-excluded rows, 0 elsewhere; returns v^T J^T J v (the PCG alpha
+ *             denominator) (reference applyJTJ, o.t:2029-2126, called by PCGStep1 solver.t:421-434).
+ *   EvalCost: 1/2 sum r^2 over non-excluded elements (reference cost, o.t:2375-2385). */
+void OptAmd_EvalJTF(Opt_State* state, Opt_Plan* plan, void** problemparams, void* jtf, void* diag);
+double OptAmd_ApplyJTJ(Opt_State* state, Opt_Plan* plan, void** problemparams, const void* v, void* out);
+double OptAmd_EvalCost(Opt_State* state, Opt_Plan* plan, void** problemparams);
+
+/* Per-PCG-iteration scalars of the solve since the last Opt_ProblemInit.  Recording costs one device->host
+ * read per PCG iteration, so it is off unless enabled.  Row = {nIter, lIter, alphaNumerator,
+ * alphaDenominator, betaNumerator, q}. */
+void OptAmd_PlanEnableTrace(Opt_Plan* plan, int enable);
+long OptAmd_PlanTraceRows(Opt_Plan* plan);
+void OptAmd_PlanGetTrace(Opt_Plan* plan, double* rows6);
+
+/* Current LM trust-region radius (reference pd.parameters.trust_region_radius). */
+double OptAmd_PlanTrustRegionRadius(Opt_Plan* plan);
+
+/* hipEvent timing of one kernel name since the last Opt_ProblemInit (requires
+ * collectPerKernelTimingInfo).  Returns 0 if the name was never launched. */
+int OptAmd_PlanKernelTiming(Opt_Plan* plan, const char* kernel, long* count, double* total_ms);
+/* Number of distinct kernel names timed, and the i-th name. */
+int OptAmd_PlanKernelCount(Opt_Plan* plan);
+const char* OptAmd_PlanKernelName(Opt_Plan* plan, int i);
+
+/* ---- multi-GPU tiling of image problems (one process per GPU) -------------------------------------
+ * The image is split into contiguous row slabs; this process owns rows [row0, row0+rows) of an image of
+ * global height `globalHeight` and passes arrays that hold its slab PLUS one ghost row above and below
+ * (rows row0-1 .. row0+rows; ghost rows outside the global image are ignored).  Opt_ProblemPlan is then
+ * called with dims = {W, rows+2}.  The three callbacks carry the only inter-GPU traffic of the path:
+ * a 1-row halo exchange of a solver vector / unknown image and a sum all-reduce of a few doubles.  They
+ * are invoked on the solver's stream (passed as `stream`, a hipStream_t) and must be stream-ordered
+ * (RCCL calls enqueued on that stream, or host code that synchronises it). */
+typedef struct OptAmd_SlabComm {
+    void* ctx;
+    int rank, world;
+    /* exchange `bytes` bytes: send `sendUp` to rank-1 and `sendDown` to rank+1, receive into `recvUp`
+     * (from rank-1) and `recvDown` (from rank+1).  NULL-neighbour sides must be skipped by the callee. */
+    void (*haloExchange)(void* ctx, const void* sendUp, const void* sendDown, void* recvUp, void* recvDown, long bytes, void* stream);
+    /* in-place sum all-reduce of n doubles in device memory */
+    void (*allReduceSum)(void* ctx, double* deviceBuf, int n, void* stream);
+} OptAmd_SlabComm;
+/* Attach a slab description to a plan created with dims {W, rows+2}.  Must precede Opt_ProblemInit. */
+int OptAmd_PlanSetSlab(Opt_Plan* plan, long row0, long rows, long globalHeight, const OptAmd_SlabComm* comm);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,147 @@
+// Device primitives and launch plumbing shared by every kernel set (gfx950 / wave64 only).
+//
+// Replaces the reference's API/src/util.t: warpReduce (:612-623, 5-step shfl over 32 lanes) becomes a
+// 6-step wave64 reduction; "lane 0 does one atomicAdd on a global scalar" (solverGPUGaussNewton.t:312-317)
+// becomes "one partial per workgroup, summed in fixed order by the consumer" -- deterministic, no
+// same-address atomics, no memsets between kernels; makeGPULauncher's event pairs (util.t:800-843) become
+// the KernelTimer below.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#define HIP_CHECK(call)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            /* reference util.t:739-753: print and exit with the error code */                          \
+            fprintf(stderr, "HIP reported error %d: %s\nIn call: %s\nIn file: %s:%d\n", (int)e_,        \
+                    hipGetErrorString(e_), #call, __FILE__, __LINE__);                                    \
+            exit((int)e_);                                                                                \
+        }                                                                                                 \
+    } while (0)
+
+namespace optamd {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;          // threads per workgroup of the streaming kernels (4 waves)
+constexpr int kMaxPartials = 2048;   // per-workgroup partial sums a reduction may produce
+
+// A grid-wide sum in flight: the producer kernel writes one double per workgroup into `partials`
+// (count `n`, known on the host at launch), the consumer kernels sum them in index order.
+struct Reduction {
+    double* partials = nullptr;   // device, kMaxPartials doubles
+    int n = 0;                    // how many the last producer wrote
+};
+
+// ---- wave64 / workgroup reductions -------------------------------------------------------------------
+__device__ __forceinline__ double waveReduceSum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;   // valid in lane 0
+}
+
+// Sum `v` over the workgroup; the result is valid in thread 0.  `scratch` holds blockDim/64 doubles.
+__device__ __forceinline__ double blockReduceSum(double v, double* scratch) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    v = waveReduceSum(v);
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x * blockDim.y + kWave - 1) / kWave;
+        for (int i = 0; i < nw; ++i) t += scratch[i];
+    }
+    __syncthreads();
+    return t;
+}
+
+// Every thread of the workgroup obtains sum(partials[0..n)) -- same value, same order, in every
+// workgroup of every kernel: the deterministic replacement for reading a scalar that N/32 atomics built.
+__device__ __forceinline__ double sumPartials(const double* __restrict__ partials, int n, double* scratch /* >= blockDim/64 + 1 */) {
+    double t = 0;
+    const int tid = threadIdx.x + threadIdx.y * blockDim.x, nt = blockDim.x * blockDim.y;
+    for (int i = tid; i < n; i += nt) t += partials[i];
+    const int lane = tid & (kWave - 1), wave = tid >> 6, nw = (nt + kWave - 1) / kWave;
+    t = waveReduceSum(t);
+    if (lane == 0) scratch[wave] = t;
+    __syncthreads();
+    if (tid == 0) { double s = 0; for (int i = 0; i < nw; ++i) s += scratch[i]; scratch[nw] = s; }
+    __syncthreads();
+    const double r = scratch[nw];
+    __syncthreads();
+    return r;
+}
+
+// ---- per-kernel hipEvent timing (reference util.t:404-511) ---------------------------------------------
+struct KernelTimer {
+    bool enabled = false;
+    struct Rec { std::string name; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    std::map<std::string, std::pair<long, double>> totals;   // name -> (count, ms), filled by evaluate()
+    std::vector<std::string> order;
+
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return e;
+    }
+    void begin(const char* name, hipStream_t s) {
+        if (!enabled) return;
+        Rec r{name, get(), get()};
+        HIP_CHECK(hipEventRecord(r.a, s));
+        recs.push_back(r);
+    }
+    void end(hipStream_t s) {
+        if (!enabled) return;
+        HIP_CHECK(hipEventRecord(recs.back().b, s));
+    }
+    void reset() {
+        for (auto& r : recs) { pool.push_back(r.a); pool.push_back(r.b); }
+        recs.clear(); totals.clear(); order.clear();
+    }
+    void evaluate() {   // synchronises every pending event pair and folds it into `totals`
+        for (auto& r : recs) {
+            HIP_CHECK(hipEventSynchronize(r.b));
+            float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
+            auto it = totals.find(r.name);
+            if (it == totals.end()) { totals[r.name] = {1, (double)ms}; order.push_back(r.name); }
+            else { it->second.first += 1; it->second.second += ms; }
+            pool.push_back(r.a); pool.push_back(r.b);
+        }
+        recs.clear();
+    }
+    void print() const {   // same columns as the reference table (util.t:469-508)
+        printf("--------------------------------------------------------\n");
+        printf("        Kernel        |   Count  |   Total   | Average \n");
+        printf("----------------------+----------+-----------+----------\n");
+        for (auto& n : order) {
+            auto& t = totals.at(n);
+            printf(" %-20s |   %4ld   | %8.3fms| %7.4fms\n", n.c_str(), t.first, t.second, t.second / t.first);
+        }
+        printf("--------------------------------------------------------\n");
+    }
+    ~KernelTimer() { for (auto& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } for (auto e : pool) (void)hipEventDestroy(e); }
+};
+
+struct LaunchCtx {
+    hipStream_t stream = nullptr;
+    KernelTimer* timer = nullptr;
+};
+struct ScopedKernel {   // brackets one (logical) kernel launch with timing events + error check
+    LaunchCtx& c;
+    ScopedKernel(LaunchCtx& ctx, const char* name) : c(ctx) { if (c.timer) c.timer->begin(name, c.stream); }
+    ~ScopedKernel() { HIP_CHECK(hipGetLastError()); if (c.timer) c.timer->end(c.stream); }
+};
+
+inline int divUp(long a, long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ void sincosT(float a, float* s, float* c) { sincosf(a, s, c); }
+__device__ __forceinline__ void sincosT(double a, double* s, double* c) { sincos(a, s, c); }
+
+}  // namespace optamd

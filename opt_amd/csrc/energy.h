@@ -1,0 +1,83 @@
+// Interface between the generic GN/LM + PCG solver and one energy's hand-written HIP kernel set.
+//
+// In the reference this seam is the table of Terra functions Opt's generator emits per energy
+// (cost / evalJTF / applyJTJ / computeCtC / modelcost / precompute / exclude -- API/src/o.t:2425-2460)
+// which solverGPUGaussNewton.t's kernels call per thread.  Here each energy implements them as whole
+// kernels so it can pick its own tiling, LDS staging and reduction shape.
+#pragma once
+#include "common.h"
+
+namespace optamd {
+
+// Row-slab description of an image problem tiled over several GPUs (OptAmd_PlanSetSlab).  Local arrays
+// hold rows [0,H); rows [yBegin,yEnd) are owned (computed here); local row y is global row gy0+y, which
+// exists iff 0 <= gy0+y < Hg.  Single GPU: yBegin=0, yEnd=H, gy0=0, Hg=H.
+struct Slab {
+    int yBegin = 0, yEnd = 0, gy0 = 0, Hg = 0;
+    bool active = false;
+};
+
+struct UnknownImage {
+    int param;        // index in problemparams
+    long elems;       // pixels / vertices
+    int channels;
+    long offset;      // first scalar of this image in the solver's unknown vector
+};
+
+// Everything the solver needs from an energy.  T = opt_float (float or double).
+// Contract shared by all implementations:
+//  * solver vectors are laid out like the unknown vector: unknown images in declaration order, AoS,
+//    concatenated (reference o.t:675-687, 745-775);
+//  * rows of excluded unknowns (reference Exclude(), o.t:2452-2455) and of ghost rows are written as 0 by
+//    evalJTF (r and diag) and applyJTJ (out), so the generic streaming kernels never need the mask:
+//    with r = 0 there, p, z, delta stay 0 and X is unchanged, which is what the reference's
+//    "if not exclude" guards achieve (solverGPUGaussNewton.t:371, 424, 450, 539, 554).
+template <class T>
+struct EnergyOps {
+    std::vector<UnknownImage> unknowns;
+    long nScalars = 0;
+    bool usePreconditioner = false;   // reference o.t:214 default
+    bool usesGraph = false;
+    Slab slab;
+    virtual ~EnergyOps() {}
+    void addUnknown(int param, long elems, int channels) {
+        unknowns.push_back({param, elems, channels, nScalars});
+        nScalars += elems * channels;
+    }
+    // util.initParameters (reference util.t:664-692): re-read every pointer and host scalar; also refresh
+    // any per-solve auxiliary arrays derived from the inputs (validity flags ...).
+    virtual void bind(void** params, LaunchCtx& ctx) = 0;
+    virtual T* unknownPtr(int img) const = 0;
+    virtual void precompute(LaunchCtx&) {}                                   // ComputedArrays (solver.t:607-614)
+    // partial sums of 1/2 sum r^2 over non-excluded, owned elements (solver.t:580-592, 715-725)
+    virtual void evalCost(Reduction& out, LaunchCtx& ctx) = 0;
+    // r = -J^T F, diag = diag(J^T J) (raw, also when the energy does not precondition) (o.t:2129-2172, 2228-2253)
+    virtual void evalJTF(T* r, T* diag, LaunchCtx& ctx) = 0;
+    // out = J^T J v (+ CtC .* v if CtC != nullptr, o.t:2076-2082); dot (optional) = partial sums of v . out
+    virtual void applyJTJ(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) = 0;
+    // partial sums of 1/2 sum (F + J delta)^2 (o.t:2174-2225); LM only
+    virtual void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) = 0;
+    // slab tiling (image energies): number of scalars in one image row of unknown image `img`
+    virtual bool supportsSlab() const { return false; }
+    virtual long rowScalars(int /*img*/) const { return 0; }
+};
+
+// Registry entry: what a .t file must declare for this kernel set, and how to instantiate it.
+struct ParamDecl {
+    enum Kind { kUnknown, kArray, kScalar, kGraphCount, kGraphIndex } kind;
+    const char* name;
+    const char* type;   // "opt_float", "opt_float2", ..., "float", "uint8", "int"
+    int index;          // binding index in problemparams
+};
+struct EnergyInfo {
+    const char* name;                 // .t file stem
+    int nDims;                        // entries of `dimensions` consumed
+    std::vector<ParamDecl> params;
+    bool usePreconditioner;
+    bool floatOnly;                   // energy declares fixed `float` unknowns (tests/minimal/laplacian.t)
+    EnergyOps<float>* (*makeFloat)(const unsigned* dims);
+    EnergyOps<double>* (*makeDouble)(const unsigned* dims);
+};
+const std::vector<EnergyInfo>& energyRegistry();
+
+}  // namespace optamd

@@ -1,0 +1,367 @@
+// image_warping: 2-D as-rigid-as-possible image warp -- the north-star workload.
+//
+// Energy (reference examples/image_warping/image_warping.t:1-23): per pixel c, unknowns O_c (float2
+// offset) and a_c (angle); for the 4 stencil directions n
+//     r_reg[c,n] = w_reg * v(c,n) * [ (O_c - O_{c+n}) - R(a_c)(U_c - U_{c+n}) ],  v = InBounds(c+n) & Mask_{c+n}=0 & Mask_c=0
+//     r_fit[c]   = w_fit * [C_c >= 0] * (O_c - C_c)
+// cost = 1/2 sum r^2 over non-masked pixels (Exclude, :11).  The kernels below are the hand-derived
+// counterparts of what Opt's generator emits from that file (o.t:2029-2089 applyJTJ, :2129-2172 evalJTF,
+// :2375-2385 cost, :2174-2225 modelcost); with D_{c,n} = R'(a_c)(U_c - U_{c+n}):
+//     J p  at (c,n)      : Jp = w [ (pO_c - pO_{c+n}) - D_{c,n} pa_c ]
+//     (J^T J p)_O(c)     = w_fit^2 f_c pO_c + w sum_n v [ Jp(c,n) - Jp(c+n,-n) ]
+//     (J^T J p)_a(c)     = - w sum_n v D_{c,n} . Jp(c,n)
+//
+// MI355X design.  Every kernel here is HBM-bound (applyJTJ moves 48 B/pixel
+// algorithmically at ~150 flop/pixel, 3 flop/B against a ridge of ~20).  So:
+//  * the three per-pixel inputs that only gate terms (Mask: 4 B, Constraints: 8 B) are folded once per
+//    solve step into a 1-byte flag image, and cos/sin(a) is tabulated once per Gauss-Newton iteration,
+//    so the PCG loop's applyJTJ reads 12 (p) + 8 (cos,sin) + 8 (U) + 1 (flags) and writes 12 B/pixel
+//    instead of gathering five arrays through five neighbours;
+//  * applyJTJ marches down the image: a workgroup owns a 256-pixel-wide column strip and a contiguous
+//    range of rows, each lane keeps the rows y-1, y, y+1 of its column in registers, so vertical
+//    neighbours cost no memory traffic at all and each row is fetched from HBM once (plus 2 halo rows
+//    per workgroup); horizontal neighbours are unit-stride re-reads that hit L1/L2;
+//  * the grid is sized to be co-resident (one wave of workgroups, rows split evenly) instead of
+//    thousands of 16x16 tiles, so there is no tail and only ~1k partial sums for the dot product.
+#include "energy.h"
+#include <cstdint>
+
+namespace optamd {
+namespace {
+
+template <class T> struct V2 { T x, y; };
+
+template <class T>
+struct IWArgs {
+    int W, H;                 // local image (incl. ghost rows in slab mode)
+    int yBegin, yEnd;         // owned rows
+    int gy0, Hg;              // global row of local row 0, global height
+    const T* Offset; const T* Angle; const T* UrShape; const T* Constraints; const T* Mask;
+    T w_fit, w_reg;
+    uint8_t* flags;           // bit0: pixel exists and Mask == 0 ; bit1: fit constraint valid
+    T* cs;                    // (cos a, sin a) per pixel
+};
+
+constexpr uint8_t kActive = 1, kFit = 2;
+
+// once per Init/Step: fold Mask / Constraints / global bounds into one byte per pixel
+template <class T>
+__global__ __launch_bounds__(kBlock) void iw_flags(IWArgs<T> A) {
+    const long N = (long)A.W * A.H;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / A.W), gy = A.gy0 + y;
+        uint8_t f = 0;
+        if (gy >= 0 && gy < A.Hg && A.Mask[i] == T(0)) f |= kActive;                          // eq(Mask,0)  (image_warping.t:11,17)
+        if (A.Constraints[2 * i] >= T(0) && A.Constraints[2 * i + 1] >= T(0)) f |= kFit;      // All(greatereq(C,0)) (:22)
+        A.flags[i] = f;
+    }
+}
+// once per Gauss-Newton iteration: (cos a, sin a)
+template <class T>
+__global__ __launch_bounds__(kBlock) void iw_cossin(IWArgs<T> A) {
+    const long N = (long)A.W * A.H;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+        T s, c; sincosT(A.Angle[i], &s, &c);
+        ((V2<T>*)A.cs)[i] = V2<T>{c, s};
+    }
+}
+
+template <class T> __device__ __forceinline__ bool ownedRow(const IWArgs<T>& A, int y) { return y >= A.yBegin && y < A.yEnd; }
+
+// ---- cost -----------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(kBlock) void iw_cost(IWArgs<T> A, double* __restrict__ partials) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    const long rows = A.yEnd - A.yBegin, N = rows * A.W;
+    const V2<T>* O = (const V2<T>*)A.Offset; const V2<T>* U = (const V2<T>*)A.UrShape; const V2<T>* C = (const V2<T>*)A.Constraints;
+    double acc = 0;
+    for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < N; j += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(j % A.W), y = A.yBegin + (int)(j / A.W);
+        const long i = (long)y * A.W + x;
+        const uint8_t f = A.flags[i];
+        if (!(f & kActive)) continue;   // excluded pixel: its residuals are not part of the cost (solver.t:583)
+        T s, c; sincosT(A.Angle[i], &s, &c);
+        const V2<T> o = O[i], u = U[i];
+        T e = 0;
+        const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int nx = x + dx[n], ny = y + dy[n];
+            if (nx < 0 || nx >= A.W || ny < 0 || ny >= A.H) continue;
+            const long ni = (long)ny * A.W + nx;
+            if (!(A.flags[ni] & kActive)) continue;
+            const V2<T> on = O[ni], un = U[ni];
+            const T ux = u.x - un.x, uy = u.y - un.y;
+            const T ex = A.w_reg * ((o.x - on.x) - (c * ux - s * uy));
+            const T ey = A.w_reg * ((o.y - on.y) - (s * ux + c * uy));
+            e += ex * ex + ey * ey;
+        }
+        if (f & kFit) {
+            const V2<T> cc = C[i];
+            const T fx = A.w_fit * (o.x - cc.x), fy = A.w_fit * (o.y - cc.y);
+            e += fx * fx + fy * fy;
+        }
+        acc += (double)(T(0.5) * e);
+    }
+    double t = blockReduceSum(acc, scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// ---- evalJTF: r = -J^T F, diag = diag(J^T J) ---------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(kBlock) void iw_evalJTF(IWArgs<T> A, T* __restrict__ r, T* __restrict__ diag) {
+    const long N = (long)A.W * A.H;
+    const V2<T>* O = (const V2<T>*)A.Offset; const V2<T>* U = (const V2<T>*)A.UrShape; const V2<T>* C = (const V2<T>*)A.Constraints;
+    const V2<T>* CS = (const V2<T>*)A.cs;
+    V2<T>* rO = (V2<T>*)r; T* ra = r + 2 * N; V2<T>* dO = (V2<T>*)diag; T* da = diag + 2 * N;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % A.W), y = (int)(i / A.W);
+        const uint8_t f = A.flags[i];
+        T Fx = 0, Fy = 0, Fa = 0, Pxy = 0, Pa = 0;
+        if ((f & kActive) && ownedRow(A, y)) {
+            const V2<T> o = O[i], u = U[i], cs = CS[i];
+            const T w = A.w_reg;
+            const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int nx = x + dx[n], ny = y + dy[n];
+                if (nx < 0 || nx >= A.W || ny < 0 || ny >= A.H) continue;
+                const long ni = (long)ny * A.W + nx;
+                if (!(A.flags[ni] & kActive)) continue;
+                const V2<T> on = O[ni], un = U[ni], csn = CS[ni];
+                const T ux = u.x - un.x, uy = u.y - un.y;
+                // residual centred here, towards n
+                const T ex = w * ((o.x - on.x) - (cs.x * ux - cs.y * uy));
+                const T ey = w * ((o.y - on.y) - (cs.y * ux + cs.x * uy));
+                // residual centred at the neighbour, towards here: -(O_c - O_n) + R(a_n)(U_c - U_n)
+                const T gx = w * ((on.x - o.x) + (csn.x * ux - csn.y * uy));
+                const T gy = w * ((on.y - o.y) + (csn.y * ux + csn.x * uy));
+                Fx += w * ex - w * gx; Fy += w * ey - w * gy;
+                const T Dx = -cs.y * ux - cs.x * uy, Dy = cs.x * ux - cs.y * uy;   // R'(a)(U_c - U_n)
+                Fa += -(w * Dx) * ex - (w * Dy) * ey;
+                Pxy += w * w + w * w;
+                Pa += (w * Dx) * (w * Dx) + (w * Dy) * (w * Dy);
+            }
+            if (f & kFit) {
+                const V2<T> cc = C[i];
+                Fx += A.w_fit * (A.w_fit * (o.x - cc.x)); Fy += A.w_fit * (A.w_fit * (o.y - cc.y));
+                Pxy += A.w_fit * A.w_fit;
+            }
+        }
+        rO[i] = V2<T>{-Fx, -Fy}; ra[i] = -Fa;
+        dO[i] = V2<T>{Pxy, Pxy}; da[i] = Pa;
+    }
+}
+
+// ---- applyJTJ (PCGStep1): row-marching stencil ----------------------------------------------------------------
+template <class T>
+struct Px {
+    T ox, oy, a;    // v at this pixel (Offset part, Angle part)
+    T c, s;         // cos/sin of the pixel's angle
+    T ux, uy;       // UrShape
+    bool m;         // exists & not masked
+    uint8_t f;
+};
+
+template <class T>
+__device__ __forceinline__ Px<T> iw_load(const IWArgs<T>& A, const V2<T>* __restrict__ vO, const T* __restrict__ va, int x, int y) {
+    Px<T> p;
+    if (x < 0 || x >= A.W || y < 0 || y >= A.H) { p.ox = p.oy = p.a = p.c = p.s = p.ux = p.uy = 0; p.m = false; p.f = 0; return p; }
+    const long i = (long)y * A.W + x;
+    const uint8_t f = A.flags[i];
+    const V2<T> o = vO[i], cs = ((const V2<T>*)A.cs)[i], u = ((const V2<T>*)A.UrShape)[i];
+    p.ox = o.x; p.oy = o.y; p.a = va[i]; p.c = cs.x; p.s = cs.y; p.ux = u.x; p.uy = u.y; p.f = f; p.m = (f & kActive) != 0;
+    return p;
+}
+
+// accumulate the two residuals shared by centre c and neighbour n (the one centred at c and the one centred at n)
+template <class T>
+__device__ __forceinline__ void iw_pair(const Px<T>& c, const Px<T>& n, T& accOx, T& accOy, T& accA) {
+    if (!n.m) return;
+    const T ux = c.ux - n.ux, uy = c.uy - n.uy;
+    const T Dcx = -c.s * ux - c.c * uy, Dcy = c.c * ux - c.s * uy;     // R'(a_c)(U_c - U_n)
+    const T Dnx = n.s * ux + n.c * uy, Dny = -n.c * ux + n.s * uy;     // R'(a_n)(U_n - U_c)
+    const T jcx = (c.ox - n.ox) - Dcx * c.a, jcy = (c.oy - n.oy) - Dcy * c.a;   // J p of the residual centred at c  (/w)
+    const T jnx = (n.ox - c.ox) - Dnx * n.a, jny = (n.oy - c.oy) - Dny * n.a;   // J p of the residual centred at n  (/w)
+    accOx += jcx - jnx; accOy += jcy - jny;
+    accA -= Dcx * jcx + Dcy * jcy;
+}
+
+template <class T, bool LM>
+__global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ CtC,
+                                                      double* __restrict__ partials, int rowsPerGroup) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    const long N = (long)A.W * A.H;
+    const V2<T>* vO = (const V2<T>*)v; const T* va = v + 2 * N;
+    V2<T>* outO = (V2<T>*)out; T* outA = out + 2 * N;
+    const int x = blockIdx.x * kBlock + threadIdx.x;
+    const int yb = A.yBegin + blockIdx.y * rowsPerGroup;
+    const int ye = min(yb + rowsPerGroup, A.yEnd);
+    const T w2 = A.w_reg * A.w_reg, wf2 = A.w_fit * A.w_fit;
+    double acc = 0;
+    if (x < A.W) {
+        Px<T> up = iw_load(A, vO, va, x, yb - 1);
+        Px<T> cur = iw_load(A, vO, va, x, yb);
+        for (int y = yb; y < ye; ++y) {
+            const Px<T> dn = iw_load(A, vO, va, x, y + 1);
+            const long i = (long)y * A.W + x;
+            T rx = 0, ry = 0, ra = 0;
+            if (cur.m) {
+                const Px<T> rt = iw_load(A, vO, va, x + 1, y), lf = iw_load(A, vO, va, x - 1, y);
+                T ax = 0, ay = 0, aa = 0;
+                iw_pair(cur, rt, ax, ay, aa);
+                iw_pair(cur, lf, ax, ay, aa);
+                iw_pair(cur, dn, ax, ay, aa);
+                iw_pair(cur, up, ax, ay, aa);
+                rx = w2 * ax; ry = w2 * ay; ra = w2 * aa;
+                if (cur.f & kFit) { rx += wf2 * cur.ox; ry += wf2 * cur.oy; }
+                if (LM) {
+                    const V2<T> cO = ((const V2<T>*)CtC)[i];
+                    rx += cO.x * cur.ox; ry += cO.y * cur.oy; ra += CtC[2 * N + i] * cur.a;
+                }
+                acc += (double)(cur.ox * rx + cur.oy * ry + cur.a * ra);
+            }
+            outO[i] = V2<T>{rx, ry}; outA[i] = ra;
+            up = cur; cur = dn;
+        }
+    }
+    double t = blockReduceSum(acc, scratch);
+    if (threadIdx.x == 0 && partials) partials[blockIdx.y * gridDim.x + blockIdx.x] = t;
+}
+
+// ghost rows of `out` are zeroed so the flat streaming kernels see r = 0 / Ap = 0 there (energy.h contract)
+template <class T>
+__global__ __launch_bounds__(kBlock) void iw_zeroGhost(IWArgs<T> A, T* __restrict__ out) {
+    const long N = (long)A.W * A.H;
+    const int ghostRows[2] = {A.yBegin - 1, A.yEnd};
+    for (int g = 0; g < 2; ++g) {
+        const int y = ghostRows[g];
+        if (y < 0 || y >= A.H) continue;
+        for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < A.W; x += gridDim.x * blockDim.x) {
+            const long i = (long)y * A.W + x;
+            ((V2<T>*)out)[i] = V2<T>{0, 0}; out[2 * N + i] = 0;
+        }
+    }
+}
+
+// ---- modelcost (LM): 1/2 sum (F + J delta)^2 ------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(kBlock) void iw_modelCost(IWArgs<T> A, const T* __restrict__ delta, double* __restrict__ partials) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    const long rows = A.yEnd - A.yBegin, NN = rows * A.W, N = (long)A.W * A.H;
+    const V2<T>* O = (const V2<T>*)A.Offset; const V2<T>* U = (const V2<T>*)A.UrShape; const V2<T>* C = (const V2<T>*)A.Constraints;
+    const V2<T>* CS = (const V2<T>*)A.cs; const V2<T>* dO = (const V2<T>*)delta; const T* da = delta + 2 * N;
+    double acc = 0;
+    for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < NN; j += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(j % A.W), y = A.yBegin + (int)(j / A.W);
+        const long i = (long)y * A.W + x;
+        const uint8_t f = A.flags[i];
+        if (!(f & kActive)) continue;
+        const V2<T> o = O[i], u = U[i], cs = CS[i], d = dO[i];
+        const T dang = da[i], w = A.w_reg;
+        T e = 0;
+        const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int nx = x + dx[n], ny = y + dy[n];
+            if (nx < 0 || nx >= A.W || ny < 0 || ny >= A.H) continue;
+            const long ni = (long)ny * A.W + nx;
+            if (!(A.flags[ni] & kActive)) continue;
+            const V2<T> on = O[ni], un = U[ni], dn = dO[ni];
+            const T ux = u.x - un.x, uy = u.y - un.y;
+            const T Dx = -cs.y * ux - cs.x * uy, Dy = cs.x * ux - cs.y * uy;
+            const T mx = w * ((o.x - on.x) - (cs.x * ux - cs.y * uy)) + (w * (d.x - dn.x) - (w * Dx) * dang);
+            const T my = w * ((o.y - on.y) - (cs.y * ux + cs.x * uy)) + (w * (d.y - dn.y) - (w * Dy) * dang);
+            e += mx * mx + my * my;
+        }
+        if (f & kFit) {
+            const V2<T> cc = C[i];
+            const T fx = A.w_fit * (o.x - cc.x) + A.w_fit * d.x, fy = A.w_fit * (o.y - cc.y) + A.w_fit * d.y;
+            e += fx * fx + fy * fy;
+        }
+        acc += (double)(T(0.5) * e);
+    }
+    double t = blockReduceSum(acc, scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+template <class T>
+struct ImageWarpingOps : EnergyOps<T> {
+    IWArgs<T> A{};
+    int cus = 256;
+    ImageWarpingOps(const unsigned* dims) {
+        A.W = (int)dims[0]; A.H = (int)dims[1];
+        this->usePreconditioner = true;                                           // image_warping.t:10
+        this->addUnknown(0, (long)A.W * A.H, 2); this->addUnknown(1, (long)A.W * A.H, 1);   // Offset, Angle (:2-3)
+        HIP_CHECK(hipMalloc((void**)&A.flags, (size_t)A.W * A.H));
+        HIP_CHECK(hipMalloc((void**)&A.cs, (size_t)A.W * A.H * 2 * sizeof(T)));
+        int dev = 0; HIP_CHECK(hipGetDevice(&dev));
+        HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    ~ImageWarpingOps() override { (void)hipFree(A.flags); (void)hipFree(A.cs); }
+    int flatGrid(long n) const { return (int)std::max<long>(1, std::min<long>((n + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
+    void bind(void** p, LaunchCtx& ctx) override {
+        A.Offset = (const T*)p[0]; A.Angle = (const T*)p[1]; A.UrShape = (const T*)p[2]; A.Constraints = (const T*)p[3]; A.Mask = (const T*)p[4];
+        A.w_fit = (T) * (const float*)p[5]; A.w_reg = (T) * (const float*)p[6];   // Param(..., float, ...) stays float in double mode (:7-8)
+        const Slab& s = this->slab;
+        if (s.active) { A.yBegin = s.yBegin; A.yEnd = s.yEnd; A.gy0 = s.gy0; A.Hg = s.Hg; }
+        else { A.yBegin = 0; A.yEnd = A.H; A.gy0 = 0; A.Hg = A.H; }
+        ScopedKernel k(ctx, "bindFlags");
+        iw_flags<T><<<flatGrid((long)A.W * A.H), kBlock, 0, ctx.stream>>>(A);
+    }
+    T* unknownPtr(int img) const override { return const_cast<T*>(img == 0 ? A.Offset : A.Angle); }
+    void evalCost(Reduction& out, LaunchCtx& ctx) override {
+        ScopedKernel k(ctx, "computeCost");
+        const int g = flatGrid((long)A.W * (A.yEnd - A.yBegin));
+        iw_cost<T><<<g, kBlock, 0, ctx.stream>>>(A, out.partials);
+        out.n = g;
+    }
+    void evalJTF(T* r, T* diag, LaunchCtx& ctx) override {
+        const int g = flatGrid((long)A.W * A.H);
+        { ScopedKernel k(ctx, "cosSinTable"); iw_cossin<T><<<g, kBlock, 0, ctx.stream>>>(A); }
+        { ScopedKernel k(ctx, "PCGInit1"); iw_evalJTF<T><<<g, kBlock, 0, ctx.stream>>>(A, r, diag); }
+    }
+    void applyJTJ(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) override {
+        // co-resident grid: column strips x row groups, rows split evenly (see header comment)
+        const int gx = divUp(A.W, kBlock);
+        const int rows = A.yEnd - A.yBegin;
+        const int target = cus * 6;
+        int gy = std::max(1, std::min(std::min(rows, target / gx), kMaxPartials / gx));
+        const int rowsPerGroup = divUp(rows, gy);
+        gy = divUp(rows, rowsPerGroup);
+        {
+            ScopedKernel k(ctx, "PCGStep1");
+            dim3 grid(gx, gy);
+            if (CtC) iw_applyJTJ<T, true><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, CtC, dot ? dot->partials : nullptr, rowsPerGroup);
+            else iw_applyJTJ<T, false><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, dot ? dot->partials : nullptr, rowsPerGroup);
+            if (dot) dot->n = gx * gy;
+        }
+        if (this->slab.active) iw_zeroGhost<T><<<divUp(A.W, kBlock), kBlock, 0, ctx.stream>>>(A, out);
+    }
+    void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {
+        ScopedKernel k(ctx, "computeModelCost");
+        const int g = flatGrid((long)A.W * (A.yEnd - A.yBegin));
+        iw_modelCost<T><<<g, kBlock, 0, ctx.stream>>>(A, delta, out.partials);
+        out.n = g;
+    }
+    bool supportsSlab() const override { return true; }
+    long rowScalars(int img) const override { return (long)A.W * (img == 0 ? 2 : 1); }
+};
+
+template <class T> EnergyOps<T>* makeIW(const unsigned* dims) { return new ImageWarpingOps<T>(dims); }
+
+}  // namespace
+
+EnergyInfo imageWarpingInfo() {
+    EnergyInfo e;
+    e.name = "image_warping"; e.nDims = 2; e.usePreconditioner = true; e.floatOnly = false;
+    e.params = {{ParamDecl::kUnknown, "Offset", "opt_float2", 0}, {ParamDecl::kUnknown, "Angle", "opt_float", 1},
+                {ParamDecl::kArray, "UrShape", "opt_float2", 2},  {ParamDecl::kArray, "Constraints", "opt_float2", 3},
+                {ParamDecl::kArray, "Mask", "opt_float", 4},      {ParamDecl::kScalar, "w_fitSqrt", "float", 5},
+                {ParamDecl::kScalar, "w_regSqrt", "float", 6}};
+    e.makeFloat = makeIW<float>; e.makeDouble = makeIW<double>;
+    return e;
+}
+
+}  // namespace optamd

@@ -1,0 +1,47 @@
+// Type-erased view of the GN/LM solver that the C ABI (opt_api.cpp) drives.
+#pragma once
+#include "../../include/OptAmd.h"
+#include "energy.h"
+
+namespace optamd {
+
+// reference solverGPUGaussNewton.t:148-163 (floats even in double mode), defaults :26-39
+struct SolverParameters {
+    float min_relative_decrease = 1e-3f;
+    float min_trust_region_radius = 1e-32f;
+    float max_trust_region_radius = 1e16f;
+    float q_tolerance = 0.0001f;
+    float function_tolerance = 0.000001f;
+    float trust_region_radius = 1e4f;
+    float radius_decrease_factor = 2.0f;
+    float min_lm_diagonal = 1e-6f;
+    float max_lm_diagonal = 1e32f;
+    int residual_reset_period = 10;
+    int nIter = 0;
+    int nIterations = 10;
+    int lIterations = 10;
+};
+
+struct SolverBase {
+    SolverParameters sp;
+    KernelTimer timer;
+    int verbosity = 0;
+    bool traceEnabled = false;
+    std::vector<double> trace;   // rows of 6
+    virtual ~SolverBase() {}
+    virtual void init(void** params) = 0;
+    virtual int step(void** params) = 0;
+    virtual double cost() const = 0;
+    virtual long numUnknownScalars() const = 0;
+    virtual void* vector(const std::string& name) = 0;
+    virtual void evalJTF(void** params, void* jtf, void* diag) = 0;
+    virtual double applyJTJ(void** params, const void* v, void* out) = 0;
+    virtual double evalCost(void** params) = 0;
+    virtual double trustRegionRadius() const = 0;
+    virtual int setSlab(long row0, long rows, long globalHeight, const OptAmd_SlabComm* comm) = 0;
+    bool setParameter(const char* name, const void* value);   // solver.t:1205-1221
+};
+
+SolverBase* makeSolver(const EnergyInfo& info, bool lm, bool doublePrecision, const unsigned* dims, bool timing, int verbosity);
+
+}  // namespace optamd

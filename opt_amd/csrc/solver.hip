@@ -1,0 +1,537 @@
+// Gauss-Newton / Levenberg-Marquardt outer loop + matrix-free PCG inner loop, generic over the energy.
+//
+// What it reproduces (reference API/src/solverGPUGaussNewton.t): init :956-1007, step :1016-1177 with the
+// same kernel order, the same guards (alpha = 0 unless denominator > 0 :456-459, beta :544-547), the CERES
+// guarded inverse :323-332, the LM diagonal / trust-region logic :631-664, 1119-1157, the residual reset
+// every `residual_reset_period` iterations :1077-1086 and the q-based early out :1093-1102.
+// What it changes (MI355X-first):
+//  * the streaming kernels (Step2, Step3, LinearUpdate, ...) run over the FLAT unknown vector with 16-byte
+//    accesses -- they never touch the exclude mask (see energy.h contract);
+//  * global sums are per-workgroup partials in double, summed in index order by each consumer workgroup:
+//    no same-address atomics, no hipMemset/hipMemcpy between kernels, bitwise reproducible;
+//  * alphaNumerator <- betaNumerator (a D2D memcpy per iteration in the reference, :1091) is a two-slot
+//    rotation written by workgroup 0 of Step3.
+#include "solver.h"
+#include <cmath>
+#include <cstring>
+
+namespace optamd {
+
+// ------------------------------------------------------------------------------------------------------
+// 16-byte packs of opt_float
+template <class T> struct Pack;
+template <> struct alignas(16) Pack<float> { float v[4]; };
+template <> struct alignas(16) Pack<double> { double v[2]; };
+template <class T> struct PackN;
+template <> struct PackN<float> { static constexpr int N = 4; };
+template <> struct PackN<double> { static constexpr int N = 2; };
+
+template <class T> __device__ __forceinline__ T guardedInvert(T x) {   // solver.t:323-332 (CERES)
+    T s = T(1) + sqrt(x);
+    return T(1) / (s * s);
+}
+
+// PCGInit1 (non-graph tail) / PCGInit1_Finish (graph): solver.t:384-392, 399-419.  r already holds -J^T F.
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_initFinish(const T* __restrict__ r, const T* __restrict__ diag, T* __restrict__ pre,
+                                                       T* __restrict__ p, T* __restrict__ delta, long nPacks, int usePre, int graphMode,
+                                                       double* __restrict__ partials) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    constexpr int N = PackN<T>::N;
+    double acc = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nPacks; i += (long)gridDim.x * blockDim.x) {
+        Pack<T> R = ((const Pack<T>*)r)[i], D = ((const Pack<T>*)diag)[i], PR, PP, Z;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            T d = usePre ? D.v[k] : T(1);
+            T pr = guardedInvert(d);
+            if (graphMode && !usePre) pr = T(1);
+            T pp = pr * R.v[k];
+            PR.v[k] = pr; PP.v[k] = pp; Z.v[k] = T(0);
+            acc += (double)(R.v[k] * pp);
+        }
+        ((Pack<T>*)pre)[i] = PR; ((Pack<T>*)p)[i] = PP; ((Pack<T>*)delta)[i] = Z;
+    }
+    double t = blockReduceSum(acc, scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// total[0] = sum(partials[0..n))   (one workgroup)
+__global__ __launch_bounds__(kBlock) void k_finalizeSum(const double* __restrict__ partials, int n, double* __restrict__ total) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    double s = sumPartials(partials, n, scratch);
+    if (threadIdx.x == 0) total[0] = s;
+}
+
+// PCGStep2: solver.t:446-489
+template <class T, bool LM>
+__global__ __launch_bounds__(kBlock) void k_step2(T* __restrict__ delta, const T* __restrict__ p, T* __restrict__ r, const T* __restrict__ Ap,
+                                                  const T* __restrict__ pre /*nullptr -> 1*/, const T* __restrict__ b, T* __restrict__ z, long nPacks,
+                                                  const double* __restrict__ aNumTotal, const double* __restrict__ aDenPartials, int nDen,
+                                                  double* __restrict__ bNumPartials, double* __restrict__ qPartials) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    constexpr int N = PackN<T>::N;
+    const T aDen = (T)sumPartials(aDenPartials, nDen, scratch);
+    const T aNum = (T)aNumTotal[0];
+    const T alpha = (aDen > T(0)) ? aNum / aDen : T(0);   // guardDivisionByZero, solver.t:456-459
+    double accB = 0, accQ = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nPacks; i += (long)gridDim.x * blockDim.x) {
+        Pack<T> D = ((Pack<T>*)delta)[i], P = ((const Pack<T>*)p)[i], R = ((Pack<T>*)r)[i], A = ((const Pack<T>*)Ap)[i], M, B, Z;
+        if (pre) M = ((const Pack<T>*)pre)[i];
+        if (LM) B = ((const Pack<T>*)b)[i];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            T dl = D.v[k] + alpha * P.v[k];
+            T rr = R.v[k] - alpha * A.v[k];
+            T m = pre ? M.v[k] : T(1);
+            T zz = m * rr;
+            D.v[k] = dl; R.v[k] = rr; Z.v[k] = zz;
+            accB += (double)(zz * rr);
+            if (LM) accQ += (double)(T(0.5) * (dl * (rr + B.v[k])));
+        }
+        ((Pack<T>*)delta)[i] = D; ((Pack<T>*)r)[i] = R; ((Pack<T>*)z)[i] = Z;
+    }
+    double t = blockReduceSum(accB, scratch);
+    if (threadIdx.x == 0) bNumPartials[blockIdx.x] = t;
+    if (LM) {
+        double tq = blockReduceSum(accQ, scratch);
+        if (threadIdx.x == 0) qPartials[blockIdx.x] = tq;
+    }
+}
+
+// PCGStep2_1stHalf: solver.t:491-503
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_step2FirstHalf(T* __restrict__ delta, const T* __restrict__ p, long nPacks, const double* __restrict__ aNumTotal,
+                                                           const double* __restrict__ aDenPartials, int nDen) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    constexpr int N = PackN<T>::N;
+    const T aDen = (T)sumPartials(aDenPartials, nDen, scratch);
+    const T aNum = (T)aNumTotal[0];
+    const T alpha = (aDen > T(0)) ? aNum / aDen : T(0);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nPacks; i += (long)gridDim.x * blockDim.x) {
+        Pack<T> D = ((Pack<T>*)delta)[i], P = ((const Pack<T>*)p)[i];
+#pragma unroll
+        for (int k = 0; k < N; ++k) D.v[k] = D.v[k] + alpha * P.v[k];
+        ((Pack<T>*)delta)[i] = D;
+    }
+}
+
+// PCGStep2_2ndHalf: solver.t:505-534
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_step2SecondHalf(const T* __restrict__ delta, T* __restrict__ r, const T* __restrict__ Adelta, const T* __restrict__ b,
+                                                            const T* __restrict__ pre, T* __restrict__ z, long nPacks, double* __restrict__ bNumPartials,
+                                                            double* __restrict__ qPartials) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    constexpr int N = PackN<T>::N;
+    double accB = 0, accQ = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nPacks; i += (long)gridDim.x * blockDim.x) {
+        Pack<T> D = ((const Pack<T>*)delta)[i], A = ((const Pack<T>*)Adelta)[i], B = ((const Pack<T>*)b)[i], M, R, Z;
+        if (pre) M = ((const Pack<T>*)pre)[i];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            T rr = B.v[k] - A.v[k];
+            T m = pre ? M.v[k] : T(1);
+            T zz = m * rr;
+            R.v[k] = rr; Z.v[k] = zz;
+            accB += (double)(zz * rr);
+            accQ += (double)(T(0.5) * (D.v[k] * (rr + B.v[k])));
+        }
+        ((Pack<T>*)r)[i] = R; ((Pack<T>*)z)[i] = Z;
+    }
+    double t = blockReduceSum(accB, scratch);
+    if (threadIdx.x == 0) bNumPartials[blockIdx.x] = t;
+    double tq = blockReduceSum(accQ, scratch);
+    if (threadIdx.x == 0) qPartials[blockIdx.x] = tq;
+}
+
+// PCGStep3: solver.t:537-550; workgroup 0 also publishes betaNumerator as the next alphaNumerator (:1091)
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_step3(const T* __restrict__ z, T* __restrict__ p, long nPacks, const double* __restrict__ bNumPartials, int nB,
+                                                  const double* __restrict__ aNumOld, double* __restrict__ aNumNext) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    constexpr int N = PackN<T>::N;
+    const double bSum = sumPartials(bNumPartials, nB, scratch);
+    const T rDotzNew = (T)bSum, rDotzOld = (T)aNumOld[0];
+    const T beta = (rDotzOld > T(0)) ? rDotzNew / rDotzOld : T(0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) aNumNext[0] = bSum;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nPacks; i += (long)gridDim.x * blockDim.x) {
+        Pack<T> Z = ((const Pack<T>*)z)[i], P = ((Pack<T>*)p)[i];
+#pragma unroll
+        for (int k = 0; k < N; ++k) P.v[k] = Z.v[k] + beta * P.v[k];
+        ((Pack<T>*)p)[i] = P;
+    }
+}
+
+// PCGLinearUpdate / revertUpdate / savePreviousUnknowns on one unknown image (caller-owned array, not padded)
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_axpyImage(T* __restrict__ X, const T* __restrict__ d, long n) {   // X += d   (solver.t:552-557)
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) X[i] = X[i] + d[i];
+}
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_copy(T* __restrict__ dst, const T* __restrict__ src, long n) {    // solver.t:559-564, 573-578, 624-629
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// PCGComputeCtC + PCGFinalizeDiagonal: solver.t:616-622, 631-664.  On entry CtC holds raw diag(J^T J).
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_finalizeDiagonal(T* __restrict__ CtC, const T* __restrict__ SSq, const T* __restrict__ r, const T* __restrict__ delta,
+                                                             T* __restrict__ pre, T* __restrict__ b, T* __restrict__ p, long nPacks, T radius, T minLm, T maxLm,
+                                                             double* __restrict__ dPartials, double* __restrict__ qPartials) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    constexpr int N = PackN<T>::N;
+    const T invRadius = T(1) / radius;
+    double accD = 0, accQ = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nPacks; i += (long)gridDim.x * blockDim.x) {
+        Pack<T> C = ((Pack<T>*)CtC)[i], S = ((const Pack<T>*)SSq)[i], R = ((const Pack<T>*)r)[i], D = ((const Pack<T>*)delta)[i], M, P;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            T unclamped = C.v[k] * invRadius;                 // computeCtC: diag(J^T J) / radius (o.t:2277-2279)
+            T invS = T(1) / S.v[k];
+            T clampMul = invS / radius;
+            T lo = minLm * clampMul, hi = maxLm * clampMul;
+            T c = fmin(fmax(unclamped, lo), hi);
+            C.v[k] = c;
+            T m = T(1) / (c + radius * unclamped);
+            M.v[k] = m;
+            T pp = m * R.v[k];
+            P.v[k] = pp;
+            accD += (double)(R.v[k] * pp);
+            accQ += (double)(T(0.5) * (D.v[k] * (R.v[k] + R.v[k])));
+        }
+        ((Pack<T>*)CtC)[i] = C; ((Pack<T>*)pre)[i] = M; ((Pack<T>*)b)[i] = R; ((Pack<T>*)p)[i] = P;
+    }
+    double t = blockReduceSum(accD, scratch);
+    if (threadIdx.x == 0) dPartials[blockIdx.x] = t;
+    double tq = blockReduceSum(accQ, scratch);
+    if (threadIdx.x == 0) qPartials[blockIdx.x] = tq;
+}
+
+// ------------------------------------------------------------------------------------------------------
+template <class T>
+struct PcgSolver : SolverBase {
+    std::unique_ptr<EnergyOps<T>> E;
+    bool lm;
+    hipStream_t stream = nullptr;
+    LaunchCtx ctx;
+    long n = 0, nPad = 0, nPacks = 0;
+    int streamGrid = 0;
+    // PlanData vectors (solver.t:173-185); LM-only ones are allocated for LM plans only; `g` is never used by the reference
+    T *delta = nullptr, *r = nullptr, *b = nullptr, *Adelta = nullptr, *z = nullptr, *p = nullptr, *Ap_X = nullptr, *CtC = nullptr, *preconditioner = nullptr,
+      *SSq = nullptr, *prevX = nullptr;
+    std::vector<void*> allocs;
+    Reduction redA, redB, redQ, redC;   // alpha denominator, beta numerator, q, cost / init numerator
+    double* scal = nullptr;             // device: [0],[1] alphaNumerator ping-pong, [2..5] slab totals
+    int aSlot = 0;
+    double* hostBuf = nullptr;          // pinned
+    T prevCost = 0;
+    T trust_region_radius = 0, radius_decrease_factor = 0, min_lm_diagonal = 0, max_lm_diagonal = 0;   // pd.parameters (o.t:933-938)
+    OptAmd_SlabComm comm{};
+    bool distributed = false;
+
+    T* allocVec() {
+        T* v; HIP_CHECK(hipMalloc((void**)&v, nPad * sizeof(T))); HIP_CHECK(hipMemset(v, 0, nPad * sizeof(T)));   // zero-initialised like o.t:627-632
+        allocs.push_back(v); return v;
+    }
+    Reduction allocRed() {
+        Reduction R; HIP_CHECK(hipMalloc((void**)&R.partials, kMaxPartials * sizeof(double))); HIP_CHECK(hipMemset(R.partials, 0, kMaxPartials * sizeof(double)));
+        allocs.push_back(R.partials); return R;
+    }
+    PcgSolver(EnergyOps<T>* e, bool useLM, bool timing, int verb) : E(e), lm(useLM) {
+        verbosity = verb; timer.enabled = timing;
+        HIP_CHECK(hipStreamCreate(&stream));   // blocking stream: ordered against the caller's null-stream work
+        ctx.stream = stream; ctx.timer = timing ? &timer : nullptr;
+        n = E->nScalars; nPad = (n + 3) / 4 * 4; nPacks = nPad / PackN<T>::N;
+        int dev = 0, cus = 256; HIP_CHECK(hipGetDevice(&dev));
+        HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        long want = (nPacks + kBlock - 1) / kBlock;
+        streamGrid = (int)std::max<long>(1, std::min<long>(want, std::min<long>(kMaxPartials, (long)cus * 8)));
+        delta = allocVec(); r = allocVec(); z = allocVec(); p = allocVec(); Ap_X = allocVec(); CtC = allocVec(); preconditioner = allocVec();
+        if (lm) { b = allocVec(); Adelta = allocVec(); SSq = allocVec(); prevX = allocVec(); }
+        redA = allocRed(); redB = allocRed(); redQ = allocRed(); redC = allocRed();
+        HIP_CHECK(hipMalloc((void**)&scal, 8 * sizeof(double))); HIP_CHECK(hipMemset(scal, 0, 8 * sizeof(double))); allocs.push_back(scal);
+        HIP_CHECK(hipHostMalloc((void**)&hostBuf, kMaxPartials * sizeof(double)));
+        E->slab = Slab{};
+    }
+    ~PcgSolver() override {
+        (void)hipStreamSynchronize(stream);
+        for (void* a : allocs) (void)hipFree(a);
+        if (hostBuf) (void)hipHostFree(hostBuf);
+        (void)hipStreamDestroy(stream);
+    }
+
+    // ---- reductions ---------------------------------------------------------------------------------
+    // Host value of a reduction (blocking D2H like the reference's computeCost / fetchQ, solver.t:790-814)
+    double hostSum(const Reduction& R) {
+        if (distributed) {
+            k_finalizeSum<<<1, kBlock, 0, stream>>>(R.partials, R.n, scal + 2);
+            comm.allReduceSum(comm.ctx, scal + 2, 1, (void*)stream);
+            HIP_CHECK(hipMemcpyAsync(hostBuf, scal + 2, sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            return hostBuf[0];
+        }
+        HIP_CHECK(hipMemcpyAsync(hostBuf, R.partials, R.n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        double s = 0; for (int i = 0; i < R.n; ++i) s += hostBuf[i];
+        return s;
+    }
+    // What device consumers should sum: the partials themselves, or (slab mode) the all-reduced total.
+    Reduction forConsumers(const Reduction& R, int slot) {
+        if (!distributed) return R;
+        double* tot = scal + 3 + slot;
+        k_finalizeSum<<<1, kBlock, 0, stream>>>(R.partials, R.n, tot);
+        comm.allReduceSum(comm.ctx, tot, 1, (void*)stream);
+        Reduction out; out.partials = tot; out.n = 1; return out;
+    }
+    void finalizeTo(const Reduction& R, double* dst) {
+        ScopedKernel k(ctx, "finalizeSum");
+        k_finalizeSum<<<1, kBlock, 0, stream>>>(R.partials, R.n, dst);
+        if (distributed) comm.allReduceSum(comm.ctx, dst, 1, (void*)stream);
+    }
+
+    // ---- halo exchange (slab mode) ------------------------------------------------------------------
+    void exchangeVector(T* v) {
+        if (!distributed) return;
+        for (size_t i = 0; i < E->unknowns.size(); ++i) {
+            long rs = E->rowScalars((int)i); T* base = v + E->unknowns[i].offset; const Slab& s = E->slab;
+            comm.haloExchange(comm.ctx, base + (long)s.yBegin * rs, base + (long)(s.yEnd - 1) * rs, base + (long)(s.yBegin - 1) * rs, base + (long)s.yEnd * rs,
+                              rs * (long)sizeof(T), (void*)stream);
+        }
+    }
+    void exchangeUnknowns() {
+        if (!distributed) return;
+        for (size_t i = 0; i < E->unknowns.size(); ++i) {
+            long rs = E->rowScalars((int)i); T* base = E->unknownPtr((int)i); const Slab& s = E->slab;
+            comm.haloExchange(comm.ctx, base + (long)s.yBegin * rs, base + (long)(s.yEnd - 1) * rs, base + (long)(s.yBegin - 1) * rs, base + (long)s.yEnd * rs,
+                              rs * (long)sizeof(T), (void*)stream);
+        }
+    }
+
+    // ---- pieces ---------------------------------------------------------------------------------------
+    T computeCost() {   // solver.t:790-797
+        E->evalCost(redC, ctx);
+        return (T)hostSum(redC);
+    }
+    void imageOp(int kind) {   // 0: X += delta, 1: prevX = X, 2: X = prevX
+        for (size_t i = 0; i < E->unknowns.size(); ++i) {
+            const auto& u = E->unknowns[i];
+            long cnt = u.elems * u.channels;
+            int grid = (int)std::max<long>(1, std::min<long>((cnt + kBlock - 1) / kBlock, 4096));
+            T* X = E->unknownPtr((int)i);
+            if (kind == 0) { ScopedKernel k(ctx, "PCGLinearUpdate"); k_axpyImage<T><<<grid, kBlock, 0, stream>>>(X, delta + u.offset, cnt); }
+            else if (kind == 1) { ScopedKernel k(ctx, "savePreviousUnknowns"); k_copy<T><<<grid, kBlock, 0, stream>>>(prevX + u.offset, X, cnt); }
+            else { ScopedKernel k(ctx, "revertUpdate"); k_copy<T><<<grid, kBlock, 0, stream>>>(X, prevX + u.offset, cnt); }
+        }
+    }
+    void record(int lIter, const Reduction& aDenR, const Reduction& bNumR, double q) {
+        if (!traceEnabled) return;
+        double aDen = hostSum(aDenR), bNum = hostSum(bNumR), aNum = 0;
+        HIP_CHECK(hipMemcpyAsync(hostBuf, scal + aSlot, sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        aNum = hostBuf[0];
+        trace.insert(trace.end(), {(double)sp.nIter, (double)lIter, aNum, aDen, bNum, q});
+    }
+
+    // ---- init (solver.t:956-1007) ---------------------------------------------------------------------
+    void init(void** params) override {
+        timer.reset(); trace.clear();
+        E->bind(params, ctx);
+        sp.nIter = 0;
+        if (lm) {
+            trust_region_radius = (T)sp.trust_region_radius; radius_decrease_factor = (T)sp.radius_decrease_factor;
+            min_lm_diagonal = (T)sp.min_lm_diagonal; max_lm_diagonal = (T)sp.max_lm_diagonal;
+        }
+        exchangeUnknowns();
+        E->precompute(ctx);
+        prevCost = computeCost();
+    }
+    void cleanup() {   // solver.t:1009-1014
+        if (verbosity > 0) printf("final cost=%f\n", (double)prevCost);
+        if (timer.enabled) { timer.evaluate(); if (verbosity > 0) timer.print(); }
+    }
+
+    // ---- step (solver.t:1016-1177) --------------------------------------------------------------------
+    int step(void** params) override {
+        const T min_relative_decrease = (T)sp.min_relative_decrease, min_trust_region_radius = (T)sp.min_trust_region_radius;
+        const T max_trust_region_radius = (T)sp.max_trust_region_radius, q_tolerance = (T)sp.q_tolerance, function_tolerance = (T)sp.function_tolerance;
+        T Q0 = 0, Q1 = 0;
+        E->bind(params, ctx);
+        if (sp.nIter >= sp.nIterations) { cleanup(); return 0; }
+        const T* preArg = E->usePreconditioner ? preconditioner : nullptr;   // solver.t:467-470: pre = 1 unless the energy preconditions
+
+        // PCGInit1 [+ _Graph + _Finish]: the energy produces r = -J^T F and raw diag(J^T J) (parked in CtC)
+        E->evalJTF(r, CtC, ctx);
+        {
+            ScopedKernel k(ctx, "PCGInit1_Finish");
+            k_initFinish<T><<<streamGrid, kBlock, 0, stream>>>(r, CtC, preconditioner, p, delta, nPacks, E->usePreconditioner ? 1 : 0, E->usesGraph ? 1 : 0, redC.partials);
+            redC.n = streamGrid;
+        }
+        aSlot = 0;
+        if (lm) {
+            if (sp.nIter == 0) { ScopedKernel k(ctx, "PCGSaveSSq"); k_copy<T><<<streamGrid, kBlock, 0, stream>>>(SSq, preconditioner, nPad); }
+            {
+                ScopedKernel k(ctx, "PCGFinalizeDiagonal");
+                k_finalizeDiagonal<T><<<streamGrid, kBlock, 0, stream>>>(CtC, SSq, r, delta, preconditioner, b, p, nPacks, trust_region_radius, min_lm_diagonal,
+                                                                         max_lm_diagonal, redC.partials, redQ.partials);
+                redC.n = streamGrid; redQ.n = streamGrid;
+            }
+            preArg = E->usePreconditioner ? preconditioner : nullptr;
+            Q0 = (T)hostSum(redQ);   // fetchQ, solver.t:1050
+        }
+        finalizeTo(redC, scal + aSlot);   // alphaNumerator = sum r.p
+
+        for (int lIter = 0; lIter < sp.lIterations; ++lIter) {
+            exchangeVector(p);
+            E->applyJTJ(p, Ap_X, lm ? CtC : nullptr, &redA, ctx);        // PCGStep1 (+_Graph)
+            Reduction aDen = forConsumers(redA, 0);
+            const bool reset = lm && ((lIter + 1) % sp.residual_reset_period) == 0;
+            if (reset) {   // solver.t:1077-1083
+                { ScopedKernel k(ctx, "PCGStep2_1stHalf"); k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, p, nPacks, scal + aSlot, aDen.partials, aDen.n); }
+                exchangeVector(delta);
+                E->applyJTJ(delta, Adelta, CtC, nullptr, ctx);             // computeAdelta (+_Graph)
+                { ScopedKernel k(ctx, "PCGStep2_2ndHalf");
+                  k_step2SecondHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, r, Adelta, b, preArg, z, nPacks, redB.partials, redQ.partials); }
+                redB.n = streamGrid; redQ.n = streamGrid;
+            } else {
+                ScopedKernel k(ctx, "PCGStep2");
+                if (lm) k_step2<T, true><<<streamGrid, kBlock, 0, stream>>>(delta, p, r, Ap_X, preArg, b, z, nPacks, scal + aSlot, aDen.partials, aDen.n, redB.partials, redQ.partials);
+                else k_step2<T, false><<<streamGrid, kBlock, 0, stream>>>(delta, p, r, Ap_X, preArg, nullptr, z, nPacks, scal + aSlot, aDen.partials, aDen.n, redB.partials, nullptr);
+                redB.n = streamGrid; redQ.n = streamGrid;
+            }
+            Reduction bNum = forConsumers(redB, 1);
+            {
+                ScopedKernel k(ctx, "PCGStep3");
+                k_step3<T><<<streamGrid, kBlock, 0, stream>>>(z, p, nPacks, bNum.partials, bNum.n, scal + aSlot, scal + (aSlot ^ 1));
+            }
+            double qh = 0;
+            if (lm) { qh = hostSum(redQ); }
+            if (traceEnabled) record(lIter, aDen, bNum, qh);
+            aSlot ^= 1;   // alphaNumerator <- betaNumerator (solver.t:1091)
+            if (lm) {   // solver.t:1093-1102
+                Q1 = (T)qh;
+                T zeta = T(lIter + 1) * (Q1 - Q0) / Q1;
+                if (zeta < q_tolerance) { if (verbosity > 0) printf("zeta=%.18g, breaking at iteration: %d\n", (double)zeta, lIter + 1); break; }
+                Q0 = Q1;
+            }
+        }
+
+        T model_cost_change = 0;
+        if (lm) {   // solver.t:1108-1113, 819-827
+            exchangeVector(delta);
+            E->evalModelCost(delta, redC, ctx);
+            T model_cost = (T)hostSum(redC);
+            if (verbosity > 0) printf(" cost=%f \n model_cost=%f \n", (double)prevCost, (double)model_cost);
+            model_cost_change = prevCost - model_cost;
+            if (verbosity > 0) printf(" model_cost_change=%f \n", (double)model_cost_change);
+            imageOp(1);
+        }
+        imageOp(0);   // PCGLinearUpdate
+        exchangeUnknowns();
+        E->precompute(ctx);
+        T newCost = computeCost();
+
+        if (lm) {   // solver.t:1119-1157
+            T cost_change = prevCost - newCost;
+            T relative_decrease = cost_change / model_cost_change;
+            if (cost_change >= 0 && relative_decrease > min_relative_decrease) {
+                T absolute_function_tolerance = prevCost * function_tolerance;
+                if (cost_change <= absolute_function_tolerance) {
+                    if (verbosity > 0) printf("\nFunction tolerance reached, exiting\n");
+                    cleanup(); return 0;
+                }
+                // Terra promotes these literals to double; results are stored back as opt_float (solver.t:1135-1139)
+                double step_quality = (double)relative_decrease, min_factor = 1.0 / 3.0;
+                double tmp_factor = 1.0 - std::pow(2.0 * step_quality - 1.0, 3.0);
+                trust_region_radius = (T)((double)trust_region_radius / std::fmax(min_factor, tmp_factor));
+                trust_region_radius = std::fmin(trust_region_radius, max_trust_region_radius);
+                radius_decrease_factor = T(2.0);
+                prevCost = newCost;
+            } else {
+                imageOp(2);   // revertUpdate
+                trust_region_radius = trust_region_radius / radius_decrease_factor;
+                if (verbosity > 0) printf(" trust_region_radius=%f \n", (double)trust_region_radius);
+                radius_decrease_factor = T(2.0) * radius_decrease_factor;
+                if (trust_region_radius <= min_trust_region_radius) {
+                    if (verbosity > 0) printf("\nTrust_region_radius is less than the min, exiting\n");
+                    cleanup(); return 0;
+                }
+                if (verbosity > 0) printf("REVERT\n");
+                exchangeUnknowns();
+                E->precompute(ctx);
+                HIP_CHECK(hipStreamSynchronize(stream));   // results visible when the call returns
+            }
+        } else {
+            if (verbosity > 0) printf("cost: %f -> %f\n", (double)prevCost, (double)newCost);
+            prevCost = newCost;
+        }
+        sp.nIter += 1;
+        return 1;
+    }
+
+    double cost() const override { return (double)prevCost; }   // solver.t:1179-1182
+    long numUnknownScalars() const override { return n; }
+    double trustRegionRadius() const override { return (double)trust_region_radius; }
+    void* vector(const std::string& nm) override {
+        if (nm == "delta") return delta; if (nm == "r") return r; if (nm == "b") return b; if (nm == "Adelta") return Adelta;
+        if (nm == "z") return z; if (nm == "p") return p; if (nm == "Ap_X") return Ap_X; if (nm == "CtC") return CtC;
+        if (nm == "preconditioner") return preconditioner; if (nm == "SSq") return SSq; if (nm == "prevX") return prevX;
+        return nullptr;
+    }
+
+    // ---- kernel-level probes (OptAmd.h) ---------------------------------------------------------------
+    void evalJTF(void** params, void* jtf, void* diag) override {
+        E->bind(params, ctx); exchangeUnknowns(); E->precompute(ctx);
+        E->evalJTF(z, Ap_X, ctx);   // scratch use of z / Ap_X: z = -J^T F
+        HIP_CHECK(hipStreamSynchronize(stream));
+        std::vector<T> h(n);
+        HIP_CHECK(hipMemcpy(h.data(), z, n * sizeof(T), hipMemcpyDeviceToHost));
+        for (auto& x : h) x = -x;
+        HIP_CHECK(hipMemcpy(jtf, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(diag, Ap_X, n * sizeof(T), hipMemcpyDeviceToDevice));
+    }
+    double applyJTJ(void** params, const void* v, void* out) override {
+        E->bind(params, ctx); exchangeUnknowns(); E->precompute(ctx);
+        E->evalJTF(z, CtC, ctx);   // refreshes the energy's per-iteration auxiliaries (e.g. cos/sin tables)
+        HIP_CHECK(hipMemsetAsync(p, 0, nPad * sizeof(T), stream));
+        HIP_CHECK(hipMemcpyAsync(p, v, n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+        exchangeVector(p);
+        E->applyJTJ(p, Ap_X, nullptr, &redA, ctx);
+        double d = hostSum(redA);
+        HIP_CHECK(hipMemcpy(out, Ap_X, n * sizeof(T), hipMemcpyDeviceToDevice));
+        return d;
+    }
+    double evalCost(void** params) override {
+        E->bind(params, ctx); exchangeUnknowns(); E->precompute(ctx);
+        return (double)computeCost();
+    }
+    int setSlab(long row0, long rows, long globalHeight, const OptAmd_SlabComm* c) override {
+        if (!E->supportsSlab() || !c) return 0;
+        E->slab.active = true; E->slab.yBegin = 1; E->slab.yEnd = (int)rows + 1; E->slab.gy0 = (int)row0 - 1; E->slab.Hg = (int)globalHeight;
+        comm = *c; distributed = c->world > 1;
+        return 1;
+    }
+};
+
+bool SolverBase::setParameter(const char* name, const void* value) {   // solver.t:1205-1221
+    std::string nm(name);
+#define PF(x) if (nm == #x) { sp.x = *(const float*)value; return true; }
+#define PI(x) if (nm == #x) { sp.x = *(const int*)value; return true; }
+    PF(min_relative_decrease) PF(min_trust_region_radius) PF(max_trust_region_radius) PF(q_tolerance) PF(function_tolerance)
+    PF(trust_region_radius) PF(radius_decrease_factor) PF(min_lm_diagonal) PF(max_lm_diagonal)
+    PI(residual_reset_period) PI(nIter) PI(nIterations) PI(lIterations)
+#undef PF
+#undef PI
+    return false;
+}
+
+SolverBase* makeSolver(const EnergyInfo& info, bool lm, bool doublePrecision, const unsigned* dims, bool timing, int verbosity) {
+    if (doublePrecision && !info.floatOnly) {
+        EnergyOps<double>* e = info.makeDouble(dims);
+        if (!e) return nullptr;
+        return new PcgSolver<double>(e, lm, timing, verbosity);
+    }
+    EnergyOps<float>* e = info.makeFloat(dims);
+    if (!e) return nullptr;
+    return new PcgSolver<float>(e, lm, timing, verbosity);
+}
+
+}  // namespace optamd

@@ -1,0 +1,157 @@
+"""GPU parity tests for image_warping (-m gpu): every stage of the HIP path against the CPU oracle on the
+same seeded inputs, through the C ABI (Opt.h + the OptAmd.h probes).
+
+Tolerances: float results must agree to 1e-5 relative (BASELINE.json north_star), double to 1e-12 on
+costs; per-vector checks use the same bar relative to the vector norm.
+"""
+import numpy as np
+import pytest
+
+from opt_amd import api, workloads as wl
+from helpers import device_unknowns, flat_unknowns, hip_solver, oracle_solver, rel_err
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(64, 64), (257, 129), (31, 5), (300, 1), (1, 40)]
+
+
+def _problem(W, H, double, seed=7):
+    return wl.image_warping(W, H, double=double, random_state=seed, mask_fraction=0.08, perturb=0.4)
+
+
+@pytest.mark.parametrize("W,H", SIZES)
+@pytest.mark.parametrize("double", [False, True])
+def test_cost_jtf_diag_jtjp(oracle_lib, W, H, double):
+    import torch
+    P = _problem(W, H, double)
+    tol = 1e-11 if double else 2e-5
+    o = oracle_solver(oracle_lib, P)
+    g = hip_solver(P)
+    dev = api.to_device(P)
+    # cost
+    c_ref, c_gpu = o.eval_cost(P.params), g.eval_cost(dev)
+    assert abs(c_gpu - c_ref) <= (1e-12 if double else 1e-5) * abs(c_ref)
+    # J^T F and diag(J^T J)
+    f_ref, d_ref = o.eval_jtf(P.params)
+    f_gpu, d_gpu = g.eval_jtf(dev)
+    act = np.concatenate([np.repeat(P.params[4].reshape(-1) == 0, 2), P.params[4].reshape(-1) == 0])
+    assert rel_err(f_gpu.cpu().numpy()[act], f_ref[act]) < tol
+    assert rel_err(d_gpu.cpu().numpy()[act], d_ref[act]) < tol
+    assert np.all(f_gpu.cpu().numpy()[~act] == 0)          # excluded rows are written as zero
+    # J^T J p for a seeded p (zero on excluded rows, as in the solver)
+    rng = np.random.default_rng(11)
+    v = (rng.standard_normal(o.n) * act).astype(o.dtype)
+    Av_ref = o.apply_jtj(P.params, v)
+    Av_gpu, dot = g.apply_jtj(dev, torch.from_numpy(v).cuda())
+    assert rel_err(Av_gpu.cpu().numpy(), Av_ref) < tol
+    assert abs(dot - float(v.astype(np.float64) @ Av_ref.astype(np.float64))) <= 10 * tol * abs(dot)
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("double", [False, True])
+def test_gn_trajectory(oracle_lib, double):
+    """3 GN x 10 PCG on 48x40: per-PCG-iteration scalars, per-GN cost and final unknowns."""
+    P = _problem(48, 40, double, seed=3)
+    o = oracle_solver(oracle_lib, P, nIterations=3, lIterations=10)
+    g = hip_solver(P, nIterations=3, lIterations=10)
+    g.enable_trace()
+    dev = api.to_device(P)
+    Pref = P.clone()
+    o.init(Pref.params); g.init(dev)
+    costs_o, costs_g = [o.cost()], [g.cost()]
+    while True:
+        a, b = o.step(Pref.params), g.step(dev)
+        assert a == b
+        if not a:
+            break
+        costs_o.append(o.cost()); costs_g.append(g.cost())
+    tol = 1e-11 if double else 1e-5
+    np.testing.assert_allclose(costs_g, costs_o, rtol=tol)
+    to, tg = o.trace(), g.trace()
+    assert to.shape == tg.shape == (30, 6)
+    np.testing.assert_allclose(tg[:, 2:5], to[:, 2:5], rtol=1e-9 if double else 5e-4)
+    assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < (1e-11 if double else 1e-5)
+    g.close(); o.close()
+
+
+def test_lm_trajectory_double(oracle_lib):
+    P = _problem(40, 36, True, seed=5)
+    kw = dict(nIterations=5, lIterations=25)
+    o = oracle_solver(oracle_lib, P, "LMGPU", **kw)
+    g = hip_solver(P, "LMGPU", **kw)
+    dev = api.to_device(P)
+    Pref = P.clone()
+    o.init(Pref.params); g.init(dev)
+    assert abs(g.cost() - o.cost()) <= 1e-12 * o.cost()
+    while True:
+        a, b = o.step(Pref.params), g.step(dev)
+        assert a == b
+        assert abs(g.cost() - o.cost()) <= 1e-10 * o.cost()
+        assert abs(g.trust_region_radius() - o.trust_region_radius()) <= 1e-8 * o.trust_region_radius()
+        if not a:
+            break
+    assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < 1e-9
+    g.close(); o.close()
+
+
+def test_lm_trajectory_float(oracle_lib):
+    P = _problem(40, 36, False, seed=5)
+    kw = dict(nIterations=4, lIterations=25)
+    o = oracle_solver(oracle_lib, P, "LMGPU", **kw)
+    g = hip_solver(P, "LMGPU", **kw)
+    dev = api.to_device(P)
+    Pref = P.clone()
+    o.init(Pref.params); g.init(dev)
+    while True:
+        a, b = o.step(Pref.params), g.step(dev)
+        assert a == b
+        assert abs(g.cost() - o.cost()) <= 1e-5 * o.cost()
+        if not a:
+            break
+    g.close(); o.close()
+
+
+def test_solve_matches_init_plus_steps_and_is_deterministic():
+    import torch
+    P = wl.image_warping(96, 80)
+    outs = []
+    for mode in ("solve", "steps", "solve"):
+        g = hip_solver(P, nIterations=2, lIterations=15)
+        dev = api.to_device(P)
+        if mode == "solve":
+            g.solve(dev)
+        else:
+            g.init(dev)
+            while g.step(dev):
+                pass
+        outs.append((g.cost(), torch.cat([dev[0].reshape(-1), dev[1].reshape(-1)]).cpu().numpy()))
+        g.close()
+    assert outs[0][0] == outs[1][0] == outs[2][0]            # bitwise: reductions are order-fixed
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][1], outs[2][1])
+
+
+def test_full_size_properties():
+    """2048^2 (BASELINE config 2): size-independent properties instead of an oracle run --
+    symmetry p.Aq = q.Ap, p.Ap >= 0, A(e_i)_i = diag_i, and GN monotonically reduces the cost."""
+    import torch
+    W = H = 2048
+    P = wl.image_warping(W, H)
+    g = hip_solver(P, nIterations=2, lIterations=10)
+    dev = api.to_device(P)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+    p = torch.randn(g.n, device="cuda", generator=gen); q = torch.randn(g.n, device="cuda", generator=gen)
+    Ap, pAp = g.apply_jtj(dev, p)
+    Aq, _ = g.apply_jtj(dev, q)
+    pAq, qAp = float(p.double() @ Aq.double()), float(q.double() @ Ap.double())
+    assert abs(pAq - qAp) <= 1e-4 * max(abs(pAq), abs(qAp), 1.0)
+    assert pAp > 0 and abs(pAp - float(p.double() @ Ap.double())) <= 1e-5 * pAp
+    _, diag = g.eval_jtf(dev)
+    for i in (0, 12345, 2 * W * H + 777, g.n - 1):
+        e = torch.zeros(g.n, device="cuda"); e[i] = 1
+        Ae, _ = g.apply_jtj(dev, e)
+        assert abs(float(Ae[i]) - float(diag[i])) <= 1e-5 * abs(float(diag[i]))
+    g.init(dev); c = [g.cost()]
+    while g.step(dev):
+        c.append(g.cost())
+    assert len(c) == 3 and c[2] < c[1] < c[0]
+    g.close()
