@@ -55,6 +55,12 @@ struct EnergyOps {
     virtual void evalJTF(T* r, T* diag, LaunchCtx& ctx) = 0;
     // out = J^T J v (+ CtC .* v if CtC != nullptr, o.t:2076-2082); dot (optional) = partial sums of v . out
     virtual void applyJTJ(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) = 0;
+    // Optional fusion of the previous iteration's PCGStep3 into PCGStep1: pNew = z + beta pOld with
+    // beta = sum(bNum) / aNumOld (guarded, solver.t:544-547), aNumNext[0] = sum(bNum), then out = J^T J pNew.
+    // pNew must not alias pOld.  Return false if the energy has no fused kernel (the solver then runs
+    // the generic PCGStep3 followed by applyJTJ).
+    virtual bool applyJTJFused(const T* /*pOld*/, const T* /*z*/, T* /*pNew*/, T* /*out*/, const T* /*CtC*/, Reduction* /*dot*/,
+                               const Reduction& /*bNum*/, const double* /*aNumOld*/, double* /*aNumNext*/, LaunchCtx&) { return false; }
     // partial sums of 1/2 sum (F + J delta)^2 (o.t:2174-2225); LM only
     virtual void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) = 0;
     // slab tiling (image energies): number of scalars in one image row of unknown image `img`

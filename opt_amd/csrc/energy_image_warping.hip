@@ -153,76 +153,177 @@ __global__ __launch_bounds__(kBlock) void iw_evalJTF(IWArgs<T> A, T* __restrict_
     }
 }
 
-// ---- applyJTJ (PCGStep1): row-marching stencil ----------------------------------------------------------------
+// ---- applyJTJ (PCGStep1), optionally with the previous iteration's PCGStep3 fused in -----------------------------
+// Row-marching stencil: see the header comment.  With FUSE the kernel first forms the new search direction
+// p = z + beta p (reference PCGStep3, solverGPUGaussNewton.t:537-550) for every pixel it touches -- the
+// rows it owns plus its two halo rows -- writes it for the owned rows into a SECOND p buffer (in-place
+// would race with the neighbouring workgroup's halo reads), and applies J^T J to it.  That removes one
+// kernel and the re-read of p per PCG iteration.
+//
+// Lane layout: a wave covers 64 consecutive pixels of a row but only its inner 62 lanes produce output;
+// lanes 0 and 63 are the horizontal halo (neighbouring waves overlap by 2 pixels).  Left / right
+// neighbours are then whole-wave DPP shifts of registers -- no LDS, no divergent edge loads -- at the price
+// of 3 % redundant lanes.  Rows are fetched two ahead of use (raw registers, combined late) so that a
+// wave always has a full row of loads in flight while it computes.
 template <class T>
 struct Px {
     T ox, oy, a;    // v at this pixel (Offset part, Angle part)
     T c, s;         // cos/sin of the pixel's angle
     T ux, uy;       // UrShape
-    bool m;         // exists & not masked
-    uint8_t f;
+    int f;          // flags (0 if the pixel does not exist)
+};
+template <class T, bool FUSE>
+struct Raw {        // one pixel's loads, not yet combined (keeps the loads independent of any ALU work)
+    V2<T> o, cs, u; T a;
+    V2<T> zo; T za;
+    int f;
 };
 
+// DPP whole-wave shifts (gfx9 family): wave_shr:1 gives lane i the value of lane i-1, wave_shl:1 of lane i+1;
+// lanes shifted in from outside the wave read 0 (bound_ctrl).  One v_mov_b32_dpp per 32-bit word, no LDS.
+template <bool RIGHT> __device__ __forceinline__ int dppShift(int v) {
+    return RIGHT ? __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true) : __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true);
+}
+template <bool RIGHT> __device__ __forceinline__ float dppShift(float v) { return __int_as_float(dppShift<RIGHT>(__float_as_int(v))); }
+template <bool RIGHT> __device__ __forceinline__ double dppShift(double v) {
+    const int lo = dppShift<RIGHT>(__double2loint(v)), hi = dppShift<RIGHT>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+template <bool RIGHT, class T> __device__ __forceinline__ Px<T> dppShiftPx(const Px<T>& p) {
+    Px<T> q;
+    q.ox = dppShift<RIGHT>(p.ox); q.oy = dppShift<RIGHT>(p.oy); q.a = dppShift<RIGHT>(p.a); q.c = dppShift<RIGHT>(p.c); q.s = dppShift<RIGHT>(p.s);
+    q.ux = dppShift<RIGHT>(p.ux); q.uy = dppShift<RIGHT>(p.uy); q.f = dppShift<RIGHT>(p.f);
+    return q;
+}
+
 template <class T>
-__device__ __forceinline__ Px<T> iw_load(const IWArgs<T>& A, const V2<T>* __restrict__ vO, const T* __restrict__ va, int x, int y) {
+struct FuseArgs {            // the PCGStep3 inputs when fused (see k_step3 in solver.hip)
+    const T* z; T* vNew;
+    const double* bNumPartials; int nB;
+    const double* aNumOld; double* aNumNext;
+};
+
+// streaming (non-temporal) accesses for the once-per-kernel vectors; see solver.hip ldnt/stnt
+template <class T> struct Vec2T;
+template <> struct Vec2T<float> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct Vec2T<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <bool NT, class T> __device__ __forceinline__ V2<T> ld2(const V2<T>* p, long i) {
+    if (NT) { const typename Vec2T<T>::type v = __builtin_nontemporal_load((const typename Vec2T<T>::type*)p + i); return V2<T>{v.x, v.y}; }
+    return p[i];
+}
+template <bool NT, class T> __device__ __forceinline__ T ld1(const T* p, long i) { return NT ? __builtin_nontemporal_load(p + i) : p[i]; }
+template <bool NT, class T> __device__ __forceinline__ void st2(V2<T>* p, long i, T x, T y) {
+    if (NT) { typename Vec2T<T>::type v; v.x = x; v.y = y; __builtin_nontemporal_store(v, (typename Vec2T<T>::type*)p + i); }
+    else p[i] = V2<T>{x, y};
+}
+template <bool NT, class T> __device__ __forceinline__ void st1(T* p, long i, T x) { if (NT) __builtin_nontemporal_store(x, p + i); else p[i] = x; }
+constexpr bool kNT = false;   // measured: nt on these 4-8 B/lane accesses costs 25% (fused 250 -> 315 us at 4096^2); 16 B/lane streams in solver.hip keep it
+
+template <class T, bool FUSE>
+__device__ __forceinline__ Raw<T, FUSE> iw_loadRaw(const IWArgs<T>& A, const V2<T>* __restrict__ vO, const T* __restrict__ va, const V2<T>* __restrict__ zO,
+                                                   const T* __restrict__ za, bool xok, int x, int y) {
+    // Branch-free: out-of-image pixels read a clamped (valid) address and get flag 0; every use of the other
+    // fields is gated by the flag through selects, so their values never matter.
+    Raw<T, FUSE> r;
+    const bool ok = xok && y >= 0 && y < A.H;
+    const long i = (long)min(max(y, 0), A.H - 1) * A.W + min(max(x, 0), A.W - 1);
+    const int f = A.flags[i];
+    r.f = ok ? f : 0;
+    r.o = ld2<kNT>(vO, i); r.a = ld1<kNT>(va, i); r.cs = ld2<kNT>((const V2<T>*)A.cs, i); r.u = ld2<kNT>((const V2<T>*)A.UrShape, i);
+    if (FUSE) { r.zo = ld2<kNT>(zO, i); r.za = ld1<kNT>(za, i); } else { r.zo = V2<T>{0, 0}; r.za = 0; }
+    return r;
+}
+template <class T, bool FUSE>
+__device__ __forceinline__ Px<T> iw_combine(const Raw<T, FUSE>& r, T beta) {
     Px<T> p;
-    if (x < 0 || x >= A.W || y < 0 || y >= A.H) { p.ox = p.oy = p.a = p.c = p.s = p.ux = p.uy = 0; p.m = false; p.f = 0; return p; }
-    const long i = (long)y * A.W + x;
-    const uint8_t f = A.flags[i];
-    const V2<T> o = vO[i], cs = ((const V2<T>*)A.cs)[i], u = ((const V2<T>*)A.UrShape)[i];
-    p.ox = o.x; p.oy = o.y; p.a = va[i]; p.c = cs.x; p.s = cs.y; p.ux = u.x; p.uy = u.y; p.f = f; p.m = (f & kActive) != 0;
+    p.ox = r.o.x; p.oy = r.o.y; p.a = r.a;
+    if (FUSE) { p.ox = r.zo.x + beta * p.ox; p.oy = r.zo.y + beta * p.oy; p.a = r.za + beta * p.a; }   // PCGStep3
+    p.c = r.cs.x; p.s = r.cs.y; p.ux = r.u.x; p.uy = r.u.y; p.f = r.f;
     return p;
 }
 
 // accumulate the two residuals shared by centre c and neighbour n (the one centred at c and the one centred at n)
 template <class T>
 __device__ __forceinline__ void iw_pair(const Px<T>& c, const Px<T>& n, T& accOx, T& accOy, T& accA) {
-    if (!n.m) return;
+    const bool on = (n.f & kActive) != 0;                              // v(c,n); the centre's own flag is applied by the caller
     const T ux = c.ux - n.ux, uy = c.uy - n.uy;
     const T Dcx = -c.s * ux - c.c * uy, Dcy = c.c * ux - c.s * uy;     // R'(a_c)(U_c - U_n)
     const T Dnx = n.s * ux + n.c * uy, Dny = -n.c * ux + n.s * uy;     // R'(a_n)(U_n - U_c)
     const T jcx = (c.ox - n.ox) - Dcx * c.a, jcy = (c.oy - n.oy) - Dcy * c.a;   // J p of the residual centred at c  (/w)
     const T jnx = (n.ox - c.ox) - Dnx * n.a, jny = (n.oy - c.oy) - Dny * n.a;   // J p of the residual centred at n  (/w)
-    accOx += jcx - jnx; accOy += jcy - jny;
-    accA -= Dcx * jcx + Dcy * jcy;
+    accOx += on ? jcx - jnx : T(0); accOy += on ? jcy - jny : T(0);   // selects, not branches: the kernel stays straight-line
+    accA -= on ? Dcx * jcx + Dcy * jcy : T(0);
 }
 
-template <class T, bool LM>
+constexpr int kSpan = kWave - 2;                    // output pixels per wave per row
+constexpr int kStrip = (kBlock / kWave) * kSpan;    // output pixels per workgroup per row (248)
+
+template <class T, bool LM, bool FUSE>
 __global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ CtC,
-                                                      double* __restrict__ partials, int rowsPerGroup) {
+                                                      double* __restrict__ partials, int rowsPerGroup, FuseArgs<T> F) {
     __shared__ double scratch[kBlock / kWave + 1];
     const long N = (long)A.W * A.H;
     const V2<T>* vO = (const V2<T>*)v; const T* va = v + 2 * N;
+    const V2<T>* zO = (const V2<T>*)F.z; const T* za = F.z + 2 * N;
+    V2<T>* nO = (V2<T>*)F.vNew; T* na = F.vNew + 2 * N;
     V2<T>* outO = (V2<T>*)out; T* outA = out + 2 * N;
-    const int x = blockIdx.x * kBlock + threadIdx.x;
+    T beta = 0;
+    if (FUSE) {   // solver.t:541-547
+        const double bSum = sumPartials(F.bNumPartials, F.nB, scratch);
+        const T rDotzNew = (T)bSum, rDotzOld = (T)F.aNumOld[0];
+        beta = (rDotzOld > T(0)) ? rDotzNew / rDotzOld : T(0);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) F.aNumNext[0] = bSum;   // alphaNumerator <- betaNumerator (:1091)
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * kStrip + wave * kSpan + lane - 1;
+    const bool xok = x >= 0 && x < A.W;
+    const bool writer = xok && lane >= 1 && lane <= kSpan;       // inner lanes own their pixel; lanes 0 / 63 are halo
     const int yb = A.yBegin + blockIdx.y * rowsPerGroup;
     const int ye = min(yb + rowsPerGroup, A.yEnd);
     const T w2 = A.w_reg * A.w_reg, wf2 = A.w_fit * A.w_fit;
     double acc = 0;
-    if (x < A.W) {
-        Px<T> up = iw_load(A, vO, va, x, yb - 1);
-        Px<T> cur = iw_load(A, vO, va, x, yb);
-        for (int y = yb; y < ye; ++y) {
-            const Px<T> dn = iw_load(A, vO, va, x, y + 1);
-            const long i = (long)y * A.W + x;
-            T rx = 0, ry = 0, ra = 0;
-            if (cur.m) {
-                const Px<T> rt = iw_load(A, vO, va, x + 1, y), lf = iw_load(A, vO, va, x - 1, y);
-                T ax = 0, ay = 0, aa = 0;
-                iw_pair(cur, rt, ax, ay, aa);
-                iw_pair(cur, lf, ax, ay, aa);
-                iw_pair(cur, dn, ax, ay, aa);
-                iw_pair(cur, up, ax, ay, aa);
-                rx = w2 * ax; ry = w2 * ay; ra = w2 * aa;
-                if (cur.f & kFit) { rx += wf2 * cur.ox; ry += wf2 * cur.oy; }
-                if (LM) {
-                    const V2<T> cO = ((const V2<T>*)CtC)[i];
-                    rx += cO.x * cur.ox; ry += cO.y * cur.oy; ra += CtC[2 * N + i] * cur.a;
-                }
-                acc += (double)(cur.ox * rx + cur.oy * ry + cur.a * ra);
-            }
-            outO[i] = V2<T>{rx, ry}; outA[i] = ra;
-            up = cur; cur = dn;
+
+    Px<T> up = iw_combine<T, FUSE>(iw_loadRaw<T, FUSE>(A, vO, va, zO, za, xok, x, yb - 1), beta);
+    Px<T> cur = iw_combine<T, FUSE>(iw_loadRaw<T, FUSE>(A, vO, va, zO, za, xok, x, yb), beta);
+    if (FUSE && writer && yb < ye) {
+        const long i = (long)yb * A.W + x;
+        st2<kNT>(nO, i, cur.ox, cur.oy); st1<kNT>(na, i, cur.a);
+        if (yb - 1 >= 0 && yb == A.yBegin) { const long j = i - A.W; st2<kNT>(nO, j, up.ox, up.oy); st1<kNT>(na, j, up.a); }   // ghost row above (slab mode)
+    }
+    // one row: `rdn` holds the raw loads of row y+1 (issued one iteration earlier)
+    auto row = [&](int y, const Raw<T, FUSE>& rdn) {
+        const Px<T> dn = iw_combine<T, FUSE>(rdn, beta);
+        const long i = (long)y * A.W + x;
+        if (FUSE && writer && y + 1 < A.H && (y + 1 < ye || y + 1 == A.yEnd)) { const long j = i + A.W; st2<kNT>(nO, j, dn.ox, dn.oy); st1<kNT>(na, j, dn.a); }
+        const Px<T> lf = dppShiftPx<true>(cur), rt = dppShiftPx<false>(cur);
+        T ax = 0, ay = 0, aa = 0;
+        iw_pair(cur, rt, ax, ay, aa);
+        iw_pair(cur, lf, ax, ay, aa);
+        iw_pair(cur, dn, ax, ay, aa);
+        iw_pair(cur, up, ax, ay, aa);
+        T rx = w2 * ax, ry = w2 * ay, ra = w2 * aa;
+        const bool fit = (cur.f & kFit) != 0;
+        rx += fit ? wf2 * cur.ox : T(0); ry += fit ? wf2 * cur.oy : T(0);
+        if (LM) {
+            const long ic = writer ? i : 0;
+            const V2<T> cO = ((const V2<T>*)CtC)[ic];
+            rx += cO.x * cur.ox; ry += cO.y * cur.oy; ra += CtC[2 * N + ic] * cur.a;
+        }
+        const bool act = (cur.f & kActive) != 0;       // excluded / non-existent centre: row of J^T J is 0 (solver.t:424)
+        rx = act ? rx : T(0); ry = act ? ry : T(0); ra = act ? ra : T(0);
+        if (writer) {
+            acc += (double)(cur.ox * rx + cur.oy * ry + cur.a * ra);
+            st2<kNT>(outO, i, rx, ry); st1<kNT>(outA, i, ra);
+        }
+        up = cur; cur = dn;
+    };
+    Raw<T, FUSE> rA = iw_loadRaw<T, FUSE>(A, vO, va, zO, za, xok, x, yb + 1), rB;
+    for (int y = yb; y < ye; y += 2) {
+        rB = iw_loadRaw<T, FUSE>(A, vO, va, zO, za, xok, x, y + 2);
+        row(y, rA);
+        if (y + 1 < ye) {
+            rA = iw_loadRaw<T, FUSE>(A, vO, va, zO, za, xok, x, y + 3);
+            row(y + 1, rB);
         }
     }
     double t = blockReduceSum(acc, scratch);
@@ -322,22 +423,48 @@ struct ImageWarpingOps : EnergyOps<T> {
         { ScopedKernel k(ctx, "cosSinTable"); iw_cossin<T><<<g, kBlock, 0, ctx.stream>>>(A); }
         { ScopedKernel k(ctx, "PCGInit1"); iw_evalJTF<T><<<g, kBlock, 0, ctx.stream>>>(A, r, diag); }
     }
-    void applyJTJ(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) override {
-        // co-resident grid: column strips x row groups, rows split evenly (see header comment)
-        const int gx = divUp(A.W, kBlock);
+    int occ[2][2] = {{0, 0}, {0, 0}};
+    int blocksPerCU(bool lmv, bool fused) {
+        int& o = occ[lmv][fused];
+        if (o == 0) {
+            const void* fn = lmv ? (fused ? (const void*)iw_applyJTJ<T, true, true> : (const void*)iw_applyJTJ<T, true, false>)
+                                 : (fused ? (const void*)iw_applyJTJ<T, false, true> : (const void*)iw_applyJTJ<T, false, false>);
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, fn, kBlock, 0));
+            o = std::max(1, std::min(o, 8));
+        }
+        return o;
+    }
+    void launchApply(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx, const FuseArgs<T>* fuse) {
+        // co-resident grid: column strips x row groups sized from the kernel's real occupancy, rows split
+        // evenly, so every workgroup is resident at once and all finish together (see header comment)
+        const int gx = divUp(A.W, kStrip);
         const int rows = A.yEnd - A.yBegin;
-        const int target = cus * 6;
+        const int target = cus * blocksPerCU(CtC != nullptr, fuse != nullptr);
         int gy = std::max(1, std::min(std::min(rows, target / gx), kMaxPartials / gx));
         const int rowsPerGroup = divUp(rows, gy);
         gy = divUp(rows, rowsPerGroup);
         {
-            ScopedKernel k(ctx, "PCGStep1");
+            ScopedKernel k(ctx, fuse ? "PCGStep3+PCGStep1" : "PCGStep1");
             dim3 grid(gx, gy);
-            if (CtC) iw_applyJTJ<T, true><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, CtC, dot ? dot->partials : nullptr, rowsPerGroup);
-            else iw_applyJTJ<T, false><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, dot ? dot->partials : nullptr, rowsPerGroup);
+            double* part = dot ? dot->partials : nullptr;
+            FuseArgs<T> F = fuse ? *fuse : FuseArgs<T>{};
+            if (fuse) {
+                if (CtC) iw_applyJTJ<T, true, true><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, CtC, part, rowsPerGroup, F);
+                else iw_applyJTJ<T, false, true><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, part, rowsPerGroup, F);
+            } else {
+                if (CtC) iw_applyJTJ<T, true, false><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, CtC, part, rowsPerGroup, F);
+                else iw_applyJTJ<T, false, false><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, part, rowsPerGroup, F);
+            }
             if (dot) dot->n = gx * gy;
         }
         if (this->slab.active) iw_zeroGhost<T><<<divUp(A.W, kBlock), kBlock, 0, ctx.stream>>>(A, out);
+    }
+    void applyJTJ(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) override { launchApply(v, out, CtC, dot, ctx, nullptr); }
+    bool applyJTJFused(const T* pOld, const T* z, T* pNew, T* out, const T* CtC, Reduction* dot, const Reduction& bNum, const double* aNumOld,
+                       double* aNumNext, LaunchCtx& ctx) override {
+        FuseArgs<T> F{z, pNew, bNum.partials, bNum.n, aNumOld, aNumNext};
+        launchApply(pOld, out, CtC, dot, ctx, &F);
+        return true;
     }
     void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {
         ScopedKernel k(ctx, "computeModelCost");

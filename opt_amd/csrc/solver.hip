@@ -23,8 +23,28 @@ template <class T> struct Pack;
 template <> struct alignas(16) Pack<float> { float v[4]; };
 template <> struct alignas(16) Pack<double> { double v[2]; };
 template <class T> struct PackN;
-template <> struct PackN<float> { static constexpr int N = 4; };
-template <> struct PackN<double> { static constexpr int N = 2; };
+template <> struct PackN<float> { static constexpr int N = 4; typedef float vec __attribute__((ext_vector_type(4))); };
+template <> struct PackN<double> { static constexpr int N = 2; typedef double vec __attribute__((ext_vector_type(2))); };
+
+// Streaming (non-temporal) 16-byte accesses: every PCG vector is far larger than L2 + Infinity Cache and is
+// touched once per kernel, so the hot streaming kernels ask the memory system not to retain the lines.
+// Measured on MI355X (tools/microbench_stream.hip, PCGStep2 shape at 4096^2): plain 302 us, nt + 2 packs in
+// flight per lane 270 us.
+template <class T> __device__ __forceinline__ Pack<T> ldnt(const T* base, long i) {
+    typedef typename PackN<T>::vec V;
+    const V v = __builtin_nontemporal_load((const V*)base + i);
+    Pack<T> p;
+#pragma unroll
+    for (int k = 0; k < PackN<T>::N; ++k) p.v[k] = v[k];
+    return p;
+}
+template <class T> __device__ __forceinline__ void stnt(T* base, long i, const Pack<T>& p) {
+    typedef typename PackN<T>::vec V;
+    V v;
+#pragma unroll
+    for (int k = 0; k < PackN<T>::N; ++k) v[k] = p.v[k];
+    __builtin_nontemporal_store(v, (V*)base + i);
+}
 
 template <class T> __device__ __forceinline__ T guardedInvert(T x) {   // solver.t:323-332 (CERES)
     T s = T(1) + sqrt(x);
@@ -75,21 +95,36 @@ __global__ __launch_bounds__(kBlock) void k_step2(T* __restrict__ delta, const T
     const T aNum = (T)aNumTotal[0];
     const T alpha = (aDen > T(0)) ? aNum / aDen : T(0);   // guardDivisionByZero, solver.t:456-459
     double accB = 0, accQ = 0;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nPacks; i += (long)gridDim.x * blockDim.x) {
-        Pack<T> D = ((Pack<T>*)delta)[i], P = ((const Pack<T>*)p)[i], R = ((Pack<T>*)r)[i], A = ((const Pack<T>*)Ap)[i], M, B, Z;
-        if (pre) M = ((const Pack<T>*)pre)[i];
-        if (LM) B = ((const Pack<T>*)b)[i];
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x; i0 < nPacks; i0 += 2 * stride) {
+        // two packs per lane in flight: issue all loads of both before the first use
+        Pack<T> D[2], P[2], R[2], A[2], M[2], B[2], Z;
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            T dl = D.v[k] + alpha * P.v[k];
-            T rr = R.v[k] - alpha * A.v[k];
-            T m = pre ? M.v[k] : T(1);
-            T zz = m * rr;
-            D.v[k] = dl; R.v[k] = rr; Z.v[k] = zz;
-            accB += (double)(zz * rr);
-            if (LM) accQ += (double)(T(0.5) * (dl * (rr + B.v[k])));
+        for (int u = 0; u < 2; ++u) {
+            const long i = i0 + u * stride;
+            if (i < nPacks) {
+                D[u] = ldnt(delta, i); P[u] = ldnt(p, i); R[u] = ldnt(r, i); A[u] = ldnt(Ap, i);
+                if (pre) M[u] = ldnt(pre, i);
+                if (LM) B[u] = ldnt(b, i);
+            }
         }
-        ((Pack<T>*)delta)[i] = D; ((Pack<T>*)r)[i] = R; ((Pack<T>*)z)[i] = Z;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long i = i0 + u * stride;
+            if (i < nPacks) {
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    T dl = D[u].v[k] + alpha * P[u].v[k];
+                    T rr = R[u].v[k] - alpha * A[u].v[k];
+                    T m = pre ? M[u].v[k] : T(1);
+                    T zz = m * rr;
+                    D[u].v[k] = dl; R[u].v[k] = rr; Z.v[k] = zz;
+                    accB += (double)(zz * rr);
+                    if (LM) accQ += (double)(T(0.5) * (dl * (rr + B[u].v[k])));
+                }
+                stnt(delta, i, D[u]); stnt(r, i, R[u]); stnt(z, i, Z);
+            }
+        }
     }
     double t = blockReduceSum(accB, scratch);
     if (threadIdx.x == 0) bNumPartials[blockIdx.x] = t;
@@ -218,6 +253,9 @@ struct PcgSolver : SolverBase {
     // PlanData vectors (solver.t:173-185); LM-only ones are allocated for LM plans only; `g` is never used by the reference
     T *delta = nullptr, *r = nullptr, *b = nullptr, *Adelta = nullptr, *z = nullptr, *p = nullptr, *Ap_X = nullptr, *CtC = nullptr, *preconditioner = nullptr,
       *SSq = nullptr, *prevX = nullptr;
+    T* p2 = nullptr;                    // second search-direction buffer for the fused PCGStep3+PCGStep1 kernel
+    bool fuseStep3 = true;              // OPT_AMD_FUSE=0 disables (A/B switch)
+    bool keepReferenceP = false;        // run the (dead) last PCGStep3 so that `p` matches the reference after a step
     std::vector<void*> allocs;
     Reduction redA, redB, redQ, redC;   // alpha denominator, beta numerator, q, cost / init numerator
     double* scal = nullptr;             // device: [0],[1] alphaNumerator ping-pong, [2..5] slab totals
@@ -247,6 +285,8 @@ struct PcgSolver : SolverBase {
         streamGrid = (int)std::max<long>(1, std::min<long>(want, std::min<long>(kMaxPartials, (long)cus * 8)));
         delta = allocVec(); r = allocVec(); z = allocVec(); p = allocVec(); Ap_X = allocVec(); CtC = allocVec(); preconditioner = allocVec();
         if (lm) { b = allocVec(); Adelta = allocVec(); SSq = allocVec(); prevX = allocVec(); }
+        p2 = allocVec();
+        if (const char* e = getenv("OPT_AMD_FUSE")) fuseStep3 = atoi(e) != 0;
         redA = allocRed(); redB = allocRed(); redQ = allocRed(); redC = allocRed();
         HIP_CHECK(hipMalloc((void**)&scal, 8 * sizeof(double))); HIP_CHECK(hipMemset(scal, 0, 8 * sizeof(double))); allocs.push_back(scal);
         HIP_CHECK(hipHostMalloc((void**)&hostBuf, kMaxPartials * sizeof(double)));
@@ -324,7 +364,8 @@ struct PcgSolver : SolverBase {
     }
     void record(int lIter, const Reduction& aDenR, const Reduction& bNumR, double q) {
         if (!traceEnabled) return;
-        double aDen = hostSum(aDenR), bNum = hostSum(bNumR), aNum = 0;
+        double aDen = hostSum(aDenR), bNum = distributed ? 0.0 : hostSum(bNumR), aNum = 0;
+        if (distributed) { HIP_CHECK(hipMemcpyAsync(hostBuf, bNumR.partials, sizeof(double), hipMemcpyDeviceToHost, stream)); HIP_CHECK(hipStreamSynchronize(stream)); bNum = hostBuf[0]; }
         HIP_CHECK(hipMemcpyAsync(hostBuf, scal + aSlot, sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         aNum = hostBuf[0];
@@ -379,9 +420,30 @@ struct PcgSolver : SolverBase {
         }
         finalizeTo(redC, scal + aSlot);   // alphaNumerator = sum r.p
 
+        // Loop structure: the reference runs Step1, Step2, Step3 per iteration (:1056-1103).  Here Step3 of
+        // iteration k is fused into Step1 of iteration k+1 when the energy offers that kernel (it only
+        // feeds the next Step1; after the last iteration p is dead).
+        bool pendingStep3 = false;
+        Reduction bNum;
         for (int lIter = 0; lIter < sp.lIterations; ++lIter) {
-            exchangeVector(p);
-            E->applyJTJ(p, Ap_X, lm ? CtC : nullptr, &redA, ctx);        // PCGStep1 (+_Graph)
+            bool applied = false;
+            if (pendingStep3) {
+                if (fuseStep3) {
+                    exchangeVector(z);
+                    applied = E->applyJTJFused(p, z, p2, Ap_X, lm ? CtC : nullptr, &redA, bNum, scal + aSlot, scal + (aSlot ^ 1), ctx);
+                    if (applied) std::swap(p, p2);
+                }
+                if (!applied) {
+                    ScopedKernel k(ctx, "PCGStep3");
+                    k_step3<T><<<streamGrid, kBlock, 0, stream>>>(z, p, nPacks, bNum.partials, bNum.n, scal + aSlot, scal + (aSlot ^ 1));
+                }
+                aSlot ^= 1;   // alphaNumerator <- betaNumerator (solver.t:1091)
+                pendingStep3 = false;
+            }
+            if (!applied) {
+                exchangeVector(p);
+                E->applyJTJ(p, Ap_X, lm ? CtC : nullptr, &redA, ctx);    // PCGStep1 (+_Graph)
+            }
             Reduction aDen = forConsumers(redA, 0);
             const bool reset = lm && ((lIter + 1) % sp.residual_reset_period) == 0;
             if (reset) {   // solver.t:1077-1083
@@ -397,21 +459,22 @@ struct PcgSolver : SolverBase {
                 else k_step2<T, false><<<streamGrid, kBlock, 0, stream>>>(delta, p, r, Ap_X, preArg, nullptr, z, nPacks, scal + aSlot, aDen.partials, aDen.n, redB.partials, nullptr);
                 redB.n = streamGrid; redQ.n = streamGrid;
             }
-            Reduction bNum = forConsumers(redB, 1);
-            {
-                ScopedKernel k(ctx, "PCGStep3");
-                k_step3<T><<<streamGrid, kBlock, 0, stream>>>(z, p, nPacks, bNum.partials, bNum.n, scal + aSlot, scal + (aSlot ^ 1));
-            }
+            bNum = forConsumers(redB, 1);
+            pendingStep3 = true;   // PCGStep3 of this iteration runs with the next PCGStep1
             double qh = 0;
             if (lm) { qh = hostSum(redQ); }
             if (traceEnabled) record(lIter, aDen, bNum, qh);
-            aSlot ^= 1;   // alphaNumerator <- betaNumerator (solver.t:1091)
             if (lm) {   // solver.t:1093-1102
                 Q1 = (T)qh;
                 T zeta = T(lIter + 1) * (Q1 - Q0) / Q1;
                 if (zeta < q_tolerance) { if (verbosity > 0) printf("zeta=%.18g, breaking at iteration: %d\n", (double)zeta, lIter + 1); break; }
                 Q0 = Q1;
             }
+        }
+        if (pendingStep3 && keepReferenceP) {   // the reference's final PCGStep3 only matters to someone probing `p`
+            ScopedKernel k(ctx, "PCGStep3");
+            k_step3<T><<<streamGrid, kBlock, 0, stream>>>(z, p, nPacks, bNum.partials, bNum.n, scal + aSlot, scal + (aSlot ^ 1));
+            aSlot ^= 1;
         }
 
         T model_cost_change = 0;
