@@ -1,0 +1,244 @@
+// poisson_image_editing (gradient-domain blend) and laplacian (the reference's tests/minimal energy):
+// linear 4-neighbour / 2-neighbour stencils over one unknown image.
+//
+// Energies restated (reference examples/poisson_image_editing/poisson_image_editing.t:1-13 and
+// tests/minimal/laplacian.t:1-7):
+//   poisson  : X float4 unknown, T float4, M mask.  r[c,n,k] = InBounds(c+n) * [(X_c - X_n) - (T_c - T_n)]_k for the 4
+//              neighbours; UsePreconditioner(false); Exclude(M != 0).  Every in-bounds edge appears twice in J^T J
+//              (the residual centred at c and the one centred at the neighbour, the latter also when the
+//              neighbour is excluded -- SURVEY.md 8a "exclude" row), so
+//                 J^T F (c) = 2 sum_n [(X_c - X_n) - (T_c - T_n)],  diag = 2 #n,  (J^T J p)(c) = 2 sum_n (p_c - p_n).
+//   laplacian: X float unknown, A float.  r = { 0.2 (X - A), X(0,0) - X(1,0), X(0,0) - X(0,1) }; a residual that
+//              leaves the image is 0 (o.t:1930-1933); no Exclude, no preconditioner.
+// Both are HBM-bound streaming stencils (poisson: 36 B/pixel algorithmic in applyJTJ).  Kernels are
+// one-thread-per-pixel with direct neighbour loads: rows are W*16 B (poisson) so the +-1 row re-reads come from
+// L2; these energies are not the headline workload and keep the simple shape.
+#include "energy.h"
+
+namespace optamd {
+namespace {
+
+struct F4 { float x, y, z, w; };
+template <class T> struct V4 { T x, y, z, w; };
+template <class T> __device__ __forceinline__ V4<T> operator-(const V4<T>& a, const V4<T>& b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+template <class T> __device__ __forceinline__ V4<T> operator+(const V4<T>& a, const V4<T>& b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+template <class T> __device__ __forceinline__ V4<T> operator*(T s, const V4<T>& a) { return {s * a.x, s * a.y, s * a.z, s * a.w}; }
+template <class T> __device__ __forceinline__ T dot4(const V4<T>& a, const V4<T>& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+template <class T>
+struct PArgs {
+    int W, H;
+    const T* X; const T* Tg; const T* M;
+};
+
+__device__ __forceinline__ int flatGridLoopBegin() { return blockIdx.x * blockDim.x + threadIdx.x; }
+
+// mode 0: cost partials ; mode 1: model cost partials (needs delta)
+template <class T, int MODE>
+__global__ __launch_bounds__(kBlock) void poisson_cost(PArgs<T> A, const T* __restrict__ delta, double* __restrict__ partials) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    const long N = (long)A.W * A.H;
+    const V4<T>* X = (const V4<T>*)A.X; const V4<T>* Tg = (const V4<T>*)A.Tg; const V4<T>* D = (const V4<T>*)delta;
+    double acc = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+        if (A.M[i] != T(0)) continue;   // residuals centred on excluded pixels are not part of the cost (solver.t:583)
+        const int x = (int)(i % A.W), y = (int)(i / A.W);
+        const V4<T> xc = X[i], tc = Tg[i];
+        V4<T> dc{0, 0, 0, 0}; if (MODE == 1) dc = D[i];
+        T e = 0;
+        const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int nx = x + dx[n], ny = y + dy[n];
+            if (nx < 0 || nx >= A.W || ny < 0 || ny >= A.H) continue;
+            const long ni = (long)ny * A.W + nx;
+            V4<T> r = (xc - X[ni]) - (tc - Tg[ni]);
+            if (MODE == 1) r = r + (dc - D[ni]);
+            e += dot4(r, r);
+        }
+        acc += (double)(T(0.5) * e);
+    }
+    double t = blockReduceSum(acc, scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void poisson_evalJTF(PArgs<T> A, T* __restrict__ r, T* __restrict__ diag) {
+    const long N = (long)A.W * A.H;
+    const V4<T>* X = (const V4<T>*)A.X; const V4<T>* Tg = (const V4<T>*)A.Tg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+        V4<T> F{0, 0, 0, 0}; T P = 0;
+        if (A.M[i] == T(0)) {
+            const int x = (int)(i % A.W), y = (int)(i / A.W);
+            const V4<T> xc = X[i], tc = Tg[i];
+            const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int nx = x + dx[n], ny = y + dy[n];
+                if (nx < 0 || nx >= A.W || ny < 0 || ny >= A.H) continue;
+                const long ni = (long)ny * A.W + nx;
+                const V4<T> e = (xc - X[ni]) - (tc - Tg[ni]);
+                F = F + (e + e);      // own residual (+1 * e) and the neighbour-centred one (-1 * -e)
+                P += T(2);
+            }
+        }
+        ((V4<T>*)r)[i] = V4<T>{-F.x, -F.y, -F.z, -F.w};
+        ((V4<T>*)diag)[i] = V4<T>{P, P, P, P};
+    }
+}
+
+template <class T, bool LM>
+__global__ __launch_bounds__(kBlock) void poisson_applyJTJ(PArgs<T> A, const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ CtC, double* __restrict__ partials) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    const long N = (long)A.W * A.H;
+    const V4<T>* P = (const V4<T>*)v;
+    double acc = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+        V4<T> o{0, 0, 0, 0};
+        if (A.M[i] == T(0)) {
+            const int x = (int)(i % A.W), y = (int)(i / A.W);
+            const V4<T> pc = P[i];
+            const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int nx = x + dx[n], ny = y + dy[n];
+                if (nx < 0 || nx >= A.W || ny < 0 || ny >= A.H) continue;
+                const V4<T> d = pc - P[(long)ny * A.W + nx];   // p is 0 on excluded neighbours
+                o = o + (d + d);
+            }
+            if (LM) { const V4<T> c = ((const V4<T>*)CtC)[i]; o = o + V4<T>{c.x * pc.x, c.y * pc.y, c.z * pc.z, c.w * pc.w}; }
+            acc += (double)dot4(pc, o);
+        }
+        ((V4<T>*)out)[i] = o;
+    }
+    double t = blockReduceSum(acc, scratch);
+    if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
+}
+
+template <class T>
+struct PoissonOps : EnergyOps<T> {
+    PArgs<T> A{};
+    int cus = 256;
+    PoissonOps(const unsigned* dims) {
+        A.W = (int)dims[0]; A.H = (int)dims[1];
+        this->usePreconditioner = false;                       // poisson_image_editing.t:5
+        this->addUnknown(0, (long)A.W * A.H, 4);
+        int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    int grid() const { return (int)std::max<long>(1, std::min<long>(((long)A.W * A.H + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
+    void bind(void** p, LaunchCtx&) override { A.X = (const T*)p[0]; A.Tg = (const T*)p[1]; A.M = (const T*)p[2]; }
+    T* unknownPtr(int) const override { return const_cast<T*>(A.X); }
+    void evalCost(Reduction& out, LaunchCtx& ctx) override { ScopedKernel k(ctx, "computeCost"); poisson_cost<T, 0><<<grid(), kBlock, 0, ctx.stream>>>(A, nullptr, out.partials); out.n = grid(); }
+    void evalJTF(T* r, T* diag, LaunchCtx& ctx) override { ScopedKernel k(ctx, "PCGInit1"); poisson_evalJTF<T><<<grid(), kBlock, 0, ctx.stream>>>(A, r, diag); }
+    void applyJTJ(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) override {
+        ScopedKernel k(ctx, "PCGStep1");
+        if (CtC) poisson_applyJTJ<T, true><<<grid(), kBlock, 0, ctx.stream>>>(A, v, out, CtC, dot ? dot->partials : nullptr);
+        else poisson_applyJTJ<T, false><<<grid(), kBlock, 0, ctx.stream>>>(A, v, out, nullptr, dot ? dot->partials : nullptr);
+        if (dot) dot->n = grid();
+    }
+    void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {
+        ScopedKernel k(ctx, "computeModelCost"); poisson_cost<T, 1><<<grid(), kBlock, 0, ctx.stream>>>(A, delta, out.partials); out.n = grid();
+    }
+};
+
+// ---- laplacian (tests/minimal, tests/create_delete_cycle): float only --------------------------------------------
+struct LArgs { int W, H; const float* X; const float* Aim; };
+
+template <int MODE>   // 0 cost, 1 model cost
+__global__ __launch_bounds__(kBlock) void lap_cost(LArgs A, const float* __restrict__ delta, double* __restrict__ partials) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    const long N = (long)A.W * A.H;
+    double acc = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % A.W), y = (int)(i / A.W);
+        const float xc = A.X[i], dc = MODE ? delta[i] : 0.f;
+        float f = 0.2f * (xc - A.Aim[i]) + (MODE ? 0.2f * dc : 0.f);
+        float e = f * f;
+        if (x + 1 < A.W) { float r = xc - A.X[i + 1]; if (MODE) r += dc - delta[i + 1]; e += r * r; }
+        if (y + 1 < A.H) { float r = xc - A.X[i + A.W]; if (MODE) r += dc - delta[i + A.W]; e += r * r; }
+        acc += (double)(0.5f * e);
+    }
+    double t = blockReduceSum(acc, scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(kBlock) void lap_evalJTF(LArgs A, float* __restrict__ r, float* __restrict__ diag) {
+    const long N = (long)A.W * A.H;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % A.W), y = (int)(i / A.W);
+        const float xc = A.X[i];
+        float F = 0.2f * (0.2f * (xc - A.Aim[i])), P = 0.2f * 0.2f;
+        if (x + 1 < A.W) { F += xc - A.X[i + 1]; P += 1.f; }
+        if (x >= 1) { F -= A.X[i - 1] - xc; P += 1.f; }
+        if (y + 1 < A.H) { F += xc - A.X[i + A.W]; P += 1.f; }
+        if (y >= 1) { F -= A.X[i - A.W] - xc; P += 1.f; }
+        r[i] = -F; diag[i] = P;
+    }
+}
+template <bool LM>
+__global__ __launch_bounds__(kBlock) void lap_applyJTJ(LArgs A, const float* __restrict__ v, float* __restrict__ out, const float* __restrict__ CtC, double* __restrict__ partials) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    const long N = (long)A.W * A.H;
+    double acc = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % A.W), y = (int)(i / A.W);
+        const float pc = v[i];
+        float o = 0.2f * 0.2f * pc;
+        if (x + 1 < A.W) o += pc - v[i + 1];
+        if (x >= 1) o += pc - v[i - 1];
+        if (y + 1 < A.H) o += pc - v[i + A.W];
+        if (y >= 1) o += pc - v[i - A.W];
+        if (LM) o += CtC[i] * pc;
+        out[i] = o;
+        acc += (double)(pc * o);
+    }
+    double t = blockReduceSum(acc, scratch);
+    if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
+}
+
+struct LaplacianOps : EnergyOps<float> {
+    LArgs A{};
+    int cus = 256;
+    LaplacianOps(const unsigned* dims) {
+        A.W = (int)dims[0]; A.H = (int)dims[1];
+        this->usePreconditioner = false;                       // no UsePreconditioner call in laplacian.t (default o.t:214)
+        this->addUnknown(0, (long)A.W * A.H, 1);
+        int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    int grid() const { return (int)std::max<long>(1, std::min<long>(((long)A.W * A.H + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
+    void bind(void** p, LaunchCtx&) override { A.X = (const float*)p[0]; A.Aim = (const float*)p[1]; }
+    float* unknownPtr(int) const override { return const_cast<float*>(A.X); }
+    void evalCost(Reduction& out, LaunchCtx& ctx) override { ScopedKernel k(ctx, "computeCost"); lap_cost<0><<<grid(), kBlock, 0, ctx.stream>>>(A, nullptr, out.partials); out.n = grid(); }
+    void evalJTF(float* r, float* diag, LaunchCtx& ctx) override { ScopedKernel k(ctx, "PCGInit1"); lap_evalJTF<<<grid(), kBlock, 0, ctx.stream>>>(A, r, diag); }
+    void applyJTJ(const float* v, float* out, const float* CtC, Reduction* dot, LaunchCtx& ctx) override {
+        ScopedKernel k(ctx, "PCGStep1");
+        if (CtC) lap_applyJTJ<true><<<grid(), kBlock, 0, ctx.stream>>>(A, v, out, CtC, dot ? dot->partials : nullptr);
+        else lap_applyJTJ<false><<<grid(), kBlock, 0, ctx.stream>>>(A, v, out, nullptr, dot ? dot->partials : nullptr);
+        if (dot) dot->n = grid();
+    }
+    void evalModelCost(const float* delta, Reduction& out, LaunchCtx& ctx) override {
+        ScopedKernel k(ctx, "computeModelCost"); lap_cost<1><<<grid(), kBlock, 0, ctx.stream>>>(A, delta, out.partials); out.n = grid();
+    }
+};
+
+template <class T> EnergyOps<T>* makePoisson(const unsigned* dims) { return new PoissonOps<T>(dims); }
+EnergyOps<float>* makeLaplacian(const unsigned* dims) { return new LaplacianOps(dims); }
+EnergyOps<double>* makeLaplacianD(const unsigned*) { return nullptr; }
+
+}  // namespace
+
+EnergyInfo poissonInfo() {
+    EnergyInfo e;
+    e.name = "poisson_image_editing"; e.nDims = 2; e.usePreconditioner = false; e.floatOnly = false;
+    e.params = {{ParamDecl::kUnknown, "X", "opt_float4", 0}, {ParamDecl::kArray, "T", "opt_float4", 1}, {ParamDecl::kArray, "M", "opt_float", 2}};
+    e.makeFloat = makePoisson<float>; e.makeDouble = makePoisson<double>;
+    return e;
+}
+EnergyInfo laplacianInfo() {
+    EnergyInfo e;
+    e.name = "laplacian"; e.nDims = 2; e.usePreconditioner = false; e.floatOnly = true;
+    e.params = {{ParamDecl::kUnknown, "X", "float", 0}, {ParamDecl::kArray, "A", "float", 1}};
+    e.makeFloat = makeLaplacian; e.makeDouble = makeLaplacianD;
+    return e;
+}
+
+}  // namespace optamd

@@ -26,8 +26,12 @@ struct Opt_Plan {
 
 namespace optamd {
 EnergyInfo imageWarpingInfo();
+EnergyInfo poissonInfo();
+EnergyInfo laplacianInfo();
+EnergyInfo curveFittingInfo();
+EnergyInfo arapInfo();
 const std::vector<EnergyInfo>& energyRegistry() {
-    static std::vector<EnergyInfo> reg = {imageWarpingInfo()};
+    static std::vector<EnergyInfo> reg = {imageWarpingInfo(), poissonInfo(), laplacianInfo(), curveFittingInfo(), arapInfo()};
     return reg;
 }
 }  // namespace optamd

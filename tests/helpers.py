@@ -32,3 +32,15 @@ def hip_solver(problem, kind="gaussNewtonGPU", timing=False, verbosity=0, **para
 def device_unknowns(problem, dev_params):
     import torch
     return torch.cat([dev_params[i].reshape(-1) for i in problem.unknown_slots]).cpu().numpy()
+
+
+def active_mask(P):
+    """Boolean mask over the flat unknown vector: rows of non-excluded unknowns."""
+    if P.energy == "image_warping":
+        m = np.asarray(P.params[4]).reshape(-1) == 0
+        return np.concatenate([np.repeat(m, 2), m])
+    if P.energy == "poisson_image_editing":
+        return np.repeat(np.asarray(P.params[2]).reshape(-1) == 0, 4)
+    if P.energy == "shape_from_shading":
+        return np.asarray(P.params[17]).reshape(-1) > 0
+    return np.ones(flat_unknowns(P).size, dtype=bool)

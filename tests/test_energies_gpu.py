@@ -1,0 +1,130 @@
+"""GPU parity tests (-m gpu) for every registered energy other than the headline one: each stage of the HIP
+path against the CPU oracle through the C ABI, then GN and LM trajectories.  Same bar as
+test_image_warping_gpu.py: 1e-5 relative in float, 1e-12 on double costs."""
+import numpy as np
+import pytest
+
+from opt_amd import api, workloads as wl
+from helpers import active_mask, device_unknowns, flat_unknowns, hip_solver, oracle_solver, rel_err
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "poisson": lambda double: wl.poisson_image_editing(70, 45, double=double, seed=2),
+    "poisson_tiny": lambda double: wl.poisson_image_editing(5, 3, double=double, seed=4),
+    "laplacian": lambda double: wl.laplacian(67, 33, seed=1),
+    "curveFitting": lambda double: wl.curve_fitting(200, double=double),
+    "arap": lambda double: wl.arap_mesh_deformation(23, 17, double=double, seed=3, perturb=0.01),
+    "arap_rest": lambda double: wl.arap_mesh_deformation(12, 9, double=double),
+}
+
+
+def _cases():
+    out = []
+    for name in sorted(CASES):
+        for double in (False, True):
+            if name == "laplacian" and double:
+                continue   # the energy declares fixed `float` images (tests/minimal/laplacian.t)
+            out.append(pytest.param(name, double, id=f"{name}-{'f64' if double else 'f32'}"))
+    return out
+
+
+@pytest.mark.parametrize("name,double", _cases())
+def test_cost_jtf_diag_jtjp(oracle_lib, name, double):
+    import torch
+    P = CASES[name](double)
+    tol = 1e-11 if P.double else 3e-5
+    o = oracle_solver(oracle_lib, P)
+    g = hip_solver(P)
+    dev = api.to_device(P)
+    c_ref, c_gpu = o.eval_cost(P.params), g.eval_cost(dev)
+    assert abs(c_gpu - c_ref) <= (1e-12 if P.double else 1e-5) * abs(c_ref) + 1e-30
+    f_ref, d_ref = o.eval_jtf(P.params)
+    f_gpu, d_gpu = g.eval_jtf(dev)
+    act = active_mask(P)
+    assert rel_err(f_gpu.cpu().numpy()[act], f_ref[act]) < tol
+    assert rel_err(d_gpu.cpu().numpy()[act], d_ref[act]) < tol
+    rng = np.random.default_rng(5)
+    v = (rng.standard_normal(o.n) * act).astype(o.dtype)
+    Av_ref = o.apply_jtj(P.params, v)
+    Av_gpu, dot = g.apply_jtj(dev, torch.from_numpy(v).cuda())
+    assert rel_err(Av_gpu.cpu().numpy(), Av_ref) < tol
+    assert abs(dot - float(v.astype(np.float64) @ Av_ref.astype(np.float64))) <= 10 * tol * abs(dot) + 1e-30
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("kind", ["gaussNewtonGPU", "LMGPU"])
+@pytest.mark.parametrize("name,double", _cases())
+def test_trajectory(oracle_lib, name, double, kind):
+    P = CASES[name](double)
+    kw = dict(nIterations=4, lIterations=12)
+    o = oracle_solver(oracle_lib, P, kind, **kw)
+    g = hip_solver(P, kind, **kw)
+    dev = api.to_device(P)
+    Pref = P.clone()
+    o.init(Pref.params); g.init(dev)
+    ctol = 1e-10 if P.double else 1e-5
+    xtol = 1e-9 if P.double else 2e-5
+    if name == "curveFitting" and not P.double:
+        # cos(b x) with b x ~ 600 rad loses ~4 digits in float, so libm and the device sincosf legitimately differ;
+        # the reference runs this energy in double (tests/minimal_graph_only/main.cpp:11).  Float is a smoke check.
+        ctol, xtol = 5e-3, 1e-3
+    scale = max(abs(o.cost()), 1e-300)
+    assert abs(g.cost() - o.cost()) <= ctol * scale
+    while True:
+        a, b = o.step(Pref.params), g.step(dev)
+        assert a == b
+        # costs are compared relative to the initial cost: a converged energy can be ~0 (curve fit)
+        assert abs(g.cost() - o.cost()) <= ctol * max(abs(o.cost()), 1e-7 * scale)
+        if not a:
+            break
+    assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < xtol
+    g.close(); o.close()
+
+
+def test_minimal_graph_only_known_answer():
+    """Reference tests/minimal_graph_only/main.cpp:43-61, 88-90: double precision, GN defaults,
+    unknowns (99.7, 101.6) must reach the generator parameters (100, 102)."""
+    P = wl.curve_fitting(512, double=True)
+    dev = api.to_device(P)
+    g = api.Solver(api.energy_file("curveFitting"), "gaussNewtonGPU", P.dims, double=True)
+    g.solve(dev)
+    a, b = dev[0].cpu().numpy().reshape(-1)
+    assert abs(a - 100.0) < 1e-8 and abs(b - 102.0) < 1e-8
+    assert g.cost() < 1e-10
+    g.close()
+
+
+def test_minimal_laplacian_solve():
+    """Reference tests/minimal/main.cpp: 512^2 random target, GN defaults (10 x 10); the solve must smooth the
+    image (cost falls monotonically) and leave it finite."""
+    import torch
+    P = wl.laplacian(512, 512)
+    dev = api.to_device(P)
+    g = api.Solver(api.energy_file("laplacian"), "gaussNewtonGPU", P.dims)
+    g.init(dev); costs = [g.cost()]
+    while g.step(dev):
+        costs.append(g.cost())
+    assert len(costs) == 11 and all(b <= a * (1 + 1e-6) for a, b in zip(costs, costs[1:])) and costs[-1] < 0.2 * costs[0]
+    assert torch.isfinite(dev[0]).all()
+    g.close()
+
+
+def test_create_delete_cycle():
+    """Reference tests/create_delete_cycle/main.cpp:22-31: repeated ProblemPlan / PlanFree must not leak or crash."""
+    import torch
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(200):
+        s = api.Solver(api.energy_file("laplacian"), "gaussNewtonGPU", (512, 512))
+        s.close()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 * 1024 * 1024
+
+
+def test_plan_failures_return_null():
+    with pytest.raises(RuntimeError):
+        api.Solver(api.energy_file("image_warping"), "gradientDescentGPU", (8, 8))      # o.t:122
+    with pytest.raises(RuntimeError):
+        api.Solver("/nonexistent/image_warping.t", "gaussNewtonGPU", (8, 8))
