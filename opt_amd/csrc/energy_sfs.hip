@@ -1,0 +1,264 @@
+// shape_from_shading: depth refinement under spherical-harmonics lighting (BASELINE config 3: double LM).
+//
+// Energy restated (reference examples/shape_from_shading/shape_from_shading.t:1-90), per pixel c = (i,j):
+//   ComputedArray B_I(c) = [interior(c) & D_i>0 at c,(-1,0),(0,-1)] (B(c) - I(c)),  B = SH shading of the normal built
+//                 from d0 = X(-1,0), d1 = X(0,0), d2 = X(0,-1);  I = Im/2 + (Im(-1,0) + Im(0,-1))/4            (:32-66)
+//   ComputedArray valid(c) = all five depths > 0 & four |X_c - X_nb| < 0.01 & interior                         (:82-87)
+//   E_p   = [D_i > 0] w_p (X - D_i)                                                                             (:73-74)
+//   E_g_h = [interior] w_g (B_I(0,0) - B_I(1,0)) edgeMaskR ,  E_g_v likewise with (0,1) / edgeMaskC            (:77-80)
+//   E_s   = [valid] w_s (4 P(0,0) - P(-1,0) - P(0,-1) - P(1,0) - P(0,1)),  P(u) = ((i_u-u_x)/f_x d, (j_u-u_y)/f_y d, d)  (:89-90)
+//   Exclude(D_i <= 0); no UsePreconditioner call -> false.
+// Opt re-evaluates the ComputedArrays and their per-unknown gradient images in a `precompute` kernel after
+// every update / revert (o.t:1007-1040, 2387-2409; solver.t:1005, 1116, 1155) and differentiates residuals that
+// read them through those stored gradients (o.t:913-925).  The same structure is kept here: sfs_precompute
+// writes B_I, dB_I/d{d0,d1,d2} and valid; everything else is linear algebra on those images.
+//
+// Kernel structure.  The shading rows couple a pixel with a 2-pixel neighbourhood (5 unknowns per row, 15
+// rows touching each unknown), so J^T J p is evaluated as two stencil passes instead of one wide gather:
+//   sfs_rows   : for every pixel, the 5 coupled residual rows -> q_r = r (for J^T F) or (J v)_r (for J^T J v),
+//                or directly the reduced cost / model cost;
+//   sfs_gather : out(c) = sum over the <= 16 rows that touch X_c of dr/dX_c * q_r  (+ diag, + CtC v).
+// Both are radius-1 stencils over W*H doubles; at the 1024^2 config every array involved sits in the 256 MB
+// Infinity Cache, so they are cache-bandwidth bound and kept simple.
+#include "energy.h"
+#include <cstdint>
+
+namespace optamd {
+namespace {
+
+template <class T>
+struct SArgs {
+    int W, H;
+    T w_p, w_s, w_g, f_x, f_y, u_x, u_y, L[9];
+    const T* X; const T* D_i; const T* Im; const uint8_t* mR; const uint8_t* mC;
+    T *B_I, *g0, *g1, *g2, *valid;     // ComputedArrays + gradient images
+    T* q;                              // 5 row values per pixel: [gh, gv, s0, s1, s2] planes
+};
+
+// 3-partial forward-mode scalar for the precompute kernel (the chain rule through the normalised normal)
+template <class T> struct D3 { T v, a, b, c; };
+template <class T> __device__ __forceinline__ D3<T> operator+(D3<T> x, D3<T> y) { return {x.v + y.v, x.a + y.a, x.b + y.b, x.c + y.c}; }
+template <class T> __device__ __forceinline__ D3<T> operator-(D3<T> x, D3<T> y) { return {x.v - y.v, x.a - y.a, x.b - y.b, x.c - y.c}; }
+template <class T> __device__ __forceinline__ D3<T> operator-(D3<T> x) { return {-x.v, -x.a, -x.b, -x.c}; }
+template <class T> __device__ __forceinline__ D3<T> operator*(D3<T> x, D3<T> y) { return {x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b, x.c * y.v + x.v * y.c}; }
+template <class T> __device__ __forceinline__ D3<T> operator*(T s, D3<T> x) { return {s * x.v, s * x.a, s * x.b, s * x.c}; }
+template <class T> __device__ __forceinline__ D3<T> operator*(D3<T> x, T s) { return s * x; }
+template <class T> __device__ __forceinline__ D3<T> operator/(D3<T> x, T s) { return (T(1) / s) * x; }
+template <class T> __device__ __forceinline__ D3<T> rsqrtD(D3<T> x) { const T r = T(1) / sqrt(x.v); const T k = T(-0.5) * r / x.v; return {r, k * x.a, k * x.b, k * x.c}; }
+
+template <class T> __device__ __forceinline__ bool sfs_interior(const SArgs<T>& A, int x, int y) { return x >= 1 && x <= A.W - 2 && y >= 1 && y <= A.H - 2; }
+template <class T> __device__ __forceinline__ bool sfs_dv(const SArgs<T>& A, int x, int y) { return x >= 0 && x < A.W && y >= 0 && y < A.H && A.D_i[(long)y * A.W + x] > T(0); }
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void sfs_precompute(SArgs<T> A) {
+    const long N = (long)A.W * A.H;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < N; e += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(e % A.W), y = (int)(e / A.W);
+        T bi = 0, g0 = 0, g1 = 0, g2 = 0, vl = 0;
+        if (sfs_interior(A, x, y)) {
+            if (sfs_dv(A, x - 1, y) && sfs_dv(A, x, y) && sfs_dv(A, x, y - 1)) {
+                const D3<T> d0{A.X[e - 1], 1, 0, 0}, d1{A.X[e], 0, 1, 0}, d2{A.X[e - A.W], 0, 0, 1};
+                const T i = (T)x, j = (T)y;
+                D3<T> nx = (d2 * (d1 - d0)) / A.f_y;
+                D3<T> ny = (d0 * (d1 - d2)) / A.f_x;
+                D3<T> nz = (nx * (A.u_x - i)) / A.f_x + (ny * (A.u_y - j)) / A.f_y - (d0 * d2) / (A.f_x * A.f_y);
+                const D3<T> sq = nx * nx + ny * ny + nz * nz;
+                if (sq.v > T(0)) { const D3<T> inv = rsqrtD(sq); nx = inv * nx; ny = inv * ny; nz = inv * nz; }
+                D3<T> B = A.L[1] * ny + A.L[2] * nz + A.L[3] * nx + A.L[4] * (nx * ny) + A.L[5] * (ny * nz) +
+                          A.L[6] * (-(nx * nx) - ny * ny + T(2) * (nz * nz)) + A.L[7] * (nz * nx) + A.L[8] * (nx * nx - ny * ny);
+                B.v += A.L[0];
+                const T Iv = A.Im[e] * T(0.5) + T(0.25) * (A.Im[e - 1] + A.Im[e - A.W]);
+                bi = B.v - Iv; g0 = B.a; g1 = B.b; g2 = B.c;
+            }
+            bool v = sfs_dv(A, x, y) && sfs_dv(A, x, y - 1) && sfs_dv(A, x, y + 1) && sfs_dv(A, x - 1, y) && sfs_dv(A, x + 1, y);
+            const T thr = T(0.01), xc = A.X[e];
+            v = v && fabs(xc - A.X[e - A.W]) < thr && fabs(xc - A.X[e + A.W]) < thr && fabs(xc - A.X[e - 1]) < thr && fabs(xc - A.X[e + 1]) < thr;
+            vl = v ? T(1) : T(0);
+        }
+        A.B_I[e] = bi; A.g0[e] = g0; A.g1[e] = g1; A.g2[e] = g2; A.valid[e] = vl;
+    }
+}
+
+template <class T> __device__ __forceinline__ T coefK(const SArgs<T>& A, int k, int x, int y) {
+    return k == 0 ? ((T)x - A.u_x) / A.f_x : k == 1 ? ((T)y - A.u_y) / A.f_y : T(1);
+}
+
+// MODE 0: cost partials; 1: model-cost partials (v = delta); 2: q = residual values; 3: q = J v
+template <class T, int MODE>
+__global__ __launch_bounds__(kBlock) void sfs_rows(SArgs<T> A, const T* __restrict__ v, double* __restrict__ partials) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    const long N = (long)A.W * A.H;
+    double acc = 0;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < N; e += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(e % A.W), y = (int)(e / A.W);
+        const bool in1 = sfs_interior(A, x, y);
+        const bool dvalid = A.D_i[e] > T(0);
+        T rp = 0, rgh = 0, rgv = 0, rs[3] = {0, 0, 0};       // residual values
+        T jp = 0, jgh = 0, jgv = 0, js[3] = {0, 0, 0};       // (J v) per row
+        const bool needR = MODE != 3, needJ = MODE == 1 || MODE == 3;
+        if (dvalid) { if (needR) rp = A.w_p * (A.X[e] - A.D_i[e]); if (needJ) jp = A.w_p * v[e]; }
+        if (in1) {
+            const long er = e + 1, ed = e + A.W;
+            const T mr = (T)A.mR[e], mc = (T)A.mC[e];
+            if (needR) { rgh = A.w_g * ((A.B_I[e] - A.B_I[er]) * mr); rgv = A.w_g * ((A.B_I[e] - A.B_I[ed]) * mc); }
+            if (needJ) {
+                const T base = A.g1[e] * v[e] + A.g0[e] * v[e - 1] + A.g2[e] * v[e - A.W];          // d B_I(c) . v
+                const T right = A.g1[er] * v[er] + A.g0[er] * v[e] + A.g2[er] * v[er - A.W];         // d B_I(c+ex) . v
+                const T down = A.g1[ed] * v[ed] + A.g0[ed] * v[ed - 1] + A.g2[ed] * v[e];            // d B_I(c+ey) . v
+                jgh = A.w_g * mr * (base - right); jgv = A.w_g * mc * (base - down);
+            }
+            if (A.valid[e] == T(1)) {
+                const long nb[5] = {e, e - 1, e - A.W, e + 1, e + A.W};
+                const int ox[5] = {0, -1, 0, 1, 0}, oy[5] = {0, 0, -1, 0, 1};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    T sr = 0, sj = 0;
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) {
+                        const T cf = (u == 0 ? T(4) : T(-1)) * coefK(A, k, x + ox[u], y + oy[u]);
+                        if (needR) sr += cf * A.X[nb[u]];
+                        if (needJ) sj += cf * v[nb[u]];
+                    }
+                    rs[k] = A.w_s * sr; js[k] = A.w_s * sj;
+                }
+            }
+        }
+        if (MODE == 0 || MODE == 1) {
+            if (dvalid) {   // rows centred on excluded pixels are not part of the cost (solver.t:583, 669)
+                const T a = rp + jp, b = rgh + jgh, c = rgv + jgv, d0 = rs[0] + js[0], d1 = rs[1] + js[1], d2 = rs[2] + js[2];
+                acc += (double)(T(0.5) * (a * a + b * b + c * c + d0 * d0 + d1 * d1 + d2 * d2));
+            }
+        } else {
+            const bool J = MODE == 3;
+            A.q[e] = J ? jgh : rgh; A.q[N + e] = J ? jgv : rgv;
+            A.q[2 * N + e] = J ? js[0] : rs[0]; A.q[3 * N + e] = J ? js[1] : rs[1]; A.q[4 * N + e] = J ? js[2] : rs[2];
+        }
+    }
+    if (MODE == 0 || MODE == 1) {
+        double t = blockReduceSum(acc, scratch);
+        if (threadIdx.x == 0) partials[blockIdx.x] = t;
+    }
+}
+
+// out(c) = sum_rows dr/dX_c * q_r.  JTF: out = -(...) and diag = sum (dr/dX_c)^2;  JTJ: out = ... (+ CtC v), dot partials.
+template <class T, bool JTF, bool LM>
+__global__ __launch_bounds__(kBlock) void sfs_gather(SArgs<T> A, const T* __restrict__ v, T* __restrict__ out, T* __restrict__ diag, const T* __restrict__ CtC,
+                                                     double* __restrict__ partials) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    const long N = (long)A.W * A.H;
+    const T* qgh = A.q; const T* qgv = A.q + N; const T* qs = A.q + 2 * N;
+    double acc = 0;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < N; e += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(e % A.W), y = (int)(e / A.W);
+        T s = 0, d = 0;
+        if (A.D_i[e] > T(0)) {
+            auto add = [&](T coef, T q) { s += coef * q; if (JTF) d += coef * coef; };
+            // fitting row at c (its q is recomputed: one multiply)
+            { const T q = JTF ? A.w_p * (A.X[e] - A.D_i[e]) : A.w_p * v[e]; add(A.w_p, q); }
+            // shading rows: which (row centre c', slot) pairs contain X_c -- see the header comment of sfs_rows
+            auto gh = [&](int cx, int cy, int slot) {
+                if (!sfs_interior(A, cx, cy)) return;
+                const long c = (long)cy * A.W + cx, cr = c + 1;
+                const T m = A.w_g * (T)A.mR[c];
+                const T coef = slot == 0 ? m * (A.g1[c] - A.g0[cr]) : slot == 1 ? m * A.g0[c] : slot == 2 ? m * A.g2[c] : slot == 3 ? -(m * A.g1[cr]) : -(m * A.g2[cr]);
+                add(coef, qgh[c]);
+            };
+            auto gv = [&](int cx, int cy, int slot) {
+                if (!sfs_interior(A, cx, cy)) return;
+                const long c = (long)cy * A.W + cx, cd = c + A.W;
+                const T m = A.w_g * (T)A.mC[c];
+                const T coef = slot == 0 ? m * (A.g1[c] - A.g2[cd]) : slot == 1 ? m * A.g0[c] : slot == 2 ? m * A.g2[c] : slot == 3 ? -(m * A.g1[cd]) : -(m * A.g0[cd]);
+                add(coef, qgv[c]);
+            };
+            gh(x, y, 0); gh(x + 1, y, 1); gh(x, y + 1, 2); gh(x - 1, y, 3); gh(x - 1, y + 1, 4);
+            gv(x, y, 0); gv(x + 1, y, 1); gv(x, y + 1, 2); gv(x, y - 1, 3); gv(x + 1, y - 1, 4);
+            // regularisation rows centred at c and its 4 neighbours
+            const int ox[5] = {0, 1, -1, 0, 0}, oy[5] = {0, 0, 0, 1, -1};
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int cx = x + ox[u], cy = y + oy[u];
+                if (!sfs_interior(A, cx, cy)) continue;
+                const long c = (long)cy * A.W + cx;
+                if (A.valid[c] != T(1)) continue;
+                const T wgt = A.w_s * (u == 0 ? T(4) : T(-1));
+#pragma unroll
+                for (int k = 0; k < 3; ++k) add(wgt * coefK(A, k, x, y), qs[(long)k * N + c]);
+            }
+        }
+        if (JTF) { out[e] = -s; diag[e] = d; }
+        else {
+            if (LM) s += CtC[e] * v[e];
+            if (!(A.D_i[e] > T(0))) s = 0;
+            out[e] = s;
+            acc += (double)(v[e] * s);
+        }
+    }
+    if (!JTF) {
+        double t = blockReduceSum(acc, scratch);
+        if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
+    }
+}
+
+template <class T>
+struct SfsOps : EnergyOps<T> {
+    SArgs<T> A{};
+    int cus = 256;
+    std::vector<void*> owned;
+    SfsOps(const unsigned* dims) {
+        A.W = (int)dims[0]; A.H = (int)dims[1];
+        this->usePreconditioner = false;                         // no UsePreconditioner call in the .t (default o.t:214)
+        this->addUnknown(16, (long)A.W * A.H, 1);
+        const size_t n = (size_t)A.W * A.H;
+        T** imgs[5] = {&A.B_I, &A.g0, &A.g1, &A.g2, &A.valid};
+        for (auto pp : imgs) { HIP_CHECK(hipMalloc((void**)pp, n * sizeof(T))); HIP_CHECK(hipMemset(*pp, 0, n * sizeof(T))); owned.push_back(*pp); }
+        HIP_CHECK(hipMalloc((void**)&A.q, 5 * n * sizeof(T))); owned.push_back(A.q);
+        int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    ~SfsOps() override { for (void* p : owned) (void)hipFree(p); }
+    int grid() const { return (int)std::max<long>(1, std::min<long>(((long)A.W * A.H + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
+    void bind(void** p, LaunchCtx&) override {
+        // sqrt(Param(...)) is evaluated in opt_float on the float parameter (shape_from_shading.t:4-6)
+        A.w_p = std::sqrt((T) * (const float*)p[0]); A.w_s = std::sqrt((T) * (const float*)p[1]); A.w_g = std::sqrt((T) * (const float*)p[2]);
+        A.f_x = (T) * (const float*)p[3]; A.f_y = (T) * (const float*)p[4]; A.u_x = (T) * (const float*)p[5]; A.u_y = (T) * (const float*)p[6];
+        for (int i = 0; i < 9; ++i) A.L[i] = (T) * (const float*)p[7 + i];
+        A.X = (const T*)p[16]; A.D_i = (const T*)p[17]; A.Im = (const T*)p[18]; A.mR = (const uint8_t*)p[19]; A.mC = (const uint8_t*)p[20];
+    }
+    T* unknownPtr(int) const override { return const_cast<T*>(A.X); }
+    void precompute(LaunchCtx& ctx) override { ScopedKernel k(ctx, "precompute"); sfs_precompute<T><<<grid(), kBlock, 0, ctx.stream>>>(A); }
+    void evalCost(Reduction& out, LaunchCtx& ctx) override { ScopedKernel k(ctx, "computeCost"); sfs_rows<T, 0><<<grid(), kBlock, 0, ctx.stream>>>(A, nullptr, out.partials); out.n = grid(); }
+    void evalJTF(T* r, T* diag, LaunchCtx& ctx) override {
+        { ScopedKernel k(ctx, "PCGInit1_rows"); sfs_rows<T, 2><<<grid(), kBlock, 0, ctx.stream>>>(A, nullptr, nullptr); }
+        { ScopedKernel k(ctx, "PCGInit1"); sfs_gather<T, true, false><<<grid(), kBlock, 0, ctx.stream>>>(A, nullptr, r, diag, nullptr, nullptr); }
+    }
+    void applyJTJ(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) override {
+        { ScopedKernel k(ctx, "PCGStep1_rows"); sfs_rows<T, 3><<<grid(), kBlock, 0, ctx.stream>>>(A, v, nullptr); }
+        { ScopedKernel k(ctx, "PCGStep1");
+          if (CtC) sfs_gather<T, false, true><<<grid(), kBlock, 0, ctx.stream>>>(A, v, out, nullptr, CtC, dot ? dot->partials : nullptr);
+          else sfs_gather<T, false, false><<<grid(), kBlock, 0, ctx.stream>>>(A, v, out, nullptr, nullptr, dot ? dot->partials : nullptr); }
+        if (dot) dot->n = grid();
+    }
+    void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {
+        ScopedKernel k(ctx, "computeModelCost"); sfs_rows<T, 1><<<grid(), kBlock, 0, ctx.stream>>>(A, delta, out.partials); out.n = grid();
+    }
+};
+
+template <class T> EnergyOps<T>* makeSfs(const unsigned* dims) { return new SfsOps<T>(dims); }
+
+}  // namespace
+
+EnergyInfo sfsInfo() {
+    EnergyInfo e;
+    e.name = "shape_from_shading"; e.nDims = 2; e.usePreconditioner = false; e.floatOnly = false;
+    e.params = {{ParamDecl::kScalar, "w_p", "float", 0}, {ParamDecl::kScalar, "w_s", "float", 1}, {ParamDecl::kScalar, "w_g", "float", 2},
+                {ParamDecl::kScalar, "f_x", "float", 3}, {ParamDecl::kScalar, "f_y", "float", 4}, {ParamDecl::kScalar, "u_x", "float", 5},
+                {ParamDecl::kScalar, "u_y", "float", 6},
+                {ParamDecl::kScalar, "L_1", "float", 7}, {ParamDecl::kScalar, "L_2", "float", 8}, {ParamDecl::kScalar, "L_3", "float", 9},
+                {ParamDecl::kScalar, "L_4", "float", 10}, {ParamDecl::kScalar, "L_5", "float", 11}, {ParamDecl::kScalar, "L_6", "float", 12},
+                {ParamDecl::kScalar, "L_7", "float", 13}, {ParamDecl::kScalar, "L_8", "float", 14}, {ParamDecl::kScalar, "L_9", "float", 15},
+                {ParamDecl::kUnknown, "X", "opt_float", 16}, {ParamDecl::kArray, "D_i", "opt_float", 17}, {ParamDecl::kArray, "Im", "opt_float", 18},
+                {ParamDecl::kArray, "edgeMaskR", "uint8", 19}, {ParamDecl::kArray, "edgeMaskC", "uint8", 20}};
+    e.makeFloat = makeSfs<float>; e.makeDouble = makeSfs<double>;
+    return e;
+}
+
+}  // namespace optamd

@@ -30,8 +30,9 @@ EnergyInfo poissonInfo();
 EnergyInfo laplacianInfo();
 EnergyInfo curveFittingInfo();
 EnergyInfo arapInfo();
+EnergyInfo sfsInfo();
 const std::vector<EnergyInfo>& energyRegistry() {
-    static std::vector<EnergyInfo> reg = {imageWarpingInfo(), poissonInfo(), laplacianInfo(), curveFittingInfo(), arapInfo()};
+    static std::vector<EnergyInfo> reg = {imageWarpingInfo(), poissonInfo(), laplacianInfo(), curveFittingInfo(), arapInfo(), sfsInfo()};
     return reg;
 }
 }  // namespace optamd

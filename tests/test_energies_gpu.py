@@ -16,6 +16,8 @@ CASES = {
     "curveFitting": lambda double: wl.curve_fitting(200, double=double),
     "arap": lambda double: wl.arap_mesh_deformation(23, 17, double=double, seed=3, perturb=0.01),
     "arap_rest": lambda double: wl.arap_mesh_deformation(12, 9, double=double),
+    "sfs": lambda double: wl.shape_from_shading(40, 32, double=double, seed=6, holes=True, noise=2e-3),
+    "sfs_clean": lambda double: wl.shape_from_shading(33, 21, double=double, seed=7),
 }
 
 

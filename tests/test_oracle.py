@@ -54,6 +54,7 @@ CASES = {
     "poisson_image_editing": lambda: wl.poisson_image_editing(8, 6, double=True, seed=3),
     "arap_mesh_deformation": lambda: wl.arap_mesh_deformation(5, 4, double=True, seed=2, perturb=0.02),
     "curveFitting": lambda: wl.curve_fitting(16, double=True),
+    "shape_from_shading": lambda: wl.shape_from_shading(12, 10, double=True, seed=4, holes=True, noise=2e-3),
 }
 
 
@@ -67,9 +68,9 @@ def test_jtf_is_gradient_of_cost(oracle_lib, name):
         P.params[2][...] = 0
     s = oracle_solver(oracle_lib, P)
     f, d = s.eval_jtf(P.params)
-    g = _fd_gradient(s, P, 1e-6)
+    g = _fd_gradient(s, P, 1e-7 if name == "shape_from_shading" else 1e-6)
     act = _active_mask(P)
-    assert rel_err(f[act], g[act]) < 1e-6
+    assert rel_err(f[act], g[act]) < (1e-5 if name == "shape_from_shading" else 1e-6)
     assert np.all(d >= 0)
 
 
