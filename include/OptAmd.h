@@ -72,9 +72,11 @@ const char* OptAmd_PlanKernelName(Opt_Plan* plan, int i);
 typedef struct OptAmd_SlabComm {
     void* ctx;
     int rank, world;
-    /* exchange `bytes` bytes: send `sendUp` to rank-1 and `sendDown` to rank+1, receive into `recvUp`
-     * (from rank-1) and `recvDown` (from rank+1).  NULL-neighbour sides must be skipped by the callee. */
-    void (*haloExchange)(void* ctx, const void* sendUp, const void* sendDown, void* recvUp, void* recvDown, long bytes, void* stream);
+    /* One halo exchange of `nBuffers` row buffers (one per unknown image): for each k send bytes[k] bytes from
+     * sendUp[k] to rank-1 and from sendDown[k] to rank+1, receive into recvUp[k] (from rank-1) and recvDown[k]
+     * (from rank+1).  Sides without a neighbour (rank 0 / rank world-1) must be skipped by the callee. */
+    void (*haloExchange)(void* ctx, int nBuffers, const void* const* sendUp, const void* const* sendDown, void* const* recvUp, void* const* recvDown,
+                         const long* bytes, void* stream);
     /* in-place sum all-reduce of n doubles in device memory */
     void (*allReduceSum)(void* ctx, double* deviceBuf, int n, void* stream);
 } OptAmd_SlabComm;

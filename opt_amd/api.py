@@ -31,7 +31,8 @@ class Opt_InitializationParameters(ctypes.Structure):
                 ("collectPerKernelTimingInfo", ctypes.c_int), ("threadsPerBlock", ctypes.c_int)]
 
 
-HALO_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p)
+HALO_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                           ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_long), ctypes.c_void_p)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
 
 

@@ -47,7 +47,22 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    build_comm(force=force, verbose=verbose)
     return LIB
+
+
+COMM_LIB = os.path.join(LIBDIR, "libOptComm.so")
+
+
+def build_comm(force=False, verbose=False):
+    """libOptComm.so: the RCCL / in-process implementations of OptAmd_SlabComm (multi-GPU slab tiling)."""
+    src = os.path.join(CSRC, "comm", "opt_comm.cpp")
+    if force or not os.path.exists(COMM_LIB) or os.path.getmtime(COMM_LIB) < max(os.path.getmtime(src), _deps_mtime()):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", COMM_LIB, src, "-L/opt/rocm/lib", "-lrccl", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return COMM_LIB
 
 
 if __name__ == "__main__":

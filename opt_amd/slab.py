@@ -1,0 +1,187 @@
+"""Row-slab tiling of an image problem over the GPUs of one node (one rank per GPU).
+
+The reference is single-GPU; this is the MI355X-native extension the north star asks for:
+rank g owns rows [row0, row0+rows) of the image and passes libOpt.so arrays that hold its slab plus one ghost
+row above and below (OptAmd_PlanSetSlab, include/OptAmd.h).  Per PCG iteration the ranks exchange one image row
+per neighbour per unknown image and all-reduce two scalars; nothing else crosses GPUs.
+
+Host-side pieces (numpy only, unit-tested on CPU with gloo): SlabLayout, split_problem, merge_unknowns.
+Device-side drivers: SlabJob (RCCL, one process per GPU, used by bench.py) and run_threads (all ranks as
+threads of one process on one GPU -- the single-GPU test harness).
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+from . import api, workloads as wl
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+COMM_LIB_PATH = os.path.join(_HERE, "lib", "libOptComm.so")
+_comm = None
+
+
+class SlabLayout:
+    """Even split of H rows over `world` ranks; earlier ranks take the remainder."""
+
+    def __init__(self, W, H, rank, world):
+        if world > H:
+            raise ValueError("more ranks than image rows")
+        self.W, self.H, self.rank, self.world = W, H, rank, world
+        base, rem = divmod(H, world)
+        self.rows = base + (1 if rank < rem else 0)
+        self.row0 = rank * base + min(rank, rem)
+        self.local_H = self.rows + 2                      # + ghost row above and below
+
+    @property
+    def owned(self):
+        return slice(self.row0, self.row0 + self.rows)
+
+    def has_up(self):
+        return self.rank > 0
+
+    def has_down(self):
+        return self.rank < self.world - 1
+
+
+def _is_image(a, H, W):
+    return isinstance(a, np.ndarray) and a.ndim >= 2 and a.shape[0] == H and a.shape[1] == W
+
+
+def split_problem(problem, layout):
+    """Local copy of a global (host) workloads.Problem for one rank: every image keeps rows row0-1 .. row0+rows
+    (ghost rows outside the global image are zero-filled; for image_warping their Mask is set non-zero so they
+    are also excluded by the energy itself).  Scalars are shared."""
+    W, H = layout.W, layout.H
+    out = []
+    for idx, p in enumerate(problem.params):
+        a = np.asarray(p)
+        if not _is_image(a, H, W):
+            out.append(np.array(a, copy=True))
+            continue
+        loc = np.zeros((layout.local_H,) + a.shape[1:], dtype=a.dtype)
+        lo, hi = layout.row0 - 1, layout.row0 + layout.rows + 1
+        glo, ghi = max(lo, 0), min(hi, H)
+        loc[glo - lo: glo - lo + (ghi - glo)] = a[glo:ghi]
+        if problem.energy == "image_warping" and idx == 4:          # Mask
+            if lo < 0:
+                loc[0] = 255
+            if hi > H:
+                loc[-1] = 255
+        out.append(loc)
+    return wl.Problem(problem.energy, (W, layout.local_H), out, problem.unknown_slots, problem.double, dict(problem.meta))
+
+
+def merge_unknowns(problem, layouts, local_unknowns):
+    """Write every rank's owned rows of the unknown images back into the global problem (in place)."""
+    for lay, unk in zip(layouts, local_unknowns):
+        for slot, arr in zip(problem.unknown_slots, unk):
+            problem.params[slot][lay.owned] = np.asarray(arr)[1:1 + lay.rows]
+
+
+def comm_lib():
+    global _comm
+    if _comm is None:
+        if not os.path.exists(COMM_LIB_PATH):
+            raise RuntimeError(f"{COMM_LIB_PATH} not found: build it with `python -m opt_amd.build`")
+        L = ctypes.CDLL(COMM_LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        L.OptComm_UniqueIdBytes.restype = ci
+        L.OptComm_GetUniqueId.restype = ci; L.OptComm_GetUniqueId.argtypes = [ctypes.c_char_p]
+        L.OptComm_CreateRccl.restype = vp; L.OptComm_CreateRccl.argtypes = [ctypes.c_char_p, ci, ci]
+        L.OptComm_RcclSlabComm.restype = ctypes.POINTER(api.OptAmd_SlabComm); L.OptComm_RcclSlabComm.argtypes = [vp]
+        L.OptComm_DestroyRccl.argtypes = [vp]
+        L.OptComm_CreateThreadWorld.restype = vp; L.OptComm_CreateThreadWorld.argtypes = [ci]
+        L.OptComm_DestroyThreadWorld.argtypes = [vp]
+        L.OptComm_CreateThreadRank.restype = vp; L.OptComm_CreateThreadRank.argtypes = [vp, ci]
+        L.OptComm_ThreadSlabComm.restype = ctypes.POINTER(api.OptAmd_SlabComm); L.OptComm_ThreadSlabComm.argtypes = [vp]
+        L.OptComm_DestroyThreadRank.argtypes = [vp]
+        _comm = L
+    return _comm
+
+
+def attach_slab(solver, layout, slab_comm_ptr):
+    ok = api.lib().OptAmd_PlanSetSlab(solver.plan, layout.row0, layout.rows, layout.H, slab_comm_ptr)
+    if not ok:
+        raise RuntimeError("this energy's kernel set does not support slab tiling")
+
+
+class SlabJob:
+    """One rank of a multi-process solve (bench.py --gpus N): torch.distributed is already initialised with the
+    nccl (= RCCL) backend; the RCCL communicator used inside the solver is created here from a broadcast id."""
+
+    def __init__(self, energy, W, H, rank, world, kind="gaussNewtonGPU", double=False, problem=None):
+        import torch
+        import torch.distributed as dist
+        self.layout = SlabLayout(W, H, rank, world)
+        glob = problem if problem is not None else getattr(wl, energy)(W, H, double=double)
+        self.local = split_problem(glob, self.layout)
+        del glob
+        self.params = api.to_device(self.local)
+        L = comm_lib()
+        n = L.OptComm_UniqueIdBytes()
+        buf = ctypes.create_string_buffer(n)
+        if rank == 0:
+            assert L.OptComm_GetUniqueId(buf)
+        t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).cuda()
+        dist.broadcast(t, src=0)
+        self._id = bytes(t.cpu().numpy().tobytes())
+        self._ctx = L.OptComm_CreateRccl(self._id, rank, world)
+        self.solver = api.Solver(api.energy_file(energy), kind, (W, self.layout.local_H), double=double)
+        attach_slab(self.solver, self.layout, L.OptComm_RcclSlabComm(self._ctx))
+
+    def close(self):
+        self.solver.close()
+        comm_lib().OptComm_DestroyRccl(self._ctx)
+
+
+def run_threads(problem, world, kind="gaussNewtonGPU", solver_params=None, steps=None):
+    """Solve `problem` (host arrays, modified in place) with `world` slabs as threads of this process on the
+    current GPU.  Returns the per-step cost list of rank 0.  Test harness for single-GPU boxes."""
+    import torch
+    L = comm_lib()
+    W, H = problem.dims
+    tw = L.OptComm_CreateThreadWorld(world)
+    layouts = [SlabLayout(W, H, r, world) for r in range(world)]
+    costs = [[] for _ in range(world)]
+    results = [None] * world
+    errors = []
+    dev_index = torch.cuda.current_device()
+
+    def work(r):
+        try:
+            torch.cuda.set_device(dev_index)
+            lay = layouts[r]
+            loc = split_problem(problem, lay)
+            dev = api.to_device(loc)
+            s = api.Solver(api.energy_file(problem.energy), kind, (W, lay.local_H), double=problem.double)
+            for k, v in (solver_params or {}).items():
+                s.set_parameter(k, v)
+            ctx = L.OptComm_CreateThreadRank(tw, r)
+            attach_slab(s, lay, L.OptComm_ThreadSlabComm(ctx))
+            s.init(dev)
+            costs[r].append(s.cost())
+            n = 0
+            while s.step(dev):
+                costs[r].append(s.cost())
+                n += 1
+                if steps is not None and n >= steps:
+                    break
+            torch.cuda.synchronize()
+            results[r] = [dev[i].cpu().numpy() for i in problem.unknown_slots]
+            s.close()
+            L.OptComm_DestroyThreadRank(ctx)
+        except Exception as e:  # noqa
+            errors.append((r, e))
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    L.OptComm_DestroyThreadWorld(tw)
+    if errors:
+        raise errors[0][1]
+    merge_unknowns(problem, layouts, results)
+    return costs[0]
