@@ -138,8 +138,17 @@ def main():
         avg_ms = tot / cnt
         achieved = algo * W * H / (avg_ms * 1e-3) / 1e9
         per_iter = {k: v[1] / v[0] for k, v in kt.items()}
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate runs of this command, FETCH_SIZE doubled per MI355X_MICROARCH.md; tools/summarize_profile.py)
+        traffic, traffic_src = None, None
+        if W == 4096 and kname == "PCGStep3+PCGStep1":
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+            if cands:
+                tj = json.load(open(cands[-1]))
+                traffic, traffic_src = tj["hbm_bytes_per_launch"], os.path.basename(cands[-1])
         roofline = {"bound": "hbm", "kernel": kname + " (applyJTJ)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": avg_ms, "launches": cnt,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_ms": avg_ms, "launches": cnt,
                     "algorithmic_bytes_per_pixel": algo, "algorithmic_bytes_per_launch": algo * W * H,
                     "kernel_avg_ms": per_iter}
         ts.close()
