@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libOpt.so")
+LIB_PATH = os.environ.get("OPT_AMD_LIB") or os.path.join(_HERE, "lib", "libOpt.so")   # OPT_AMD_LIB: development A/B builds
 _lib = None
 
 OPT_SYMBOLS = ["Opt_NewState", "Opt_ProblemDefine", "Opt_ProblemDelete", "Opt_ProblemPlan", "Opt_PlanFree",

@@ -26,6 +26,25 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hs)
 
 
+def build_variant(name, defines):
+    """Development aid: build opt_amd/lib/libOpt_<name>.so with extra -D flags (select it with OPT_AMD_LIB=<path>)."""
+    objdir = os.path.join(HERE, "build_" + name)
+    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    objs, procs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        cmd = [HIPCC] + FLAGS + ["-D" + d for d in defines] + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
+        procs.append((src, subprocess.Popen(cmd)))
+    failed = [s for s, p in procs if p.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed for: " + ", ".join(failed))
+    lib = os.path.join(LIBDIR, f"libOpt_{name}.so")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)

@@ -217,7 +217,16 @@ template <bool NT, class T> __device__ __forceinline__ void st2(V2<T>* p, long i
     else p[i] = V2<T>{x, y};
 }
 template <bool NT, class T> __device__ __forceinline__ void st1(T* p, long i, T x) { if (NT) __builtin_nontemporal_store(x, p + i); else p[i] = x; }
-constexpr bool kNT = false;   // measured: nt on these 4-8 B/lane accesses costs 25% (fused 250 -> 315 us at 4096^2); 16 B/lane streams in solver.hip keep it
+// Measured at 4096^2 (same box, interleaved A/B, tools in opt_amd/build.py::build_variant): nt LOADS here are worth +4 % PCG it/s
+// (they keep this kernel's single-use streams from displacing the next kernel's inputs in L2 / Infinity Cache);
+// nt STORES on the 4-8 B/lane outputs cost 15 %; XCD-aware strip mapping (xcdMap) costs 8 %.
+#ifndef IW_NT_LOAD
+#define IW_NT_LOAD 1
+#endif
+#ifndef IW_NT_STORE
+#define IW_NT_STORE 0
+#endif
+constexpr bool kNTL = IW_NT_LOAD != 0, kNTS = IW_NT_STORE != 0;   // measured: nt on these 4-8 B/lane accesses costs 25% (fused 250 -> 315 us at 4096^2); 16 B/lane streams in solver.hip keep it
 
 template <class T, bool FUSE>
 __device__ __forceinline__ Raw<T, FUSE> iw_loadRaw(const IWArgs<T>& A, const V2<T>* __restrict__ vO, const T* __restrict__ va, const V2<T>* __restrict__ zO,
@@ -229,8 +238,8 @@ __device__ __forceinline__ Raw<T, FUSE> iw_loadRaw(const IWArgs<T>& A, const V2<
     const long i = (long)min(max(y, 0), A.H - 1) * A.W + min(max(x, 0), A.W - 1);
     const int f = A.flags[i];
     r.f = ok ? f : 0;
-    r.o = ld2<kNT>(vO, i); r.a = ld1<kNT>(va, i); r.cs = ld2<kNT>((const V2<T>*)A.cs, i); r.u = ld2<kNT>((const V2<T>*)A.UrShape, i);
-    if (FUSE) { r.zo = ld2<kNT>(zO, i); r.za = ld1<kNT>(za, i); } else { r.zo = V2<T>{0, 0}; r.za = 0; }
+    r.o = ld2<kNTL>(vO, i); r.a = ld1<kNTL>(va, i); r.cs = ld2<kNTL>((const V2<T>*)A.cs, i); r.u = ld2<kNTL>((const V2<T>*)A.UrShape, i);
+    if (FUSE) { r.zo = ld2<kNTL>(zO, i); r.za = ld1<kNTL>(za, i); } else { r.zo = V2<T>{0, 0}; r.za = 0; }
     return r;
 }
 template <class T, bool FUSE>
@@ -260,8 +269,16 @@ constexpr int kStrip = (kBlock / kWave) * kSpan;    // output pixels per workgro
 
 template <class T, bool LM, bool FUSE>
 __global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ CtC,
-                                                      double* __restrict__ partials, int rowsPerGroup, FuseArgs<T> F) {
+                                                      double* __restrict__ partials, int rowsPerGroup, int gx, int gy, int xcdMap, FuseArgs<T> F) {
     __shared__ double scratch[kBlock / kWave + 1];
+    // Workgroup -> (strip bx, row group by).  The dispatcher places workgroup b on XCD b % 8, each XCD with its own L2
+    // (MI355X_MICROARCH.md); with xcdMap the 8 XCDs take whole row groups, so the strips of one row group -- which
+    // share cache lines at their 248-pixel seams and the 2 overlap pixels -- hit the same L2 instead of fetching the
+    // seam lines from HBM twice.  Purely a locality choice: any mapping gives the same result.
+    int bx, by;
+    if (xcdMap) { const int id = blockIdx.x, xcd = id & 7, slot = id >> 3; by = (slot / gx) * 8 + xcd; bx = slot % gx; }
+    else { bx = blockIdx.x % gx; by = blockIdx.x / gx; }
+    const bool idle = by >= gy;
     const long N = (long)A.W * A.H;
     const V2<T>* vO = (const V2<T>*)v; const T* va = v + 2 * N;
     const V2<T>* zO = (const V2<T>*)F.z; const T* za = F.z + 2 * N;
@@ -272,14 +289,14 @@ __global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __re
         const double bSum = sumPartials(F.bNumPartials, F.nB, scratch);
         const T rDotzNew = (T)bSum, rDotzOld = (T)F.aNumOld[0];
         beta = (rDotzOld > T(0)) ? rDotzNew / rDotzOld : T(0);
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) F.aNumNext[0] = bSum;   // alphaNumerator <- betaNumerator (:1091)
+        if (blockIdx.x == 0 && threadIdx.x == 0) F.aNumNext[0] = bSum;   // alphaNumerator <- betaNumerator (:1091)
     }
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * kStrip + wave * kSpan + lane - 1;
+    const int x = bx * kStrip + wave * kSpan + lane - 1;
     const bool xok = x >= 0 && x < A.W;
     const bool writer = xok && lane >= 1 && lane <= kSpan;       // inner lanes own their pixel; lanes 0 / 63 are halo
-    const int yb = A.yBegin + blockIdx.y * rowsPerGroup;
-    const int ye = min(yb + rowsPerGroup, A.yEnd);
+    const int yb = idle ? A.yEnd : A.yBegin + by * rowsPerGroup;
+    const int ye = idle ? A.yEnd : min(yb + rowsPerGroup, A.yEnd);
     const T w2 = A.w_reg * A.w_reg, wf2 = A.w_fit * A.w_fit;
     double acc = 0;
 
@@ -287,14 +304,14 @@ __global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __re
     Px<T> cur = iw_combine<T, FUSE>(iw_loadRaw<T, FUSE>(A, vO, va, zO, za, xok, x, yb), beta);
     if (FUSE && writer && yb < ye) {
         const long i = (long)yb * A.W + x;
-        st2<kNT>(nO, i, cur.ox, cur.oy); st1<kNT>(na, i, cur.a);
-        if (yb - 1 >= 0 && yb == A.yBegin) { const long j = i - A.W; st2<kNT>(nO, j, up.ox, up.oy); st1<kNT>(na, j, up.a); }   // ghost row above (slab mode)
+        st2<kNTS>(nO, i, cur.ox, cur.oy); st1<kNTS>(na, i, cur.a);
+        if (yb - 1 >= 0 && yb == A.yBegin) { const long j = i - A.W; st2<kNTS>(nO, j, up.ox, up.oy); st1<kNTS>(na, j, up.a); }   // ghost row above (slab mode)
     }
     // one row: `rdn` holds the raw loads of row y+1 (issued one iteration earlier)
     auto row = [&](int y, const Raw<T, FUSE>& rdn) {
         const Px<T> dn = iw_combine<T, FUSE>(rdn, beta);
         const long i = (long)y * A.W + x;
-        if (FUSE && writer && y + 1 < A.H && (y + 1 < ye || y + 1 == A.yEnd)) { const long j = i + A.W; st2<kNT>(nO, j, dn.ox, dn.oy); st1<kNT>(na, j, dn.a); }
+        if (FUSE && writer && y + 1 < A.H && (y + 1 < ye || y + 1 == A.yEnd)) { const long j = i + A.W; st2<kNTS>(nO, j, dn.ox, dn.oy); st1<kNTS>(na, j, dn.a); }
         const Px<T> lf = dppShiftPx<true>(cur), rt = dppShiftPx<false>(cur);
         T ax = 0, ay = 0, aa = 0;
         iw_pair(cur, rt, ax, ay, aa);
@@ -313,7 +330,7 @@ __global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __re
         rx = act ? rx : T(0); ry = act ? ry : T(0); ra = act ? ra : T(0);
         if (writer) {
             acc += (double)(cur.ox * rx + cur.oy * ry + cur.a * ra);
-            st2<kNT>(outO, i, rx, ry); st1<kNT>(outA, i, ra);
+            st2<kNTS>(outO, i, rx, ry); st1<kNTS>(outA, i, ra);
         }
         up = cur; cur = dn;
     };
@@ -327,7 +344,7 @@ __global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __re
         }
     }
     double t = blockReduceSum(acc, scratch);
-    if (threadIdx.x == 0 && partials) partials[blockIdx.y * gridDim.x + blockIdx.x] = t;
+    if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
 }
 
 // ghost rows of `out` are zeroed so the flat streaming kernels see r = 0 / Ap = 0 there (energy.h contract)
@@ -399,6 +416,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         HIP_CHECK(hipMalloc((void**)&A.cs, (size_t)A.W * A.H * 2 * sizeof(T)));
         int dev = 0; HIP_CHECK(hipGetDevice(&dev));
         HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (const char* e = getenv("OPT_AMD_XCD")) xcdMap = atoi(e) != 0;
     }
     ~ImageWarpingOps() override { (void)hipFree(A.flags); (void)hipFree(A.cs); }
     int flatGrid(long n) const { return (int)std::max<long>(1, std::min<long>((n + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
@@ -423,6 +441,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         { ScopedKernel k(ctx, "cosSinTable"); iw_cossin<T><<<g, kBlock, 0, ctx.stream>>>(A); }
         { ScopedKernel k(ctx, "PCGInit1"); iw_evalJTF<T><<<g, kBlock, 0, ctx.stream>>>(A, r, diag); }
     }
+    int xcdMap = 0;                                    // OPT_AMD_XCD=0 disables the XCD-aware workgroup mapping (A/B switch)
     int occ[2][2] = {{0, 0}, {0, 0}};
     int blocksPerCU(bool lmv, bool fused) {
         int& o = occ[lmv][fused];
@@ -443,19 +462,21 @@ struct ImageWarpingOps : EnergyOps<T> {
         int gy = std::max(1, std::min(std::min(rows, target / gx), kMaxPartials / gx));
         const int rowsPerGroup = divUp(rows, gy);
         gy = divUp(rows, rowsPerGroup);
+        const int gyPad = xcdMap ? divUp(gy, 8) * 8 : gy;
+        const int nBlocks = gx * gyPad;
         {
             ScopedKernel k(ctx, fuse ? "PCGStep3+PCGStep1" : "PCGStep1");
-            dim3 grid(gx, gy);
+            const int grid = nBlocks;
             double* part = dot ? dot->partials : nullptr;
             FuseArgs<T> F = fuse ? *fuse : FuseArgs<T>{};
             if (fuse) {
-                if (CtC) iw_applyJTJ<T, true, true><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, CtC, part, rowsPerGroup, F);
-                else iw_applyJTJ<T, false, true><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, part, rowsPerGroup, F);
+                if (CtC) iw_applyJTJ<T, true, true><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, CtC, part, rowsPerGroup, gx, gy, xcdMap, F);
+                else iw_applyJTJ<T, false, true><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, part, rowsPerGroup, gx, gy, xcdMap, F);
             } else {
-                if (CtC) iw_applyJTJ<T, true, false><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, CtC, part, rowsPerGroup, F);
-                else iw_applyJTJ<T, false, false><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, part, rowsPerGroup, F);
+                if (CtC) iw_applyJTJ<T, true, false><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, CtC, part, rowsPerGroup, gx, gy, xcdMap, F);
+                else iw_applyJTJ<T, false, false><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, part, rowsPerGroup, gx, gy, xcdMap, F);
             }
-            if (dot) dot->n = gx * gy;
+            if (dot) dot->n = nBlocks;
         }
         if (this->slab.active) iw_zeroGhost<T><<<divUp(A.W, kBlock), kBlock, 0, ctx.stream>>>(A, out);
     }

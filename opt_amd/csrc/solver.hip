@@ -30,9 +30,12 @@ template <> struct PackN<double> { static constexpr int N = 2; typedef double ve
 // touched once per kernel, so the hot streaming kernels ask the memory system not to retain the lines.
 // Measured on MI355X (tools/microbench_stream.hip, PCGStep2 shape at 4096^2): plain 302 us, nt + 2 packs in
 // flight per lane 270 us.
+#ifndef S2_NT_LOAD
+#define S2_NT_LOAD 1
+#endif
 template <class T> __device__ __forceinline__ Pack<T> ldnt(const T* base, long i) {
     typedef typename PackN<T>::vec V;
-    const V v = __builtin_nontemporal_load((const V*)base + i);
+    const V v = S2_NT_LOAD ? __builtin_nontemporal_load((const V*)base + i) : ((const V*)base)[i];
     Pack<T> p;
 #pragma unroll
     for (int k = 0; k < PackN<T>::N; ++k) p.v[k] = v[k];
@@ -49,6 +52,19 @@ template <class T> __device__ __forceinline__ void stnt(T* base, long i, const P
 template <class T> __device__ __forceinline__ T guardedInvert(T x) {   // solver.t:323-332 (CERES)
     T s = T(1) + sqrt(x);
     return T(1) / (s * s);
+}
+
+// Write-through (sc1) 16-byte store through a buffer descriptor: the line leaves the XCD's L2 immediately instead of
+// lingering dirty until the end-of-kernel write-back (MI355X_MICROARCH.md, "stores of each flavour").  Measured
+// with tools/microbench_boundary.hip on the PCGStep2 shape at 4096^2: plain 294 us, nt 291 us, sc1 285 us per launch.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <class T> __device__ __forceinline__ void stwt(__amdgpu_buffer_rsrc_t rsrc, long i, const Pack<T>& p) {
+    u32x4 v;
+    __builtin_memcpy(&v, &p, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)(i * 16), 0, /*aux: sc1*/ 16);
+}
+template <class T> __device__ __forceinline__ __amdgpu_buffer_rsrc_t makeRsrc(T* base, long nPacks) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(nPacks * 16), 0x00020000);
 }
 
 // PCGInit1 (non-graph tail) / PCGInit1_Finish (graph): solver.t:384-392, 399-419.  r already holds -J^T F.
@@ -84,7 +100,7 @@ __global__ __launch_bounds__(kBlock) void k_finalizeSum(const double* __restrict
 }
 
 // PCGStep2: solver.t:446-489
-template <class T, bool LM>
+template <class T, bool LM, int WT>
 __global__ __launch_bounds__(kBlock) void k_step2(T* __restrict__ delta, const T* __restrict__ p, T* __restrict__ r, const T* __restrict__ Ap,
                                                   const T* __restrict__ pre /*nullptr -> 1*/, const T* __restrict__ b, T* __restrict__ z, long nPacks,
                                                   const double* __restrict__ aNumTotal, const double* __restrict__ aDenPartials, int nDen,
@@ -96,6 +112,8 @@ __global__ __launch_bounds__(kBlock) void k_step2(T* __restrict__ delta, const T
     const T alpha = (aDen > T(0)) ? aNum / aDen : T(0);   // guardDivisionByZero, solver.t:456-459
     double accB = 0, accQ = 0;
     const long stride = (long)gridDim.x * blockDim.x;
+    __amdgpu_buffer_rsrc_t rsDelta, rsR, rsZ;
+    if (WT) { rsDelta = makeRsrc(delta, nPacks); rsR = makeRsrc(r, nPacks); rsZ = makeRsrc(z, nPacks); }
     for (long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x; i0 < nPacks; i0 += 2 * stride) {
         // two packs per lane in flight: issue all loads of both before the first use
         Pack<T> D[2], P[2], R[2], A[2], M[2], B[2], Z;
@@ -122,7 +140,12 @@ __global__ __launch_bounds__(kBlock) void k_step2(T* __restrict__ delta, const T
                     accB += (double)(zz * rr);
                     if (LM) accQ += (double)(T(0.5) * (dl * (rr + B[u].v[k])));
                 }
-                stnt(delta, i, D[u]); stnt(r, i, R[u]); stnt(z, i, Z);
+                // WT: 0 = all non-temporal; 1 = all write-through; 2 = delta, r write-through + z plain; 3 = delta, r write-through + z nt; 4 = all plain
+                if (WT == 1) { stwt(rsDelta, i, D[u]); stwt(rsR, i, R[u]); stwt(rsZ, i, Z); }
+                else if (WT == 2) { stwt(rsDelta, i, D[u]); stwt(rsR, i, R[u]); ((Pack<T>*)z)[i] = Z; }
+                else if (WT == 3) { stwt(rsDelta, i, D[u]); stwt(rsR, i, R[u]); stnt(z, i, Z); }
+                else if (WT == 4) { ((Pack<T>*)delta)[i] = D[u]; ((Pack<T>*)r)[i] = R[u]; ((Pack<T>*)z)[i] = Z; }
+                else { stnt(delta, i, D[u]); stnt(r, i, R[u]); stnt(z, i, Z); }
             }
         }
     }
@@ -255,6 +278,7 @@ struct PcgSolver : SolverBase {
       *SSq = nullptr, *prevX = nullptr;
     T* p2 = nullptr;                    // second search-direction buffer for the fused PCGStep3+PCGStep1 kernel
     bool fuseStep3 = true;              // OPT_AMD_FUSE=0 disables (A/B switch)
+    int storeMode = 0;                  // OPT_AMD_SC1=0..4: store flavours of PCGStep2 (see k_step2), A/B switch
     bool keepReferenceP = false;        // run the (dead) last PCGStep3 so that `p` matches the reference after a step
     std::vector<void*> allocs;
     Reduction redA, redB, redQ, redC;   // alpha denominator, beta numerator, q, cost / init numerator
@@ -287,6 +311,7 @@ struct PcgSolver : SolverBase {
         if (lm) { b = allocVec(); Adelta = allocVec(); SSq = allocVec(); prevX = allocVec(); }
         p2 = allocVec();
         if (const char* e = getenv("OPT_AMD_FUSE")) fuseStep3 = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_SC1")) storeMode = atoi(e);
         redA = allocRed(); redB = allocRed(); redQ = allocRed(); redC = allocRed();
         HIP_CHECK(hipMalloc((void**)&scal, 8 * sizeof(double))); HIP_CHECK(hipMemset(scal, 0, 8 * sizeof(double))); allocs.push_back(scal);
         HIP_CHECK(hipHostMalloc((void**)&hostBuf, kMaxPartials * sizeof(double)));
@@ -462,8 +487,13 @@ struct PcgSolver : SolverBase {
                 redB.n = streamGrid; redQ.n = streamGrid;
             } else {
                 ScopedKernel k(ctx, "PCGStep2");
-                if (lm) k_step2<T, true><<<streamGrid, kBlock, 0, stream>>>(delta, p, r, Ap_X, preArg, b, z, nPacks, scal + aSlot, aDen.partials, aDen.n, redB.partials, redQ.partials);
-                else k_step2<T, false><<<streamGrid, kBlock, 0, stream>>>(delta, p, r, Ap_X, preArg, nullptr, z, nPacks, scal + aSlot, aDen.partials, aDen.n, redB.partials, nullptr);
+                const int wt = (nPad * (long)sizeof(T) < (1L << 31)) ? storeMode : 0;   // 32-bit buffer offsets
+#define OPTAMD_STEP2(LMV, WTV, BV, QV) k_step2<T, LMV, WTV><<<streamGrid, kBlock, 0, stream>>>(delta, p, r, Ap_X, preArg, BV, z, nPacks, scal + aSlot, aDen.partials, aDen.n, redB.partials, QV)
+                if (lm) { switch (wt) { case 1: OPTAMD_STEP2(true, 1, b, redQ.partials); break; case 2: OPTAMD_STEP2(true, 2, b, redQ.partials); break; case 3: OPTAMD_STEP2(true, 3, b, redQ.partials); break;
+                                        case 4: OPTAMD_STEP2(true, 4, b, redQ.partials); break; default: OPTAMD_STEP2(true, 0, b, redQ.partials); } }
+                else { switch (wt) { case 1: OPTAMD_STEP2(false, 1, nullptr, nullptr); break; case 2: OPTAMD_STEP2(false, 2, nullptr, nullptr); break; case 3: OPTAMD_STEP2(false, 3, nullptr, nullptr); break;
+                                     case 4: OPTAMD_STEP2(false, 4, nullptr, nullptr); break; default: OPTAMD_STEP2(false, 0, nullptr, nullptr); } }
+#undef OPTAMD_STEP2
                 redB.n = streamGrid; redQ.n = streamGrid;
             }
             bNum = forConsumers(redB, 1);
