@@ -42,6 +42,7 @@ def lib():
         L.OptOracle_Step.argtypes = [vp, ctypes.POINTER(vp)]
         L.OptOracle_CurrentCost.restype = cd
         L.OptOracle_CurrentCost.argtypes = [vp]
+        L.OptOracle_SetThreads.argtypes = [vp, ci]
         L.OptOracle_NumUnknownScalars.restype = cl
         L.OptOracle_NumUnknownScalars.argtypes = [vp]
         L.OptOracle_GetVector.restype = ci
@@ -97,6 +98,10 @@ class OracleSolver:
         ok = lib().OptOracle_SetSolverParameter(self._h, name.encode(), v.ctypes.data)
         if not ok:
             raise KeyError(name)
+
+    def set_threads(self, n):
+        """OpenMP threads for the timed CPU baseline (row bands); parity tests keep the default of 1."""
+        lib().OptOracle_SetThreads(self._h, int(n))
 
     def init(self, params):
         a, self._keep = _param_array(params)

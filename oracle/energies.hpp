@@ -31,6 +31,7 @@ struct ImageWarping : Energy<T> {
     }
     T* unknownPtr(int img) override { return img == 0 ? Offset : Angle; }
     long nCentered() const override { return W * H; }
+    long rowWidth() const override { return W; }
     bool excluded(int, long e) const override { return Mask[e] != T(0); }   // Exclude(Not(eq(Mask(0,0),0))) (:11)
     bool excludedCentered(long e) const override { return Mask[e] != T(0); }
     int evalCentered(long e, Inst<T>* out) const override {
@@ -88,6 +89,7 @@ struct Poisson : Energy<T> {
     void bind(void** p) override { X = (T*)p[0]; Tg = (const T*)p[1]; M = (const T*)p[2]; }
     T* unknownPtr(int) override { return X; }
     long nCentered() const override { return W * H; }
+    long rowWidth() const override { return W; }
     bool excluded(int, long e) const override { return M[e] != T(0); }    // (:8)
     bool excludedCentered(long e) const override { return M[e] != T(0); }
     int evalCentered(long e, Inst<T>* out) const override {
@@ -122,6 +124,7 @@ struct Laplacian : Energy<T> {
     void bind(void** p) override { X = (T*)p[0]; A = (const T*)p[1]; }
     T* unknownPtr(int) override { return X; }
     long nCentered() const override { return W * H; }
+    long rowWidth() const override { return W; }
     int evalCentered(long e, Inst<T>* out) const override {
         const long x = e % W, y = e / W;
         Inst<T>& F = out[0];

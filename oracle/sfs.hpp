@@ -34,6 +34,7 @@ struct ShapeFromShading : Energy<T> {
     }
     T* unknownPtr(int) override { return X; }
     long nCentered() const override { return W * H; }
+    long rowWidth() const override { return W; }
     bool depthValid(long x, long y) const { return x >= 0 && x < W && y >= 0 && y < H && D_i[y * W + x] > T(0); }
     bool excluded(int, long e) const override { return !(D_i[e] > T(0)); }   // Exclude(Not(DepthValid(0,0))) (:70)
     bool excludedCentered(long e) const override { return !(D_i[e] > T(0)); }

@@ -34,6 +34,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 namespace oracle {
@@ -74,6 +75,7 @@ struct Energy {
     virtual long nEdges() const { return 0; }
     virtual int evalEdge(long /*e*/, Inst<T>* /*out*/) const { return 0; }
     virtual void precompute() {}                          // ComputedArrays (o.t:2387-2409)
+    virtual long rowWidth() const { return 0; }            // image energies: W (lets the timed baseline split rows over threads)
 };
 
 struct SolverParameters {   // solver.t:148-163 (floats even in double mode), defaults :26-39
@@ -108,6 +110,8 @@ struct Solver {
     std::vector<TraceRow> trace;
     std::vector<double> costHistory;
     int verbosity = 0;
+    mutable std::vector<T> scratchAcc;
+    int threads = 1;   // > 1: OpenMP over row bands (timed CPU baseline only; parity tests run single-threaded)
 
     Solver(Energy<T>* e, bool useLM) : E(e), lm(useLM) {
         long n = E->nScalars;
@@ -140,34 +144,68 @@ struct Solver {
         }
     }
 
+    // Row-banded traversal of the centred instances for the multi-threaded baseline.  Every residual's support lies
+    // within +-1 row of its centre, so bands of 4 rows processed in two colours (even bands, then odd bands) never
+    // scatter into the same row from two threads; per-band partial sums keep reductions deterministic.
+    template <class F> void forEachInstanceBanded(bool skipExcludedCentres, F&& f, std::vector<long double>* bandSums = nullptr) const {
+        const long W = E->rowWidth(), nc = E->nCentered();
+        if (threads <= 1 || W <= 0 || nc % W != 0) {
+            long double s = 0; long double* sp = bandSums ? &s : nullptr;
+            forEachInstance(skipExcludedCentres, [&](const Inst<T>* in, int k) { f(in, k, sp); });
+            if (bandSums) bandSums->assign(1, s);
+            return;
+        }
+        const long H = nc / W, band = 4, nb = (H + band - 1) / band;
+        if (bandSums) bandSums->assign(nb + 1, 0.0L);
+        for (int colour = 0; colour < 2; ++colour) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+            for (long bi = colour; bi < nb; bi += 2) {
+                Inst<T> buf[MAXR];
+                long double s = 0;
+                const long e0 = bi * band * W, e1 = std::min(nc, (bi + 1) * band * W);
+                for (long e = e0; e < e1; ++e) {
+                    if (skipExcludedCentres && E->excludedCentered(e)) continue;
+                    int k = E->evalCentered(e, buf);
+                    f(buf, k, bandSums ? &s : nullptr);
+                }
+                if (bandSums) (*bandSums)[bi] = s;
+            }
+        }
+        Inst<T> buf[MAXR];
+        long double s = 0;
+        for (long e = 0; e < E->nEdges(); ++e) { int k = E->evalEdge(e, buf); f(buf, k, bandSums ? &s : nullptr); }
+        if (bandSums) (*bandSums)[nb] = s;
+    }
+    static long double sumBands(const std::vector<long double>& v) { long double s = 0; for (auto x : v) s += x; return s; }
+
     // cost = sum over non-excluded elements of 1/2 sum_k r_k^2  (solver.t:580-592, 715-725; o.t:2375-2385)
     T computeCost() const {
-        long double s = 0;
-        forEachInstance(true, [&](const Inst<T>* in, int k) {
+        std::vector<long double> bands;
+        forEachInstanceBanded(true, [&](const Inst<T>* in, int k, long double* s) {
             T c = 0; for (int i = 0; i < k; ++i) c += in[i].val * in[i].val;
-            s += (long double)(T(0.5) * c);
-        });
-        return (T)s;
+            *s += (long double)(T(0.5) * c);
+        }, &bands);
+        return (T)sumBands(bands);
     }
     // modelcost = 1/2 sum (F + J delta)^2  (o.t:2174-2225)
     T computeModelCost() const {
-        long double s = 0;
-        forEachInstance(true, [&](const Inst<T>* in, int k) {
+        std::vector<long double> bands;
+        forEachInstanceBanded(true, [&](const Inst<T>* in, int k, long double* s) {
             T c = 0;
             for (int i = 0; i < k; ++i) {
                 T jd = 0;
                 for (int u = 0; u < in[i].n; ++u) if (in[i].idx[u] >= 0) jd += in[i].dv[u] * delta[in[i].idx[u]];
                 T m = in[i].val + jd; c += m * m;
             }
-            s += (long double)(T(0.5) * c);
-        });
-        return (T)s;
+            *s += (long double)(T(0.5) * c);
+        }, &bands);
+        return (T)sumBands(bands);
     }
     // F^ = sum dr/dx * r ; P^ = sum (dr/dx)^2 over every residual touching x (incl. residuals centred on
     // excluded neighbours: the gather of o.t:2045-2064 has no exclude test).
     void evalJTF(std::vector<T>& F, std::vector<T>& P) const {
         F.assign(E->nScalars, T(0)); P.assign(E->nScalars, T(0));
-        forEachInstance(false, [&](const Inst<T>* in, int k) {
+        forEachInstanceBanded(false, [&](const Inst<T>* in, int k, long double*) {
             for (int i = 0; i < k; ++i)
                 for (int u = 0; u < in[i].n; ++u) {
                     long t = in[i].idx[u];
@@ -179,14 +217,18 @@ struct Solver {
     }
     // out = J^T J v (+ CtC .* v for LM, o.t:2076-2082); only active rows are produced (solver.t:424).
     void applyJTJ(const std::vector<T>& v, std::vector<T>& out) const {
-        std::vector<T> acc(E->nScalars, T(0));
-        forEachInstance(false, [&](const Inst<T>* in, int k) {
+        if ((long)scratchAcc.size() != E->nScalars) scratchAcc.resize(E->nScalars);
+        std::vector<T>& acc = scratchAcc;
+#pragma omp parallel for num_threads(threads) if (threads > 1)
+        for (long i = 0; i < E->nScalars; ++i) acc[i] = T(0);
+        forEachInstanceBanded(false, [&](const Inst<T>* in, int k, long double*) {
             for (int i = 0; i < k; ++i) {
                 T jp = 0;
                 for (int u = 0; u < in[i].n; ++u) if (in[i].idx[u] >= 0) jp += in[i].dv[u] * v[in[i].idx[u]];
                 for (int u = 0; u < in[i].n; ++u) if (in[i].idx[u] >= 0) acc[in[i].idx[u]] += in[i].dv[u] * jp;
             }
         });
+#pragma omp parallel for num_threads(threads) if (threads > 1)
         for (long i = 0; i < E->nScalars; ++i) {
             if (!active[i]) continue;
             out[i] = acc[i] + (lm ? CtC[i] * v[i] : T(0));
@@ -194,6 +236,7 @@ struct Solver {
     }
     T dotActive(const std::vector<T>& a, const std::vector<T>& c) const {
         long double s = 0;
+#pragma omp parallel for reduction(+ : s) num_threads(threads) if (threads > 1)
         for (long i = 0; i < E->nScalars; ++i) if (active[i]) s += (long double)(a[i] * c[i]);
         return (T)s;
     }
@@ -271,7 +314,7 @@ struct Solver {
     void computeCtC() {   // solver.t:616-622, 739-744 ; o.t:2255-2316 (true diag(JtJ)/radius, independent of usepreconditioner)
         std::vector<T> acc(E->nScalars, T(0));
         T inv_radius = T(1) / trust_region_radius;
-        forEachInstance(false, [&](const Inst<T>* in, int k) {
+        forEachInstanceBanded(false, [&](const Inst<T>* in, int k, long double*) {
             for (int i = 0; i < k; ++i) for (int u = 0; u < in[i].n; ++u) if (in[i].idx[u] >= 0) acc[in[i].idx[u]] += in[i].dv[u] * in[i].dv[u] * inv_radius;
         });
         for (long i = 0; i < E->nScalars; ++i) if (active[i]) CtC[i] = acc[i];
@@ -305,6 +348,7 @@ struct Solver {
     void pcgStep2() {   // solver.t:446-489
         T a = alpha();
         long double bn = 0, qq = 0;
+#pragma omp parallel for reduction(+ : bn, qq) num_threads(threads) if (threads > 1)
         for (long i = 0; i < E->nScalars; ++i) {
             if (!active[i]) continue;
             T dl = delta[i] + a * p[i]; delta[i] = dl;
@@ -333,6 +377,7 @@ struct Solver {
     }
     void pcgStep3() {   // solver.t:537-550
         T beta = (aNum > T(0)) ? bNum / aNum : T(0);
+#pragma omp parallel for num_threads(threads) if (threads > 1)
         for (long i = 0; i < E->nScalars; ++i) if (active[i]) p[i] = z[i] + beta * p[i];
     }
 
