@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_PIXEL_STEP1 = 48       # PCGStep1: (2C + A_in) * 4 B, C = 3, A_in = 6  
+ALGO_BYTES_PER_PIXEL_STEP2 = 96       # PCGStep2: 8C * 4 B
 ALGO_BYTES_PER_PIXEL_STEP3 = 36       # PCGStep3: 3C * 4 B
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -135,7 +136,9 @@ def main():
         kt = ts.kernel_timings()
         # the dominant kernel is applyJTJ; when the previous iteration's PCGStep3 is fused into it, one launch
         # does the algorithmic work of both reference kernels (48 + 36 B/pixel)
-        if "PCGStep3+PCGStep1" in kt:
+        if "PCGIteration" in kt:      # the whole iteration in one launch: PCGStep2 + PCGStep3 of iteration k-1, PCGStep1 of iteration k
+            kname, algo = "PCGIteration", ALGO_BYTES_PER_PIXEL_STEP1 + ALGO_BYTES_PER_PIXEL_STEP2 + ALGO_BYTES_PER_PIXEL_STEP3
+        elif "PCGStep3+PCGStep1" in kt:
             kname, algo = "PCGStep3+PCGStep1", ALGO_BYTES_PER_PIXEL_STEP1 + ALGO_BYTES_PER_PIXEL_STEP3
         else:
             kname, algo = "PCGStep1", ALGO_BYTES_PER_PIXEL_STEP1
@@ -146,12 +149,13 @@ def main():
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate runs of this command, FETCH_SIZE doubled per MI355X_MICROARCH.md; tools/summarize_profile.py)
         traffic, traffic_src = None, None
-        if W == 4096 and kname == "PCGStep3+PCGStep1":
+        if W == 4096:
             import glob
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-            if cands:
-                tj = json.load(open(cands[-1]))
-                traffic, traffic_src = tj["hbm_bytes_per_launch"], os.path.basename(cands[-1])
+            for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+                tj = json.load(open(cand))
+                if tj.get("bench_kernel", "PCGStep3+PCGStep1") == kname:
+                    traffic, traffic_src = tj["hbm_bytes_per_launch"], os.path.basename(cand)
+                    break
         roofline = {"bound": "hbm", "kernel": kname + " (applyJTJ)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_ms": avg_ms, "launches": cnt,
                     "algorithmic_bytes_per_pixel": algo, "algorithmic_bytes_per_launch": algo * W * H,

@@ -24,6 +24,28 @@ struct UnknownImage {
     long offset;      // first scalar of this image in the solver's unknown vector
 };
 
+// Arguments of the single-kernel PCG iteration (EnergyOps::pcgIteration).  The reference runs three kernels per
+// iteration -- PCGStep1 (Ap = A p, alphaDen = p.Ap), PCGStep2 (delta += alpha p, r -= alpha Ap, z = M r,
+// betaNum = z.r), PCGStep3 (p = z + beta p) -- separated by two grid-wide sums (solverGPUGaussNewton.t:1056-1091).
+// Launch k of the fused kernel does, for every pixel it touches (its rows plus the stencil halo),
+//     r_k = r_{k-1} - alpha_{k-1} Ap_{k-1};  z_k = M r_k;  p_k = z_k + beta_{k-1} p_{k-1}          (Step2 + Step3 of iteration k-1)
+// then for its own rows   delta += alpha_{k-1} p_{k-1};  Ap_k = A p_k                              (rest of Step2, Step1 of iteration k)
+// and the sums  alphaDen_k = p_k.Ap_k,  alphaNum_k = z_k.r_k (direct),  s2 = z_k.Ap_k,  s3 = (M Ap_k).Ap_k.
+// beta_{k-1} needs betaNum_{k-1} = sum M r_k^2 before r_k exists; it is obtained from the previous launch's sums by
+// expanding the square:  sum M (r - alpha Ap)^2 = alphaNum - 2 alpha s2 + alpha^2 s3  (all sums in double).  Every
+// vector update is the reference's; only where that one dot product is evaluated changes.  Old and new r / Ap / p
+// buffers must not alias (neighbouring workgroups read the old halo while this one writes).
+template <class T>
+struct PcgIterArgs {
+    const T *rOld, *ApOld, *pOld;
+    T *rNew, *ApNew, *pNew;
+    T* delta;
+    const T* pre;                                        // Jacobi preconditioner (nullptr -> identity)
+    int first;                                           // first iteration of a linear solve: alpha_{-1} = beta_{-1} = 0
+    Reduction aNumPrev, aDenPrev, s2Prev, s3Prev;        // sums of the previous launch (aNumPrev of launch 0: sum r.p of PCGInit1)
+    Reduction *aNum, *aDen, *s2, *s3;                    // sums this launch writes
+};
+
 // Everything the solver needs from an energy.  T = opt_float (float or double).
 // Contract shared by all implementations:
 //  * solver vectors are laid out like the unknown vector: unknown images in declaration order, AoS,
@@ -61,6 +83,8 @@ struct EnergyOps {
     // the generic PCGStep3 followed by applyJTJ).
     virtual bool applyJTJFused(const T* /*pOld*/, const T* /*z*/, T* /*pNew*/, T* /*out*/, const T* /*CtC*/, Reduction* /*dot*/,
                                const Reduction& /*bNum*/, const double* /*aNumOld*/, double* /*aNumNext*/, LaunchCtx&) { return false; }
+    // Optional: one WHOLE Gauss-Newton PCG iteration as a single kernel (see PcgIterArgs and solver.hip).
+    virtual bool pcgIteration(const PcgIterArgs<T>& /*args*/, LaunchCtx&) { return false; }
     // partial sums of 1/2 sum (F + J delta)^2 (o.t:2174-2225); LM only
     virtual void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) = 0;
     // slab tiling (image energies): number of scalars in one image row of unknown image `img`

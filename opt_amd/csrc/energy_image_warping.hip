@@ -223,6 +223,9 @@ template <bool NT, class T> __device__ __forceinline__ void st1(T* p, long i, T 
 #ifndef IW_NT_LOAD
 #define IW_NT_LOAD 1
 #endif
+#ifndef IW_ROW_SYNC
+#define IW_ROW_SYNC 1
+#endif
 #ifndef IW_NT_STORE
 #define IW_NT_STORE 0
 #endif
@@ -336,6 +339,7 @@ __global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __re
     };
     Raw<T, FUSE> rA = iw_loadRaw<T, FUSE>(A, vO, va, zO, za, xok, x, yb + 1), rB;
     for (int y = yb; y < ye; y += 2) {
+        if (IW_ROW_SYNC) __syncthreads();   // keep the 4 waves of a strip on the same rows: their shared seam lines then hit L2
         rB = iw_loadRaw<T, FUSE>(A, vO, va, zO, za, xok, x, y + 2);
         row(y, rA);
         if (y + 1 < ye) {
@@ -345,6 +349,146 @@ __global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __re
     }
     double t = blockReduceSum(acc, scratch);
     if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
+}
+
+// ---- one whole PCG iteration per launch (energy.h PcgIterArgs) --------------------------------------------------
+// Same marching / DPP / prefetch structure as iw_applyJTJ; per pixel it additionally applies the previous
+// iteration's PCGStep2 and PCGStep3 before the stencil, so the PCG loop is ONE kernel per iteration moving
+// r 12 + Ap 12 + p 12 + delta 12 + pre 12 + (cos,sin) 8 + U 8 + flags 1 in and r, p, delta, Ap 48 out = 125 B/pixel
+// (three reference kernels: 180 B/pixel algorithmic).
+template <class T>
+struct IterRaw {
+    V2<T> ro, ao, po, mo, cs, u; T ra, aa, pa, ma;   // r, Ap, p, pre (Offset part / Angle part), table, UrShape
+    int f;
+};
+template <class T>
+struct IterPx {            // what the stencil needs (Px) + what the sums / stores need
+    Px<T> p;               // p_new, cos/sin, U, flags
+    T zx, zy, za;          // z = M r_new
+    T mx, my, ma;          // M
+};
+template <class T>
+struct IterK {             // kernel argument block
+    const T *rOld, *ApOld, *pOld; T *rNew, *ApNew, *pNew; T* delta; const T* pre; int first;
+    const double *aNumPrev, *aDenPrev, *s2Prev, *s3Prev; int nNum, nDen, n2, n3;
+    double *aNum, *aDen, *s2, *s3;
+};
+
+template <class T>
+__device__ __forceinline__ IterRaw<T> iw_iterLoad(const IWArgs<T>& A, const IterK<T>& K, long N, bool xok, int x, int y) {
+    IterRaw<T> r;
+    const bool ok = xok && y >= 0 && y < A.H;
+    const long i = (long)min(max(y, 0), A.H - 1) * A.W + min(max(x, 0), A.W - 1);
+    const int f = A.flags[i];
+    r.f = ok ? f : 0;
+    r.ro = ld2<kNTL>((const V2<T>*)K.rOld, i); r.ra = ld1<kNTL>(K.rOld + 2 * N, i);
+    r.ao = ld2<kNTL>((const V2<T>*)K.ApOld, i); r.aa = ld1<kNTL>(K.ApOld + 2 * N, i);
+    r.po = ld2<kNTL>((const V2<T>*)K.pOld, i); r.pa = ld1<kNTL>(K.pOld + 2 * N, i);
+    if (K.pre) { r.mo = ld2<kNTL>((const V2<T>*)K.pre, i); r.ma = ld1<kNTL>(K.pre + 2 * N, i); } else { r.mo = V2<T>{1, 1}; r.ma = 1; }
+    r.cs = ld2<kNTL>((const V2<T>*)A.cs, i); r.u = ld2<kNTL>((const V2<T>*)A.UrShape, i);
+    return r;
+}
+
+#ifndef ITER_MIN_WAVES
+#define ITER_MIN_WAVES 1
+#endif
+// Workgroup size of the single-kernel iteration.  Measured at 4096^2 (interleaved A/B on one box, PCG it/s):
+// 256 threads 2090, 512 threads 2220-2370, 1024 threads 2200; a workgroup barrier every two rows (IW_ROW_SYNC=1:
+// keeps the strip's waves on the same rows, so the cache lines they share at the 62-pixel seams are fetched while
+// still hot) is worth +15 % over free-running waves, every row (=2) no better.
+#ifndef ITER_BLOCK
+#define ITER_BLOCK 512
+#endif
+constexpr int kIterBlock = ITER_BLOCK;
+constexpr int kIterStrip = (kIterBlock / kWave) * kSpan;
+template <class T>
+__global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter(IWArgs<T> A, IterK<T> K, int rowsPerGroup, int gx, int gy) {
+    __shared__ double scratch[kIterBlock / kWave + 1];
+    const long N = (long)A.W * A.H;
+    // scalars of the previous iteration (solver.t:456-459, 544-547 guards), betaNumerator by expansion (energy.h)
+    T alpha = 0, beta = 0;
+    if (!K.first) {
+        const double aNumD = sumPartials(K.aNumPrev, K.nNum, scratch), aDenD = sumPartials(K.aDenPrev, K.nDen, scratch);
+        const double s2 = sumPartials(K.s2Prev, K.n2, scratch), s3 = sumPartials(K.s3Prev, K.n3, scratch);
+        const T aNum = (T)aNumD, aDen = (T)aDenD;
+        alpha = (aDen > T(0)) ? aNum / aDen : T(0);
+        const double bNumD = aNumD - 2.0 * (double)alpha * s2 + (double)alpha * (double)alpha * s3;
+        beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
+    }
+    const int bx = blockIdx.x % gx, by = blockIdx.x / gx;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int x = bx * kIterStrip + wave * kSpan + lane - 1;
+    const bool xok = x >= 0 && x < A.W;
+    const bool writer = xok && lane >= 1 && lane <= kSpan;
+    const int yb = A.yBegin + by * rowsPerGroup;
+    const int ye = min(yb + rowsPerGroup, A.yEnd);
+    const T w2 = A.w_reg * A.w_reg, wf2 = A.w_fit * A.w_fit;
+    double accDen = 0, accNum = 0, acc2 = 0, acc3 = 0;
+    V2<T>* rO = (V2<T>*)K.rNew; T* rA = K.rNew + 2 * N; V2<T>* pO = (V2<T>*)K.pNew; T* pA = K.pNew + 2 * N;
+    V2<T>* dO = (V2<T>*)K.delta; T* dA = K.delta + 2 * N; V2<T>* aO = (V2<T>*)K.ApNew; T* aA = K.ApNew + 2 * N;
+
+    // Step2 + Step3 of the previous iteration for one pixel; `own` rows also store r, p, delta and feed alphaNum
+    auto combine = [&](const IterRaw<T>& w, int y, bool own) {
+        IterPx<T> q;
+        const T rx = K.first ? w.ro.x : w.ro.x - alpha * w.ao.x, ry = K.first ? w.ro.y : w.ro.y - alpha * w.ao.y, ra = K.first ? w.ra : w.ra - alpha * w.aa;
+        q.mx = w.mo.x; q.my = w.mo.y; q.ma = w.ma;
+        q.zx = q.mx * rx; q.zy = q.my * ry; q.za = q.ma * ra;
+        q.p.ox = q.zx + beta * w.po.x; q.p.oy = q.zy + beta * w.po.y; q.p.a = q.za + beta * w.pa;
+        q.p.c = w.cs.x; q.p.s = w.cs.y; q.p.ux = w.u.x; q.p.uy = w.u.y; q.p.f = w.f;
+        if (own && xok && y >= 0 && y < A.H) {
+            const long i = (long)y * A.W + x;
+            const bool ghost = y < A.yBegin || y >= A.yEnd;     // slab mode: ghost rows keep r / p current for the next launch
+            if (writer || (ghost && xok)) { st2<kNTS>(rO, i, rx, ry); st1<kNTS>(rA, i, ra); st2<kNTS>(pO, i, q.p.ox, q.p.oy); st1<kNTS>(pA, i, q.p.a); }
+            if (writer && !ghost) {
+                if (!K.first) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462)
+                    const V2<T> d = dO[i]; const T da = dA[i];
+                    st2<kNTS>(dO, i, d.x + alpha * w.po.x, d.y + alpha * w.po.y); st1<kNTS>(dA, i, da + alpha * w.pa);
+                }
+                accNum += (double)(q.zx * rx + q.zy * ry + q.za * ra);
+            }
+        }
+        return q;
+    };
+    IterPx<T> up = combine(iw_iterLoad(A, K, N, xok, x, yb - 1), yb - 1, yb == A.yBegin && yb - 1 >= 0);
+    IterPx<T> cur = combine(iw_iterLoad(A, K, N, xok, x, yb), yb, yb < ye);
+    auto row = [&](int y, const IterRaw<T>& rdn) {
+        const IterPx<T> dn = combine(rdn, y + 1, y + 1 < A.H && (y + 1 < ye || y + 1 == A.yEnd));
+        const long i = (long)y * A.W + x;
+        const Px<T> lf = dppShiftPx<true>(cur.p), rt = dppShiftPx<false>(cur.p);
+        T ax = 0, ay = 0, aa = 0;
+        iw_pair(cur.p, rt, ax, ay, aa);
+        iw_pair(cur.p, lf, ax, ay, aa);
+        iw_pair(cur.p, dn.p, ax, ay, aa);
+        iw_pair(cur.p, up.p, ax, ay, aa);
+        T ox = w2 * ax, oy = w2 * ay, oa = w2 * aa;
+        const bool fit = (cur.p.f & kFit) != 0;
+        ox += fit ? wf2 * cur.p.ox : T(0); oy += fit ? wf2 * cur.p.oy : T(0);
+        const bool act = (cur.p.f & kActive) != 0;
+        ox = act ? ox : T(0); oy = act ? oy : T(0); oa = act ? oa : T(0);
+        if (writer) {
+            accDen += (double)(cur.p.ox * ox + cur.p.oy * oy + cur.p.a * oa);
+            acc2 += (double)(cur.zx * ox + cur.zy * oy + cur.za * oa);
+            acc3 += (double)((cur.mx * ox) * ox + (cur.my * oy) * oy + (cur.ma * oa) * oa);
+            st2<kNTS>(aO, i, ox, oy); st1<kNTS>(aA, i, oa);
+        }
+        up = cur; cur = dn;
+    };
+    IterRaw<T> rA2 = iw_iterLoad(A, K, N, xok, x, yb + 1), rB2;
+    for (int y = yb; y < ye; y += 2) {
+        if (IW_ROW_SYNC) __syncthreads();
+        rB2 = iw_iterLoad(A, K, N, xok, x, y + 2);
+        row(y, rA2);
+        if (IW_ROW_SYNC == 2) __syncthreads();
+        if (y + 1 < ye) {
+            rA2 = iw_iterLoad(A, K, N, xok, x, y + 3);
+            row(y + 1, rB2);
+        }
+    }
+    double t;
+    t = blockReduceSum(accDen, scratch); if (threadIdx.x == 0) K.aDen[blockIdx.x] = t;
+    t = blockReduceSum(accNum, scratch); if (threadIdx.x == 0) K.aNum[blockIdx.x] = t;
+    t = blockReduceSum(acc2, scratch); if (threadIdx.x == 0) K.s2[blockIdx.x] = t;
+    t = blockReduceSum(acc3, scratch); if (threadIdx.x == 0) K.s3[blockIdx.x] = t;
 }
 
 // ghost rows of `out` are zeroed so the flat streaming kernels see r = 0 / Ap = 0 there (energy.h contract)
@@ -485,6 +629,28 @@ struct ImageWarpingOps : EnergyOps<T> {
                        double* aNumNext, LaunchCtx& ctx) override {
         FuseArgs<T> F{z, pNew, bNum.partials, bNum.n, aNumOld, aNumNext};
         launchApply(pOld, out, CtC, dot, ctx, &F);
+        return true;
+    }
+    int occIter = 0;
+    bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
+        if (occIter == 0) {
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occIter, (const void*)iw_pcgIter<T>, kIterBlock, 0));
+            occIter = std::max(1, std::min(occIter, 8));
+        }
+        const int gx = divUp(A.W, kIterStrip);
+        const int rows = A.yEnd - A.yBegin;
+        int gy = std::max(1, std::min(std::min(rows, cus * occIter / gx), kMaxPartials / gx));
+        const int rowsPerGroup = divUp(rows, gy);
+        gy = divUp(rows, rowsPerGroup);
+        IterK<T> K{a.rOld, a.ApOld, a.pOld, a.rNew, a.ApNew, a.pNew, a.delta, a.pre, a.first,
+                   a.aNumPrev.partials, a.aDenPrev.partials, a.s2Prev.partials, a.s3Prev.partials, a.aNumPrev.n, a.aDenPrev.n, a.s2Prev.n, a.s3Prev.n,
+                   a.aNum->partials, a.aDen->partials, a.s2->partials, a.s3->partials};
+        {
+            ScopedKernel k(ctx, "PCGIteration");
+            iw_pcgIter<T><<<gx * gy, kIterBlock, 0, ctx.stream>>>(A, K, rowsPerGroup, gx, gy);
+        }
+        a.aNum->n = a.aDen->n = a.s2->n = a.s3->n = gx * gy;
+        if (this->slab.active) iw_zeroGhost<T><<<divUp(A.W, kBlock), kBlock, 0, ctx.stream>>>(A, a.ApNew);
         return true;
     }
     void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {

@@ -278,6 +278,9 @@ struct PcgSolver : SolverBase {
       *SSq = nullptr, *prevX = nullptr;
     T* p2 = nullptr;                    // second search-direction buffer for the fused PCGStep3+PCGStep1 kernel
     bool fuseStep3 = true;              // OPT_AMD_FUSE=0 disables (A/B switch)
+    T *r2 = nullptr, *Ap2 = nullptr;    // second r / Ap buffers for the single-kernel PCG iteration (z doubles as nothing there)
+    bool oneKernel = true;              // OPT_AMD_ONEKERNEL=0: use the Step1(+3)/Step2 pair instead of one kernel per PCG iteration
+    Reduction setS[2][4];               // ping-pong {alphaNum, alphaDen, s2, s3} of the single-kernel iteration
     int storeMode = 0;                  // OPT_AMD_SC1=0..4: store flavours of PCGStep2 (see k_step2), A/B switch
     bool keepReferenceP = false;        // run the (dead) last PCGStep3 so that `p` matches the reference after a step
     std::vector<void*> allocs;
@@ -311,6 +314,8 @@ struct PcgSolver : SolverBase {
         if (lm) { b = allocVec(); Adelta = allocVec(); SSq = allocVec(); prevX = allocVec(); }
         p2 = allocVec();
         if (const char* e = getenv("OPT_AMD_FUSE")) fuseStep3 = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_ONEKERNEL")) oneKernel = atoi(e) != 0;
+        if (!lm) { r2 = allocVec(); Ap2 = allocVec(); for (auto& st : setS) for (auto& R : st) R = allocRed(); }
         if (const char* e = getenv("OPT_AMD_SC1")) storeMode = atoi(e);
         redA = allocRed(); redB = allocRed(); redQ = allocRed(); redC = allocRed();
         HIP_CHECK(hipMalloc((void**)&scal, 8 * sizeof(double))); HIP_CHECK(hipMemset(scal, 0, 8 * sizeof(double))); allocs.push_back(scal);
@@ -404,6 +409,49 @@ struct PcgSolver : SolverBase {
         trace.insert(trace.end(), {(double)sp.nIter, (double)lIter, aNum, aDen, bNum, q});
     }
 
+    // ---- PCG loop as one kernel per iteration (energy.h PcgIterArgs); returns false if the energy has no such kernel ----
+    bool runSingleKernelLoop(const T* preArg) {
+        Reduction prev[4] = {redC, Reduction{}, Reduction{}, Reduction{}};   // alphaNum_0 = sum r.p from PCGInit1
+        if (distributed) {   // ghost rows of r_0, M and p_0 (written as 0 by evalJTF / PCGInit1_Finish) come from the slab neighbours once
+            exchangeVector(r); exchangeVector(p); if (preArg) exchangeVector(preconditioner);
+            prev[0] = forConsumers(redC, 0);
+        }
+        int cur = 0;
+        for (int lIter = 0; lIter < sp.lIterations; ++lIter) {
+            PcgIterArgs<T> a{};
+            a.rOld = r; a.ApOld = Ap_X; a.pOld = p; a.rNew = r2; a.ApNew = Ap2; a.pNew = p2; a.delta = delta; a.pre = preArg; a.first = lIter == 0;
+            a.aNumPrev = prev[0]; a.aDenPrev = prev[1]; a.s2Prev = prev[2]; a.s3Prev = prev[3];
+            a.aNum = &setS[cur][0]; a.aDen = &setS[cur][1]; a.s2 = &setS[cur][2]; a.s3 = &setS[cur][3];
+            if (distributed && lIter > 0) exchangeVector(Ap_X);   // r and p ghost rows are kept current by the kernel itself
+            if (!E->pcgIteration(a, ctx)) { if (lIter == 0) return false; fprintf(stderr, "pcgIteration refused mid-loop\n"); exit(1); }
+            std::swap(r, r2); std::swap(Ap_X, Ap2); std::swap(p, p2);
+            for (int i = 0; i < 4; ++i) prev[i] = setS[cur][i];
+            if (distributed) {   // one all-reduce of the four sums
+                for (int i = 0; i < 4; ++i) k_finalizeSum<<<1, kBlock, 0, stream>>>(setS[cur][i].partials, setS[cur][i].n, scal + 4 + i);
+                comm.allReduceSum(comm.ctx, scal + 4, 4, (void*)stream);
+                for (int i = 0; i < 4; ++i) { prev[i].partials = scal + 4 + i; prev[i].n = 1; }
+            }
+            if (traceEnabled) {
+                const double aNum = hostSumLocal(prev[0]), aDen = hostSumLocal(prev[1]), s2 = hostSumLocal(prev[2]), s3 = hostSumLocal(prev[3]);
+                const T al = ((T)aDen > T(0)) ? (T)aNum / (T)aDen : T(0);
+                const double bNum = aNum - 2.0 * (double)al * s2 + (double)al * (double)al * s3;
+                trace.insert(trace.end(), {(double)sp.nIter, (double)lIter, aNum, aDen, bNum, 0.0});
+            }
+            cur ^= 1;
+        }
+        // the last iteration's delta += alpha p (PCGStep2, solver.t:461-462); r, z, p of that iteration are dead
+        finalizeLocal(prev[0], scal + 2);
+        { ScopedKernel k(ctx, "PCGStep2_delta"); k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, p, nPacks, scal + 2, prev[1].partials, prev[1].n); }
+        return true;
+    }
+    double hostSumLocal(const Reduction& R) {   // host value of an (already all-reduced, if distributed) reduction
+        HIP_CHECK(hipMemcpyAsync(hostBuf, R.partials, R.n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        double s = 0; for (int i = 0; i < R.n; ++i) s += hostBuf[i];
+        return s;
+    }
+    void finalizeLocal(const Reduction& R, double* dst) { k_finalizeSum<<<1, kBlock, 0, stream>>>(R.partials, R.n, dst); }
+
     // ---- init (solver.t:956-1007) ---------------------------------------------------------------------
     void init(void** params) override {
         timer.reset(); trace.clear();
@@ -457,7 +505,8 @@ struct PcgSolver : SolverBase {
         // feeds the next Step1; after the last iteration p is dead).
         bool pendingStep3 = false;
         Reduction bNum;
-        for (int lIter = 0; lIter < sp.lIterations; ++lIter) {
+        const bool single = !lm && oneKernel && r2 && runSingleKernelLoop(preArg);
+        for (int lIter = 0; !single && lIter < sp.lIterations; ++lIter) {
             bool applied = false;
             if (pendingStep3) {
                 if (fuseStep3) {

@@ -65,6 +65,7 @@ def test_hip_matches_golden(path):
     hist = z["cost_history"]
     np.testing.assert_allclose(costs, hist[:len(costs)], rtol=1e-9, atol=1e-18)
     t = g.trace()
-    np.testing.assert_allclose(t[:, 2:5], z["trace"][:len(t), 2:5], rtol=1e-7, atol=1e-300)
+    # PCG scalars of a converged solve are round-off noise (curve fit reaches cost 0): compare relative to the first iteration's scale
+    np.testing.assert_allclose(t[:, 2:5], z["trace"][:len(t), 2:5], rtol=1e-7, atol=1e-16 * np.abs(z["trace"][0, 2:5]).max())
     assert rel_err(device_unknowns(P, dev), z["final_unknowns"]) < 1e-9
     g.close()

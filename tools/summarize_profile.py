@@ -53,11 +53,13 @@ def main(src, out):
         rd_mb, wr_mb = 2 * f * 1024 / 1e6, w * 1024 / 1e6
         gbs = (rd_mb + wr_mb) / 1e3 / (avg_us * 1e-6) if avg_us > 0 else 0
         lines.append(f"| {short(name)} | {r['Calls']} | {avg_us:.1f} | {f:.0f} | {w:.0f} | {rd_mb:.1f} | {wr_mb:.1f} | {gbs:.0f} |")
-    # traffic of the dominant kernel (applyJTJ) for bench.py's roofline.traffic
+    # traffic of the dominant kernel for bench.py's roofline.traffic (bench_kernel = the name bench.py times it under)
     for r in rows:
-        if "iw_applyJTJ" in r["Name"] and ", true>(" in r["Name"]:
-            f = fetch.get(r["Name"], (0, 0.0))[1]; w = write.get(r["Name"], (0, 0.0))[1]
-            json.dump({"kernel": short(r["Name"]), "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024, "fetch_size_kib": f, "write_size_kib": w,
+        n = r["Name"]
+        bench_kernel = "PCGIteration" if "iw_pcgIter" in n else "PCGStep3+PCGStep1" if ("iw_applyJTJ" in n and ", true>(" in n) else None
+        if bench_kernel:
+            f = fetch.get(n, (0, 0.0))[1]; w = write.get(n, (0, 0.0))[1]
+            json.dump({"kernel": short(n), "bench_kernel": bench_kernel, "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024, "fetch_size_kib": f, "write_size_kib": w,
                        "correction": "2 x FETCH_SIZE (gfx950) + WRITE_SIZE", "avg_us_rocprof": float(r["AverageNs"]) / 1e3,
                        "workload": "image_warping 4096x4096 float", "source": os.path.basename(out)}, open(out + "_traffic.json", "w"))
             break
