@@ -12,6 +12,7 @@
 // f32/f64 atomic (gfx950 has both natively -- no CAS loop as in util.t:574-597).  Runs need not be sorted for
 // correctness, only for the aggregation to pay off.  Tail-vertex targets are irregular and use plain atomics.
 #include "energy.h"
+#include <hipcub/hipcub.hpp>
 
 namespace optamd {
 namespace {
@@ -135,6 +136,8 @@ struct ArapArgs {
     long N;
     const T* Offset; const T* Angle; const T* UrShape; const T* Constraints;
     T w_fit, w_reg; int nE; const int* v0; const int* v1;
+    T* D;   // per-edge dR3/da_k (U_v0 - U_v1), k = 0..2: 9 planes of nE scalars, rebuilt by the PCGInit1_Graph pass of every
+            // Gauss-Newton iteration so that the PCG loop's edge kernel needs no sin/cos (3 sincos per edge per iteration otherwise)
 };
 template <class T> struct V3 { T x, y, z; };
 template <class T> __device__ __forceinline__ V3<T> ld3(const T* p, long i) { return V3<T>{p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
@@ -209,7 +212,19 @@ __global__ __launch_bounds__(kBlock) void arap_edges(ArapArgs<T> A, const T* __r
         const long a0 = ok ? A.v0[e] : 0, a1 = ok ? A.v1[e] : 0;
         const V3<T> O0 = ld3(A.Offset, a0), O1 = ld3(A.Offset, a1), ang = ld3(A.Angle, a0), U0 = ld3(A.UrShape, a0), U1 = ld3(A.UrShape, a1);
         const V3<T> u{U0.x - U1.x, U0.y - U1.y, U0.z - U1.z};
-        V3<T> Ru, D0, D1, D2; arap_rot(ang, u, Ru, D0, D1, D2);
+        V3<T> Ru{0, 0, 0}, D0, D1, D2;
+        const long ee = ok ? e : 0, nE = A.nE;
+        if (MODE == 1 || MODE == 3) {   // PCG loop / model cost: tabulated derivative columns
+            D0 = V3<T>{A.D[ee], A.D[nE + ee], A.D[2 * nE + ee]}; D1 = V3<T>{A.D[3 * nE + ee], A.D[4 * nE + ee], A.D[5 * nE + ee]};
+            D2 = V3<T>{A.D[6 * nE + ee], A.D[7 * nE + ee], A.D[8 * nE + ee]};
+            if (MODE == 1) { V3<T> d0, d1, d2; arap_rot(ang, u, Ru, d0, d1, d2); }
+        } else {
+            arap_rot(ang, u, Ru, D0, D1, D2);
+            if (MODE == 2 && ok) {
+                A.D[e] = D0.x; A.D[nE + e] = D0.y; A.D[2 * nE + e] = D0.z; A.D[3 * nE + e] = D1.x; A.D[4 * nE + e] = D1.y; A.D[5 * nE + e] = D1.z;
+                A.D[6 * nE + e] = D2.x; A.D[7 * nE + e] = D2.y; A.D[8 * nE + e] = D2.z;
+            }
+        }
         const T w = A.w_reg;
         const V3<T> res{w * ((O0.x - O1.x) - Ru.x), w * ((O0.y - O1.y) - Ru.y), w * ((O0.z - O1.z) - Ru.z)};
         if (MODE == 0) { if (ok) acc += (double)(T(0.5) * dot3(res, res)); }
@@ -247,20 +262,170 @@ __global__ __launch_bounds__(kBlock) void arap_edges(ArapArgs<T> A, const T* __r
     if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
 }
 
+// ---- atomics-free J^T J p for ARAP: edge pass + vertex gather ----------------------------------------------------
+// The scatter formulation spends its time in 9 atomics per half-edge (measured: 261 us per applyJTJ at 500 k vertices /
+// 3 M half-edges, unchanged when the sin/cos were tabulated).  With the edge lists of every vertex known -- the
+// half-edges it heads (out) and the ones it tails (in), built once per graph by a counting sort -- the same sums are
+// gathers:  (J^T J p)_O(v) = w sum_{e in out(v)} Jp_e - w sum_{e in in(v)} Jp_e,   (J^T J p)_a(v)_k = -w sum_{e in out(v)} D_{e,k} . Jp_e.
+// Pass 1 writes Jp_e (3 scalars per half-edge), pass 2 is one thread per vertex.  Deterministic (lists are sorted by
+// edge id), no atomics, and the per-vertex kernel of the scatter path is folded into pass 2.
+struct GraphCsr { const int* outOff; const int* outIdx; const int* inOff; const int* inIdx; };
+
+__global__ __launch_bounds__(kBlock) void csr_count(const int* __restrict__ v0, const int* __restrict__ v1, int nE, int* __restrict__ outDeg, int* __restrict__ inDeg) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nE; e += gridDim.x * blockDim.x) { atomicAdd(outDeg + v0[e], 1); atomicAdd(inDeg + v1[e], 1); }
+}
+__global__ __launch_bounds__(kBlock) void csr_fill(const int* __restrict__ v0, const int* __restrict__ v1, int nE, const int* __restrict__ outOff, const int* __restrict__ inOff,
+                                                   int* __restrict__ outCur, int* __restrict__ inCur, int* __restrict__ outIdx, int* __restrict__ inIdx) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nE; e += gridDim.x * blockDim.x) {
+        const int a = v0[e], b = v1[e];
+        outIdx[outOff[a] + atomicAdd(outCur + a, 1)] = e;
+        inIdx[inOff[b] + atomicAdd(inCur + b, 1)] = e;
+    }
+}
+__global__ __launch_bounds__(kBlock) void csr_sort(long N, const int* __restrict__ off, int* __restrict__ idx) {   // per-vertex insertion sort: fixed summation order
+    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < N; v += (long)gridDim.x * blockDim.x) {
+        const int b = off[v], e = off[v + 1];
+        for (int i = b + 1; i < e; ++i) { const int x = idx[i]; int j = i - 1; while (j >= b && idx[j] > x) { idx[j + 1] = idx[j]; --j; } idx[j + 1] = x; }
+    }
+}
+__global__ __launch_bounds__(kBlock) void csr_checksum(const int* __restrict__ v0, const int* __restrict__ v1, int nE, unsigned long long* __restrict__ out) {
+    unsigned long long acc = 0;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nE; e += gridDim.x * blockDim.x)
+        acc += ((unsigned long long)(unsigned)v0[e] * 0x9E3779B97F4A7C15ull + (unsigned long long)(unsigned)v1[e] * 0xC2B2AE3D27D4EB4Full) ^ ((unsigned long long)e * 0x165667B19E3779F9ull);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(out, acc);
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void arap_edgeJp(ArapArgs<T> A, const T* __restrict__ v, T* __restrict__ Jp, double* __restrict__ partials) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    double acc = 0;
+    const long offA = 3 * A.N, nE = A.nE;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < nE; e += (long)gridDim.x * blockDim.x) {
+        const long a0 = A.v0[e], a1 = A.v1[e];
+        const V3<T> p0 = ld3(v, a0), p1 = ld3(v, a1), pa = ld3(v + offA, a0);
+        const T w = A.w_reg;
+        const T jx = w * (p0.x - p1.x) - w * (A.D[e] * pa.x + A.D[3 * nE + e] * pa.y + A.D[6 * nE + e] * pa.z);
+        const T jy = w * (p0.y - p1.y) - w * (A.D[nE + e] * pa.x + A.D[4 * nE + e] * pa.y + A.D[7 * nE + e] * pa.z);
+        const T jz = w * (p0.z - p1.z) - w * (A.D[2 * nE + e] * pa.x + A.D[5 * nE + e] * pa.y + A.D[8 * nE + e] * pa.z);
+        // {J p, D_k . J p}: everything the vertex pass needs from this half-edge, 24 contiguous bytes
+        T* o = Jp + 6 * e;
+        o[0] = jx; o[1] = jy; o[2] = jz;
+        o[3] = A.D[e] * jx + A.D[nE + e] * jy + A.D[2 * nE + e] * jz;
+        o[4] = A.D[3 * nE + e] * jx + A.D[4 * nE + e] * jy + A.D[5 * nE + e] * jz;
+        o[5] = A.D[6 * nE + e] * jx + A.D[7 * nE + e] * jy + A.D[8 * nE + e] * jz;
+        acc += (double)(jx * jx + jy * jy + jz * jz);   // sum_u p_u (J^T J p)_u of this edge = |J p|^2 (o.t:2117-2122)
+    }
+    double t = blockReduceSum(acc, scratch);
+    if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
+}
+// 16 lanes per vertex: lanes 0-7 walk the out-list, lanes 8-15 the in-list (a mesh vertex has ~6 of each), so the
+// dependent index -> record gathers of one vertex are in flight together instead of in a 12-trip serial loop
+// (one thread per vertex: 113 us per launch at 500 k vertices; this shape: see profiles).
+constexpr int kLanesPerVertex = 16;
+template <class T>
+__global__ __launch_bounds__(kBlock) void arap_vertexGather(ArapArgs<T> A, GraphCsr G, const T* __restrict__ v, const T* __restrict__ Jp, T* __restrict__ out, const T* __restrict__ CtC,
+                                                            double* __restrict__ partials) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    double acc = 0;
+    const long offA = 3 * A.N;
+    const int sub = threadIdx.x % kLanesPerVertex, slot = sub & 7;
+    const bool inList = sub >= 8;
+    const long nGroups = (A.N + (kBlock / kLanesPerVertex) - 1) / (kBlock / kLanesPerVertex);
+    for (long g = blockIdx.x; g < nGroups; g += gridDim.x) {       // uniform trip count: the shuffles below need whole waves
+        const long i = g * (kBlock / kLanesPerVertex) + threadIdx.x / kLanesPerVertex;
+        const bool ok = i < A.N;
+        const long iv = ok ? i : 0;
+        const T w = A.w_reg;
+        T s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
+        const int* off = inList ? G.inOff : G.outOff; const int* idx = inList ? G.inIdx : G.outIdx;
+        const int b = off[iv], e = ok ? off[iv + 1] : b;
+        for (int k = b + slot; k < e; k += 8) {
+            const T* o = Jp + 6 * (long)idx[k];
+            if (inList) { s0 -= w * o[0]; s1 -= w * o[1]; s2 -= w * o[2]; }
+            else { s0 += w * o[0]; s1 += w * o[1]; s2 += w * o[2]; s3 -= w * o[3]; s4 -= w * o[4]; s5 -= w * o[5]; }
+        }
+#pragma unroll
+        for (int m = 1; m < kLanesPerVertex; m <<= 1) {
+            s0 += __shfl_xor(s0, m, kWave); s1 += __shfl_xor(s1, m, kWave); s2 += __shfl_xor(s2, m, kWave);
+            s3 += __shfl_xor(s3, m, kWave); s4 += __shfl_xor(s4, m, kWave); s5 += __shfl_xor(s5, m, kWave);
+        }
+        if (ok && sub == 0) {
+            // per-vertex ("centred") part: fitting term and, for LM, CtC p  -- what arap_vertices<3> computes
+            const bool valid = A.Constraints[3 * i] >= T(-999999.9);
+            const T wf = valid ? A.w_fit : T(0);
+            const V3<T> p = ld3(v, i), pa = ld3(v + offA, i);
+            V3<T> q{wf * wf * p.x, wf * wf * p.y, wf * wf * p.z}, qa{0, 0, 0};
+            if (CtC) { const V3<T> cO = ld3(CtC, i), cA = ld3(CtC + offA, i); q.x += cO.x * p.x; q.y += cO.y * p.y; q.z += cO.z * p.z; qa.x = cA.x * pa.x; qa.y = cA.y * pa.y; qa.z = cA.z * pa.z; }
+            acc += (double)(dot3(p, q) + dot3(pa, qa));
+            out[3 * i] = q.x + s0; out[3 * i + 1] = q.y + s1; out[3 * i + 2] = q.z + s2;
+            out[offA + 3 * i] = qa.x + s3; out[offA + 3 * i + 1] = qa.y + s4; out[offA + 3 * i + 2] = qa.z + s5;
+        }
+    }
+    double t = blockReduceSum(acc, scratch);
+    if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
+}
+
 template <class T>
 struct ArapOps : EnergyOps<T> {
     ArapArgs<T> A{};
     int cus = 256;
+    long dCapacity = 0;
+    // edge lists per vertex for the gather path (rebuilt when the graph arrays change)
+    int *outOff = nullptr, *outIdx = nullptr, *inOff = nullptr, *inIdx = nullptr, *cursors = nullptr; T* Jp = nullptr;
+    void* scanTemp = nullptr; size_t scanTempBytes = 0; unsigned long long* dChecksum = nullptr;
+    const int *csrV0 = nullptr, *csrV1 = nullptr; int csrNE = -1; unsigned long long csrSum = 0; bool csrValid = false;
+    bool useGather = true;   // OPT_AMD_ARAP_GATHER=0: scatter with wave-aggregated atomics instead
+    ~ArapOps() override {
+        for (void* q : {(void*)A.D, (void*)outOff, (void*)outIdx, (void*)inOff, (void*)inIdx, (void*)cursors, (void*)Jp, scanTemp, (void*)dChecksum}) if (q) (void)hipFree(q);
+    }
+    void ensureCsr(LaunchCtx& ctx) {
+        hipStream_t st = ctx.stream;
+        if (!dChecksum) HIP_CHECK(hipMalloc((void**)&dChecksum, 8));
+        HIP_CHECK(hipMemsetAsync(dChecksum, 0, 8, st));
+        const int ge = edgeGrid(A.nE, cus);
+        csr_checksum<<<ge, kBlock, 0, st>>>(A.v0, A.v1, A.nE, dChecksum);
+        unsigned long long sum = 0;
+        HIP_CHECK(hipMemcpyAsync(&sum, dChecksum, 8, hipMemcpyDeviceToHost, st)); HIP_CHECK(hipStreamSynchronize(st));
+        if (csrValid && csrV0 == A.v0 && csrV1 == A.v1 && csrNE == A.nE && csrSum == sum) return;
+        ScopedKernel k(ctx, "buildEdgeLists");
+        for (void* q : {(void*)outOff, (void*)outIdx, (void*)inOff, (void*)inIdx, (void*)cursors, (void*)Jp}) if (q) HIP_CHECK(hipFree(q));
+        const size_t nv = (size_t)A.N + 1;
+        HIP_CHECK(hipMalloc((void**)&outOff, nv * 4)); HIP_CHECK(hipMalloc((void**)&inOff, nv * 4)); HIP_CHECK(hipMalloc((void**)&cursors, 2 * nv * 4));
+        HIP_CHECK(hipMalloc((void**)&outIdx, (size_t)std::max(1, A.nE) * 4)); HIP_CHECK(hipMalloc((void**)&inIdx, (size_t)std::max(1, A.nE) * 4));
+        HIP_CHECK(hipMalloc((void**)&Jp, (size_t)6 * std::max(1, A.nE) * sizeof(T)));
+        HIP_CHECK(hipMemsetAsync(cursors, 0, 2 * nv * 4, st));
+        int* outDeg = cursors; int* inDeg = cursors + nv;
+        csr_count<<<ge, kBlock, 0, st>>>(A.v0, A.v1, A.nE, outDeg, inDeg);
+        size_t need = 0;
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, outDeg, outOff, (int)nv, st));
+        if (need > scanTempBytes) { if (scanTemp) HIP_CHECK(hipFree(scanTemp)); HIP_CHECK(hipMalloc(&scanTemp, need)); scanTempBytes = need; }
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTemp, need, outDeg, outOff, (int)nv, st));
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTemp, need, inDeg, inOff, (int)nv, st));
+        HIP_CHECK(hipMemsetAsync(cursors, 0, 2 * nv * 4, st));
+        csr_fill<<<ge, kBlock, 0, st>>>(A.v0, A.v1, A.nE, outOff, inOff, outDeg, inDeg, outIdx, inIdx);
+        csr_sort<<<vgrid(), kBlock, 0, st>>>(A.N, outOff, outIdx);
+        csr_sort<<<vgrid(), kBlock, 0, st>>>(A.N, inOff, inIdx);
+        csrV0 = A.v0; csrV1 = A.v1; csrNE = A.nE; csrSum = sum; csrValid = true;
+    }
     ArapOps(const unsigned* dims) {
         A.N = dims[0];
         this->usePreconditioner = true; this->usesGraph = true;                  // arap_mesh_deformation.t:9
         this->addUnknown(2, A.N, 3); this->addUnknown(3, A.N, 3);                // Offset, Angle (:4-5)
         int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (const char* e = getenv("OPT_AMD_ARAP_GATHER")) useGather = atoi(e) != 0;
     }
-    void bind(void** p, LaunchCtx&) override {
+    void bind(void** p, LaunchCtx& ctx) override {
         A.w_fit = (T) * (const float*)p[0]; A.w_reg = (T) * (const float*)p[1];
         A.Offset = (const T*)p[2]; A.Angle = (const T*)p[3]; A.UrShape = (const T*)p[4]; A.Constraints = (const T*)p[5];
         A.nE = *(const int*)p[6]; A.v0 = (const int*)p[7]; A.v1 = (const int*)p[8];   // Graph("G", 6, "v0", {N}, 7, "v1", {N}, 8)
+        if (A.nE > dCapacity) {
+            if (A.D) HIP_CHECK(hipFree(A.D));
+            dCapacity = A.nE;
+            HIP_CHECK(hipMalloc((void**)&A.D, (size_t)9 * dCapacity * sizeof(T)));
+            HIP_CHECK(hipMemset(A.D, 0, (size_t)9 * dCapacity * sizeof(T)));
+        }
+        if (useGather) ensureCsr(ctx);
     }
     T* unknownPtr(int img) const override { return const_cast<T*>(img == 0 ? A.Offset : A.Angle); }
     int vgrid() const { return (int)std::max<long>(1, std::min<long>((A.N + kBlock - 1) / kBlock, kMaxPartials / 2)); }
@@ -276,8 +441,14 @@ struct ArapOps : EnergyOps<T> {
     }
     void applyJTJ(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) override {
         const int gv = vgrid(), ge = edgeGrid(A.nE, cus);
-        { ScopedKernel k(ctx, "PCGStep1"); arap_vertices<T, 3><<<gv, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, CtC, dot ? dot->partials : nullptr); }
-        { ScopedKernel k(ctx, "PCGStep1_Graph"); arap_edges<T, 3><<<ge, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, dot ? dot->partials + gv : nullptr); }
+        if (useGather) {
+            GraphCsr G{outOff, outIdx, inOff, inIdx};
+            { ScopedKernel k(ctx, "PCGStep1_Graph"); arap_edgeJp<T><<<ge, kBlock, 0, ctx.stream>>>(A, v, Jp, dot ? dot->partials + gv : nullptr); }
+            { ScopedKernel k(ctx, "PCGStep1"); arap_vertexGather<T><<<gv, kBlock, 0, ctx.stream>>>(A, G, v, Jp, out, CtC, dot ? dot->partials : nullptr); }   // gv <= kMaxPartials/2 workgroups, grid-stride over 16-vertex groups
+        } else {
+            { ScopedKernel k(ctx, "PCGStep1"); arap_vertices<T, 3><<<gv, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, CtC, dot ? dot->partials : nullptr); }
+            { ScopedKernel k(ctx, "PCGStep1_Graph"); arap_edges<T, 3><<<ge, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, dot ? dot->partials + gv : nullptr); }
+        }
         if (dot) dot->n = gv + ge;
     }
     void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {

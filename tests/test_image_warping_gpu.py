@@ -155,3 +155,23 @@ def test_full_size_properties():
         c.append(g.cost())
     assert len(c) == 3 and c[2] < c[1] < c[0]
     g.close()
+
+
+@pytest.mark.parametrize("double", [False, True])
+def test_single_kernel_iteration_matches_three_kernel_loop(double, monkeypatch):
+    """The fused one-kernel-per-iteration PCG loop evaluates the beta numerator by expanding sum M (r - alpha Ap)^2
+    (energy.h PcgIterArgs).  Over a long solve (2 GN x 200 PCG) it must track the Step1/Step2/Step3 loop: identical
+    math, so double agrees to 1e-9 and float to the 1e-5 cost bar."""
+    P = wl.image_warping(200, 160, double=double, random_state=21, mask_fraction=0.05, perturb=0.4)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("OPT_AMD_ONEKERNEL", mode)
+        g = hip_solver(P, nIterations=2, lIterations=200)
+        dev = api.to_device(P)
+        g.init(dev); costs = [g.cost()]
+        while g.step(dev):
+            costs.append(g.cost())
+        res[mode] = (costs, device_unknowns(P, dev))
+        g.close()
+    np.testing.assert_allclose(res["1"][0], res["0"][0], rtol=1e-9 if double else 1e-5)
+    assert rel_err(res["1"][1], res["0"][1]) < (1e-8 if double else 1e-4)

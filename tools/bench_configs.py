@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Time BASELINE.json's configs 1-4 on one MI355X (the metric itself, config 5 / image_warping 4096^2, is bench.py).
+
+    python tools/bench_configs.py > gpurun_out/configs.json
+
+One JSON line per config: solver wall time (Opt_ProblemInit + all Opt_ProblemStep calls, inputs resident in HBM), PCG
+iterations/s, final cost, and per-kernel hipEvent averages from a second, timed solve.  The iteration counts are
+the reference harness defaults.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch                                   # noqa: E402
+from opt_amd import api, workloads as wl       # noqa: E402
+
+CONFIGS = [
+    ("config1 poisson_image_editing 256x256 float GN 1x10", lambda: wl.poisson_image_editing(256, 256), "gaussNewtonGPU", 1, 10),
+    ("poisson_image_editing 2048x2048 float GN 1x100", lambda: wl.poisson_image_editing(2048, 2048), "gaussNewtonGPU", 1, 100),
+    ("config2 image_warping 2048x2048 float GN 8x400", lambda: wl.image_warping(2048, 2048), "gaussNewtonGPU", 8, 400),
+    ("config3 shape_from_shading 1024x1024 double LM 60x10", lambda: wl.shape_from_shading(1024, 1024, double=True), "LMGPU", 60, 10),
+    ("config4 arap_mesh_deformation 708x707 grid (500k vertices) float GN 20x100", lambda: wl.arap_mesh_deformation(708, 707), "gaussNewtonGPU", 20, 100),
+    ("image_warping 2048x2048 float LM 8x400", lambda: wl.image_warping(2048, 2048), "LMGPU", 8, 400),
+]
+
+
+def run(P, kind, nit, lit, timing):
+    dev = api.to_device(P)
+    s = api.Solver(api.energy_file(P.energy), kind, P.dims, double=P.double, timing=timing)
+    s.set_parameter("nIterations", nit); s.set_parameter("lIterations", lit)
+    if timing or kind == "LMGPU":
+        s.enable_trace(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.init(dev)
+    c0 = s.cost(); steps = 0
+    while s.step(dev):
+        steps += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kt = s.kernel_timings() if timing else None
+    out = (dt, c0, s.cost(), steps, kt)
+    s.close()
+    return out
+
+
+def main():
+    for name, make, kind, nit, lit in CONFIGS:
+        P = make()
+        run(make(), kind, 1, min(lit, 5), False)                     # warm-up (module load, allocator)
+        dt, c0, c1, steps, _ = run(P, kind, nit, lit, False)
+        _, _, _, _, kt = run(make(), kind, min(nit, 3), lit, True)
+        pcg = sum(v[0] for k, v in kt.items() if k in ("PCGStep2", "PCGStep2_2ndHalf", "PCGIteration")) if kt else 0
+        print(json.dumps({"config": name, "solver": kind, "double": P.double, "wall_s": dt, "outer_steps": steps, "cost_initial": c0, "cost_final": c1,
+                          "pcg_iters_per_s_nominal": steps * lit / dt, "kernel_avg_us": {k: round(v[1] / v[0] * 1e3, 2) for k, v in kt.items()},
+                          "pcg_iterations_in_timed_solve": pcg}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
