@@ -67,7 +67,33 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     build_comm(force=force, verbose=verbose)
+    build_examples(force=force, verbose=verbose)
     return LIB
+
+
+EXAMPLES_DIR = os.path.join(HERE, "..", "examples")
+EXAMPLES = ["minimal_laplacian", "minimal_graph_only", "create_delete_cycle", "image_warping_example"]
+
+
+def build_examples(force=False, verbose=False):
+    """C++ callers of the C ABI (examples/*.cpp -> examples/bin/*), linked against libOpt.so like a reference user would."""
+    bindir = os.path.join(EXAMPLES_DIR, "bin")
+    os.makedirs(bindir, exist_ok=True)
+    outs, procs = [], []
+    hdr = max(os.path.getmtime(os.path.join(EXAMPLES_DIR, "common.h")), os.path.getmtime(os.path.join(HERE, "..", "include", "Opt.h")))
+    for name in EXAMPLES:
+        src, out = os.path.join(EXAMPLES_DIR, name + ".cpp"), os.path.join(bindir, name)
+        outs.append(out)
+        if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), hdr, os.path.getmtime(LIB)):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(HERE, "..", "include"), src, "-o", out,
+                   "-L" + LIBDIR, "-lOpt", "-Wl,-rpath," + LIBDIR]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((src, subprocess.Popen(cmd)))
+    failed = [s for s, p in procs if p.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed for: " + ", ".join(failed))
+    return outs
 
 
 COMM_LIB = os.path.join(LIBDIR, "libOptComm.so")

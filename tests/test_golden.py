@@ -33,7 +33,7 @@ def test_oracle_reproduces_golden(oracle_lib, path):
     f, d = o.eval_jtf(P.params)
     assert rel_err(f, z["jtf"]) < 1e-13 and rel_err(d, z["diag"]) < 1e-13
     assert rel_err(o.apply_jtj(P.params, z["p"]), z["jtjp_unmasked"]) < 1e-13
-    o.set("nIterations", 3); o.set("lIterations", 10)
+    o.set("nIterations", int(z["n_iterations"]) if "n_iterations" in z.files else 3); o.set("lIterations", 10)
     o.solve(P.params)
     np.testing.assert_allclose(o.cost_history(), z["cost_history"], rtol=1e-12, atol=1e-300)
     np.testing.assert_allclose(o.trace(), z["trace"], rtol=1e-10, atol=1e-300)
@@ -46,7 +46,7 @@ def test_hip_matches_golden(path):
     from opt_amd import api
     from helpers import active_mask, device_unknowns, hip_solver
     z, P, kind = _load(path)
-    g = hip_solver(P, kind, nIterations=3, lIterations=10)
+    g = hip_solver(P, kind, nIterations=int(z["n_iterations"]) if "n_iterations" in z.files else 3, lIterations=10)
     dev = api.to_device(P)
     assert abs(g.eval_cost(dev) - float(z["cost"])) <= 1e-12 * abs(float(z["cost"])) + 1e-300
     act = active_mask(P)
