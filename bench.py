@@ -7,11 +7,13 @@ A "step" is one Opt_ProblemStep: one Gauss-Newton iteration = evalJTF + `lIterat
 reference's examples/image_warping/src/main.cpp:113-114) matrix-free PCG iterations + update + cost.
 value = K * lIterations / wall time of the K timed steps (max over ranks), inputs resident in HBM.
 N > 1 (launched by torch.distributed.run, one rank per GPU): the 4096^2 image is split into row slabs,
-1-row halo exchange of p + scalar all-reduces over RCCL -- total work fixed => "strong" scaling.
+one 1-row halo exchange + one 4-double all-reduce per PCG iteration over RCCL -- total work fixed => "strong" scaling.
 
 The same JSON line carries
-  roofline     : the dominant kernel (PCGStep1 = applyJTJ) timed with hipEvents on the solver's stream,
-                 achieved = 48 B/pixel (SURVEY.md 8d) * pixels / average launch time, against 8 TB/s;
+  roofline     : the dominant kernel timed with hipEvents on the solver's stream.  For Gauss-Newton image_warping that is
+                 `PCGIteration`, ONE launch per PCG iteration doing the work of the reference's PCGStep1 + PCGStep2 + PCGStep3,
+                 so achieved = (48 + 96 + 36) B/pixel (SURVEY.md 8d) * pixels / average launch time, against 8 TB/s;
+                 `traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/;
   cpu_baseline : the CPU oracle (a port, not the reference) timed on a bounded sample on the host cores.
 """
 import argparse
