@@ -17,12 +17,15 @@
 //    solve step into a 1-byte flag image, and cos/sin(a) is tabulated once per Gauss-Newton iteration,
 //    so the PCG loop's applyJTJ reads 12 (p) + 8 (cos,sin) + 8 (U) + 1 (flags) and writes 12 B/pixel
 //    instead of gathering five arrays through five neighbours;
-//  * applyJTJ marches down the image: a workgroup owns a 256-pixel-wide column strip and a contiguous
-//    range of rows, each lane keeps the rows y-1, y, y+1 of its column in registers, so vertical
-//    neighbours cost no memory traffic at all and each row is fetched from HBM once (plus 2 halo rows
-//    per workgroup); horizontal neighbours are unit-stride re-reads that hit L1/L2;
+//  * the stencil kernels march down the image: a workgroup owns a column strip (62 output pixels per wave)
+//    and a contiguous range of rows, each lane keeps the rows y-1, y, y+1 of its column in registers, so
+//    vertical neighbours cost no memory traffic at all and each row is fetched from HBM once (plus 2 halo
+//    rows per workgroup); horizontal neighbours are whole-wave DPP shifts of registers (no LDS);
 //  * the grid is sized to be co-resident (one wave of workgroups, rows split evenly) instead of
-//    thousands of 16x16 tiles, so there is no tail and only ~1k partial sums for the dot product.
+//    thousands of 16x16 tiles, so there is no tail and only ~1k partial sums per dot product;
+//  * for Gauss-Newton the whole PCG iteration (the reference's PCGStep1 + PCGStep2 + PCGStep3) is ONE such
+//    kernel, iw_pcgIter (125 B/pixel of HBM traffic against 180 B/pixel algorithmic); iw_applyJTJ (with the
+//    previous PCGStep3 optionally fused in) serves LM, probes and the OPT_AMD_ONEKERNEL=0 fallback.
 #include "energy.h"
 #include <cstdint>
 
