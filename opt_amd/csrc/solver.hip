@@ -99,6 +99,15 @@ __global__ __launch_bounds__(kBlock) void k_finalizeSum(const double* __restrict
     if (threadIdx.x == 0) total[0] = s;
 }
 
+// total[k] = sum(partials_k[0..n_k)) for four reductions at once: workgroup k handles array k (slab mode: one launch
+// before the single 4-double all-reduce of the fused PCG iteration)
+struct Partials4 { const double* p[4]; int n[4]; };
+__global__ __launch_bounds__(kBlock) void k_finalizeSum4(Partials4 in, double* __restrict__ total) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    double s = sumPartials(in.p[blockIdx.x], in.n[blockIdx.x], scratch);
+    if (threadIdx.x == 0) total[blockIdx.x] = s;
+}
+
 // PCGStep2: solver.t:446-489
 template <class T, bool LM, int WT>
 __global__ __launch_bounds__(kBlock) void k_step2(T* __restrict__ delta, const T* __restrict__ p, T* __restrict__ r, const T* __restrict__ Ap,
@@ -427,7 +436,8 @@ struct PcgSolver : SolverBase {
             std::swap(r, r2); std::swap(Ap_X, Ap2); std::swap(p, p2);
             for (int i = 0; i < 4; ++i) prev[i] = setS[cur][i];
             if (distributed) {   // one all-reduce of the four sums
-                for (int i = 0; i < 4; ++i) k_finalizeSum<<<1, kBlock, 0, stream>>>(setS[cur][i].partials, setS[cur][i].n, scal + 4 + i);
+                Partials4 in4; for (int i = 0; i < 4; ++i) { in4.p[i] = setS[cur][i].partials; in4.n[i] = setS[cur][i].n; }
+                k_finalizeSum4<<<4, kBlock, 0, stream>>>(in4, scal + 4);
                 comm.allReduceSum(comm.ctx, scal + 4, 4, (void*)stream);
                 for (int i = 0; i < 4; ++i) { prev[i].partials = scal + 4 + i; prev[i].n = 1; }
             }
