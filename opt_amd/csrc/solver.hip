@@ -299,6 +299,7 @@ struct PcgSolver : SolverBase {
     double* hostBuf = nullptr;          // pinned
     T prevCost = 0;
     T trust_region_radius = 0, radius_decrease_factor = 0, min_lm_diagonal = 0, max_lm_diagonal = 0;   // pd.parameters (o.t:933-938)
+    hipEvent_t overallStart = nullptr; bool overallOpen = false;
     OptAmd_SlabComm comm{};
     bool distributed = false;
 
@@ -465,6 +466,8 @@ struct PcgSolver : SolverBase {
     // ---- init (solver.t:956-1007) ---------------------------------------------------------------------
     void init(void** params) override {
         timer.reset(); trace.clear();
+        if (overallOpen) { timer.pool.push_back(overallStart); overallOpen = false; }
+        if (timer.enabled) { overallStart = timer.get(); HIP_CHECK(hipEventRecord(overallStart, stream)); overallOpen = true; }   // "overall": init -> cleanup (solver.t:959, 1011)
         E->bind(params, ctx);
         sp.nIter = 0;
         if (lm) {
@@ -477,7 +480,11 @@ struct PcgSolver : SolverBase {
     }
     void cleanup() {   // solver.t:1009-1014
         if (verbosity > 0) printf("final cost=%f\n", (double)prevCost);
-        if (timer.enabled) { timer.evaluate(); if (verbosity > 0) timer.print(); }
+        if (timer.enabled) {
+            if (overallOpen) { KernelTimer::Rec rec{"overall", overallStart, timer.get()}; HIP_CHECK(hipEventRecord(rec.b, stream)); timer.recs.push_back(rec); overallOpen = false; }
+            timer.evaluate();
+            if (verbosity > 0) timer.print();
+        }
     }
 
     // ---- step (solver.t:1016-1177) --------------------------------------------------------------------
