@@ -30,11 +30,13 @@ class Problem:
                        self.double, dict(self.meta))
 
 
-def image_warping(W, H=None, double=False, random_state=None, mask_fraction=0.0, perturb=0.0):
+def image_warping(W, H=None, double=False, random_state=None, mask_fraction=0.0, perturb=0.0, jitter_urshape=0.0):
     """examples/image_warping/src/CombinedSolver.h:110-207 + main.cpp:98-108, constraint ramp alpha=1.
 
     random_state/mask_fraction/perturb > 0 give the randomised variant used by the parity tests
     (masked pixels, non-zero angles, perturbed offsets) so every branch of the energy is exercised.
+    jitter_urshape > 0 moves the rest positions off the pixel lattice (the reference example always uses the
+    lattice itself; the backend has a fast path for it and a general path for everything else).
     """
     H = H or W
     ft = np.float64 if double else np.float32
@@ -56,6 +58,9 @@ def image_warping(W, H=None, double=False, random_state=None, mask_fraction=0.0,
             constraints[y, x] = (int(x1 * sx), int(y1 * sy))
     if random_state is not None:
         rng = np.random.default_rng(random_state)
+        if jitter_urshape > 0:
+            urshape += (jitter_urshape * rng.standard_normal((H, W, 2))).astype(ft)
+            offset = urshape.copy()
         if mask_fraction > 0:
             mask[rng.random((H, W)) < mask_fraction] = 255.0
         if perturb > 0:

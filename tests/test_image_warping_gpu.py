@@ -15,15 +15,18 @@ pytestmark = pytest.mark.gpu
 SIZES = [(64, 64), (257, 129), (31, 5), (300, 1), (1, 40)]
 
 
-def _problem(W, H, double, seed=7):
-    return wl.image_warping(W, H, double=double, random_state=seed, mask_fraction=0.08, perturb=0.4)
+def _problem(W, H, double, seed=7, jitter=0.0):
+    # jitter = 0: rest shape is the pixel lattice (the reference example's case, lattice fast path);
+    # jitter > 0: arbitrary rest shape (general kernels)
+    return wl.image_warping(W, H, double=double, random_state=seed, mask_fraction=0.08, perturb=0.4, jitter_urshape=jitter)
 
 
+@pytest.mark.parametrize("jitter", [0.0, 0.2])
 @pytest.mark.parametrize("W,H", SIZES)
 @pytest.mark.parametrize("double", [False, True])
-def test_cost_jtf_diag_jtjp(oracle_lib, W, H, double):
+def test_cost_jtf_diag_jtjp(oracle_lib, W, H, double, jitter):
     import torch
-    P = _problem(W, H, double)
+    P = _problem(W, H, double, jitter=jitter)
     tol = 1e-11 if double else 2e-5
     o = oracle_solver(oracle_lib, P)
     g = hip_solver(P)
@@ -48,10 +51,11 @@ def test_cost_jtf_diag_jtjp(oracle_lib, W, H, double):
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("jitter", [0.0, 0.2])
 @pytest.mark.parametrize("double", [False, True])
-def test_gn_trajectory(oracle_lib, double):
+def test_gn_trajectory(oracle_lib, double, jitter):
     """3 GN x 10 PCG on 48x40: per-PCG-iteration scalars, per-GN cost and final unknowns."""
-    P = _problem(48, 40, double, seed=3)
+    P = _problem(48, 40, double, seed=3, jitter=jitter)
     o = oracle_solver(oracle_lib, P, nIterations=3, lIterations=10)
     g = hip_solver(P, nIterations=3, lIterations=10)
     g.enable_trace()
@@ -175,3 +179,18 @@ def test_single_kernel_iteration_matches_three_kernel_loop(double, monkeypatch):
         g.close()
     np.testing.assert_allclose(res["1"][0], res["0"][0], rtol=1e-9 if double else 1e-5)
     assert rel_err(res["1"][1], res["0"][1]) < (1e-8 if double else 1e-4)
+
+
+def test_lattice_fast_path_matches_the_general_path(monkeypatch):
+    """The unit-lattice kernel drops the UrShape loads; its arithmetic is the general kernel's with U_c - U_n = -n folded
+    in (only FMA contraction may differ), so on a lattice input both must agree to rounding."""
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("OPT_AMD_LATTICE", flag)
+        P = wl.image_warping(150, 70, random_state=4, mask_fraction=0.05, perturb=0.3)
+        g = hip_solver(P, nIterations=2, lIterations=25)
+        dev = api.to_device(P)
+        g.solve(dev)
+        outs.append((g.cost(), device_unknowns(P, dev)))
+        g.close()
+    assert abs(outs[0][0] - outs[1][0]) <= 2e-6 * outs[1][0] and rel_err(outs[0][1], outs[1][1]) < 2e-6
