@@ -129,3 +129,182 @@ def test_unknown_energy_or_kind_rejected(oracle_lib):
         oracle_lib.OracleSolver("no_such_energy", "gaussNewtonGPU", False, (4, 4))
     with pytest.raises(ValueError):
         oracle_lib.OracleSolver("image_warping", "gradientDescentCPU", False, (4, 4))   # o.t:122
+
+
+def _laplacian_system(A):
+    """Residual matrix of tests/minimal/laplacian.t written out by hand: rows 0.2 (X - A), X(0,0) - X(1,0), X(0,0) - X(0,1);
+    a row whose stencil leaves the image is dropped (it is identically 0, o.t:1930-1933)."""
+    import scipy.sparse as sp
+    H, W = A.shape
+    idx = np.arange(H * W).reshape(H, W)
+    rows, cols, vals, rhs = [], [], [], []
+    def add(entries, b):
+        r = len(rhs)
+        for c, v in entries:
+            rows.append(r); cols.append(c); vals.append(v)
+        rhs.append(b)
+    for y in range(H):
+        for x in range(W):
+            add([(idx[y, x], 0.2)], 0.2 * A[y, x])
+            if x + 1 < W:
+                add([(idx[y, x], 1.0), (idx[y, x + 1], -1.0)], 0.0)
+            if y + 1 < H:
+                add([(idx[y, x], 1.0), (idx[y + 1, x], -1.0)], 0.0)
+    return sp.csr_matrix((vals, (rows, cols)), shape=(len(rhs), H * W)), np.array(rhs)
+
+
+def test_linear_energy_minimiser_matches_independent_least_squares(oracle_lib):
+    """Known answer independent of the oracle's own machinery: laplacian.t is linear, so Gauss-Newton with enough
+    PCG iterations must land on the least-squares solution of the residual system written out by hand and solved
+    with scipy.  Pins cost scaling (1/2 sum r^2), boundary handling and the CG loop together."""
+    import scipy.sparse.linalg as spla
+    P = wl.laplacian(21, 17, seed=5)
+    A = P.params[1].astype(np.float64)
+    J, b = _laplacian_system(A)
+    x_ls = spla.lsqr(J, b, atol=1e-14, btol=1e-14, iter_lim=20000)[0]
+    cost_ls = 0.5 * np.sum((J @ x_ls - b) ** 2)
+    s = oracle_solver(oracle_lib, P, nIterations=3, lIterations=400)
+    s.solve(P.params)
+    assert rel_err(P.params[0].reshape(-1), x_ls) < 2e-4            # float solver vs double least squares
+    assert abs(s.cost() - cost_ls) <= 2e-5 * cost_ls
+
+
+def test_poisson_minimiser_matches_independent_least_squares(oracle_lib):
+    """Same for poisson_image_editing.t (double): unknowns = pixels with M == 0; every in-bounds directed edge (c, n) whose
+    CENTRE c is unmasked is a residual row (X_c - X_n) - (T_c - T_n) in the cost; rows centred on masked pixels do not count
+    towards the cost but still pull on their unmasked neighbour through J^T F -- so the stationary point GN
+    reaches is that of the row set {centre unmasked} + {centre masked, neighbour unmasked}."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    P = wl.poisson_image_editing(14, 11, double=True, seed=2)
+    X0, T, M = P.params[0].copy(), P.params[1], P.params[2]
+    H, W = M.shape
+    free = M == 0
+    col = -np.ones((H, W), dtype=int); col[free] = np.arange(free.sum())
+    rows, cols, vals, rhs = [], [], [], []
+    for y in range(H):
+        for x in range(W):
+            for dx, dy in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+                nx, ny = x + dx, y + dy
+                if not (0 <= nx < W and 0 <= ny < H):
+                    continue
+                if not (free[y, x] or free[ny, nx]):
+                    continue
+                for k in range(4):
+                    r = len(rhs)
+                    bk = T[y, x, k] - T[ny, nx, k]
+                    if free[y, x]:
+                        rows.append(r); cols.append(4 * col[y, x] + k); vals.append(1.0)
+                    else:
+                        bk -= X0[y, x, k]
+                    if free[ny, nx]:
+                        rows.append(r); cols.append(4 * col[ny, nx] + k); vals.append(-1.0)
+                    else:
+                        bk += X0[ny, nx, k]
+                    rhs.append(bk)
+    J = sp.csr_matrix((vals, (rows, cols)), shape=(len(rhs), 4 * int(free.sum())))
+    x_ls = spla.lsqr(J, np.array(rhs), atol=1e-14, btol=1e-14, iter_lim=50000)[0]
+    s = oracle_solver(oracle_lib, P, nIterations=2, lIterations=600)
+    s.solve(P.params)
+    got = P.params[0][free].reshape(-1)
+    assert rel_err(got, x_ls) < 1e-8
+    assert np.array_equal(P.params[0][~free], X0[~free])            # excluded pixels never move
+
+
+def test_image_warping_minimum_matches_scipy_least_squares(oracle_lib):
+    """Nonlinear known answer: the image_warping energy written directly from the .t as a numpy residual function and
+    minimised by scipy.optimize.least_squares must reach the same minimum as the oracle's Gauss-Newton (double)."""
+    from scipy.optimize import least_squares
+    P = wl.image_warping(7, 6, double=True, random_state=9, mask_fraction=0.1, perturb=0.3)
+    O0, a0, U, C, M = [np.asarray(P.params[i], dtype=np.float64) for i in range(5)]
+    wf, wr = float(P.params[5]), float(P.params[6])
+    H, W = M.shape
+    free = M == 0
+    nfree = int(free.sum())
+
+    def unpack(x):
+        O, a = O0.copy(), a0.copy()
+        O[free] = x[:2 * nfree].reshape(nfree, 2); a[free] = x[2 * nfree:]
+        return O, a
+
+    def residuals(x):
+        O, a = unpack(x)
+        out = []
+        for y in range(H):
+            for xx in range(W):
+                if not free[y, xx]:
+                    continue                                   # Exclude: rows centred on masked pixels are not in the cost
+                c, s = np.cos(a[y, xx]), np.sin(a[y, xx])
+                for dx, dy in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+                    nx, ny = xx + dx, y + dy
+                    if 0 <= nx < W and 0 <= ny < H and free[ny, nx]:
+                        du = U[y, xx] - U[ny, nx]
+                        rot = np.array([c * du[0] - s * du[1], s * du[0] + c * du[1]])
+                        out.extend(wr * ((O[y, xx] - O[ny, nx]) - rot))
+                if C[y, xx, 0] >= 0 and C[y, xx, 1] >= 0:
+                    out.extend(wf * (O[y, xx] - C[y, xx]))
+        return np.array(out)
+
+    x0 = np.concatenate([O0[free].reshape(-1), a0[free]])
+    sol = least_squares(residuals, x0, method="lm", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=20000)
+    cost_ref = 0.5 * np.sum(sol.fun ** 2)
+    s = oracle_solver(oracle_lib, P, nIterations=60, lIterations=200)
+    assert abs(s.eval_cost(P.params) - 0.5 * np.sum(residuals(x0) ** 2)) <= 1e-12 * cost_ref + 1e-12   # same cost function
+    s.solve(P.params)
+    assert abs(s.cost() - cost_ref) <= 1e-7 * max(cost_ref, 1e-9)
+
+
+def test_arap_cost_matches_numpy_restatement(oracle_lib):
+    """arap_mesh_deformation.t evaluated with plain numpy (Rotate3D as in lib.t:77-91) must give the oracle's cost."""
+    P = wl.arap_mesh_deformation(6, 5, double=True, seed=1, perturb=0.05)
+    wf, wr, O, A, U, C, nE, v0, v1 = P.params
+    cost = 0.0
+    for v in range(P.dims[0]):
+        if C[v, 0] >= -999999.9:
+            cost += 0.5 * np.sum((float(wf) * (O[v] - C[v])) ** 2)
+    for e in range(int(nE)):
+        al, be, ga = A[v0[e]]
+        ca, cb, cg, sa, sb, sg = np.cos(al), np.cos(be), np.cos(ga), np.sin(al), np.sin(be), np.sin(ga)
+        R = np.array([[cg * cb, -sg * ca + cg * sb * sa, sg * sa + cg * sb * ca],
+                      [sg * cb, cg * ca + sg * sb * sa, -cg * sa + sg * sb * ca],
+                      [-sb, cb * sa, cb * ca]])
+        r = float(wr) * ((O[v0[e]] - O[v1[e]]) - R @ (U[v0[e]] - U[v1[e]]))
+        cost += 0.5 * np.sum(r ** 2)
+    s = oracle_solver(oracle_lib, P)
+    assert abs(s.eval_cost(P.params) - cost) <= 1e-12 * cost
+
+
+def test_sfs_cost_matches_numpy_restatement(oracle_lib):
+    """shape_from_shading.t evaluated with plain numpy -- B_I from workloads._sfs_render (the .t's equations 8/10 in array form),
+    the three energy terms and the valid / interior gating written out -- must give the oracle's cost."""
+    P = wl.shape_from_shading(18, 15, double=True, seed=3, holes=True, noise=2e-3)
+    p = P.params
+    w_p, w_s, w_g = (np.sqrt(float(p[i])) for i in range(3))
+    fx, fy, ux, uy = (float(p[i]) for i in range(3, 7))
+    L = [float(p[7 + i]) for i in range(9)]
+    X, D, Im, mR, mC = p[16], p[17], p[18], p[19].astype(float), p[20].astype(float)
+    H, W = X.shape
+    B = wl._sfs_render(X, fx, fy, ux, uy, L)
+    I = 0.5 * Im + 0.25 * (np.roll(Im, 1, axis=1) + np.roll(Im, 1, axis=0))
+    dv = D > 0
+    interior = np.zeros((H, W), bool); interior[1:-1, 1:-1] = True
+    ok = interior & dv & np.roll(dv, 1, axis=1) & np.roll(dv, 1, axis=0)
+    BI = np.where(ok, B - I, 0.0)
+    cost = 0.0
+    jj, ii = np.meshgrid(np.arange(H, dtype=float), np.arange(W, dtype=float), indexing="ij")
+    Pts = np.stack([(ii - ux) / fx * X, (jj - uy) / fy * X, X], -1)
+    for y in range(H):
+        for x in range(W):
+            if not dv[y, x]:
+                continue                                                      # Exclude(D_i <= 0)
+            cost += 0.5 * (w_p * (X[y, x] - D[y, x])) ** 2
+            if interior[y, x]:
+                cost += 0.5 * (w_g * (BI[y, x] - BI[y, x + 1]) * mR[y, x]) ** 2
+                cost += 0.5 * (w_g * (BI[y, x] - BI[y + 1, x]) * mC[y, x]) ** 2
+                nb = [(0, -1), (0, 1), (-1, 0), (1, 0)]
+                valid = all(dv[y + dy, x + dx] for dx, dy in nb) and all(abs(X[y, x] - X[y + dy, x + dx]) < 0.01 for dx, dy in nb)
+                if valid:
+                    lap = 4.0 * Pts[y, x] - sum(Pts[y + dy, x + dx] for dx, dy in nb)
+                    cost += 0.5 * np.sum((w_s * lap) ** 2)
+    s = oracle_solver(oracle_lib, P)
+    assert abs(s.eval_cost(P.params) - cost) <= 1e-10 * cost
