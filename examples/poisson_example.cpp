@@ -1,0 +1,49 @@
+// poisson_image_editing through the C API, in the shape of the reference example (examples/poisson_image_editing/src/
+// main.cpp:66-70, CombinedSolver.h:29-98): float4 base image X (unknown), inserted image T, mask M (0 = solved, 255 =
+// kept), one solve of 1 nonlinear x 100 linear iterations with GN and with LM; final costs in the reference's report
+// block.  Images are procedural (no PNG decoder here).
+//   usage: poisson_example [width=512] [height=512] [linearIter=100] [energy.t]
+#include "common.h"
+#include <cmath>
+
+int main(int argc, char** argv) {
+    const unsigned W = argc > 1 ? atoi(argv[1]) : 512, H = argc > 2 ? atoi(argv[2]) : 512;
+    int nonLinearIter = 1, linearIter = argc > 3 ? atoi(argv[3]) : 100;
+    const std::string energy = argc > 4 ? argv[4] : "opt_amd/energies/poisson_image_editing.t";
+    std::vector<float> base(4 * W * H), ins(4 * W * H), mask(W * H, 255.f);
+    unsigned s = 99u;
+    for (unsigned y = 0; y < H; ++y) for (unsigned x = 0; x < W; ++x) {
+        const size_t i = (size_t)y * W + x;
+        base[4 * i] = 128 + 100 * std::sin(x / 17.f); base[4 * i + 1] = 128 + 100 * std::cos(y / 23.f); base[4 * i + 2] = (float)((x + y) / 2 % 255); base[4 * i + 3] = 255;
+        for (int k = 0; k < 3; ++k) { s = s * 1664525u + 1013904223u; ins[4 * i + k] = 255.f * (float)(s >> 8) / (float)(1u << 24); }
+        ins[4 * i + 3] = 255;
+        if (x >= W / 4 && x < W / 4 + W / 2 && y >= H / 4 && y < H / 4 + H / 2) mask[i] = 0.f;   // pasted region
+    }
+    DeviceBuffer<float> dT(ins), dM(mask), dX(base.size());
+    Opt_InitializationParameters ip = {};
+    Opt_State* state = Opt_NewState(ip);
+    if (!state) return 2;
+    unsigned int dims[] = {W, H};
+    const char* kinds[2] = {"gaussNewtonGPU", "LMGPU"};
+    std::vector<SolverIteration> iters[2];
+    double finalCost[2] = {0, 0};
+    for (int k = 0; k < 2; ++k) {
+        Opt_Problem* problem = Opt_ProblemDefine(state, energy.c_str(), kinds[k]);
+        Opt_Plan* plan = Opt_ProblemPlan(state, problem, dims);
+        if (!plan) return 3;
+        Opt_SetSolverParameter(state, plan, "nIterations", &nonLinearIter);
+        Opt_SetSolverParameter(state, plan, "lIterations", &linearIter);
+        dX.upload(base);                                                       // preSingleSolve: reset the unknown
+        void* params[] = {dX.ptr, dT.ptr, dM.ptr};
+        std::cout << "//////////// (" << (k ? "Opt(LM)" : "Opt(GN)") << ") ///////////////" << std::endl;
+        profiledSolve(state, plan, params, iters[k]);
+        finalCost[k] = Opt_ProblemCurrentCost(state, plan);
+        Opt_PlanFree(state, plan); Opt_ProblemDelete(state, problem);
+    }
+    // pixels outside the pasted region must be untouched
+    const std::vector<float> out = dX.download();
+    for (size_t i = 0; i < (size_t)W * H; ++i) if (mask[i] != 0.f) for (int k = 0; k < 4; ++k) if (out[4 * i + k] != base[4 * i + k]) { fprintf(stderr, "excluded pixel moved\n"); return 1; }
+    saveSolverResults("results_float.csv", iters[0], iters[1], false);
+    reportFinalCosts("Poisson Image Editing", true, finalCost[0], true, finalCost[1]);
+    return (finalCost[0] < iters[0][0].cost && finalCost[1] < iters[1][0].cost) ? 0 : 1;
+}

@@ -72,7 +72,7 @@ def build(force=False, verbose=False):
 
 
 EXAMPLES_DIR = os.path.join(HERE, "..", "examples")
-EXAMPLES = ["minimal_laplacian", "minimal_graph_only", "create_delete_cycle", "image_warping_example"]
+EXAMPLES = ["minimal_laplacian", "minimal_graph_only", "create_delete_cycle", "image_warping_example", "poisson_example", "arap_example", "sfs_example"]
 
 
 def build_examples(force=False, verbose=False):

@@ -51,3 +51,31 @@ def test_image_warping_example_flow(tmp_path):
     rows = open(os.path.join(ROOT, "results_float.csv")).read().strip().splitlines()
     assert rows[0].startswith("Iter, Opt(GN) Error (float)") and len(rows) > 10
     os.remove(os.path.join(ROOT, "results_float.csv"))
+
+
+def _final_costs(stdout):
+    line = stdout.split("Opt GN,Opt LM,CERES")[1].strip().splitlines()[0]
+    return [float(x) if x else None for x in line.split(",")[:2]]
+
+
+def test_poisson_example_flow():
+    r = _run("poisson_example", 256, 192, 60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    gn, lm = _final_costs(r.stdout)
+    assert "===Poisson Image Editing===" in r.stdout and gn > 0 and lm > 0
+    os.remove(os.path.join(ROOT, "results_float.csv"))
+
+
+def test_arap_example_flow():
+    r = _run("arap_example", 60, 50, 3, 6, 40)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "===Mesh Deformation ARAP===" in r.stdout and "half-edges" in r.stdout
+    os.remove(os.path.join(ROOT, "results_float.csv"))
+
+
+def test_sfs_example_flow_double_lm():
+    r = _run("sfs_example", "-", 192)
+    assert r.returncode == 0, r.stdout + r.stderr
+    gn, lm = _final_costs(r.stdout)
+    assert "===Shape From Shading===" in r.stdout and gn is None and lm > 0
+    os.remove(os.path.join(ROOT, "results_double.csv"))
