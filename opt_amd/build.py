@@ -27,7 +27,8 @@ def _deps_mtime():
 
 
 def build_variant(name, defines):
-    """Development aid: build opt_amd/lib/libOpt_<name>.so with extra -D flags (select it with OPT_AMD_LIB=<path>)."""
+    """Development aid: build opt_amd/lib/libOpt_<name>.so with extra -D defines (entries starting with '-' are passed
+    to hipcc verbatim); select it at run time with OPT_AMD_LIB=<path>."""
     objdir = os.path.join(HERE, "build_" + name)
     os.makedirs(objdir, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
@@ -35,7 +36,7 @@ def build_variant(name, defines):
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [HIPCC] + FLAGS + ["-D" + d for d in defines] + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + [d if d.startswith("-") else "-D" + d for d in defines] + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
         procs.append((src, subprocess.Popen(cmd)))
     failed = [s for s, p in procs if p.wait() != 0]
     if failed:

@@ -179,7 +179,7 @@ template <class T, bool FUSE>
 struct Raw {        // one pixel's loads, not yet combined (keeps the loads independent of any ALU work)
     V2<T> o, cs, u; T a;
     V2<T> zo; T za;
-    int f;
+    int f, ok;      // raw flag byte; ok = the pixel exists (known without the load)
 };
 
 // DPP whole-wave shifts (gfx9 family): wave_shr:1 gives lane i the value of lane i-1, wave_shl:1 of lane i+1;
@@ -198,6 +198,15 @@ template <bool RIGHT, class T> __device__ __forceinline__ Px<T> dppShiftPx(const
     q.ux = dppShift<RIGHT>(p.ux); q.uy = dppShift<RIGHT>(p.uy); q.f = dppShift<RIGHT>(p.f);
     return q;
 }
+
+// A real register copy the compiler cannot fold.  The marching kernels pass some loaded fields (cos/sin, U, M) through
+// unchanged for three rows; left to itself the compiler keeps them in the registers the load wrote, has to rotate the
+// prefetch buffers with v_movs at the loop back-edge, and a v_mov of a register whose load is still in flight costs an
+// s_waitcnt there -- the prefetch drains every trip.  Copying once, where the data is consumed anyway, frees the raw
+// registers so the next prefetch lands in the same ones and the back-edge carries no waits.
+__device__ __forceinline__ float regCopy(float v) { float r; asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(v)); return r; }
+__device__ __forceinline__ int regCopy(int v) { int r; asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(v)); return r; }
+__device__ __forceinline__ double regCopy(double v) { return __hiloint2double(regCopy(__double2hiint(v)), regCopy(__double2loint(v))); }
 
 template <class T>
 struct FuseArgs {            // the PCGStep3 inputs when fused (see k_step3 in solver.hip)
@@ -242,8 +251,7 @@ __device__ __forceinline__ Raw<T, FUSE> iw_loadRaw(const IWArgs<T>& A, const V2<
     Raw<T, FUSE> r;
     const bool ok = xok && y >= 0 && y < A.H;
     const long i = (long)min(max(y, 0), A.H - 1) * A.W + min(max(x, 0), A.W - 1);
-    const int f = A.flags[i];
-    r.f = ok ? f : 0;
+    r.f = A.flags[i]; r.ok = ok;      // NOT `ok ? f : 0` here: any ALU op on a loaded value forces its s_waitcnt before the loop back-edge
     r.o = ld2<kNTL>(vO, i); r.a = ld1<kNTL>(va, i); r.cs = ld2<kNTL>((const V2<T>*)A.cs, i); r.u = ld2<kNTL>((const V2<T>*)A.UrShape, i);
     if (FUSE) { r.zo = ld2<kNTL>(zO, i); r.za = ld1<kNTL>(za, i); } else { r.zo = V2<T>{0, 0}; r.za = 0; }
     return r;
@@ -253,7 +261,8 @@ __device__ __forceinline__ Px<T> iw_combine(const Raw<T, FUSE>& r, T beta) {
     Px<T> p;
     p.ox = r.o.x; p.oy = r.o.y; p.a = r.a;
     if (FUSE) { p.ox = r.zo.x + beta * p.ox; p.oy = r.zo.y + beta * p.oy; p.a = r.za + beta * p.a; }   // PCGStep3
-    p.c = r.cs.x; p.s = r.cs.y; p.ux = r.u.x; p.uy = r.u.y; p.f = r.f;
+    p.c = regCopy(r.cs.x); p.s = regCopy(r.cs.y); p.ux = regCopy(r.u.x); p.uy = regCopy(r.u.y); p.f = r.ok ? r.f : 0;
+    if (!FUSE) { p.ox = regCopy(p.ox); p.oy = regCopy(p.oy); p.a = regCopy(p.a); }
     return p;
 }
 
@@ -273,9 +282,9 @@ __device__ __forceinline__ void iw_pair(const Px<T>& c, const Px<T>& n, T& accOx
 // The same two residuals when UrShape is a unit lattice (U_c - U_{c+n} = -n exactly): nothing of U is needed and the
 // derivative columns collapse to +-(sin, cos) permutations.  Same arithmetic as iw_pair up to FMA contraction.
 template <int DX, int DY, class T>
-__device__ __forceinline__ void iw_pairLattice(const Px<T>& c, const Px<T>& n, T& accOx, T& accOy, T& accA) {
+__device__ __forceinline__ void iw_pairLattice(const Px<T>& c, const Px<T>& n, T& accOx, T& accOy, T& accA, T sy = T(1)) {
     const bool on = (n.f & kActive) != 0;
-    const T ux = T(-DX), uy = T(-DY);
+    const T ux = T(-DX), uy = T(-DY) * sy;      // sy = -1 when the kernel sweeps the image bottom-up (rows mirrored)
     const T Dcx = -c.s * ux - c.c * uy, Dcy = c.c * ux - c.s * uy;
     const T Dnx = n.s * ux + n.c * uy, Dny = -n.c * ux + n.s * uy;
     const T jcx = (c.ox - n.ox) - Dcx * c.a, jcy = (c.oy - n.oy) - Dcy * c.a;
@@ -328,10 +337,10 @@ __global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __re
         if (yb - 1 >= 0 && yb == A.yBegin) { const long j = i - A.W; st2<kNTS>(nO, j, up.ox, up.oy); st1<kNTS>(na, j, up.a); }   // ghost row above (slab mode)
     }
     // one row: `rdn` holds the raw loads of row y+1 (issued one iteration earlier)
-    auto row = [&](int y, const Raw<T, FUSE>& rdn) {
+    auto row = [&](int y, const Raw<T, FUSE>& rdn, bool live) {
         const Px<T> dn = iw_combine<T, FUSE>(rdn, beta);
         const long i = (long)y * A.W + x;
-        if (FUSE && writer && y + 1 < A.H && (y + 1 < ye || y + 1 == A.yEnd)) { const long j = i + A.W; st2<kNTS>(nO, j, dn.ox, dn.oy); st1<kNTS>(na, j, dn.a); }
+        if (FUSE && writer && live && y + 1 < A.H && (y + 1 < ye || y + 1 == A.yEnd)) { const long j = i + A.W; st2<kNTS>(nO, j, dn.ox, dn.oy); st1<kNTS>(na, j, dn.a); }
         const Px<T> lf = dppShiftPx<true>(cur), rt = dppShiftPx<false>(cur);
         T ax = 0, ay = 0, aa = 0;
         iw_pair(cur, rt, ax, ay, aa);
@@ -342,27 +351,28 @@ __global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __re
         const bool fit = (cur.f & kFit) != 0;
         rx += fit ? wf2 * cur.ox : T(0); ry += fit ? wf2 * cur.oy : T(0);
         if (LM) {
-            const long ic = writer ? i : 0;
+            const long ic = (writer && live) ? i : 0;
             const V2<T> cO = ((const V2<T>*)CtC)[ic];
             rx += cO.x * cur.ox; ry += cO.y * cur.oy; ra += CtC[2 * N + ic] * cur.a;
         }
         const bool act = (cur.f & kActive) != 0;       // excluded / non-existent centre: row of J^T J is 0 (solver.t:424)
         rx = act ? rx : T(0); ry = act ? ry : T(0); ra = act ? ra : T(0);
-        if (writer) {
+        if (writer && live) {
             acc += (double)(cur.ox * rx + cur.oy * ry + cur.a * ra);
             st2<kNTS>(outO, i, rx, ry); st1<kNTS>(outA, i, ra);
         }
         up = cur; cur = dn;
     };
+    // Two rows per trip, no branch around a load: a load inside a conditional block makes the compiler drain the whole
+    // queue (s_waitcnt vmcnt(0)) where the paths merge, which would serialise the prefetch.  An odd last row runs as a
+    // predicated no-op (clamped addresses, nothing stored or summed).
     Raw<T, FUSE> rA = iw_loadRaw<T, FUSE>(A, vO, va, zO, za, xok, x, yb + 1), rB;
     for (int y = yb; y < ye; y += 2) {
         if (IW_ROW_SYNC) __syncthreads();   // keep the 4 waves of a strip on the same rows: their shared seam lines then hit L2
         rB = iw_loadRaw<T, FUSE>(A, vO, va, zO, za, xok, x, y + 2);
-        row(y, rA);
-        if (y + 1 < ye) {
-            rA = iw_loadRaw<T, FUSE>(A, vO, va, zO, za, xok, x, y + 3);
-            row(y + 1, rB);
-        }
+        row(y, rA, true);
+        rA = iw_loadRaw<T, FUSE>(A, vO, va, zO, za, xok, x, y + 3);
+        row(y + 1, rB, y + 1 < ye);
     }
     double t = blockReduceSum(acc, scratch);
     if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
@@ -374,9 +384,9 @@ __global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __re
 // r 12 + Ap 12 + p 12 + delta 12 + pre 12 + (cos,sin) 8 + U 8 + flags 1 in and r, p, delta, Ap 48 out = 125 B/pixel
 // (three reference kernels: 180 B/pixel algorithmic).
 template <class T>
-struct IterRaw {
-    V2<T> ro, ao, po, mo, cs, u; T ra, aa, pa, ma;   // r, Ap, p, pre (Offset part / Angle part), table, UrShape
-    int f;
+struct IterRaw {           // one pixel's loads, untouched (any ALU op here would force a wait before the loop back-edge)
+    V2<T> ro, ao, po, mo, cs, u, dO; T ra, aa, pa, ma, dA;   // r, Ap, p, pre (Offset part / Angle part), table, UrShape, delta
+    int f, ok;
 };
 template <class T>
 struct IterPx {            // what the stencil needs (Px) + what the sums / stores need
@@ -388,25 +398,38 @@ template <class T>
 struct IterK {             // kernel argument block
     const T *rOld, *ApOld, *pOld; T *rNew, *ApNew, *pNew; T* delta; const T* pre; int first;
     const T* mc;           // compact preconditioner {M_O, M_a} per pixel (M_O.x == M_O.y for this energy), or nullptr
+    int flip;              // 1: sweep bottom-up (the kernel works in mirrored row coordinates, see iw_pcgIter)
     const double *aNumPrev, *aDenPrev, *s2Prev, *s3Prev; int nNum, nDen, n2, n3;
     double *aNum, *aDen, *s2, *s3;
 };
 
-template <class T, bool LATTICE>
+// PRE: 0 = identity preconditioner, 1 = the solver's 3-channel one (12 B/px), 2 = compact {M_O, M_a} (8 B/px).  A template
+// parameter, not a test of K.mc / K.pre: a load inside a (even uniform) branch costs an s_waitcnt vmcnt(0) at the merge.
+template <class T, bool LATTICE, int PRE>
 __device__ __forceinline__ IterRaw<T> iw_iterLoad(const IWArgs<T>& A, const IterK<T>& K, long N, bool xok, int x, int y) {
     IterRaw<T> r;
-    const bool ok = xok && y >= 0 && y < A.H;
-    const long i = (long)min(max(y, 0), A.H - 1) * A.W + min(max(x, 0), A.W - 1);
-    const int f = A.flags[i];
-    r.f = ok ? f : 0;
+    r.ok = xok && y >= 0 && y < A.H;
+    const int yc = min(max(y, 0), A.H - 1);
+    const long i = (long)(K.flip ? A.H - 1 - yc : yc) * A.W + min(max(x, 0), A.W - 1);
+    r.f = A.flags[i];
     r.ro = ld2<kNTL>((const V2<T>*)K.rOld, i); r.ra = ld1<kNTL>(K.rOld + 2 * N, i);
     r.ao = ld2<kNTL>((const V2<T>*)K.ApOld, i); r.aa = ld1<kNTL>(K.ApOld + 2 * N, i);
     r.po = ld2<kNTL>((const V2<T>*)K.pOld, i); r.pa = ld1<kNTL>(K.pOld + 2 * N, i);
-    if (K.mc) { const V2<T> m = ld2<kNTL>((const V2<T>*)K.mc, i); r.mo = V2<T>{m.x, m.x}; r.ma = m.y; }
-    else if (K.pre) { r.mo = ld2<kNTL>((const V2<T>*)K.pre, i); r.ma = ld1<kNTL>(K.pre + 2 * N, i); }
+    if (PRE == 2) { r.mo = ld2<kNTL>((const V2<T>*)K.mc, i); r.ma = 0; }
+    else if (PRE == 1) { r.mo = ld2<kNTL>((const V2<T>*)K.pre, i); r.ma = ld1<kNTL>(K.pre + 2 * N, i); }
     else { r.mo = V2<T>{1, 1}; r.ma = 1; }
     r.cs = ld2<kNTL>((const V2<T>*)A.cs, i);
     if (LATTICE) r.u = V2<T>{0, 0}; else r.u = ld2<kNTL>((const V2<T>*)A.UrShape, i);
+#ifndef IW_DELTA_NT
+#define IW_DELTA_NT 1
+#endif
+    // delta: read where it is written (IW_DELTA_LATE=1) rather than prefetched with the row -- measured equal or +3 % (interleaved
+    // A/B, 3 rounds, on a box where the prefetched form lost that much); the prefetched form is kept for comparison.
+#ifndef IW_DELTA_LATE
+#define IW_DELTA_LATE 1
+#endif
+    if (IW_DELTA_LATE) { r.dO = V2<T>{0, 0}; r.dA = 0; }
+    else { r.dO = ld2<IW_DELTA_NT != 0>((const V2<T>*)K.delta, i); r.dA = ld1<IW_DELTA_NT != 0>(K.delta + 2 * N, i); }     // prefetched with the row (was a load-wait-store inside the row)
     return r;
 }
 
@@ -422,13 +445,19 @@ __device__ __forceinline__ IterRaw<T> iw_iterLoad(const IWArgs<T>& A, const Iter
 #endif
 constexpr int kIterBlock = ITER_BLOCK;
 constexpr int kIterStrip = (kIterBlock / kWave) * kSpan;
-template <class T, bool LATTICE>
+// Sweep direction.  Successive launches alternate top-down / bottom-up (K.flip): the rows a launch finishes with -- inputs
+// it just read and r / p / Ap / delta it just wrote -- are the ones still resident in the 256 MB Infinity Cache (and L2)
+// when the next launch starts, so the next launch starts there.  A flipped launch runs the identical code in mirrored
+// row coordinates (logical row y <-> image row H-1-y; the slab bounds mirror too); only addresses go through phys().
+// The two vertical stencil terms are taken in image order in both directions, so Ap is bitwise independent of the sweep.
+template <class T, bool LATTICE, int PRE>
 __global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter(IWArgs<T> A, IterK<T> K, int rowsPerGroup, int gx, int gy) {
     __shared__ double scratch[kIterBlock / kWave + 1];
     const long N = (long)A.W * A.H;
     // scalars of the previous iteration (solver.t:456-459, 544-547 guards), betaNumerator by expansion (energy.h)
     T alpha = 0, beta = 0;
-    if (!K.first) {
+    const bool first = K.first != 0;
+    if (!first) {
         const double aNumD = sumPartials(K.aNumPrev, K.nNum, scratch), aDenD = sumPartials(K.aDenPrev, K.nDen, scratch);
         const double s2 = sumPartials(K.s2Prev, K.n2, scratch), s3 = sumPartials(K.s3Prev, K.n3, scratch);
         const T aNum = (T)aNumD, aDen = (T)aDenD;
@@ -441,8 +470,11 @@ __global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter(IWArgs<
     const int x = bx * kIterStrip + wave * kSpan + lane - 1;
     const bool xok = x >= 0 && x < A.W;
     const bool writer = xok && lane >= 1 && lane <= kSpan;
-    const int yb = A.yBegin + by * rowsPerGroup;
-    const int ye = min(yb + rowsPerGroup, A.yEnd);
+    const bool flip = K.flip != 0;
+    const int lyBegin = flip ? A.H - A.yEnd : A.yBegin, lyEnd = flip ? A.H - A.yBegin : A.yEnd;     // owned rows, logical
+    auto phys = [&](int y) { return flip ? A.H - 1 - y : y; };
+    const int yb = lyBegin + by * rowsPerGroup;
+    const int ye = min(yb + rowsPerGroup, lyEnd);
     const T w2 = A.w_reg * A.w_reg, wf2 = A.w_fit * A.w_fit;
     double accDen = 0, accNum = 0, acc2 = 0, acc3 = 0;
     V2<T>* rO = (V2<T>*)K.rNew; T* rA = K.rNew + 2 * N; V2<T>* pO = (V2<T>*)K.pNew; T* pA = K.pNew + 2 * N;
@@ -451,44 +483,46 @@ __global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter(IWArgs<
     // Step2 + Step3 of the previous iteration for one pixel; `own` rows also store r, p, delta and feed alphaNum
     auto combine = [&](const IterRaw<T>& w, int y, bool own) {
         IterPx<T> q;
-        const T rx = K.first ? w.ro.x : w.ro.x - alpha * w.ao.x, ry = K.first ? w.ro.y : w.ro.y - alpha * w.ao.y, ra = K.first ? w.ra : w.ra - alpha * w.aa;
-        q.mx = w.mo.x; q.my = w.mo.y; q.ma = w.ma;
+        const T rx = first ? w.ro.x : w.ro.x - alpha * w.ao.x, ry = first ? w.ro.y : w.ro.y - alpha * w.ao.y, ra = first ? w.ra : w.ra - alpha * w.aa;
+        q.mx = regCopy(w.mo.x); q.my = (PRE == 2) ? q.mx : regCopy(w.mo.y); q.ma = regCopy((PRE == 2) ? w.mo.y : w.ma);
         q.zx = q.mx * rx; q.zy = q.my * ry; q.za = q.ma * ra;
         q.p.ox = q.zx + beta * w.po.x; q.p.oy = q.zy + beta * w.po.y; q.p.a = q.za + beta * w.pa;
-        q.p.c = w.cs.x; q.p.s = w.cs.y; q.p.ux = w.u.x; q.p.uy = w.u.y; q.p.f = w.f;
+        q.p.c = regCopy(w.cs.x); q.p.s = regCopy(w.cs.y); q.p.f = w.ok ? w.f : 0;
+        if (LATTICE) { q.p.ux = 0; q.p.uy = 0; } else { q.p.ux = regCopy(w.u.x); q.p.uy = regCopy(w.u.y); }
         if (own && xok && y >= 0 && y < A.H) {
-            const long i = (long)y * A.W + x;
-            const bool ghost = y < A.yBegin || y >= A.yEnd;     // slab mode: ghost rows keep r / p current for the next launch
+            const long i = (long)phys(y) * A.W + x;
+            const bool ghost = y < lyBegin || y >= lyEnd;       // slab mode: ghost rows keep r / p current for the next launch
             if (writer || (ghost && xok)) { st2<kNTS>(rO, i, rx, ry); st1<kNTS>(rA, i, ra); st2<kNTS>(pO, i, q.p.ox, q.p.oy); st1<kNTS>(pA, i, q.p.a); }
             if (writer && !ghost) {
-                if (!K.first) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462)
-                    const V2<T> d = dO[i]; const T da = dA[i];
-                    st2<kNTS>(dO, i, d.x + alpha * w.po.x, d.y + alpha * w.po.y); st1<kNTS>(dA, i, da + alpha * w.pa);
+                if (!first) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462); stores only inside the branch
+                    if (IW_DELTA_LATE) { const V2<T> d = dO[i]; const T da = dA[i]; st2<kNTS>(dO, i, d.x + alpha * w.po.x, d.y + alpha * w.po.y); st1<kNTS>(dA, i, da + alpha * w.pa); }
+                    else { st2<kNTS>(dO, i, w.dO.x + alpha * w.po.x, w.dO.y + alpha * w.po.y); st1<kNTS>(dA, i, w.dA + alpha * w.pa); }
                 }
                 accNum += (double)(q.zx * rx + q.zy * ry + q.za * ra);
             }
         }
         return q;
     };
-    IterPx<T> up = combine(iw_iterLoad<T, LATTICE>(A, K, N, xok, x, yb - 1), yb - 1, yb == A.yBegin && yb - 1 >= 0);
-    IterPx<T> cur = combine(iw_iterLoad<T, LATTICE>(A, K, N, xok, x, yb), yb, yb < ye);
-    auto row = [&](int y, const IterRaw<T>& rdn) {
-        const IterPx<T> dn = combine(rdn, y + 1, y + 1 < A.H && (y + 1 < ye || y + 1 == A.yEnd));
-        const long i = (long)y * A.W + x;
+    IterPx<T> up = combine(iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, yb - 1), yb - 1, yb == lyBegin && yb - 1 >= 0);
+    IterPx<T> cur = combine(iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, yb), yb, yb < ye);
+    auto row = [&](int y, const IterRaw<T>& rdn, bool live) {
+        const IterPx<T> dn = combine(rdn, y + 1, live && y + 1 < A.H && (y + 1 < ye || y + 1 == lyEnd));
+        const long i = (long)phys(y) * A.W + x;
         const Px<T> lf = dppShiftPx<true>(cur.p), rt = dppShiftPx<false>(cur.p);
+        const Px<T> below = flip ? up.p : dn.p, above = flip ? dn.p : up.p;     // image row y+1 / y-1 whichever way the sweep runs
         T ax = 0, ay = 0, aa = 0;
         if (LATTICE) {
             iw_pairLattice<1, 0>(cur.p, rt, ax, ay, aa); iw_pairLattice<-1, 0>(cur.p, lf, ax, ay, aa);
-            iw_pairLattice<0, 1>(cur.p, dn.p, ax, ay, aa); iw_pairLattice<0, -1>(cur.p, up.p, ax, ay, aa);
+            iw_pairLattice<0, 1>(cur.p, below, ax, ay, aa); iw_pairLattice<0, -1>(cur.p, above, ax, ay, aa);
         } else {
-            iw_pair(cur.p, rt, ax, ay, aa); iw_pair(cur.p, lf, ax, ay, aa); iw_pair(cur.p, dn.p, ax, ay, aa); iw_pair(cur.p, up.p, ax, ay, aa);
+            iw_pair(cur.p, rt, ax, ay, aa); iw_pair(cur.p, lf, ax, ay, aa); iw_pair(cur.p, below, ax, ay, aa); iw_pair(cur.p, above, ax, ay, aa);
         }
         T ox = w2 * ax, oy = w2 * ay, oa = w2 * aa;
         const bool fit = (cur.p.f & kFit) != 0;
         ox += fit ? wf2 * cur.p.ox : T(0); oy += fit ? wf2 * cur.p.oy : T(0);
         const bool act = (cur.p.f & kActive) != 0;
         ox = act ? ox : T(0); oy = act ? oy : T(0); oa = act ? oa : T(0);
-        if (writer) {
+        if (writer && live) {
             accDen += (double)(cur.p.ox * ox + cur.p.oy * oy + cur.p.a * oa);
             acc2 += (double)(cur.zx * ox + cur.zy * oy + cur.za * oa);
             acc3 += (double)((cur.mx * ox) * ox + (cur.my * oy) * oy + (cur.ma * oa) * oa);
@@ -496,16 +530,138 @@ __global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter(IWArgs<
         }
         up = cur; cur = dn;
     };
-    IterRaw<T> rA2 = iw_iterLoad<T, LATTICE>(A, K, N, xok, x, yb + 1), rB2;
+    // two rows per trip, no branch around a load (see iw_applyJTJ); an odd last row runs as a predicated no-op
+    IterRaw<T> rA2 = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, yb + 1), rB2;
     for (int y = yb; y < ye; y += 2) {
         if (IW_ROW_SYNC) __syncthreads();
-        rB2 = iw_iterLoad<T, LATTICE>(A, K, N, xok, x, y + 2);
-        row(y, rA2);
+        rB2 = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, y + 2);
+        row(y, rA2, true);
         if (IW_ROW_SYNC == 2) __syncthreads();
-        if (y + 1 < ye) {
-            rA2 = iw_iterLoad<T, LATTICE>(A, K, N, xok, x, y + 3);
-            row(y + 1, rB2);
+        rA2 = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, y + 3);
+        row(y + 1, rB2, y + 1 < ye);
+    }
+    double t;
+    t = blockReduceSum(accDen, scratch); if (threadIdx.x == 0) K.aDen[blockIdx.x] = t;
+    t = blockReduceSum(accNum, scratch); if (threadIdx.x == 0) K.aNum[blockIdx.x] = t;
+    t = blockReduceSum(acc2, scratch); if (threadIdx.x == 0) K.s2[blockIdx.x] = t;
+    t = blockReduceSum(acc3, scratch); if (threadIdx.x == 0) K.s3[blockIdx.x] = t;
+}
+
+// ---- the same iteration without Ap in memory ------------------------------------------------------------------
+// iw_pcgIter stores Ap_k only so that the NEXT launch can form r_{k+1} = r_k - alpha_k Ap_k (12 B/px written + 12 B/px
+// read of 118).  Ap_k = J^T J p_k is a pure function of p_k, which the next launch reads anyway, so iw_pcgIter2 recomputes
+// it: launch k reads r_{k-1}, p_{k-1} on a 2-pixel ring, forms Ap_{k-1} on the 1-ring (second stencil evaluation, VALU is
+// idle 80 % of the time in this kernel), then r_k, z_k, p_k there, and Ap_k on its own pixels for the dot products --
+// never written.  State in memory is r, p, delta; per pixel per iteration 24 + 24 + 24 + M 8 + (cos,sin) 8 + flags 1 =
+// 89 B against 118 B (and 180 B for the three reference kernels).  The recomputed Ap_{k-1} is the same instruction
+// sequence on the same inputs as the Ap_{k-1} whose dot products the previous launch reduced.
+// A wave covers 64 consecutive pixels and produces the inner 60 (p_k needs one DPP ring, Ap_k a second).  Rows: a
+// sliding window of three rows of p_{k-1} and three of p_k in registers; trip y turns the freshly loaded row y+2 into
+// Ap_{k-1}(y+1), p_k(y+1) and then Ap_k(y).  Not used with row slabs (the halo exchange would need two ghost rows).
+constexpr int kSpan2 = kWave - 4;
+constexpr int kIterStrip2 = (kIterBlock / kWave) * kSpan2;
+template <class T>
+struct OldRow {            // one row of iteration k-1: p_{k-1} (+ cos/sin, U, flags) and, while still needed, r_{k-1} and M
+    Px<T> p;
+    T rx, ry, ra, mx, my, ma;
+};
+template <class T, bool LATTICE, int PRE>
+__global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter2(IWArgs<T> A, IterK<T> K, int rowsPerGroup, int gx, int gy) {
+    __shared__ double scratch[kIterBlock / kWave + 1];
+    const long N = (long)A.W * A.H;
+    T alpha = 0, beta = 0;
+    const bool first = K.first != 0;
+    if (!first) {
+        const double aNumD = sumPartials(K.aNumPrev, K.nNum, scratch), aDenD = sumPartials(K.aDenPrev, K.nDen, scratch);
+        const double s2 = sumPartials(K.s2Prev, K.n2, scratch), s3 = sumPartials(K.s3Prev, K.n3, scratch);
+        const T aNum = (T)aNumD, aDen = (T)aDenD;
+        alpha = (aDen > T(0)) ? aNum / aDen : T(0);
+        const double bNumD = aNumD - 2.0 * (double)alpha * s2 + (double)alpha * (double)alpha * s3;
+        beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
+    }
+    const int bx = blockIdx.x % gx, by = blockIdx.x / gx;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int x = bx * kIterStrip2 + wave * kSpan2 + lane - 2;
+    const bool xok = x >= 0 && x < A.W;
+    const bool writer = xok && lane >= 2 && lane < 2 + kSpan2;
+    const bool flip = K.flip != 0;                              // mirrored row coordinates, see iw_pcgIter
+    auto phys = [&](int y) { return flip ? A.H - 1 - y : y; };
+    const int yb = by * rowsPerGroup, ye = min(yb + rowsPerGroup, A.H);
+    const T w2 = A.w_reg * A.w_reg, wf2 = A.w_fit * A.w_fit;
+    double accDen = 0, accNum = 0, acc2 = 0, acc3 = 0;
+    V2<T>* rO = (V2<T>*)K.rNew; T* rA = K.rNew + 2 * N; V2<T>* pO = (V2<T>*)K.pNew; T* pA = K.pNew + 2 * N;
+    V2<T>* dO = (V2<T>*)K.delta; T* dA = K.delta + 2 * N;
+
+    auto makeOld = [&](const IterRaw<T>& w) {
+        OldRow<T> o;
+        o.p.ox = w.po.x; o.p.oy = w.po.y; o.p.a = w.pa;
+        o.p.c = regCopy(w.cs.x); o.p.s = regCopy(w.cs.y); o.p.f = w.ok ? w.f : 0;
+        if (LATTICE) { o.p.ux = 0; o.p.uy = 0; } else { o.p.ux = regCopy(w.u.x); o.p.uy = regCopy(w.u.y); }
+        o.rx = w.ro.x; o.ry = w.ro.y; o.ra = w.ra;
+        o.mx = regCopy(w.mo.x); o.my = (PRE == 2) ? o.mx : regCopy(w.mo.y); o.ma = regCopy((PRE == 2) ? w.mo.y : w.ma);
+        return o;
+    };
+    // J^T J applied at the centre row `c` (image rows: `prev` is the row before it in sweep order, `next` the one after)
+    auto applyA = [&](const Px<T>& c, const Px<T>& prev, const Px<T>& next, T& ox, T& oy, T& oa) {
+        const Px<T> lf = dppShiftPx<true>(c), rt = dppShiftPx<false>(c);
+        const Px<T> below = flip ? prev : next, above = flip ? next : prev;
+        T ax = 0, ay = 0, aa = 0;
+        if (LATTICE) {
+            iw_pairLattice<1, 0>(c, rt, ax, ay, aa); iw_pairLattice<-1, 0>(c, lf, ax, ay, aa);
+            iw_pairLattice<0, 1>(c, below, ax, ay, aa); iw_pairLattice<0, -1>(c, above, ax, ay, aa);
+        } else {
+            iw_pair(c, rt, ax, ay, aa); iw_pair(c, lf, ax, ay, aa); iw_pair(c, below, ax, ay, aa); iw_pair(c, above, ax, ay, aa);
         }
+        ox = w2 * ax; oy = w2 * ay; oa = w2 * aa;
+        const bool fit = (c.f & kFit) != 0;
+        ox += fit ? wf2 * c.ox : T(0); oy += fit ? wf2 * c.oy : T(0);
+        const bool act = (c.f & kActive) != 0;
+        ox = act ? ox : T(0); oy = act ? oy : T(0); oa = act ? oa : T(0);
+    };
+    // window state: o0, o1 = p_{k-1} rows y, y+1;  n0, n1 = p_k rows y-1, y
+    OldRow<T> o0 = makeOld(iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, yb - 2));
+    OldRow<T> o1 = makeOld(iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, yb - 1));
+    IterPx<T> n0{}, n1{};
+    auto trip = [&](int y, const IterRaw<T>& raw, bool live) {     // raw = row y+2
+        const OldRow<T> o2 = makeOld(raw);
+        // Step1 of iteration k-1 again at row y+1, then its Step2 + Step3
+        T ax, ay, aa;
+        applyA(o1.p, o0.p, o2.p, ax, ay, aa);
+        const T rx = first ? o1.rx : o1.rx - alpha * ax, ry = first ? o1.ry : o1.ry - alpha * ay, ra = first ? o1.ra : o1.ra - alpha * aa;
+        IterPx<T> n2;
+        n2.mx = o1.mx; n2.my = o1.my; n2.ma = o1.ma;
+        n2.zx = n2.mx * rx; n2.zy = n2.my * ry; n2.za = n2.ma * ra;
+        n2.p = o1.p;
+        n2.p.ox = n2.zx + beta * o1.p.ox; n2.p.oy = n2.zy + beta * o1.p.oy; n2.p.a = n2.za + beta * o1.p.a;
+        if (live && writer && y + 1 >= yb && y + 1 < ye) {
+            const long i = (long)phys(y + 1) * A.W + x;
+            st2<kNTS>(rO, i, rx, ry); st1<kNTS>(rA, i, ra); st2<kNTS>(pO, i, n2.p.ox, n2.p.oy); st1<kNTS>(pA, i, n2.p.a);
+            if (!first) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462)
+                const V2<T> d = dO[i]; const T da = dA[i];
+                st2<kNTS>(dO, i, d.x + alpha * o1.p.ox, d.y + alpha * o1.p.oy); st1<kNTS>(dA, i, da + alpha * o1.p.a);
+            }
+            accNum += (double)(n2.zx * rx + n2.zy * ry + n2.za * ra);
+        }
+        // Step1 of iteration k at row y
+        T ox, oy, oa;
+        applyA(n1.p, n0.p, n2.p, ox, oy, oa);
+        if (live && writer && y >= yb) {
+            accDen += (double)(n1.p.ox * ox + n1.p.oy * oy + n1.p.a * oa);
+            acc2 += (double)(n1.zx * ox + n1.zy * oy + n1.za * oa);
+            acc3 += (double)((n1.mx * ox) * ox + (n1.my * oy) * oy + (n1.ma * oa) * oa);
+        }
+        o0 = o1; o1 = o2; n0 = n1; n1 = n2;
+    };
+    // trips y = yb-2 .. ye-1: the first two only build p_k(yb-1), p_k(yb); two per loop pass, no branch around a load
+    IterRaw<T> rA2 = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, yb), rB2 = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, yb + 1);
+    for (int y = yb - 2; y < ye; y += 2) {
+        if (IW_ROW_SYNC) __syncthreads();
+        const IterRaw<T> a = rA2;
+        rA2 = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, y + 4);
+        trip(y, a, true);
+        const IterRaw<T> b = rB2;
+        rB2 = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, y + 5);
+        trip(y + 1, b, y + 1 < ye);
     }
     double t;
     t = blockReduceSum(accDen, scratch); if (threadIdx.x == 0) K.aDen[blockIdx.x] = t;
@@ -609,6 +765,8 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_XCD")) xcdMap = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_LATTICE")) useLattice = atoi(e) != 0;       // A/B switches
         if (const char* e = getenv("OPT_AMD_COMPACT_M")) useCompactM = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_SWEEP")) alternateSweep = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_RECOMPUTE_AP")) recomputeAp = atoi(e) != 0;
         HIP_CHECK(hipMalloc((void**)&dNotLattice, sizeof(int)));
     }
     ~ImageWarpingOps() override { (void)hipFree(A.flags); (void)hipFree(A.cs); if (mc) (void)hipFree(mc); (void)hipFree(dNotLattice); }
@@ -689,12 +847,20 @@ struct ImageWarpingOps : EnergyOps<T> {
         launchApply(pOld, out, CtC, dot, ctx, &F);
         return true;
     }
-    int occIter[2] = {0, 0};
+    int occIter[12] = {0};
+    int iterFlip = 0; bool alternateSweep = true, recomputeAp = true;
+    template <bool LAT, int PRE> static const void* iterFn(bool noAp) { return noAp ? (const void*)iw_pcgIter2<T, LAT, PRE> : (const void*)iw_pcgIter<T, LAT, PRE>; }
+    static const void* iterKernel(bool lat, int pre, bool noAp) {
+        return lat ? (pre == 2 ? iterFn<true, 2>(noAp) : pre == 1 ? iterFn<true, 1>(noAp) : iterFn<true, 0>(noAp))
+                   : (pre == 2 ? iterFn<false, 2>(noAp) : pre == 1 ? iterFn<false, 1>(noAp) : iterFn<false, 0>(noAp));
+    }
     T* mc = nullptr; int* dNotLattice = nullptr; bool lattice = false, useLattice = true, useCompactM = true;
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
-        const int L = lattice ? 1 : 0;
+        const int pre = !a.pre ? 0 : useCompactM ? 2 : 1;
+        const bool noAp = recomputeAp && !this->slab.active;      // iw_pcgIter2: Ap recomputed instead of stored (single GPU)
+        const int L = (noAp ? 6 : 0) + (lattice ? 3 : 0) + pre;
+        const void* fn = iterKernel(lattice, pre, noAp);
         if (occIter[L] == 0) {
-            const void* fn = lattice ? (const void*)iw_pcgIter<T, true> : (const void*)iw_pcgIter<T, false>;
             HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occIter[L], fn, kIterBlock, 0));
             occIter[L] = std::max(1, std::min(occIter[L], 8));
         }
@@ -703,19 +869,23 @@ struct ImageWarpingOps : EnergyOps<T> {
             ScopedKernel k(ctx, "compactPreconditioner");
             iw_compactM<T><<<flatGrid((long)A.W * A.H), kBlock, 0, ctx.stream>>>(a.pre, mc, (long)A.W * A.H);
         }
-        const int gx = divUp(A.W, kIterStrip);
+        const int gx = divUp(A.W, noAp ? kIterStrip2 : kIterStrip);
         const int rows = A.yEnd - A.yBegin;
         int gy = std::max(1, std::min(std::min(rows, cus * occIter[L] / gx), kMaxPartials / gx));
-        const int rowsPerGroup = divUp(rows, gy);
+        int rowsPerGroup = divUp(rows, gy);
+        if (const char* e = getenv("OPT_AMD_ITER_ROWS")) rowsPerGroup = std::max(atoi(e), divUp(rows, kMaxPartials / gx));   // experiment: more, shorter groups
         gy = divUp(rows, rowsPerGroup);
-        IterK<T> K{a.rOld, a.ApOld, a.pOld, a.rNew, a.ApNew, a.pNew, a.delta, a.pre, a.first, (a.pre && useCompactM) ? mc : nullptr,
+        if (a.first) iterFlip = 0;      // every linear solve starts top-down, so a solve is reproducible whatever ran before it
+        IterK<T> K{a.rOld, a.ApOld, a.pOld, a.rNew, a.ApNew, a.pNew, a.delta, a.pre, a.first, (a.pre && useCompactM) ? mc : nullptr, iterFlip,
                    a.aNumPrev.partials, a.aDenPrev.partials, a.s2Prev.partials, a.s3Prev.partials, a.aNumPrev.n, a.aDenPrev.n, a.s2Prev.n, a.s3Prev.n,
                    a.aNum->partials, a.aDen->partials, a.s2->partials, a.s3->partials};
         {
             ScopedKernel k(ctx, "PCGIteration");
-            if (lattice) iw_pcgIter<T, true><<<gx * gy, kIterBlock, 0, ctx.stream>>>(A, K, rowsPerGroup, gx, gy);
-            else iw_pcgIter<T, false><<<gx * gy, kIterBlock, 0, ctx.stream>>>(A, K, rowsPerGroup, gx, gy);
+            int rpg = rowsPerGroup, gxa = gx, gya = gy;
+            void* kargs[] = {(void*)&A, (void*)&K, (void*)&rpg, (void*)&gxa, (void*)&gya};
+            HIP_CHECK(hipLaunchKernel(fn, dim3(gx * gy), dim3(kIterBlock), kargs, 0, ctx.stream));
         }
+        if (alternateSweep) iterFlip ^= 1;
         a.aNum->n = a.aDen->n = a.s2->n = a.s3->n = gx * gy;
         if (this->slab.active) iw_zeroGhost<T><<<divUp(A.W, kBlock), kBlock, 0, ctx.stream>>>(A, a.ApNew);
         return true;
