@@ -46,17 +46,26 @@ struct IWArgs {
 };
 
 constexpr uint8_t kActive = 1, kFit = 2;
+constexpr int kCountShift = 2;       // bits 2..4: number of active 4-neighbours (0..4) of an active pixel
 
 // once per Init/Step: fold Mask / Constraints / global bounds into one byte per pixel
 template <class T>
 __global__ __launch_bounds__(kBlock) void iw_flags(IWArgs<T> A) {
     const long N = (long)A.W * A.H;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
-        const int y = (int)(i / A.W), gy = A.gy0 + y;
+        const int y = (int)(i / A.W), x = (int)(i % A.W), gy = A.gy0 + y;
         uint8_t f = 0;
         if (gy >= 0 && gy < A.Hg && A.Mask[i] == T(0)) f |= kActive;                          // eq(Mask,0)  (image_warping.t:11,17)
         if (A.Constraints[2 * i] >= T(0) && A.Constraints[2 * i + 1] >= T(0)) f |= kFit;      // All(greatereq(C,0)) (:22)
-        A.flags[i] = f;
+        // how many regularisation residuals v(c,n) are on: with it the Jacobi preconditioner of the Offset part (and, on a
+        // unit lattice, of the Angle part) is a function of this byte alone and need not be streamed (iw_pcgIter2, PRE == 3)
+        int cnt = 0;
+        const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};
+        for (int n = 0; n < 4; ++n) {
+            const int nx = x + dx[n], ny = y + dy[n], ngy = A.gy0 + ny;
+            if (nx >= 0 && nx < A.W && ny >= 0 && ny < A.H && ngy >= 0 && ngy < A.Hg && A.Mask[(long)ny * A.W + nx] == T(0)) ++cnt;
+        }
+        A.flags[i] = f | (uint8_t)(cnt << kCountShift);
     }
 }
 // once per Gauss-Newton iteration: (cos a, sin a)
@@ -415,7 +424,8 @@ __device__ __forceinline__ IterRaw<T> iw_iterLoad(const IWArgs<T>& A, const Iter
     r.ro = ld2<kNTL>((const V2<T>*)K.rOld, i); r.ra = ld1<kNTL>(K.rOld + 2 * N, i);
     r.ao = ld2<kNTL>((const V2<T>*)K.ApOld, i); r.aa = ld1<kNTL>(K.ApOld + 2 * N, i);
     r.po = ld2<kNTL>((const V2<T>*)K.pOld, i); r.pa = ld1<kNTL>(K.pOld + 2 * N, i);
-    if (PRE == 2) { r.mo = ld2<kNTL>((const V2<T>*)K.mc, i); r.ma = 0; }
+    if (PRE == 3) { r.mo = V2<T>{0, 0}; r.ma = 0; }
+    else if (PRE == 2) { r.mo = ld2<kNTL>((const V2<T>*)K.mc, i); r.ma = 0; }
     else if (PRE == 1) { r.mo = ld2<kNTL>((const V2<T>*)K.pre, i); r.ma = ld1<kNTL>(K.pre + 2 * N, i); }
     else { r.mo = V2<T>{1, 1}; r.ma = 1; }
     r.cs = ld2<kNTL>((const V2<T>*)A.cs, i);
@@ -591,6 +601,23 @@ __global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter2(IWArgs
     double accDen = 0, accNum = 0, acc2 = 0, acc3 = 0;
     V2<T>* rO = (V2<T>*)K.rNew; T* rA = K.rNew + 2 * N; V2<T>* pO = (V2<T>*)K.pNew; T* pA = K.pNew + 2 * N;
     V2<T>* dO = (V2<T>*)K.delta; T* dA = K.delta + 2 * N;
+    // PRE == 3 (unit lattice): M = guardedInvert(diag J^T J) takes one of 10 (Offset) / 5 (Angle) values, indexed by the fit bit
+    // and the neighbour count of the flag byte.  The Offset entries repeat iw_evalJTF's accumulation order, so they are the
+    // values the solver's preconditioner vector holds, bit for bit; the Angle entries use |R'(a) n|^2 = 1 exactly where
+    // iw_evalJTF rounds cos^2 + sin^2.
+    __shared__ T mTab[16];
+    if (PRE == 3) {
+        if (threadIdx.x < 15) {
+            const int t = threadIdx.x, cnt = t < 10 ? t % 5 : t - 10;
+            const T w = A.w_reg;
+            T d = 0;
+            if (t < 10) { for (int n = 0; n < cnt; ++n) d += w * w + w * w; if (t >= 5) d += A.w_fit * A.w_fit; }
+            else for (int n = 0; n < cnt; ++n) d += (w * T(1)) * (w * T(1));
+            const T sq = T(1) + sqrt(d);
+            mTab[t] = T(1) / (sq * sq);                      // solver.hip guardedInvert (solver.t:323-332)
+        }
+        __syncthreads();
+    }
 
     auto makeOld = [&](const IterRaw<T>& w) {
         OldRow<T> o;
@@ -598,7 +625,10 @@ __global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter2(IWArgs
         o.p.c = regCopy(w.cs.x); o.p.s = regCopy(w.cs.y); o.p.f = w.ok ? w.f : 0;
         if (LATTICE) { o.p.ux = 0; o.p.uy = 0; } else { o.p.ux = regCopy(w.u.x); o.p.uy = regCopy(w.u.y); }
         o.rx = w.ro.x; o.ry = w.ro.y; o.ra = w.ra;
-        o.mx = regCopy(w.mo.x); o.my = (PRE == 2) ? o.mx : regCopy(w.mo.y); o.ma = regCopy((PRE == 2) ? w.mo.y : w.ma);
+        if (PRE == 3) {
+            const int cnt = (w.f >> kCountShift) & 7;
+            o.mx = o.my = mTab[cnt + ((w.f & kFit) ? 5 : 0)]; o.ma = mTab[10 + cnt];
+        } else { o.mx = regCopy(w.mo.x); o.my = (PRE == 2) ? o.mx : regCopy(w.mo.y); o.ma = regCopy((PRE == 2) ? w.mo.y : w.ma); }
         return o;
     };
     // J^T J applied at the centre row `c` (image rows: `prev` is the row before it in sweep order, `next` the one after)
@@ -767,6 +797,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_COMPACT_M")) useCompactM = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_SWEEP")) alternateSweep = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_RECOMPUTE_AP")) recomputeAp = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_FLAG_M")) flagPreconditioner = atoi(e) != 0;
         HIP_CHECK(hipMalloc((void**)&dNotLattice, sizeof(int)));
     }
     ~ImageWarpingOps() override { (void)hipFree(A.flags); (void)hipFree(A.cs); if (mc) (void)hipFree(mc); (void)hipFree(dNotLattice); }
@@ -847,24 +878,26 @@ struct ImageWarpingOps : EnergyOps<T> {
         launchApply(pOld, out, CtC, dot, ctx, &F);
         return true;
     }
-    int occIter[12] = {0};
+    int occIter[13] = {0};
     int iterFlip = 0; bool alternateSweep = true, recomputeAp = true;
     template <bool LAT, int PRE> static const void* iterFn(bool noAp) { return noAp ? (const void*)iw_pcgIter2<T, LAT, PRE> : (const void*)iw_pcgIter<T, LAT, PRE>; }
     static const void* iterKernel(bool lat, int pre, bool noAp) {
+        if (pre == 3) return (const void*)iw_pcgIter2<T, true, 3>;
         return lat ? (pre == 2 ? iterFn<true, 2>(noAp) : pre == 1 ? iterFn<true, 1>(noAp) : iterFn<true, 0>(noAp))
                    : (pre == 2 ? iterFn<false, 2>(noAp) : pre == 1 ? iterFn<false, 1>(noAp) : iterFn<false, 0>(noAp));
     }
+    bool flagPreconditioner = true;
     T* mc = nullptr; int* dNotLattice = nullptr; bool lattice = false, useLattice = true, useCompactM = true;
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
-        const int pre = !a.pre ? 0 : useCompactM ? 2 : 1;
         const bool noAp = recomputeAp && !this->slab.active;      // iw_pcgIter2: Ap recomputed instead of stored (single GPU)
-        const int L = (noAp ? 6 : 0) + (lattice ? 3 : 0) + pre;
+        const int pre = !a.pre ? 0 : (noAp && lattice && flagPreconditioner) ? 3 : useCompactM ? 2 : 1;
+        const int L = pre == 3 ? 12 : (noAp ? 6 : 0) + (lattice ? 3 : 0) + pre;
         const void* fn = iterKernel(lattice, pre, noAp);
         if (occIter[L] == 0) {
             HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occIter[L], fn, kIterBlock, 0));
             occIter[L] = std::max(1, std::min(occIter[L], 8));
         }
-        if (a.first && a.pre && useCompactM) {
+        if (a.first && pre == 2) {
             if (!mc) HIP_CHECK(hipMalloc((void**)&mc, (size_t)A.W * A.H * 2 * sizeof(T)));
             ScopedKernel k(ctx, "compactPreconditioner");
             iw_compactM<T><<<flatGrid((long)A.W * A.H), kBlock, 0, ctx.stream>>>(a.pre, mc, (long)A.W * A.H);
@@ -876,7 +909,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_ITER_ROWS")) rowsPerGroup = std::max(atoi(e), divUp(rows, kMaxPartials / gx));   // experiment: more, shorter groups
         gy = divUp(rows, rowsPerGroup);
         if (a.first) iterFlip = 0;      // every linear solve starts top-down, so a solve is reproducible whatever ran before it
-        IterK<T> K{a.rOld, a.ApOld, a.pOld, a.rNew, a.ApNew, a.pNew, a.delta, a.pre, a.first, (a.pre && useCompactM) ? mc : nullptr, iterFlip,
+        IterK<T> K{a.rOld, a.ApOld, a.pOld, a.rNew, a.ApNew, a.pNew, a.delta, a.pre, a.first, pre == 2 ? mc : nullptr, iterFlip,
                    a.aNumPrev.partials, a.aDenPrev.partials, a.s2Prev.partials, a.s3Prev.partials, a.aNumPrev.n, a.aDenPrev.n, a.s2Prev.n, a.s3Prev.n,
                    a.aNum->partials, a.aDen->partials, a.s2->partials, a.s3->partials};
         {
