@@ -13,8 +13,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libOpt.so")
 OBJDIR = os.path.join(HERE, "build")
+# -fno-slp-vectorize: the SLP vectoriser pairs unrelated fp32 operations into v_pk_* instructions and pays for it with
+# v_mov packing (and, in the row-marching kernels, with copies of not-yet-arrived loads); measured 1-3 % slower.
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-Wno-misleading-indentation"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-Wno-misleading-indentation"]
 
 
 def sources():

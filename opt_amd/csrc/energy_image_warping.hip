@@ -568,16 +568,69 @@ __global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter(IWArgs<
 // A wave covers 64 consecutive pixels and produces the inner 60 (p_k needs one DPP ring, Ap_k a second).  Rows: a
 // sliding window of three rows of p_{k-1} and three of p_k in registers; trip y turns the freshly loaded row y+2 into
 // Ap_{k-1}(y+1), p_k(y+1) and then Ap_k(y).  Not used with row slabs (the halo exchange would need two ghost rows).
+// Workgroup shape (two stencil evaluations per pixel, 150-170 VGPRs): 768 threads = 3 waves per SIMD is the best,
+// 3400 PCG it/s against 3030 (512), 3190 (1024: fewer registers per wave), 2840 (256); interleaved A/B on one box.
+#ifndef ITER2_BLOCK
+#define ITER2_BLOCK 768
+#endif
+constexpr int kIterBlock2 = ITER2_BLOCK;
 constexpr int kSpan2 = kWave - 4;
-constexpr int kIterStrip2 = (kIterBlock / kWave) * kSpan2;
+constexpr int kIterStrip2 = (kIterBlock2 / kWave) * kSpan2;
+// VALU matters in this kernel (two stencil evaluations per pixel), so its inner loop avoids selects and moves:
+//  * activity is a 0/1 multiplier (`on`), the fit weight a 0/w_fit^2 multiplier (`fw`): an inactive or non-existent
+//    neighbour drops out of an FMA instead of a v_cndmask (its fields are finite: clamped loads, zero-filled DPP edges);
+//  * on a unit lattice the derivative columns R'(a)(U_c - U_n) are +-(sin, cos) picked at compile time per direction;
+//  * the sweep direction is a template parameter; the row windows are rotated by name over three trips per loop
+//    pass (three prefetch buffers), so no register copies are needed at the back-edge;
+//  * the shifted cos / sin / on of a row are kept from its first use (centre of Ap_{k-1}) for its second (centre of Ap_k).
 template <class T>
-struct OldRow {            // one row of iteration k-1: p_{k-1} (+ cos/sin, U, flags) and, while still needed, r_{k-1} and M
-    Px<T> p;
+struct Q {            // one pixel of a row held in registers
+    T ox, oy, a;      // the vector (p_{k-1} or p_k)
+    T c, s;           // cos/sin of the pixel's angle
+    T ux, uy;         // UrShape (dead on a unit lattice)
+    T on;             // 1 if the pixel exists and is not excluded, else 0
+    T fw;             // w_fit^2 if its fit residual is on, else 0
+};
+template <bool RIGHT, bool LATTICE, class T> __device__ __forceinline__ void dppShiftConst(const Q<T>& p, Q<T>& q) {   // the fields that do not change between p_{k-1} and p_k
+    q.c = dppShift<RIGHT>(p.c); q.s = dppShift<RIGHT>(p.s); q.on = dppShift<RIGHT>(p.on);
+    if (LATTICE) { q.ux = 0; q.uy = 0; } else { q.ux = dppShift<RIGHT>(p.ux); q.uy = dppShift<RIGHT>(p.uy); }
+    q.fw = 0;
+}
+template <bool RIGHT, class T> __device__ __forceinline__ void dppShiftVec(const Q<T>& p, Q<T>& q) {
+    q.ox = dppShift<RIGHT>(p.ox); q.oy = dppShift<RIGHT>(p.oy); q.a = dppShift<RIGHT>(p.a);
+}
+// the two residuals shared by centre c and its neighbour n in direction (DX, DY) (see iw_pair)
+template <int DX, int DY, bool LATTICE, class T>
+__device__ __forceinline__ void iw_pairQ(const Q<T>& c, const Q<T>& n, T& ax, T& ay, T& aa) {
+    T Dcx, Dcy, Dnx, Dny;
+    if (LATTICE) {       // U_c - U_n = -(DX, DY)
+        Dcx = DX ? T(DX) * c.s : T(DY) * c.c;   Dcy = DX ? T(-DX) * c.c : T(DY) * c.s;
+        Dnx = DX ? T(-DX) * n.s : T(-DY) * n.c; Dny = DX ? T(DX) * n.c : T(-DY) * n.s;
+    } else {
+        const T ux = c.ux - n.ux, uy = c.uy - n.uy;
+        Dcx = -c.s * ux - c.c * uy; Dcy = c.c * ux - c.s * uy;
+        Dnx = n.s * ux + n.c * uy;  Dny = -n.c * ux + n.s * uy;
+    }
+    const T dx = c.ox - n.ox, dy = c.oy - n.oy;
+    const T jcx = dx - Dcx * c.a, jcy = dy - Dcy * c.a;
+    const T jnx = -dx - Dnx * n.a, jny = -dy - Dny * n.a;
+    ax += n.on * (jcx - jnx); ay += n.on * (jcy - jny);
+    aa -= n.on * (Dcx * jcx + Dcy * jcy);
+}
+template <class T>
+struct OldRow {            // one row of iteration k-1: p_{k-1} and, while still needed, r_{k-1} and M
+    Q<T> q;
     T rx, ry, ra, mx, my, ma;
 };
-template <class T, bool LATTICE, int PRE>
-__global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter2(IWArgs<T> A, IterK<T> K, int rowsPerGroup, int gx, int gy) {
-    __shared__ double scratch[kIterBlock / kWave + 1];
+template <class T>
+struct NewRow {            // one row of iteration k: p_k, z_k, M, and the shifted constant fields of its neighbours
+    Q<T> q;
+    T zx, zy, za, mx, my, ma;
+    Q<T> lf, rt;           // only c, s, (ux, uy,) on are kept here
+};
+template <class T, bool LATTICE, int PRE, bool FLIP>
+__global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArgs<T> A, IterK<T> K, int rowsPerGroup, int gx, int gy) {
+    __shared__ double scratch[kIterBlock2 / kWave + 1];
     const long N = (long)A.W * A.H;
     T alpha = 0, beta = 0;
     const bool first = K.first != 0;
@@ -594,8 +647,7 @@ __global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter2(IWArgs
     const int x = bx * kIterStrip2 + wave * kSpan2 + lane - 2;
     const bool xok = x >= 0 && x < A.W;
     const bool writer = xok && lane >= 2 && lane < 2 + kSpan2;
-    const bool flip = K.flip != 0;                              // mirrored row coordinates, see iw_pcgIter
-    auto phys = [&](int y) { return flip ? A.H - 1 - y : y; };
+    auto phys = [&](int y) { return FLIP ? A.H - 1 - y : y; };   // mirrored row coordinates, see iw_pcgIter (K.flip == FLIP)
     const int yb = by * rowsPerGroup, ye = min(yb + rowsPerGroup, A.H);
     const T w2 = A.w_reg * A.w_reg, wf2 = A.w_fit * A.w_fit;
     double accDen = 0, accNum = 0, acc2 = 0, acc3 = 0;
@@ -619,79 +671,72 @@ __global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter2(IWArgs
         __syncthreads();
     }
 
-    auto makeOld = [&](const IterRaw<T>& w) {
-        OldRow<T> o;
-        o.p.ox = w.po.x; o.p.oy = w.po.y; o.p.a = w.pa;
-        o.p.c = regCopy(w.cs.x); o.p.s = regCopy(w.cs.y); o.p.f = w.ok ? w.f : 0;
-        if (LATTICE) { o.p.ux = 0; o.p.uy = 0; } else { o.p.ux = regCopy(w.u.x); o.p.uy = regCopy(w.u.y); }
+    auto makeOld = [&](const IterRaw<T>& w, OldRow<T>& o) {
+        o.q.ox = w.po.x; o.q.oy = w.po.y; o.q.a = w.pa;
+        o.q.c = w.cs.x; o.q.s = w.cs.y;
+        if (LATTICE) { o.q.ux = 0; o.q.uy = 0; } else { o.q.ux = w.u.x; o.q.uy = w.u.y; }
+        o.q.on = (w.ok && (w.f & kActive)) ? T(1) : T(0);
+        o.q.fw = (w.f & kFit) ? wf2 : T(0);
         o.rx = w.ro.x; o.ry = w.ro.y; o.ra = w.ra;
         if (PRE == 3) {
             const int cnt = (w.f >> kCountShift) & 7;
             o.mx = o.my = mTab[cnt + ((w.f & kFit) ? 5 : 0)]; o.ma = mTab[10 + cnt];
-        } else { o.mx = regCopy(w.mo.x); o.my = (PRE == 2) ? o.mx : regCopy(w.mo.y); o.ma = regCopy((PRE == 2) ? w.mo.y : w.ma); }
-        return o;
+        } else { o.mx = w.mo.x; o.my = (PRE == 2) ? w.mo.x : w.mo.y; o.ma = (PRE == 2) ? w.mo.y : w.ma; }
     };
-    // J^T J applied at the centre row `c` (image rows: `prev` is the row before it in sweep order, `next` the one after)
-    auto applyA = [&](const Px<T>& c, const Px<T>& prev, const Px<T>& next, T& ox, T& oy, T& oa) {
-        const Px<T> lf = dppShiftPx<true>(c), rt = dppShiftPx<false>(c);
-        const Px<T> below = flip ? prev : next, above = flip ? next : prev;
+    // J^T J at centre c; prev / next are the rows before / after it in sweep order
+    auto applyA = [&](const Q<T>& c, const Q<T>& lf, const Q<T>& rt, const Q<T>& prev, const Q<T>& next, T& ox, T& oy, T& oa) {
+        const Q<T>& below = FLIP ? prev : next; const Q<T>& above = FLIP ? next : prev;     // image rows y+1 / y-1
         T ax = 0, ay = 0, aa = 0;
-        if (LATTICE) {
-            iw_pairLattice<1, 0>(c, rt, ax, ay, aa); iw_pairLattice<-1, 0>(c, lf, ax, ay, aa);
-            iw_pairLattice<0, 1>(c, below, ax, ay, aa); iw_pairLattice<0, -1>(c, above, ax, ay, aa);
-        } else {
-            iw_pair(c, rt, ax, ay, aa); iw_pair(c, lf, ax, ay, aa); iw_pair(c, below, ax, ay, aa); iw_pair(c, above, ax, ay, aa);
-        }
-        ox = w2 * ax; oy = w2 * ay; oa = w2 * aa;
-        const bool fit = (c.f & kFit) != 0;
-        ox += fit ? wf2 * c.ox : T(0); oy += fit ? wf2 * c.oy : T(0);
-        const bool act = (c.f & kActive) != 0;
-        ox = act ? ox : T(0); oy = act ? oy : T(0); oa = act ? oa : T(0);
+        iw_pairQ<1, 0, LATTICE>(c, rt, ax, ay, aa); iw_pairQ<-1, 0, LATTICE>(c, lf, ax, ay, aa);
+        iw_pairQ<0, 1, LATTICE>(c, below, ax, ay, aa); iw_pairQ<0, -1, LATTICE>(c, above, ax, ay, aa);
+        ox = c.on * (w2 * ax + c.fw * c.ox); oy = c.on * (w2 * ay + c.fw * c.oy); oa = c.on * (w2 * aa);
     };
-    // window state: o0, o1 = p_{k-1} rows y, y+1;  n0, n1 = p_k rows y-1, y
-    OldRow<T> o0 = makeOld(iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, yb - 2));
-    OldRow<T> o1 = makeOld(iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, yb - 1));
-    IterPx<T> n0{}, n1{};
-    auto trip = [&](int y, const IterRaw<T>& raw, bool live) {     // raw = row y+2
-        const OldRow<T> o2 = makeOld(raw);
-        // Step1 of iteration k-1 again at row y+1, then its Step2 + Step3
+    // One trip: the freshly loaded row y+2 -> Ap_{k-1}(y+1), r_k, z_k, p_k (y+1) -> Ap_k(y).
+    // oA, oB = p_{k-1} rows y, y+1 (oC receives y+2);  nA, nB = p_k rows y-1, y (nC receives y+1)
+    auto trip = [&](int y, const IterRaw<T>& raw, const OldRow<T>& oA, const OldRow<T>& oB, OldRow<T>& oC,
+                    const NewRow<T>& nA, const NewRow<T>& nB, NewRow<T>& nC, bool live) {
+        makeOld(raw, oC);
+        nC.q = oB.q;
+        dppShiftConst<true, LATTICE>(oB.q, nC.lf); dppShiftConst<false, LATTICE>(oB.q, nC.rt);
+        Q<T> lf = nC.lf, rt = nC.rt;
+        dppShiftVec<true>(oB.q, lf); dppShiftVec<false>(oB.q, rt);
         T ax, ay, aa;
-        applyA(o1.p, o0.p, o2.p, ax, ay, aa);
-        const T rx = first ? o1.rx : o1.rx - alpha * ax, ry = first ? o1.ry : o1.ry - alpha * ay, ra = first ? o1.ra : o1.ra - alpha * aa;
-        IterPx<T> n2;
-        n2.mx = o1.mx; n2.my = o1.my; n2.ma = o1.ma;
-        n2.zx = n2.mx * rx; n2.zy = n2.my * ry; n2.za = n2.ma * ra;
-        n2.p = o1.p;
-        n2.p.ox = n2.zx + beta * o1.p.ox; n2.p.oy = n2.zy + beta * o1.p.oy; n2.p.a = n2.za + beta * o1.p.a;
+        applyA(oB.q, lf, rt, oA.q, oC.q, ax, ay, aa);                                   // Step1 of iteration k-1 again
+        const T rx = first ? oB.rx : oB.rx - alpha * ax, ry = first ? oB.ry : oB.ry - alpha * ay, ra = first ? oB.ra : oB.ra - alpha * aa;   // Step2
+        nC.mx = oB.mx; nC.my = oB.my; nC.ma = oB.ma;
+        nC.zx = nC.mx * rx; nC.zy = nC.my * ry; nC.za = nC.ma * ra;
+        nC.q.ox = nC.zx + beta * oB.q.ox; nC.q.oy = nC.zy + beta * oB.q.oy; nC.q.a = nC.za + beta * oB.q.a;                               // Step3
         if (live && writer && y + 1 >= yb && y + 1 < ye) {
             const long i = (long)phys(y + 1) * A.W + x;
-            st2<kNTS>(rO, i, rx, ry); st1<kNTS>(rA, i, ra); st2<kNTS>(pO, i, n2.p.ox, n2.p.oy); st1<kNTS>(pA, i, n2.p.a);
+            st2<kNTS>(rO, i, rx, ry); st1<kNTS>(rA, i, ra); st2<kNTS>(pO, i, nC.q.ox, nC.q.oy); st1<kNTS>(pA, i, nC.q.a);
             if (!first) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462)
                 const V2<T> d = dO[i]; const T da = dA[i];
-                st2<kNTS>(dO, i, d.x + alpha * o1.p.ox, d.y + alpha * o1.p.oy); st1<kNTS>(dA, i, da + alpha * o1.p.a);
+                st2<kNTS>(dO, i, d.x + alpha * oB.q.ox, d.y + alpha * oB.q.oy); st1<kNTS>(dA, i, da + alpha * oB.q.a);
             }
-            accNum += (double)(n2.zx * rx + n2.zy * ry + n2.za * ra);
+            accNum += (double)(nC.zx * rx + nC.zy * ry + nC.za * ra);
         }
-        // Step1 of iteration k at row y
+        Q<T> l2 = nB.lf, r2 = nB.rt;
+        dppShiftVec<true>(nB.q, l2); dppShiftVec<false>(nB.q, r2);
         T ox, oy, oa;
-        applyA(n1.p, n0.p, n2.p, ox, oy, oa);
+        applyA(nB.q, l2, r2, nA.q, nC.q, ox, oy, oa);                                   // Step1 of iteration k
         if (live && writer && y >= yb) {
-            accDen += (double)(n1.p.ox * ox + n1.p.oy * oy + n1.p.a * oa);
-            acc2 += (double)(n1.zx * ox + n1.zy * oy + n1.za * oa);
-            acc3 += (double)((n1.mx * ox) * ox + (n1.my * oy) * oy + (n1.ma * oa) * oa);
+            accDen += (double)(nB.q.ox * ox + nB.q.oy * oy + nB.q.a * oa);
+            acc2 += (double)(nB.zx * ox + nB.zy * oy + nB.za * oa);
+            acc3 += (double)((nB.mx * ox) * ox + (nB.my * oy) * oy + (nB.ma * oa) * oa);
         }
-        o0 = o1; o1 = o2; n0 = n1; n1 = n2;
     };
-    // trips y = yb-2 .. ye-1: the first two only build p_k(yb-1), p_k(yb); two per loop pass, no branch around a load
-    IterRaw<T> rA2 = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, yb), rB2 = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, yb + 1);
-    for (int y = yb - 2; y < ye; y += 2) {
+    OldRow<T> o0, o1, o2;
+    NewRow<T> n0{}, n1{}, n2{};
+    makeOld(iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, yb - 2), o0);
+    makeOld(iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, yb - 1), o1);
+    // trips y = yb-2 .. ye-1 (the first two only build p_k(yb-1), p_k(yb)); three per pass, no branch around a load
+    IterRaw<T> rwA = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, yb), rwB = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, yb + 1),
+               rwC = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, yb + 2);
+    for (int y = yb - 2; y < ye; y += 3) {
         if (IW_ROW_SYNC) __syncthreads();
-        const IterRaw<T> a = rA2;
-        rA2 = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, y + 4);
-        trip(y, a, true);
-        const IterRaw<T> b = rB2;
-        rB2 = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, y + 5);
-        trip(y + 1, b, y + 1 < ye);
+        { const IterRaw<T> w = rwA; rwA = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, y + 5); trip(y, w, o0, o1, o2, n0, n1, n2, true); }
+        { const IterRaw<T> w = rwB; rwB = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, y + 6); trip(y + 1, w, o1, o2, o0, n1, n2, n0, y + 1 < ye); }
+        { const IterRaw<T> w = rwC; rwC = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, y + 7); trip(y + 2, w, o2, o0, o1, n2, n0, n1, y + 2 < ye); }
     }
     double t;
     t = blockReduceSum(accDen, scratch); if (threadIdx.x == 0) K.aDen[blockIdx.x] = t;
@@ -880,11 +925,13 @@ struct ImageWarpingOps : EnergyOps<T> {
     }
     int occIter[13] = {0};
     int iterFlip = 0; bool alternateSweep = true, recomputeAp = true;
-    template <bool LAT, int PRE> static const void* iterFn(bool noAp) { return noAp ? (const void*)iw_pcgIter2<T, LAT, PRE> : (const void*)iw_pcgIter<T, LAT, PRE>; }
-    static const void* iterKernel(bool lat, int pre, bool noAp) {
-        if (pre == 3) return (const void*)iw_pcgIter2<T, true, 3>;
-        return lat ? (pre == 2 ? iterFn<true, 2>(noAp) : pre == 1 ? iterFn<true, 1>(noAp) : iterFn<true, 0>(noAp))
-                   : (pre == 2 ? iterFn<false, 2>(noAp) : pre == 1 ? iterFn<false, 1>(noAp) : iterFn<false, 0>(noAp));
+    template <bool LAT, int PRE> static const void* iterFn(bool noAp, bool flip) {
+        return !noAp ? (const void*)iw_pcgIter<T, LAT, PRE> : flip ? (const void*)iw_pcgIter2<T, LAT, PRE, true> : (const void*)iw_pcgIter2<T, LAT, PRE, false>;
+    }
+    static const void* iterKernel(bool lat, int pre, bool noAp, bool flip) {
+        if (pre == 3) return flip ? (const void*)iw_pcgIter2<T, true, 3, true> : (const void*)iw_pcgIter2<T, true, 3, false>;
+        return lat ? (pre == 2 ? iterFn<true, 2>(noAp, flip) : pre == 1 ? iterFn<true, 1>(noAp, flip) : iterFn<true, 0>(noAp, flip))
+                   : (pre == 2 ? iterFn<false, 2>(noAp, flip) : pre == 1 ? iterFn<false, 1>(noAp, flip) : iterFn<false, 0>(noAp, flip));
     }
     bool flagPreconditioner = true;
     T* mc = nullptr; int* dNotLattice = nullptr; bool lattice = false, useLattice = true, useCompactM = true;
@@ -892,9 +939,10 @@ struct ImageWarpingOps : EnergyOps<T> {
         const bool noAp = recomputeAp && !this->slab.active;      // iw_pcgIter2: Ap recomputed instead of stored (single GPU)
         const int pre = !a.pre ? 0 : (noAp && lattice && flagPreconditioner) ? 3 : useCompactM ? 2 : 1;
         const int L = pre == 3 ? 12 : (noAp ? 6 : 0) + (lattice ? 3 : 0) + pre;
-        const void* fn = iterKernel(lattice, pre, noAp);
+        if (a.first) iterFlip = 0;      // every linear solve starts top-down, so a solve is reproducible whatever ran before it
+        const void* fn = iterKernel(lattice, pre, noAp, iterFlip != 0);
         if (occIter[L] == 0) {
-            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occIter[L], fn, kIterBlock, 0));
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occIter[L], fn, noAp ? kIterBlock2 : kIterBlock, 0));
             occIter[L] = std::max(1, std::min(occIter[L], 8));
         }
         if (a.first && pre == 2) {
@@ -908,7 +956,6 @@ struct ImageWarpingOps : EnergyOps<T> {
         int rowsPerGroup = divUp(rows, gy);
         if (const char* e = getenv("OPT_AMD_ITER_ROWS")) rowsPerGroup = std::max(atoi(e), divUp(rows, kMaxPartials / gx));   // experiment: more, shorter groups
         gy = divUp(rows, rowsPerGroup);
-        if (a.first) iterFlip = 0;      // every linear solve starts top-down, so a solve is reproducible whatever ran before it
         IterK<T> K{a.rOld, a.ApOld, a.pOld, a.rNew, a.ApNew, a.pNew, a.delta, a.pre, a.first, pre == 2 ? mc : nullptr, iterFlip,
                    a.aNumPrev.partials, a.aDenPrev.partials, a.s2Prev.partials, a.s3Prev.partials, a.aNumPrev.n, a.aDenPrev.n, a.s2Prev.n, a.s3Prev.n,
                    a.aNum->partials, a.aDen->partials, a.s2->partials, a.s3->partials};
@@ -916,7 +963,7 @@ struct ImageWarpingOps : EnergyOps<T> {
             ScopedKernel k(ctx, "PCGIteration");
             int rpg = rowsPerGroup, gxa = gx, gya = gy;
             void* kargs[] = {(void*)&A, (void*)&K, (void*)&rpg, (void*)&gxa, (void*)&gya};
-            HIP_CHECK(hipLaunchKernel(fn, dim3(gx * gy), dim3(kIterBlock), kargs, 0, ctx.stream));
+            HIP_CHECK(hipLaunchKernel(fn, dim3(gx * gy), dim3(noAp ? kIterBlock2 : kIterBlock), kargs, 0, ctx.stream));
         }
         if (alternateSweep) iterFlip ^= 1;
         a.aNum->n = a.aDen->n = a.s2->n = a.s3->n = gx * gy;
