@@ -14,6 +14,7 @@ namespace optamd {
 // exists iff 0 <= gy0+y < Hg.  Single GPU: yBegin=0, yEnd=H, gy0=0, Hg=H.
 struct Slab {
     int yBegin = 0, yEnd = 0, gy0 = 0, Hg = 0;
+    int ghost = 1;            // ghost rows above and below the owned rows (yBegin == ghost)
     bool active = false;
 };
 
@@ -61,6 +62,7 @@ struct EnergyOps {
     bool usePreconditioner = false;   // reference o.t:214 default
     bool usesGraph = false;
     Slab slab;
+    bool iterStateExchange = false;   // set by pcgIteration: in slab mode the solver exchanges the ghost rows of r and p after each launch (else of Ap before it)
     virtual ~EnergyOps() {}
     void addUnknown(int param, long elems, int channels) {
         unknowns.push_back({param, elems, channels, nScalars});

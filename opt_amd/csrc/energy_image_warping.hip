@@ -567,7 +567,8 @@ __global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter(IWArgs<
 // sequence on the same inputs as the Ap_{k-1} whose dot products the previous launch reduced.
 // A wave covers 64 consecutive pixels and produces the inner 60 (p_k needs one DPP ring, Ap_k a second).  Rows: a
 // sliding window of three rows of p_{k-1} and three of p_k in registers; trip y turns the freshly loaded row y+2 into
-// Ap_{k-1}(y+1), p_k(y+1) and then Ap_k(y).  Not used with row slabs (the halo exchange would need two ghost rows).
+// Ap_{k-1}(y+1), p_k(y+1) and then Ap_k(y).  With row slabs it needs two ghost rows per side (r and p of the neighbours'
+// edge rows, exchanged by the solver after every launch); with one ghost row the solver falls back to iw_pcgIter.
 // Workgroup shape (two stencil evaluations per pixel, 150-170 VGPRs): 768 threads = 3 waves per SIMD is the best,
 // 3400 PCG it/s against 3030 (512), 3190 (1024: fewer registers per wave), 2840 (256); interleaved A/B on one box.
 #ifndef ITER2_BLOCK
@@ -648,7 +649,8 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
     const bool xok = x >= 0 && x < A.W;
     const bool writer = xok && lane >= 2 && lane < 2 + kSpan2;
     auto phys = [&](int y) { return FLIP ? A.H - 1 - y : y; };   // mirrored row coordinates, see iw_pcgIter (K.flip == FLIP)
-    const int yb = by * rowsPerGroup, ye = min(yb + rowsPerGroup, A.H);
+    const int lyBegin = FLIP ? A.H - A.yEnd : A.yBegin, lyEnd = FLIP ? A.H - A.yBegin : A.yEnd;     // owned rows (a slab's ghost rows are plain halo here)
+    const int yb = lyBegin + by * rowsPerGroup, ye = min(yb + rowsPerGroup, lyEnd);
     const T w2 = A.w_reg * A.w_reg, wf2 = A.w_fit * A.w_fit;
     double accDen = 0, accNum = 0, acc2 = 0, acc3 = 0;
     V2<T>* rO = (V2<T>*)K.rNew; T* rA = K.rNew + 2 * N; V2<T>* pO = (V2<T>*)K.pNew; T* pA = K.pNew + 2 * N;
@@ -936,7 +938,8 @@ struct ImageWarpingOps : EnergyOps<T> {
     bool flagPreconditioner = true;
     T* mc = nullptr; int* dNotLattice = nullptr; bool lattice = false, useLattice = true, useCompactM = true;
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
-        const bool noAp = recomputeAp && !this->slab.active;      // iw_pcgIter2: Ap recomputed instead of stored (single GPU)
+        const bool noAp = recomputeAp && (!this->slab.active || this->slab.ghost >= 2);      // iw_pcgIter2: Ap recomputed instead of stored
+        this->iterStateExchange = noAp;     // slab mode: r and p ghost rows come from the neighbours after each launch (iw_pcgIter: Ap before it)
         const int pre = !a.pre ? 0 : (noAp && lattice && flagPreconditioner) ? 3 : useCompactM ? 2 : 1;
         const int L = pre == 3 ? 12 : (noAp ? 6 : 0) + (lattice ? 3 : 0) + pre;
         if (a.first) iterFlip = 0;      // every linear solve starts top-down, so a solve is reproducible whatever ran before it
@@ -967,7 +970,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         }
         if (alternateSweep) iterFlip ^= 1;
         a.aNum->n = a.aDen->n = a.s2->n = a.s3->n = gx * gy;
-        if (this->slab.active) iw_zeroGhost<T><<<divUp(A.W, kBlock), kBlock, 0, ctx.stream>>>(A, a.ApNew);
+        if (this->slab.active && !noAp) iw_zeroGhost<T><<<divUp(A.W, kBlock), kBlock, 0, ctx.stream>>>(A, a.ApNew);
         return true;
     }
     void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {

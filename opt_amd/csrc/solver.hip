@@ -374,9 +374,9 @@ struct PcgSolver : SolverBase {
         const void* su[8]; const void* sd[8]; void* ru[8]; void* rd[8]; long bytes[8];
         const int nb = (int)bases.size();
         for (int i = 0; i < nb; ++i) {
-            const long rs = E->rowScalars(i); T* base = bases[i];
-            su[i] = base + (long)s.yBegin * rs; sd[i] = base + (long)(s.yEnd - 1) * rs;
-            ru[i] = base + (long)(s.yBegin - 1) * rs; rd[i] = base + (long)s.yEnd * rs; bytes[i] = rs * (long)sizeof(T);
+            const long rs = E->rowScalars(i % (int)E->unknowns.size()); T* base = bases[i];   // bases: one per unknown image, possibly for several vectors
+            su[i] = base + (long)s.yBegin * rs; sd[i] = base + (long)(s.yEnd - s.ghost) * rs;          // my first / last `ghost` owned rows
+            ru[i] = base + (long)(s.yBegin - s.ghost) * rs; rd[i] = base + (long)s.yEnd * rs; bytes[i] = (long)s.ghost * rs * (long)sizeof(T);
         }
         comm.haloExchange(comm.ctx, nb, su, sd, ru, rd, bytes, (void*)stream);
     }
@@ -432,9 +432,14 @@ struct PcgSolver : SolverBase {
             a.rOld = r; a.ApOld = Ap_X; a.pOld = p; a.rNew = r2; a.ApNew = Ap2; a.pNew = p2; a.delta = delta; a.pre = preArg; a.first = lIter == 0;
             a.aNumPrev = prev[0]; a.aDenPrev = prev[1]; a.s2Prev = prev[2]; a.s3Prev = prev[3];
             a.aNum = &setS[cur][0]; a.aDen = &setS[cur][1]; a.s2 = &setS[cur][2]; a.s3 = &setS[cur][3];
-            if (distributed && lIter > 0) exchangeVector(Ap_X);   // r and p ghost rows are kept current by the kernel itself
+            if (distributed && lIter > 0 && !E->iterStateExchange) exchangeVector(Ap_X);   // kernel with Ap in memory: r and p ghost rows are kept current by the kernel itself
             if (!E->pcgIteration(a, ctx)) { if (lIter == 0) return false; fprintf(stderr, "pcgIteration refused mid-loop\n"); exit(1); }
             std::swap(r, r2); std::swap(Ap_X, Ap2); std::swap(p, p2);
+            if (distributed && E->iterStateExchange) {   // Ap-free kernel: the neighbours' edge rows of r_k and p_k, one grouped exchange
+                std::vector<T*> bases;
+                for (T* v : {r, p}) for (size_t i = 0; i < E->unknowns.size(); ++i) bases.push_back(v + E->unknowns[i].offset);
+                exchangeRows(bases);
+            }
             for (int i = 0; i < 4; ++i) prev[i] = setS[cur][i];
             if (distributed) {   // one all-reduce of the four sums
                 Partials4 in4; for (int i = 0; i < 4; ++i) { in4.p[i] = setS[cur][i].partials; in4.n[i] = setS[cur][i].n; }
@@ -671,7 +676,11 @@ struct PcgSolver : SolverBase {
     }
     int setSlab(long row0, long rows, long globalHeight, const OptAmd_SlabComm* c) override {
         if (!E->supportsSlab() || !c) return 0;
-        E->slab.active = true; E->slab.yBegin = 1; E->slab.yEnd = (int)rows + 1; E->slab.gy0 = (int)row0 - 1; E->slab.Hg = (int)globalHeight;
+        // local height = rows + 2 * ghost: the plan was created with dims {W, rows + 2 * ghost}
+        const long localH = E->unknowns[0].elems * E->unknowns[0].channels / E->rowScalars(0);
+        const long g = (localH - rows) / 2;
+        if (g < 1 || rows + 2 * g != localH) return 0;
+        E->slab.active = true; E->slab.ghost = (int)g; E->slab.yBegin = (int)g; E->slab.yEnd = (int)(rows + g); E->slab.gy0 = (int)(row0 - g); E->slab.Hg = (int)globalHeight;
         comm = *c; distributed = c->world > 1 || getenv("OPT_AMD_FORCE_COMM") != nullptr;   // the env switch lets a 1-rank test drive the comm callbacks
         return 1;
     }

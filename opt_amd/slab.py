@@ -1,9 +1,10 @@
 """Row-slab tiling of an image problem over the GPUs of one node (one rank per GPU).
 
 The reference is single-GPU; this is the MI355X-native extension the north star asks for:
-rank g owns rows [row0, row0+rows) of the image and passes libOpt.so arrays that hold its slab plus one ghost
-row above and below (OptAmd_PlanSetSlab, include/OptAmd.h).  Per PCG iteration the ranks exchange one image row
-per neighbour per unknown image and all-reduce two scalars; nothing else crosses GPUs.
+rank g owns rows [row0, row0+rows) of the image and passes libOpt.so arrays that hold its slab plus `ghost` ghost
+rows above and below (OptAmd_PlanSetSlab, include/OptAmd.h; 2 by default, which lets image_warping run its PCG iteration
+without the A*p vector in memory).  Per PCG iteration the ranks exchange `ghost` image rows per neighbour per vector and
+all-reduce four scalars; nothing else crosses GPUs.
 
 Host-side pieces (numpy only, unit-tested on CPU with gloo): SlabLayout, split_problem, merge_unknowns.
 Device-side drivers: SlabJob (RCCL, one process per GPU, used by bench.py) and run_threads (all ranks as
@@ -25,14 +26,14 @@ _comm = None
 class SlabLayout:
     """Even split of H rows over `world` ranks; earlier ranks take the remainder."""
 
-    def __init__(self, W, H, rank, world):
-        if world > H:
-            raise ValueError("more ranks than image rows")
-        self.W, self.H, self.rank, self.world = W, H, rank, world
+    def __init__(self, W, H, rank, world, ghost=2):
+        if world * ghost > H:
+            raise ValueError("more ranks than image rows allow (every slab must own at least `ghost` rows)")
+        self.W, self.H, self.rank, self.world, self.ghost = W, H, rank, world, ghost
         base, rem = divmod(H, world)
         self.rows = base + (1 if rank < rem else 0)
         self.row0 = rank * base + min(rank, rem)
-        self.local_H = self.rows + 2                      # + ghost row above and below
+        self.local_H = self.rows + 2 * ghost              # + ghost rows above and below
 
     @property
     def owned(self):
@@ -50,7 +51,7 @@ def _is_image(a, H, W):
 
 
 def split_problem(problem, layout):
-    """Local copy of a global (host) workloads.Problem for one rank: every image keeps rows row0-1 .. row0+rows
+    """Local copy of a global (host) workloads.Problem for one rank: every image keeps rows row0-ghost .. row0+rows+ghost-1
     (ghost rows outside the global image are zero-filled; for image_warping their Mask is set non-zero so they
     are also excluded by the energy itself).  Scalars are shared."""
     W, H = layout.W, layout.H
@@ -61,14 +62,15 @@ def split_problem(problem, layout):
             out.append(np.array(a, copy=True))
             continue
         loc = np.zeros((layout.local_H,) + a.shape[1:], dtype=a.dtype)
-        lo, hi = layout.row0 - 1, layout.row0 + layout.rows + 1
+        g = layout.ghost
+        lo, hi = layout.row0 - g, layout.row0 + layout.rows + g
         glo, ghi = max(lo, 0), min(hi, H)
         loc[glo - lo: glo - lo + (ghi - glo)] = a[glo:ghi]
         if problem.energy == "image_warping" and idx == 4:          # Mask
             if lo < 0:
-                loc[0] = 255
+                loc[:-lo] = 255
             if hi > H:
-                loc[-1] = 255
+                loc[layout.local_H - (hi - H):] = 255
         out.append(loc)
     return wl.Problem(problem.energy, (W, layout.local_H), out, problem.unknown_slots, problem.double, dict(problem.meta))
 
@@ -77,7 +79,7 @@ def merge_unknowns(problem, layouts, local_unknowns):
     """Write every rank's owned rows of the unknown images back into the global problem (in place)."""
     for lay, unk in zip(layouts, local_unknowns):
         for slot, arr in zip(problem.unknown_slots, unk):
-            problem.params[slot][lay.owned] = np.asarray(arr)[1:1 + lay.rows]
+            problem.params[slot][lay.owned] = np.asarray(arr)[lay.ghost:lay.ghost + lay.rows]
 
 
 def comm_lib():
@@ -111,10 +113,10 @@ class SlabJob:
     """One rank of a multi-process solve (bench.py --gpus N): torch.distributed is already initialised with the
     nccl (= RCCL) backend; the RCCL communicator used inside the solver is created here from a broadcast id."""
 
-    def __init__(self, energy, W, H, rank, world, kind="gaussNewtonGPU", double=False, problem=None):
+    def __init__(self, energy, W, H, rank, world, kind="gaussNewtonGPU", double=False, problem=None, ghost=2):
         import torch
         import torch.distributed as dist
-        self.layout = SlabLayout(W, H, rank, world)
+        self.layout = SlabLayout(W, H, rank, world, ghost)
         glob = problem if problem is not None else getattr(wl, energy)(W, H, double=double)
         self.local = split_problem(glob, self.layout)
         del glob
@@ -136,14 +138,14 @@ class SlabJob:
         comm_lib().OptComm_DestroyRccl(self._ctx)
 
 
-def run_threads(problem, world, kind="gaussNewtonGPU", solver_params=None, steps=None):
+def run_threads(problem, world, kind="gaussNewtonGPU", solver_params=None, steps=None, ghost=2):
     """Solve `problem` (host arrays, modified in place) with `world` slabs as threads of this process on the
     current GPU.  Returns the per-step cost list of rank 0.  Test harness for single-GPU boxes."""
     import torch
     L = comm_lib()
     W, H = problem.dims
     tw = L.OptComm_CreateThreadWorld(world)
-    layouts = [SlabLayout(W, H, r, world) for r in range(world)]
+    layouts = [SlabLayout(W, H, r, world, ghost) for r in range(world)]
     costs = [[] for _ in range(world)]
     results = [None] * world
     errors = []

@@ -14,7 +14,7 @@ from helpers import flat_unknowns
 
 def test_layout_partitions_rows():
     for H, world in [(4096, 8), (53, 3), (7, 7), (10, 4)]:
-        lays = [slab.SlabLayout(64, H, r, world) for r in range(world)]
+        lays = [slab.SlabLayout(64, H, r, world, ghost=1 if H < 2 * world else 2) for r in range(world)]
         assert lays[0].row0 == 0 and lays[-1].row0 + lays[-1].rows == H
         for a, b in zip(lays, lays[1:]):
             assert a.row0 + a.rows == b.row0
@@ -26,7 +26,7 @@ def test_layout_partitions_rows():
 def test_split_and_merge_roundtrip():
     P = wl.image_warping(20, 13, random_state=1, mask_fraction=0.1, perturb=0.2)
     world = 3
-    lays = [slab.SlabLayout(20, 13, r, world) for r in range(world)]
+    lays = [slab.SlabLayout(20, 13, r, world, ghost=1) for r in range(world)]
     locs = [slab.split_problem(P, l) for l in lays]
     for l, q in zip(lays, locs):
         assert q.dims == (20, l.rows + 2)
@@ -60,7 +60,7 @@ def _rank_main(rank, world, port, q):
     from oracle.binding import OracleSolver
     W, H = 18, 14
     P = wl.image_warping(W, H, double=True, random_state=2, mask_fraction=0.08, perturb=0.3)
-    lay = slab.SlabLayout(W, H, rank, world)
+    lay = slab.SlabLayout(W, H, rank, world, ghost=1)
     loc = slab.split_problem(P, lay)
     o = OracleSolver("image_warping", "gaussNewtonGPU", True, loc.dims)
     npx = W * lay.local_H
@@ -134,3 +134,30 @@ def test_two_rank_gloo_pcg_matches_single_process(oracle_lib):
     for rank, row0, rows, lo, la in parts:
         np.testing.assert_allclose(lo, dO[row0:row0 + rows], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(la, dA[row0:row0 + rows], rtol=1e-9, atol=1e-12)
+
+
+def test_split_with_two_ghost_rows():
+    """ghost=2 (the default: lets image_warping iterate without A*p in memory): two rows of the neighbours either side,
+    rows outside the global image zero-filled and masked out, merge takes the owned rows only."""
+    P = wl.image_warping(12, 11, random_state=4, mask_fraction=0.0)
+    lays = [slab.SlabLayout(12, 11, r, 3) for r in range(3)]
+    assert all(l.ghost == 2 and l.local_H == l.rows + 4 for l in lays)
+    locs = [slab.split_problem(P, l) for l in lays]
+    for l, q in zip(lays, locs):
+        np.testing.assert_array_equal(q.params[0][2:-2], P.params[0][l.owned])
+        if l.has_up():
+            np.testing.assert_array_equal(q.params[2][:2], P.params[2][l.row0 - 2:l.row0])
+        else:
+            assert (q.params[4][:2] != 0).all() and (q.params[0][:2] == 0).all()
+        if l.has_down():
+            np.testing.assert_array_equal(q.params[2][-2:], P.params[2][l.row0 + l.rows:l.row0 + l.rows + 2])
+        else:
+            assert (q.params[4][-2:] != 0).all()
+    Q = P.clone()
+    for s_ in Q.unknown_slots:
+        Q.params[s_][...] = -1
+    slab.merge_unknowns(Q, lays, [[q.params[s_] for s_ in P.unknown_slots] for q in locs])
+    for s_ in P.unknown_slots:
+        np.testing.assert_array_equal(Q.params[s_], P.params[s_])
+    with pytest.raises(ValueError):
+        slab.SlabLayout(8, 7, 0, 4)          # 4 slabs x 2 ghost rows need at least 8 image rows

@@ -21,14 +21,15 @@ def _single(P, kind, **kw):
     return costs, np.concatenate([o.reshape(-1) for o in out])
 
 
+@pytest.mark.parametrize("ghost", [1, 2])      # 1: PCG iteration with A*p in memory (iw_pcgIter); 2: without (iw_pcgIter2)
 @pytest.mark.parametrize("world", [2, 3, 4])
 @pytest.mark.parametrize("double", [False, True])
-def test_gn_slabs_match_single(world, double):
+def test_gn_slabs_match_single(world, double, ghost):
     P = wl.image_warping(70, 53, double=double, random_state=3, mask_fraction=0.06, perturb=0.3)
     kw = dict(nIterations=3, lIterations=14)
     c1, x1 = _single(P.clone(), "gaussNewtonGPU", **kw)
     Q = P.clone()
-    cN = slab.run_threads(Q, world, "gaussNewtonGPU", kw)
+    cN = slab.run_threads(Q, world, "gaussNewtonGPU", kw, ghost=ghost)
     tol = 1e-11 if double else 2e-5
     np.testing.assert_allclose(cN, c1, rtol=tol)
     assert rel_err(flat_unknowns(Q), x1) < tol
@@ -68,7 +69,8 @@ def _rccl_world1(q):
     job.solver.init(job.params); costs = [job.solver.cost()]
     while job.solver.step(job.params):
         costs.append(job.solver.cost())
-    x = torch.cat([job.params[0][1:-1].reshape(-1), job.params[1][1:-1].reshape(-1)]).cpu().numpy()
+    g = job.layout.ghost
+    x = torch.cat([job.params[0][g:-g].reshape(-1), job.params[1][g:-g].reshape(-1)]).cpu().numpy()
     job.close()
     dist.destroy_process_group()
     q.put((costs, x))
@@ -90,3 +92,16 @@ def test_rccl_comm_single_rank():
     c1, x1 = _single(P, "gaussNewtonGPU", nIterations=2, lIterations=10)
     np.testing.assert_allclose(costs, c1, rtol=2e-5)
     assert rel_err(x, x1) < 2e-5
+
+
+def test_gn_slabs_lattice_and_general_ur_shape():
+    """Ap-free iteration on slabs for both preconditioner sources: unit-lattice UrShape (M from the flag byte) and a
+    jittered UrShape (compact M exchanged once), odd row counts so the slabs differ in height."""
+    for jitter in (0.0, 0.2):
+        P = wl.image_warping(66, 47, random_state=11, mask_fraction=0.05, perturb=0.3, jitter_urshape=jitter)
+        kw = dict(nIterations=2, lIterations=25)
+        c1, x1 = _single(P.clone(), "gaussNewtonGPU", **kw)
+        Q = P.clone()
+        cN = slab.run_threads(Q, 3, "gaussNewtonGPU", kw)
+        np.testing.assert_allclose(cN, c1, rtol=5e-5)
+        assert rel_err(flat_unknowns(Q), x1) < 5e-5
