@@ -56,7 +56,7 @@ def main(src, out):
     # traffic of the dominant kernel for bench.py's roofline.traffic (bench_kernel = the name bench.py times it under)
     for r in rows:
         n = r["Name"]
-        bench_kernel = "PCGIteration" if "iw_pcgIter" in n else "PCGStep3+PCGStep1" if ("iw_applyJTJ" in n and ", true>(" in n) else None
+        bench_kernel = "PCGIteration" if "iw_pcgIter2" in n else "PCGStep3+PCGStep1" if ("iw_applyJTJ" in n and ", true>(" in n) else None
         if bench_kernel:
             f = fetch.get(n, (0, 0.0))[1]; w = write.get(n, (0, 0.0))[1]
             json.dump({"kernel": short(n), "bench_kernel": bench_kernel, "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024, "fetch_size_kib": f, "write_size_kib": w,
