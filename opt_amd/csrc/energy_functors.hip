@@ -1,0 +1,187 @@
+// The stencil energies served by the functor engine (stencil_engine.h): optical_flow, intrinsic_image_decomposition,
+// volumetric_mesh_deformation -- SURVEY.md 8(f) rank 3.  Each functor restates the residuals of its reference .t once,
+// against a scalar type S that the engine instantiates as T or as a dual number.
+#include "stencil_engine.h"
+
+namespace optamd {
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------
+// examples/optical_flow/optical_flow.t:1-19.  X float2 flow; e_fit = w_fit (I(0,0) - I_hat(i + u, j + v)) with I_hat a
+// SampledImage (bilinear, o.t:578-589) whose partials are the sampled derivative images (o.t:2486-2501);
+// e_reg = w_reg (X(0,0) - X(n)) for the 4-neighbourhood, Select(InBounds(n), ., 0).  UsePreconditioner(false).
+template <class T>
+struct OpticalFlowE {
+    static constexpr int NDIM = 2, NIMG = 1, K = 2, R = 9, NOFF = 5;
+    static constexpr __host__ __device__ int off(int i, int a) { return a == 0 ? (i == 1 ? 1 : i == 2 ? -1 : 0) : a == 1 ? (i == 3 ? 1 : i == 4 ? -1 : 0) : 0; }
+    static constexpr __host__ __device__ int imgOf(int) { return 0; }
+    static constexpr __host__ __device__ int chOf(int k) { return k; }
+    static constexpr __host__ __device__ int channels(int) { return 2; }
+    static constexpr __host__ __device__ bool depends(int ri, int oi) { return oi == 0 || (ri >= 1 && (ri - 1) / 2 + 1 == oi); }
+    static int unknownParam(int) { return 2; }
+    int W, H, D;
+    const T* X[NIMG];
+    const T *I, *Ihat, *Idx, *Idy;
+    T w_fit, w_reg;
+    void bindParams(void** p) {
+        w_fit = (T) * (const float*)p[0]; w_reg = (T) * (const float*)p[1];
+        X[0] = (const T*)p[2]; I = (const T*)p[3]; Ihat = (const T*)p[4]; Idx = (const T*)p[5]; Idy = (const T*)p[6];
+    }
+    __device__ bool excluded(int, int, int) const { return false; }
+    __device__ T get(const T* im, int x, int y) const { return (x >= 0 && x < W && y >= 0 && y < H) ? im[(long)y * W + x] : T(0); }   // Image:get (o.t:570-576)
+    __device__ T sample(const T* im, T x, T y) const {                                                                            // Image:sample (o.t:582-589)
+        const int x0 = (int)floor(x), x1 = (int)ceil(x), y0 = (int)floor(y), y1 = (int)ceil(y);
+        const T xn = x - T(x0), yn = y - T(y0);
+        const T u = (T(1) - xn) * get(im, x0, y0) + xn * get(im, x1, y0);
+        const T b = (T(1) - xn) * get(im, x0, y1) + xn * get(im, x1, y1);
+        return (T(1) - yn) * u + yn * b;
+    }
+    template <class S, class C>
+    __device__ __forceinline__ void residuals(const C& Xc, int x, int y, int, S* r) const {
+        const S u = Xc(0), v = Xc(1);
+        const T px = T(x) + valueOf(u), py = T(y) + valueOf(v);
+        const S ih = chain2(sample(Ihat, px, py), sample(Idx, px, py), sample(Idy, px, py), u, v);
+        r[0] = w_fit * (I[(long)y * W + x] - ih);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int dx = off(n + 1, 0), dy = off(n + 1, 1);
+            const bool inb = Xc.in(dx, dy, 0);
+            const S ex = w_reg * (u - Xc(0, dx, dy)), ey = w_reg * (v - Xc(1, dx, dy));
+            r[1 + 2 * n] = inb ? ex : S(T(0)); r[2 + 2 * n] = inb ? ey : S(T(0));
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// examples/intrinsic_image_decomposition/intrinsic_image_decomposition.t:1-31.  Unknowns r (float3, log-albedo) and s (float,
+// log-shading).  Albedo smoothness is an L_p norm through lib.t:106-114: sqrt((|r_c - r_n| + 1e-7)^(p-2)) is a ComputedArray --
+// a constant of the linearisation, re-evaluated from the current r after every update (inline here: r is fixed between
+// updates) -- times (r_c - r_n); shading smoothness is plain; fit r + s - i.  No UsePreconditioner call -> false; no Exclude.
+template <class T>
+struct IntrinsicE {
+    static constexpr int NDIM = 2, NIMG = 2, K = 4, R = 19, NOFF = 5;
+    static constexpr __host__ __device__ int off(int i, int a) { return a == 0 ? (i == 1 ? 1 : i == 2 ? -1 : 0) : a == 1 ? (i == 3 ? 1 : i == 4 ? -1 : 0) : 0; }
+    static constexpr __host__ __device__ int imgOf(int k) { return k < 3 ? 0 : 1; }
+    static constexpr __host__ __device__ int chOf(int k) { return k < 3 ? k : 0; }
+    static constexpr __host__ __device__ int channels(int img) { return img == 0 ? 3 : 1; }
+    // rows 0..11: albedo (direction n = ri / 3), 12..15: shading (direction ri - 12), 16..18: fit (centre only)
+    static constexpr __host__ __device__ bool depends(int ri, int oi) { return oi == 0 || (ri < 12 && ri / 3 + 1 == oi) || (ri >= 12 && ri < 16 && ri - 12 + 1 == oi); }
+    static int unknownParam(int img) { return img == 0 ? 4 : 6; }
+    int W, H, D;
+    const T* X[NIMG];
+    const T* target;
+    T w_fit, w_regA, w_regS, pNorm;
+    void bindParams(void** p) {
+        w_fit = (T) * (const float*)p[0]; w_regA = (T) * (const float*)p[1]; w_regS = (T) * (const float*)p[2];
+        pNorm = *(const T*)p[3];                      // Param("pNorm", opt_float, 3)
+        X[0] = (const T*)p[4]; target = (const T*)p[5]; X[1] = (const T*)p[6];
+    }
+    __device__ bool excluded(int, int, int) const { return false; }
+    template <class S, class C>
+    __device__ __forceinline__ void residuals(const C& Xc, int x, int y, int, S* r) const {
+        const ValueCtx<T, IntrinsicE> V(*this, x, y, 0);           // the constant view r_const (same binding as r)
+        const S rc[3] = {Xc(0), Xc(1), Xc(2)};
+        const S sc = Xc(3);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int dx = off(n + 1, 0), dy = off(n + 1, 1);
+            const bool inb = Xc.in(dx, dy, 0);
+            const T c0 = V(0) - V(0, dx, dy), c1 = V(1) - V(1, dx, dy), c2 = V(2) - V(2, dx, dy);
+            const T dist = sqrt(c0 * c0 + c1 * c1 + c2 * c2);                                   // L_2_norm(val_const)
+            const T sqrtC = sqrt(pow(dist + T(0.0000001), pNorm - T(2)));                      // lib.t:108-110
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const S e = w_regA * (sqrtC * (rc[c] - Xc(c, dx, dy))); r[3 * n + c] = inb ? e : S(T(0)); }
+            const S es = w_regS * (sc - Xc(3, dx, dy));
+            r[12 + n] = inb ? es : S(T(0));
+        }
+        const long i = (long)y * W + x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r[16 + c] = w_fit * (rc[c] + sc - target[3 * i + c]);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// examples/volumetric_mesh_deformation/volumetric_mesh_deformation.t:1-20.  3-D lattice, unknowns Offset and Angle (float3 each);
+// fit (Offset - Constraints) where Constraints.x >= -999999.9; ARAP regulariser over the 6-neighbourhood with Rotate3D
+// (lib.t:77-91), Select(InBounds(0,0,0), Select(InBounds(n), ., 0), 0).  UsePreconditioner(true).
+template <class T>
+struct VolumetricE {
+    static constexpr int NDIM = 3, NIMG = 2, K = 6, R = 21, NOFF = 7;
+    static constexpr __host__ __device__ int off(int i, int a) {
+        return a == 0 ? (i == 1 ? 1 : i == 2 ? -1 : 0) : a == 1 ? (i == 3 ? 1 : i == 4 ? -1 : 0) : (i == 5 ? 1 : i == 6 ? -1 : 0);
+    }
+    static constexpr __host__ __device__ int imgOf(int k) { return k < 3 ? 0 : 1; }
+    static constexpr __host__ __device__ int chOf(int k) { return k % 3; }
+    static constexpr __host__ __device__ int channels(int) { return 3; }
+    static constexpr __host__ __device__ bool depends(int ri, int oi) { return oi == 0 || (ri >= 3 && (ri - 3) / 3 + 1 == oi); }
+    static int unknownParam(int img) { return img; }
+    int W, H, D;
+    const T* X[NIMG];
+    const T *Ur, *Cons;
+    T w_fit, w_reg;
+    void bindParams(void** p) {
+        X[0] = (const T*)p[0]; X[1] = (const T*)p[1]; Ur = (const T*)p[2]; Cons = (const T*)p[3];
+        w_fit = (T) * (const float*)p[4]; w_reg = (T) * (const float*)p[5];
+    }
+    __device__ bool excluded(int, int, int) const { return false; }
+    template <class S, class C>
+    __device__ __forceinline__ void residuals(const C& Xc, int x, int y, int z, S* r) const {
+        const long i = ((long)z * H + y) * W + x;
+        const S o[3] = {Xc(0), Xc(1), Xc(2)};
+        const bool valid = Cons[3 * i] >= T(-999999.9);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const S e = w_fit * (o[c] - Cons[3 * i + c]); r[c] = valid ? e : S(T(0)); }
+        // Rotate3D(Angle, v): lib.t:77-91
+        const S al = Xc(3), be = Xc(4), ga = Xc(5);
+        const S ca = cos(al), cb = cos(be), cg = cos(ga), sa = sin(al), sb = sin(be), sg = sin(ga);
+        const S m0 = cg * cb, m1 = -sg * ca + cg * sb * sa, m2 = sg * sa + cg * sb * ca;
+        const S m3 = sg * cb, m4 = cg * ca + sg * sb * sa, m5 = -cg * sa + sg * sb * ca;
+        const S m6 = -sb, m7 = cb * sa, m8 = cb * ca;
+#pragma unroll
+        for (int n = 0; n < 6; ++n) {
+            const int dx = off(n + 1, 0), dy = off(n + 1, 1), dz = off(n + 1, 2);
+            const bool inb = Xc.in(dx, dy, dz);
+            const long j = inb ? Xc.at(dx, dy, dz) : i;
+            const T u0 = Ur[3 * i] - (inb ? Ur[3 * j] : T(0)), u1 = Ur[3 * i + 1] - (inb ? Ur[3 * j + 1] : T(0)), u2 = Ur[3 * i + 2] - (inb ? Ur[3 * j + 2] : T(0));
+            const S e0 = w_reg * ((o[0] - Xc(0, dx, dy, dz)) - (m0 * u0 + m1 * u1 + m2 * u2));
+            const S e1 = w_reg * ((o[1] - Xc(1, dx, dy, dz)) - (m3 * u0 + m4 * u1 + m5 * u2));
+            const S e2 = w_reg * ((o[2] - Xc(2, dx, dy, dz)) - (m6 * u0 + m7 * u1 + m8 * u2));
+            r[3 + 3 * n] = inb ? e0 : S(T(0)); r[4 + 3 * n] = inb ? e1 : S(T(0)); r[5 + 3 * n] = inb ? e2 : S(T(0));
+        }
+    }
+};
+
+template <class T> EnergyOps<T>* makeFlow(const unsigned* dims) { return new StencilOps<T, OpticalFlowE<T>>(dims, false); }
+template <class T> EnergyOps<T>* makeIntrinsic(const unsigned* dims) { return new StencilOps<T, IntrinsicE<T>>(dims, false); }
+template <class T> EnergyOps<T>* makeVolumetric(const unsigned* dims) { return new StencilOps<T, VolumetricE<T>>(dims, true); }
+
+}  // namespace
+
+EnergyInfo opticalFlowInfo() {
+    EnergyInfo e;
+    e.name = "optical_flow"; e.nDims = 2; e.usePreconditioner = false; e.floatOnly = false;
+    e.params = {{ParamDecl::kScalar, "w_fit", "float", 0}, {ParamDecl::kScalar, "w_reg", "float", 1}, {ParamDecl::kUnknown, "X", "opt_float2", 2},
+                {ParamDecl::kArray, "I", "opt_float", 3}, {ParamDecl::kArray, "I_hat", "opt_float", 4}, {ParamDecl::kArray, "I_hat_dx", "opt_float", 5},
+                {ParamDecl::kArray, "I_hat_dy", "opt_float", 6}};
+    e.makeFloat = makeFlow<float>; e.makeDouble = makeFlow<double>;
+    return e;
+}
+EnergyInfo intrinsicInfo() {
+    EnergyInfo e;
+    e.name = "intrinsic_image_decomposition"; e.nDims = 2; e.usePreconditioner = false; e.floatOnly = false;
+    e.params = {{ParamDecl::kScalar, "w_fitSqrt", "float", 0}, {ParamDecl::kScalar, "w_regSqrtAlbedo", "float", 1}, {ParamDecl::kScalar, "w_regSqrtShading", "float", 2},
+                {ParamDecl::kScalar, "pNorm", "opt_float", 3}, {ParamDecl::kUnknown, "r", "opt_float3", 4}, {ParamDecl::kArray, "r_const", "opt_float3", 4},
+                {ParamDecl::kArray, "i", "opt_float3", 5}, {ParamDecl::kUnknown, "s", "opt_float", 6}};
+    e.makeFloat = makeIntrinsic<float>; e.makeDouble = makeIntrinsic<double>;
+    return e;
+}
+EnergyInfo volumetricInfo() {
+    EnergyInfo e;
+    e.name = "volumetric_mesh_deformation"; e.nDims = 3; e.usePreconditioner = true; e.floatOnly = false;
+    e.params = {{ParamDecl::kUnknown, "Offset", "opt_float3", 0}, {ParamDecl::kUnknown, "Angle", "opt_float3", 1}, {ParamDecl::kArray, "UrShape", "opt_float3", 2},
+                {ParamDecl::kArray, "Constraints", "opt_float3", 3}, {ParamDecl::kScalar, "w_fitSqrt", "float", 4}, {ParamDecl::kScalar, "w_regSqrt", "float", 5}};
+    e.makeFloat = makeVolumetric<float>; e.makeDouble = makeVolumetric<double>;
+    return e;
+}
+
+}  // namespace optamd

@@ -31,8 +31,12 @@ EnergyInfo laplacianInfo();
 EnergyInfo curveFittingInfo();
 EnergyInfo arapInfo();
 EnergyInfo sfsInfo();
+EnergyInfo opticalFlowInfo();
+EnergyInfo intrinsicInfo();
+EnergyInfo volumetricInfo();
 const std::vector<EnergyInfo>& energyRegistry() {
-    static std::vector<EnergyInfo> reg = {imageWarpingInfo(), poissonInfo(), laplacianInfo(), curveFittingInfo(), arapInfo(), sfsInfo()};
+    static std::vector<EnergyInfo> reg = {imageWarpingInfo(), poissonInfo(), laplacianInfo(), curveFittingInfo(), arapInfo(), sfsInfo(),
+                                           opticalFlowInfo(), intrinsicInfo(), volumetricInfo()};
     return reg;
 }
 }  // namespace optamd

@@ -215,3 +215,70 @@ def shape_from_shading(W, H=None, double=True, seed=0, holes=False, noise=1e-3):
     params += [f32(v) for v in L]
     params += [X.astype(ft), D_i.astype(ft), Im.astype(ft), edgeR, edgeC]
     return Problem("shape_from_shading", (W, H), params, (16,), double)
+
+
+def _smooth_image(W, H, rng, octaves=4):
+    """A band-limited random image in [0, 1] (sum of a few random sinusoids): stands in for a blurred photograph."""
+    xs, ys = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    im = np.zeros((H, W))
+    for o in range(octaves):
+        fx, fy = rng.uniform(0.02, 0.12, 2) * (1.6 ** o)
+        im += rng.uniform(0.3, 1.0) / (1.5 ** o) * np.sin(fx * xs + rng.uniform(0, 6.3)) * np.cos(fy * ys + rng.uniform(0, 6.3))
+    im -= im.min()
+    return im / max(im.max(), 1e-12)
+
+
+def optical_flow(W, H=None, double=False, seed=0, init_flow=0.0):
+    """examples/optical_flow/src/CombinedSolver.h:72-83, 107-171: source / target frames, the target's derivative images
+    (3x3 Prewitt / 8, zero border), flow initialised to 0 (init_flow > 0: seeded random flow, so tests sample off-lattice);
+    w_fit = sqrt(10), w_reg = sqrt(0.1)."""
+    H = H or W
+    ft = np.float64 if double else np.float32
+    rng = np.random.default_rng(seed)
+    target = _smooth_image(W + 8, H + 8, rng)
+    source = target[3:3 + H, 5:5 + W].copy()                 # the source frame is the target moved by (+1, -1) px
+    target = target[4:4 + H, 4:4 + W].copy()
+    du = np.zeros((H, W)); dv = np.zeros((H, W))
+    du[1:-1, 1:-1] = (-target[:-2, :-2] - target[1:-1, :-2] - target[2:, :-2] + target[:-2, 2:] + target[1:-1, 2:] + target[2:, 2:]) / 8.0
+    dv[1:-1, 1:-1] = (-target[:-2, :-2] - target[:-2, 1:-1] - target[:-2, 2:] + target[2:, :-2] + target[2:, 1:-1] + target[2:, 2:]) / 8.0
+    X = rng.uniform(-init_flow, init_flow, size=(H, W, 2)) if init_flow > 0 else np.zeros((H, W, 2))
+    return Problem("optical_flow", (W, H), [np.float32(np.sqrt(10.0)), np.float32(np.sqrt(0.1)), X.astype(ft), source.astype(ft), target.astype(ft),
+                                            du.astype(ft), dv.astype(ft)], (2,), double)
+
+
+def intrinsic_image_decomposition(W, H=None, double=False, seed=0):
+    """examples/intrinsic_image_decomposition/src/CombinedSolver.h:28-45, 60-90: log input image i (float3), unknown log-albedo r
+    initialised to the input, unknown log-shading s initialised to 0 (here + small seeded noise so gradients are generic);
+    weights 500 / 1000 / 10000 (sqrt taken by the caller), p = 0.8."""
+    H = H or W
+    ft = np.float64 if double else np.float32
+    rng = np.random.default_rng(seed)
+    albedo = np.stack([np.round(3 * _smooth_image(W, H, rng)) / 3 for _ in range(3)], -1) * 0.8 + 0.1      # piecewise constant
+    shading = 0.4 + 0.6 * _smooth_image(W, H, rng, octaves=2)
+    i = np.log(albedo * shading[..., None] + 1e-3)
+    r = i + rng.normal(0, 0.02, size=i.shape)
+    s = rng.normal(0, 0.02, size=(H, W))
+    return Problem("intrinsic_image_decomposition", (W, H),
+                   [np.float32(np.sqrt(500.0)), np.float32(np.sqrt(1000.0)), np.float32(np.sqrt(10000.0)), ft(0.8), r.astype(ft), i.astype(ft), s.astype(ft)],
+                   (4, 6), double)
+
+
+def volumetric_mesh_deformation(W, H=None, D=None, double=False, seed=0, perturb=0.0):
+    """examples/volumetric_mesh_deformation/src/CombinedSolver.h:40-60, 95-160: regular lattice, Offset = UrShape = lattice positions,
+    Angle = 0, constraints = -inf except the bottom layer (pinned) and the top layer (moved and twisted); w_fit = 1, w_reg = 0.05."""
+    H = H or W; D = D or W
+    ft = np.float64 if double else np.float32
+    rng = np.random.default_rng(seed)
+    zs, ys, xs = np.meshgrid(np.arange(D, dtype=np.float64), np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    ur = np.stack([xs, ys, zs], -1) * 0.1
+    cons = np.full(ur.shape, -np.inf)
+    cons[0] = ur[0]
+    th = 0.4
+    top = ur[-1].copy()
+    cx, cy = top[..., 0].mean(), top[..., 1].mean()
+    tx, ty = top[..., 0] - cx, top[..., 1] - cy
+    cons[-1] = np.stack([cx + np.cos(th) * tx - np.sin(th) * ty + 0.05, cy + np.sin(th) * tx + np.cos(th) * ty, top[..., 2] + 0.1], -1)
+    off = ur + (rng.normal(0, perturb, size=ur.shape) if perturb > 0 else 0)
+    ang = rng.normal(0, perturb, size=ur.shape) if perturb > 0 else np.zeros(ur.shape)
+    return Problem("volumetric_mesh_deformation", (W, H, D), [off.astype(ft), ang.astype(ft), ur.astype(ft), cons.astype(ft), np.float32(1.0), np.float32(np.sqrt(0.05))],
+                   (0, 1), double)

@@ -7,6 +7,7 @@
 // the intermediate vectors so tests can compare them with the HIP solver's.
 #include "energies.hpp"
 #include "sfs.hpp"
+#include "energies_grid.hpp"
 #include <memory>
 
 using namespace oracle;
@@ -24,6 +25,9 @@ template <class T> Energy<T>* makeEnergy(const std::string& n, const unsigned* d
     if (n == "curveFitting") return new CurveFitting<T>(dims);
     if (n == "arap_mesh_deformation") return new Arap<T>(dims);
     if (n == "shape_from_shading") return new ShapeFromShading<T>(dims);
+    if (n == "optical_flow") return new OpticalFlow<T>(dims);
+    if (n == "intrinsic_image_decomposition") return new IntrinsicImage<T>(dims);
+    if (n == "volumetric_mesh_deformation") return new VolumetricMesh<T>(dims);
     return nullptr;
 }
 template <class T> std::vector<T>* vecByName(Solver<T>* s, const std::string& n) {

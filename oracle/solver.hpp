@@ -40,7 +40,7 @@
 namespace oracle {
 
 constexpr int MAXS = 9;    // largest residual support (ARAP edge: O(v0)3 + O(v1)3 + a(v0)3)
-constexpr int MAXR = 16;   // most scalar residuals per element (poisson: 4 dirs x 4 channels)
+constexpr int MAXR = 24;   // most scalar residuals per element (volumetric_mesh_deformation: 3 fit + 6 dirs x 3)
 
 // One scalar residual instance: value, and partials w.r.t. the unknown scalars of its support.
 // idx[k] = flat index into the unknown vector, or -1 if that access is outside the image

@@ -87,3 +87,21 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not bad.search(text), os.path.join(dirpath, f)
+
+
+def test_reference_energy_files_are_accepted(opt_lib):
+    """Drop-in check, only where the reference checkout is mounted (this container; never on the GPU box): the .t files the
+    reference's own examples pass to Opt_ProblemDefine must validate against the registered binding layouts unchanged."""
+    import glob
+    import os
+    root = "/root/reference"
+    if not os.path.isdir(root):
+        pytest.skip("reference checkout not present")
+    seen = 0
+    for n in opt_lib.registered_energies():
+        hits = glob.glob(os.path.join(root, "examples", "*", n + ".t")) + glob.glob(os.path.join(root, "tests", "*", n + ".t"))
+        for h in hits:
+            ok, msg = opt_lib.check_problem_file(h)
+            assert ok, f"{h}: {msg}"
+            seen += 1
+    assert seen >= 8

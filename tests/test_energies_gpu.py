@@ -18,6 +18,12 @@ CASES = {
     "arap_rest": lambda double: wl.arap_mesh_deformation(12, 9, double=double),
     "sfs": lambda double: wl.shape_from_shading(40, 32, double=double, seed=6, holes=True, noise=2e-3),
     "sfs_clean": lambda double: wl.shape_from_shading(33, 21, double=double, seed=7),
+    # the functor engine (stencil_engine.h)
+    "flow": lambda double: wl.optical_flow(37, 26, double=double, seed=2, init_flow=1.2),
+    "flow_zero_init": lambda double: wl.optical_flow(24, 31, double=double, seed=3),          # integer sample positions: floor == ceil
+    "intrinsic": lambda double: wl.intrinsic_image_decomposition(29, 23, double=double, seed=4),
+    "volumetric": lambda double: wl.volumetric_mesh_deformation(9, 7, 5, double=double, seed=5, perturb=0.05),
+    "volumetric_rest": lambda double: wl.volumetric_mesh_deformation(6, 6, 6, double=double),
 }
 
 
@@ -71,6 +77,12 @@ def test_trajectory(oracle_lib, name, double, kind):
         # cos(b x) with b x ~ 600 rad loses ~4 digits in float, so libm and the device sincosf legitimately differ;
         # the reference runs this energy in double (tests/minimal_graph_only/main.cpp:11).  Float is a smoke check.
         ctol, xtol = 5e-3, 1e-3
+    if name == "intrinsic":
+        # weights of 500 / 1000 / 10000 on differences of ~0.02 plus the (|dr| + 1e-7)^(-0.6) re-weighting make the system
+        # ill-conditioned (unpreconditioned, 12 PCG iterations, far from converged): a 1-ulp difference between libm pow and the
+        # device pow is amplified ~1e7-fold in the Gauss-Newton step -- 1.3e-9 in double, 1e-3 in float; the LM runs (damped)
+        # and the per-stage checks of cost / J^T F / J^T J p above hold the usual bars on the same inputs.
+        ctol, xtol = (1e-8, 1e-7) if P.double else (3e-2, 1e-1)     # float: smoke level, like curveFitting
     scale = max(abs(o.cost()), 1e-300)
     assert abs(g.cost() - o.cost()) <= ctol * scale
     while True:
