@@ -26,6 +26,9 @@ CASES = {
     "arap_7x6": (lambda: wl.arap_mesh_deformation(7, 6, double=True, seed=8, perturb=0.01), "gaussNewtonGPU"),
     "sfs_20x16_lm": (lambda: wl.shape_from_shading(20, 16, double=True, seed=9, holes=True, noise=2e-3), "LMGPU"),
     "curve_fitting_64": (lambda: wl.curve_fitting(64, double=True), "gaussNewtonGPU"),
+    "optical_flow_18x14": (lambda: wl.optical_flow(18, 14, double=True, seed=12, init_flow=0.9), "gaussNewtonGPU"),
+    "intrinsic_14x12_lm": (lambda: wl.intrinsic_image_decomposition(14, 12, double=True, seed=13), "LMGPU"),
+    "volumetric_5x4x4": (lambda: wl.volumetric_mesh_deformation(5, 4, 4, double=True, seed=14, perturb=0.04), "gaussNewtonGPU"),
 }
 
 
@@ -53,6 +56,6 @@ def build(name):
 
 
 if __name__ == "__main__":
-    for name in CASES:
+    for name in (sys.argv[1:] or CASES):          # optional: only the named cases
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **build(name))
         print("wrote", name)
