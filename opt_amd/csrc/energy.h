@@ -87,6 +87,9 @@ struct EnergyOps {
                                const Reduction& /*bNum*/, const double* /*aNumOld*/, double* /*aNumNext*/, LaunchCtx&) { return false; }
     // Optional: one WHOLE Gauss-Newton PCG iteration as a single kernel (see PcgIterArgs and solver.hip).
     virtual bool pcgIteration(const PcgIterArgs<T>& /*args*/, LaunchCtx&) { return false; }
+    // Called once after the last pcgIteration of a linear solve, before the solver adds the last term alpha p to delta:
+    // lets a kernel set that defers part of its delta update apply what is left.  pPrev = the p buffer the last launch read.
+    virtual void pcgFinish(const T* /*pPrev*/, T* /*delta*/, LaunchCtx&) {}
     // partial sums of 1/2 sum (F + J delta)^2 (o.t:2174-2225); LM only
     virtual void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) = 0;
     // slab tiling (image energies): number of scalars in one image row of unknown image `img`

@@ -408,6 +408,10 @@ struct IterK {             // kernel argument block
     const T *rOld, *ApOld, *pOld; T *rNew, *ApNew, *pNew; T* delta; const T* pre; int first;
     const T* mc;           // compact preconditioner {M_O, M_a} per pixel (M_O.x == M_O.y for this energy), or nullptr
     int flip;              // 1: sweep bottom-up (the kernel works in mirrored row coordinates, see iw_pcgIter)
+    // iw_pcgIter2 only.  deltaMode 0: delta += alpha_{k-1} p_{k-1} in every launch.  Paired: 2 = this launch leaves delta alone,
+    // 1 = this launch applies the two pending terms alpha_{k-2} p_{k-2} + alpha_{k-1} p_{k-1}, reading p_{k-2} from the pNew buffer
+    // just before overwriting it (same thread, same address) -- 12 B/px extra every second launch instead of 24 B/px every launch.
+    int deltaMode; const T* alphaIn; T* alphaOut;   // alpha_{k-2} (written by the previous launch) / where this launch leaves alpha_{k-1}
     const double *aNumPrev, *aDenPrev, *s2Prev, *s3Prev; int nNum, nDen, n2, n3;
     double *aNum, *aDen, *s2, *s3;
 };
@@ -643,6 +647,8 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
         const double bNumD = aNumD - 2.0 * (double)alpha * s2 + (double)alpha * (double)alpha * s3;
         beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
     }
+    if (K.alphaOut && blockIdx.x == 0 && threadIdx.x == 0) *K.alphaOut = alpha;
+    const T alpha2 = (K.deltaMode == 1) ? *K.alphaIn : T(0);
     const int bx = blockIdx.x % gx, by = blockIdx.x / gx;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int x = bx * kIterStrip2 + wave * kSpan2 + lane - 2;
@@ -710,11 +716,12 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
         nC.q.ox = nC.zx + beta * oB.q.ox; nC.q.oy = nC.zy + beta * oB.q.oy; nC.q.a = nC.za + beta * oB.q.a;                               // Step3
         if (live && writer && y + 1 >= yb && y + 1 < ye) {
             const long i = (long)phys(y + 1) * A.W + x;
-            st2<kNTS>(rO, i, rx, ry); st1<kNTS>(rA, i, ra); st2<kNTS>(pO, i, nC.q.ox, nC.q.oy); st1<kNTS>(pA, i, nC.q.a);
-            if (!first) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462)
-                const V2<T> d = dO[i]; const T da = dA[i];
+            if (!first && K.deltaMode != 2) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462), preceded by the deferred term of launch k-1
+                V2<T> d = dO[i]; T da = dA[i];
+                if (K.deltaMode == 1) { const V2<T> q = pO[i]; const T qa = pA[i]; d.x += alpha2 * q.x; d.y += alpha2 * q.y; da += alpha2 * qa; }   // p_{k-2}, about to be overwritten
                 st2<kNTS>(dO, i, d.x + alpha * oB.q.ox, d.y + alpha * oB.q.oy); st1<kNTS>(dA, i, da + alpha * oB.q.a);
             }
+            st2<kNTS>(rO, i, rx, ry); st1<kNTS>(rA, i, ra); st2<kNTS>(pO, i, nC.q.ox, nC.q.oy); st1<kNTS>(pA, i, nC.q.a);
             accNum += (double)(nC.zx * rx + nC.zy * ry + nC.za * ra);
         }
         Q<T> l2 = nB.lf, r2 = nB.rt;
@@ -745,6 +752,13 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
     t = blockReduceSum(accNum, scratch); if (threadIdx.x == 0) K.aNum[blockIdx.x] = t;
     t = blockReduceSum(acc2, scratch); if (threadIdx.x == 0) K.s2[blockIdx.x] = t;
     t = blockReduceSum(acc3, scratch); if (threadIdx.x == 0) K.s3[blockIdx.x] = t;
+}
+
+// delta += alpha[0] * p over n scalars (the deferred term left over when the PCG loop ends on an odd launch)
+template <class T>
+__global__ __launch_bounds__(kBlock) void iw_axpyDeferred(T* __restrict__ delta, const T* __restrict__ p, const T* __restrict__ alpha, long n) {
+    const T a = alpha[0];
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) delta[i] = delta[i] + a * p[i];
 }
 
 // {M_O, M_a} per pixel from the solver's 3-channel preconditioner (its two Offset channels are equal for this energy)
@@ -845,9 +859,10 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_SWEEP")) alternateSweep = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_RECOMPUTE_AP")) recomputeAp = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_FLAG_M")) flagPreconditioner = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_PAIR_DELTA")) pairDelta = atoi(e) != 0;
         HIP_CHECK(hipMalloc((void**)&dNotLattice, sizeof(int)));
     }
-    ~ImageWarpingOps() override { (void)hipFree(A.flags); (void)hipFree(A.cs); if (mc) (void)hipFree(mc); (void)hipFree(dNotLattice); }
+    ~ImageWarpingOps() override { (void)hipFree(A.flags); (void)hipFree(A.cs); if (mc) (void)hipFree(mc); if (alphaSlots) (void)hipFree(alphaSlots); (void)hipFree(dNotLattice); }
     int flatGrid(long n) const { return (int)std::max<long>(1, std::min<long>((n + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
     void bind(void** p, LaunchCtx& ctx) override {
         A.Offset = (const T*)p[0]; A.Angle = (const T*)p[1]; A.UrShape = (const T*)p[2]; A.Constraints = (const T*)p[3]; A.Mask = (const T*)p[4];
@@ -935,7 +950,8 @@ struct ImageWarpingOps : EnergyOps<T> {
         return lat ? (pre == 2 ? iterFn<true, 2>(noAp, flip) : pre == 1 ? iterFn<true, 1>(noAp, flip) : iterFn<true, 0>(noAp, flip))
                    : (pre == 2 ? iterFn<false, 2>(noAp, flip) : pre == 1 ? iterFn<false, 1>(noAp, flip) : iterFn<false, 0>(noAp, flip));
     }
-    bool flagPreconditioner = true;
+    bool flagPreconditioner = true, pairDelta = true;
+    int iterIndex = 0; bool deferredTerm = false; T* alphaSlots = nullptr;
     T* mc = nullptr; int* dNotLattice = nullptr; bool lattice = false, useLattice = true, useCompactM = true;
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
         const bool noAp = recomputeAp && (!this->slab.active || this->slab.ghost >= 2);      // iw_pcgIter2: Ap recomputed instead of stored
@@ -959,7 +975,16 @@ struct ImageWarpingOps : EnergyOps<T> {
         int rowsPerGroup = divUp(rows, gy);
         if (const char* e = getenv("OPT_AMD_ITER_ROWS")) rowsPerGroup = std::max(atoi(e), divUp(rows, kMaxPartials / gx));   // experiment: more, shorter groups
         gy = divUp(rows, rowsPerGroup);
-        IterK<T> K{a.rOld, a.ApOld, a.pOld, a.rNew, a.ApNew, a.pNew, a.delta, a.pre, a.first, pre == 2 ? mc : nullptr, iterFlip,
+        if (a.first) iterIndex = 0;
+        const bool paired = noAp && pairDelta;
+        int deltaMode = 0; const T* alphaIn = nullptr; T* alphaOut = nullptr;
+        if (paired) {
+            if (!alphaSlots) HIP_CHECK(hipMalloc((void**)&alphaSlots, 2 * sizeof(T)));
+            deltaMode = (iterIndex >= 2 && iterIndex % 2 == 0) ? 1 : 2;           // launch 0 has nothing to apply; odd launches defer
+            alphaOut = alphaSlots + (iterIndex & 1); alphaIn = alphaSlots + ((iterIndex & 1) ^ 1);
+        }
+        deferredTerm = paired && iterIndex >= 1 && iterIndex % 2 == 1;            // after an odd launch alpha_{k-1} p_{k-1} is still owed (pcgFinish)
+        IterK<T> K{a.rOld, a.ApOld, a.pOld, a.rNew, a.ApNew, a.pNew, a.delta, a.pre, a.first, pre == 2 ? mc : nullptr, iterFlip, deltaMode, alphaIn, alphaOut,
                    a.aNumPrev.partials, a.aDenPrev.partials, a.s2Prev.partials, a.s3Prev.partials, a.aNumPrev.n, a.aDenPrev.n, a.s2Prev.n, a.s3Prev.n,
                    a.aNum->partials, a.aDen->partials, a.s2->partials, a.s3->partials};
         {
@@ -969,9 +994,19 @@ struct ImageWarpingOps : EnergyOps<T> {
             HIP_CHECK(hipLaunchKernel(fn, dim3(gx * gy), dim3(noAp ? kIterBlock2 : kIterBlock), kargs, 0, ctx.stream));
         }
         if (alternateSweep) iterFlip ^= 1;
+        ++iterIndex;
         a.aNum->n = a.aDen->n = a.s2->n = a.s3->n = gx * gy;
         if (this->slab.active && !noAp) iw_zeroGhost<T><<<divUp(A.W, kBlock), kBlock, 0, ctx.stream>>>(A, a.ApNew);
         return true;
+    }
+    // After the last launch L-1 of a linear solve.  If it was an odd launch, the term alpha_{L-2} p_{L-2} was deferred: pPrev is the
+    // p buffer that launch read (p_{L-2}) and alpha_{L-2} sits in the slot that launch wrote.  The solver then adds alpha_{L-1} p_{L-1}.
+    void pcgFinish(const T* pPrev, T* delta, LaunchCtx& ctx) override {
+        if (!deferredTerm) return;
+        ScopedKernel k(ctx, "PCGStep2_delta");
+        const long n = 3L * A.W * A.H;
+        iw_axpyDeferred<T><<<flatGrid(n), kBlock, 0, ctx.stream>>>(delta, pPrev, alphaSlots + ((iterIndex - 1) & 1), n);
+        deferredTerm = false;
     }
     void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {
         ScopedKernel k(ctx, "computeModelCost");

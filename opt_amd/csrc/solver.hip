@@ -456,6 +456,7 @@ struct PcgSolver : SolverBase {
             cur ^= 1;
         }
         // the last iteration's delta += alpha p (PCGStep2, solver.t:461-462); r, z, p of that iteration are dead
+        E->pcgFinish(p2, delta, ctx);
         finalizeLocal(prev[0], scal + 2);
         { ScopedKernel k(ctx, "PCGStep2_delta"); k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, p, nPacks, scal + 2, prev[1].partials, prev[1].n); }
         return true;
