@@ -49,7 +49,10 @@ def run(P, kind, nit, lit, timing):
 
 
 def main():
+    only = os.environ.get("OPT_AMD_CONFIG")          # substring filter, e.g. "config3" (used by tools/profile_config.sh)
     for name, make, kind, nit, lit in CONFIGS:
+        if only and only not in name:
+            continue
         P = make()
         run(make(), kind, 1, min(lit, 5), False)                     # warm-up (module load, allocator)
         dt, c0, c1, steps, _ = run(P, kind, nit, lit, False)
