@@ -194,3 +194,29 @@ def test_lattice_fast_path_matches_the_general_path(monkeypatch):
         outs.append((g.cost(), device_unknowns(P, dev)))
         g.close()
     assert abs(outs[0][0] - outs[1][0]) <= 2e-6 * outs[1][0] and rel_err(outs[0][1], outs[1][1]) < 2e-6
+
+
+RAGGED = [(1, 1), (2, 1), (1, 6), (3, 3), (59, 2), (60, 5), (61, 3), (63, 4), (64, 2), (65, 7), (119, 3), (121, 6), (719, 2), (720, 3), (721, 5), (1441, 4), (7, 301)]
+
+
+@pytest.mark.parametrize("liters", [1, 2, 7, 8])
+@pytest.mark.parametrize("W,H", RAGGED)
+def test_iteration_kernel_on_ragged_sizes(oracle_lib, W, H, liters):
+    """The single-kernel PCG iteration tiles an image into 60-pixel wave spans (720-pixel strips), keeps a 2-pixel ring and marches
+    three rows per pass: sizes around every one of those boundaries, down to 1x1, for odd and even launch counts (the delta
+    update is paired over two launches), against the oracle in double."""
+    P = wl.image_warping(W, H, double=True, random_state=W * 31 + H, mask_fraction=0.1 if W * H > 8 else 0.0, perturb=0.3)
+    o = oracle_solver(oracle_lib, P, nIterations=2, lIterations=liters)
+    g = hip_solver(P, nIterations=2, lIterations=liters)
+    dev = api.to_device(P)
+    Pref = P.clone()
+    o.init(Pref.params); g.init(dev)
+    scale = max(abs(o.cost()), 1e-300)
+    while True:
+        a, b = o.step(Pref.params), g.step(dev)
+        assert a == b
+        assert abs(g.cost() - o.cost()) <= 1e-10 * max(abs(o.cost()), 1e-12 * scale)      # a 1x1 image converges to cost ~1e-31
+        if not a:
+            break
+    assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < 1e-9
+    g.close(); o.close()
