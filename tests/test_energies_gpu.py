@@ -9,13 +9,38 @@ from helpers import active_mask, device_unknowns, flat_unknowns, hip_solver, ora
 
 pytestmark = pytest.mark.gpu
 
+def _raptor(double):
+    """The reference's ARAP example mesh (examples/data/raptor_simplify2k.off + .mrk, frozen as tests/fixtures/raptor2k_mesh.npz):
+    irregular valence 3..12, 12108 half-edges, 11 landmark constraints pulled 30 % of the way."""
+    import os
+    from opt_amd import io
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fixtures", "raptor2k_mesh.npz"))
+    return io.arap_problem_from_mesh(z["vertices"], z["faces"].tolist(), z["marker_index"], z["marker_position"], double=double, alpha=0.3)
+
+
+def _poisson_real(double):
+    """poisson_image_editing on the reference example's own images (examples/data/poisson0.png, poisson1.png, poisson_mask.png sampled
+    every 4th pixel, tests/fixtures/poisson_real_112x80.npz), assembled like CombinedSolver.h:66-90: alpha = 255, M = 0 where the mask is 255."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fixtures", "poisson_real_112x80.npz"))
+    ft = np.float64 if double else np.float32
+    H, W = z["mask"].shape
+    alpha = np.full((H, W, 1), 255.0)
+    X = np.concatenate([z["base"].astype(np.float64), alpha], -1)
+    T = np.concatenate([z["inserted"].astype(np.float64), alpha], -1)
+    M = np.where(z["mask"] == 255, 0.0, 255.0)
+    return wl.Problem("poisson_image_editing", (W, H), [X.astype(ft), T.astype(ft), M.astype(ft)], (0,), double)
+
+
 CASES = {
     "poisson": lambda double: wl.poisson_image_editing(70, 45, double=double, seed=2),
     "poisson_tiny": lambda double: wl.poisson_image_editing(5, 3, double=double, seed=4),
+    "poisson_real": _poisson_real,
     "laplacian": lambda double: wl.laplacian(67, 33, seed=1),
     "curveFitting": lambda double: wl.curve_fitting(200, double=double),
     "arap": lambda double: wl.arap_mesh_deformation(23, 17, double=double, seed=3, perturb=0.01),
     "arap_rest": lambda double: wl.arap_mesh_deformation(12, 9, double=double),
+    "arap_raptor": _raptor,
     "sfs": lambda double: wl.shape_from_shading(40, 32, double=double, seed=6, holes=True, noise=2e-3),
     "sfs_clean": lambda double: wl.shape_from_shading(33, 21, double=double, seed=7),
     # the functor engine (stencil_engine.h)
