@@ -24,8 +24,11 @@
 //  * the grid is sized to be co-resident (one wave of workgroups, rows split evenly) instead of
 //    thousands of 16x16 tiles, so there is no tail and only ~1k partial sums per dot product;
 //  * for Gauss-Newton the whole PCG iteration (the reference's PCGStep1 + PCGStep2 + PCGStep3) is ONE such
-//    kernel, iw_pcgIter (125 B/pixel of HBM traffic against 180 B/pixel algorithmic); iw_applyJTJ (with the
-//    previous PCGStep3 optionally fused in) serves LM, probes and the OPT_AMD_ONEKERNEL=0 fallback.
+//    kernel.  iw_pcgIter2 -- the default -- also keeps A*p out of memory (it is recomputed from p on a 2-pixel ring),
+//    derives the preconditioner from the flag byte, recomputes (cos, sin) from the angle and pairs the delta updates:
+//    71 B/pixel of HBM traffic per iteration against 180 B/pixel for the three reference kernels.  iw_pcgIter (A*p in
+//    memory, 113-121 B/pixel) remains for slabs with a single ghost row; iw_applyJTJ (with the previous PCGStep3
+//    optionally fused in) serves LM, probes and the OPT_AMD_ONEKERNEL=0 fallback.
 #include "energy.h"
 #include <cstdint>
 
@@ -41,7 +44,7 @@ struct IWArgs {
     int gy0, Hg;              // global row of local row 0, global height
     const T* Offset; const T* Angle; const T* UrShape; const T* Constraints; const T* Mask;
     T w_fit, w_reg;
-    uint8_t* flags;           // bit0: pixel exists and Mask == 0 ; bit1: fit constraint valid
+    uint8_t* flags;           // bit0: pixel exists and Mask == 0 ; bit1: fit constraint valid ; bits 2-4: number of active 4-neighbours
     T* cs;                    // (cos a, sin a) per pixel
 };
 
