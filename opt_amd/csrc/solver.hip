@@ -297,6 +297,7 @@ struct PcgSolver : SolverBase {
     double* scal = nullptr;             // device: [0],[1] alphaNumerator ping-pong, [2..5] slab totals
     int aSlot = 0;
     double* hostBuf = nullptr;          // pinned
+    double* hostBufQ = nullptr; hipEvent_t qEvent = nullptr; int qCount = 0;   // pinned buffer + event of the overlapped q fetch
     T prevCost = 0;
     T trust_region_radius = 0, radius_decrease_factor = 0, min_lm_diagonal = 0, max_lm_diagonal = 0;   // pd.parameters (o.t:933-938)
     hipEvent_t overallStart = nullptr; bool overallOpen = false;
@@ -336,6 +337,7 @@ struct PcgSolver : SolverBase {
         (void)hipStreamSynchronize(stream);
         for (void* a : allocs) (void)hipFree(a);
         if (hostBuf) (void)hipHostFree(hostBuf);
+        if (hostBufQ) { (void)hipHostFree(hostBufQ); (void)hipEventDestroy(qEvent); }
         (void)hipStreamDestroy(stream);
     }
 
@@ -352,6 +354,25 @@ struct PcgSolver : SolverBase {
         HIP_CHECK(hipMemcpyAsync(hostBuf, R.partials, R.n * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         double s = 0; for (int i = 0; i < R.n; ++i) s += hostBuf[i];
+        return s;
+    }
+    // The same value without draining the stream: begin enqueues the copy and an event, end waits for that event only.
+    void beginHostSum(const Reduction& R) {
+        if (!hostBufQ) { HIP_CHECK(hipHostMalloc((void**)&hostBufQ, kMaxPartials * sizeof(double))); HIP_CHECK(hipEventCreateWithFlags(&qEvent, hipEventDisableTiming)); }
+        if (distributed) {
+            k_finalizeSum<<<1, kBlock, 0, stream>>>(R.partials, R.n, scal + 2);
+            comm.allReduceSum(comm.ctx, scal + 2, 1, (void*)stream);
+            HIP_CHECK(hipMemcpyAsync(hostBufQ, scal + 2, sizeof(double), hipMemcpyDeviceToHost, stream));
+            qCount = 1;
+        } else {
+            HIP_CHECK(hipMemcpyAsync(hostBufQ, R.partials, R.n * sizeof(double), hipMemcpyDeviceToHost, stream));
+            qCount = R.n;
+        }
+        HIP_CHECK(hipEventRecord(qEvent, stream));
+    }
+    double endHostSum() {
+        HIP_CHECK(hipEventSynchronize(qEvent));
+        double s = 0; for (int i = 0; i < qCount; ++i) s += hostBufQ[i];
         return s;
     }
     // What device consumers should sum: the partials themselves, or (slab mode) the all-reduced total.
@@ -529,7 +550,12 @@ struct PcgSolver : SolverBase {
         bool pendingStep3 = false;
         Reduction bNum;
         const bool single = !lm && oneKernel && r2 && runSingleKernelLoop(preArg);
-        for (int lIter = 0; !single && lIter < sp.lIterations; ++lIter) {
+        // Step3 of the previous iteration (when pending) and Step1 of the next one.  None of it touches what survives a q early-out
+        // (delta, and p only through the very Step3 the reference also runs before its q test), so in LM it is enqueued BEFORE the
+        // host reads q of the current iteration: the blocking fetchQ of solver.t:1098 then overlaps with useful kernels instead of
+        // draining the GPU once per PCG iteration.  With tracing on, the original order (decide, then launch) is kept.
+        Reduction aDen;
+        auto stepThreeAndOne = [&]() {
             bool applied = false;
             if (pendingStep3) {
                 if (fuseStep3) {
@@ -548,7 +574,12 @@ struct PcgSolver : SolverBase {
                 exchangeVector(p);
                 E->applyJTJ(p, Ap_X, lm ? CtC : nullptr, &redA, ctx);    // PCGStep1 (+_Graph)
             }
-            Reduction aDen = forConsumers(redA, 0);
+            aDen = forConsumers(redA, 0);
+        };
+        static const bool overlapQ = [] { const char* e = getenv("OPT_AMD_OVERLAP_Q"); return !e || atoi(e) != 0; }();   // A/B switch
+        const bool speculate = !traceEnabled && overlapQ;
+        if (!single && sp.lIterations > 0) stepThreeAndOne();     // Step1 of iteration 0
+        for (int lIter = 0; !single && lIter < sp.lIterations; ++lIter) {
             const bool reset = lm && ((lIter + 1) % sp.residual_reset_period) == 0;
             if (reset) {   // solver.t:1077-1083
                 { ScopedKernel k(ctx, "PCGStep2_1stHalf"); k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, p, nPacks, scal + aSlot, aDen.partials, aDen.n); }
@@ -570,15 +601,23 @@ struct PcgSolver : SolverBase {
             }
             bNum = forConsumers(redB, 1);
             pendingStep3 = true;   // PCGStep3 of this iteration runs with the next PCGStep1
+            const bool more = lIter + 1 < sp.lIterations;
             double qh = 0;
-            if (lm) { qh = hostSum(redQ); }
-            if (traceEnabled) record(lIter, aDen, bNum, qh);
+            if (lm && speculate) {
+                beginHostSum(redQ);
+                if (more) stepThreeAndOne();
+                qh = endHostSum();
+            } else {
+                if (lm) qh = hostSum(redQ);
+                if (traceEnabled) record(lIter, aDen, bNum, qh);
+            }
             if (lm) {   // solver.t:1093-1102
                 Q1 = (T)qh;
                 T zeta = T(lIter + 1) * (Q1 - Q0) / Q1;
                 if (zeta < q_tolerance) { if (verbosity > 0) printf("zeta=%.18g, breaking at iteration: %d\n", (double)zeta, lIter + 1); break; }
                 Q0 = Q1;
             }
+            if (more && !(lm && speculate)) stepThreeAndOne();
         }
         if (pendingStep3 && keepReferenceP) {   // the reference's final PCGStep3 only matters to someone probing `p`
             ScopedKernel k(ctx, "PCGStep3");
