@@ -155,19 +155,22 @@ __global__ __launch_bounds__(kBlock) void sfs_gather(SArgs<T> A, const T* __rest
             auto add = [&](T coef, T q) { s += coef * q; if (JTF) d += coef * coef; };
             // fitting row at c (its q is recomputed: one multiply)
             { const T q = JTF ? A.w_p * (A.X[e] - A.D_i[e]) : A.w_p * v[e]; add(A.w_p, q); }
-            // shading rows: which (row centre c', slot) pairs contain X_c -- see the header comment of sfs_rows
+            // shading rows: which (row centre c', slot) pairs contain X_c -- see the header comment of sfs_rows.  Branch-free: a row
+            // centre outside the interior reads this pixel's (valid) addresses and gets coefficient 0, so every load of the pixel
+            // can be in flight at once instead of one behind each `if`.
+            auto centre = [&](int cx, int cy, bool& ok) { ok = sfs_interior(A, cx, cy); return ok ? (long)cy * A.W + cx : (x >= 1 && x <= A.W - 2 && y >= 1 && y <= A.H - 2 ? e : (long)A.W + 1); };
             auto gh = [&](int cx, int cy, int slot) {
-                if (!sfs_interior(A, cx, cy)) return;
-                const long c = (long)cy * A.W + cx, cr = c + 1;
+                bool ok; const long c = centre(cx, cy, ok), cr = c + 1;
                 const T m = A.w_g * (T)A.mR[c];
-                const T coef = slot == 0 ? m * (A.g1[c] - A.g0[cr]) : slot == 1 ? m * A.g0[c] : slot == 2 ? m * A.g2[c] : slot == 3 ? -(m * A.g1[cr]) : -(m * A.g2[cr]);
+                T coef = slot == 0 ? m * (A.g1[c] - A.g0[cr]) : slot == 1 ? m * A.g0[c] : slot == 2 ? m * A.g2[c] : slot == 3 ? -(m * A.g1[cr]) : -(m * A.g2[cr]);
+                coef = ok ? coef : T(0);
                 add(coef, qgh[c]);
             };
             auto gv = [&](int cx, int cy, int slot) {
-                if (!sfs_interior(A, cx, cy)) return;
-                const long c = (long)cy * A.W + cx, cd = c + A.W;
+                bool ok; const long c = centre(cx, cy, ok), cd = c + A.W;
                 const T m = A.w_g * (T)A.mC[c];
-                const T coef = slot == 0 ? m * (A.g1[c] - A.g2[cd]) : slot == 1 ? m * A.g0[c] : slot == 2 ? m * A.g2[c] : slot == 3 ? -(m * A.g1[cd]) : -(m * A.g0[cd]);
+                T coef = slot == 0 ? m * (A.g1[c] - A.g2[cd]) : slot == 1 ? m * A.g0[c] : slot == 2 ? m * A.g2[c] : slot == 3 ? -(m * A.g1[cd]) : -(m * A.g0[cd]);
+                coef = ok ? coef : T(0);
                 add(coef, qgv[c]);
             };
             gh(x, y, 0); gh(x + 1, y, 1); gh(x, y + 1, 2); gh(x - 1, y, 3); gh(x - 1, y + 1, 4);
@@ -176,11 +179,9 @@ __global__ __launch_bounds__(kBlock) void sfs_gather(SArgs<T> A, const T* __rest
             const int ox[5] = {0, 1, -1, 0, 0}, oy[5] = {0, 0, 0, 1, -1};
 #pragma unroll
             for (int u = 0; u < 5; ++u) {
-                const int cx = x + ox[u], cy = y + oy[u];
-                if (!sfs_interior(A, cx, cy)) continue;
-                const long c = (long)cy * A.W + cx;
-                if (A.valid[c] != T(1)) continue;
-                const T wgt = A.w_s * (u == 0 ? T(4) : T(-1));
+                bool ok; const long c = centre(x + ox[u], y + oy[u], ok);
+                ok = ok && A.valid[c] == T(1);
+                const T wgt = ok ? A.w_s * (u == 0 ? T(4) : T(-1)) : T(0);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) add(wgt * coefK(A, k, x, y), qs[(long)k * N + c]);
             }
