@@ -97,18 +97,21 @@ __global__ __launch_bounds__(kBlock) void sfs_rows(SArgs<T> A, const T* __restri
         T jp = 0, jgh = 0, jgv = 0, js[3] = {0, 0, 0};       // (J v) per row
         const bool needR = MODE != 3, needJ = MODE == 1 || MODE == 3;
         if (dvalid) { if (needR) rp = A.w_p * (A.X[e] - A.D_i[e]); if (needJ) jp = A.w_p * v[e]; }
-        if (in1) {
-            const long er = e + 1, ed = e + A.W;
-            const T mr = (T)A.mR[e], mc = (T)A.mC[e];
-            if (needR) { rgh = A.w_g * ((A.B_I[e] - A.B_I[er]) * mr); rgv = A.w_g * ((A.B_I[e] - A.B_I[ed]) * mc); }
+        {   // branch-free: a border pixel reads the addresses of the interior pixel (1,1) and masks the results, so the loads
+            // are not queued up behind `if (interior)` / `if (valid)`
+            const long c = in1 ? e : (long)A.W + 1;
+            const long er = c + 1, ed = c + A.W;
+            const T mr = (T)A.mR[c], mc = (T)A.mC[c];
+            if (needR) { rgh = A.w_g * ((A.B_I[c] - A.B_I[er]) * mr); rgv = A.w_g * ((A.B_I[c] - A.B_I[ed]) * mc); }
             if (needJ) {
-                const T base = A.g1[e] * v[e] + A.g0[e] * v[e - 1] + A.g2[e] * v[e - A.W];          // d B_I(c) . v
-                const T right = A.g1[er] * v[er] + A.g0[er] * v[e] + A.g2[er] * v[er - A.W];         // d B_I(c+ex) . v
-                const T down = A.g1[ed] * v[ed] + A.g0[ed] * v[ed - 1] + A.g2[ed] * v[e];            // d B_I(c+ey) . v
+                const T base = A.g1[c] * v[c] + A.g0[c] * v[c - 1] + A.g2[c] * v[c - A.W];          // d B_I(c) . v
+                const T right = A.g1[er] * v[er] + A.g0[er] * v[c] + A.g2[er] * v[er - A.W];         // d B_I(c+ex) . v
+                const T down = A.g1[ed] * v[ed] + A.g0[ed] * v[ed - 1] + A.g2[ed] * v[c];            // d B_I(c+ey) . v
                 jgh = A.w_g * mr * (base - right); jgv = A.w_g * mc * (base - down);
             }
-            if (A.valid[e] == T(1)) {
-                const long nb[5] = {e, e - 1, e - A.W, e + 1, e + A.W};
+            const bool vok = in1 && A.valid[c] == T(1);
+            {
+                const long nb[5] = {c, c - 1, c - A.W, c + 1, c + A.W};
                 const int ox[5] = {0, -1, 0, 1, 0}, oy[5] = {0, 0, -1, 0, 1};
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
@@ -119,9 +122,10 @@ __global__ __launch_bounds__(kBlock) void sfs_rows(SArgs<T> A, const T* __restri
                         if (needR) sr += cf * A.X[nb[u]];
                         if (needJ) sj += cf * v[nb[u]];
                     }
-                    rs[k] = A.w_s * sr; js[k] = A.w_s * sj;
+                    rs[k] = vok ? A.w_s * sr : T(0); js[k] = vok ? A.w_s * sj : T(0);
                 }
             }
+            if (!in1) { rgh = 0; rgv = 0; jgh = 0; jgv = 0; }
         }
         if (MODE == 0 || MODE == 1) {
             if (dvalid) {   // rows centred on excluded pixels are not part of the cost (solver.t:583, 669)
