@@ -53,16 +53,24 @@ def main(src, out):
         rd_mb, wr_mb = 2 * f * 1024 / 1e6, w * 1024 / 1e6
         gbs = (rd_mb + wr_mb) / 1e3 / (avg_us * 1e-6) if avg_us > 0 else 0
         lines.append(f"| {short(name)} | {r['Calls']} | {avg_us:.1f} | {f:.0f} | {w:.0f} | {rd_mb:.1f} | {wr_mb:.1f} | {gbs:.0f} |")
-    # traffic of the dominant kernel for bench.py's roofline.traffic (bench_kernel = the name bench.py times it under)
-    for r in rows:
-        n = r["Name"]
-        bench_kernel = "PCGIteration" if "iw_pcgIter2" in n else "PCGStep3+PCGStep1" if ("iw_applyJTJ" in n and ", true>(" in n) else None
-        if bench_kernel:
-            f = fetch.get(n, (0, 0.0))[1]; w = write.get(n, (0, 0.0))[1]
-            json.dump({"kernel": short(n), "bench_kernel": bench_kernel, "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024, "fetch_size_kib": f, "write_size_kib": w,
-                       "correction": "2 x FETCH_SIZE (gfx950) + WRITE_SIZE", "avg_us_rocprof": float(r["AverageNs"]) / 1e3,
-                       "workload": "image_warping 4096x4096 float", "source": os.path.basename(out)}, open(out + "_traffic.json", "w"))
-            break
+    # traffic of the dominant kernel for bench.py's roofline.traffic (bench_kernel = the name bench.py times it under).  The iteration
+    # kernel exists in two template variants that alternate launch by launch (sweep direction; the paired delta update makes the
+    # even launches heavier), so the per-launch figure is the call-weighted mean over all variants.
+    groups = {"PCGIteration": [r for r in rows if "iw_pcgIter2" in r["Name"]] or [r for r in rows if "iw_pcgIter" in r["Name"]],
+              "PCGStep3+PCGStep1": [r for r in rows if "iw_applyJTJ" in r["Name"] and ", true>(" in r["Name"]]}
+    for bench_kernel, rs in groups.items():
+        if not rs:
+            continue
+        calls = sum(int(r["Calls"]) for r in rs)
+        f = sum(int(r["Calls"]) * fetch.get(r["Name"], (0, 0.0))[1] for r in rs) / calls
+        w = sum(int(r["Calls"]) * write.get(r["Name"], (0, 0.0))[1] for r in rs) / calls
+        avg = sum(int(r["Calls"]) * float(r["AverageNs"]) for r in rs) / calls / 1e3
+        json.dump({"kernel": " + ".join(sorted(short(r["Name"]) for r in rs)), "bench_kernel": bench_kernel, "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024,
+                   "fetch_size_kib": f, "write_size_kib": w, "correction": "2 x FETCH_SIZE (gfx950) + WRITE_SIZE, call-weighted mean over the kernel's variants",
+                   "avg_us_rocprof": avg, "launches": calls, "workload": "image_warping 4096x4096 float", "source": os.path.basename(out)}, open(out + "_traffic.json", "w"))
+        lines += ["", f"dominant kernel ({bench_kernel}): {calls} launches, call-weighted mean {avg:.1f} us, {(2 * f + w) * 1024 / 1e9:.3f} GB of HBM traffic per launch "
+                      f"= {(2 * f + w) * 1024 / (4096 * 4096):.1f} B/pixel, {(2 * f + w) * 1024 / 1e3 / avg:.0f} GB/s"]
+        break
     if os.path.exists(os.path.join(src, "bench.json")):
         try:
             b = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
