@@ -115,15 +115,104 @@ __global__ __launch_bounds__(kBlock) void poisson_applyJTJ(PArgs<T> A, const T* 
     if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
 }
 
+// ---- one whole Gauss-Newton PCG iteration per launch, A p never stored (energy.h PcgIterArgs; the scheme of iw_pcgIter2) -------------
+// Launch k: for the pixel and its 4 neighbours  Ap_{k-1} = J^T J p_{k-1} (p on a 13-point diamond),  r_k = r_{k-1} - alpha_{k-1} Ap_{k-1},
+// p_k = r_k + beta_{k-1} p_{k-1}  (this energy does not precondition: z = r);  then Ap_k at the pixel for the sums.  State in
+// memory is r, p, delta: 100 B/pixel per iteration instead of 212 in three launches.  One thread per pixel -- the 18 float4 loads
+// per pixel are L1 / L2 hits on what neighbouring threads fetch; with 4 independent channels per pixel there is no point in
+// marching rows through registers.  The reference's start-up quirk is kept: PCGInit leaves p_0 = 0.25 r_0 and
+// alphaNumerator_0 = r_0 . p_0 although later z = r (guardedInvert(1) = 1/4, solver.t:323-332, 384-392); launch 0 therefore takes
+// p_0 from memory, and launch 1 expands betaNumerator_0 = sum r_1^2 from 4 alphaNumerator_0 = sum r_0^2 (exact: a power of two).
+template <class T>
+struct PIterK {
+    const T *rOld, *pOld; T *rNew, *pNew, *delta; int iter;
+    const double *aNumPrev, *aDenPrev, *s2Prev, *s3Prev; int nNum, nDen, n2, n3;
+    double *aNum, *aDen, *s2, *s3;
+};
+constexpr int kPTileW = 64, kPTileH = 4;     // 256 threads
+template <class T>
+__global__ __launch_bounds__(kBlock) void poisson_pcgIter(PArgs<T> A, PIterK<T> K) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    const bool first = K.iter == 0;
+    T alpha = 0, beta = 0;
+    if (!first) {
+        const double aNumD = sumPartials(K.aNumPrev, K.nNum, scratch), aDenD = sumPartials(K.aDenPrev, K.nDen, scratch);
+        const double s2 = sumPartials(K.s2Prev, K.n2, scratch), s3 = sumPartials(K.s3Prev, K.n3, scratch);
+        const T aNum = (T)aNumD, aDen = (T)aDenD;
+        alpha = (aDen > T(0)) ? aNum / aDen : T(0);
+        const double rr = (K.iter == 1) ? 4.0 * aNumD : aNumD;                  // sum r_{k-1}^2 (see above)
+        const double bNumD = rr - 2.0 * (double)alpha * s2 + (double)alpha * (double)alpha * s3;
+        beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
+    }
+    const V4<T>* R = (const V4<T>*)K.rOld; const V4<T>* P = (const V4<T>*)K.pOld;
+    const int tx = threadIdx.x % kPTileW, ty = threadIdx.x / kPTileW;
+    const int tilesX = (A.W + kPTileW - 1) / kPTileW, tilesY = (A.H + kPTileH - 1) / kPTileH;
+    double accDen = 0, accNum = 0, acc2 = 0, acc3 = 0;
+    const V4<T> zero{0, 0, 0, 0};
+    auto inb = [&](int x, int y) { return x >= 0 && x < A.W && y >= 0 && y < A.H; };
+    auto pAt = [&](int x, int y) { return inb(x, y) ? P[(long)y * A.W + x] : zero; };          // p is 0 on excluded pixels already
+    // J^T J p_{k-1} at (x, y): 2 sum over in-bounds neighbours of (p_c - p_n); the row of an excluded or non-existent pixel is 0
+    auto applyOld = [&](int x, int y, const V4<T>& pc) {
+        V4<T> o = zero;
+        const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};
+#pragma unroll
+        for (int n = 0; n < 4; ++n) if (inb(x + dx[n], y + dy[n])) { const V4<T> d = pc - pAt(x + dx[n], y + dy[n]); o = o + (d + d); }
+        return o;
+    };
+    // r_k and p_k at (x, y); both 0 where the pixel is excluded or outside
+    auto update = [&](int x, int y, V4<T>& rk, V4<T>& pk, V4<T>& pold) {
+        rk = zero; pk = zero; pold = zero;
+        if (!inb(x, y)) return;
+        const long i = (long)y * A.W + x;
+        if (A.M[i] != T(0)) return;
+        pold = P[i];
+        const V4<T> r0 = R[i];
+        if (first) { rk = r0; pk = pold; return; }
+        const V4<T> ap = applyOld(x, y, pold);
+        rk = r0 - alpha * ap;
+        pk = rk + beta * pold;
+    };
+    for (int t = blockIdx.x; t < tilesX * tilesY; t += gridDim.x) {
+        const int x = (t % tilesX) * kPTileW + tx, y = (t / tilesX) * kPTileH + ty;
+        if (!inb(x, y)) continue;
+        const long i = (long)y * A.W + x;
+        V4<T> rk, pk, pold;
+        update(x, y, rk, pk, pold);
+        ((V4<T>*)K.rNew)[i] = rk; ((V4<T>*)K.pNew)[i] = pk;
+        if (A.M[i] != T(0)) continue;
+        if (!first) { V4<T>* D = (V4<T>*)K.delta; D[i] = D[i] + alpha * pold; }          // delta += alpha_{k-1} p_{k-1} (solver.t:461-462)
+        V4<T> o = zero;
+        const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            if (!inb(x + dx[n], y + dy[n])) continue;
+            V4<T> rn, pn, pon;
+            update(x + dx[n], y + dy[n], rn, pn, pon);
+            const V4<T> d = pk - pn;
+            o = o + (d + d);
+        }
+        const V4<T> z = first ? pold : rk;                 // z_0 . r_0 is the reference's r_0 . p_0
+        accNum += (double)dot4(z, rk); accDen += (double)dot4(pk, o);
+        acc2 += (double)dot4(rk, o); acc3 += (double)dot4(o, o);
+    }
+    double t;
+    t = blockReduceSum(accDen, scratch); if (threadIdx.x == 0) K.aDen[blockIdx.x] = t;
+    t = blockReduceSum(accNum, scratch); if (threadIdx.x == 0) K.aNum[blockIdx.x] = t;
+    t = blockReduceSum(acc2, scratch); if (threadIdx.x == 0) K.s2[blockIdx.x] = t;
+    t = blockReduceSum(acc3, scratch); if (threadIdx.x == 0) K.s3[blockIdx.x] = t;
+}
+
 template <class T>
 struct PoissonOps : EnergyOps<T> {
     PArgs<T> A{};
     int cus = 256;
+    int iterIndex = 0; bool singleKernel = true;
     PoissonOps(const unsigned* dims) {
         A.W = (int)dims[0]; A.H = (int)dims[1];
         this->usePreconditioner = false;                       // poisson_image_editing.t:5
         this->addUnknown(0, (long)A.W * A.H, 4);
         int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (const char* e = getenv("OPT_AMD_POISSON_ONEKERNEL")) singleKernel = atoi(e) != 0;
     }
     int grid() const { return (int)std::max<long>(1, std::min<long>(((long)A.W * A.H + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
     void bind(void** p, LaunchCtx&) override { A.X = (const T*)p[0]; A.Tg = (const T*)p[1]; A.M = (const T*)p[2]; }
@@ -138,6 +227,19 @@ struct PoissonOps : EnergyOps<T> {
     }
     void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {
         ScopedKernel k(ctx, "computeModelCost"); poisson_cost<T, 1><<<grid(), kBlock, 0, ctx.stream>>>(A, delta, out.partials); out.n = grid();
+    }
+    bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
+        if (!singleKernel || a.pre) return false;
+        if (a.first) iterIndex = 0;
+        const int tiles = ((A.W + kPTileW - 1) / kPTileW) * ((A.H + kPTileH - 1) / kPTileH);
+        const int g = std::max(1, std::min(tiles, std::min(kMaxPartials, cus * 8)));
+        PIterK<T> K{a.rOld, a.pOld, a.rNew, a.pNew, a.delta, iterIndex,
+                    a.aNumPrev.partials, a.aDenPrev.partials, a.s2Prev.partials, a.s3Prev.partials, a.aNumPrev.n, a.aDenPrev.n, a.s2Prev.n, a.s3Prev.n,
+                    a.aNum->partials, a.aDen->partials, a.s2->partials, a.s3->partials};
+        { ScopedKernel k(ctx, "PCGIteration"); poisson_pcgIter<T><<<g, kBlock, 0, ctx.stream>>>(A, K); }
+        a.aNum->n = a.aDen->n = a.s2->n = a.s3->n = g;
+        ++iterIndex;
+        return true;
     }
 };
 
