@@ -30,7 +30,7 @@ namespace optamd {
 
 constexpr int kWave = 64;
 constexpr int kBlock = 256;          // threads per workgroup of the streaming kernels (4 waves)
-constexpr int kMaxPartials = 2048;   // per-workgroup partial sums a reduction may produce
+constexpr int kMaxPartials = 4096;   // per-workgroup partial sums a reduction may produce (ARAP: 2048 vertex-pass + 2048 edge-pass workgroups)
 
 // A grid-wide sum in flight: the producer kernel writes one double per workgroup into `partials`
 // (count `n`, known on the host at launch), the consumer kernels sum them in index order.

@@ -428,7 +428,7 @@ struct ArapOps : EnergyOps<T> {
         if (useGather) ensureCsr(ctx);
     }
     T* unknownPtr(int img) const override { return const_cast<T*>(img == 0 ? A.Offset : A.Angle); }
-    int vgrid() const { return (int)std::max<long>(1, std::min<long>((A.N + kBlock - 1) / kBlock, kMaxPartials / 2)); }
+    int vgrid() const { static const int cap = getenv("OPT_AMD_ARAP_VGRID") ? atoi(getenv("OPT_AMD_ARAP_VGRID")) : kMaxPartials / 2; return (int)std::max<long>(1, std::min<long>((A.N + kBlock - 1) / kBlock, cap)); }
     void evalCost(Reduction& out, LaunchCtx& ctx) override {
         const int gv = vgrid(), ge = edgeGrid(A.nE, cus);
         { ScopedKernel k(ctx, "computeCost"); arap_vertices<T, 0><<<gv, kBlock, 0, ctx.stream>>>(A, nullptr, nullptr, nullptr, nullptr, out.partials); }
