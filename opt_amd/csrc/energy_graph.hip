@@ -319,18 +319,17 @@ __global__ __launch_bounds__(kBlock) void arap_edgeJp(ArapArgs<T> A, const T* __
     double t = blockReduceSum(acc, scratch);
     if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
 }
-// 16 lanes per vertex: lanes 0-7 walk the out-list, lanes 8-15 the in-list (a mesh vertex has ~6 of each), so the
-// dependent index -> record gathers of one vertex are in flight together instead of in a 12-trip serial loop
-// (one thread per vertex: 113 us per launch at 500 k vertices; this shape: see profiles).
-constexpr int kLanesPerVertex = 16;
+// 8 lanes per vertex, each walking one slot of the out-list and one of the in-list (a mesh vertex has ~6 of each), so the
+// dependent index -> record gathers of one vertex are in flight together instead of in a 12-trip serial loop.  The kernel is
+// bound by how many such chains are in flight (time ~ 1 / resident workgroups), hence the full-occupancy grid.
+constexpr int kLanesPerVertex = 8;
 template <class T>
 __global__ __launch_bounds__(kBlock) void arap_vertexGather(ArapArgs<T> A, GraphCsr G, const T* __restrict__ v, const T* __restrict__ Jp, T* __restrict__ out, const T* __restrict__ CtC,
                                                             double* __restrict__ partials) {
     __shared__ double scratch[kBlock / kWave + 1];
     double acc = 0;
     const long offA = 3 * A.N;
-    const int sub = threadIdx.x % kLanesPerVertex, slot = sub & 7;
-    const bool inList = sub >= 8;
+    const int sub = threadIdx.x % kLanesPerVertex, slot = sub;
     const long nGroups = (A.N + (kBlock / kLanesPerVertex) - 1) / (kBlock / kLanesPerVertex);
     for (long g = blockIdx.x; g < nGroups; g += gridDim.x) {       // uniform trip count: the shuffles below need whole waves
         const long i = g * (kBlock / kLanesPerVertex) + threadIdx.x / kLanesPerVertex;
@@ -338,12 +337,15 @@ __global__ __launch_bounds__(kBlock) void arap_vertexGather(ArapArgs<T> A, Graph
         const long iv = ok ? i : 0;
         const T w = A.w_reg;
         T s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
-        const int* off = inList ? G.inOff : G.outOff; const int* idx = inList ? G.inIdx : G.outIdx;
-        const int b = off[iv], e = ok ? off[iv + 1] : b;
-        for (int k = b + slot; k < e; k += 8) {
-            const T* o = Jp + 6 * (long)idx[k];
-            if (inList) { s0 -= w * o[0]; s1 -= w * o[1]; s2 -= w * o[2]; }
-            else { s0 += w * o[0]; s1 += w * o[1]; s2 += w * o[2]; s3 -= w * o[3]; s4 -= w * o[4]; s5 -= w * o[5]; }
+        // each lane walks one slot of the out-list and one of the in-list: two independent index -> record chains in flight
+        const int bo = G.outOff[iv], eo = ok ? G.outOff[iv + 1] : bo, bi = G.inOff[iv], ei = ok ? G.inOff[iv + 1] : bi;
+        for (int k = 0; k < max(eo - bo, ei - bi); k += 8) {
+            const int ko = bo + slot + k, ki = bi + slot + k;
+            const int eOut = ko < eo ? G.outIdx[ko] : -1, eIn = ki < ei ? G.inIdx[ki] : -1;
+            const T* o = Jp + 6 * (long)max(eOut, 0); const T* q = Jp + 6 * (long)max(eIn, 0);
+            const T wo = eOut >= 0 ? w : T(0), wi = eIn >= 0 ? w : T(0);
+            s0 += wo * o[0]; s1 += wo * o[1]; s2 += wo * o[2]; s3 -= wo * o[3]; s4 -= wo * o[4]; s5 -= wo * o[5];
+            s0 -= wi * q[0]; s1 -= wi * q[1]; s2 -= wi * q[2];
         }
 #pragma unroll
         for (int m = 1; m < kLanesPerVertex; m <<= 1) {
