@@ -322,7 +322,10 @@ __global__ __launch_bounds__(kBlock) void arap_edgeJp(ArapArgs<T> A, const T* __
 // 8 lanes per vertex, each walking one slot of the out-list and one of the in-list (a mesh vertex has ~6 of each), so the
 // dependent index -> record gathers of one vertex are in flight together instead of in a 12-trip serial loop.  The kernel is
 // bound by how many such chains are in flight (time ~ 1 / resident workgroups), hence the full-occupancy grid.
-constexpr int kLanesPerVertex = 8;
+#ifndef ARAP_LANES
+#define ARAP_LANES 8
+#endif
+constexpr int kLanesPerVertex = ARAP_LANES;
 template <class T>
 __global__ __launch_bounds__(kBlock) void arap_vertexGather(ArapArgs<T> A, GraphCsr G, const T* __restrict__ v, const T* __restrict__ Jp, T* __restrict__ out, const T* __restrict__ CtC,
                                                             double* __restrict__ partials) {
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void arap_vertexGather(ArapArgs<T> A, Graph
         T s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
         // each lane walks one slot of the out-list and one of the in-list: two independent index -> record chains in flight
         const int bo = G.outOff[iv], eo = ok ? G.outOff[iv + 1] : bo, bi = G.inOff[iv], ei = ok ? G.inOff[iv + 1] : bi;
-        for (int k = 0; k < max(eo - bo, ei - bi); k += 8) {
+        for (int k = 0; k < max(eo - bo, ei - bi); k += kLanesPerVertex) {
             const int ko = bo + slot + k, ki = bi + slot + k;
             const int eOut = ko < eo ? G.outIdx[ko] : -1, eIn = ki < ei ? G.inIdx[ki] : -1;
             const T* o = Jp + 6 * (long)max(eOut, 0); const T* q = Jp + 6 * (long)max(eIn, 0);
