@@ -161,3 +161,91 @@ def test_split_with_two_ghost_rows():
         np.testing.assert_array_equal(Q.params[s_], P.params[s_])
     with pytest.raises(ValueError):
         slab.SlabLayout(8, 7, 0, 4)          # 4 slabs x 2 ghost rows need at least 8 image rows
+
+
+def _rank_main_two_ghost(rank, world, port, q):
+    """The protocol of the A*p-free iteration on slabs (OptAmd_PlanSetSlab with two ghost rows): no A*p vector crosses ranks; after
+    every iteration the two edge rows of r_k and p_k do.  A rank evaluates J^T J p on its slab with p valid on two ghost rows, which
+    makes A p valid on the first ghost row, updates r and p there as well as on its own rows, and sums dot products over own rows."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.binding import OracleSolver
+    W, H, G = 18, 14, 2
+    P = wl.image_warping(W, H, double=True, random_state=2, mask_fraction=0.08, perturb=0.3)
+    lay = slab.SlabLayout(W, H, rank, world, ghost=G)
+    loc = slab.split_problem(P, lay)
+    o = OracleSolver("image_warping", "gaussNewtonGPU", True, loc.dims)
+    LH = lay.local_H
+    npx = W * LH
+
+    def rows_mask(lo, hi):   # unknown-vector mask of local rows [lo, hi) that are not excluded
+        m = np.zeros((LH, W), dtype=bool); m[lo:hi] = True
+        m &= (loc.params[4] == 0)
+        return np.concatenate([np.repeat(m.reshape(-1), 2), m.reshape(-1)])
+
+    own, ring1 = rows_mask(G, LH - G), rows_mask(G - 1, LH - G + 1)
+
+    def exchange(vec):       # the neighbours' two edge rows -> my two ghost rows, per unknown image
+        for im in (vec[:2 * npx].reshape(LH, W, 2), vec[2 * npx:].reshape(LH, W)):
+            reqs = []
+            up, down = torch.from_numpy(im[G:2 * G].copy()), torch.from_numpy(im[LH - 2 * G:LH - G].copy())
+            rup, rdown = torch.zeros_like(up), torch.zeros_like(down)
+            if lay.has_up():
+                reqs += [dist.isend(up, rank - 1), dist.irecv(rup, rank - 1)]
+            if lay.has_down():
+                reqs += [dist.isend(down, rank + 1), dist.irecv(rdown, rank + 1)]
+            for r_ in reqs:
+                r_.wait()
+            if lay.has_up():
+                im[:G] = rup.numpy()
+            if lay.has_down():
+                im[LH - G:] = rdown.numpy()
+
+    def allsum(x):
+        t = torch.tensor([x], dtype=torch.float64); dist.all_reduce(t); return float(t.item())
+
+    f, d = o.eval_jtf(loc.params)                                   # valid on own rows (their residuals only reach the first ghost row)
+    r = np.where(own, -f, 0.0); pre = np.where(own, 1.0 / (1.0 + np.sqrt(d)) ** 2, 0.0)
+    exchange(r); exchange(pre)                                      # once per Gauss-Newton step
+    p = pre * r; delta = np.zeros_like(p)
+    aNum = allsum(float((r * own) @ p))
+    for _ in range(6):
+        Ap = np.where(ring1, o.apply_jtj(loc.params, p), 0.0)       # p is valid two rows out, so A p is valid one row out
+        aDen = allsum(float((p * own) @ Ap))
+        alpha = aNum / aDen if aDen > 0 else 0.0
+        delta += alpha * p * own
+        r = np.where(ring1, r - alpha * Ap, r)
+        z = pre * r
+        bNum = allsum(float((z * own) @ r))
+        beta = bNum / aNum if aNum > 0 else 0.0
+        p = np.where(ring1, z + beta * p, p)
+        aNum = bNum
+        exchange(r); exchange(p)                                    # refresh both ghost rows for the next iteration
+    q.put((rank, lay.row0, lay.rows, delta[:2 * npx].reshape(LH, W, 2)[G:LH - G].copy(), delta[2 * npx:].reshape(LH, W)[G:LH - G].copy()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_two_ghost_row_protocol(oracle_lib):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main_two_ghost, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    W, H = 18, 14
+    P = wl.image_warping(W, H, double=True, random_state=2, mask_fraction=0.08, perturb=0.3)
+    o = oracle_lib.OracleSolver("image_warping", "gaussNewtonGPU", True, P.dims)
+    o.set("nIterations", 1); o.set("lIterations", 6)
+    o.init(P.params); o.step(P.params)
+    delta = o.vector("delta")
+    dO, dA = delta[:2 * W * H].reshape(H, W, 2), delta[2 * W * H:].reshape(H, W)
+    for rank, row0, rows, lo, la in parts:
+        np.testing.assert_allclose(lo, dO[row0:row0 + rows], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(la, dA[row0:row0 + rows], rtol=1e-9, atol=1e-12)
