@@ -12,29 +12,11 @@
 // f32/f64 atomic (gfx950 has both natively -- no CAS loop as in util.t:574-597).  Runs need not be sorted for
 // correctness, only for the aggregation to pay off.  Tail-vertex targets are irregular and use plain atomics.
 #include "energy.h"
+#include "graph_common.h"
 #include <hipcub/hipcub.hpp>
 
 namespace optamd {
 namespace {
-
-// val summed over each contiguous run of equal `key` inside the wave; then one atomic per run.
-template <class T>
-__device__ __forceinline__ void segmentedAtomicAdd(T* __restrict__ base, long key, T val, bool active) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const long k = active ? key : -1 - lane;              // inactive lanes get unique keys: never merged
-    const long prev = __shfl_up(k, 1, kWave);
-    const bool head = (lane == 0) || (prev != k);
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long above = (lane == kWave - 1) ? 0ull : (heads >> (lane + 1));
-    const int runEnd = above ? lane + 1 + __builtin_ctzll(above) : kWave;   // first lane of the next run
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const T other = __shfl_down(val, off, kWave);
-        if (lane + off < runEnd) val += other;             // only lanes of my own contiguous run are folded in
-    }
-    if (active && head) unsafeAtomicAdd(base + key, val);
-}
-template <class T> __device__ __forceinline__ void plainAtomicAdd(T* addr, T val) { unsafeAtomicAdd(addr, val); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // curveFitting.t: unknown funcParams(a,b) over U, data(x,y) over N, edge (d,p): r = y - (a cos(b x) + b sin(a x))
@@ -90,7 +72,6 @@ __global__ __launch_bounds__(kBlock) void zeroOrCtC(T* __restrict__ out, T* __re
     if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
 }
 
-inline int edgeGrid(long nE, int cus) { return (int)std::max<long>(1, std::min<long>((nE + kBlock - 1) / kBlock, std::min<long>(kMaxPartials / 2, (long)cus * 8))); }
 
 template <class T>
 struct CurveFittingOps : EnergyOps<T> {

@@ -34,9 +34,13 @@ EnergyInfo sfsInfo();
 EnergyInfo opticalFlowInfo();
 EnergyInfo intrinsicInfo();
 EnergyInfo volumetricInfo();
+EnergyInfo cotangentInfo();
+EnergyInfo embeddedInfo();
+EnergyInfo robustInfo();
 const std::vector<EnergyInfo>& energyRegistry() {
     static std::vector<EnergyInfo> reg = {imageWarpingInfo(), poissonInfo(), laplacianInfo(), curveFittingInfo(), arapInfo(), sfsInfo(),
-                                           opticalFlowInfo(), intrinsicInfo(), volumetricInfo()};
+                                           opticalFlowInfo(), intrinsicInfo(), volumetricInfo(),
+                                           cotangentInfo(), embeddedInfo(), robustInfo()};
     return reg;
 }
 }  // namespace optamd

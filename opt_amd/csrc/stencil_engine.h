@@ -42,12 +42,18 @@ template <class T, int N> __device__ __forceinline__ Dual<T, N> operator*(const 
 template <class T, int N> __device__ __forceinline__ Dual<T, N> operator*(T a, const Dual<T, N>& b) { return b * a; }
 template <class T, int N> __device__ __forceinline__ Dual<T, N> sin(const Dual<T, N>& a) { Dual<T, N> r; T s, c; sincosT(a.v, &s, &c); r.v = s; OPTAMD_DUAL_LOOP r.d[i] = c * a.d[i]; return r; }   // ad.t:795
 template <class T, int N> __device__ __forceinline__ Dual<T, N> cos(const Dual<T, N>& a) { Dual<T, N> r; T s, c; sincosT(a.v, &s, &c); r.v = c; OPTAMD_DUAL_LOOP r.d[i] = -s * a.d[i]; return r; }  // ad.t:787
+template <class T, int N> __device__ __forceinline__ Dual<T, N> operator/(const Dual<T, N>& a, const Dual<T, N>& b) { Dual<T, N> r; const T inv = T(1) / b.v; r.v = a.v * inv; OPTAMD_DUAL_LOOP r.d[i] = (a.d[i] - r.v * b.d[i]) * inv; return r; }
+template <class T, int N> __device__ __forceinline__ Dual<T, N> operator/(const Dual<T, N>& a, T b) { return a * (T(1) / b); }
+template <class T, int N> __device__ __forceinline__ Dual<T, N> operator/(T a, const Dual<T, N>& b) { return Dual<T, N>(a) / b; }
+template <class T, int N> __device__ __forceinline__ Dual<T, N> sqrt(const Dual<T, N>& a) { Dual<T, N> r; r.v = ::sqrt(a.v); const T k = T(1) / (T(2) * r.v); OPTAMD_DUAL_LOOP r.d[i] = k * a.d[i]; return r; }   // ad.t:797
 #undef OPTAMD_DUAL_LOOP
 // scalar overloads next to the dual ones (a functor calls sin(x) / cos(x) on S = T as well; the templates above hide ::sin)
 __device__ __forceinline__ float sin(float x) { return ::sinf(x); }
 __device__ __forceinline__ double sin(double x) { return ::sin(x); }
 __device__ __forceinline__ float cos(float x) { return ::cosf(x); }
 __device__ __forceinline__ double cos(double x) { return ::cos(x); }
+__device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
+__device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
 template <class T> __device__ __forceinline__ T valueOf(T x) { return x; }
 template <class T, int N> __device__ __forceinline__ T valueOf(const Dual<T, N>& x) { return x.v; }
 // f(u, v) with known partials (the SampledImage operator, o.t:2486-2501): value and chain rule

@@ -254,3 +254,29 @@ def image_warping_problem_from_mask(mask_red, markers=wl.CAT512_MARKERS, downsam
             cons[y, x] = (tx / downsample, ty / downsample)
     P.params[3] = cons.astype(ft)
     return P
+
+
+def mesh_vertex_rings(n_vertices, faces):
+    """Ordered one-ring of every vertex of a manifold triangle mesh (what OpenMesh's vertex-vertex circulator yields, up to the
+    starting point and orientation): list of neighbour-index lists.  Interior vertices give a closed ring; at a boundary vertex the
+    ring starts at the boundary edge that has no predecessor."""
+    nxt = [dict() for _ in range(n_vertices)]          # around v: neighbour a is followed by neighbour b in triangle (v, a, b)
+    for f in faces:
+        assert len(f) == 3, "triangle meshes only"
+        for i in range(3):
+            v, a, b = f[i], f[(i + 1) % 3], f[(i + 2) % 3]
+            nxt[v][a] = b
+    rings = []
+    for v in range(n_vertices):
+        m = nxt[v]
+        if not m:
+            rings.append([]); continue
+        followers = set(m.values())
+        starts = [a for a in m if a not in followers]
+        cur = min(starts) if starts else min(m)
+        ring, seen = [], set()
+        while cur is not None and cur not in seen:
+            ring.append(cur); seen.add(cur)
+            cur = m.get(cur)
+        rings.append(ring)
+    return rings

@@ -282,3 +282,103 @@ def volumetric_mesh_deformation(W, H=None, D=None, double=False, seed=0, perturb
     ang = rng.normal(0, perturb, size=ur.shape) if perturb > 0 else np.zeros(ur.shape)
     return Problem("volumetric_mesh_deformation", (W, H, D), [off.astype(ft), ang.astype(ft), ur.astype(ft), cons.astype(ft), np.float32(1.0), np.float32(np.sqrt(0.05))],
                    (0, 1), double)
+
+
+def grid_surface_mesh(nx, ny, seed=0, bump=0.3):
+    """A triangulated height-field patch: (vertices float64 [nx*ny, 3], triangle list).  Stands in for the example meshes."""
+    rng = np.random.default_rng(seed)
+    ys, xs = np.meshgrid(np.arange(ny, dtype=np.float64), np.arange(nx, dtype=np.float64), indexing="ij")
+    z = bump * np.sin(0.9 * xs + rng.uniform(0, 3)) * np.cos(0.7 * ys + rng.uniform(0, 3))
+    V = np.stack([xs.reshape(-1), ys.reshape(-1), z.reshape(-1)], -1)
+    F = []
+    for y in range(ny - 1):
+        for x in range(nx - 1):
+            a, b, c, d = y * nx + x, y * nx + x + 1, (y + 1) * nx + x, (y + 1) * nx + x + 1
+            F.append([a, b, d]); F.append([a, d, c])
+    return V, F
+
+
+def torus_mesh(nx, ny, seed=0, R=3.0, r=1.0):
+    """A closed triangulated torus (every vertex has a full ring of 6): (vertices float64 [nx*ny, 3], triangle list).  Stands in for
+    the closed example meshes of the smoothing example."""
+    rng = np.random.default_rng(seed)
+    js, is_ = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+    u, v = 2 * np.pi * is_ / nx, 2 * np.pi * js / ny
+    rr = r * (1 + 0.15 * np.sin(3 * u + rng.uniform(0, 3)))
+    V = np.stack([(R + rr * np.cos(v)) * np.cos(u), (R + rr * np.cos(v)) * np.sin(u), rr * np.sin(v)], -1).reshape(-1, 3)
+    F = []
+    for y in range(ny):
+        for x in range(nx):
+            a, b = y * nx + x, y * nx + (x + 1) % nx
+            c, d = ((y + 1) % ny) * nx + x, ((y + 1) % ny) * nx + (x + 1) % nx
+            F.append([a, b, d]); F.append([a, d, c])
+    return V, F
+
+
+def _half_edges_from_rings(rings):
+    heads = np.concatenate([np.full(len(r), v, dtype=np.int32) for v, r in enumerate(rings)])
+    tails = np.concatenate([np.array(r, dtype=np.int32) for r in rings])
+    return heads, tails
+
+
+def cotangent_mesh_smoothing(nx, ny=None, double=False, seed=0, noise=0.05):
+    """examples/cotangent_mesh_smoothing/src/CombinedSolver.h:16-44, 68-113: X = A = the (noisy) input vertices; one hyperedge per
+    (vertex, ring neighbour): v0 = vertex, v1 = neighbour, v2 / v3 = previous / next neighbour in the ring (cyclic);
+    w_fit = 1, w_reg = 0.5 (main.cpp:34-35)."""
+    from . import io
+    ny = ny or nx
+    ft = np.float64 if double else np.float32
+    V, F = torus_mesh(nx, ny, seed)          # closed, like the example's meshes: no hyperedge lists a vertex twice
+    V = V + np.random.default_rng(seed + 1).normal(0, noise, size=V.shape)
+    rings = io.mesh_vertex_rings(len(V), F)
+    v0, v1, v2, v3 = [], [], [], []
+    for v, r in enumerate(rings):
+        n = len(r)
+        for i in range(n):
+            v0.append(v); v1.append(r[i]); v2.append(r[(i + n - 1) % n]); v3.append(r[(i + 1) % n])
+    idx = [np.array(a, dtype=np.int32) for a in (v0, v1, v2, v3)]
+    return Problem("cotangent_mesh_smoothing", (len(V),),
+                   [np.float32(np.sqrt(1.0)), np.float32(np.sqrt(0.5)), V.astype(ft), V.astype(ft), np.array(len(v0), dtype=np.int32)] + idx, (2,), double,
+                   {"n_edges": len(v0)})
+
+
+def embedded_mesh_deformation(nx, ny=None, double=False, seed=0, perturb=0.0):
+    """examples/embedded_mesh_deformation/src/CombinedSolver.h:33-56, 95-160: Offset = UrShape = node positions, RotMatrix = identity,
+    Constraints = -inf except handle nodes (one edge column pinned, the opposite one lifted); weights 3 / 12 / 5."""
+    from . import io
+    ny = ny or nx
+    ft = np.float64 if double else np.float32
+    V, F = grid_surface_mesh(nx, ny, seed)
+    rng = np.random.default_rng(seed + 2)
+    heads, tails = _half_edges_from_rings(io.mesh_vertex_rings(len(V), F))
+    off = V + (rng.normal(0, perturb, size=V.shape) if perturb > 0 else 0)
+    rot = np.tile(np.eye(3).reshape(-1), (len(V), 1)) + (rng.normal(0, perturb, size=(len(V), 9)) if perturb > 0 else 0)
+    cons = np.full(V.shape, -np.inf)
+    left, right = np.arange(ny) * nx, np.arange(ny) * nx + nx - 1
+    cons[left] = V[left]; cons[right] = V[right] + np.array([0.0, 0.3, 0.8])
+    return Problem("embedded_mesh_deformation", (len(V),),
+                   [np.float32(np.sqrt(3.0)), np.float32(np.sqrt(12.0)), np.float32(np.sqrt(5.0)), off.astype(ft), rot.astype(ft), V.astype(ft), cons.astype(ft),
+                    np.array(len(heads), dtype=np.int32), heads, tails], (3, 4), double, {"n_edges": int(len(heads))})
+
+
+def robust_nonrigid_alignment(nx, ny=None, double=False, seed=0, perturb=0.0):
+    """examples/robust_nonrigid_alignment/src/CombinedSolver.h:150-180: Offset = UrShape = source vertices, Angle = 0, RobustWeights = 1,
+    Constraints / ConstraintNormals = the corresponding point and normal on the target surface where a correspondence exists
+    (-inf otherwise); w_fit = 10, w_reg = 64 (its starting value)."""
+    from . import io
+    ny = ny or nx
+    ft = np.float64 if double else np.float32
+    V, F = grid_surface_mesh(nx, ny, seed)
+    rng = np.random.default_rng(seed + 3)
+    heads, tails = _half_edges_from_rings(io.mesh_vertex_rings(len(V), F))
+    target = V + np.stack([0.05 * np.sin(V[:, 1]), 0.04 * np.cos(V[:, 0]), 0.3 + 0.1 * np.sin(0.5 * V[:, 0])], -1)
+    nrm = np.stack([-0.05 * np.cos(0.5 * V[:, 0]), 0.02 * np.sin(V[:, 1]), np.ones(len(V))], -1)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    has = rng.random(len(V)) < 0.7
+    cons = np.where(has[:, None], target, -np.inf)
+    off = V + (rng.normal(0, perturb, size=V.shape) if perturb > 0 else 0)
+    ang = rng.normal(0, perturb, size=V.shape) if perturb > 0 else np.zeros(V.shape)
+    rw = 1.0 + (rng.normal(0, perturb, size=len(V)) if perturb > 0 else 0) * np.ones(len(V))
+    return Problem("robust_nonrigid_alignment", (len(V),),
+                   [np.float32(np.sqrt(10.0)), np.float32(np.sqrt(64.0)), off.astype(ft), ang.astype(ft), rw.astype(ft), V.astype(ft), cons.astype(ft), nrm.astype(ft),
+                    np.array(len(heads), dtype=np.int32), heads, tails], (2, 3, 4), double, {"n_edges": int(len(heads))})

@@ -8,6 +8,7 @@
 #include "energies.hpp"
 #include "sfs.hpp"
 #include "energies_grid.hpp"
+#include "energies_mesh.hpp"
 #include <memory>
 
 using namespace oracle;
@@ -28,6 +29,9 @@ template <class T> Energy<T>* makeEnergy(const std::string& n, const unsigned* d
     if (n == "optical_flow") return new OpticalFlow<T>(dims);
     if (n == "intrinsic_image_decomposition") return new IntrinsicImage<T>(dims);
     if (n == "volumetric_mesh_deformation") return new VolumetricMesh<T>(dims);
+    if (n == "cotangent_mesh_smoothing") return new CotangentSmoothing<T>(dims);
+    if (n == "embedded_mesh_deformation") return new EmbeddedDeformation<T>(dims);
+    if (n == "robust_nonrigid_alignment") return new RobustAlignment<T>(dims);
     return nullptr;
 }
 template <class T> std::vector<T>* vecByName(Solver<T>* s, const std::string& n) {

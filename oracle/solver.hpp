@@ -39,7 +39,7 @@
 
 namespace oracle {
 
-constexpr int MAXS = 9;    // largest residual support (ARAP edge: O(v0)3 + O(v1)3 + a(v0)3)
+constexpr int MAXS = 12;   // largest residual support (cotangent_mesh_smoothing edge: X of 4 vertices x 3)
 constexpr int MAXR = 24;   // most scalar residuals per element (volumetric_mesh_deformation: 3 fit + 6 dirs x 3)
 
 // One scalar residual instance: value, and partials w.r.t. the unknown scalars of its support.

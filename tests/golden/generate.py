@@ -29,6 +29,9 @@ CASES = {
     "optical_flow_18x14": (lambda: wl.optical_flow(18, 14, double=True, seed=12, init_flow=0.9), "gaussNewtonGPU"),
     "intrinsic_14x12_lm": (lambda: wl.intrinsic_image_decomposition(14, 12, double=True, seed=13), "LMGPU"),
     "volumetric_5x4x4": (lambda: wl.volumetric_mesh_deformation(5, 4, 4, double=True, seed=14, perturb=0.04), "gaussNewtonGPU"),
+    "cotangent_torus_8x6": (lambda: wl.cotangent_mesh_smoothing(8, 6, double=True, seed=15), "gaussNewtonGPU"),
+    "embedded_7x5_lm": (lambda: wl.embedded_mesh_deformation(7, 5, double=True, seed=16, perturb=0.03), "LMGPU"),
+    "robust_7x6": (lambda: wl.robust_nonrigid_alignment(7, 6, double=True, seed=17, perturb=0.03), "gaussNewtonGPU"),
 }
 
 

@@ -49,6 +49,11 @@ CASES = {
     "intrinsic": lambda double: wl.intrinsic_image_decomposition(29, 23, double=double, seed=4),
     "volumetric": lambda double: wl.volumetric_mesh_deformation(9, 7, 5, double=double, seed=5, perturb=0.05),
     "volumetric_rest": lambda double: wl.volumetric_mesh_deformation(6, 6, 6, double=double),
+    # the graph functor engine (graph_engine.h)
+    "cotangent": lambda double: wl.cotangent_mesh_smoothing(19, 13, double=double, seed=6),
+    "embedded": lambda double: wl.embedded_mesh_deformation(17, 11, double=double, seed=7, perturb=0.03),
+    "embedded_rest": lambda double: wl.embedded_mesh_deformation(9, 9, double=double),
+    "robust": lambda double: wl.robust_nonrigid_alignment(15, 12, double=double, seed=8, perturb=0.03),
 }
 
 
@@ -102,6 +107,12 @@ def test_trajectory(oracle_lib, name, double, kind):
         # cos(b x) with b x ~ 600 rad loses ~4 digits in float, so libm and the device sincosf legitimately differ;
         # the reference runs this energy in double (tests/minimal_graph_only/main.cpp:11).  Float is a smoke check.
         ctol, xtol = 5e-3, 1e-3
+    if name in ("cotangent", "embedded", "embedded_rest", "robust") and not P.double:
+        # the edge pass scatters with hardware float atomics in no fixed order (like the reference's graph kernels), so float
+        # trajectories wander at the 1e-5 level from run to run; the double runs of the same cases hold 1e-10
+        ctol, xtol = 5e-5, 1e-4
+        if name == "cotangent":     # normalize / cot / sqrt chains differentiated in float: 8e-5 after four Gauss-Newton steps
+            ctol, xtol = 3e-4, 1e-3
     if name == "intrinsic":
         # weights of 500 / 1000 / 10000 on differences of ~0.02 plus the (|dr| + 1e-7)^(-0.6) re-weighting make the system
         # ill-conditioned (unpreconditioned, 12 PCG iterations, far from converged): a 1-ulp difference between libm pow and the

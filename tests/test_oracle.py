@@ -58,6 +58,9 @@ CASES = {
     "optical_flow": lambda: wl.optical_flow(10, 8, double=True, seed=1, init_flow=0.7),
     "intrinsic_image_decomposition": lambda: wl.intrinsic_image_decomposition(8, 7, double=True, seed=2),
     "volumetric_mesh_deformation": lambda: wl.volumetric_mesh_deformation(4, 3, 3, double=True, seed=3, perturb=0.05),
+    "cotangent_mesh_smoothing": lambda: wl.cotangent_mesh_smoothing(5, 4, double=True, seed=1),
+    "embedded_mesh_deformation": lambda: wl.embedded_mesh_deformation(5, 4, double=True, seed=2, perturb=0.05),
+    "robust_nonrigid_alignment": lambda: wl.robust_nonrigid_alignment(5, 4, double=True, seed=3, perturb=0.05),
 }
 
 
@@ -382,5 +385,65 @@ def test_volumetric_cost_matches_numpy_restatement(oracle_lib):
             c, n = tuple(c), tuple(n)
             e = (O[c] - O[n]) - np.einsum("...ij,...j->...i", R[c], U[c] - U[n])
             cost += 0.5 * ((wr * e) ** 2).sum()
+    s = oracle_solver(oracle_lib, P)
+    assert abs(s.eval_cost(P.params) - cost) <= 1e-12 * cost
+
+
+def _rot3(angles):
+    """Rotate3D's matrix (lib.t:77-91) for an [n, 3] array of Euler angles -> [n, 3, 3]."""
+    al, be, ga = angles[:, 0], angles[:, 1], angles[:, 2]
+    ca, cb, cg, sa, sb, sg = np.cos(al), np.cos(be), np.cos(ga), np.sin(al), np.sin(be), np.sin(ga)
+    return np.stack([np.stack([cg * cb, -sg * ca + cg * sb * sa, sg * sa + cg * sb * ca], -1),
+                     np.stack([sg * cb, cg * ca + sg * sb * sa, -cg * sa + sg * sb * ca], -1),
+                     np.stack([-sb, cb * sa, cb * ca], -1)], -2)
+
+
+def test_cotangent_cost_matches_numpy_restatement(oracle_lib):
+    """cotangent_mesh_smoothing.t written with whole-array numpy operations over the hyperedge list."""
+    P = wl.cotangent_mesh_smoothing(6, 5, double=True, seed=4)
+    wf, wr, X, A, nE, v0, v1, v2, v3 = [np.asarray(a) for a in P.params]
+    X = X.astype(np.float64)
+
+    def unit(d):
+        return d / np.sqrt((d * d).sum(-1, keepdims=True))
+
+    def cot(a, b):
+        ab = (a * b).sum(-1)
+        disc = (a * a).sum(-1) * (b * b).sum(-1) - ab * ab
+        disc = np.where(disc > 0, disc, 0.0001)
+        return ab / np.sqrt(disc)
+    w = 0.5 * (cot(unit(X[v0] - X[v2]), unit(X[v1] - X[v2])) + cot(unit(X[v0] - X[v3]), unit(X[v1] - X[v3])))
+    w = np.sqrt(np.where(w > 0, w, 0.0001))
+    cost = 0.5 * ((float(wf) * (X - A)) ** 2).sum() + 0.5 * ((float(wr) * w[:, None] * (X[v1] - X[v0])) ** 2).sum()
+    s = oracle_solver(oracle_lib, P)
+    assert abs(s.eval_cost(P.params) - cost) <= 1e-12 * cost
+
+
+def test_embedded_cost_matches_numpy_restatement(oracle_lib):
+    P = wl.embedded_mesh_deformation(6, 4, double=True, seed=5, perturb=0.1)
+    wf, wr, wrot, O, R, U, C, nE, v0, v1 = [np.asarray(a) for a in P.params]
+    M = R.reshape(-1, 3, 3).astype(np.float64)                                   # row-major frames
+    valid = C[:, 0] >= -999999.9
+    cost = 0.5 * ((float(wf) * (O - np.where(np.isfinite(C), C, 0.0))) ** 2 * valid[:, None]).sum()
+    G = np.einsum("nki,nkj->nij", M, M)                                          # columns' Gram matrix
+    ortho = np.stack([G[:, 0, 1], G[:, 0, 2], G[:, 1, 2], G[:, 0, 0] - 1, G[:, 1, 1] - 1, G[:, 2, 2] - 1], -1)
+    cost += 0.5 * ((float(wrot) * ortho) ** 2).sum()
+    e = (O[v1] - O[v0]) - np.einsum("eij,ej->ei", M[v0], U[v1] - U[v0])
+    cost += 0.5 * ((float(wr) * e) ** 2).sum()
+    s = oracle_solver(oracle_lib, P)
+    assert abs(s.eval_cost(P.params) - cost) <= 1e-12 * cost
+
+
+def test_robust_alignment_cost_matches_numpy_restatement(oracle_lib):
+    """robust_nonrigid_alignment.t: the scalar point-to-plane term and the confidence penalty are each selected by the three
+    component-wise tests of greatereq(Constraints, -999999.9) (ad.t:327-349), i.e. counted once per valid component."""
+    P = wl.robust_nonrigid_alignment(6, 5, double=True, seed=6, perturb=0.1)
+    wf, wr, O, A, rw, U, C, Nn, nE, v0, v1 = [np.asarray(a) for a in P.params]
+    valid = C >= -999999.9                                                        # [n, 3]
+    Cz = np.where(np.isfinite(C), C, 0.0)
+    fit = rw * (Nn * (O - Cz)).sum(-1)
+    cost = 0.5 * ((float(wf) * fit[:, None]) ** 2 * valid).sum() + 0.5 * ((0.1 * (1 - rw * rw)[:, None]) ** 2 * valid).sum()
+    e = (O[v0] - O[v1]) - np.einsum("eij,ej->ei", _rot3(A.astype(np.float64))[v0], U[v0] - U[v1])
+    cost += 0.5 * ((float(wr) * e) ** 2).sum()
     s = oracle_solver(oracle_lib, P)
     assert abs(s.eval_cost(P.params) - cost) <= 1e-12 * cost
