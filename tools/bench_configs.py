@@ -48,8 +48,26 @@ def run(P, kind, nit, lit, timing):
     return out
 
 
+def cpu_port(P, kind, lit):
+    """The CPU oracle (a port of the reference algorithm, not the reference) on a bounded sample of the same problem: one outer
+    iteration with at most `lit` PCG iterations, all host cores for the row-banded image energies."""
+    from oracle.binding import OracleSolver
+    threads = max(1, min(os.cpu_count() or 1, 128))
+    o = OracleSolver(P.energy, kind, P.double, P.dims)
+    o.set_threads(threads)
+    o.set("nIterations", 1); o.set("lIterations", lit)
+    Q = P.clone()
+    o.init(Q.params)
+    t0 = time.perf_counter()
+    o.step(Q.params)
+    dt = time.perf_counter() - t0
+    o.close()
+    return {"pcg_iters_per_s": lit / dt, "wall_s": dt, "threads": threads, "sample": f"1 outer iteration x {lit} PCG iterations (incl. that step's J^T F, update and cost)"}
+
+
 def main():
     only = os.environ.get("OPT_AMD_CONFIG")          # substring filter, e.g. "config3" (used by tools/profile_config.sh)
+    with_cpu = os.environ.get("OPT_AMD_CPU_PORT") == "1"
     for name, make, kind, nit, lit in CONFIGS:
         if only and only not in name:
             continue
@@ -58,9 +76,13 @@ def main():
         dt, c0, c1, steps, _ = run(P, kind, nit, lit, False)
         _, _, _, _, kt = run(make(), kind, min(nit, 3), lit, True)
         pcg = sum(v[0] for k, v in kt.items() if k in ("PCGStep2", "PCGStep2_2ndHalf", "PCGIteration")) if kt else 0
-        print(json.dumps({"config": name, "solver": kind, "double": P.double, "wall_s": dt, "outer_steps": steps, "cost_initial": c0, "cost_final": c1,
-                          "pcg_iters_per_s_nominal": steps * lit / dt, "kernel_avg_us": {k: round(v[1] / v[0] * 1e3, 2) for k, v in kt.items()},
-                          "pcg_iterations_in_timed_solve": pcg}), flush=True)
+        row = {"config": name, "solver": kind, "double": P.double, "wall_s": dt, "outer_steps": steps, "cost_initial": c0, "cost_final": c1,
+               "pcg_iters_per_s_nominal": steps * lit / dt, "kernel_avg_us": {k: round(v[1] / v[0] * 1e3, 2) for k, v in kt.items()},
+               "pcg_iterations_in_timed_solve": pcg}
+        if with_cpu:
+            row["cpu_port"] = cpu_port(make(), kind, min(lit, 10))
+            row["gpu_over_cpu_port"] = row["pcg_iters_per_s_nominal"] / row["cpu_port"]["pcg_iters_per_s"]
+        print(json.dumps(row), flush=True)
 
 
 if __name__ == "__main__":
