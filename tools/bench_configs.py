@@ -25,6 +25,13 @@ CONFIGS = [
     ("config3 shape_from_shading 1024x1024 double LM 60x10", lambda: wl.shape_from_shading(1024, 1024, double=True), "LMGPU", 60, 10),
     ("config4 arap_mesh_deformation 708x707 grid (500k vertices) float GN 20x100", lambda: wl.arap_mesh_deformation(708, 707), "gaussNewtonGPU", 20, 100),
     ("image_warping 2048x2048 float LM 8x400", lambda: wl.image_warping(2048, 2048), "LMGPU", 8, 400),
+    # the functor-engine energies at their examples' iteration counts (not BASELINE configs)
+    ("extra optical_flow 1024x1024 float GN 3x50", lambda: wl.optical_flow(1024, 1024), "gaussNewtonGPU", 3, 50),
+    ("extra intrinsic_image_decomposition 1024x1024 float GN 7x10", lambda: wl.intrinsic_image_decomposition(1024, 1024), "gaussNewtonGPU", 7, 10),
+    ("extra volumetric_mesh_deformation 96^3 float GN 20x60", lambda: wl.volumetric_mesh_deformation(96, 96, 96), "gaussNewtonGPU", 20, 60),
+    ("extra cotangent_mesh_smoothing 512x512 torus float GN 5x25", lambda: wl.cotangent_mesh_smoothing(512, 512), "gaussNewtonGPU", 5, 25),
+    ("extra embedded_mesh_deformation 512x512 float GN 5x125", lambda: wl.embedded_mesh_deformation(512, 512), "gaussNewtonGPU", 5, 125),
+    ("extra robust_nonrigid_alignment 512x512 float GN 5x50", lambda: wl.robust_nonrigid_alignment(512, 512), "gaussNewtonGPU", 5, 50),
 ]
 
 
