@@ -178,3 +178,23 @@ def test_plan_failures_return_null():
         api.Solver(api.energy_file("image_warping"), "gradientDescentGPU", (8, 8))      # o.t:122
     with pytest.raises(RuntimeError):
         api.Solver("/nonexistent/image_warping.t", "gaussNewtonGPU", (8, 8))
+
+
+@pytest.mark.parametrize("double", [False, True])
+def test_poisson_single_kernel_iteration_matches_three_kernel_loop(double, monkeypatch):
+    """poisson_pcgIter (whole PCG iteration in one launch, A p recomputed, the p0 = r0 / 4 start-up quirk carried through the
+    beta-numerator expansion) against the Step1 / Step2 / Step3 loop over 150 iterations, odd and even image sizes."""
+    P = wl.poisson_image_editing(333, 257, double=double, seed=9)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("OPT_AMD_ONEKERNEL", mode)
+        g = hip_solver(P, nIterations=1, lIterations=150)
+        g.enable_trace()
+        dev = api.to_device(P)
+        g.init(dev); g.step(dev)
+        res[mode] = (g.cost(), device_unknowns(P, dev), g.trace())
+        g.close()
+    assert abs(res["1"][0] - res["0"][0]) <= (1e-9 if double else 1e-5) * abs(res["0"][0])
+    assert rel_err(res["1"][1], res["0"][1]) < (1e-9 if double else 1e-5)
+    # alphaNumerator / alphaDenominator / betaNumerator of the first iterations: the quirk shows up exactly there
+    np.testing.assert_allclose(res["1"][2][:5, 2:5], res["0"][2][:5, 2:5], rtol=1e-9 if double else 1e-4)
