@@ -45,6 +45,14 @@ struct PcgIterArgs {
     int first;                                           // first iteration of a linear solve: alpha_{-1} = beta_{-1} = 0
     Reduction aNumPrev, aDenPrev, s2Prev, s3Prev;        // sums of the previous launch (aNumPrev of launch 0: sum r.p of PCGInit1)
     Reduction *aNum, *aDen, *s2, *s3;                    // sums this launch writes
+    // Levenberg-Marquardt (all null / 0 for Gauss-Newton): A = J^T J + diag(CtC); the launch that applies Step2 of iteration k-1 also
+    // writes the partial sums of Q_{k-1} = 1/2 sum delta . (r + b) (solver.t:483-485), which the host's q early-out test reads.
+    // afterReset: the previous iteration ended with the split residual reset (solver.t:1077-1083), which already updated delta
+    // and r; this launch then only forms p = M r + beta p with beta = sum(betaNum) / sum(betaDen) and applies J^T J.
+    const T* CtC = nullptr; const T* b = nullptr; Reduction* q = nullptr;
+    int afterReset = 0; Reduction betaNum, betaDen;
+    T* deltaOut = nullptr;                               // if set, the updated delta goes here instead of in place (lets the solver enqueue
+                                                         // the next launch before it has read Q: an early-out then still finds the old delta)
 };
 
 // Everything the solver needs from an energy.  T = opt_float (float or double).

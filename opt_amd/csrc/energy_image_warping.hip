@@ -398,6 +398,7 @@ __global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __re
 template <class T>
 struct IterRaw {           // one pixel's loads, untouched (any ALU op here would force a wait before the loop back-edge)
     V2<T> ro, ao, po, mo, cs, u, dO; T ra, aa, pa, ma, dA;   // r, Ap, p, pre (Offset part / Angle part), table, UrShape, delta
+    V2<T> co; T ca;                                          // CtC (Levenberg-Marquardt only)
     int f, ok;
 };
 template <class T>
@@ -415,13 +416,16 @@ struct IterK {             // kernel argument block
     // 1 = this launch applies the two pending terms alpha_{k-2} p_{k-2} + alpha_{k-1} p_{k-1}, reading p_{k-2} from the pNew buffer
     // just before overwriting it (same thread, same address) -- 12 B/px extra every second launch instead of 24 B/px every launch.
     int deltaMode; const T* alphaIn; T* alphaOut;   // alpha_{k-2} (written by the previous launch) / where this launch leaves alpha_{k-1}
+    // Levenberg-Marquardt variant of iw_pcgIter2 (energy.h PcgIterArgs): CtC, b, the Q partial sums, and the after-reset mode
+    const T* CtC; const T* b; double* q; int afterReset; const double* betaNum; int nBetaNum; const double* betaDen; int nBetaDen;
+    T* deltaOut;           // where the updated delta is written (== delta: in place)
     const double *aNumPrev, *aDenPrev, *s2Prev, *s3Prev; int nNum, nDen, n2, n3;
     double *aNum, *aDen, *s2, *s3;
 };
 
 // PRE: 0 = identity preconditioner, 1 = the solver's 3-channel one (12 B/px), 2 = compact {M_O, M_a} (8 B/px).  A template
 // parameter, not a test of K.mc / K.pre: a load inside a (even uniform) branch costs an s_waitcnt vmcnt(0) at the merge.
-template <class T, bool LATTICE, int PRE, bool ANGLE = false>
+template <class T, bool LATTICE, int PRE, bool ANGLE = false, bool LMV = false>
 __device__ __forceinline__ IterRaw<T> iw_iterLoad(const IWArgs<T>& A, const IterK<T>& K, long N, bool xok, int x, int y) {
     IterRaw<T> r;
     r.ok = xok && y >= 0 && y < A.H;
@@ -435,6 +439,7 @@ __device__ __forceinline__ IterRaw<T> iw_iterLoad(const IWArgs<T>& A, const Iter
     else if (PRE == 2) { r.mo = ld2<kNTL>((const V2<T>*)K.mc, i); r.ma = 0; }
     else if (PRE == 1) { r.mo = ld2<kNTL>((const V2<T>*)K.pre, i); r.ma = ld1<kNTL>(K.pre + 2 * N, i); }
     else { r.mo = V2<T>{1, 1}; r.ma = 1; }
+    if (LMV) { r.co = ld2<kNTL>((const V2<T>*)K.CtC, i); r.ca = ld1<kNTL>(K.CtC + 2 * N, i); } else { r.co = V2<T>{0, 0}; r.ca = 0; }
     if (ANGLE) { r.cs.x = ld1<kNTL>(A.Angle, i); r.cs.y = 0; }     // iw_pcgIter2: the 4 B/px angle instead of the 8 B/px (cos, sin) table
     else r.cs = ld2<kNTL>((const V2<T>*)A.cs, i);
     if (LATTICE) r.u = V2<T>{0, 0}; else r.u = ld2<kNTL>((const V2<T>*)A.UrShape, i);
@@ -627,14 +632,16 @@ __device__ __forceinline__ void iw_pairQ(const Q<T>& c, const Q<T>& n, T& ax, T&
     aa -= n.on * (Dcx * jcx + Dcy * jcy);
 }
 template <class T>
-struct OldRow {            // one row of iteration k-1: p_{k-1} and, while still needed, r_{k-1} and M
+struct OldRow {            // one row of iteration k-1: p_{k-1} and, while still needed, r_{k-1}, M and (LM) CtC
     Q<T> q;
     T rx, ry, ra, mx, my, ma;
+    T cx, cy, ca;
 };
 template <class T>
 struct NewRow {            // one row of iteration k: p_k, z_k, M, and the shifted constant fields of its neighbours
     Q<T> q;
     T zx, zy, za, mx, my, ma;
+    T cx, cy, ca;          // CtC (LM)
     Q<T> lf, rt;           // only c, s, (ux, uy,) on are kept here
 };
 // (cos a, sin a) recomputed per pixel per launch from the 4 B angle instead of read from the 8 B table: +4.7 % PCG it/s
@@ -643,13 +650,18 @@ struct NewRow {            // one row of iteration k: p_k, z_k, M, and the shift
 #define IW_SINCOS_INLINE 1
 #endif
 constexpr bool kSinCosInline = IW_SINCOS_INLINE != 0;
-template <class T, bool LATTICE, int PRE, bool FLIP>
+// LM = true: the Levenberg-Marquardt loop (A = J^T J + diag(CtC), Q sums, restart after a residual reset); see energy.h PcgIterArgs.
+template <class T, bool LATTICE, int PRE, bool FLIP, bool LM = false>
 __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArgs<T> A, IterK<T> K, int rowsPerGroup, int gx, int gy) {
     __shared__ double scratch[kIterBlock2 / kWave + 1];
     const long N = (long)A.W * A.H;
     T alpha = 0, beta = 0;
     const bool first = K.first != 0;
-    if (!first) {
+    const bool restart = LM && K.afterReset != 0;      // r and delta are already those of this iteration (split residual reset)
+    if (restart) {
+        const T bNum = (T)sumPartials(K.betaNum, K.nBetaNum, scratch), bDen = (T)sumPartials(K.betaDen, K.nBetaDen, scratch);
+        beta = (bDen > T(0)) ? bNum / bDen : T(0);     // solver.t:544-547
+    } else if (!first) {
         const double aNumD = sumPartials(K.aNumPrev, K.nNum, scratch), aDenD = sumPartials(K.aDenPrev, K.nDen, scratch);
         const double s2 = sumPartials(K.s2Prev, K.n2, scratch), s3 = sumPartials(K.s3Prev, K.n3, scratch);
         const T aNum = (T)aNumD, aDen = (T)aDenD;
@@ -668,9 +680,11 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
     const int lyBegin = FLIP ? A.H - A.yEnd : A.yBegin, lyEnd = FLIP ? A.H - A.yBegin : A.yEnd;     // owned rows (a slab's ghost rows are plain halo here)
     const int yb = lyBegin + by * rowsPerGroup, ye = min(yb + rowsPerGroup, lyEnd);
     const T w2 = A.w_reg * A.w_reg, wf2 = A.w_fit * A.w_fit;
-    double accDen = 0, accNum = 0, acc2 = 0, acc3 = 0;
+    double accDen = 0, accNum = 0, acc2 = 0, acc3 = 0, accQ = 0;
+    const bool keepR = first || restart;
     V2<T>* rO = (V2<T>*)K.rNew; T* rA = K.rNew + 2 * N; V2<T>* pO = (V2<T>*)K.pNew; T* pA = K.pNew + 2 * N;
-    V2<T>* dO = (V2<T>*)K.delta; T* dA = K.delta + 2 * N;
+    const V2<T>* dO = (const V2<T>*)K.delta; const T* dA = K.delta + 2 * N;
+    V2<T>* dOut = (V2<T>*)K.deltaOut; T* dAout = K.deltaOut + 2 * N;
     // PRE == 3 (unit lattice): M = guardedInvert(diag J^T J) takes one of 10 (Offset) / 5 (Angle) values, indexed by the fit bit
     // and the neighbour count of the flag byte.  The Offset entries repeat iw_evalJTF's accumulation order, so they are the
     // values the solver's preconditioner vector holds, bit for bit; the Angle entries use |R'(a) n|^2 = 1 exactly where
@@ -697,6 +711,7 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
         o.q.on = (w.ok && (w.f & kActive)) ? T(1) : T(0);
         o.q.fw = (w.f & kFit) ? wf2 : T(0);
         o.rx = w.ro.x; o.ry = w.ro.y; o.ra = w.ra;
+        o.cx = w.co.x; o.cy = w.co.y; o.ca = w.ca;
         if (PRE == 3) {
             const int cnt = (w.f >> kCountShift) & 7;
             o.mx = o.my = mTab[cnt + ((w.f & kFit) ? 5 : 0)]; o.ma = mTab[10 + cnt];
@@ -721,16 +736,23 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
         dppShiftVec<true>(oB.q, lf); dppShiftVec<false>(oB.q, rt);
         T ax, ay, aa;
         applyA(oB.q, lf, rt, oA.q, oC.q, ax, ay, aa);                                   // Step1 of iteration k-1 again
-        const T rx = first ? oB.rx : oB.rx - alpha * ax, ry = first ? oB.ry : oB.ry - alpha * ay, ra = first ? oB.ra : oB.ra - alpha * aa;   // Step2
+        if (LM) { ax += oB.cx * oB.q.ox; ay += oB.cy * oB.q.oy; aa += oB.ca * oB.q.a; }                                                       // + CtC p (o.t:2076-2082)
+        const T rx = keepR ? oB.rx : oB.rx - alpha * ax, ry = keepR ? oB.ry : oB.ry - alpha * ay, ra = keepR ? oB.ra : oB.ra - alpha * aa;   // Step2
         nC.mx = oB.mx; nC.my = oB.my; nC.ma = oB.ma;
+        nC.cx = oB.cx; nC.cy = oB.cy; nC.ca = oB.ca;
         nC.zx = nC.mx * rx; nC.zy = nC.my * ry; nC.za = nC.ma * ra;
         nC.q.ox = nC.zx + beta * oB.q.ox; nC.q.oy = nC.zy + beta * oB.q.oy; nC.q.a = nC.za + beta * oB.q.a;                               // Step3
         if (live && writer && y + 1 >= yb && y + 1 < ye) {
             const long i = (long)phys(y + 1) * A.W + x;
-            if (!first && K.deltaMode != 2) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462), preceded by the deferred term of launch k-1
+            if (!keepR && K.deltaMode != 2) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462), preceded by the deferred term of launch k-1
                 V2<T> d = dO[i]; T da = dA[i];
                 if (K.deltaMode == 1) { const V2<T> q = pO[i]; const T qa = pA[i]; d.x += alpha2 * q.x; d.y += alpha2 * q.y; da += alpha2 * qa; }   // p_{k-2}, about to be overwritten
-                st2<kNTS>(dO, i, d.x + alpha * oB.q.ox, d.y + alpha * oB.q.oy); st1<kNTS>(dA, i, da + alpha * oB.q.a);
+                d.x += alpha * oB.q.ox; d.y += alpha * oB.q.oy; da += alpha * oB.q.a;
+                st2<kNTS>(dOut, i, d.x, d.y); st1<kNTS>(dAout, i, da);
+                if (LM) {   // Q = 1/2 sum delta . (r + b) with the updated delta and r (solver.t:483-485)
+                    const V2<T> bo = ((const V2<T>*)K.b)[i]; const T ba = K.b[2 * N + i];
+                    accQ += (double)(T(0.5) * (d.x * (rx + bo.x))) + (double)(T(0.5) * (d.y * (ry + bo.y))) + (double)(T(0.5) * (da * (ra + ba)));
+                }
             }
             st2<kNTS>(rO, i, rx, ry); st1<kNTS>(rA, i, ra); st2<kNTS>(pO, i, nC.q.ox, nC.q.oy); st1<kNTS>(pA, i, nC.q.a);
             accNum += (double)(nC.zx * rx + nC.zy * ry + nC.za * ra);
@@ -739,6 +761,7 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
         dppShiftVec<true>(nB.q, l2); dppShiftVec<false>(nB.q, r2);
         T ox, oy, oa;
         applyA(nB.q, l2, r2, nA.q, nC.q, ox, oy, oa);                                   // Step1 of iteration k
+        if (LM) { ox += nB.cx * nB.q.ox; oy += nB.cy * nB.q.oy; oa += nB.ca * nB.q.a; }
         if (live && writer && y >= yb) {
             accDen += (double)(nB.q.ox * ox + nB.q.oy * oy + nB.q.a * oa);
             acc2 += (double)(nB.zx * ox + nB.zy * oy + nB.za * oa);
@@ -747,22 +770,23 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
     };
     OldRow<T> o0, o1, o2;
     NewRow<T> n0{}, n1{}, n2{};
-    makeOld(iw_iterLoad<T, LATTICE, PRE, kSinCosInline>(A, K, N, xok, x, yb - 2), o0);
-    makeOld(iw_iterLoad<T, LATTICE, PRE, kSinCosInline>(A, K, N, xok, x, yb - 1), o1);
+    makeOld(iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM>(A, K, N, xok, x, yb - 2), o0);
+    makeOld(iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM>(A, K, N, xok, x, yb - 1), o1);
     // trips y = yb-2 .. ye-1 (the first two only build p_k(yb-1), p_k(yb)); three per pass, no branch around a load
-    IterRaw<T> rwA = iw_iterLoad<T, LATTICE, PRE, kSinCosInline>(A, K, N, xok, x, yb), rwB = iw_iterLoad<T, LATTICE, PRE, kSinCosInline>(A, K, N, xok, x, yb + 1),
-               rwC = iw_iterLoad<T, LATTICE, PRE, kSinCosInline>(A, K, N, xok, x, yb + 2);
+    IterRaw<T> rwA = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM>(A, K, N, xok, x, yb), rwB = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM>(A, K, N, xok, x, yb + 1),
+               rwC = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM>(A, K, N, xok, x, yb + 2);
     for (int y = yb - 2; y < ye; y += 3) {
         if (IW_ROW_SYNC) __syncthreads();
-        { const IterRaw<T> w = rwA; rwA = iw_iterLoad<T, LATTICE, PRE, kSinCosInline>(A, K, N, xok, x, y + 5); trip(y, w, o0, o1, o2, n0, n1, n2, true); }
-        { const IterRaw<T> w = rwB; rwB = iw_iterLoad<T, LATTICE, PRE, kSinCosInline>(A, K, N, xok, x, y + 6); trip(y + 1, w, o1, o2, o0, n1, n2, n0, y + 1 < ye); }
-        { const IterRaw<T> w = rwC; rwC = iw_iterLoad<T, LATTICE, PRE, kSinCosInline>(A, K, N, xok, x, y + 7); trip(y + 2, w, o2, o0, o1, n2, n0, n1, y + 2 < ye); }
+        { const IterRaw<T> w = rwA; rwA = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM>(A, K, N, xok, x, y + 5); trip(y, w, o0, o1, o2, n0, n1, n2, true); }
+        { const IterRaw<T> w = rwB; rwB = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM>(A, K, N, xok, x, y + 6); trip(y + 1, w, o1, o2, o0, n1, n2, n0, y + 1 < ye); }
+        { const IterRaw<T> w = rwC; rwC = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM>(A, K, N, xok, x, y + 7); trip(y + 2, w, o2, o0, o1, n2, n0, n1, y + 2 < ye); }
     }
     double t;
     t = blockReduceSum(accDen, scratch); if (threadIdx.x == 0) K.aDen[blockIdx.x] = t;
     t = blockReduceSum(accNum, scratch); if (threadIdx.x == 0) K.aNum[blockIdx.x] = t;
     t = blockReduceSum(acc2, scratch); if (threadIdx.x == 0) K.s2[blockIdx.x] = t;
     t = blockReduceSum(acc3, scratch); if (threadIdx.x == 0) K.s3[blockIdx.x] = t;
+    if (LM) { t = blockReduceSum(accQ, scratch); if (threadIdx.x == 0) K.q[blockIdx.x] = t; }
 }
 
 // delta += alpha[0] * p over n scalars (the deferred term left over when the PCG loop ends on an odd launch)
@@ -951,7 +975,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         launchApply(pOld, out, CtC, dot, ctx, &F);
         return true;
     }
-    int occIter[13] = {0};
+    int occIter[15] = {0};
     int iterFlip = 0; bool alternateSweep = true, recomputeAp = true;
     template <bool LAT, int PRE> static const void* iterFn(bool noAp, bool flip) {
         return !noAp ? (const void*)iw_pcgIter<T, LAT, PRE> : flip ? (const void*)iw_pcgIter2<T, LAT, PRE, true> : (const void*)iw_pcgIter2<T, LAT, PRE, false>;
@@ -961,16 +985,22 @@ struct ImageWarpingOps : EnergyOps<T> {
         return lat ? (pre == 2 ? iterFn<true, 2>(noAp, flip) : pre == 1 ? iterFn<true, 1>(noAp, flip) : iterFn<true, 0>(noAp, flip))
                    : (pre == 2 ? iterFn<false, 2>(noAp, flip) : pre == 1 ? iterFn<false, 1>(noAp, flip) : iterFn<false, 0>(noAp, flip));
     }
+    static const void* lmKernel(bool lat, bool flip) {
+        return lat ? (flip ? (const void*)iw_pcgIter2<T, true, 1, true, true> : (const void*)iw_pcgIter2<T, true, 1, false, true>)
+                   : (flip ? (const void*)iw_pcgIter2<T, false, 1, true, true> : (const void*)iw_pcgIter2<T, false, 1, false, true>);
+    }
     bool flagPreconditioner = true, pairDelta = true;
     int iterIndex = 0; bool deferredTerm = false; T* alphaSlots = nullptr;
     T* mc = nullptr; int* dNotLattice = nullptr; bool lattice = false, useLattice = true, useCompactM = true;
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
         const bool noAp = recomputeAp && (!this->slab.active || this->slab.ghost >= 2);      // iw_pcgIter2: Ap recomputed instead of stored
+        const bool lmLoop = a.CtC != nullptr;
+        if (lmLoop && (!noAp || !a.pre || this->slab.active)) return false;      // LM: only the A p-free kernel has the variant (single GPU)
         this->iterStateExchange = noAp;     // slab mode: r and p ghost rows come from the neighbours after each launch (iw_pcgIter: Ap before it)
-        const int pre = !a.pre ? 0 : (noAp && lattice && flagPreconditioner) ? 3 : useCompactM ? 2 : 1;
-        const int L = pre == 3 ? 12 : (noAp ? 6 : 0) + (lattice ? 3 : 0) + pre;
+        const int pre = !a.pre ? 0 : lmLoop ? 1 : (noAp && lattice && flagPreconditioner) ? 3 : useCompactM ? 2 : 1;
+        const int L = lmLoop ? (lattice ? 14 : 13) : pre == 3 ? 12 : (noAp ? 6 : 0) + (lattice ? 3 : 0) + pre;
         if (a.first) iterFlip = 0;      // every linear solve starts top-down, so a solve is reproducible whatever ran before it
-        const void* fn = iterKernel(lattice, pre, noAp, iterFlip != 0);
+        const void* fn = lmLoop ? lmKernel(lattice, iterFlip != 0) : iterKernel(lattice, pre, noAp, iterFlip != 0);
         if (occIter[L] == 0) {
             HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occIter[L], fn, noAp ? kIterBlock2 : kIterBlock, 0));
             occIter[L] = std::max(1, std::min(occIter[L], 8));
@@ -987,7 +1017,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_ITER_ROWS")) rowsPerGroup = std::max(atoi(e), divUp(rows, kMaxPartials / gx));   // experiment: more, shorter groups
         gy = divUp(rows, rowsPerGroup);
         if (a.first) iterIndex = 0;
-        const bool paired = noAp && pairDelta;
+        const bool paired = noAp && pairDelta && !lmLoop;      // LM needs the current delta every iteration for Q
         int deltaMode = 0; const T* alphaIn = nullptr; T* alphaOut = nullptr;
         if (paired) {
             if (!alphaSlots) HIP_CHECK(hipMalloc((void**)&alphaSlots, 2 * sizeof(T)));
@@ -996,6 +1026,8 @@ struct ImageWarpingOps : EnergyOps<T> {
         }
         deferredTerm = paired && iterIndex >= 1 && iterIndex % 2 == 1;            // after an odd launch alpha_{k-1} p_{k-1} is still owed (pcgFinish)
         IterK<T> K{a.rOld, a.ApOld, a.pOld, a.rNew, a.ApNew, a.pNew, a.delta, a.pre, a.first, pre == 2 ? mc : nullptr, iterFlip, deltaMode, alphaIn, alphaOut,
+                   a.CtC, a.b, a.q ? a.q->partials : nullptr, a.afterReset, a.betaNum.partials, a.betaNum.n, a.betaDen.partials, a.betaDen.n,
+                   a.deltaOut ? a.deltaOut : a.delta,
                    a.aNumPrev.partials, a.aDenPrev.partials, a.s2Prev.partials, a.s3Prev.partials, a.aNumPrev.n, a.aDenPrev.n, a.s2Prev.n, a.s3Prev.n,
                    a.aNum->partials, a.aDen->partials, a.s2->partials, a.s3->partials};
         {
@@ -1007,6 +1039,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (alternateSweep) iterFlip ^= 1;
         ++iterIndex;
         a.aNum->n = a.aDen->n = a.s2->n = a.s3->n = gx * gy;
+        if (a.q) a.q->n = gx * gy;
         if (this->slab.active && !noAp) iw_zeroGhost<T><<<divUp(A.W, kBlock), kBlock, 0, ctx.stream>>>(A, a.ApNew);
         return true;
     }

@@ -288,7 +288,9 @@ struct PcgSolver : SolverBase {
     T* p2 = nullptr;                    // second search-direction buffer for the fused PCGStep3+PCGStep1 kernel
     bool fuseStep3 = true;              // OPT_AMD_FUSE=0 disables (A/B switch)
     T *r2 = nullptr, *Ap2 = nullptr;    // second r / Ap buffers for the single-kernel PCG iteration (z doubles as nothing there)
+    T* delta2 = nullptr;                // second delta buffer of the LM single-kernel loop (allocated on first use)
     bool oneKernel = true;              // OPT_AMD_ONEKERNEL=0: use the Step1(+3)/Step2 pair instead of one kernel per PCG iteration
+    bool oneKernelLM = true;            // OPT_AMD_ONEKERNEL_LM=0: the same switch for the Levenberg-Marquardt loop only
     Reduction setS[2][4];               // ping-pong {alphaNum, alphaDen, s2, s3} of the single-kernel iteration
     int storeMode = 0;                  // OPT_AMD_SC1=0..4: store flavours of PCGStep2 (see k_step2), A/B switch
     bool keepReferenceP = false;        // run the (dead) last PCGStep3 so that `p` matches the reference after a step
@@ -326,7 +328,9 @@ struct PcgSolver : SolverBase {
         p2 = allocVec();
         if (const char* e = getenv("OPT_AMD_FUSE")) fuseStep3 = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ONEKERNEL")) oneKernel = atoi(e) != 0;
-        if (!lm) { r2 = allocVec(); Ap2 = allocVec(); for (auto& st : setS) for (auto& R : st) R = allocRed(); }
+        if (const char* e = getenv("OPT_AMD_ONEKERNEL_LM")) oneKernelLM = atoi(e) != 0;
+        r2 = allocVec(); if (!lm) Ap2 = allocVec();       // LM uses the A p-free iteration kernel only: no second A p buffer
+        for (auto& st : setS) for (auto& R : st) R = allocRed();
         if (const char* e = getenv("OPT_AMD_SC1")) storeMode = atoi(e);
         redA = allocRed(); redB = allocRed(); redQ = allocRed(); redC = allocRed();
         HIP_CHECK(hipMalloc((void**)&scal, 8 * sizeof(double))); HIP_CHECK(hipMemset(scal, 0, 8 * sizeof(double))); allocs.push_back(scal);
@@ -485,6 +489,72 @@ struct PcgSolver : SolverBase {
         { ScopedKernel k(ctx, "PCGStep2_delta"); k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, p, nPacks, scal + 2, prev[1].partials, prev[1].n); }
         return true;
     }
+    // ---- the same for Levenberg-Marquardt (energy.h PcgIterArgs, LM fields).  Launch k applies Step2 and Step3 of iteration k-1 and
+    // delivers Q_{k-1}, so the q early-out of iteration k-1 (solver.t:1093-1102) is decided after launch k -- by which time the
+    // state is exactly the reference's at its break (Step3 runs before fetchQ there too).  Every residual_reset_period-th iteration
+    // ends with the reference's split Step2 (delta, A delta, r = b - A delta; :1077-1083) on the generic kernels; the next launch then
+    // restarts from that r with beta given directly.  Returns false (nothing touched) if the energy has no such kernel.
+    bool runSingleKernelLoopLM(const T* preArg, T Q0, T q_tolerance) {
+        if (distributed || traceEnabled || keepReferenceP || !preArg) return false;
+        if (!delta2) delta2 = allocVec();                       // zero-filled like delta; every launch that updates delta rewrites all of it
+        Reduction prev[4] = {redC, Reduction{}, Reduction{}, Reduction{}};
+        int cur = 0;
+        bool afterReset = false, deltaOwed = false, issued = false, issuedRestart = false;
+        Reduction bNumDirect{}, bDenDirect{};
+        // One launch from the current state into the alternate buffers (r2, p2, delta2, setS[cur]); adopted later by pointer swaps.
+        auto issue = [&](int k, bool restart) -> bool {
+            PcgIterArgs<T> a{};
+            a.rOld = r; a.ApOld = Ap_X; a.pOld = p; a.rNew = r2; a.ApNew = Ap_X; a.pNew = p2; a.delta = delta; a.deltaOut = delta2; a.pre = preArg; a.first = k == 0;
+            a.aNumPrev = prev[0]; a.aDenPrev = prev[1]; a.s2Prev = prev[2]; a.s3Prev = prev[3];
+            a.aNum = &setS[cur][0]; a.aDen = &setS[cur][1]; a.s2 = &setS[cur][2]; a.s3 = &setS[cur][3];
+            a.CtC = CtC; a.b = b; a.q = &redQ; a.afterReset = restart ? 1 : 0; a.betaNum = bNumDirect; a.betaDen = bDenDirect;
+            issuedRestart = restart;
+            return E->pcgIteration(a, ctx);
+        };
+        for (int lIter = 0; lIter < sp.lIterations; ++lIter) {
+            if (!issued && !issue(lIter, afterReset)) { if (lIter == 0) return false; fprintf(stderr, "pcgIteration refused mid-loop\n"); exit(1); }
+            issued = false;
+            // adopt launch lIter
+            const bool appliedStep2 = lIter > 0 && !issuedRestart;    // it finished iteration lIter-1 (delta, r, z, p) and summed Q_{lIter-1}
+            std::swap(r, r2); std::swap(p, p2);
+            if (appliedStep2) std::swap(delta, delta2);
+            for (int i = 0; i < 4; ++i) prev[i] = setS[cur][i];
+            cur ^= 1;
+            afterReset = false;
+            const bool resetNow = ((lIter + 1) % sp.residual_reset_period) == 0;
+            if (appliedStep2) {
+                beginHostSum(redQ);
+                // The next launch is enqueued before Q is known: it writes only the alternate buffers, so if the test below ends the
+                // linear solve its results are simply never adopted (the fetchQ of solver.t:1098 no longer idles the GPU).
+                if (lIter + 1 < sp.lIterations && !resetNow) { if (!issue(lIter + 1, false)) { fprintf(stderr, "pcgIteration refused mid-loop\n"); exit(1); } issued = true; }
+                const T Q1 = (T)endHostSum();
+                const T zeta = T(lIter) * (Q1 - Q0) / Q1;
+                if (zeta < q_tolerance) { if (verbosity > 0) printf("zeta=%.18g, breaking at iteration: %d\n", (double)zeta, lIter); return true; }
+                Q0 = Q1;
+            }
+            deltaOwed = true;                                          // iteration lIter: Step1 done, its Step2 still to come
+            if (resetNow) {                                            // solver.t:1077-1083
+                finalizeLocal(prev[0], scal + 2);
+                { ScopedKernel k(ctx, "PCGStep2_1stHalf"); k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, p, nPacks, scal + 2, prev[1].partials, prev[1].n); }
+                E->applyJTJ(delta, Adelta, CtC, nullptr, ctx);             // computeAdelta
+                { ScopedKernel k(ctx, "PCGStep2_2ndHalf");
+                  k_step2SecondHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, r, Adelta, b, preArg, z, nPacks, redB.partials, redQ.partials); }
+                redB.n = streamGrid; redQ.n = streamGrid;
+                deltaOwed = false;
+                const T Q1 = (T)hostSum(redQ);
+                const T zeta = T(lIter + 1) * (Q1 - Q0) / Q1;
+                if (zeta < q_tolerance) { if (verbosity > 0) printf("zeta=%.18g, breaking at iteration: %d\n", (double)zeta, lIter + 1); return true; }
+                Q0 = Q1;
+                afterReset = true; bNumDirect = redB; bDenDirect = prev[0];
+            }
+        }
+        if (deltaOwed) {   // the last iteration's delta += alpha p; its r, z, p and Q are dead (the reference's last fetchQ can only break a finished loop)
+            finalizeLocal(prev[0], scal + 2);
+            ScopedKernel k(ctx, "PCGStep2_delta");
+            k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, p, nPacks, scal + 2, prev[1].partials, prev[1].n);
+        }
+        return true;
+    }
     double hostSumLocal(const Reduction& R) {   // host value of an (already all-reduced, if distributed) reduction
         HIP_CHECK(hipMemcpyAsync(hostBuf, R.partials, R.n * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
@@ -552,7 +622,7 @@ struct PcgSolver : SolverBase {
         // feeds the next Step1; after the last iteration p is dead).
         bool pendingStep3 = false;
         Reduction bNum;
-        const bool single = !lm && oneKernel && r2 && runSingleKernelLoop(preArg);
+        const bool single = oneKernel && r2 && (lm ? (oneKernelLM && runSingleKernelLoopLM(preArg, Q0, q_tolerance)) : runSingleKernelLoop(preArg));
         // Step3 of the previous iteration (when pending) and Step1 of the next one.  None of it touches what survives a q early-out
         // (delta, and p only through the very Step3 the reference also runs before its q test), so in LM it is enqueued BEFORE the
         // host reads q of the current iteration: the blocking fetchQ of solver.t:1098 then overlaps with useful kernels instead of
