@@ -255,3 +255,24 @@ def test_real_cat_mask(oracle_lib, double):
         assert abs(g.cost() - o.cost()) <= 1e-9 * abs(o.cost())
         assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < 1e-9
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("double", [False, True])
+def test_lm_single_kernel_loop_matches_three_kernel_loop(double, monkeypatch):
+    """Levenberg-Marquardt on the A p-free single-kernel iteration (Q delivered one launch late, split residual reset every 10th
+    iteration followed by a restart launch, q early-out) against the Step1 / Step2 / Step3 loop: costs, trust-region radius, unknowns."""
+    P = wl.image_warping(150, 131, double=double, random_state=23, mask_fraction=0.05, perturb=0.4)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("OPT_AMD_ONEKERNEL_LM", mode)
+        g = hip_solver(P, "LMGPU", nIterations=4, lIterations=45)
+        dev = api.to_device(P)
+        g.init(dev); costs = [g.cost()]; radii = []
+        while g.step(dev):
+            costs.append(g.cost()); radii.append(g.trust_region_radius())
+        res[mode] = (costs, radii, device_unknowns(P, dev))
+        g.close()
+    assert len(res["1"][0]) == len(res["0"][0])
+    np.testing.assert_allclose(res["1"][0], res["0"][0], rtol=1e-9 if double else 1e-5)
+    np.testing.assert_allclose(res["1"][1], res["0"][1], rtol=1e-7 if double else 1e-3)
+    assert rel_err(res["1"][2], res["0"][2]) < (1e-8 if double else 1e-4)
