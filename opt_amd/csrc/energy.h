@@ -51,6 +51,8 @@ struct PcgIterArgs {
     // and r; this launch then only forms p = M r + beta p with beta = sum(betaNum) / sum(betaDen) and applies J^T J.
     const T* CtC = nullptr; const T* b = nullptr; Reduction* q = nullptr;
     int afterReset = 0; Reduction betaNum, betaDen;
+    T lmRadius = 0, lmMinDiag = 0, lmMaxDiag = 0;        // the scalars of PCGFinalizeDiagonal (solver.t:631-664): an energy whose diag(J^T J) is a known
+                                                         // function of per-pixel flags can rebuild CtC and the LM preconditioner from them instead of reading both
     T* deltaOut = nullptr;                               // if set, the updated delta goes here instead of in place (lets the solver enqueue
                                                          // the next launch before it has read Q: an early-out then still finds the old delta)
 };

@@ -419,6 +419,7 @@ struct IterK {             // kernel argument block
     // Levenberg-Marquardt variant of iw_pcgIter2 (energy.h PcgIterArgs): CtC, b, the Q partial sums, and the after-reset mode
     const T* CtC; const T* b; double* q; int afterReset; const double* betaNum; int nBetaNum; const double* betaDen; int nBetaDen;
     T* deltaOut;           // where the updated delta is written (== delta: in place)
+    T lmRadius, lmMin, lmMax;   // PRE == 3 with LM: CtC and the LM preconditioner are rebuilt from the flag byte (see the kernel)
     const double *aNumPrev, *aDenPrev, *s2Prev, *s3Prev; int nNum, nDen, n2, n3;
     double *aNum, *aDen, *s2, *s3;
 };
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
     // and the neighbour count of the flag byte.  The Offset entries repeat iw_evalJTF's accumulation order, so they are the
     // values the solver's preconditioner vector holds, bit for bit; the Angle entries use |R'(a) n|^2 = 1 exactly where
     // iw_evalJTF rounds cos^2 + sin^2.
-    __shared__ T mTab[16];
+    __shared__ T mTab[16], cTab[16];
     if (PRE == 3) {
         if (threadIdx.x < 15) {
             const int t = threadIdx.x, cnt = t < 10 ? t % 5 : t - 10;
@@ -698,7 +699,12 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
             if (t < 10) { for (int n = 0; n < cnt; ++n) d += w * w + w * w; if (t >= 5) d += A.w_fit * A.w_fit; }
             else for (int n = 0; n < cnt; ++n) d += (w * T(1)) * (w * T(1));
             const T sq = T(1) + sqrt(d);
-            mTab[t] = T(1) / (sq * sq);                      // solver.hip guardedInvert (solver.t:323-332)
+            const T gi = T(1) / (sq * sq);                   // solver.hip guardedInvert (solver.t:323-332)
+            if (LM) {   // k_finalizeDiagonal (solver.t:631-664) on the table: SSq is the first outer iteration's guardedInvert(diag), and diag does not change
+                const T radius = K.lmRadius, unclamped = d * (T(1) / radius), clampMul = (T(1) / gi) / radius;
+                const T c = fmin(fmax(unclamped, K.lmMin * clampMul), K.lmMax * clampMul);
+                cTab[t] = c; mTab[t] = T(1) / (c + radius * unclamped);
+            } else mTab[t] = gi;
         }
         __syncthreads();
     }
@@ -711,10 +717,11 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
         o.q.on = (w.ok && (w.f & kActive)) ? T(1) : T(0);
         o.q.fw = (w.f & kFit) ? wf2 : T(0);
         o.rx = w.ro.x; o.ry = w.ro.y; o.ra = w.ra;
-        o.cx = w.co.x; o.cy = w.co.y; o.ca = w.ca;
+        if (!(LM && PRE == 3)) { o.cx = w.co.x; o.cy = w.co.y; o.ca = w.ca; }
         if (PRE == 3) {
-            const int cnt = (w.f >> kCountShift) & 7;
-            o.mx = o.my = mTab[cnt + ((w.f & kFit) ? 5 : 0)]; o.ma = mTab[10 + cnt];
+            const int cnt = (w.f >> kCountShift) & 7, io = cnt + ((w.f & kFit) ? 5 : 0);
+            o.mx = o.my = mTab[io]; o.ma = mTab[10 + cnt];
+            if (LM) { o.cx = o.cy = cTab[io]; o.ca = cTab[10 + cnt]; }
         } else { o.mx = w.mo.x; o.my = (PRE == 2) ? w.mo.x : w.mo.y; o.ma = (PRE == 2) ? w.mo.y : w.ma; }
     };
     // J^T J at centre c; prev / next are the rows before / after it in sweep order
@@ -770,16 +777,16 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
     };
     OldRow<T> o0, o1, o2;
     NewRow<T> n0{}, n1{}, n2{};
-    makeOld(iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM>(A, K, N, xok, x, yb - 2), o0);
-    makeOld(iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM>(A, K, N, xok, x, yb - 1), o1);
+    makeOld(iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb - 2), o0);
+    makeOld(iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb - 1), o1);
     // trips y = yb-2 .. ye-1 (the first two only build p_k(yb-1), p_k(yb)); three per pass, no branch around a load
-    IterRaw<T> rwA = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM>(A, K, N, xok, x, yb), rwB = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM>(A, K, N, xok, x, yb + 1),
-               rwC = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM>(A, K, N, xok, x, yb + 2);
+    IterRaw<T> rwA = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb), rwB = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb + 1),
+               rwC = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb + 2);
     for (int y = yb - 2; y < ye; y += 3) {
         if (IW_ROW_SYNC) __syncthreads();
-        { const IterRaw<T> w = rwA; rwA = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM>(A, K, N, xok, x, y + 5); trip(y, w, o0, o1, o2, n0, n1, n2, true); }
-        { const IterRaw<T> w = rwB; rwB = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM>(A, K, N, xok, x, y + 6); trip(y + 1, w, o1, o2, o0, n1, n2, n0, y + 1 < ye); }
-        { const IterRaw<T> w = rwC; rwC = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM>(A, K, N, xok, x, y + 7); trip(y + 2, w, o2, o0, o1, n2, n0, n1, y + 2 < ye); }
+        { const IterRaw<T> w = rwA; rwA = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, y + 5); trip(y, w, o0, o1, o2, n0, n1, n2, true); }
+        { const IterRaw<T> w = rwB; rwB = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, y + 6); trip(y + 1, w, o1, o2, o0, n1, n2, n0, y + 1 < ye); }
+        { const IterRaw<T> w = rwC; rwC = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, y + 7); trip(y + 2, w, o2, o0, o1, n2, n0, n1, y + 2 < ye); }
     }
     double t;
     t = blockReduceSum(accDen, scratch); if (threadIdx.x == 0) K.aDen[blockIdx.x] = t;
@@ -985,7 +992,8 @@ struct ImageWarpingOps : EnergyOps<T> {
         return lat ? (pre == 2 ? iterFn<true, 2>(noAp, flip) : pre == 1 ? iterFn<true, 1>(noAp, flip) : iterFn<true, 0>(noAp, flip))
                    : (pre == 2 ? iterFn<false, 2>(noAp, flip) : pre == 1 ? iterFn<false, 1>(noAp, flip) : iterFn<false, 0>(noAp, flip));
     }
-    static const void* lmKernel(bool lat, bool flip) {
+    static const void* lmKernel(bool lat, bool tables, bool flip) {
+        if (lat && tables) return flip ? (const void*)iw_pcgIter2<T, true, 3, true, true> : (const void*)iw_pcgIter2<T, true, 3, false, true>;
         return lat ? (flip ? (const void*)iw_pcgIter2<T, true, 1, true, true> : (const void*)iw_pcgIter2<T, true, 1, false, true>)
                    : (flip ? (const void*)iw_pcgIter2<T, false, 1, true, true> : (const void*)iw_pcgIter2<T, false, 1, false, true>);
     }
@@ -997,10 +1005,10 @@ struct ImageWarpingOps : EnergyOps<T> {
         const bool lmLoop = a.CtC != nullptr;
         if (lmLoop && (!noAp || !a.pre || this->slab.active)) return false;      // LM: only the A p-free kernel has the variant (single GPU)
         this->iterStateExchange = noAp;     // slab mode: r and p ghost rows come from the neighbours after each launch (iw_pcgIter: Ap before it)
-        const int pre = !a.pre ? 0 : lmLoop ? 1 : (noAp && lattice && flagPreconditioner) ? 3 : useCompactM ? 2 : 1;
+        const int pre = !a.pre ? 0 : (noAp && lattice && flagPreconditioner) ? 3 : lmLoop ? 1 : useCompactM ? 2 : 1;
         const int L = lmLoop ? (lattice ? 14 : 13) : pre == 3 ? 12 : (noAp ? 6 : 0) + (lattice ? 3 : 0) + pre;
         if (a.first) iterFlip = 0;      // every linear solve starts top-down, so a solve is reproducible whatever ran before it
-        const void* fn = lmLoop ? lmKernel(lattice, iterFlip != 0) : iterKernel(lattice, pre, noAp, iterFlip != 0);
+        const void* fn = lmLoop ? lmKernel(lattice, pre == 3, iterFlip != 0) : iterKernel(lattice, pre, noAp, iterFlip != 0);
         if (occIter[L] == 0) {
             HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occIter[L], fn, noAp ? kIterBlock2 : kIterBlock, 0));
             occIter[L] = std::max(1, std::min(occIter[L], 8));
@@ -1027,7 +1035,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         deferredTerm = paired && iterIndex >= 1 && iterIndex % 2 == 1;            // after an odd launch alpha_{k-1} p_{k-1} is still owed (pcgFinish)
         IterK<T> K{a.rOld, a.ApOld, a.pOld, a.rNew, a.ApNew, a.pNew, a.delta, a.pre, a.first, pre == 2 ? mc : nullptr, iterFlip, deltaMode, alphaIn, alphaOut,
                    a.CtC, a.b, a.q ? a.q->partials : nullptr, a.afterReset, a.betaNum.partials, a.betaNum.n, a.betaDen.partials, a.betaDen.n,
-                   a.deltaOut ? a.deltaOut : a.delta,
+                   a.deltaOut ? a.deltaOut : a.delta, a.lmRadius, a.lmMinDiag, a.lmMaxDiag,
                    a.aNumPrev.partials, a.aDenPrev.partials, a.s2Prev.partials, a.s3Prev.partials, a.aNumPrev.n, a.aDenPrev.n, a.s2Prev.n, a.s3Prev.n,
                    a.aNum->partials, a.aDen->partials, a.s2->partials, a.s3->partials};
         {
