@@ -393,7 +393,7 @@ __global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __re
 // ---- one whole PCG iteration per launch (energy.h PcgIterArgs) --------------------------------------------------
 // Same marching / DPP / prefetch structure as iw_applyJTJ; per pixel it additionally applies the previous
 // iteration's PCGStep2 and PCGStep3 before the stencil, so the PCG loop is ONE kernel per iteration moving
-// r 12 + Ap 12 + p 12 + delta 12 + pre 12 + (cos,sin) 8 + U 8 + flags 1 in and r, p, delta, Ap 48 out = 125 B/pixel
+// r 12 + Ap 12 + p 12 + delta 12 + pre 12 (8 compact) + (cos,sin) 8 + U 8 (0 on a lattice) + flags 1 in and r, p, delta, Ap 48 out = 113-125 B/pixel
 // (three reference kernels: 180 B/pixel algorithmic).
 template <class T>
 struct IterRaw {           // one pixel's loads, untouched (any ALU op here would force a wait before the loop back-edge)
@@ -1022,7 +1022,6 @@ struct ImageWarpingOps : EnergyOps<T> {
         const int rows = A.yEnd - A.yBegin;
         int gy = std::max(1, std::min(std::min(rows, cus * occIter[L] / gx), kMaxPartials / gx));
         int rowsPerGroup = divUp(rows, gy);
-        if (const char* e = getenv("OPT_AMD_ITER_ROWS")) rowsPerGroup = std::max(atoi(e), divUp(rows, kMaxPartials / gx));   // experiment: more, shorter groups
         gy = divUp(rows, rowsPerGroup);
         if (a.first) iterIndex = 0;
         const bool paired = noAp && pairDelta && !lmLoop;      // LM needs the current delta every iteration for Q
