@@ -204,6 +204,110 @@ __global__ __launch_bounds__(kBlock) void sfs_gather(SArgs<T> A, const T* __rest
     }
 }
 
+// J^T J v in one launch through LDS: a workgroup owns a 32 x 8 tile of pixels, stages v and the gradient / mask images of the tile
+// plus a 2-pixel apron once, forms the five row values (J v)_r of every row centre in the tile + 1-pixel ring in LDS (what sfs_rows<3>
+// writes to the q planes), and gathers from there (what sfs_gather<false> reads back).  Same expressions in the same order as the
+// two passes; HBM traffic ~90 B/px instead of ~290 B/px, one launch instead of two.
+#ifndef SFS_TW
+#define SFS_TW 32
+#define SFS_TH 8
+#endif
+constexpr int kSfsTW = SFS_TW, kSfsTH = SFS_TH;
+template <class T, bool LM>
+__global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ CtC, double* __restrict__ partials) {
+    constexpr int TW = kSfsTW, TH = kSfsTH, VW = TW + 4, VH = TH + 4, QW = TW + 2, QH = TH + 2;
+    static_assert(TW * TH == kBlock, "one thread per tile pixel");
+    __shared__ double scratch[kBlock / kWave + 1];
+    __shared__ T sv[VH][VW], s0[VH][VW], s1[VH][VW], s2[VH][VW];      // v, g0, g1, g2 on the tile + 2 apron (index [y+2][x+2])
+    __shared__ T sq[5][QH][QW];                                       // gh, gv, s0..s2 row values on the tile + 1 ring (index [y+1][x+1])
+    __shared__ uint8_t smr[QH][QW], smc[QH][QW], sok[QH][QW], svalid[QH][QW];
+    const int tilesX = (A.W + TW - 1) / TW, tilesY = (A.H + TH - 1) / TH;
+    double acc = 0;
+    for (int t = blockIdx.x; t < tilesX * tilesY; t += gridDim.x) {
+        const int x0 = (t % tilesX) * TW, y0 = (t / tilesX) * TH;
+        __syncthreads();                                              // previous tile's readers are done
+        for (int i = threadIdx.x; i < VW * VH; i += kBlock) {
+            const int lx = i % VW, ly = i / VW, gx = x0 + lx - 2, gy = y0 + ly - 2;
+            const bool in = gx >= 0 && gx < A.W && gy >= 0 && gy < A.H;
+            const long g = in ? (long)gy * A.W + gx : 0;
+            sv[ly][lx] = in ? v[g] : T(0); s0[ly][lx] = in ? A.g0[g] : T(0); s1[ly][lx] = in ? A.g1[g] : T(0); s2[ly][lx] = in ? A.g2[g] : T(0);
+        }
+        for (int i = threadIdx.x; i < QW * QH; i += kBlock) {
+            const int lx = i % QW, ly = i / QW, gx = x0 + lx - 1, gy = y0 + ly - 1;
+            const bool ok = sfs_interior(A, gx, gy);
+            const long g = ok ? (long)gy * A.W + gx : 0;
+            sok[ly][lx] = ok; smr[ly][lx] = ok ? A.mR[g] : 0; smc[ly][lx] = ok ? A.mC[g] : 0; svalid[ly][lx] = ok && A.valid[g] == T(1);
+        }
+        __syncthreads();
+        // row values at every centre of the tile + ring (sfs_rows<3>): centre (qx, qy) in q coordinates = (qx + 1, qy + 1) in v coordinates
+        for (int i = threadIdx.x; i < QW * QH; i += kBlock) {
+            const int qx = i % QW, qy = i / QW, vx = qx + 1, vy = qy + 1, gx = x0 + qx - 1, gy = y0 + qy - 1;
+            T jgh = 0, jgv = 0, js[3] = {0, 0, 0};
+            if (sok[qy][qx]) {
+                const T mr = (T)smr[qy][qx], mc = (T)smc[qy][qx];
+                const T base = s1[vy][vx] * sv[vy][vx] + s0[vy][vx] * sv[vy][vx - 1] + s2[vy][vx] * sv[vy - 1][vx];
+                const T right = s1[vy][vx + 1] * sv[vy][vx + 1] + s0[vy][vx + 1] * sv[vy][vx] + s2[vy][vx + 1] * sv[vy - 1][vx + 1];
+                const T down = s1[vy + 1][vx] * sv[vy + 1][vx] + s0[vy + 1][vx] * sv[vy + 1][vx - 1] + s2[vy + 1][vx] * sv[vy][vx];
+                jgh = A.w_g * mr * (base - right); jgv = A.w_g * mc * (base - down);
+                if (svalid[qy][qx]) {
+                    const int ox[5] = {0, -1, 0, 1, 0}, oy[5] = {0, 0, -1, 0, 1};
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        T sj = 0;
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) sj += ((u == 0 ? T(4) : T(-1)) * coefK(A, k, gx + ox[u], gy + oy[u])) * sv[vy + oy[u]][vx + ox[u]];
+                        js[k] = A.w_s * sj;
+                    }
+                }
+            }
+            sq[0][qy][qx] = jgh; sq[1][qy][qx] = jgv; sq[2][qy][qx] = js[0]; sq[3][qy][qx] = js[1]; sq[4][qy][qx] = js[2];
+        }
+        __syncthreads();
+        // gather (sfs_gather<false>): this thread's pixel is (tx, ty) in the tile = (tx + 1, ty + 1) in q coordinates
+        const int tx = threadIdx.x % TW, ty = threadIdx.x / TW, x = x0 + tx, y = y0 + ty;
+        if (x < A.W && y < A.H) {
+            const long e = (long)y * A.W + x;
+            const T ve = sv[ty + 2][tx + 2];
+            T s = 0;
+            if (A.D_i[e] > T(0)) {
+                auto add = [&](T coef, T q) { s += coef * q; };
+                add(A.w_p, A.w_p * ve);
+                // (dx, dy): the row centre relative to this pixel; g arrays are read at the centre c and at c + 1 (gh) / c + W (gv)
+                auto gh = [&](int dx, int dy, int slot) {
+                    const int qx = tx + 1 + dx, qy = ty + 1 + dy, vx = qx + 1, vy = qy + 1;
+                    const T m = A.w_g * (T)smr[qy][qx];
+                    T coef = slot == 0 ? m * (s1[vy][vx] - s0[vy][vx + 1]) : slot == 1 ? m * s0[vy][vx] : slot == 2 ? m * s2[vy][vx] : slot == 3 ? -(m * s1[vy][vx + 1]) : -(m * s2[vy][vx + 1]);
+                    coef = sok[qy][qx] ? coef : T(0);
+                    add(coef, sq[0][qy][qx]);
+                };
+                auto gv = [&](int dx, int dy, int slot) {
+                    const int qx = tx + 1 + dx, qy = ty + 1 + dy, vx = qx + 1, vy = qy + 1;
+                    const T m = A.w_g * (T)smc[qy][qx];
+                    T coef = slot == 0 ? m * (s1[vy][vx] - s2[vy + 1][vx]) : slot == 1 ? m * s0[vy][vx] : slot == 2 ? m * s2[vy][vx] : slot == 3 ? -(m * s1[vy + 1][vx]) : -(m * s0[vy + 1][vx]);
+                    coef = sok[qy][qx] ? coef : T(0);
+                    add(coef, sq[1][qy][qx]);
+                };
+                gh(0, 0, 0); gh(1, 0, 1); gh(0, 1, 2); gh(-1, 0, 3); gh(-1, 1, 4);
+                gv(0, 0, 0); gv(1, 0, 1); gv(0, 1, 2); gv(0, -1, 3); gv(1, -1, 4);
+                const int ox[5] = {0, 1, -1, 0, 0}, oy[5] = {0, 0, 0, 1, -1};
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const int qx = tx + 1 + ox[u], qy = ty + 1 + oy[u];
+                    const T wgt = svalid[qy][qx] ? A.w_s * (u == 0 ? T(4) : T(-1)) : T(0);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) add(wgt * coefK(A, k, x, y), sq[2 + k][qy][qx]);
+                }
+            }
+            if (LM) s += CtC[e] * ve;
+            if (!(A.D_i[e] > T(0))) s = 0;
+            out[e] = s;
+            acc += (double)(ve * s);
+        }
+    }
+    double t = blockReduceSum(acc, scratch);
+    if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
+}
+
 template <class T>
 struct SfsOps : EnergyOps<T> {
     SArgs<T> A{};
@@ -218,6 +322,7 @@ struct SfsOps : EnergyOps<T> {
         for (auto pp : imgs) { HIP_CHECK(hipMalloc((void**)pp, n * sizeof(T))); HIP_CHECK(hipMemset(*pp, 0, n * sizeof(T))); owned.push_back(*pp); }
         HIP_CHECK(hipMalloc((void**)&A.q, 5 * n * sizeof(T))); owned.push_back(A.q);
         int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (const char* e = getenv("OPT_AMD_SFS_TILED")) tiledApply = atoi(e) != 0;
     }
     ~SfsOps() override { for (void* p : owned) (void)hipFree(p); }
     int grid() const { return (int)std::max<long>(1, std::min<long>(((long)A.W * A.H + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
@@ -235,7 +340,17 @@ struct SfsOps : EnergyOps<T> {
         { ScopedKernel k(ctx, "PCGInit1_rows"); sfs_rows<T, 2><<<grid(), kBlock, 0, ctx.stream>>>(A, nullptr, nullptr); }
         { ScopedKernel k(ctx, "PCGInit1"); sfs_gather<T, true, false><<<grid(), kBlock, 0, ctx.stream>>>(A, nullptr, r, diag, nullptr, nullptr); }
     }
+    bool tiledApply = true;     // OPT_AMD_SFS_TILED=0: rows pass + gather pass through the q planes
+    int tileGrid() const { const long t = (long)((A.W + kSfsTW - 1) / kSfsTW) * ((A.H + kSfsTH - 1) / kSfsTH); return (int)std::max<long>(1, std::min<long>(t, std::min<long>(kMaxPartials / 2, (long)cus * 8))); }
     void applyJTJ(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) override {
+        if (tiledApply) {
+            ScopedKernel k(ctx, "PCGStep1");
+            const int g = tileGrid();
+            if (CtC) sfs_applyTiled<T, true><<<g, kBlock, 0, ctx.stream>>>(A, v, out, CtC, dot ? dot->partials : nullptr);
+            else sfs_applyTiled<T, false><<<g, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, dot ? dot->partials : nullptr);
+            if (dot) dot->n = g;
+            return;
+        }
         { ScopedKernel k(ctx, "PCGStep1_rows"); sfs_rows<T, 3><<<grid(), kBlock, 0, ctx.stream>>>(A, v, nullptr); }
         { ScopedKernel k(ctx, "PCGStep1");
           if (CtC) sfs_gather<T, false, true><<<grid(), kBlock, 0, ctx.stream>>>(A, v, out, nullptr, CtC, dot ? dot->partials : nullptr);
