@@ -352,6 +352,63 @@ __global__ __launch_bounds__(kBlock) void arap_vertexGather(ArapArgs<T> A, Graph
     if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
 }
 
+// ---- the same for J^T F and diag(J^T J) (once per Gauss-Newton iteration) ---------------------------------------------------------
+// Edge pass: rotation-derivative columns into the D planes (as arap_edges<2>) and one 9-scalar record per half-edge,
+// {w res, w D_k . res, w^2 D_k . D_k}; vertex pass: adds the records of the vertex's out- and in-lists to what arap_vertices<2> wrote.
+// With it the whole ARAP path is free of atomics: the same inputs give the same bits.
+template <class T>
+__global__ __launch_bounds__(kBlock) void arap_edgeJTF(ArapArgs<T> A, T* __restrict__ rec) {
+    const long nE = A.nE;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < nE; e += (long)gridDim.x * blockDim.x) {
+        const long a0 = A.v0[e], a1 = A.v1[e];
+        const V3<T> O0 = ld3(A.Offset, a0), O1 = ld3(A.Offset, a1), ang = ld3(A.Angle, a0), U0 = ld3(A.UrShape, a0), U1 = ld3(A.UrShape, a1);
+        const V3<T> u{U0.x - U1.x, U0.y - U1.y, U0.z - U1.z};
+        V3<T> Ru{0, 0, 0}, D0, D1, D2;
+        arap_rot(ang, u, Ru, D0, D1, D2);
+        A.D[e] = D0.x; A.D[nE + e] = D0.y; A.D[2 * nE + e] = D0.z; A.D[3 * nE + e] = D1.x; A.D[4 * nE + e] = D1.y; A.D[5 * nE + e] = D1.z;
+        A.D[6 * nE + e] = D2.x; A.D[7 * nE + e] = D2.y; A.D[8 * nE + e] = D2.z;
+        const T w = A.w_reg, w2 = w * w;
+        const V3<T> res{w * ((O0.x - O1.x) - Ru.x), w * ((O0.y - O1.y) - Ru.y), w * ((O0.z - O1.z) - Ru.z)};
+        T* o = rec + 9 * e;
+        o[0] = w * res.x; o[1] = w * res.y; o[2] = w * res.z;
+        o[3] = w * dot3(D0, res); o[4] = w * dot3(D1, res); o[5] = w * dot3(D2, res);
+        o[6] = w2 * dot3(D0, D0); o[7] = w2 * dot3(D1, D1); o[8] = w2 * dot3(D2, D2);
+    }
+}
+template <class T>
+__global__ __launch_bounds__(kBlock) void arap_vertexGatherJTF(ArapArgs<T> A, GraphCsr G, const T* __restrict__ rec, T* __restrict__ r, T* __restrict__ diag) {
+    const long offA = 3 * A.N;
+    const int slot = threadIdx.x % kLanesPerVertex;
+    const long nGroups = (A.N + (kBlock / kLanesPerVertex) - 1) / (kBlock / kLanesPerVertex);
+    for (long g = blockIdx.x; g < nGroups; g += gridDim.x) {
+        const long i = g * (kBlock / kLanesPerVertex) + threadIdx.x / kLanesPerVertex;
+        const bool ok = i < A.N;
+        const long iv = ok ? i : 0;
+        T s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const int bo = G.outOff[iv], eo = ok ? G.outOff[iv + 1] : bo, bi = G.inOff[iv], ei = ok ? G.inOff[iv + 1] : bi;
+        for (int k = 0; k < max(eo - bo, ei - bi); k += kLanesPerVertex) {
+            const int ko = bo + slot + k, ki = bi + slot + k;
+            const int eOut = ko < eo ? G.outIdx[ko] : -1, eIn = ki < ei ? G.inIdx[ki] : -1;
+            const T* o = rec + 9 * (long)max(eOut, 0); const T* q = rec + 9 * (long)max(eIn, 0);
+            const T mo = eOut >= 0 ? T(1) : T(0), mi = eIn >= 0 ? T(1) : T(0);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { s[c] += mi * q[c] - mo * o[c]; s[3 + c] += mo * o[3 + c]; s[6 + c] += mo * o[6 + c]; }   // r -= J^T F: head -w res, tail +w res
+        }
+#pragma unroll
+        for (int m = 1; m < kLanesPerVertex; m <<= 1)
+#pragma unroll
+            for (int c = 0; c < 9; ++c) s[c] += __shfl_xor(s[c], m, kWave);
+        if (ok && slot == 0) {
+            const T w2 = A.w_reg * A.w_reg, deg = (T)((eo - bo) + (ei - bi));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                r[3 * i + c] += s[c]; r[offA + 3 * i + c] += s[3 + c];
+                diag[3 * i + c] += w2 * deg; diag[offA + 3 * i + c] += s[6 + c];
+            }
+        }
+    }
+}
+
 template <class T>
 struct ArapOps : EnergyOps<T> {
     ArapArgs<T> A{};
@@ -379,7 +436,7 @@ struct ArapOps : EnergyOps<T> {
         const size_t nv = (size_t)A.N + 1;
         HIP_CHECK(hipMalloc((void**)&outOff, nv * 4)); HIP_CHECK(hipMalloc((void**)&inOff, nv * 4)); HIP_CHECK(hipMalloc((void**)&cursors, 2 * nv * 4));
         HIP_CHECK(hipMalloc((void**)&outIdx, (size_t)std::max(1, A.nE) * 4)); HIP_CHECK(hipMalloc((void**)&inIdx, (size_t)std::max(1, A.nE) * 4));
-        HIP_CHECK(hipMalloc((void**)&Jp, (size_t)6 * std::max(1, A.nE) * sizeof(T)));
+        HIP_CHECK(hipMalloc((void**)&Jp, (size_t)9 * std::max(1, A.nE) * sizeof(T)));       // 6-scalar records of J^T J p, 9-scalar records of J^T F
         HIP_CHECK(hipMemsetAsync(cursors, 0, 2 * nv * 4, st));
         int* outDeg = cursors; int* inDeg = cursors + nv;
         csr_count<<<ge, kBlock, 0, st>>>(A.v0, A.v1, A.nE, outDeg, inDeg);
@@ -423,7 +480,11 @@ struct ArapOps : EnergyOps<T> {
     }
     void evalJTF(T* r, T* diag, LaunchCtx& ctx) override {
         { ScopedKernel k(ctx, "PCGInit1"); arap_vertices<T, 2><<<vgrid(), kBlock, 0, ctx.stream>>>(A, nullptr, r, diag, nullptr, nullptr); }
-        { ScopedKernel k(ctx, "PCGInit1_Graph"); arap_edges<T, 2><<<edgeGrid(A.nE, cus), kBlock, 0, ctx.stream>>>(A, nullptr, r, diag, nullptr); }
+        if (useGather) {
+            GraphCsr G{outOff, outIdx, inOff, inIdx};
+            { ScopedKernel k(ctx, "PCGInit1_Graph"); arap_edgeJTF<T><<<edgeGrid(A.nE, cus), kBlock, 0, ctx.stream>>>(A, Jp); }
+            { ScopedKernel k(ctx, "PCGInit1_Gather"); arap_vertexGatherJTF<T><<<vgrid(), kBlock, 0, ctx.stream>>>(A, G, Jp, r, diag); }
+        } else { ScopedKernel k(ctx, "PCGInit1_Graph"); arap_edges<T, 2><<<edgeGrid(A.nE, cus), kBlock, 0, ctx.stream>>>(A, nullptr, r, diag, nullptr); }
     }
     void applyJTJ(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) override {
         const int gv = vgrid(), ge = edgeGrid(A.nE, cus);

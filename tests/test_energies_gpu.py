@@ -198,3 +198,20 @@ def test_poisson_single_kernel_iteration_matches_three_kernel_loop(double, monke
     assert rel_err(res["1"][1], res["0"][1]) < (1e-9 if double else 1e-5)
     # alphaNumerator / alphaDenominator / betaNumerator of the first iterations: the quirk shows up exactly there
     np.testing.assert_allclose(res["1"][2][:5, 2:5], res["0"][2][:5, 2:5], rtol=1e-9 if double else 1e-4)
+
+
+def test_arap_path_is_deterministic():
+    """The ARAP kernel set uses no atomics (edge pass -> records, vertex pass gathers sorted lists) for J^T F as well as J^T J p:
+    two solves of the same problem give the same bits (the reference's scatter kernels do not)."""
+    outs = []
+    for _ in range(2):
+        P = _raptor(False)
+        g = hip_solver(P, "gaussNewtonGPU", nIterations=3, lIterations=30)
+        dev = api.to_device(P)
+        g.init(dev)
+        while g.step(dev):
+            pass
+        outs.append((g.cost(), device_unknowns(P, dev)))
+        g.close()
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1], outs[1][1])
