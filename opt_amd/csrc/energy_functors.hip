@@ -12,7 +12,7 @@ namespace {
 // e_reg = w_reg (X(0,0) - X(n)) for the 4-neighbourhood, Select(InBounds(n), ., 0).  UsePreconditioner(false).
 template <class T>
 struct OpticalFlowE {
-    static constexpr int NDIM = 2, NIMG = 1, K = 2, R = 9, NOFF = 5;
+    static constexpr int NDIM = 2, NIMG = 1, K = 2, R = 9, NOFF = 5, NAUX = 0;
     static constexpr __host__ __device__ int off(int i, int a) { return a == 0 ? (i == 1 ? 1 : i == 2 ? -1 : 0) : a == 1 ? (i == 3 ? 1 : i == 4 ? -1 : 0) : 0; }
     static constexpr __host__ __device__ int imgOf(int) { return 0; }
     static constexpr __host__ __device__ int chOf(int k) { return k; }
@@ -22,7 +22,8 @@ struct OpticalFlowE {
     int W, H, D;
     const T* X[NIMG];
     const T *I, *Ihat, *Idx, *Idy;
-    T w_fit, w_reg;
+    T w_fit, w_reg; T* aux;
+    __device__ void computeAux(int, int, int, T*) const {}
     void bindParams(void** p) {
         w_fit = (T) * (const float*)p[0]; w_reg = (T) * (const float*)p[1];
         X[0] = (const T*)p[2]; I = (const T*)p[3]; Ihat = (const T*)p[4]; Idx = (const T*)p[5]; Idy = (const T*)p[6];
@@ -55,11 +56,12 @@ struct OpticalFlowE {
 // ------------------------------------------------------------------------------------------------------------------
 // examples/intrinsic_image_decomposition/intrinsic_image_decomposition.t:1-31.  Unknowns r (float3, log-albedo) and s (float,
 // log-shading).  Albedo smoothness is an L_p norm through lib.t:106-114: sqrt((|r_c - r_n| + 1e-7)^(p-2)) is a ComputedArray --
-// a constant of the linearisation, re-evaluated from the current r after every update (inline here: r is fixed between
-// updates) -- times (r_c - r_n); shading smoothness is plain; fit r + s - i.  No UsePreconditioner call -> false; no Exclude.
+// a constant of the linearisation, re-evaluated from the current r after every update (computeAux / the engine's precompute
+// kernel: four planes, so the PCG loop evaluates no pow) -- times (r_c - r_n); shading smoothness is plain; fit r + s - i.
+// No UsePreconditioner call -> false; no Exclude.
 template <class T>
 struct IntrinsicE {
-    static constexpr int NDIM = 2, NIMG = 2, K = 4, R = 19, NOFF = 5;
+    static constexpr int NDIM = 2, NIMG = 2, K = 4, R = 19, NOFF = 5, NAUX = 4;      // four L_p weight planes, one per stencil direction
     static constexpr __host__ __device__ int off(int i, int a) { return a == 0 ? (i == 1 ? 1 : i == 2 ? -1 : 0) : a == 1 ? (i == 3 ? 1 : i == 4 ? -1 : 0) : 0; }
     static constexpr __host__ __device__ int imgOf(int k) { return k < 3 ? 0 : 1; }
     static constexpr __host__ __device__ int chOf(int k) { return k < 3 ? k : 0; }
@@ -70,7 +72,18 @@ struct IntrinsicE {
     int W, H, D;
     const T* X[NIMG];
     const T* target;
-    T w_fit, w_regA, w_regS, pNorm;
+    T w_fit, w_regA, w_regS, pNorm; T* aux;
+    // the ComputedArray of L_p (lib.t:106-114) for stencil direction n at pixel (x, y): sqrt((|r_c - r_n| + 1e-7)^(p - 2)), from the current r
+    __device__ void computeAux(int x, int y, int, T* out) const {
+        const ValueCtx<T, IntrinsicE> V(*this, x, y, 0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int dx = off(n + 1, 0), dy = off(n + 1, 1);
+            const T c0 = V(0) - V(0, dx, dy), c1 = V(1) - V(1, dx, dy), c2 = V(2) - V(2, dx, dy);
+            const T dist = sqrt(c0 * c0 + c1 * c1 + c2 * c2);                                   // L_2_norm(val_const)
+            out[n] = sqrt(pow(dist + T(0.0000001), pNorm - T(2)));                             // lib.t:108-110
+        }
+    }
     void bindParams(void** p) {
         w_fit = (T) * (const float*)p[0]; w_regA = (T) * (const float*)p[1]; w_regS = (T) * (const float*)p[2];
         pNorm = *(const T*)p[3];                      // Param("pNorm", opt_float, 3)
@@ -79,16 +92,14 @@ struct IntrinsicE {
     __device__ bool excluded(int, int, int) const { return false; }
     template <class S, class C>
     __device__ __forceinline__ void residuals(const C& Xc, int x, int y, int, S* r) const {
-        const ValueCtx<T, IntrinsicE> V(*this, x, y, 0);           // the constant view r_const (same binding as r)
+        const long N = (long)W * H, cpx = (long)y * W + x;
         const S rc[3] = {Xc(0), Xc(1), Xc(2)};
         const S sc = Xc(3);
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int dx = off(n + 1, 0), dy = off(n + 1, 1);
             const bool inb = Xc.in(dx, dy, 0);
-            const T c0 = V(0) - V(0, dx, dy), c1 = V(1) - V(1, dx, dy), c2 = V(2) - V(2, dx, dy);
-            const T dist = sqrt(c0 * c0 + c1 * c1 + c2 * c2);                                   // L_2_norm(val_const)
-            const T sqrtC = sqrt(pow(dist + T(0.0000001), pNorm - T(2)));                      // lib.t:108-110
+            const T sqrtC = aux[(long)n * N + cpx];                                            // the ComputedArray, frozen since the last precompute
 #pragma unroll
             for (int c = 0; c < 3; ++c) { const S e = w_regA * (sqrtC * (rc[c] - Xc(c, dx, dy))); r[3 * n + c] = inb ? e : S(T(0)); }
             const S es = w_regS * (sc - Xc(3, dx, dy));
@@ -106,7 +117,7 @@ struct IntrinsicE {
 // (lib.t:77-91), Select(InBounds(0,0,0), Select(InBounds(n), ., 0), 0).  UsePreconditioner(true).
 template <class T>
 struct VolumetricE {
-    static constexpr int NDIM = 3, NIMG = 2, K = 6, R = 21, NOFF = 7;
+    static constexpr int NDIM = 3, NIMG = 2, K = 6, R = 21, NOFF = 7, NAUX = 0;
     static constexpr __host__ __device__ int off(int i, int a) {
         return a == 0 ? (i == 1 ? 1 : i == 2 ? -1 : 0) : a == 1 ? (i == 3 ? 1 : i == 4 ? -1 : 0) : (i == 5 ? 1 : i == 6 ? -1 : 0);
     }
@@ -118,7 +129,8 @@ struct VolumetricE {
     int W, H, D;
     const T* X[NIMG];
     const T *Ur, *Cons;
-    T w_fit, w_reg;
+    T w_fit, w_reg; T* aux;
+    __device__ void computeAux(int, int, int, T*) const {}
     void bindParams(void** p) {
         X[0] = (const T*)p[0]; X[1] = (const T*)p[1]; Ur = (const T*)p[2]; Cons = (const T*)p[3];
         w_fit = (T) * (const float*)p[4]; w_reg = (T) * (const float*)p[5];

@@ -107,6 +107,21 @@ struct DualCtx : GridView<T, E> {
 
 template <class E> struct VOff { long o[E::NIMG]; };
 
+// ComputedArrays (o.t:2387-2409): a functor with NAUX > 0 gets NAUX planes `aux` (plane k at aux + k * N) that the engine fills with
+// computeAux() in EnergyOps::precompute -- after bind and after every update / revert, like the reference's precompute kernel
+// (solver.t:607-614, 1005, 1116, 1155) -- and that residuals() may read as constants of the linearisation.
+template <class T, class E>
+__global__ __launch_bounds__(kBlock) void se_precompute(E e) {
+    const long N = (long)e.W * e.H * e.D;
+    for (long c = blockIdx.x * (long)blockDim.x + threadIdx.x; c < N; c += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(c % e.W), y = (int)((c / e.W) % e.H), z = (int)(c / ((long)e.W * e.H));
+        T vals[E::NAUX > 0 ? E::NAUX : 1];
+        e.computeAux(x, y, z, vals);
+#pragma unroll
+        for (int k = 0; k < E::NAUX; ++k) e.aux[(long)k * N + c] = vals[k];
+    }
+}
+
 // ---- kernels --------------------------------------------------------------------------------------------------------
 template <class T, class E>
 __global__ __launch_bounds__(kBlock) void se_cost(E e, double* __restrict__ partials) {
@@ -216,6 +231,11 @@ struct StencilOps : EnergyOps<T> {
         const long n = (long)e.W * e.H * e.D;
         for (int i = 0; i < E::NIMG; ++i) { vo.o[i] = this->nScalars; this->addUnknown(E::unknownParam(i), n, E::channels(i)); }
         int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if constexpr (E::NAUX > 0) { HIP_CHECK(hipMalloc((void**)&e.aux, (size_t)E::NAUX * n * sizeof(T))); HIP_CHECK(hipMemset(e.aux, 0, (size_t)E::NAUX * n * sizeof(T))); }
+    }
+    ~StencilOps() override { if constexpr (E::NAUX > 0) (void)hipFree(e.aux); }
+    void precompute(LaunchCtx& ctx) override {
+        if constexpr (E::NAUX > 0) { ScopedKernel k(ctx, "precompute"); se_precompute<T, E><<<grid(), kBlock, 0, ctx.stream>>>(e); }
     }
     int grid() const { const long n = (long)e.W * e.H * e.D; return (int)std::max<long>(1, std::min<long>((n + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
     void bind(void** p, LaunchCtx&) override { e.bindParams(p); }
