@@ -40,6 +40,24 @@ int main(int argc, char** argv) {
         finalCost[k] = Opt_ProblemCurrentCost(state, plan);
         Opt_PlanFree(state, plan); Opt_ProblemDelete(state, problem);
     }
+    // "CUDA Patch" of the reference example (CombinedSolver.h:39, off by default there too): this backend's block-local solver, reached through the same
+    // Opt_* calls with its own solver kind
+    if (argc > 5 && std::string(argv[5]) == "patch") {
+        Opt_Problem* problem = Opt_ProblemDefine(state, energy.c_str(), "patchGaussNewtonGPU");
+        Opt_Plan* plan = Opt_ProblemPlan(state, problem, dims);
+        if (!plan) return 3;
+        Opt_SetSolverParameter(state, plan, "nIterations", &nonLinearIter);
+        Opt_SetSolverParameter(state, plan, "lIterations", &linearIter);
+        dX.upload(base);
+        void* params[] = {dX.ptr, dT.ptr, dM.ptr};
+        std::vector<SolverIteration> it;
+        std::cout << "//////////// (Patch) ///////////////" << std::endl;
+        profiledSolve(state, plan, params, it);
+        const double c = Opt_ProblemCurrentCost(state, plan);
+        std::cout << "Patch final cost: " << c << std::endl;
+        Opt_PlanFree(state, plan); Opt_ProblemDelete(state, problem);
+        if (!(c < it[0].cost)) return 1;
+    }
     // pixels outside the pasted region must be untouched
     const std::vector<float> out = dX.download();
     for (size_t i = 0; i < (size_t)W * H; ++i) if (mask[i] != 0.f) for (int k = 0; k < 4; ++k) if (out[4 * i + k] != base[4 * i + k]) { fprintf(stderr, "excluded pixel moved\n"); return 1; }

@@ -43,7 +43,8 @@ typedef struct Opt_InitializationParameters Opt_InitializationParameters;
 Opt_State* Opt_NewState(Opt_InitializationParameters params);
 
 /* Record the problem specification `filename` (a .t energy file) and the solver kind: "gaussNewtonGPU"
- * or "LMGPU" (reference Opt.h:40, o.t:2521-2525, o.t:122).  Nothing is parsed until Opt_ProblemPlan. */
+ * or "LMGPU" (reference Opt.h:40, o.t:2521-2525, o.t:122).  Nothing is parsed until Opt_ProblemPlan.
+ * Extension of this backend: "patchGaussNewtonGPU" (block-local patch solver, see OptAmd.h). */
 Opt_Problem* Opt_ProblemDefine(Opt_State* state, const char* filename, const char* solverkind);
 void Opt_ProblemDelete(Opt_State* state, Opt_Problem* problem);
 

@@ -6,6 +6,14 @@
  * intermediate vector of the HIP solver with the CPU oracle, (b) bench.py can read per-kernel hipEvent
  * timings for the roofline figure, (c) a multi-process launcher can tile an image problem over the GPUs
  * of a node.  A caller that only needs the reference behaviour never touches this header.
+ *
+ * One extension has no entry point of its own: Opt_ProblemDefine accepts a third solver kind,
+ * "patchGaussNewtonGPU" -- the block-local patch solver that the reference ships as a separate CUDA solver
+ * of its poisson example (examples/poisson_image_editing/src/PatchSolverWarping.cu:67-241, driven by
+ * CUDAPatchSolverWarping.cpp:14-33).  Opt_ProblemPlan returns NULL for energies without a patch kernel.
+ * Opt_SetSolverParameter names: "nIterations" (outer steps), "lIterations" (sweeps per step; the tiling
+ * is shifted by the next Halton point before each), "patchIterations" (int, PCG iterations inside a patch,
+ * default 16), "patchSize" (int, 16 or 32, default 32).  Init / Step / CurrentCost behave as for the other kinds.
  */
 #pragma once
 #include "Opt.h"

@@ -89,7 +89,7 @@ def check_problem_file(path):
     return bool(ok), buf.value.decode()
 
 
-_INT_PARAMS = {"nIterations", "lIterations", "residual_reset_period", "nIter"}
+_INT_PARAMS = {"nIterations", "lIterations", "residual_reset_period", "nIter", "patchIterations", "patchSize"}
 
 
 def energy_file(stem):

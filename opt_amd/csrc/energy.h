@@ -100,6 +100,12 @@ struct EnergyOps {
     // Called once after the last pcgIteration of a linear solve, before the solver adds the last term alpha p to delta:
     // lets a kernel set that defers part of its delta update apply what is left.  pPrev = the p buffer the last launch read.
     virtual void pcgFinish(const T* /*pPrev*/, T* /*delta*/, LaunchCtx&) {}
+    // Optional block-local solver (kind "patchGaussNewtonGPU", OptAmd.h): one additive-Schwarz sweep of LDS-resident patch PCG solves over
+    // a tiling shifted by (fx, fy) patch widths, nPatchIters inner iterations each, applied to the unknowns directly; patchFinish is called
+    // after the last sweep of a step and must leave the result in the caller's unknown buffers.  false = the energy has no such kernel.
+    virtual bool patchIteration(float /*fx*/, float /*fy*/, int /*nPatchIters*/, int /*patchSize*/, LaunchCtx&) { return false; }
+    virtual void patchFinish(LaunchCtx&) {}
+    virtual bool supportsPatch() const { return false; }
     // partial sums of 1/2 sum (F + J delta)^2 (o.t:2174-2225); LM only
     virtual void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) = 0;
     // slab tiling (image energies): number of scalars in one image row of unknown image `img`

@@ -202,6 +202,101 @@ __global__ __launch_bounds__(kBlock) void poisson_pcgIter(PArgs<T> A, PIterK<T> 
     t = blockReduceSum(acc3, scratch); if (threadIdx.x == 0) K.s3[blockIdx.x] = t;
 }
 
+// ---- block-local "patch" PCG (the reference's LDS-resident comparator solver, examples/poisson_image_editing/src/
+// PatchSolverWarping.cu:67-241 with the Halton-shifted tiling of :208-209) ------------------------------------------------------------
+// One workgroup = one PS x PS patch of the image, shifted by (ox, oy).  It linearises at the current X (the problem is linear: b = -J^T F),
+// runs nPatchIters iterations of Jacobi-preconditioned CG on the patch's own sub-system with the search direction resident in LDS, and adds
+// the patch's delta to X.  Everything outside the patch -- and every excluded pixel -- keeps delta = 0 for this launch (the LDS apron stays
+// 0), i.e. one launch is one additive-Schwarz sweep over non-overlapping blocks; successive launches shift the tiling so that block borders move.
+// MI355X shape: PS = 32 gives 1024-thread workgroups (16 waves; a wave covers two 512-byte image rows), the only LDS array is p with its apron
+// (18.5 KB in float): x, t and the mask are read once from HBM/L2 to form b and never staged.  Dot products: DPP wave sums + one LDS slot per
+// wave, every thread adds the <= 16 wave sums in the same order (2 + 1 barriers per inner iteration; no atomics, deterministic).
+// Unlike the reference kernel, which updates X in place while neighbouring blocks may still be reading their apron from it (a benign race that
+// makes its output order-dependent), a launch reads Xin and writes Xout; the host ping-pongs the two.
+template <class T, int NW> __device__ __forceinline__ T patchSum(T v, T* slot) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) slot[threadIdx.x >> 6] = v;
+    __syncthreads();
+    T s = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) s += slot[i];
+    return s;
+}
+
+template <class T, int PS>
+__global__ __launch_bounds__(PS * PS) void poisson_patchSolve(int W, int H, const T* __restrict__ Xin, T* __restrict__ Xout, const T* __restrict__ Tg,
+                                                              const T* __restrict__ M, int ox, int oy, int nPatchIters) {
+    constexpr int LW = PS + 2, NW = PS * PS / kWave;
+    __shared__ V4<T> P[LW * LW];
+    __shared__ T red[2][NW];
+    const int tid = threadIdx.x, tx = tid % PS, ty = tid / PS;
+    const int gx = blockIdx.x * PS + tx - ox, gy = blockIdx.y * PS + ty - oy;
+    const bool inImage = gx >= 0 && gx < W && gy >= 0 && gy < H;
+    for (int i = tid; i < LW * LW; i += PS * PS) P[i] = V4<T>{0, 0, 0, 0};
+    const long c = (long)gy * W + gx;
+    const V4<T>* X = (const V4<T>*)Xin; const V4<T>* Tv = (const V4<T>*)Tg;
+    const bool active = inImage && M[c] == T(0);
+    const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};
+    V4<T> xc{0, 0, 0, 0}, R{0, 0, 0, 0}, delta{0, 0, 0, 0}, AP{0, 0, 0, 0}, pc{0, 0, 0, 0};
+    T pre = 0; bool nb[4] = {false, false, false, false};
+    if (inImage) xc = X[c];
+    if (active) {
+        const V4<T> tc = Tv[c];
+        T cnt = 0;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int nx = gx + dx[n], ny = gy + dy[n];
+            nb[n] = nx >= 0 && nx < W && ny >= 0 && ny < H;
+            if (!nb[n]) continue;
+            const long ni = (long)ny * W + nx;
+            const V4<T> e = (xc - X[ni]) - (tc - Tv[ni]);
+            R = R - (e + e);                                  // r = -J^T F: the residual centred here and the one centred at the neighbour
+            cnt += T(2);
+        }
+        pre = cnt > T(0) ? T(1) / cnt : T(1);                 // Jacobi: 1 / diag(J^T J)
+        pc = pre * R;
+    }
+    __syncthreads();                                          // p zeroed (apron included) before the patch writes its own entries
+    const int l = (ty + 1) * LW + tx + 1;
+    if (active) P[l] = pc;
+    T rz = patchSum<T, NW>(active ? dot4(R, pc) : T(0), red[1]);   // its barrier also publishes p
+    if (rz > T(0)) {                                          // uniform: a patch without active pixels (or already converged) has nothing to do
+        for (int it = 0; it < nPatchIters; ++it) {
+            T d = 0;
+            if (active) {
+                AP = V4<T>{0, 0, 0, 0};
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    if (!nb[n]) continue;
+                    const V4<T> q = pc - P[l + dy[n] * LW + dx[n]];   // p is 0 on excluded pixels and outside the patch
+                    AP = AP + (q + q);
+                }
+                d = dot4(pc, AP);
+            }
+            const T den = patchSum<T, NW>(d, red[0]);
+            T bn = 0;
+            V4<T> Z{0, 0, 0, 0};
+            if (active) {
+                const T alpha = den > T(0) ? rz / den : T(0);
+                delta = delta + alpha * pc;
+                R = R - alpha * AP;
+                Z = pre * R;
+                bn = dot4(Z, R);
+            }
+            const T rzNew = patchSum<T, NW>(bn, red[1]);
+            if (active) {
+                const T beta = rz > T(0) ? rzNew / rz : T(0);
+                pc = Z + beta * pc;
+                P[l] = pc;
+            }
+            rz = rzNew;
+            __syncthreads();
+        }
+    }
+    if (inImage) ((V4<T>*)Xout)[c] = xc + delta;
+}
+
 template <class T>
 struct PoissonOps : EnergyOps<T> {
     PArgs<T> A{};
@@ -240,6 +335,27 @@ struct PoissonOps : EnergyOps<T> {
         a.aNum->n = a.aDen->n = a.s2->n = a.s3->n = g;
         ++iterIndex;
         return true;
+    }
+    // ---- patch solver: ping-pong between the caller's X and a scratch copy; patchFinish leaves the result in the caller's buffer
+    T* scratchX = nullptr; bool inScratch = false;
+    bool supportsPatch() const override { return true; }
+    ~PoissonOps() override { if (scratchX) (void)hipFree(scratchX); }
+    template <int PS> void launchPatch(const T* in, T* out, float fx, float fy, int nPatchIters, LaunchCtx& ctx) {
+        const dim3 g((A.W + PS - 1) / PS + 1, (A.H + PS - 1) / PS + 1);     // one more block per axis for the shift
+        poisson_patchSolve<T, PS><<<g, PS * PS, 0, ctx.stream>>>(A.W, A.H, in, out, A.Tg, A.M, (int)(fx * PS), (int)(fy * PS), nPatchIters);
+    }
+    bool patchIteration(float fx, float fy, int nPatchIters, int patchSize, LaunchCtx& ctx) override {
+        if (patchSize != 16 && patchSize != 32) return false;
+        if (!scratchX) HIP_CHECK(hipMalloc((void**)&scratchX, (size_t)A.W * A.H * 4 * sizeof(T)));
+        const T* in = inScratch ? scratchX : A.X; T* out = inScratch ? const_cast<T*>(A.X) : scratchX;
+        ScopedKernel k(ctx, "PCGIterationPatch");
+        if (patchSize == 16) launchPatch<16>(in, out, fx, fy, nPatchIters, ctx); else launchPatch<32>(in, out, fx, fy, nPatchIters, ctx);
+        inScratch = !inScratch;
+        return true;
+    }
+    void patchFinish(LaunchCtx& ctx) override {
+        if (inScratch) HIP_CHECK(hipMemcpyAsync(const_cast<T*>(A.X), scratchX, (size_t)A.W * A.H * 4 * sizeof(T), hipMemcpyDeviceToDevice, ctx.stream));
+        inScratch = false;
     }
 };
 

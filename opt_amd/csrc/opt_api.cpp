@@ -122,11 +122,13 @@ void Opt_ProblemDelete(Opt_State*, Opt_Problem* problem) { delete problem; }
 Opt_Plan* Opt_ProblemPlan(Opt_State* state, Opt_Problem* problem, unsigned int* dimensions) {
     if (!state || !problem || !dimensions) return nullptr;
     // o.t:122: the solver kind must be one of the two known names
-    if (problem->kind != "gaussNewtonGPU" && problem->kind != "LMGPU") {
+    // (plus this backend's extension "patchGaussNewtonGPU", OptAmd.h: block-local LDS-resident PCG sweeps, for energies that ship that kernel)
+    const bool patch = problem->kind == "patchGaussNewtonGPU";
+    if (problem->kind != "gaussNewtonGPU" && problem->kind != "LMGPU" && !patch) {
         fprintf(stderr, "Opt_ProblemPlan: expected solver kind to be gaussNewtonGPU or LMGPU, got '%s'\n", problem->kind.c_str());
         return nullptr;
     }
-    const bool lm = problem->kind.find("LM") != std::string::npos;   // o.t:315
+    const bool lm = !patch && problem->kind.find("LM") != std::string::npos;   // o.t:315
     TFile tf; std::string err;
     if (!readTFile(problem->filename, tf, err)) { fprintf(stderr, "Opt_ProblemPlan: %s\n", err.c_str()); return nullptr; }
     const EnergyInfo* info = findEnergy(tf.stem);
@@ -140,8 +142,8 @@ Opt_Plan* Opt_ProblemPlan(Opt_State* state, Opt_Problem* problem, unsigned int* 
     if (!validate(tf, *info, why)) { fprintf(stderr, "Opt_ProblemPlan: %s: %s\n", problem->filename.c_str(), why.c_str()); return nullptr; }
     if (state->params.doublePrecision && info->floatOnly && state->params.verbosityLevel > 0)
         printf("Opt_ProblemPlan: '%s' declares fixed float unknowns; solving in float\n", info->name);
-    SolverBase* s = makeSolver(*info, lm, state->params.doublePrecision != 0, dimensions, state->params.collectPerKernelTimingInfo != 0, state->params.verbosityLevel);
-    if (!s) { fprintf(stderr, "Opt_ProblemPlan: could not instantiate kernel set '%s'\n", info->name); return nullptr; }
+    SolverBase* s = makeSolver(*info, lm, patch, state->params.doublePrecision != 0, dimensions, state->params.collectPerKernelTimingInfo != 0, state->params.verbosityLevel);
+    if (!s) { fprintf(stderr, "Opt_ProblemPlan: could not instantiate kernel set '%s'%s\n", info->name, patch ? " (it has no patch solver)" : ""); return nullptr; }
     if (state->params.verbosityLevel > 1) printf("Opt_ProblemPlan: %s (%s), nUnknowns = %ld, .t hash %016lx\n", info->name, problem->kind.c_str(), s->numUnknownScalars(), tf.bodyHash);
     auto* plan = new Opt_Plan; plan->solver.reset(s); plan->energy = info->name;
     return plan;

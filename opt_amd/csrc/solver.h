@@ -20,6 +20,8 @@ struct SolverParameters {
     int nIter = 0;
     int nIterations = 10;
     int lIterations = 10;
+    int patchIterations = 16;     // kind "patchGaussNewtonGPU" only: inner PCG iterations per patch and sweep (reference CUDAPatchSolverWarping.cpp:19)
+    int patchSize = 32;           // 16 (the reference's PATCH_SIZE) or 32
 };
 
 struct SolverBase {
@@ -42,6 +44,6 @@ struct SolverBase {
     bool setParameter(const char* name, const void* value);   // solver.t:1205-1221
 };
 
-SolverBase* makeSolver(const EnergyInfo& info, bool lm, bool doublePrecision, const unsigned* dims, bool timing, int verbosity);
+SolverBase* makeSolver(const EnergyInfo& info, bool lm, bool patch, bool doublePrecision, const unsigned* dims, bool timing, int verbosity);
 
 }  // namespace optamd

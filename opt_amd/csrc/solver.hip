@@ -278,6 +278,7 @@ template <class T>
 struct PcgSolver : SolverBase {
     std::unique_ptr<EnergyOps<T>> E;
     bool lm;
+    bool patch = false; int patchSweep = 0;   // kind "patchGaussNewtonGPU": block-local sweeps instead of the global PCG loop (stepPatch)
     hipStream_t stream = nullptr;
     LaunchCtx ctx;
     long n = 0, nPad = 0, nPacks = 0;
@@ -570,7 +571,7 @@ struct PcgSolver : SolverBase {
         if (overallOpen) { timer.pool.push_back(overallStart); overallOpen = false; }
         if (timer.enabled) { overallStart = timer.get(); HIP_CHECK(hipEventRecord(overallStart, stream)); overallOpen = true; }   // "overall": init -> cleanup (solver.t:959, 1011)
         E->bind(params, ctx);
-        sp.nIter = 0;
+        sp.nIter = 0; patchSweep = 0;
         if (lm) {
             trust_region_radius = (T)sp.trust_region_radius; radius_decrease_factor = (T)sp.radius_decrease_factor;
             min_lm_diagonal = (T)sp.min_lm_diagonal; max_lm_diagonal = (T)sp.max_lm_diagonal;
@@ -588,8 +589,33 @@ struct PcgSolver : SolverBase {
         }
     }
 
+    // ---- step of the block-local solver (control flow of the reference comparator, PatchSolverWarping.cu:211-241) ----
+    // nIterations outer steps of lIterations sweeps; sweep s shifts the patch tiling by the s-th point (mod 8) of the Halton sequence in bases
+    // (2, 3), scaled by the patch size (:208-209).  Each sweep re-linearises at the current unknowns inside its kernel, so there is no global
+    // r / p / delta and no grid-wide sum in the loop: one launch per sweep, the cost once per outer step.
+    static double radicalInverse(int i, int base) { double f = 1, r = 0; while (i > 0) { f /= base; r += f * (i % base); i /= base; } return r; }
+    int stepPatch(void** params) {
+        E->bind(params, ctx);
+        if (sp.nIter >= sp.nIterations) { cleanup(); return 0; }
+        for (int lIter = 0; lIter < sp.lIterations; ++lIter) {
+            const int o = patchSweep % 8;
+            if (!E->patchIteration((float)radicalInverse(o, 2), (float)radicalInverse(o, 3), sp.patchIterations, sp.patchSize, ctx)) {
+                fprintf(stderr, "patchGaussNewtonGPU: unsupported patchSize %d (16 or 32)\n", sp.patchSize); exit(1);
+            }
+            ++patchSweep;
+        }
+        E->patchFinish(ctx);
+        E->precompute(ctx);
+        const T newCost = computeCost();
+        if (verbosity > 0) printf("cost: %f -> %f\n", (double)prevCost, (double)newCost);
+        prevCost = newCost;
+        sp.nIter += 1;
+        return 1;
+    }
+
     // ---- step (solver.t:1016-1177) --------------------------------------------------------------------
     int step(void** params) override {
+        if (patch) return stepPatch(params);
         const T min_relative_decrease = (T)sp.min_relative_decrease, min_trust_region_radius = (T)sp.min_trust_region_radius;
         const T max_trust_region_radius = (T)sp.max_trust_region_radius, q_tolerance = (T)sp.q_tolerance, function_tolerance = (T)sp.function_tolerance;
         T Q0 = 0, Q1 = 0;
@@ -789,7 +815,7 @@ struct PcgSolver : SolverBase {
         return (double)computeCost();
     }
     int setSlab(long row0, long rows, long globalHeight, const OptAmd_SlabComm* c) override {
-        if (!E->supportsSlab() || !c) return 0;
+        if (!E->supportsSlab() || !c || patch) return 0;   // the block-local solver is single-GPU
         // local height = rows + 2 * ghost: the plan was created with dims {W, rows + 2 * ghost}
         const long localH = E->unknowns[0].elems * E->unknowns[0].channels / E->rowScalars(0);
         const long g = (localH - rows) / 2;
@@ -806,21 +832,23 @@ bool SolverBase::setParameter(const char* name, const void* value) {   // solver
 #define PI(x) if (nm == #x) { sp.x = *(const int*)value; return true; }
     PF(min_relative_decrease) PF(min_trust_region_radius) PF(max_trust_region_radius) PF(q_tolerance) PF(function_tolerance)
     PF(trust_region_radius) PF(radius_decrease_factor) PF(min_lm_diagonal) PF(max_lm_diagonal)
-    PI(residual_reset_period) PI(nIter) PI(nIterations) PI(lIterations)
+    PI(residual_reset_period) PI(nIter) PI(nIterations) PI(lIterations) PI(patchIterations) PI(patchSize)
 #undef PF
 #undef PI
     return false;
 }
 
-SolverBase* makeSolver(const EnergyInfo& info, bool lm, bool doublePrecision, const unsigned* dims, bool timing, int verbosity) {
+SolverBase* makeSolver(const EnergyInfo& info, bool lm, bool patch, bool doublePrecision, const unsigned* dims, bool timing, int verbosity) {
     if (doublePrecision && !info.floatOnly) {
         EnergyOps<double>* e = info.makeDouble(dims);
         if (!e) return nullptr;
-        return new PcgSolver<double>(e, lm, timing, verbosity);
+        if (patch && !e->supportsPatch()) { delete e; return nullptr; }
+        auto* s = new PcgSolver<double>(e, lm, timing, verbosity); s->patch = patch; return s;
     }
     EnergyOps<float>* e = info.makeFloat(dims);
     if (!e) return nullptr;
-    return new PcgSolver<float>(e, lm, timing, verbosity);
+    if (patch && !e->supportsPatch()) { delete e; return nullptr; }
+    auto* s = new PcgSolver<float>(e, lm, timing, verbosity); s->patch = patch; return s;
 }
 
 }  // namespace optamd

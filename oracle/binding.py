@@ -59,6 +59,7 @@ def lib():
         L.OptOracle_GetCostHistory.argtypes = [vp, vp]
         L.OptOracle_TrustRegionRadius.restype = cd
         L.OptOracle_TrustRegionRadius.argtypes = [vp]
+        L.OptOracle_PoissonPatchSolve.argtypes = [ci, ci, ci, vp, vp, vp, ci, ci, ci, ci, vp]
         _lib = L
     return _lib
 
@@ -158,3 +159,17 @@ class OracleSolver:
 
     def trust_region_radius(self):
         return lib().OptOracle_TrustRegionRadius(self._h)
+
+
+def poisson_patch_solve(X, T, M, n_iterations, l_iterations, patch_iterations=16, patch_size=32):
+    """Block-local patch solver of oracle/patch.hpp.  X (H, W, 4), T (H, W, 4), M (H, W), all float32 or all float64.
+    Returns (X after the solve, costs[n_iterations + 1])."""
+    dt = X.dtype
+    assert dt in (np.float32, np.float64) and T.dtype == dt and M.dtype == dt
+    H, W = M.shape
+    Xo = np.ascontiguousarray(X).copy()
+    Tc, Mc = np.ascontiguousarray(T), np.ascontiguousarray(M)
+    costs = np.zeros(n_iterations + 1, dtype=np.float64)
+    lib().OptOracle_PoissonPatchSolve(int(dt == np.float64), W, H, Xo.ctypes.data, Tc.ctypes.data, Mc.ctypes.data, int(n_iterations), int(l_iterations),
+                                      int(patch_iterations), int(patch_size), costs.ctypes.data)
+    return Xo, costs

@@ -9,6 +9,7 @@
 #include "sfs.hpp"
 #include "energies_grid.hpp"
 #include "energies_mesh.hpp"
+#include "patch.hpp"
 #include <memory>
 
 using namespace oracle;
@@ -114,6 +115,12 @@ long OptOracle_CostHistoryLen(void* hv) { auto* h = (Handle*)hv; return (long)(h
 void OptOracle_GetCostHistory(void* hv, double* out) {
     auto* h = (Handle*)hv; const auto& c = h->dbl ? h->sd->costHistory : h->sf->costHistory;
     for (size_t i = 0; i < c.size(); ++i) out[i] = c[i];
+}
+// block-local patch solver for poisson_image_editing (patch.hpp): X in/out, costs[nIterations + 1]
+void OptOracle_PoissonPatchSolve(int doublePrecision, int W, int H, void* X, const void* T, const void* M, int nIterations, int lIterations,
+                                 int patchIterations, int patchSize, double* costs) {
+    if (doublePrecision) { PoissonPatch<double> p{W, H, (const double*)T, (const double*)M}; p.solve((double*)X, nIterations, lIterations, patchIterations, patchSize, costs); }
+    else { PoissonPatch<float> p{W, H, (const float*)T, (const float*)M}; p.solve((float*)X, nIterations, lIterations, patchIterations, patchSize, costs); }
 }
 double OptOracle_TrustRegionRadius(void* hv) { auto* h = (Handle*)hv; return h->dbl ? (double)h->sd->trust_region_radius : (double)h->sf->trust_region_radius; }
 

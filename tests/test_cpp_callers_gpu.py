@@ -66,6 +66,13 @@ def test_poisson_example_flow():
     os.remove(os.path.join(ROOT, "results_float.csv"))
 
 
+def test_poisson_example_with_patch_solver():
+    r = _run("poisson_example", 200, 136, 24, "opt_amd/energies/poisson_image_editing.t", "patch")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "(Patch)" in r.stdout and "Patch final cost:" in r.stdout
+    os.remove(os.path.join(ROOT, "results_float.csv"))
+
+
 def test_arap_example_flow():
     r = _run("arap_example", 60, 50, 3, 6, 40)
     assert r.returncode == 0, r.stdout + r.stderr
