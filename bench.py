@@ -6,8 +6,9 @@
 A "step" is one Opt_ProblemStep: one Gauss-Newton iteration = evalJTF + `lIterations` (400, the
 reference's examples/image_warping/src/main.cpp:113-114) matrix-free PCG iterations + update + cost.
 value = K * lIterations / wall time of the K timed steps (max over ranks), inputs resident in HBM.
-N > 1 (launched by torch.distributed.run, one rank per GPU): the 4096^2 image is split into row slabs,
-one 1-row halo exchange + one 4-double all-reduce per PCG iteration over RCCL -- total work fixed => "strong" scaling.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the 4096^2 image is split into row slabs with 8 ghost rows;
+one 4-double all-reduce per PCG iteration and one exchange of r / p edge rows per 7 iterations over RCCL -- total work fixed
+=> "strong" scaling.
 
 The same JSON line carries
   roofline     : the dominant kernel timed with hipEvents on the solver's stream.  For Gauss-Newton image_warping that is

@@ -89,9 +89,10 @@ typedef struct OptAmd_SlabComm {
     void (*allReduceSum)(void* ctx, double* deviceBuf, int n, void* stream);
 } OptAmd_SlabComm;
 /* Attach a slab description to a plan created with dims {W, rows + 2*g}: g >= 1 ghost rows above and below the `rows` owned
- * rows (g is inferred from the plan's height).  g = 1 is enough for every kernel set; with g = 2 image_warping runs its
- * PCG iteration without the A*p vector in memory (the neighbours' two edge rows of r and p are exchanged instead of one
- * row of A*p).  Must precede Opt_ProblemInit. */
+ * rows (g is inferred from the plan's height).  g = 1 is enough for every kernel set; with g >= 2 image_warping runs its
+ * PCG iteration without the A*p vector in memory (the neighbours' g edge rows of r and p are exchanged instead of one
+ * row of A*p), and that exchange is needed only every g - 1 iterations because the kernel keeps the ghost rows it still
+ * needs current by itself.  Must precede Opt_ProblemInit. */
 int OptAmd_PlanSetSlab(Opt_Plan* plan, long row0, long rows, long globalHeight, const OptAmd_SlabComm* comm);
 
 #ifdef __cplusplus

@@ -72,7 +72,8 @@ struct EnergyOps {
     bool usePreconditioner = false;   // reference o.t:214 default
     bool usesGraph = false;
     Slab slab;
-    bool iterStateExchange = false;   // set by pcgIteration: in slab mode the solver exchanges the ghost rows of r and p after each launch (else of Ap before it)
+    bool iterStateExchange = false;   // set by pcgIteration: in slab mode the solver exchanges the ghost rows of r and p after a launch (else of Ap before it)
+    bool iterExchangeDue = true;      // ... and whether that exchange is needed after THIS launch (deep ghost zones let a kernel skip some)
     virtual ~EnergyOps() {}
     void addUnknown(int param, long elems, int channels) {
         unknowns.push_back({param, elems, channels, nScalars});

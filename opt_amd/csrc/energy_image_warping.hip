@@ -422,6 +422,9 @@ struct IterK {             // kernel argument block
     T lmRadius, lmMin, lmMax;   // PRE == 3 with LM: CtC and the LM preconditioner are rebuilt from the flag byte (see the kernel)
     const double *aNumPrev, *aDenPrev, *s2Prev, *s3Prev; int nNum, nDen, n2, n3;
     double *aNum, *aDen, *s2, *s3;
+    // iw_pcgIter2 in slab mode: the launch may update r and p on some ghost rows too (A.yBegin / A.yEnd then include them) so that the
+    // neighbours' rows are needed only every few launches; the sums and delta stay on the owned rows [ownBegin, ownEnd) (image rows)
+    int ownBegin, ownEnd;
 };
 
 // PRE: 0 = identity preconditioner, 1 = the solver's 3-channel one (12 B/px), 2 = compact {M_O, M_a} (8 B/px).  A template
@@ -750,8 +753,10 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
         nC.zx = nC.mx * rx; nC.zy = nC.my * ry; nC.za = nC.ma * ra;
         nC.q.ox = nC.zx + beta * oB.q.ox; nC.q.oy = nC.zy + beta * oB.q.oy; nC.q.a = nC.za + beta * oB.q.a;                               // Step3
         if (live && writer && y + 1 >= yb && y + 1 < ye) {
-            const long i = (long)phys(y + 1) * A.W + x;
-            if (!keepR && K.deltaMode != 2) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462), preceded by the deferred term of launch k-1
+            const int yp = phys(y + 1);
+            const long i = (long)yp * A.W + x;
+            const bool own = yp >= K.ownBegin && yp < K.ownEnd;
+            if (own && !keepR && K.deltaMode != 2) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462), preceded by the deferred term of launch k-1
                 V2<T> d = dO[i]; T da = dA[i];
                 if (K.deltaMode == 1) { const V2<T> q = pO[i]; const T qa = pA[i]; d.x += alpha2 * q.x; d.y += alpha2 * q.y; da += alpha2 * qa; }   // p_{k-2}, about to be overwritten
                 d.x += alpha * oB.q.ox; d.y += alpha * oB.q.oy; da += alpha * oB.q.a;
@@ -762,14 +767,14 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
                 }
             }
             st2<kNTS>(rO, i, rx, ry); st1<kNTS>(rA, i, ra); st2<kNTS>(pO, i, nC.q.ox, nC.q.oy); st1<kNTS>(pA, i, nC.q.a);
-            accNum += (double)(nC.zx * rx + nC.zy * ry + nC.za * ra);
+            if (own) accNum += (double)(nC.zx * rx + nC.zy * ry + nC.za * ra);
         }
         Q<T> l2 = nB.lf, r2 = nB.rt;
         dppShiftVec<true>(nB.q, l2); dppShiftVec<false>(nB.q, r2);
         T ox, oy, oa;
         applyA(nB.q, l2, r2, nA.q, nC.q, ox, oy, oa);                                   // Step1 of iteration k
         if (LM) { ox += nB.cx * nB.q.ox; oy += nB.cy * nB.q.oy; oa += nB.ca * nB.q.a; }
-        if (live && writer && y >= yb) {
+        if (live && writer && y >= yb && phys(y) >= K.ownBegin && phys(y) < K.ownEnd) {
             accDen += (double)(nB.q.ox * ox + nB.q.oy * oy + nB.q.a * oa);
             acc2 += (double)(nB.zx * ox + nB.zy * oy + nB.za * oa);
             acc3 += (double)((nB.mx * ox) * ox + (nB.my * oy) * oy + (nB.ma * oa) * oa);
@@ -900,6 +905,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_COMPACT_M")) useCompactM = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_SWEEP")) alternateSweep = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_RECOMPUTE_AP")) recomputeAp = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_SLAB_PERIOD")) maxExchangePeriod = std::max(1, atoi(e));
         if (const char* e = getenv("OPT_AMD_FLAG_M")) flagPreconditioner = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_PAIR_DELTA")) pairDelta = atoi(e) != 0;
         HIP_CHECK(hipMalloc((void**)&dNotLattice, sizeof(int)));
@@ -984,6 +990,7 @@ struct ImageWarpingOps : EnergyOps<T> {
     }
     int occIter[15] = {0};
     int iterFlip = 0; bool alternateSweep = true, recomputeAp = true;
+    int sinceExchange = 0, maxExchangePeriod = 1 << 20;      // OPT_AMD_SLAB_PERIOD=1: exchange after every launch whatever the ghost depth (A/B switch)
     template <bool LAT, int PRE> static const void* iterFn(bool noAp, bool flip) {
         return !noAp ? (const void*)iw_pcgIter<T, LAT, PRE> : flip ? (const void*)iw_pcgIter2<T, LAT, PRE, true> : (const void*)iw_pcgIter2<T, LAT, PRE, false>;
     }
@@ -1004,7 +1011,22 @@ struct ImageWarpingOps : EnergyOps<T> {
         const bool noAp = recomputeAp && (!this->slab.active || this->slab.ghost >= 2);      // iw_pcgIter2: Ap recomputed instead of stored
         const bool lmLoop = a.CtC != nullptr;
         if (lmLoop && (!noAp || !a.pre || this->slab.active)) return false;      // LM: only the A p-free kernel has the variant (single GPU)
-        this->iterStateExchange = noAp;     // slab mode: r and p ghost rows come from the neighbours after each launch (iw_pcgIter: Ap before it)
+        this->iterStateExchange = noAp;     // slab mode: r and p ghost rows come from the neighbours after a launch (iw_pcgIter: Ap before it)
+        // With g >= 2 ghost rows whose r and p are current to depth v, a launch can also update the ghost rows to depth v - 1 (their A p needs one
+        // more row on either side) and its sums need depth 2; so after an exchange at depth g the slab runs g - 1 launches before it needs the
+        // neighbours again, launch j = 1 .. g - 1 of the period updating g - j ghost rows (none in the last one: they are about to be overwritten).
+        int ext = 0;
+        this->iterExchangeDue = true;
+        if (noAp && this->slab.active) {
+            if (a.first) sinceExchange = 0;
+            const int period = std::max(1, std::min(this->slab.ghost - 1, maxExchangePeriod)), j = sinceExchange + 1;
+            const bool due = j >= period;
+            ext = due ? 0 : this->slab.ghost - j;
+            sinceExchange = due ? 0 : j;
+            this->iterExchangeDue = due;
+        }
+        IWArgs<T> Ax = A;                   // what the kernel sees: the rows it updates
+        Ax.yBegin = std::max(0, A.yBegin - ext); Ax.yEnd = std::min(A.H, A.yEnd + ext);
         const int pre = !a.pre ? 0 : (noAp && lattice && flagPreconditioner) ? 3 : lmLoop ? 1 : useCompactM ? 2 : 1;
         const int L = lmLoop ? (lattice ? 14 : 13) : pre == 3 ? 12 : (noAp ? 6 : 0) + (lattice ? 3 : 0) + pre;
         if (a.first) iterFlip = 0;      // every linear solve starts top-down, so a solve is reproducible whatever ran before it
@@ -1019,7 +1041,7 @@ struct ImageWarpingOps : EnergyOps<T> {
             iw_compactM<T><<<flatGrid((long)A.W * A.H), kBlock, 0, ctx.stream>>>(a.pre, mc, (long)A.W * A.H);
         }
         const int gx = divUp(A.W, noAp ? kIterStrip2 : kIterStrip);
-        const int rows = A.yEnd - A.yBegin;
+        const int rows = Ax.yEnd - Ax.yBegin;
         int gy = std::max(1, std::min(std::min(rows, cus * occIter[L] / gx), kMaxPartials / gx));
         int rowsPerGroup = divUp(rows, gy);
         gy = divUp(rows, rowsPerGroup);
@@ -1036,11 +1058,11 @@ struct ImageWarpingOps : EnergyOps<T> {
                    a.CtC, a.b, a.q ? a.q->partials : nullptr, a.afterReset, a.betaNum.partials, a.betaNum.n, a.betaDen.partials, a.betaDen.n,
                    a.deltaOut ? a.deltaOut : a.delta, a.lmRadius, a.lmMinDiag, a.lmMaxDiag,
                    a.aNumPrev.partials, a.aDenPrev.partials, a.s2Prev.partials, a.s3Prev.partials, a.aNumPrev.n, a.aDenPrev.n, a.s2Prev.n, a.s3Prev.n,
-                   a.aNum->partials, a.aDen->partials, a.s2->partials, a.s3->partials};
+                   a.aNum->partials, a.aDen->partials, a.s2->partials, a.s3->partials, A.yBegin, A.yEnd};
         {
             ScopedKernel k(ctx, "PCGIteration");
             int rpg = rowsPerGroup, gxa = gx, gya = gy;
-            void* kargs[] = {(void*)&A, (void*)&K, (void*)&rpg, (void*)&gxa, (void*)&gya};
+            void* kargs[] = {(void*)&Ax, (void*)&K, (void*)&rpg, (void*)&gxa, (void*)&gya};
             HIP_CHECK(hipLaunchKernel(fn, dim3(gx * gy), dim3(noAp ? kIterBlock2 : kIterBlock), kargs, 0, ctx.stream));
         }
         if (alternateSweep) iterFlip ^= 1;

@@ -461,7 +461,7 @@ struct PcgSolver : SolverBase {
             if (distributed && lIter > 0 && !E->iterStateExchange) exchangeVector(Ap_X);   // kernel with Ap in memory: r and p ghost rows are kept current by the kernel itself
             if (!E->pcgIteration(a, ctx)) { if (lIter == 0) return false; fprintf(stderr, "pcgIteration refused mid-loop\n"); exit(1); }
             std::swap(r, r2); std::swap(Ap_X, Ap2); std::swap(p, p2);
-            if (distributed && E->iterStateExchange) {   // Ap-free kernel: the neighbours' edge rows of r_k and p_k, one grouped exchange
+            if (distributed && E->iterStateExchange && E->iterExchangeDue) {   // Ap-free kernel: the neighbours' edge rows of r_k and p_k, one grouped exchange
                 std::vector<T*> bases;
                 for (T* v : {r, p}) for (size_t i = 0; i < E->unknowns.size(); ++i) bases.push_back(v + E->unknowns[i].offset);
                 exchangeRows(bases);

@@ -2,9 +2,10 @@
 
 The reference is single-GPU; this is the MI355X-native extension the north star asks for:
 rank g owns rows [row0, row0+rows) of the image and passes libOpt.so arrays that hold its slab plus `ghost` ghost
-rows above and below (OptAmd_PlanSetSlab, include/OptAmd.h; 2 by default, which lets image_warping run its PCG iteration
-without the A*p vector in memory).  Per PCG iteration the ranks exchange `ghost` image rows per neighbour per vector and
-all-reduce four scalars; nothing else crosses GPUs.
+rows above and below (OptAmd_PlanSetSlab, include/OptAmd.h; at least 2 lets image_warping run its PCG iteration without
+the A*p vector in memory).  Per PCG iteration the ranks all-reduce four scalars; every `ghost` - 1 iterations they exchange
+`ghost` image rows of r and p per neighbour (in between, the iteration kernel keeps the ghost rows it still needs current by
+itself: SlabJob uses 8 ghost rows, one exchange per 7 iterations).  Nothing else crosses GPUs.
 
 Host-side pieces (numpy only, unit-tested on CPU with gloo): SlabLayout, split_problem, merge_unknowns.
 Device-side drivers: SlabJob (RCCL, one process per GPU, used by bench.py) and run_threads (all ranks as
@@ -113,9 +114,11 @@ class SlabJob:
     """One rank of a multi-process solve (bench.py --gpus N): torch.distributed is already initialised with the
     nccl (= RCCL) backend; the RCCL communicator used inside the solver is created here from a broadcast id."""
 
-    def __init__(self, energy, W, H, rank, world, kind="gaussNewtonGPU", double=False, problem=None, ghost=2):
+    def __init__(self, energy, W, H, rank, world, kind="gaussNewtonGPU", double=False, problem=None, ghost=None):
         import torch
         import torch.distributed as dist
+        if ghost is None:                      # deep ghost zones: 16 extra rows per slab buy 6 of 7 halo exchanges (DESIGN.md section 4)
+            ghost = max(2, min(8, H // world))
         self.layout = SlabLayout(W, H, rank, world, ghost)
         glob = problem if problem is not None else getattr(wl, energy)(W, H, double=double)
         self.local = split_problem(glob, self.layout)

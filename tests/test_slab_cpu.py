@@ -163,16 +163,17 @@ def test_split_with_two_ghost_rows():
         slab.SlabLayout(8, 7, 0, 4)          # 4 slabs x 2 ghost rows need at least 8 image rows
 
 
-def _rank_main_two_ghost(rank, world, port, q):
-    """The protocol of the A*p-free iteration on slabs (OptAmd_PlanSetSlab with two ghost rows): no A*p vector crosses ranks; after
-    every iteration the two edge rows of r_k and p_k do.  A rank evaluates J^T J p on its slab with p valid on two ghost rows, which
-    makes A p valid on the first ghost row, updates r and p there as well as on its own rows, and sums dot products over own rows."""
+def _rank_main_two_ghost(rank, world, port, q, G=2):
+    """The protocol of the A*p-free iteration on slabs (OptAmd_PlanSetSlab with G >= 2 ghost rows): no A*p vector crosses ranks; the G
+    edge rows of r_k and p_k do, once every G - 1 iterations.  With r and p valid v rows out, J^T J p is valid v - 1 rows out, so a
+    rank updates r and p on its own rows plus G - j ghost rows in iteration j of a period (none in the last: they are about to be
+    overwritten), and sums dot products over own rows only."""
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle.binding import OracleSolver
-    W, H, G = 18, 14, 2
+    W, H = 18, 14
     P = wl.image_warping(W, H, double=True, random_state=2, mask_fraction=0.08, perturb=0.3)
     lay = slab.SlabLayout(W, H, rank, world, ghost=G)
     loc = slab.split_problem(P, lay)
@@ -185,7 +186,7 @@ def _rank_main_two_ghost(rank, world, port, q):
         m &= (loc.params[4] == 0)
         return np.concatenate([np.repeat(m.reshape(-1), 2), m.reshape(-1)])
 
-    own, ring1 = rows_mask(G, LH - G), rows_mask(G - 1, LH - G + 1)
+    own = rows_mask(G, LH - G)
 
     def exchange(vec):       # the neighbours' two edge rows -> my two ghost rows, per unknown image
         for im in (vec[:2 * npx].reshape(LH, W, 2), vec[2 * npx:].reshape(LH, W)):
@@ -211,28 +212,36 @@ def _rank_main_two_ghost(rank, world, port, q):
     exchange(r); exchange(pre)                                      # once per Gauss-Newton step
     p = pre * r; delta = np.zeros_like(p)
     aNum = allsum(float((r * own) @ p))
+    period, j, exchanges = max(1, G - 1), 0, 0
     for _ in range(6):
-        Ap = np.where(ring1, o.apply_jtj(loc.params, p), 0.0)       # p is valid two rows out, so A p is valid one row out
+        j += 1
+        due = j >= period
+        ext = 0 if due else G - j                                   # ghost rows this iteration keeps current by itself
+        upd = rows_mask(G - ext, LH - G + ext)
+        Ap = np.where(upd, o.apply_jtj(loc.params, p), 0.0)         # p is valid ext + 1 rows out (at least), so A p is valid ext rows out
         aDen = allsum(float((p * own) @ Ap))
         alpha = aNum / aDen if aDen > 0 else 0.0
         delta += alpha * p * own
-        r = np.where(ring1, r - alpha * Ap, r)
+        r = np.where(upd, r - alpha * Ap, r)
         z = pre * r
         bNum = allsum(float((z * own) @ r))
         beta = bNum / aNum if aNum > 0 else 0.0
-        p = np.where(ring1, z + beta * p, p)
+        p = np.where(upd, z + beta * p, p)
         aNum = bNum
-        exchange(r); exchange(p)                                    # refresh both ghost rows for the next iteration
+        if due:
+            exchange(r); exchange(p); j = 0; exchanges += 1         # refresh all G ghost rows for the next period
+    assert exchanges == 6 // period
     q.put((rank, lay.row0, lay.rows, delta[:2 * npx].reshape(LH, W, 2)[G:LH - G].copy(), delta[2 * npx:].reshape(LH, W)[G:LH - G].copy()))
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_two_ghost_row_protocol(oracle_lib):
+@pytest.mark.parametrize("ghost", [2, 4])      # 4: the neighbours' rows cross every third iteration only
+def test_two_rank_gloo_two_ghost_row_protocol(oracle_lib, ghost):
     import torch.multiprocessing as mp
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_main_two_ghost, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main_two_ghost, args=(r, world, port, q, ghost)) for r in range(world)]
     for p in procs:
         p.start()
     parts = [q.get(timeout=120) for _ in range(world)]

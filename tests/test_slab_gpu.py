@@ -21,7 +21,9 @@ def _single(P, kind, **kw):
     return costs, np.concatenate([o.reshape(-1) for o in out])
 
 
-@pytest.mark.parametrize("ghost", [1, 2])      # 1: PCG iteration with A*p in memory (iw_pcgIter); 2: without (iw_pcgIter2)
+# ghost 1: PCG iteration with A*p in memory (iw_pcgIter); 2: without (iw_pcgIter2), r / p edge rows exchanged after every launch;
+# 4, 8: the same kernel keeps ghost rows current by itself and the exchange happens every 3rd / 7th launch (14 launches: 4 / 2 exchanges)
+@pytest.mark.parametrize("ghost", [1, 2, 4, 8])
 @pytest.mark.parametrize("world", [2, 3, 4])
 @pytest.mark.parametrize("double", [False, True])
 def test_gn_slabs_match_single(world, double, ghost):
@@ -92,6 +94,22 @@ def test_rccl_comm_single_rank():
     c1, x1 = _single(P, "gaussNewtonGPU", nIterations=2, lIterations=10)
     np.testing.assert_allclose(costs, c1, rtol=2e-5)
     assert rel_err(x, x1) < 2e-5
+
+
+def test_deep_ghost_slabs_general_ur_shape_and_period_switch(monkeypatch):
+    """5 ghost rows (period 4) with a jittered UrShape (compact preconditioner from the solver's vector, valid on all ghost rows after the
+    one exchange per step), and the same slabs with OPT_AMD_SLAB_PERIOD=1 (exchange after every launch): identical results."""
+    P = wl.image_warping(66, 47, double=True, random_state=13, mask_fraction=0.05, perturb=0.3, jitter_urshape=0.2)
+    kw = dict(nIterations=2, lIterations=11)
+    c1, x1 = _single(P.clone(), "gaussNewtonGPU", **kw)
+    Q = P.clone()
+    cN = slab.run_threads(Q, 3, "gaussNewtonGPU", kw, ghost=5)
+    np.testing.assert_allclose(cN, c1, rtol=1e-11)
+    assert rel_err(flat_unknowns(Q), x1) < 1e-11
+    monkeypatch.setenv("OPT_AMD_SLAB_PERIOD", "1")
+    R = P.clone()
+    cR = slab.run_threads(R, 3, "gaussNewtonGPU", kw, ghost=5)
+    np.testing.assert_allclose(cR, cN, rtol=1e-13)
 
 
 def test_gn_slabs_lattice_and_general_ur_shape():
