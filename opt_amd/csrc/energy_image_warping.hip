@@ -654,6 +654,9 @@ struct NewRow {            // one row of iteration k: p_k, z_k, M, and the shift
 #define IW_SINCOS_INLINE 1
 #endif
 constexpr bool kSinCosInline = IW_SINCOS_INLINE != 0;
+#ifndef IW_OWN_CHECK
+#define IW_OWN_CHECK 1      // 0: compile the owned-row tests of the slab mode out (single-GPU A/B of their cost; slabs then need OPT_AMD_SLAB_PERIOD=1)
+#endif
 // LM = true: the Levenberg-Marquardt loop (A = J^T J + diag(CtC), Q sums, restart after a residual reset); see energy.h PcgIterArgs.
 template <class T, bool LATTICE, int PRE, bool FLIP, bool LM = false>
 __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArgs<T> A, IterK<T> K, int rowsPerGroup, int gx, int gy) {
@@ -755,7 +758,7 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
         if (live && writer && y + 1 >= yb && y + 1 < ye) {
             const int yp = phys(y + 1);
             const long i = (long)yp * A.W + x;
-            const bool own = yp >= K.ownBegin && yp < K.ownEnd;
+            const bool own = !IW_OWN_CHECK || (yp >= K.ownBegin && yp < K.ownEnd);
             if (own && !keepR && K.deltaMode != 2) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462), preceded by the deferred term of launch k-1
                 V2<T> d = dO[i]; T da = dA[i];
                 if (K.deltaMode == 1) { const V2<T> q = pO[i]; const T qa = pA[i]; d.x += alpha2 * q.x; d.y += alpha2 * q.y; da += alpha2 * qa; }   // p_{k-2}, about to be overwritten
@@ -774,7 +777,7 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
         T ox, oy, oa;
         applyA(nB.q, l2, r2, nA.q, nC.q, ox, oy, oa);                                   // Step1 of iteration k
         if (LM) { ox += nB.cx * nB.q.ox; oy += nB.cy * nB.q.oy; oa += nB.ca * nB.q.a; }
-        if (live && writer && y >= yb && phys(y) >= K.ownBegin && phys(y) < K.ownEnd) {
+        if (live && writer && y >= yb && (!IW_OWN_CHECK || (phys(y) >= K.ownBegin && phys(y) < K.ownEnd))) {
             accDen += (double)(nB.q.ox * ox + nB.q.oy * oy + nB.q.a * oa);
             acc2 += (double)(nB.zx * ox + nB.zy * oy + nB.za * oa);
             acc3 += (double)((nB.mx * ox) * ox + (nB.my * oy) * oy + (nB.ma * oa) * oa);
