@@ -79,17 +79,23 @@ __global__ __launch_bounds__(kBlock) void inc_sort(long N, const int* __restrict
     }
 }
 
-// MODE 0: cost, 1: model cost (vec = delta), 2: J^T F + diag, 3: J^T J vec
-template <class T, class G, int MODE>
+// MODE 0: cost, 1: model cost (vec = delta), 2: J^T F + diag, 3: J^T J vec.  LANES > 1 (gather mode): LANES adjacent lanes share one vertex;
+// lane 0 evaluates the vertex's own residuals, every lane walks every LANES-th record of the incidence list, and the partial sums are
+// folded with shuffles in a fixed order (more independent loads in flight than one thread walking ~24 records).
+#ifndef GE_GATHER_LANES
+#define GE_GATHER_LANES 4
+#endif
+template <class T, class G, int MODE, int LANES = 1>
 __global__ __launch_bounds__(kBlock) void ge_vertices(G g, const T* __restrict__ vec, GOff<G> vo, T* __restrict__ out, T* __restrict__ diag, const T* __restrict__ CtC,
                                                        double* __restrict__ partials, Incidence inc = Incidence{nullptr, nullptr}, const T* __restrict__ rec = nullptr) {
     __shared__ double scratch[kBlock / kWave + 1];
     double acc = 0;
-    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < g.N; v += (long)gridDim.x * blockDim.x) {
+    const int sub = LANES > 1 ? threadIdx.x % LANES : 0;
+    for (long v = (blockIdx.x * (long)blockDim.x + threadIdx.x) / LANES; v < g.N; v += (long)gridDim.x * blockDim.x / LANES) {
         typedef VertexCtx<T, G, MODE == 1 || MODE == 3, MODE >= 2> Ctx;
         typedef typename Ctx::S S;
         S r[G::RV > 0 ? G::RV : 1];
-        g.template vertexResiduals<S>(Ctx{g, v, vec, vo}, v, r);
+        if (sub == 0) g.template vertexResiduals<S>(Ctx{g, v, vec, vo}, v, r);
         if constexpr (MODE == 0) { T s = 0; for (int i = 0; i < G::RV; ++i) s += r[i] * r[i]; acc += (double)(T(0.5) * s); }
         else if constexpr (MODE == 1) { T s = 0; for (int i = 0; i < G::RV; ++i) { const T m = r[i].v + r[i].d[0]; s += m * m; } acc += (double)(T(0.5) * s); }
         else {
@@ -97,26 +103,36 @@ __global__ __launch_bounds__(kBlock) void ge_vertices(G g, const T* __restrict__
 #pragma unroll
             for (int k = 0; k < G::K; ++k) {
                 T gk = 0, dk = 0;
+                if (sub == 0) {
 #pragma unroll
-                for (int i = 0; i < G::RV; ++i) {
-                    if (MODE == 2) { gk += r[i].d[k] * r[i].v; dk += r[i].d[k] * r[i].d[k]; }
-                    else gk += r[i].d[1 + k] * r[i].d[0];
+                    for (int i = 0; i < G::RV; ++i) {
+                        if (MODE == 2) { gk += r[i].d[k] * r[i].v; dk += r[i].d[k] * r[i].d[k]; }
+                        else gk += r[i].d[1 + k] * r[i].d[0];
+                    }
+                    if (MODE == 3) { const long u = unknownIndex<T, G>(vo, v, k); if (CtC) gk += CtC[u] * vec[u]; acc += (double)(vec[u] * gk); }   // the edges' share of p . A p is |J p|^2, summed by the edge pass
                 }
-                if (MODE == 3) { const long u = unknownIndex<T, G>(vo, v, k); if (CtC) gk += CtC[u] * vec[u]; acc += (double)(vec[u] * gk); }   // the edges' share of p . A p is |J p|^2, summed by the edge pass
                 gs[k] = gk; ds[k] = dk;
             }
             if (inc.off) {      // gather mode: add the records of the (hyperedge, slot) pairs of this vertex, ascending
                 constexpr int KK = MODE == 2 ? 2 * G::K : G::K;
-                for (int t = inc.off[v], te = inc.off[v + 1]; t < te; ++t) {
+                for (int t = inc.off[v] + sub, te = inc.off[v + 1]; t < te; t += LANES) {
                     const T* q = rec + (long)inc.idx[t] * KK;
 #pragma unroll
                     for (int k = 0; k < G::K; ++k) { gs[k] += q[k]; if (MODE == 2) ds[k] += q[G::K + k]; }
                 }
-            }
+                if (LANES > 1) {
 #pragma unroll
-            for (int k = 0; k < G::K; ++k) {
-                const long u = unknownIndex<T, G>(vo, v, k);
-                if (MODE == 2) { out[u] = -gs[k]; diag[u] = ds[k]; } else out[u] = gs[k];
+                    for (int off = LANES / 2; off > 0; off >>= 1)
+#pragma unroll
+                        for (int k = 0; k < G::K; ++k) { gs[k] += __shfl_down(gs[k], off, LANES); if (MODE == 2) ds[k] += __shfl_down(ds[k], off, LANES); }
+                }
+            }
+            if (sub == 0) {
+#pragma unroll
+                for (int k = 0; k < G::K; ++k) {
+                    const long u = unknownIndex<T, G>(vo, v, k);
+                    if (MODE == 2) { out[u] = -gs[k]; diag[u] = ds[k]; } else out[u] = gs[k];
+                }
             }
         }
     }
@@ -182,7 +198,7 @@ struct GraphOps : EnergyOps<T> {
         int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (const char* e = getenv("OPT_AMD_GRAPH_GATHER")) useGather = atoi(e) != 0;
     }
-    int vgrid() const { return (int)std::max<long>(1, std::min<long>((g.N + kBlock - 1) / kBlock, kMaxPartials / 2)); }
+    int vgrid(int lanes = 1) const { return (int)std::max<long>(1, std::min<long>((g.N * lanes + kBlock - 1) / kBlock, kMaxPartials / 2)); }
     // gather mode state: incidence lists (rebuilt when the graph arrays change: pointers, count or an order-independent checksum) and the record buffer
     bool useGather = true;
     int *incOff = nullptr, *incIdx = nullptr, *cursors = nullptr; T* rec = nullptr; long recCapacity = 0;
@@ -229,17 +245,17 @@ struct GraphOps : EnergyOps<T> {
     void evalJTF(T* r, T* diag, LaunchCtx& ctx) override {
         if (useGather) {    // records first, then the vertex pass gathers them
             { ScopedKernel k(ctx, "PCGInit1_Graph"); ge_edges<T, G, 2><<<edgeGrid(g.nE, cus), kBlock, 0, ctx.stream>>>(g, nullptr, vo, r, diag, nullptr, rec); }
-            { ScopedKernel k(ctx, "PCGInit1"); ge_vertices<T, G, 2><<<vgrid(), kBlock, 0, ctx.stream>>>(g, nullptr, vo, r, diag, nullptr, nullptr, incidence(), rec); }
+            { ScopedKernel k(ctx, "PCGInit1"); ge_vertices<T, G, 2, GE_GATHER_LANES><<<vgrid(GE_GATHER_LANES), kBlock, 0, ctx.stream>>>(g, nullptr, vo, r, diag, nullptr, nullptr, incidence(), rec); }
             return;
         }
         { ScopedKernel k(ctx, "PCGInit1"); ge_vertices<T, G, 2><<<vgrid(), kBlock, 0, ctx.stream>>>(g, nullptr, vo, r, diag, nullptr, nullptr); }
         { ScopedKernel k(ctx, "PCGInit1_Graph"); ge_edges<T, G, 2><<<edgeGrid(g.nE, cus), kBlock, 0, ctx.stream>>>(g, nullptr, vo, r, diag, nullptr); }
     }
     void applyJTJ(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) override {
-        const int gv = vgrid(), ge = edgeGrid(g.nE, cus);
+        const int gv = vgrid(useGather ? GE_GATHER_LANES : 1), ge = edgeGrid(g.nE, cus);
         if (useGather) {
             { ScopedKernel k(ctx, "PCGStep1_Graph"); ge_edges<T, G, 3><<<ge, kBlock, 0, ctx.stream>>>(g, v, vo, out, nullptr, dot ? dot->partials + gv : nullptr, rec); }
-            { ScopedKernel k(ctx, "PCGStep1"); ge_vertices<T, G, 3><<<gv, kBlock, 0, ctx.stream>>>(g, v, vo, out, nullptr, CtC, dot ? dot->partials : nullptr, incidence(), rec); }
+            { ScopedKernel k(ctx, "PCGStep1"); ge_vertices<T, G, 3, GE_GATHER_LANES><<<gv, kBlock, 0, ctx.stream>>>(g, v, vo, out, nullptr, CtC, dot ? dot->partials : nullptr, incidence(), rec); }
             if (dot) dot->n = gv + ge;
             return;
         }
