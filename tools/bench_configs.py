@@ -32,6 +32,8 @@ CONFIGS = [
     ("extra cotangent_mesh_smoothing 512x512 torus float GN 5x25", lambda: wl.cotangent_mesh_smoothing(512, 512), "gaussNewtonGPU", 5, 25),
     ("extra embedded_mesh_deformation 512x512 float GN 5x125", lambda: wl.embedded_mesh_deformation(512, 512), "gaussNewtonGPU", 5, 125),
     ("extra robust_nonrigid_alignment 512x512 float GN 5x50", lambda: wl.robust_nonrigid_alignment(512, 512), "gaussNewtonGPU", 5, 50),
+    # the block-local patch solver: 4 outer steps x 16 sweeps of 16 in-LDS PCG iterations, 32x32 patches
+    ("extra poisson_image_editing 2048x2048 float patch solver 4x16", lambda: wl.poisson_image_editing(2048, 2048), "patchGaussNewtonGPU", 4, 16),
 ]
 
 
@@ -86,7 +88,7 @@ def main():
         row = {"config": name, "solver": kind, "double": P.double, "wall_s": dt, "outer_steps": steps, "cost_initial": c0, "cost_final": c1,
                "pcg_iters_per_s_nominal": steps * lit / dt, "kernel_avg_us": {k: round(v[1] / v[0] * 1e3, 2) for k, v in kt.items()},
                "pcg_iterations_in_timed_solve": pcg}
-        if with_cpu:
+        if with_cpu and not kind.startswith("patch"):
             row["cpu_port"] = cpu_port(make(), kind, min(lit, 10))
             row["gpu_over_cpu_port"] = row["pcg_iters_per_s_nominal"] / row["cpu_port"]["pcg_iters_per_s"]
         print(json.dumps(row), flush=True)
