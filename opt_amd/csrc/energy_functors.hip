@@ -117,7 +117,8 @@ struct IntrinsicE {
 // (lib.t:77-91), Select(InBounds(0,0,0), Select(InBounds(n), ., 0), 0).  UsePreconditioner(true).
 template <class T>
 struct VolumetricE {
-    static constexpr int NDIM = 3, NIMG = 2, K = 6, R = 21, NOFF = 7, NAUX = 0;
+    static constexpr int NDIM = 3, NIMG = 2, K = 6, R = 21, NOFF = 7, NAUX = 6;      // sin and cos of the three angles: every residual centre a voxel's gather
+                                                                                     // visits needs them (21 sincos per voxel per J^T J p otherwise)
     static constexpr __host__ __device__ int off(int i, int a) {
         return a == 0 ? (i == 1 ? 1 : i == 2 ? -1 : 0) : a == 1 ? (i == 3 ? 1 : i == 4 ? -1 : 0) : (i == 5 ? 1 : i == 6 ? -1 : 0);
     }
@@ -130,7 +131,11 @@ struct VolumetricE {
     const T* X[NIMG];
     const T *Ur, *Cons;
     T w_fit, w_reg; T* aux;
-    __device__ void computeAux(int, int, int, T*) const {}
+    __device__ void computeAux(int x, int y, int z, T* out) const {                   // planes 0..2 sin, 3..5 cos of Angle at the voxel
+        const long i = ((long)z * H + y) * W + x;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const T a = X[1][3 * i + k]; out[k] = sin(a); out[3 + k] = cos(a); }
+    }
     void bindParams(void** p) {
         X[0] = (const T*)p[0]; X[1] = (const T*)p[1]; Ur = (const T*)p[2]; Cons = (const T*)p[3];
         w_fit = (T) * (const float*)p[4]; w_reg = (T) * (const float*)p[5];
@@ -145,7 +150,11 @@ struct VolumetricE {
         for (int c = 0; c < 3; ++c) { const S e = w_fit * (o[c] - Cons[3 * i + c]); r[c] = valid ? e : S(T(0)); }
         // Rotate3D(Angle, v): lib.t:77-91
         const S al = Xc(3), be = Xc(4), ga = Xc(5);
-        const S ca = cos(al), cb = cos(be), cg = cos(ga), sa = sin(al), sb = sin(be), sg = sin(ga);
+        // sin / cos come from the aux planes (same values as sin(al) ... evaluated here; refreshed after every update), their partials by the chain rule
+        const long NV = (long)W * H * D;
+        const T sav = aux[i], sbv = aux[NV + i], sgv = aux[2 * NV + i], cav = aux[3 * NV + i], cbv = aux[4 * NV + i], cgv = aux[5 * NV + i];
+        const S sa = chain1(sav, cav, al), sb = chain1(sbv, cbv, be), sg = chain1(sgv, cgv, ga);
+        const S ca = chain1(cav, -sav, al), cb = chain1(cbv, -sbv, be), cg = chain1(cgv, -sgv, ga);
         const S m0 = cg * cb, m1 = -sg * ca + cg * sb * sa, m2 = sg * sa + cg * sb * ca;
         const S m3 = sg * cb, m4 = cg * ca + sg * sb * sa, m5 = -cg * sa + sg * sb * ca;
         const S m6 = -sb, m7 = cb * sa, m8 = cb * ca;

@@ -61,6 +61,11 @@ template <class T> __device__ __forceinline__ T chain2(T f, T, T, T, T) { return
 template <class T, int N> __device__ __forceinline__ Dual<T, N> chain2(T f, T fu, T fv, const Dual<T, N>& u, const Dual<T, N>& v) {
     Dual<T, N> r; r.v = f; for (int i = 0; i < N; ++i) r.d[i] = fu * u.d[i] + fv * v.d[i]; return r;
 }
+// f(u) with known value and derivative (e.g. a sine tabulated in an aux plane)
+template <class T> __device__ __forceinline__ T chain1(T f, T, T) { return f; }
+template <class T, int N> __device__ __forceinline__ Dual<T, N> chain1(T f, T fu, const Dual<T, N>& u) {
+    Dual<T, N> r; r.v = f; for (int i = 0; i < N; ++i) r.d[i] = fu * u.d[i]; return r;
+}
 template <class T> __device__ __forceinline__ T part0(T) { return T(0); }      // chain2 needs the arguments as S; scalars carry no partials
 
 // ---- accessors handed to the functor ----------------------------------------------------------------------------------
