@@ -58,7 +58,32 @@ def build(name):
     return out
 
 
+def build_patch():
+    """Block-local patch solver (oracle/patch.hpp) on a ragged-mask poisson problem: X after every outer step for both patch sizes.
+    Lives in patch/ because its schema differs from the per-energy fixtures above."""
+    from oracle.binding import poisson_patch_solve
+    W, H = 29, 23
+    P = wl.poisson_image_editing(W, H, double=True, seed=21)
+    X, T, M = [np.array(a) for a in P.params]
+    ys, xs = np.mgrid[0:H, 0:W]
+    M[:] = 255.0
+    M[(xs - 13) ** 2 + (ys - 11) ** 2 < 81] = 0.0
+    M[7:9, :] = 0.0
+    M[10, 12] = 255.0
+    out = {"X": X, "T": T, "M": M, "nIterations": np.array(3), "lIterations": np.array(5), "patchIterations": np.array(16)}
+    for ps in (16, 32):
+        Xo, costs = poisson_patch_solve(X, T, M, 3, 5, 16, ps)
+        out[f"X_final_{ps}"] = Xo
+        out[f"costs_{ps}"] = costs
+    return out
+
+
 if __name__ == "__main__":
-    for name in (sys.argv[1:] or CASES):          # optional: only the named cases
-        np.savez_compressed(os.path.join(HERE, name + ".npz"), **build(name))
+    names = sys.argv[1:] or (list(CASES) + ["patch"])          # optional: only the named cases
+    for name in names:
+        if name == "patch":
+            os.makedirs(os.path.join(HERE, "patch"), exist_ok=True)
+            np.savez_compressed(os.path.join(HERE, "patch", "poisson_patch_29x23.npz"), **build_patch())
+        else:
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **build(name))
         print("wrote", name)

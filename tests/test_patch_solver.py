@@ -160,3 +160,29 @@ def test_hip_patch_solver_is_deterministic_and_reaches_the_pcg_minimiser():
     # 64 sweeps of 32x32 blocks over a 256x256 solved region: the smooth error modes are still converging; the energy is within a few percent
     assert ca[-1] <= 1.05 * s.cost()
     assert np.array_equal(Xa[M != 0], np.array(P.params[0])[M != 0])
+
+
+# ---- committed golden vectors (tests/golden/patch, written by tests/golden/generate.py patch) -------------------------------------------------
+def _golden():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "patch", "poisson_patch_29x23.npz"))
+
+
+@pytest.mark.parametrize("patch", [16, 32])
+def test_oracle_patch_solver_reproduces_golden(oracle_lib, patch):
+    z = _golden()
+    Xo, costs = oracle_lib.poisson_patch_solve(z["X"], z["T"], z["M"], int(z["nIterations"]), int(z["lIterations"]), int(z["patchIterations"]), patch)
+    assert np.abs(Xo - z[f"X_final_{patch}"]).max() <= 1e-12 * np.abs(z["X"]).max()
+    np.testing.assert_allclose(costs, z[f"costs_{patch}"], rtol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("double", [False, True])
+@pytest.mark.parametrize("patch", [16, 32])
+def test_hip_patch_solver_matches_golden(double, patch):
+    z = _golden()
+    ft = np.float64 if double else np.float32
+    H, W = z["M"].shape
+    P = wl.Problem("poisson_image_editing", (W, H), [z["X"].astype(ft), z["T"].astype(ft), z["M"].astype(ft)], (0,), double)
+    Xh, ch, _ = _run_hip(P, int(z["nIterations"]), int(z["lIterations"]), int(z["patchIterations"]), patch)
+    assert np.abs(Xh - z[f"X_final_{patch}"]).max() <= (1e-11 if double else 3e-5) * np.abs(z["X"]).max()
+    np.testing.assert_allclose(ch, z[f"costs_{patch}"], rtol=1e-10 if double else 1e-4)
