@@ -234,7 +234,11 @@ struct GraphOps : EnergyOps<T> {
         for (int j = 0; j < G::V; ++j) incV[j] = g.vidx[j];
         incNE = g.nE; incSum = sum; incValid = true;
     }
-    void bind(void** p, LaunchCtx& ctx) override { g.bindParams(p); if (useGather) ensureIncidence(ctx); }
+    void bind(void** p, LaunchCtx& ctx) override {
+        g.bindParams(p);
+        if (useGather && (long)g.nE * G::V > 0x7fffffffL) useGather = false;      // incidence ids j * nE + e are 32-bit: beyond that, scatter
+        if (useGather) ensureIncidence(ctx);
+    }
     T* unknownPtr(int img) const override { return const_cast<T*>(g.X[img]); }
     void evalCost(Reduction& out, LaunchCtx& ctx) override {
         const int gv = vgrid(), ge = edgeGrid(g.nE, cus);
