@@ -105,3 +105,57 @@ def test_reference_energy_files_are_accepted(opt_lib):
             assert ok, f"{h}: {msg}"
             seen += 1
     assert seen >= 8
+
+
+def _prototypes(path):
+    """{name: (return type, [parameter types])} of the Opt_* declarations in a header, comments and parameter names removed."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    out = {}
+    for ret, name, args in re.findall(r"([A-Za-z_][\w\s\*]*?)\b(Opt_[A-Za-z]+)\s*\(([^)]*)\)\s*;", text):
+        def norm(t):
+            return re.sub(r"\s*\*\s*", "*", " ".join(t.split()))
+        params = []
+        for a in args.split(","):
+            a = norm(a)
+            m = re.match(r"^(.*?[\*\s])([A-Za-z_]\w*)$", a)          # drop the parameter name
+            params.append(norm(m.group(1)) if m else a)
+        out[name] = (norm(ret), params)
+    return out
+
+
+def test_prototypes_equal_the_reference_header_and_a_reference_caller_links(opt_lib, tmp_path):
+    """Source and link compatibility with the reference's own header: same return and parameter types for all ten entry points, and a
+    C caller compiled against /root/reference/API/release/include/Opt.h links against libOpt.so unchanged."""
+    ref = "/root/reference/API/release/include/Opt.h"
+    if not os.path.exists(ref):
+        pytest.skip("reference checkout not present")
+    mine = _prototypes(os.path.join(ROOT, "include", "Opt.h"))
+    theirs = _prototypes(ref)
+    assert sorted(mine) == sorted(theirs) and len(theirs) == 10
+    for name in theirs:
+        assert mine[name] == theirs[name], (name, mine[name], theirs[name])
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "caller.c"
+    src.write_text('#include "Opt.h"\n'
+                   "int main(int argc, char** argv) {\n"
+                   "  if (argc < 100) return 0;            /* never runs: the test is that it compiles and links */\n"
+                   "  struct Opt_InitializationParameters ip = {0, 0, 0, 0};\n"
+                   "  Opt_State* s = Opt_NewState(ip);\n"
+                   '  Opt_Problem* p = Opt_ProblemDefine(s, argv[1], "gaussNewtonGPU");\n'
+                   "  unsigned int dims[2] = {4, 4}; void* params[1] = {0}; int n = 1;\n"
+                   "  Opt_Plan* pl = Opt_ProblemPlan(s, p, dims);\n"
+                   '  Opt_SetSolverParameter(s, pl, "nIterations", &n);\n'
+                   "  Opt_ProblemInit(s, pl, params); while (Opt_ProblemStep(s, pl, params)) {}\n"
+                   "  Opt_ProblemSolve(s, pl, params);\n"
+                   "  double c = Opt_ProblemCurrentCost(s, pl);\n"
+                   "  Opt_PlanFree(s, pl); Opt_ProblemDelete(s, p);\n"
+                   "  return c > 0;\n}\n")
+    libdir = os.path.dirname(opt_lib.LIB_PATH)
+    r = subprocess.run(["gcc", "-I", os.path.dirname(ref), str(src), "-L", libdir, "-lOpt", "-Wl,-rpath," + libdir, "-o", str(tmp_path / "caller")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
