@@ -15,7 +15,7 @@ The same JSON line carries
                  `PCGIteration`, ONE launch per PCG iteration doing the work of the reference's PCGStep1 + PCGStep2 + PCGStep3,
                  so achieved = (48 + 96 + 36) B/pixel (SURVEY.md 8d) * pixels / average launch time, against 8 TB/s;
                  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (the kernel keeps
-                 A*p out of memory and derives the preconditioner from a flag byte: 81 B/pixel), `hbm_achieved` = traffic / time;
+                 A*p out of memory and derives the preconditioner from a flag byte: 75.8 B/pixel), `hbm_achieved` = traffic / time;
   cpu_baseline : the CPU oracle (a port, not the reference) timed on a bounded sample on the host cores.
 """
 import argparse
