@@ -1,38 +1,54 @@
 #!/usr/bin/env python
 """bench.py -- PCG iterations/s of the Gauss-Newton solve of image_warping 4096^2 (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--size 4096]
 
-A "step" is one Opt_ProblemStep: one Gauss-Newton iteration = evalJTF + `lIterations` (400, the
-reference's examples/image_warping/src/main.cpp:113-114) matrix-free PCG iterations + update + cost.
+A "step" is one Opt_ProblemStep: one Gauss-Newton iteration = evalJTF + `lIterations` (400, the reference's
+examples/image_warping/src/main.cpp:113-114) matrix-free PCG iterations + update + cost.
 value = K * lIterations / wall time of the K timed steps (max over ranks), inputs resident in HBM.
-N > 1 (launched by torch.distributed.run, one rank per GPU): the 4096^2 image is split into row slabs with 8 ghost rows;
-one 4-double all-reduce per PCG iteration and one exchange of r / p edge rows per 7 iterations over RCCL -- total work fixed
-=> "strong" scaling.
+
+N > 1: one rank per GPU.  Under torch.distributed.run (how the driver launches it) the ranks are already there; a plain
+`python bench.py --gpus N` re-executes itself under torch.distributed.run with N ranks.  The image is split into row slabs with 8
+ghost rows; per PCG iteration the ranks all-reduce four doubles (peer-mapped mailbox over xGMI, opt_amd/csrc/comm; RCCL with
+OPT_AMD_COMM=rccl) and every 7th iteration exchange 8 edge rows of r and p with each slab neighbour -- total work fixed => "strong" scaling.
+`--size 8192` is BASELINE config 5.
 
 The same JSON line carries
-  roofline     : the dominant kernel timed with hipEvents on the solver's stream.  For Gauss-Newton image_warping that is
-                 `PCGIteration`, ONE launch per PCG iteration doing the work of the reference's PCGStep1 + PCGStep2 + PCGStep3,
-                 so achieved = (48 + 96 + 36) B/pixel * pixels / average launch time, against 8 TB/s;
-                 `traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (the kernel keeps
-                 A*p out of memory and derives the preconditioner from a flag byte: 75.8 B/pixel), `hbm_achieved` = traffic / time;
-  cpu_baseline : the CPU oracle (a port, not the reference) timed on a bounded sample on the host cores.
+  roofline     : the dominant kernel (`PCGIteration`: ONE launch per PCG iteration doing the work of the reference's PCGStep1 + PCGStep2 +
+                 PCGStep3) timed with hipEvents on the solver's stream.  `achieved` = the bytes the kernel has to move (its own byte model,
+                 71 B/pixel: r, p in and out, angle, flags, delta every second launch -- DESIGN.md section 3.1) / average launch time,
+                 `frac` = achieved / 8 TB/s: a physical fraction.  `traffic` = HBM bytes per launch measured with rocprofv3 PMC passes of
+                 THIS kernel source (profiles/*_traffic.json carries the source hash; a stale file is ignored), `hbm_frac` = traffic / time / peak.
+                 `algorithmic_equiv` keeps SURVEY.md 8(d)'s scale: the reference algorithm's 180 B/pixel (three kernels) over the same time.
+  cpu_baseline : the CPU oracle (a port, not the reference) timed on a bounded sample on the host cores (rank 0, N = 1 only).
+  parity       : cost after the first step next to the frozen oracle value for this workload (tests/golden/bench_costs.json).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_PIXEL_STEP1 = 48       # PCGStep1: (2C + A_in) * 4 B, C = 3, A_in = 6  
-ALGO_BYTES_PER_PIXEL_STEP2 = 96       # PCGStep2: 8C * 4 B
-ALGO_BYTES_PER_PIXEL_STEP3 = 36       # PCGStep3: 3C * 4 B
+ALGO_BYTES_PER_PIXEL = 48 + 96 + 36   # PCGStep1 + PCGStep2 + PCGStep3 of the reference formulation
+# what iw_pcgIter2 has to move per pixel per launch, float: r 12 + p 12 in, r 12 + p 12 out, angle 4, flags 1 = 53;
+# every second launch additionally delta 12 in / 12 out and p_{k-2} 12 in = 36 -> 18 on average; general UrShape: + U 8 + M 8
+MODEL_BYTES_PER_PIXEL = {"lattice": 53 + 18, "general": 53 + 18 + 16}
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+KERNEL_SOURCES = ["opt_amd/csrc/energy_image_warping.hip", "opt_amd/csrc/solver.hip", "opt_amd/csrc/common.h", "opt_amd/csrc/energy.h", "opt_amd/build.py"]
+
+
+def kernel_src_sha16():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -43,9 +59,29 @@ def parse():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--liters", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the roofline / general-UrShape legs (profiling runs)")
     ap.add_argument("--cpu-size", type=int, default=4096)
-    ap.add_argument("--cpu-liters", type=int, default=20)
+    ap.add_argument("--cpu-liters", type=int, default=12)
+    ap.add_argument("--comm", default=os.environ.get("OPT_AMD_COMM", "peer"), choices=["peer", "rccl"])
+    ap.add_argument("--cpu-smoke", action="store_true", help="launcher check without GPUs: ranks rendezvous over gloo and report the world size")
     return ap.parse_args()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def relaunch(n):
+    """`python bench.py --gpus N` without a launcher: run N ranks of this script under torch.distributed.run."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(size, liters):
@@ -57,46 +93,88 @@ def cpu_baseline(size, liters):
     P = wl.image_warping(size, size)
     s = OracleSolver("image_warping", "gaussNewtonGPU", False, P.dims)
     s.set_threads(threads)
-    s.set("nIterations", 1); s.set("lIterations", 1)
-    W = P.clone(); s.init(W.params); s.step(W.params)          # warm-up (thread pool, page faults)
-    s.set("lIterations", liters)
+    s.set("nIterations", 1); s.set("lIterations", liters)
     s.init(P.params)
     t0 = time.perf_counter()
     s.step(P.params)
     dt = time.perf_counter() - t0
     rate = liters / dt * (size * size) / (4096.0 * 4096.0)     # scaled to 4096^2-equivalent PCG iterations/s
     return {"value": rate, "unit": "PCG iters/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (C++ port of solverGPUGaussNewton.t, {threads} OpenMP threads over row bands), image_warping {size}x{size} float, "
-                      f"1 GN step x {liters} PCG iterations, {dt:.1f} s wall incl. the step's evalJTF/update/cost; host has {cores} logical cores"}
+            "sample": f"oracle (C++ port of solverGPUGaussNewton.t: generic dual-number residuals scattered per thread band, {threads} OpenMP threads), "
+                      f"image_warping {size}x{size} float, 1 GN step x {liters} PCG iterations, {dt:.1f} s wall incl. the step's evalJTF/update/cost; "
+                      f"host has {cores} logical cores.  A stated baseline, not a tuned CPU solver: no speed-up claim is made from it"}
+
+
+def golden_cost(size, liters):
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "bench_costs.json")) as f:
+            return json.load(f)[f"image_warping_{size}x{size}_float_gaussNewtonGPU_{liters}"]["costs"]
+    except (OSError, KeyError):
+        return None
+
+
+def measured_traffic(sha):
+    """HBM bytes per launch of the iteration kernel from the newest profiles/*_traffic.json taken with this kernel source."""
+    import glob
+    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        tj = json.load(open(cand))
+        if tj.get("bench_kernel") == "PCGIteration" and tj.get("kernel_src_sha16") == sha:
+            return tj["hbm_bytes_per_launch"], os.path.basename(cand)
+    return None, None
 
 
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-    from opt_amd import api, build, workloads as wl
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(relaunch(args.gpus))
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not os.path.exists(api.LIB_PATH):
-        if rank == 0:
-            build.build()
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); they must agree")
     distributed = world > 1
+
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+
+    if args.cpu_smoke:      # launcher / rendezvous check on a box without GPUs (tests/test_slab_cpu.py)
+        if distributed:
+            dist.init_process_group("gloo")
+            t = torch.ones(1, dtype=torch.int64)
+            dist.all_reduce(t)
+            seen = int(t.item())
+            dist.destroy_process_group()
+        else:
+            seen = 1
+        if rank == 0:
+            print(json.dumps({"cpu_smoke": True, "n_gpus": world, "ranks_seen": seen}))
+        return
+
+    from opt_amd import api, build, workloads as wl
     torch.cuda.set_device(local_rank)
     if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist.barrier()
+    if rank == 0 and not os.path.exists(api.LIB_PATH):
+        build.build()
+    if distributed:
+        dist.barrier()          # nobody loads libOpt.so before rank 0 has finished building it
 
     W = H = args.size
     total_steps = args.warmup + args.steps
 
+    # CPU leg first: the GPU work then sits at the end of the run in one block
+    cpu = None
+    if rank == 0 and not distributed and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_size, args.cpu_liters)
+
+    comm_ranks = 1
     if distributed:
         from opt_amd import slab
-        job = slab.SlabJob("image_warping", W, H, rank, world)
+        job = slab.SlabJob("image_warping", W, H, rank, world, comm=args.comm)
         solver, dev = job.solver, job.params
-        comm_keep = job
+        comm_ranks = job.comm_ranks()
     else:
         P = wl.image_warping(W, H)
         dev = api.to_device(P)
@@ -111,70 +189,81 @@ def main():
             torch.cuda.synchronize()
 
     solver.init(dev)
-    cost0 = solver.cost()
+    costs = [solver.cost()]
     for _ in range(args.warmup):
         solver.step(dev)
+        costs.append(solver.cost())
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         solver.step(dev)
+        if len(costs) < 3:
+            costs.append(solver.cost())      # a host-side read of a stored scalar: no device work
     sync()
     dt = time.perf_counter() - t0
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    cost1 = solver.cost()
+    cost_final = solver.cost()
     value = args.steps * args.liters / dt
 
-    # ---- roofline leg: per-kernel hipEvent timing of PCGStep1 (applyJTJ) on the solver's stream ----------
-    roofline = None
-    if not distributed:
+    gold = golden_cost(W, args.liters)
+    parity = None
+    if gold is not None and len(costs) >= 2:
+        n = min(len(costs), len(gold))
+        parity = {"cost_hip": costs[:n], "cost_oracle_frozen": gold[:n],
+                  "rel_err": [abs(a - b) / abs(b) for a, b in zip(costs[:n], gold[:n])], "tolerance": 1e-5,
+                  "source": "tests/golden/bench_costs.json (oracle, float, generated offline by tests/golden/make_bench_cost.py)"}
+        parity["ok"] = all(e <= 1e-5 for e in parity["rel_err"])
+
+    # ---- roofline leg: per-kernel hipEvent timing on the solver's stream, and the general-UrShape path beside it ----------
+    roofline, general = None, None
+    sha = kernel_src_sha16()
+    if not distributed and not args.no_extras:
         solver.close()
+        del dev
         P2 = wl.image_warping(W, H)
         dev2 = api.to_device(P2)
         ts = api.Solver(api.energy_file("image_warping"), "gaussNewtonGPU", (W, H), timing=True)
-        ts.set_parameter("nIterations", 2); ts.set_parameter("lIterations", 100)
+        ts.set_parameter("nIterations", 2); ts.set_parameter("lIterations", args.liters)
         ts.init(dev2); ts.step(dev2); ts.step(dev2)
         torch.cuda.synchronize()
         kt = ts.kernel_timings()
-        # the dominant kernel is applyJTJ; when the previous iteration's PCGStep3 is fused into it, one launch
-        # does the algorithmic work of both reference kernels (48 + 36 B/pixel)
-        if "PCGIteration" in kt:      # the whole iteration in one launch: PCGStep2 + PCGStep3 of iteration k-1, PCGStep1 of iteration k
-            kname, algo = "PCGIteration", ALGO_BYTES_PER_PIXEL_STEP1 + ALGO_BYTES_PER_PIXEL_STEP2 + ALGO_BYTES_PER_PIXEL_STEP3
-        elif "PCGStep3+PCGStep1" in kt:
-            kname, algo = "PCGStep3+PCGStep1", ALGO_BYTES_PER_PIXEL_STEP1 + ALGO_BYTES_PER_PIXEL_STEP3
-        else:
-            kname, algo = "PCGStep1", ALGO_BYTES_PER_PIXEL_STEP1
+        kname = "PCGIteration"
         cnt, tot = kt[kname]
-        avg_ms = tot / cnt
-        achieved = algo * W * H / (avg_ms * 1e-3) / 1e9
-        per_iter = {k: v[1] / v[0] for k, v in kt.items()}
-        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-        # separate runs of this command, FETCH_SIZE doubled per MI355X_MICROARCH.md; tools/summarize_profile.py)
-        traffic, traffic_src = None, None
-        if W == 4096:
-            import glob
-            for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
-                tj = json.load(open(cand))
-                if tj.get("bench_kernel", "PCGStep3+PCGStep1") == kname:
-                    traffic, traffic_src = tj["hbm_bytes_per_launch"], os.path.basename(cand)
-                    break
-        # `achieved` / `frac` follow SURVEY.md 8(d): the reference algorithm's bytes (three kernels, 180 B/pixel) over this kernel's time,
-        # so a kernel that moves fewer bytes than the reference algorithm can exceed the HBM peak on that scale; `hbm_achieved` /
-        # `hbm_frac` are the kernel's REAL HBM traffic (PMC) over the same time -- the number that cannot exceed 1.
-        hbm_achieved = traffic / (avg_ms * 1e-3) / 1e9 if traffic else None
-        roofline = {"bound": "hbm", "kernel": kname + " (PCGStep1+2+3 in one launch)" if kname == "PCGIteration" else kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+        avg_s = tot / cnt * 1e-3
+        model = MODEL_BYTES_PER_PIXEL["lattice"]
+        achieved = model * W * H / avg_s / 1e9
+        traffic, traffic_src = measured_traffic(sha) if W == 4096 else (None, None)
+        hbm_achieved = traffic / avg_s / 1e9 if traffic else None
+        algo = ALGO_BYTES_PER_PIXEL * W * H / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": "PCGIteration = iw_pcgIter2 (PCGStep1+2+3 in one launch)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "hbm_achieved": hbm_achieved, "hbm_frac": hbm_achieved / HBM_PEAK_GBS if hbm_achieved else None,
-                    "avg_kernel_ms": avg_ms, "launches": cnt,
-                    "algorithmic_bytes_per_pixel": algo, "algorithmic_bytes_per_launch": algo * W * H,
-                    "kernel_avg_ms": per_iter}
+                    "avg_kernel_ms": avg_s * 1e3, "launches": cnt, "model_bytes_per_pixel": model, "model_bytes_per_launch": model * W * H,
+                    "algorithmic_equiv": {"bytes_per_pixel": ALGO_BYTES_PER_PIXEL, "bytes_per_launch": ALGO_BYTES_PER_PIXEL * W * H,
+                                          "achieved": algo, "ratio_to_peak": algo / HBM_PEAK_GBS,
+                                          "note": "reference formulation (3 kernels, SURVEY 8d) over this kernel's time; not a physical fraction"},
+                    "kernel_avg_ms": {k: v[1] / v[0] for k, v in kt.items()}}
         ts.close()
-
-    cpu = None
-    if rank == 0 and not distributed and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.cpu_size, args.cpu_liters)
+        # the general kernel (arbitrary UrShape: + U and a compact preconditioner, 87 B/pixel) on the same input
+        os.environ["OPT_AMD_LATTICE"] = "0"
+        P3 = wl.image_warping(W, H)
+        dev3 = api.to_device(P3)
+        gs = api.Solver(api.energy_file("image_warping"), "gaussNewtonGPU", (W, H))
+        gs.set_parameter("nIterations", 4); gs.set_parameter("lIterations", args.liters)
+        gs.init(dev3); gs.step(dev3)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            gs.step(dev3)
+        torch.cuda.synchronize()
+        gdt = time.perf_counter() - t1
+        general = {"value": 3 * args.liters / gdt, "unit": "PCG iters/s", "model_bytes_per_pixel": MODEL_BYTES_PER_PIXEL["general"],
+                   "note": "same workload with the unit-lattice specialisation switched off (OPT_AMD_LATTICE=0): the path any other UrShape takes"}
+        gs.close()
+        del os.environ["OPT_AMD_LATTICE"]
 
     if rank == 0:
         out = {"metric": "PCG iters/s, GN solve of image_warping 4096^2", "value": value, "unit": "PCG iters/s", "n_gpus": world,
@@ -182,13 +271,14 @@ def main():
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"image_warping {W}x{H} float, gaussNewtonGPU, {args.liters} PCG iterations per GN step "
                                       "(synthetic cat512-style constraints, border pinned)",
-                          "parallelism": f"row-slabs x{world}" if distributed else "single GPU",
+                          "parallelism": f"row-slabs x{world}, comm={args.comm}, ranks in the communicator: {comm_ranks}" if distributed else "single GPU",
                           "step": "one Opt_ProblemStep (1 GN iteration)"},
                "gn_solve_ms_8_steps": dt / args.steps * 8 * 1e3,
-               "cost_initial": cost0, "cost_final": cost1,
-               "roofline": roofline, "cpu_baseline": cpu}
+               "cost_initial": costs[0], "cost_final": cost_final, "parity": parity, "comm_ranks": comm_ranks,
+               "kernel_src_sha16": sha, "roofline": roofline, "general_urshape": general, "cpu_baseline": cpu}
         print(json.dumps(out))
     if distributed:
+        job.close()
         dist.destroy_process_group()
 
 

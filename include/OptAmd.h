@@ -87,6 +87,10 @@ typedef struct OptAmd_SlabComm {
                          const long* bytes, void* stream);
     /* in-place sum all-reduce of n doubles in device memory */
     void (*allReduceSum)(void* ctx, double* deviceBuf, int n, void* stream);
+    /* Optional (may be NULL): the same all-reduce fed with per-workgroup partial sums -- value i = sum over ranks of
+     * sum(partials[i][0 .. counts[i])) -- written to out[0 .. n) on every rank; lets an implementation fold the local
+     * reduction into its own kernel (one launch between two PCG iterations instead of two).  n <= 8. */
+    void (*allReducePartials)(void* ctx, const double* const* partials, const int* counts, int n, double* out, void* stream);
 } OptAmd_SlabComm;
 /* Attach a slab description to a plan created with dims {W, rows + 2*g}: g >= 1 ghost rows above and below the `rows` owned
  * rows (g is inferred from the plan's height).  g = 1 is enough for every kernel set; with g >= 2 image_warping runs its

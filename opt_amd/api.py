@@ -34,11 +34,12 @@ class Opt_InitializationParameters(ctypes.Structure):
 HALO_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                            ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_long), ctypes.c_void_p)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
+ALLREDUCE_PARTIALS_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 
 
 class OptAmd_SlabComm(ctypes.Structure):
     _fields_ = [("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("world", ctypes.c_int),
-                ("haloExchange", HALO_FN), ("allReduceSum", ALLREDUCE_FN)]
+                ("haloExchange", HALO_FN), ("allReduceSum", ALLREDUCE_FN), ("allReducePartials", ALLREDUCE_PARTIALS_FN)]
 
 
 def lib():

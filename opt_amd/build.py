@@ -103,10 +103,12 @@ COMM_LIB = os.path.join(LIBDIR, "libOptComm.so")
 
 
 def build_comm(force=False, verbose=False):
-    """libOptComm.so: the RCCL / in-process implementations of OptAmd_SlabComm (multi-GPU slab tiling)."""
+    """libOptComm.so: the peer-mailbox (HIP kernels over IPC-mapped windows), RCCL and in-process implementations of
+    OptAmd_SlabComm (multi-GPU slab tiling)."""
     src = os.path.join(CSRC, "comm", "opt_comm.cpp")
-    if force or not os.path.exists(COMM_LIB) or os.path.getmtime(COMM_LIB) < max(os.path.getmtime(src), _deps_mtime()):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", COMM_LIB, src, "-L/opt/rocm/lib", "-lrccl", "-lpthread"]
+    peer = os.path.join(CSRC, "comm", "peer_comm.hip")
+    if force or not os.path.exists(COMM_LIB) or os.path.getmtime(COMM_LIB) < max(os.path.getmtime(src), os.path.getmtime(peer), _deps_mtime()):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", COMM_LIB, src, "-x", "hip", peer, "-L/opt/rocm/lib", "-lrccl", "-lpthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

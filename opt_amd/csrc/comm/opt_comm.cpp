@@ -6,6 +6,7 @@
 // touches the host.
 //   * "rccl"   : ncclSend/ncclRecv pairs (grouped) for the halo rows, ncclAllReduce for the sums.  One process
 //                per GPU; the communicator is created from a unique id that the launcher broadcasts.
+//   * "peer"   : peer-mapped mailboxes written by small kernels (peer_comm.hip) -- the default of bench.py --gpus N.
 //   * "threads": all ranks are threads of ONE process sharing ONE device (test harness for single-GPU boxes):
 //                rows are copied device-to-device, sums go through the host, std::barrier-style rendezvous.
 #include "../../../include/OptAmd.h"
@@ -100,17 +101,18 @@ void* OptComm_CreateRccl(const char* uniqueId, int rank, int world) {
     auto* x = new RcclCtx; x->rank = rank; x->world = world;
     ncclUniqueId id; memcpy(&id, uniqueId, sizeof(id));
     CK_NCCL(ncclCommInitRank(&x->comm, world, id, rank));
-    x->api = OptAmd_SlabComm{x, rank, world, rcclHalo, rcclAllReduce};
+    x->api = OptAmd_SlabComm{x, rank, world, rcclHalo, rcclAllReduce, nullptr};
     return x;
 }
 const OptAmd_SlabComm* OptComm_RcclSlabComm(void* c) { return &((RcclCtx*)c)->api; }
+int OptComm_RcclCount(void* c) { int n = 0; if (ncclCommCount(((RcclCtx*)c)->comm, &n) != ncclSuccess) return -1; return n; }   // ranks RCCL itself sees
 void OptComm_DestroyRccl(void* c) { auto* x = (RcclCtx*)c; ncclCommDestroy(x->comm); delete x; }
 
 void* OptComm_CreateThreadWorld(int world) { return new ThreadWorld(world); }
 void OptComm_DestroyThreadWorld(void* w) { delete (ThreadWorld*)w; }
 void* OptComm_CreateThreadRank(void* world, int rank) {
     auto* x = new ThreadCtx; x->W = (ThreadWorld*)world; x->rank = rank;
-    x->api = OptAmd_SlabComm{x, rank, x->W->world, thrHalo, thrAllReduce};
+    x->api = OptAmd_SlabComm{x, rank, x->W->world, thrHalo, thrAllReduce, nullptr};
     return x;
 }
 const OptAmd_SlabComm* OptComm_ThreadSlabComm(void* c) { return &((ThreadCtx*)c)->api; }

@@ -1,0 +1,304 @@
+// "peer" implementation of OptAmd_SlabComm: peer-mapped mailboxes over xGMI instead of RCCL collectives.
+//
+// Why: the PCG loop's inter-GPU traffic is one sum of four doubles per iteration plus a few hundred KiB of edge rows every
+// 7th iteration.  At 8 slabs of 4096^2 the iteration kernel takes ~35 us, so the loop is bound by the
+// latency of whatever sits between two launches; an ncclAllReduce of 32 bytes costs a kernel launch plus a multi-hop
+// protocol.  Here every rank maps every other rank's window (hipIpc handles, one process per GPU) and
+//   * all-reduce = ONE small kernel: sum this rank's per-workgroup partials, store the totals into every peer's mailbox slot
+//     (direct peer stores over the pair's own xGMI link), publish a sequence number, spin on the local mailbox until all
+//     ranks' sequence numbers arrived, add the contributions in rank order (deterministic, same bits on every rank);
+//   * halo exchange = two kernels: push my edge rows into the neighbours' staging buffers + publish, then wait for the
+//     neighbours' rows in my own staging buffers and copy them into the ghost rows + acknowledge (double-buffered staging).
+// No host involvement inside the loop.  Every spin carries a wall-clock timeout that raises an error flag in pinned host
+// memory instead of hanging the GPU; the host side checks the flag at every call.
+//
+// The reference has no multi-GPU path; this is north_star work.
+#include "../../../include/OptAmd.h"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#define CK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "OptComm(peer): HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+namespace {
+
+constexpr int kMaxWorld = 16;
+constexpr int kSlots = 4;          // mailbox slots (2 would do: a rank can be at most one all-reduce ahead of any peer)
+constexpr int kMaxVals = 8;        // doubles per all-reduce
+constexpr int kStageDepth = 2;
+typedef unsigned long long u64;
+
+// One per rank, in device memory of that rank, mapped by every peer.  Only 8-byte words are used for signalling.
+struct Window {
+    u64 mailSeq[kSlots][kMaxWorld];            // [slot][source rank] = sequence number of the contribution stored there
+    double mail[kSlots][kMaxWorld][kMaxVals];
+    u64 haloSeq[2];                            // [0]: last exchange pushed by the rank above, [1]: by the rank below
+    u64 haloAck[2];                            // [0]: last exchange of MINE the rank above has consumed, [1]: the rank below
+    u64 pad[4];
+    // followed by staging[2 sides][kStageDepth][stageBytes]
+};
+
+struct PeerCtx {
+    int rank, world;
+    Window* win[kMaxWorld];        // win[rank] = my own window, others IPC-mapped
+    char* stage[kMaxWorld];        // staging area behind each window
+    size_t stageBytes;             // per side and depth
+    void* base;                    // my allocation
+    hipIpcMemHandle_t handle;
+    u64 arSeq, haloSeq;
+    unsigned int* dCounter;        // last-block counters of the copy kernels
+    volatile int* hostErr;         // pinned, device-visible
+    long long timeoutTicks;        // wall_clock64 ticks (100 MHz)
+    int memKind;                   // 3 uncached, 1 fine-grained, 0 plain hipMalloc
+    OptAmd_SlabComm api;
+};
+
+__device__ __forceinline__ u64 ldSys(const u64* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void stSys(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double ldSysD(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load((const u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+__device__ __forceinline__ void stSysD(double* p, double v) { __hip_atomic_store((u64*)p, (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// spin until *p >= want or the wall clock runs out; returns false on timeout
+__device__ __forceinline__ bool waitAtLeast(const u64* p, u64 want, long long timeoutTicks) {
+    if (ldSys(p) >= want) return true;
+    const long long t0 = wall_clock64();
+    while (ldSys(p) < want) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > timeoutTicks) return false;
+    }
+    return true;
+}
+
+struct Peers { Window* win[kMaxWorld]; };
+
+struct PartialsIn { const double* p[kMaxVals]; int n[kMaxVals]; };
+
+// ---- all-reduce: one workgroup of 256 threads --------------------------------------------------------------------------------------
+// `in` != nullptr semantics: if parts.p[i] is set, value i = sum of parts.n[i] partials (fixed order); else value i = buf[i].
+__global__ __launch_bounds__(256) void k_mailAllReduce(double* __restrict__ buf, PartialsIn parts, int usePartials, int n, Peers P, int rank, int world, u64 seq,
+                                                       long long timeoutTicks, volatile int* hostErr) {
+    __shared__ double vals[kMaxVals];
+    __shared__ double wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (usePartials) {
+        for (int i = 0; i < n; ++i) {
+            double t = 0;
+            for (int k = tid; k < parts.n[i]; k += 256) t += parts.p[i][k];
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+            if (lane == 0) wsum[wave] = t;
+            __syncthreads();
+            if (tid == 0) vals[i] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+            __syncthreads();
+        }
+    } else {
+        if (tid < n) vals[tid] = buf[tid];
+        __syncthreads();
+    }
+    const int slot = (int)(seq % kSlots);
+    if (tid < world) {                                   // thread t serves peer t: post my contribution there, then wait for t's here
+        Window* w = P.win[tid];
+        for (int i = 0; i < n; ++i) stSysD(&w->mail[slot][rank][i], vals[i]);
+        __threadfence_system();
+        stSys(&w->mailSeq[slot][rank], seq);
+        if (!waitAtLeast(&P.win[rank]->mailSeq[slot][tid], seq, timeoutTicks)) *hostErr = 1;
+    }
+    __syncthreads();
+    if (tid < n) {
+        const Window* me = P.win[rank];
+        double t = 0;
+        for (int r = 0; r < world; ++r) t += ldSysD(&me->mail[slot][r][tid]);     // rank order: identical bits on every rank
+        buf[tid] = t;
+    }
+}
+
+// ---- halo exchange -------------------------------------------------------------------------------------------------------------------
+struct HaloArgs {
+    int nb;
+    const char* sendUp[8]; const char* sendDown[8]; char* recvUp[8]; char* recvDown[8];
+    long bytes[8], offset[8];      // offset of buffer k inside a staging block
+};
+__device__ __forceinline__ void copyBytes(char* dst, const char* src, long bytes, int tid, int nthreads) {   // all pointers and sizes are multiples of 4 B; 16 B when aligned
+    if ((((size_t)dst | (size_t)src | (size_t)bytes) & 15) == 0) {
+        const uint4* s = (const uint4*)src; uint4* d = (uint4*)dst;
+        for (long i = tid; i < bytes / 16; i += nthreads) d[i] = s[i];
+    } else {
+        const unsigned* s = (const unsigned*)src; unsigned* d = (unsigned*)dst;
+        for (long i = tid; i < bytes / 4; i += nthreads) d[i] = s[i];
+    }
+}
+// push: my first owned rows -> the staging block "from below" of the rank above; my last owned rows -> "from above" of the rank below
+__global__ __launch_bounds__(256) void k_haloPush(HaloArgs H, Peers P, char* stageUp, char* stageDown, int rank, int world, u64 seq, unsigned int* counter,
+                                                  long long timeoutTicks, volatile int* hostErr) {
+    const bool up = rank > 0, down = rank < world - 1;
+    // the staging block of exchange `seq` was last used by exchange seq - kStageDepth: the neighbour must have consumed that one
+    if (threadIdx.x == 0 && seq > kStageDepth) {
+        if (up && !waitAtLeast(&P.win[rank]->haloAck[0], seq - kStageDepth, timeoutTicks)) *hostErr = 2;
+        if (down && !waitAtLeast(&P.win[rank]->haloAck[1], seq - kStageDepth, timeoutTicks)) *hostErr = 2;
+    }
+    __syncthreads();
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    for (int k = 0; k < H.nb; ++k) {
+        if (up) copyBytes(stageUp + H.offset[k], H.sendUp[k], H.bytes[k], tid, nt);
+        if (down) copyBytes(stageDown + H.offset[k], H.sendDown[k], H.bytes[k], tid, nt);
+    }
+    __threadfence_system();
+    __syncthreads();
+    __shared__ bool last;
+    if (threadIdx.x == 0) last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        *counter = 0;
+        __threadfence_system();
+        if (up) stSys(&P.win[rank - 1]->haloSeq[1], seq);        // I am the rank below my upper neighbour
+        if (down) stSys(&P.win[rank + 1]->haloSeq[0], seq);
+    }
+}
+// pull: wait for the neighbours' rows in my staging blocks, copy them into the ghost rows, acknowledge
+__global__ __launch_bounds__(256) void k_haloPull(HaloArgs H, Peers P, const char* fromUp, const char* fromDown, int rank, int world, u64 seq, unsigned int* counter,
+                                                  long long timeoutTicks, volatile int* hostErr) {
+    const bool up = rank > 0, down = rank < world - 1;
+    if (threadIdx.x == 0) {
+        if (up && !waitAtLeast(&P.win[rank]->haloSeq[0], seq, timeoutTicks)) *hostErr = 3;
+        if (down && !waitAtLeast(&P.win[rank]->haloSeq[1], seq, timeoutTicks)) *hostErr = 3;
+    }
+    __syncthreads();
+    __threadfence_system();      // every thread acquires what thread 0 waited for
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    for (int k = 0; k < H.nb; ++k) {
+        if (up) copyBytes(H.recvUp[k], fromUp + H.offset[k], H.bytes[k], tid, nt);
+        if (down) copyBytes(H.recvDown[k], fromDown + H.offset[k], H.bytes[k], tid, nt);
+    }
+    __threadfence();
+    __syncthreads();
+    __shared__ bool last;
+    if (threadIdx.x == 0) last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        *counter = 0;
+        if (up) stSys(&P.win[rank - 1]->haloAck[1], seq);
+        if (down) stSys(&P.win[rank + 1]->haloAck[0], seq);
+    }
+}
+
+void checkErr(PeerCtx* x, const char* where) {
+    const int e = *x->hostErr;
+    if (e) {
+        fprintf(stderr, "OptComm(peer) rank %d: timeout waiting for a peer (%s; code %d: 1 = all-reduce, 2 = halo ack, 3 = halo rows) -- a rank died or fell out of step\n",
+                x->rank, where, e);
+        exit(3);
+    }
+}
+Peers peersOf(PeerCtx* x) { Peers P; for (int r = 0; r < kMaxWorld; ++r) P.win[r] = x->win[r]; return P; }
+
+void peerAllReduceImpl(PeerCtx* x, double* buf, const PartialsIn* parts, int n, hipStream_t s) {
+    checkErr(x, "allReduce");
+    if (n > kMaxVals) { fprintf(stderr, "OptComm(peer): all-reduce of %d > %d doubles\n", n, kMaxVals); exit(1); }
+    PartialsIn pin{}; if (parts) pin = *parts;
+    ++x->arSeq;
+    k_mailAllReduce<<<1, 256, 0, s>>>(buf, pin, parts ? 1 : 0, n, peersOf(x), x->rank, x->world, x->arSeq, x->timeoutTicks, x->hostErr);
+    CK_HIP(hipGetLastError());
+}
+void peerAllReduce(void* c, double* buf, int n, void* stream) { peerAllReduceImpl((PeerCtx*)c, buf, nullptr, n, (hipStream_t)stream); }
+void peerAllReducePartials(void* c, const double* const* parts, const int* counts, int n, double* out, void* stream) {
+    PartialsIn pin{};
+    for (int i = 0; i < n && i < kMaxVals; ++i) { pin.p[i] = parts[i]; pin.n[i] = counts[i]; }
+    peerAllReduceImpl((PeerCtx*)c, out, &pin, n, (hipStream_t)stream);
+}
+void peerHalo(void* c, int nb, const void* const* su, const void* const* sd, void* const* ru, void* const* rd, const long* bytes, void* stream) {
+    auto* x = (PeerCtx*)c; hipStream_t s = (hipStream_t)stream;
+    checkErr(x, "haloExchange");
+    if (x->world == 1) return;
+    if (nb > 8) { fprintf(stderr, "OptComm(peer): %d > 8 buffers in one exchange\n", nb); exit(1); }
+    HaloArgs H{}; H.nb = nb;
+    long off = 0;
+    for (int k = 0; k < nb; ++k) {
+        H.sendUp[k] = (const char*)su[k]; H.sendDown[k] = (const char*)sd[k]; H.recvUp[k] = (char*)ru[k]; H.recvDown[k] = (char*)rd[k];
+        H.bytes[k] = bytes[k]; H.offset[k] = off; off += (bytes[k] + 15) / 16 * 16;
+    }
+    if ((size_t)off > x->stageBytes) { fprintf(stderr, "OptComm(peer): exchange of %ld bytes per side exceeds the staging capacity %zu (OptComm_PeerCreate)\n", off, x->stageBytes); exit(1); }
+    const u64 seq = ++x->haloSeq;
+    const size_t blk = (size_t)(seq % kStageDepth) * x->stageBytes;
+    // staging layout behind every window: [side 0 = rows coming from the rank above][side 1 = from the rank below], each kStageDepth blocks
+    char* stageUp = x->rank > 0 ? x->stage[x->rank - 1] + (size_t)kStageDepth * x->stageBytes + blk : nullptr;      // I am "below" for the rank above
+    char* stageDown = x->rank < x->world - 1 ? x->stage[x->rank + 1] + blk : nullptr;                                // I am "above" for the rank below
+    const char* fromUp = x->stage[x->rank] + blk;
+    const char* fromDown = x->stage[x->rank] + (size_t)kStageDepth * x->stageBytes + blk;
+    const int grid = (int)std::max<long>(1, std::min<long>(64, off / (256 * 16) + 1));
+    k_haloPush<<<grid, 256, 0, s>>>(H, peersOf(x), stageUp, stageDown, x->rank, x->world, seq, x->dCounter, x->timeoutTicks, x->hostErr);
+    k_haloPull<<<grid, 256, 0, s>>>(H, peersOf(x), fromUp, fromDown, x->rank, x->world, seq, x->dCounter + 1, x->timeoutTicks, x->hostErr);
+    CK_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+extern "C" {
+
+int OptComm_PeerHandleBytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+int OptComm_PeerMaxWorld(void) { return kMaxWorld; }
+
+// Phase 1 (every rank, its own GPU current): allocate the window + staging (stageBytes per side and depth), export its IPC handle.
+void* OptComm_PeerCreate(int rank, int world, long stageBytes, double timeoutSeconds) {
+    if (world > kMaxWorld || rank < 0 || rank >= world) { fprintf(stderr, "OptComm(peer): world %d > %d\n", world, kMaxWorld); return nullptr; }
+    auto* x = new PeerCtx();
+    x->rank = rank; x->world = world; x->stageBytes = (size_t)((stageBytes + 255) / 256 * 256);
+    const size_t total = (sizeof(Window) + 255) / 256 * 256 + 2 * (size_t)kStageDepth * x->stageBytes;
+    // uncached device memory: peers' stores and our polling loads bypass the local caches (what RCCL uses for its own flags);
+    // fall back to fine-grained, then plain device memory (loads/stores above are system-scope atomics either way)
+    x->memKind = -1;
+    if (const char* e = getenv("OPT_AMD_PEER_MEM")) x->memKind = atoi(e);
+    // (plain hipMalloc memory -- OPT_AMD_PEER_MEM=0, experiments only -- may be cached in a reader's L2 and is not tried by default)
+    const int kinds[3] = {hipDeviceMallocUncached, hipDeviceMallocFinegrained, 0};
+    for (int k : kinds) {
+        if (x->memKind >= 0 ? k != x->memKind : k == 0) continue;
+        hipError_t e = k ? hipExtMallocWithFlags(&x->base, total, k) : hipMalloc(&x->base, total);
+        if (e == hipSuccess) {
+            if (hipIpcGetMemHandle(&x->handle, x->base) == hipSuccess) { x->memKind = k; break; }
+            (void)hipFree(x->base);
+        }
+        (void)hipGetLastError();
+        x->base = nullptr;
+    }
+    if (!x->base) { fprintf(stderr, "OptComm(peer): could not allocate an IPC-exportable window (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)\n"); delete x; return nullptr; }
+    CK_HIP(hipMemset(x->base, 0, total));
+    CK_HIP(hipDeviceSynchronize());
+    x->win[rank] = (Window*)x->base;
+    x->stage[rank] = (char*)x->base + (sizeof(Window) + 255) / 256 * 256;
+    CK_HIP(hipMalloc((void**)&x->dCounter, 2 * sizeof(unsigned int)));
+    CK_HIP(hipMemset(x->dCounter, 0, 2 * sizeof(unsigned int)));
+    CK_HIP(hipHostMalloc((void**)&x->hostErr, sizeof(int), hipHostMallocMapped));
+    *x->hostErr = 0;
+    x->timeoutTicks = (long long)((timeoutSeconds > 0 ? timeoutSeconds : 20.0) * 1e8);       // wall_clock64 runs at 100 MHz
+    x->api = OptAmd_SlabComm{x, rank, world, peerHalo, peerAllReduce, peerAllReducePartials};
+    return x;
+}
+void OptComm_PeerHandle(void* c, char* out) { memcpy(out, &((PeerCtx*)c)->handle, sizeof(hipIpcMemHandle_t)); }
+int OptComm_PeerMemKind(void* c) { return ((PeerCtx*)c)->memKind; }
+// Phase 2 (after the handles of all ranks were gathered, rank-major): map every peer's window.
+int OptComm_PeerConnect(void* c, const char* allHandles) {
+    auto* x = (PeerCtx*)c;
+    for (int r = 0; r < x->world; ++r) {
+        if (r == x->rank) continue;
+        hipIpcMemHandle_t h; memcpy(&h, allHandles + (size_t)r * sizeof(h), sizeof(h));
+        void* p = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { fprintf(stderr, "OptComm(peer) rank %d: hipIpcOpenMemHandle(rank %d) failed: %s\n", x->rank, r, hipGetErrorString(e)); return 0; }
+        x->win[r] = (Window*)p;
+        x->stage[r] = (char*)p + (sizeof(Window) + 255) / 256 * 256;
+    }
+    return 1;
+}
+const OptAmd_SlabComm* OptComm_PeerSlabComm(void* c) { return &((PeerCtx*)c)->api; }
+int OptComm_PeerError(void* c) { return *((PeerCtx*)c)->hostErr; }
+// Callers must make sure (barrier) that no peer still uses this rank's window.
+void OptComm_PeerDestroy(void* c) {
+    auto* x = (PeerCtx*)c;
+    (void)hipDeviceSynchronize();
+    for (int r = 0; r < x->world; ++r) if (r != x->rank && x->win[r]) (void)hipIpcCloseMemHandle(x->win[r]);
+    (void)hipFree(x->base); (void)hipFree(x->dCounter); (void)hipHostFree((void*)x->hostErr);
+    delete x;
+}
+
+}  // extern "C"

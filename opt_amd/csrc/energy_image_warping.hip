@@ -489,7 +489,9 @@ __global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter(IWArgs<
         const double s2 = sumPartials(K.s2Prev, K.n2, scratch), s3 = sumPartials(K.s3Prev, K.n3, scratch);
         const T aNum = (T)aNumD, aDen = (T)aDenD;
         alpha = (aDen > T(0)) ? aNum / aDen : T(0);
-        const double bNumD = aNumD - 2.0 * (double)alpha * s2 + (double)alpha * (double)alpha * s3;
+        // betaNumerator = sum M r_k^2 by expansion (energy.h); the reference's direct sum cannot be negative, so cancellation
+        // noise below zero (residual dropping by >~1e3 in one iteration) is clamped away
+        const double bNumD = fmax(aNumD - 2.0 * (double)alpha * s2 + (double)alpha * (double)alpha * s3, 0.0);
         beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
     }
     const int bx = blockIdx.x % gx, by = blockIdx.x / gx;
@@ -673,7 +675,9 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
         const double s2 = sumPartials(K.s2Prev, K.n2, scratch), s3 = sumPartials(K.s3Prev, K.n3, scratch);
         const T aNum = (T)aNumD, aDen = (T)aDenD;
         alpha = (aDen > T(0)) ? aNum / aDen : T(0);
-        const double bNumD = aNumD - 2.0 * (double)alpha * s2 + (double)alpha * (double)alpha * s3;
+        // betaNumerator = sum M r_k^2 by expansion (energy.h); the reference's direct sum cannot be negative, so cancellation
+        // noise below zero (residual dropping by >~1e3 in one iteration) is clamped away
+        const double bNumD = fmax(aNumD - 2.0 * (double)alpha * s2 + (double)alpha * (double)alpha * s3, 0.0);
         beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
     }
     if (K.alphaOut && blockIdx.x == 0 && threadIdx.x == 0) *K.alphaOut = alpha;
@@ -911,6 +915,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_SLAB_PERIOD")) maxExchangePeriod = std::max(1, atoi(e));
         if (const char* e = getenv("OPT_AMD_FLAG_M")) flagPreconditioner = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_PAIR_DELTA")) pairDelta = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_ITER_ROWS")) forceRows = std::max(0, atoi(e));
         HIP_CHECK(hipMalloc((void**)&dNotLattice, sizeof(int)));
     }
     ~ImageWarpingOps() override { (void)hipFree(A.flags); (void)hipFree(A.cs); if (mc) (void)hipFree(mc); if (alphaSlots) (void)hipFree(alphaSlots); (void)hipFree(dNotLattice); }
@@ -946,6 +951,16 @@ struct ImageWarpingOps : EnergyOps<T> {
         { ScopedKernel k(ctx, "PCGInit1"); iw_evalJTF<T><<<g, kBlock, 0, ctx.stream>>>(A, r, diag); }
     }
     int xcdMap = 0;                                    // OPT_AMD_XCD=0 disables the XCD-aware workgroup mapping (A/B switch)
+    // OPT_AMD_ITER_ROWS=R: every row-marching workgroup takes R rows (fewer if the image is shorter) instead of rows / (co-resident
+    // row groups).  The kernels have no inter-workgroup synchronisation, so any split is valid; the switch exists so that small test
+    // images run the marching loop in the regime of the benchmark (4096^2: 98 rows per workgroup) -- tests/test_steady_state_gpu.py.
+    int forceRows = 0;
+    void splitRows(int rows, int gx, int target, int& gy, int& rowsPerGroup) const {
+        gy = std::max(1, std::min(std::min(rows, target / gx), kMaxPartials / gx));
+        rowsPerGroup = divUp(rows, gy);
+        if (forceRows > 0) rowsPerGroup = std::max(divUp(rows, std::max(1, kMaxPartials / gx)), std::min(rows, forceRows));
+        gy = divUp(rows, rowsPerGroup);
+    }
     int occ[2][2] = {{0, 0}, {0, 0}};
     int blocksPerCU(bool lmv, bool fused) {
         int& o = occ[lmv][fused];
@@ -963,9 +978,8 @@ struct ImageWarpingOps : EnergyOps<T> {
         const int gx = divUp(A.W, kStrip);
         const int rows = A.yEnd - A.yBegin;
         const int target = cus * blocksPerCU(CtC != nullptr, fuse != nullptr);
-        int gy = std::max(1, std::min(std::min(rows, target / gx), kMaxPartials / gx));
-        const int rowsPerGroup = divUp(rows, gy);
-        gy = divUp(rows, rowsPerGroup);
+        int gy, rowsPerGroup;
+        splitRows(rows, gx, target, gy, rowsPerGroup);
         const int gyPad = xcdMap ? divUp(gy, 8) * 8 : gy;
         const int nBlocks = gx * gyPad;
         {
@@ -1045,9 +1059,8 @@ struct ImageWarpingOps : EnergyOps<T> {
         }
         const int gx = divUp(A.W, noAp ? kIterStrip2 : kIterStrip);
         const int rows = Ax.yEnd - Ax.yBegin;
-        int gy = std::max(1, std::min(std::min(rows, cus * occIter[L] / gx), kMaxPartials / gx));
-        int rowsPerGroup = divUp(rows, gy);
-        gy = divUp(rows, rowsPerGroup);
+        int gy, rowsPerGroup;
+        splitRows(rows, gx, cus * occIter[L], gy, rowsPerGroup);
         if (a.first) iterIndex = 0;
         const bool paired = noAp && pairDelta && !lmLoop;      // LM needs the current delta every iteration for Q
         int deltaMode = 0; const T* alphaIn = nullptr; T* alphaOut = nullptr;

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void poisson_pcgIter(PArgs<T> A, PIterK<T> 
         const T aNum = (T)aNumD, aDen = (T)aDenD;
         alpha = (aDen > T(0)) ? aNum / aDen : T(0);
         const double rr = (K.iter == 1) ? 4.0 * aNumD : aNumD;                  // sum r_{k-1}^2 (see above)
-        const double bNumD = rr - 2.0 * (double)alpha * s2 + (double)alpha * (double)alpha * s3;
+        const double bNumD = fmax(rr - 2.0 * (double)alpha * s2 + (double)alpha * (double)alpha * s3, 0.0);   // the direct sum is >= 0: clamp cancellation noise
         beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
     }
     const V4<T>* R = (const V4<T>*)K.rOld; const V4<T>* P = (const V4<T>*)K.pOld;

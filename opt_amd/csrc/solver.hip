@@ -298,6 +298,7 @@ struct PcgSolver : SolverBase {
     std::vector<void*> allocs;
     Reduction redA, redB, redQ, redC;   // alpha denominator, beta numerator, q, cost / init numerator
     double* scal = nullptr;             // device: [0],[1] alphaNumerator ping-pong, [2..5] slab totals
+    double* scal4[2] = {nullptr, nullptr};   // device: all-reduced {alphaNum, alphaDen, s2, s3} of the single-kernel iteration (slab mode), ping-pong
     int aSlot = 0;
     double* hostBuf = nullptr;          // pinned
     double* hostBufQ = nullptr; hipEvent_t qEvent = nullptr; int qCount = 0;   // pinned buffer + event of the overlapped q fetch
@@ -334,7 +335,8 @@ struct PcgSolver : SolverBase {
         for (auto& st : setS) for (auto& R : st) R = allocRed();
         if (const char* e = getenv("OPT_AMD_SC1")) storeMode = atoi(e);
         redA = allocRed(); redB = allocRed(); redQ = allocRed(); redC = allocRed();
-        HIP_CHECK(hipMalloc((void**)&scal, 8 * sizeof(double))); HIP_CHECK(hipMemset(scal, 0, 8 * sizeof(double))); allocs.push_back(scal);
+        HIP_CHECK(hipMalloc((void**)&scal, 16 * sizeof(double))); HIP_CHECK(hipMemset(scal, 0, 16 * sizeof(double))); allocs.push_back(scal);
+        scal4[0] = scal + 8; scal4[1] = scal + 12;
         HIP_CHECK(hipHostMalloc((void**)&hostBuf, kMaxPartials * sizeof(double)));
         E->slab = Slab{};
     }
@@ -350,8 +352,7 @@ struct PcgSolver : SolverBase {
     // Host value of a reduction (blocking D2H like the reference's computeCost / fetchQ, solver.t:790-814)
     double hostSum(const Reduction& R) {
         if (distributed) {
-            k_finalizeSum<<<1, kBlock, 0, stream>>>(R.partials, R.n, scal + 2);
-            comm.allReduceSum(comm.ctx, scal + 2, 1, (void*)stream);
+            reduceAcross(&R, 1, scal + 2);
             HIP_CHECK(hipMemcpyAsync(hostBuf, scal + 2, sizeof(double), hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
             return hostBuf[0];
@@ -365,8 +366,7 @@ struct PcgSolver : SolverBase {
     void beginHostSum(const Reduction& R) {
         if (!hostBufQ) { HIP_CHECK(hipHostMalloc((void**)&hostBufQ, kMaxPartials * sizeof(double))); HIP_CHECK(hipEventCreateWithFlags(&qEvent, hipEventDisableTiming)); }
         if (distributed) {
-            k_finalizeSum<<<1, kBlock, 0, stream>>>(R.partials, R.n, scal + 2);
-            comm.allReduceSum(comm.ctx, scal + 2, 1, (void*)stream);
+            reduceAcross(&R, 1, scal + 2);
             HIP_CHECK(hipMemcpyAsync(hostBufQ, scal + 2, sizeof(double), hipMemcpyDeviceToHost, stream));
             qCount = 1;
         } else {
@@ -380,18 +380,31 @@ struct PcgSolver : SolverBase {
         double s = 0; for (int i = 0; i < qCount; ++i) s += hostBufQ[i];
         return s;
     }
+    // dst[i] = sum over ranks of sum(Rs[i].partials): one launch if the communicator folds the local reduction in (allReducePartials)
+    void reduceAcross(const Reduction* Rs, int cnt, double* dst) {
+        if (comm.allReducePartials) {
+            const double* ps[8]; int ns[8];
+            for (int i = 0; i < cnt; ++i) { ps[i] = Rs[i].partials; ns[i] = Rs[i].n; }
+            comm.allReducePartials(comm.ctx, ps, ns, cnt, dst, (void*)stream);
+            return;
+        }
+        if (cnt == 4) {
+            Partials4 in4; for (int i = 0; i < 4; ++i) { in4.p[i] = Rs[i].partials; in4.n[i] = Rs[i].n; }
+            k_finalizeSum4<<<4, kBlock, 0, stream>>>(in4, dst);
+        } else for (int i = 0; i < cnt; ++i) k_finalizeSum<<<1, kBlock, 0, stream>>>(Rs[i].partials, Rs[i].n, dst + i);
+        comm.allReduceSum(comm.ctx, dst, cnt, (void*)stream);
+    }
     // What device consumers should sum: the partials themselves, or (slab mode) the all-reduced total.
     Reduction forConsumers(const Reduction& R, int slot) {
         if (!distributed) return R;
         double* tot = scal + 3 + slot;
-        k_finalizeSum<<<1, kBlock, 0, stream>>>(R.partials, R.n, tot);
-        comm.allReduceSum(comm.ctx, tot, 1, (void*)stream);
+        reduceAcross(&R, 1, tot);
         Reduction out; out.partials = tot; out.n = 1; return out;
     }
     void finalizeTo(const Reduction& R, double* dst) {
         ScopedKernel k(ctx, "finalizeSum");
-        k_finalizeSum<<<1, kBlock, 0, stream>>>(R.partials, R.n, dst);
-        if (distributed) comm.allReduceSum(comm.ctx, dst, 1, (void*)stream);
+        if (distributed) reduceAcross(&R, 1, dst);
+        else k_finalizeSum<<<1, kBlock, 0, stream>>>(R.partials, R.n, dst);
     }
 
     // ---- halo exchange (slab mode) ------------------------------------------------------------------
@@ -467,11 +480,10 @@ struct PcgSolver : SolverBase {
                 exchangeRows(bases);
             }
             for (int i = 0; i < 4; ++i) prev[i] = setS[cur][i];
-            if (distributed) {   // one all-reduce of the four sums
-                Partials4 in4; for (int i = 0; i < 4; ++i) { in4.p[i] = setS[cur][i].partials; in4.n[i] = setS[cur][i].n; }
-                k_finalizeSum4<<<4, kBlock, 0, stream>>>(in4, scal + 4);
-                comm.allReduceSum(comm.ctx, scal + 4, 4, (void*)stream);
-                for (int i = 0; i < 4; ++i) { prev[i].partials = scal + 4 + i; prev[i].n = 1; }
+            if (distributed) {   // one all-reduce of the four sums (ping-pong destination, like the partial sets it replaces)
+                double* tot = scal4[cur];
+                reduceAcross(setS[cur], 4, tot);
+                for (int i = 0; i < 4; ++i) { prev[i].partials = tot + i; prev[i].n = 1; }
             }
             if (traceEnabled) {
                 const double aNum = hostSumLocal(prev[0]), aDen = hostSumLocal(prev[1]), s2 = hostSumLocal(prev[2]), s3 = hostSumLocal(prev[3]);
@@ -479,7 +491,7 @@ struct PcgSolver : SolverBase {
                 // an energy that does not precondition starts from p_0 = r_0 / 4 (guardedInvert(1)) but continues with z = r, so the
                 // first alphaNumerator is a quarter of sum r_0^2 -- which is what the expansion needs (see poisson_pcgIter)
                 const double rr = (lIter == 0 && !preArg && !E->usesGraph) ? 4.0 * aNum : aNum;
-                const double bNum = rr - 2.0 * (double)al * s2 + (double)al * (double)al * s3;
+                const double bNum = std::fmax(rr - 2.0 * (double)al * s2 + (double)al * (double)al * s3, 0.0);
                 trace.insert(trace.end(), {(double)sp.nIter, (double)lIter, aNum, aDen, bNum, 0.0});
             }
             cur ^= 1;

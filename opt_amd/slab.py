@@ -95,6 +95,16 @@ def comm_lib():
         L.OptComm_CreateRccl.restype = vp; L.OptComm_CreateRccl.argtypes = [ctypes.c_char_p, ci, ci]
         L.OptComm_RcclSlabComm.restype = ctypes.POINTER(api.OptAmd_SlabComm); L.OptComm_RcclSlabComm.argtypes = [vp]
         L.OptComm_DestroyRccl.argtypes = [vp]
+        L.OptComm_RcclCount.restype = ci; L.OptComm_RcclCount.argtypes = [vp]
+        L.OptComm_PeerHandleBytes.restype = ci
+        L.OptComm_PeerMaxWorld.restype = ci
+        L.OptComm_PeerCreate.restype = vp; L.OptComm_PeerCreate.argtypes = [ci, ci, ctypes.c_long, ctypes.c_double]
+        L.OptComm_PeerHandle.argtypes = [vp, ctypes.c_char_p]
+        L.OptComm_PeerMemKind.restype = ci; L.OptComm_PeerMemKind.argtypes = [vp]
+        L.OptComm_PeerConnect.restype = ci; L.OptComm_PeerConnect.argtypes = [vp, ctypes.c_char_p]
+        L.OptComm_PeerSlabComm.restype = ctypes.POINTER(api.OptAmd_SlabComm); L.OptComm_PeerSlabComm.argtypes = [vp]
+        L.OptComm_PeerError.restype = ci; L.OptComm_PeerError.argtypes = [vp]
+        L.OptComm_PeerDestroy.argtypes = [vp]
         L.OptComm_CreateThreadWorld.restype = vp; L.OptComm_CreateThreadWorld.argtypes = [ci]
         L.OptComm_DestroyThreadWorld.argtypes = [vp]
         L.OptComm_CreateThreadRank.restype = vp; L.OptComm_CreateThreadRank.argtypes = [vp, ci]
@@ -110,11 +120,57 @@ def attach_slab(solver, layout, slab_comm_ptr):
         raise RuntimeError("this energy's kernel set does not support slab tiling")
 
 
-class SlabJob:
-    """One rank of a multi-process solve (bench.py --gpus N): torch.distributed is already initialised with the
-    nccl (= RCCL) backend; the RCCL communicator used inside the solver is created here from a broadcast id."""
+class PeerComm:
+    """The peer-mailbox communicator (csrc/comm/peer_comm.hip): every rank allocates a window on its GPU, the hipIpc handles are
+    all-gathered through torch.distributed (any backend -- the data path never touches it again) and every rank maps every window."""
 
-    def __init__(self, energy, W, H, rank, world, kind="gaussNewtonGPU", double=False, problem=None, ghost=None):
+    def __init__(self, rank, world, stage_bytes, timeout_s=None):
+        import torch.distributed as dist
+        L = comm_lib()
+        if world > L.OptComm_PeerMaxWorld():
+            raise ValueError(f"peer communicator supports at most {L.OptComm_PeerMaxWorld()} ranks")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("OPT_AMD_PEER_TIMEOUT", "20"))
+        self.rank, self.world = rank, world
+        self._ctx = L.OptComm_PeerCreate(rank, world, int(stage_bytes), float(timeout_s))
+        if not self._ctx:
+            raise RuntimeError("OptComm_PeerCreate failed (IPC-exportable device memory unavailable)")
+        n = L.OptComm_PeerHandleBytes()
+        buf = ctypes.create_string_buffer(n)
+        L.OptComm_PeerHandle(self._ctx, buf)
+        handles = [None] * world
+        if world > 1:
+            dist.all_gather_object(handles, bytes(buf.raw))
+        else:
+            handles[0] = bytes(buf.raw)
+        if not L.OptComm_PeerConnect(self._ctx, b"".join(handles)):
+            raise RuntimeError("OptComm_PeerConnect failed (hipIpcOpenMemHandle)")
+        if world > 1:
+            dist.barrier()                     # every window is mapped everywhere before the first peer store
+        self.mem_kind = {3: "uncached", 1: "fine-grained", 0: "plain"}.get(L.OptComm_PeerMemKind(self._ctx), "?")
+
+    def slab_comm(self):
+        return comm_lib().OptComm_PeerSlabComm(self._ctx)
+
+    def error(self):
+        return comm_lib().OptComm_PeerError(self._ctx)
+
+    def close(self):
+        import torch.distributed as dist
+        if self._ctx:
+            if self.world > 1 and dist.is_initialized():
+                dist.barrier()                 # nobody unmaps a window a peer may still be writing to
+            comm_lib().OptComm_PeerDestroy(self._ctx)
+            self._ctx = None
+
+
+class SlabJob:
+    """One rank of a multi-process solve (bench.py --gpus N).  torch.distributed is already initialised (nccl = RCCL on the GPU
+    boxes; gloo works too: it only carries the set-up).  comm = "peer": peer-mapped mailboxes (PeerComm, the default);
+    comm = "rccl": ncclAllReduce / grouped send-recv on a communicator created here from a broadcast id."""
+
+    def __init__(self, energy, W, H, rank, world, kind="gaussNewtonGPU", double=False, problem=None, ghost=None, comm="peer"):
         import torch
         import torch.distributed as dist
         if ghost is None:                      # deep ghost zones: 16 extra rows per slab buy 6 of 7 halo exchanges (DESIGN.md section 4)
@@ -124,21 +180,46 @@ class SlabJob:
         self.local = split_problem(glob, self.layout)
         del glob
         self.params = api.to_device(self.local)
+        self.comm_kind, self.world = comm, world
         L = comm_lib()
-        n = L.OptComm_UniqueIdBytes()
-        buf = ctypes.create_string_buffer(n)
-        if rank == 0:
-            assert L.OptComm_GetUniqueId(buf)
-        t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).cuda()
-        dist.broadcast(t, src=0)
-        self._id = bytes(t.cpu().numpy().tobytes())
-        self._ctx = L.OptComm_CreateRccl(self._id, rank, world)
+        if comm == "peer":
+            # the largest exchange moves `ghost` rows of two solver vectors (r and p) per side; rows are W * (unknown scalars per pixel) wide
+            scalars = sum(int(np.prod(np.asarray(self.local.params[i]).shape[2:])) or 1 for i in self.local.unknown_slots)
+            stage = 2 * ghost * W * scalars * (8 if double else 4) + 4096
+            self._peer = PeerComm(rank, world, stage)
+            slab_comm = self._peer.slab_comm()
+        elif comm == "rccl":
+            n = L.OptComm_UniqueIdBytes()
+            buf = ctypes.create_string_buffer(n)
+            if rank == 0:
+                assert L.OptComm_GetUniqueId(buf)
+            ids = [bytes(buf.raw)]
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)
+            self._id = ids[0]
+            self._ctx = L.OptComm_CreateRccl(self._id, rank, world)
+            slab_comm = L.OptComm_RcclSlabComm(self._ctx)
+        else:
+            raise ValueError(f"unknown comm {comm!r}")
         self.solver = api.Solver(api.energy_file(energy), kind, (W, self.layout.local_H), double=double)
-        attach_slab(self.solver, self.layout, L.OptComm_RcclSlabComm(self._ctx))
+        attach_slab(self.solver, self.layout, slab_comm)
+
+    def comm_ranks(self):
+        """How many ranks the communicator itself sees (ncclCommCount for RCCL; the mapped windows for the peer communicator)."""
+        if self.comm_kind == "rccl":
+            return comm_lib().OptComm_RcclCount(self._ctx)
+        return self._peer.world
+
+    def owned_unknowns(self):
+        g = self.layout.ghost
+        return [self.params[i][g:g + self.layout.rows].cpu().numpy() for i in self.local.unknown_slots]
 
     def close(self):
         self.solver.close()
-        comm_lib().OptComm_DestroyRccl(self._ctx)
+        if self.comm_kind == "rccl":
+            comm_lib().OptComm_DestroyRccl(self._ctx)
+        else:
+            self._peer.close()
 
 
 def run_threads(problem, world, kind="gaussNewtonGPU", solver_params=None, steps=None, ghost=2):

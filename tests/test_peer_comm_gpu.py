@@ -1,0 +1,96 @@
+"""GPU tests (-m gpu) of the peer-mailbox communicator (opt_amd/csrc/comm/peer_comm.hip) with REAL processes: every rank is its own
+process with its own HIP context, windows are exchanged as hipIpc handles and written by peer stores -- the code path bench.py --gpus N
+takes on an 8-GPU node.  On a 1-GPU box the ranks share device 0 (two processes, one GPU): the IPC mapping, the sequence-numbered
+mailbox all-reduce, the double-buffered halo staging with acknowledgements and the rank-ordered sums are all exercised; only the xGMI
+hop itself is not.  Each rank's result must equal the single-GPU solve."""
+import os
+
+import numpy as np
+import pytest
+
+from opt_amd import api, workloads as wl
+from helpers import hip_solver, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _single(P, kind, **kw):
+    g = hip_solver(P, kind, **kw)
+    dev = api.to_device(P)
+    g.init(dev); costs = [g.cost()]
+    while g.step(dev):
+        costs.append(g.cost())
+    out = [dev[i].cpu().numpy() for i in P.unknown_slots]
+    g.close()
+    return costs, out
+
+
+def _rank_main(rank, world, port, case, q):
+    import torch
+    import torch.distributed as dist
+    from opt_amd import slab
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OPT_AMD_PEER_TIMEOUT="8")
+    if world == 1:
+        os.environ["OPT_AMD_FORCE_COMM"] = "1"
+    torch.cuda.set_device(0)                                   # all ranks share the box's one GPU
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = wl.image_warping(case["W"], case["H"], double=case["double"], random_state=3, mask_fraction=0.06, perturb=0.3)
+    job = slab.SlabJob("image_warping", case["W"], case["H"], rank, world, kind=case["kind"], double=case["double"], problem=P, ghost=case["ghost"], comm="peer")
+    job.solver.set_parameter("nIterations", case["n"]); job.solver.set_parameter("lIterations", case["l"])
+    job.solver.init(job.params); costs = [job.solver.cost()]
+    while job.solver.step(job.params):
+        costs.append(job.solver.cost())
+    torch.cuda.synchronize()
+    q.put((rank, costs, job.owned_unknowns(), job.layout.row0, job.layout.rows, job._peer.mem_kind, job._peer.error()))
+    job.close()
+    dist.destroy_process_group()
+
+
+def _run(world, case):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=300)
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("world", [1, 2])
+@pytest.mark.parametrize("ghost,double", [(8, False), (2, True), (1, True)])
+def test_peer_mailbox_ranks_as_processes(world, ghost, double):
+    """ghost 8: the deep-ghost protocol of bench.py (one r / p exchange per 7 launches); ghost 2: an exchange after every launch (the staging
+    double buffer and its acknowledgements turn over 14 times per step); ghost 1: the kernel with A p in memory (A p rows exchanged)."""
+    case = dict(W=70, H=64, double=double, ghost=ghost, kind="gaussNewtonGPU", n=3, l=14)
+    P = wl.image_warping(case["W"], case["H"], double=double, random_state=3, mask_fraction=0.06, perturb=0.3)
+    c1, x1 = _single(P, case["kind"], nIterations=case["n"], lIterations=case["l"])
+    res = _run(world, case)
+    tol = 1e-11 if double else 2e-5
+    for r in range(world):
+        _, costs, unk, row0, rows, mem_kind, err = res[r]
+        assert err == 0 and mem_kind in ("uncached", "fine-grained")
+        np.testing.assert_allclose(costs, c1, rtol=tol)                         # every rank sees the same global cost trajectory
+        for a, b in zip(unk, x1):
+            assert rel_err(a, b[row0:row0 + rows]) < tol
+    if world == 2:
+        assert res[0][1] == res[1][1]                                           # rank-ordered sums: bitwise identical on every rank
+
+
+def test_peer_mailbox_lm_two_processes():
+    case = dict(W=48, H=40, double=True, ghost=2, kind="LMGPU", n=3, l=12)
+    P = wl.image_warping(case["W"], case["H"], double=True, random_state=3, mask_fraction=0.06, perturb=0.3)
+    c1, x1 = _single(P, "LMGPU", nIterations=3, lIterations=12)
+    res = _run(2, case)
+    for r in range(2):
+        np.testing.assert_allclose(res[r][1], c1, rtol=1e-9)
+        for a, b in zip(res[r][2], x1):
+            assert rel_err(a, b[res[r][3]:res[r][3] + res[r][4]]) < 1e-8

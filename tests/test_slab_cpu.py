@@ -258,3 +258,21 @@ def test_two_rank_gloo_two_ghost_row_protocol(oracle_lib, ghost):
     for rank, row0, rows, lo, la in parts:
         np.testing.assert_allclose(lo, dO[row0:row0 + rows], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(la, dA[row0:row0 + rows], rtol=1e-9, atol=1e-12)
+
+
+def test_bench_launcher_spawns_the_requested_ranks():
+    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run with 2 ranks (--cpu-smoke: the ranks
+    rendezvous over gloo and report what they saw, no GPU needed); a launcher whose WORLD_SIZE disagrees with --gpus is an error."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cpu-smoke"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2
+    env["WORLD_SIZE"] = "1"
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cpu-smoke"], env=env, capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "must agree" in bad.stderr

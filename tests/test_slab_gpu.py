@@ -66,7 +66,8 @@ def _rccl_world1(q):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     P = wl.image_warping(64, 40, random_state=3, perturb=0.3)
-    job = slab.SlabJob("image_warping", 64, 40, 0, 1, problem=P.clone())
+    job = slab.SlabJob("image_warping", 64, 40, 0, 1, problem=P.clone(), comm="rccl")
+    assert job.comm_ranks() == 1
     job.solver.set_parameter("nIterations", 2); job.solver.set_parameter("lIterations", 10)
     job.solver.init(job.params); costs = [job.solver.cost()]
     while job.solver.step(job.params):

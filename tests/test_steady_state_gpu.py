@@ -1,0 +1,161 @@
+"""GPU parity tests (-m gpu) of the row-marching kernels in the regime the benchmark runs them in.
+
+The single-kernel PCG iteration (`iw_pcgIter2`, energy_image_warping.hip) sizes its grid to one co-resident wave of workgroups, so at
+4096^2 a workgroup marches ~98 rows (three trips per loop pass with by-name register rotation, a 3-deep prefetch, a row-triple
+barrier, alternating sweep direction, paired delta updates), while a small test image gives every workgroup one or two rows.  These tests
+put that steady state against the CPU oracle (reference sequencing: solverGPUGaussNewton.t:421-550, 1016-1177):
+  * large images on the natural grid (1536x1024 double: 13 rows per group; 2048^2 float: 25);
+  * small and ragged images with OPT_AMD_ITER_ROWS forcing 3 / 4 / 5 / 7 / 98 rows per workgroup;
+  * odd and even launch counts (paired delta + pcgFinish, both sweep directions), Levenberg-Marquardt, general UrShape;
+  * the frozen oracle trajectory of the benchmark workload itself (tests/golden/bench_costs.json, 400 PCG iterations per step);
+  * one full-size step of BASELINE configs 3 (SFS 1024^2 double LM) and 4 (ARAP 500 k vertices) against the oracle.
+Tolerances: double 1e-10 on costs / 1e-9 on unknowns, float 1e-5 on costs (BASELINE.json north_star).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from opt_amd import api, workloads as wl
+from helpers import device_unknowns, flat_unknowns, hip_solver, oracle_solver, rel_err
+
+pytestmark = pytest.mark.gpu
+
+THREADS = max(1, min(os.cpu_count() or 1, 64))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _pair(oracle_lib, P, kind, nsteps, liters, cost_tol, x_tol, radius_tol=None, **extra):
+    """Step the oracle and the HIP solver side by side on the same inputs; compare cost (and LM radius) after every step."""
+    o = oracle_solver(oracle_lib, P, kind, nIterations=nsteps, lIterations=liters, **extra)
+    o.set_threads(THREADS if P.params[0].size > 200_000 else 1)
+    g = hip_solver(P, kind, nIterations=nsteps, lIterations=liters, **extra)
+    dev = api.to_device(P)
+    Pref = P.clone()
+    o.init(Pref.params); g.init(dev)
+    scale = max(abs(o.cost()), 1e-300)
+    assert abs(g.cost() - o.cost()) <= cost_tol * scale
+    while True:
+        a, b = o.step(Pref.params), g.step(dev)
+        assert a == b
+        assert abs(g.cost() - o.cost()) <= cost_tol * max(abs(o.cost()), 1e-12 * scale), (g.cost(), o.cost())
+        if radius_tol is not None:
+            assert abs(g.trust_region_radius() - o.trust_region_radius()) <= radius_tol * o.trust_region_radius()
+        if not a:
+            break
+    if x_tol is not None:
+        assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < x_tol
+    g.close(); o.close()
+
+
+# ---- (a) large images, natural grid, double ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("W,H,liters", [(1536, 1024, 7), (1536, 1024, 8), (1536, 1024, 20), (1441, 600, 8), (719, 1000, 7), (721, 1200, 20)])
+def test_large_image_double_natural_grid(oracle_lib, W, H, liters):
+    """>= 6 rows per workgroup on the grid the solver picks itself; odd and even launch counts (the deferred delta term is flushed
+    by pcgFinish after an odd one), strips 720 k +- 1 wide."""
+    P = wl.image_warping(W, H, double=True, random_state=W + 7 * H + liters, mask_fraction=0.05, perturb=0.3)
+    _pair(oracle_lib, P, "gaussNewtonGPU", 1, liters, 1e-10, 1e-9)
+
+
+# ---- (b) forced rows per workgroup on small / ragged images ----------------------------------------------------------------------
+FORCED = [(61, 301), (721, 205), (1441, 103), (59, 98), (120, 197), (64, 99), (7, 400)]
+
+
+@pytest.mark.parametrize("liters", [7, 8])
+@pytest.mark.parametrize("rows", [3, 4, 5, 7, 98])
+@pytest.mark.parametrize("W,H", FORCED)
+def test_forced_rows_per_group_double(oracle_lib, monkeypatch, W, H, rows, liters):
+    monkeypatch.setenv("OPT_AMD_ITER_ROWS", str(rows))
+    P = wl.image_warping(W, H, double=True, random_state=W * 31 + H + rows, mask_fraction=0.1, perturb=0.3)
+    _pair(oracle_lib, P, "gaussNewtonGPU", 2, liters, 1e-10, 1e-9)
+
+
+@pytest.mark.parametrize("rows", [5, 98])
+@pytest.mark.parametrize("jitter,kind", [(0.0, "LMGPU"), (0.2, "gaussNewtonGPU"), (0.2, "LMGPU")])
+def test_forced_rows_lm_and_general_urshape(oracle_lib, monkeypatch, jitter, kind, rows):
+    """Levenberg-Marquardt (CtC, Q sums, the residual reset every 10th iteration and the restart launch after it) and the general-UrShape
+    kernel (PRE == 2, U read per pixel) with many rows per workgroup."""
+    monkeypatch.setenv("OPT_AMD_ITER_ROWS", str(rows))
+    P = wl.image_warping(305, 250, double=True, random_state=17 + rows, mask_fraction=0.05, perturb=0.3, jitter_urshape=jitter)
+    _pair(oracle_lib, P, kind, 2, 25, 1e-10, 1e-9, radius_tol=1e-8 if kind == "LMGPU" else None)
+
+
+@pytest.mark.parametrize("jitter,kind", [(0.0, "LMGPU"), (0.2, "gaussNewtonGPU")])
+def test_large_image_lm_and_general_urshape_natural_grid(oracle_lib, jitter, kind):
+    P = wl.image_warping(1441, 700, double=True, random_state=29, mask_fraction=0.05, perturb=0.3, jitter_urshape=jitter)
+    _pair(oracle_lib, P, kind, 1, 21, 1e-10, 1e-9, radius_tol=1e-8 if kind == "LMGPU" else None)
+
+
+# ---- (c) float at BASELINE config 2's size -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows", [None, 98])
+def test_2048_float_20_iterations(oracle_lib, monkeypatch, rows):
+    """image_warping 2048^2 float (BASELINE config 2), 1 GN x 20 PCG, cost at the 1e-5 bar: natural grid (25 rows per workgroup) and the
+    benchmark's 98."""
+    if rows:
+        monkeypatch.setenv("OPT_AMD_ITER_ROWS", str(rows))
+    P = wl.image_warping(2048, 2048)
+    rng = np.random.default_rng(2)                                 # a rougher start than the plain benchmark input: perturbed offsets and angles
+    P.params[0] += (0.3 * rng.standard_normal(P.params[0].shape)).astype(np.float32)
+    P.params[1] += (0.1 * rng.standard_normal(P.params[1].shape)).astype(np.float32)
+    _pair(oracle_lib, P, "gaussNewtonGPU", 1, 20, 1e-5, 1e-5)
+
+
+# ---- (d) the benchmark workload against its frozen oracle trajectory ----------------------------------------------------------------
+def _golden():
+    with open(os.path.join(HERE, "golden", "bench_costs.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("size", [2048, 4096])
+def test_benchmark_workload_matches_frozen_oracle_costs(size):
+    """bench.py's exact workload (400 PCG iterations per Gauss-Newton step): cost after each step against the oracle's, generated offline by
+    tests/golden/make_bench_cost.py (the float oracle is the contract; the double oracle shows how far float rounding moves either)."""
+    G = _golden()
+    ref = G[f"image_warping_{size}x{size}_float_gaussNewtonGPU_400"]["costs"]
+    P = wl.image_warping(size, size)
+    g = hip_solver(P, nIterations=len(ref) - 1, lIterations=400)
+    dev = api.to_device(P)
+    g.init(dev)
+    costs = [g.cost()]
+    while g.step(dev):
+        costs.append(g.cost())
+    g.close()
+    assert len(costs) == len(ref)
+    np.testing.assert_allclose(costs, ref, rtol=1e-5)
+
+
+# ---- (e) a fast-converging solve: the expanded beta numerator under cancellation -------------------------------------------------------
+def test_fast_converging_solve_expanded_beta(oracle_lib, monkeypatch):
+    """Every pixel constrained with a heavy fit weight: the system is nearly diagonal, the residual drops by orders of magnitude per
+    iteration and betaNumerator = alphaNum - 2 alpha s2 + alpha^2 s3 cancels almost completely (clamped at 0 like the direct sum it replaces).
+    The solve must still follow the oracle and the three-kernel loop."""
+    P = wl.image_warping(300, 210, random_state=3, mask_fraction=0.02, perturb=0.3)
+    P.params[3][...] = P.params[2] + 0.25                       # Constraints everywhere
+    P.params[5] = np.array(np.sqrt(np.float32(1e6)), dtype=np.float32)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("OPT_AMD_ONEKERNEL", mode)
+        g = hip_solver(P, nIterations=2, lIterations=30)
+        dev = api.to_device(P)
+        g.init(dev); c = [g.cost()]
+        while g.step(dev):
+            c.append(g.cost())
+        res[mode] = (c, device_unknowns(P, dev)); g.close()
+    o = oracle_solver(oracle_lib, P, nIterations=2, lIterations=30)
+    Pref = P.clone(); o.solve(Pref.params)
+    np.testing.assert_allclose(res["1"][0], o.cost_history(), rtol=1e-5)
+    np.testing.assert_allclose(res["1"][0], res["0"][0], rtol=1e-5)
+    assert np.all(np.isfinite(res["1"][1])) and rel_err(res["1"][1], flat_unknowns(Pref)) < 1e-5
+    o.close()
+
+
+# ---- (f) one full-size step of configs 3 and 4 against the oracle ----------------------------------------------------------------------
+def test_config3_sfs_1024_double_lm_step_vs_oracle(oracle_lib):
+    P = wl.shape_from_shading(1024, 1024, double=True, holes=True)
+    _pair(oracle_lib, P, "LMGPU", 1, 10, 1e-10, 1e-9, radius_tol=1e-8)
+
+
+def test_config4_arap_500k_step_vs_oracle(oracle_lib):
+    P = wl.arap_mesh_deformation(708, 707, perturb=0.01)
+    _pair(oracle_lib, P, "gaussNewtonGPU", 1, 10, 1e-5, 1e-5)

@@ -8,7 +8,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 600 python bench.py > $out/bench.json 2> $out/bench.err
-B="python bench.py --steps 1 --warmup 0 --liters 50 --no-cpu-baseline"
+B="python bench.py --steps 1 --warmup 0 --liters 50 --no-cpu-baseline --no-extras"
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $out/kt -o kt -- $B > $out/kt.log 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE -f csv -d $out/pmc_fetch -o p -- $B > $out/pmc_fetch.log 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE -f csv -d $out/pmc_write -o p -- $B > $out/pmc_write.log 2>&1

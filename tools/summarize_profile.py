@@ -58,6 +58,11 @@ def main(src, out):
     # even launches heavier), so the per-launch figure is the call-weighted mean over all variants.
     groups = {"PCGIteration": [r for r in rows if "iw_pcgIter2" in r["Name"]] or [r for r in rows if "iw_pcgIter" in r["Name"]],
               "PCGStep3+PCGStep1": [r for r in rows if "iw_applyJTJ" in r["Name"] and ", true>(" in r["Name"]]}
+    sha = None
+    try:
+        sha = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1]).get("kernel_src_sha16")
+    except Exception:  # noqa
+        pass
     for bench_kernel, rs in groups.items():
         if not rs:
             continue
@@ -67,14 +72,14 @@ def main(src, out):
         avg = sum(int(r["Calls"]) * float(r["AverageNs"]) for r in rs) / calls / 1e3
         json.dump({"kernel": " + ".join(sorted(short(r["Name"]) for r in rs)), "bench_kernel": bench_kernel, "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024,
                    "fetch_size_kib": f, "write_size_kib": w, "correction": "2 x FETCH_SIZE (gfx950) + WRITE_SIZE, call-weighted mean over the kernel's variants",
-                   "avg_us_rocprof": avg, "launches": calls, "workload": "image_warping 4096x4096 float", "source": os.path.basename(out)}, open(out + "_traffic.json", "w"))
+                   "avg_us_rocprof": avg, "launches": calls, "kernel_src_sha16": sha, "workload": "image_warping 4096x4096 float", "source": os.path.basename(out)}, open(out + "_traffic.json", "w"))
         lines += ["", f"dominant kernel ({bench_kernel}): {calls} launches, call-weighted mean {avg:.1f} us, {(2 * f + w) * 1024 / 1e9:.3f} GB of HBM traffic per launch "
                       f"= {(2 * f + w) * 1024 / (4096 * 4096):.1f} B/pixel, {(2 * f + w) * 1024 / 1e3 / avg:.0f} GB/s"]
         break
     if os.path.exists(os.path.join(src, "bench.json")):
         try:
             b = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
-            lines += ["", "bench.py line of the same box: value = %.1f %s, roofline = %s" % (b["value"], b["unit"], json.dumps({k: b["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_kernel_ms")}))]
+            lines += ["", "bench.py line of the same box: value = %.1f %s, roofline = %s" % (b["value"], b["unit"], json.dumps({k: b["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_kernel_ms")} if b.get("roofline") else None))]
         except Exception as e:  # noqa
             lines += ["", f"(bench.json unreadable: {e})"]
     open(out + "_summary.md", "w").write("\n".join(lines) + "\n")
