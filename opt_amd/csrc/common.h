@@ -78,6 +78,41 @@ __device__ __forceinline__ double sumPartials(const double* __restrict__ partial
     return r;
 }
 
+// K sums at once: the same per-array arithmetic as K calls of sumPartials / blockReduceSum (same order, same bits), but the K
+// global loads are in flight together and the workgroup synchronises once per phase instead of once per array.  The prologue of
+// a per-iteration kernel reads partials another kernel just wrote (an L2 miss of 1-2 us each), so this is worth ~6 us per launch.
+// scratch: K * (blockDim/64 + 1) doubles.
+template <int K>
+__device__ __forceinline__ void sumPartialsN(const double* const (&partials)[K], const int (&n)[K], double* scratch, double (&out)[K]) {
+    const int tid = threadIdx.x + threadIdx.y * blockDim.x, nt = blockDim.x * blockDim.y;
+    const int lane = tid & (kWave - 1), wave = tid >> 6, nw = (nt + kWave - 1) / kWave;
+    double t[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { t[k] = 0; for (int i = tid; i < n[k]; i += nt) t[k] += partials[k][i]; }
+#pragma unroll
+    for (int k = 0; k < K; ++k) { t[k] = waveReduceSum(t[k]); if (lane == 0) scratch[k * (nw + 1) + wave] = t[k]; }
+    __syncthreads();
+    if (tid < K) { double s = 0; for (int i = 0; i < nw; ++i) s += scratch[tid * (nw + 1) + i]; scratch[tid * (nw + 1) + nw] = s; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[k] = scratch[k * (nw + 1) + nw];
+    __syncthreads();
+}
+// K workgroup sums at once; results valid in thread 0.  scratch: K * blockDim/64 doubles.
+template <int K>
+__device__ __forceinline__ void blockReduceSumN(double (&v)[K], double* scratch) {
+    const int tid = threadIdx.x + threadIdx.y * blockDim.x, nt = blockDim.x * blockDim.y;
+    const int lane = tid & (kWave - 1), wave = tid >> 6, nw = (nt + kWave - 1) / kWave;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { v[k] = waveReduceSum(v[k]); if (lane == 0) scratch[k * nw + wave] = v[k]; }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) { double t = 0; for (int i = 0; i < nw; ++i) t += scratch[k * nw + i]; v[k] = t; }
+    }
+    __syncthreads();
+}
+
 // ---- per-kernel hipEvent timing (reference util.t:404-511) ---------------------------------------------
 struct KernelTimer {
     bool enabled = false;

@@ -241,11 +241,12 @@ template <bool NT, class T> __device__ __forceinline__ void st2(V2<T>* p, long i
     else p[i] = V2<T>{x, y};
 }
 template <bool NT, class T> __device__ __forceinline__ void st1(T* p, long i, T x) { if (NT) __builtin_nontemporal_store(x, p + i); else p[i] = x; }
-// Measured at 4096^2 (same box, interleaved A/B, tools in opt_amd/build.py::build_variant): nt LOADS here are worth +4 % PCG it/s
-// (they keep this kernel's single-use streams from displacing the next kernel's inputs in L2 / Infinity Cache);
-// nt STORES on the 4-8 B/lane outputs cost 15 %; XCD-aware strip mapping (xcdMap) costs 8 %.
+// Measured (interleaved A/B on one box, opt_amd/build.py::build_variant).  Non-temporal LOADS: round 1 saw +4 % at 4096^2 on one box;
+// round 2 (tools/size_ab.sh, gpurun_out r02b) finds them equal at 4096^2 (246 us either way) and slower wherever the working set is near
+// the 256 MB Infinity Cache -- 4096x512 (one of 8 slabs): 44.4 -> 37.0 us per iteration without nt, 4096x1024: 73.5 -> 69.5,
+// 2048^2: 69.1 -> 66.2 -- so plain loads are the default.  nt STORES on the 4-8 B/lane outputs cost 15 %; XCD-aware strip mapping 8 %.
 #ifndef IW_NT_LOAD
-#define IW_NT_LOAD 1
+#define IW_NT_LOAD 0
 #endif
 #ifndef IW_ROW_SYNC
 #define IW_ROW_SYNC 1
@@ -662,17 +663,20 @@ constexpr bool kSinCosInline = IW_SINCOS_INLINE != 0;
 // LM = true: the Levenberg-Marquardt loop (A = J^T J + diag(CtC), Q sums, restart after a residual reset); see energy.h PcgIterArgs.
 template <class T, bool LATTICE, int PRE, bool FLIP, bool LM = false>
 __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArgs<T> A, IterK<T> K, int rowsPerGroup, int gx, int gy) {
-    __shared__ double scratch[kIterBlock2 / kWave + 1];
+    __shared__ double scratch[5 * (kIterBlock2 / kWave + 1)];
     const long N = (long)A.W * A.H;
     T alpha = 0, beta = 0;
     const bool first = K.first != 0;
     const bool restart = LM && K.afterReset != 0;      // r and delta are already those of this iteration (split residual reset)
     if (restart) {
-        const T bNum = (T)sumPartials(K.betaNum, K.nBetaNum, scratch), bDen = (T)sumPartials(K.betaDen, K.nBetaDen, scratch);
+        const double* const ps[2] = {K.betaNum, K.betaDen}; const int ns[2] = {K.nBetaNum, K.nBetaDen}; double o2[2];
+        sumPartialsN<2>(ps, ns, scratch, o2);
+        const T bNum = (T)o2[0], bDen = (T)o2[1];
         beta = (bDen > T(0)) ? bNum / bDen : T(0);     // solver.t:544-547
     } else if (!first) {
-        const double aNumD = sumPartials(K.aNumPrev, K.nNum, scratch), aDenD = sumPartials(K.aDenPrev, K.nDen, scratch);
-        const double s2 = sumPartials(K.s2Prev, K.n2, scratch), s3 = sumPartials(K.s3Prev, K.n3, scratch);
+        const double* const ps[4] = {K.aNumPrev, K.aDenPrev, K.s2Prev, K.s3Prev}; const int ns[4] = {K.nNum, K.nDen, K.n2, K.n3}; double o4[4];
+        sumPartialsN<4>(ps, ns, scratch, o4);          // the four sums of the previous launch, loads in flight together
+        const double aNumD = o4[0], aDenD = o4[1], s2 = o4[2], s3 = o4[3];
         const T aNum = (T)aNumD, aDen = (T)aDenD;
         alpha = (aDen > T(0)) ? aNum / aDen : T(0);
         // betaNumerator = sum M r_k^2 by expansion (energy.h); the reference's direct sum cannot be negative, so cancellation
@@ -800,12 +804,12 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
         { const IterRaw<T> w = rwB; rwB = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, y + 6); trip(y + 1, w, o1, o2, o0, n1, n2, n0, y + 1 < ye); }
         { const IterRaw<T> w = rwC; rwC = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, y + 7); trip(y + 2, w, o2, o0, o1, n2, n0, n1, y + 2 < ye); }
     }
-    double t;
-    t = blockReduceSum(accDen, scratch); if (threadIdx.x == 0) K.aDen[blockIdx.x] = t;
-    t = blockReduceSum(accNum, scratch); if (threadIdx.x == 0) K.aNum[blockIdx.x] = t;
-    t = blockReduceSum(acc2, scratch); if (threadIdx.x == 0) K.s2[blockIdx.x] = t;
-    t = blockReduceSum(acc3, scratch); if (threadIdx.x == 0) K.s3[blockIdx.x] = t;
-    if (LM) { t = blockReduceSum(accQ, scratch); if (threadIdx.x == 0) K.q[blockIdx.x] = t; }
+    double v[5] = {accDen, accNum, acc2, acc3, accQ};
+    blockReduceSumN<5>(v, scratch);
+    if (threadIdx.x == 0) {
+        K.aDen[blockIdx.x] = v[0]; K.aNum[blockIdx.x] = v[1]; K.s2[blockIdx.x] = v[2]; K.s3[blockIdx.x] = v[3];
+        if (LM) K.q[blockIdx.x] = v[4];
+    }
 }
 
 // delta += alpha[0] * p over n scalars (the deferred term left over when the PCG loop ends on an odd launch)
@@ -830,10 +834,11 @@ __global__ __launch_bounds__(kBlock) void iw_checkLattice(IWArgs<T> A, int* __re
     const V2<T>* U = (const V2<T>*)A.UrShape;
     bool bad = false;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % A.W), y = (int)(i / A.W);
+        const int x = (int)(i % A.W), y = (int)(i / A.W), gy = A.gy0 + y;
+        if (gy < 0 || gy >= A.Hg) continue;       // slab mode: ghost rows beyond the global image hold no data (their pixels are inactive, U there is never used)
         const V2<T> u = U[i];
         if (x + 1 < A.W) { const V2<T> n = U[i + 1]; bad |= !(u.x - n.x == T(-1) && u.y - n.y == T(0)); }
-        if (y + 1 < A.H) { const V2<T> n = U[i + A.W]; bad |= !(u.x - n.x == T(0) && u.y - n.y == T(-1)); }
+        if (y + 1 < A.H && gy + 1 < A.Hg) { const V2<T> n = U[i + A.W]; bad |= !(u.x - n.x == T(0) && u.y - n.y == T(-1)); }
     }
     if (__any(bad) && (threadIdx.x & (kWave - 1)) == 0) atomicOr(notLattice, 1);
 }

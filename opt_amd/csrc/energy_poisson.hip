@@ -132,12 +132,13 @@ struct PIterK {
 constexpr int kPTileW = 64, kPTileH = 4;     // 256 threads
 template <class T>
 __global__ __launch_bounds__(kBlock) void poisson_pcgIter(PArgs<T> A, PIterK<T> K) {
-    __shared__ double scratch[kBlock / kWave + 1];
+    __shared__ double scratch[4 * (kBlock / kWave + 1)];
     const bool first = K.iter == 0;
     T alpha = 0, beta = 0;
     if (!first) {
-        const double aNumD = sumPartials(K.aNumPrev, K.nNum, scratch), aDenD = sumPartials(K.aDenPrev, K.nDen, scratch);
-        const double s2 = sumPartials(K.s2Prev, K.n2, scratch), s3 = sumPartials(K.s3Prev, K.n3, scratch);
+        const double* const ps[4] = {K.aNumPrev, K.aDenPrev, K.s2Prev, K.s3Prev}; const int ns[4] = {K.nNum, K.nDen, K.n2, K.n3}; double o4[4];
+        sumPartialsN<4>(ps, ns, scratch, o4);
+        const double aNumD = o4[0], aDenD = o4[1], s2 = o4[2], s3 = o4[3];
         const T aNum = (T)aNumD, aDen = (T)aDenD;
         alpha = (aDen > T(0)) ? aNum / aDen : T(0);
         const double rr = (K.iter == 1) ? 4.0 * aNumD : aNumD;                  // sum r_{k-1}^2 (see above)
@@ -195,11 +196,9 @@ __global__ __launch_bounds__(kBlock) void poisson_pcgIter(PArgs<T> A, PIterK<T> 
         accNum += (double)dot4(z, rk); accDen += (double)dot4(pk, o);
         acc2 += (double)dot4(rk, o); acc3 += (double)dot4(o, o);
     }
-    double t;
-    t = blockReduceSum(accDen, scratch); if (threadIdx.x == 0) K.aDen[blockIdx.x] = t;
-    t = blockReduceSum(accNum, scratch); if (threadIdx.x == 0) K.aNum[blockIdx.x] = t;
-    t = blockReduceSum(acc2, scratch); if (threadIdx.x == 0) K.s2[blockIdx.x] = t;
-    t = blockReduceSum(acc3, scratch); if (threadIdx.x == 0) K.s3[blockIdx.x] = t;
+    double v[4] = {accDen, accNum, acc2, acc3};
+    blockReduceSumN<4>(v, scratch);
+    if (threadIdx.x == 0) { K.aDen[blockIdx.x] = v[0]; K.aNum[blockIdx.x] = v[1]; K.s2[blockIdx.x] = v[2]; K.s3[blockIdx.x] = v[3]; }
 }
 
 // ---- block-local "patch" PCG (the reference's LDS-resident comparator solver, examples/poisson_image_editing/src/

@@ -144,8 +144,10 @@ def test_fast_converging_solve_expanded_beta(oracle_lib, monkeypatch):
         res[mode] = (c, device_unknowns(P, dev)); g.close()
     o = oracle_solver(oracle_lib, P, nIterations=2, lIterations=30)
     Pref = P.clone(); o.solve(Pref.params)
-    np.testing.assert_allclose(res["1"][0], o.cost_history(), rtol=1e-5)
-    np.testing.assert_allclose(res["1"][0], res["0"][0], rtol=1e-5)
+    # the solve converges to float rounding (cost 1e10 -> 1e-4 -> 1e-15): below 1e-12 of the initial cost only the order of magnitude is meaningful
+    atol = 1e-12 * res["1"][0][0]
+    np.testing.assert_allclose(res["1"][0], o.cost_history(), rtol=1e-5, atol=atol)
+    np.testing.assert_allclose(res["1"][0], res["0"][0], rtol=1e-5, atol=atol)
     assert np.all(np.isfinite(res["1"][1])) and rel_err(res["1"][1], flat_unknowns(Pref)) < 1e-5
     o.close()
 

@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Per-iteration overhead of the multi-GPU plumbing, measurable on ONE GPU: the same slab-sized image_warping problem solved (a) as a plain
+single-GPU problem, (b) as a 1-rank slab job with the peer-mailbox communicator forced on (every all-reduce / halo kernel runs, peers =
+self), (c) the same with RCCL.  The difference (a) -> (b)/(c) is what the communication path adds per PCG iteration before any xGMI latency."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(mode, W, H, liters, steps):
+    import torch
+    import torch.distributed as dist
+    from opt_amd import api, slab, workloads as wl
+    if mode == "plain":
+        P = wl.image_warping(W, H)
+        dev = api.to_device(P)
+        s = api.Solver(api.energy_file("image_warping"), "gaussNewtonGPU", (W, H))
+        job = None
+    else:
+        job = slab.SlabJob("image_warping", W, H, 0, 1, comm=mode)
+        s, dev = job.solver, job.params
+    s.set_parameter("nIterations", steps + 1); s.set_parameter("lIterations", liters)
+    s.init(dev); s.step(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s.step(dev)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if job:
+        job.close()
+    else:
+        s.close()
+    return dt / (steps * liters) * 1e6
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", OPT_AMD_FORCE_COMM="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    out = {}
+    for (W, H) in [(4096, 512), (4096, 1024), (4096, 2048), (8192, 1024)]:
+        for mode in ("plain", "peer", "rccl"):
+            us = run(mode, W, H, 400, 3)
+            out[f"{W}x{H}_{mode}"] = us
+            print(f"{W}x{H:5d} {mode:5s}: {us:7.1f} us per PCG iteration", flush=True)
+    print(json.dumps(out))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
