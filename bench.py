@@ -106,11 +106,16 @@ def cpu_baseline(size, liters):
 
 
 def golden_cost(size, liters):
+    """(oracle float costs, float-rounding envelope per step) for this workload from tests/golden/bench_costs.json, or (None, None)."""
     try:
         with open(os.path.join(ROOT, "tests", "golden", "bench_costs.json")) as f:
-            return json.load(f)[f"image_warping_{size}x{size}_float_gaussNewtonGPU_{liters}"]["costs"]
+            G = json.load(f)
+        fl = G[f"image_warping_{size}x{size}_float_gaussNewtonGPU_{liters}"]["costs"]
     except (OSError, KeyError):
-        return None
+        return None, None
+    db = G.get(f"image_warping_{size}x{size}_double_gaussNewtonGPU_{liters}", {}).get("costs")
+    env = [abs(a - b) / abs(b) for a, b in zip(fl, db)] if db else None
+    return fl, env
 
 
 def measured_traffic(sha):
@@ -208,14 +213,17 @@ def main():
     cost_final = solver.cost()
     value = args.steps * args.liters / dt
 
-    gold = golden_cost(W, args.liters)
+    gold, env = golden_cost(W, args.liters)
     parity = None
     if gold is not None and len(costs) >= 2:
         n = min(len(costs), len(gold))
-        parity = {"cost_hip": costs[:n], "cost_oracle_frozen": gold[:n],
-                  "rel_err": [abs(a - b) / abs(b) for a, b in zip(costs[:n], gold[:n])], "tolerance": 1e-5,
-                  "source": "tests/golden/bench_costs.json (oracle, float, generated offline by tests/golden/make_bench_cost.py)"}
-        parity["ok"] = all(e <= 1e-5 for e in parity["rel_err"])
+        rel = [abs(a - b) / abs(b) for a, b in zip(costs[:n], gold[:n])]
+        # 400 float PCG iterations decorrelate any two summation orders: the tolerance per step is the float-rounding envelope the oracle
+        # itself shows (|float oracle - double oracle|), halved; the 1e-5 contract is tested at <= 20 iterations (tests/test_steady_state_gpu.py)
+        tol = [max(1e-5, 0.5 * e) for e in env[:n]] if env else [1e-5] * n
+        parity = {"cost_hip": costs[:n], "cost_oracle_frozen": gold[:n], "rel_err": rel, "tolerance": tol,
+                  "float_rounding_envelope": env[:n] if env else None, "ok": all(r <= t for r, t in zip(rel, tol)),
+                  "source": "tests/golden/bench_costs.json (oracle float / double, generated offline by tests/golden/make_bench_cost.py)"}
 
     # ---- roofline leg: per-kernel hipEvent timing on the solver's stream, and the general-UrShape path beside it ----------
     roofline, general = None, None

@@ -32,6 +32,11 @@ const char* OptAmd_EnergyName(int i);
  * returns 1 and "ok: <energy>" in `message`, or 0 and the reason Opt_ProblemPlan would print. */
 int OptAmd_CheckProblemFile(const char* filename, char* message, int messageLen);
 
+/* FNV-1a hash of the comment- and whitespace-stripped text of a .t file: Opt_ProblemPlan accepts an energy only if this hash is one of
+ * the body versions its hand-written kernel set implements (the reference compiles whatever the file says; this backend cannot, so an
+ * edited Energy / Exclude body is refused instead of silently solved as the unedited energy).  0 if the file cannot be read. */
+unsigned long OptAmd_ProblemFileHash(const char* filename);
+
 /* Length of the solver's unknown vector: unknown images in declaration order, each AoS, concatenated
  * (the reference's UnknownType iteration order, API/src/o.t:675-687). */
 long OptAmd_PlanNumUnknownScalars(Opt_Plan* plan);

@@ -23,7 +23,7 @@ OPT_SYMBOLS = ["Opt_NewState", "Opt_ProblemDefine", "Opt_ProblemDelete", "Opt_Pr
 OPTAMD_SYMBOLS = ["OptAmd_Version", "OptAmd_EnergyCount", "OptAmd_EnergyName", "OptAmd_PlanNumUnknownScalars", "OptAmd_PlanVector",
                   "OptAmd_EvalJTF", "OptAmd_ApplyJTJ", "OptAmd_EvalCost", "OptAmd_PlanEnableTrace", "OptAmd_PlanTraceRows",
                   "OptAmd_PlanGetTrace", "OptAmd_PlanTrustRegionRadius", "OptAmd_PlanKernelTiming", "OptAmd_PlanKernelCount",
-                  "OptAmd_PlanKernelName", "OptAmd_PlanSetSlab", "OptAmd_CheckProblemFile"]
+                  "OptAmd_PlanKernelName", "OptAmd_PlanSetSlab", "OptAmd_CheckProblemFile", "OptAmd_ProblemFileHash"]
 
 
 class Opt_InitializationParameters(ctypes.Structure):

@@ -24,7 +24,7 @@ def sources():
 
 
 def _deps_mtime():
-    hs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    hs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     return max(os.path.getmtime(h) for h in hs)
 
 

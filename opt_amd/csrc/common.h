@@ -37,6 +37,7 @@ constexpr int kMaxPartials = 4096;   // per-workgroup partial sums a reduction m
 struct Reduction {
     double* partials = nullptr;   // device, kMaxPartials doubles
     int n = 0;                    // how many the last producer wrote
+    bool hostVisible = false;     // partials live in pinned host memory (zero-copy): a sum only the HOST consumes (LM's Q) needs no copy kernel
 };
 
 // ---- wave64 / workgroup reductions -------------------------------------------------------------------

@@ -127,6 +127,8 @@ struct EnergyInfo {
     std::vector<ParamDecl> params;
     bool usePreconditioner;
     bool floatOnly;                   // energy declares fixed `float` unknowns (tests/minimal/laplacian.t)
+    int residualsPerElement = 0;      // scalar residuals per element of the index space / per graph edge (plan-time report, solverGPUGaussNewton.t:128-142); 0 = not stated
+    int residualsPerEdge = 0;
     EnergyOps<float>* (*makeFloat)(const unsigned* dims);
     EnergyOps<double>* (*makeDouble)(const unsigned* dims);
 };

@@ -521,7 +521,7 @@ EnergyInfo curveFittingInfo() {
 }
 EnergyInfo arapInfo() {
     EnergyInfo e;
-    e.name = "arap_mesh_deformation"; e.nDims = 1; e.usePreconditioner = true; e.floatOnly = false;
+    e.name = "arap_mesh_deformation"; e.nDims = 1; e.usePreconditioner = true; e.floatOnly = false; e.residualsPerElement = 3; e.residualsPerEdge = 3;
     e.params = {{ParamDecl::kScalar, "w_fitSqrt", "float", 0}, {ParamDecl::kScalar, "w_regSqrt", "float", 1},
                 {ParamDecl::kUnknown, "Offset", "opt_float3", 2}, {ParamDecl::kUnknown, "Angle", "opt_float3", 3},
                 {ParamDecl::kArray, "UrShape", "opt_float3", 4}, {ParamDecl::kArray, "Constraints", "opt_float3", 5},

@@ -1118,7 +1118,7 @@ template <class T> EnergyOps<T>* makeIW(const unsigned* dims) { return new Image
 
 EnergyInfo imageWarpingInfo() {
     EnergyInfo e;
-    e.name = "image_warping"; e.nDims = 2; e.usePreconditioner = true; e.floatOnly = false;
+    e.name = "image_warping"; e.nDims = 2; e.usePreconditioner = true; e.floatOnly = false; e.residualsPerElement = 10;   // 4 directions x 2 + fit 2 (image_warping.t:13-22)
     e.params = {{ParamDecl::kUnknown, "Offset", "opt_float2", 0}, {ParamDecl::kUnknown, "Angle", "opt_float", 1},
                 {ParamDecl::kArray, "UrShape", "opt_float2", 2},  {ParamDecl::kArray, "Constraints", "opt_float2", 3},
                 {ParamDecl::kArray, "Mask", "opt_float", 4},      {ParamDecl::kScalar, "w_fitSqrt", "float", 5},

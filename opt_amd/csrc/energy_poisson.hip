@@ -323,7 +323,7 @@ struct PoissonOps : EnergyOps<T> {
         ScopedKernel k(ctx, "computeModelCost"); poisson_cost<T, 1><<<grid(), kBlock, 0, ctx.stream>>>(A, delta, out.partials); out.n = grid();
     }
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
-        if (!singleKernel || a.pre) return false;
+        if (!singleKernel || a.pre || a.CtC) return false;      // Gauss-Newton only: the Levenberg-Marquardt loop keeps the generic kernels
         if (a.first) iterIndex = 0;
         const int tiles = ((A.W + kPTileW - 1) / kPTileW) * ((A.H + kPTileH - 1) / kPTileH);
         const int g = std::max(1, std::min(tiles, std::min(kMaxPartials, cus * 8)));
@@ -445,7 +445,7 @@ EnergyOps<double>* makeLaplacianD(const unsigned*) { return nullptr; }
 
 EnergyInfo poissonInfo() {
     EnergyInfo e;
-    e.name = "poisson_image_editing"; e.nDims = 2; e.usePreconditioner = false; e.floatOnly = false;
+    e.name = "poisson_image_editing"; e.nDims = 2; e.usePreconditioner = false; e.floatOnly = false; e.residualsPerElement = 16;   // 4 directions x 4 channels
     e.params = {{ParamDecl::kUnknown, "X", "opt_float4", 0}, {ParamDecl::kArray, "T", "opt_float4", 1}, {ParamDecl::kArray, "M", "opt_float", 2}};
     e.makeFloat = makePoisson<float>; e.makeDouble = makePoisson<double>;
     return e;

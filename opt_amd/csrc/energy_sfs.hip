@@ -213,12 +213,49 @@ __global__ __launch_bounds__(kBlock) void sfs_gather(SArgs<T> A, const T* __rest
 #define SFS_TH 8
 #endif
 constexpr int kSfsTW = SFS_TW, kSfsTH = SFS_TH;
-template <class T, bool LM>
-__global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ CtC, double* __restrict__ partials) {
+// ITER = true turns the same kernel into ONE WHOLE PCG ITERATION (energy.h PcgIterArgs; the scheme of iw_pcgIter with A p kept in memory,
+// because recomputing it would need a 4-pixel apron here): while staging the tile + apron a workgroup first applies PCGStep2 and PCGStep3 of
+// the previous iteration to every pixel it stages -- r_k = r - alpha Ap_{k-1}, z_k = r_k (this energy does not precondition: pre = 1 after
+// the start, solver.t:467-472), p_k = r_k + beta p_{k-1} -- writes r_k, p_k, delta += alpha p_{k-1} (and the Q partial sums for LM) for its
+// own tile, and then applies J^T J (+ CtC) to the staged p_k.  betaNumerator = sum r_k^2 comes from the previous launch's sums by expansion:
+// rr - 2 alpha s2 + alpha^2 s3 with rr = sum r_{k-1}^2, s2 = r.Ap, s3 = Ap.Ap.  The start is the reference's: p_0 comes from memory
+// (PCGInit1: r_0 / 4; LM: the Jacobi-preconditioned r_0 of PCGFinalizeDiagonal, solver.t:650-656) and alphaNumerator_0 = r_0 . p_0, so launch 0
+// also sums rr_0 = r_0 . r_0 for launch 1's expansion.  Per PCG iteration: one launch instead of three (PCGStep1, PCGStep2, PCGStep3).
+template <class T>
+struct SIterK {
+    const T *rOld, *ApOld, *pOld; T *rNew, *pNew; const T* delta; T* deltaOut; const T* b; double* q;
+    int first, restart, rrFromPrivate;
+    const double *aNumPrev, *aDenPrev, *s2Prev, *s3Prev, *rrPrev; int nNum, nDen, n2, n3, nRR;
+    const double *betaNum, *betaDen; int nBetaNum, nBetaDen;
+    double *aNum, *aDen, *s2, *s3, *rr;
+};
+template <class T, bool LM, bool ITER = false>
+__global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ CtC, double* __restrict__ partials,
+                                                         SIterK<T> K = SIterK<T>{}) {
     constexpr int TW = kSfsTW, TH = kSfsTH, VW = TW + 4, VH = TH + 4, QW = TW + 2, QH = TH + 2;
     static_assert(TW * TH == kBlock, "one thread per tile pixel");
-    __shared__ double scratch[kBlock / kWave + 1];
+    __shared__ double scratch[6 * (kBlock / kWave + 1)];
     __shared__ T sv[VH][VW], s0[VH][VW], s1[VH][VW], s2[VH][VW];      // v, g0, g1, g2 on the tile + 2 apron (index [y+2][x+2])
+    __shared__ T sr[ITER ? VH : 1][ITER ? VW : 1];                    // ITER: r_k on the same footprint
+    T alpha = 0, beta = 0;
+    const bool keep = ITER && (K.first != 0 || K.restart != 0);       // r (and, at the start, p) are already those of this iteration
+    if (ITER) {
+        if (K.restart) {
+            const double* const ps[2] = {K.betaNum, K.betaDen}; const int ns[2] = {K.nBetaNum, K.nBetaDen}; double o2[2];
+            sumPartialsN<2>(ps, ns, scratch, o2);
+            const T bNum = (T)o2[0], bDen = (T)o2[1];
+            beta = (bDen > T(0)) ? bNum / bDen : T(0);                // solver.t:544-547
+        } else if (!K.first) {
+            const double* const ps[5] = {K.aNumPrev, K.aDenPrev, K.s2Prev, K.s3Prev, K.rrPrev}; const int ns[5] = {K.nNum, K.nDen, K.n2, K.n3, K.rrFromPrivate ? K.nRR : 0}; double o5[5];
+            sumPartialsN<5>(ps, ns, scratch, o5);
+            const T aNum = (T)o5[0], aDen = (T)o5[1];
+            alpha = (aDen > T(0)) ? aNum / aDen : T(0);               // solver.t:456-459
+            const double rr = K.rrFromPrivate ? o5[4] : o5[0];        // sum r_{k-1}^2: the previous launch's alphaNumerator, except right after the start
+            const double bNumD = fmax(rr - 2.0 * (double)alpha * o5[2] + (double)alpha * (double)alpha * o5[3], 0.0);
+            beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
+        }
+    }
+    double accNum = 0, acc2 = 0, acc3 = 0, accRR = 0, accQ = 0;
     __shared__ T sq[5][QH][QW];                                       // gh, gv, s0..s2 row values on the tile + 1 ring (index [y+1][x+1])
     __shared__ uint8_t smr[QH][QW], smc[QH][QW], sok[QH][QW], svalid[QH][QW];
     const int tilesX = (A.W + TW - 1) / TW, tilesY = (A.H + TH - 1) / TH;
@@ -230,7 +267,17 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
             const int lx = i % VW, ly = i / VW, gx = x0 + lx - 2, gy = y0 + ly - 2;
             const bool in = gx >= 0 && gx < A.W && gy >= 0 && gy < A.H;
             const long g = in ? (long)gy * A.W + gx : 0;
-            sv[ly][lx] = in ? v[g] : T(0); s0[ly][lx] = in ? A.g0[g] : T(0); s1[ly][lx] = in ? A.g1[g] : T(0); s2[ly][lx] = in ? A.g2[g] : T(0);
+            if (ITER) {
+                T rk = 0, pk = 0;
+                if (in) {
+                    const T ro = K.rOld[g], po = K.pOld[g];
+                    rk = keep ? ro : ro - alpha * K.ApOld[g];                                   // PCGStep2 (solver.t:464)
+                    pk = K.first ? po : rk + beta * po;                                         // PCGStep3 with z = r (solver.t:549)
+                    if (lx >= 2 && lx < TW + 2 && ly >= 2 && ly < TH + 2) { K.rNew[g] = rk; K.pNew[g] = pk; }     // this workgroup's own tile
+                }
+                sr[ly][lx] = rk; sv[ly][lx] = pk;
+            } else sv[ly][lx] = in ? v[g] : T(0);
+            s0[ly][lx] = in ? A.g0[g] : T(0); s1[ly][lx] = in ? A.g1[g] : T(0); s2[ly][lx] = in ? A.g2[g] : T(0);
         }
         for (int i = threadIdx.x; i < QW * QH; i += kBlock) {
             const int lx = i % QW, ly = i / QW, gx = x0 + lx - 1, gy = y0 + ly - 1;
@@ -302,10 +349,31 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
             if (!(A.D_i[e] > T(0))) s = 0;
             out[e] = s;
             acc += (double)(ve * s);
+            if (ITER) {
+                const T rk = sr[ty + 2][tx + 2];
+                const T zk = K.first ? ve : rk;                                                 // launch 0: alphaNumerator_0 = r_0 . p_0 (the reference's start)
+                accNum += (double)(zk * rk); acc2 += (double)(rk * s); acc3 += (double)(s * s);
+                if (K.first) accRR += (double)(rk * rk);
+                if (!keep) {                                                                    // the rest of PCGStep2 of iteration k-1 for this pixel
+                    const T dl = K.delta[e] + alpha * K.pOld[e];                                // solver.t:461-462
+                    K.deltaOut[e] = dl;
+                    if (LM) accQ += (double)(T(0.5) * (dl * (rk + K.b[e])));                    // solver.t:483-485
+                }
+            }
         }
     }
-    double t = blockReduceSum(acc, scratch);
-    if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
+    if (ITER) {
+        double vv[6] = {acc, accNum, acc2, acc3, accRR, accQ};
+        blockReduceSumN<6>(vv, scratch);
+        if (threadIdx.x == 0) {
+            K.aDen[blockIdx.x] = vv[0]; K.aNum[blockIdx.x] = vv[1]; K.s2[blockIdx.x] = vv[2]; K.s3[blockIdx.x] = vv[3];
+            if (K.first) K.rr[blockIdx.x] = vv[4];
+            if (LM && K.q) K.q[blockIdx.x] = vv[5];
+        }
+    } else {
+        double t = blockReduceSum(acc, scratch);
+        if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
+    }
 }
 
 template <class T>
@@ -323,6 +391,8 @@ struct SfsOps : EnergyOps<T> {
         HIP_CHECK(hipMalloc((void**)&A.q, 5 * n * sizeof(T))); owned.push_back(A.q);
         int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (const char* e = getenv("OPT_AMD_SFS_TILED")) tiledApply = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_SFS_ONEKERNEL")) oneKernel = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_SFS_GRID")) gridOverride = atoi(e);
     }
     ~SfsOps() override { for (void* p : owned) (void)hipFree(p); }
     int grid() const { return (int)std::max<long>(1, std::min<long>(((long)A.W * A.H + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
@@ -341,11 +411,25 @@ struct SfsOps : EnergyOps<T> {
         { ScopedKernel k(ctx, "PCGInit1"); sfs_gather<T, true, false><<<grid(), kBlock, 0, ctx.stream>>>(A, nullptr, r, diag, nullptr, nullptr); }
     }
     bool tiledApply = true;     // OPT_AMD_SFS_TILED=0: rows pass + gather pass through the q planes
-    int tileGrid() const { const long t = (long)((A.W + kSfsTW - 1) / kSfsTW) * ((A.H + kSfsTH - 1) / kSfsTH); return (int)std::max<long>(1, std::min<long>(t, std::min<long>(kMaxPartials / 2, (long)cus * 8))); }
+    // Grid of the tiled kernels: every workgroup loops over tiles, so the grid is capped at what is co-resident (LDS-limited: 4-5 workgroups per CU);
+    // with more, the last round of workgroups runs on a partly empty chip (2048 workgroups on 1280 slots: 1.6 rounds).  OPT_AMD_SFS_GRID overrides (A/B).
+    int occTiled[2][2] = {{0, 0}, {0, 0}}; int gridOverride = 0;
+    int tileGrid(bool lmv = false, bool iter = false) {
+        const long t = (long)((A.W + kSfsTW - 1) / kSfsTW) * ((A.H + kSfsTH - 1) / kSfsTH);
+        int& o = occTiled[lmv][iter];
+        if (o == 0) {
+            const void* fn = lmv ? (iter ? (const void*)sfs_applyTiled<T, true, true> : (const void*)sfs_applyTiled<T, true, false>)
+                                 : (iter ? (const void*)sfs_applyTiled<T, false, true> : (const void*)sfs_applyTiled<T, false, false>);
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, fn, kBlock, 0));
+            o = std::max(1, std::min(o, 8));
+        }
+        const long cap = gridOverride > 0 ? gridOverride : (long)cus * o;
+        return (int)std::max<long>(1, std::min<long>(t, std::min<long>(kMaxPartials / 2, cap)));
+    }
     void applyJTJ(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) override {
         if (tiledApply) {
             ScopedKernel k(ctx, "PCGStep1");
-            const int g = tileGrid();
+            const int g = tileGrid(CtC != nullptr, false);
             if (CtC) sfs_applyTiled<T, true><<<g, kBlock, 0, ctx.stream>>>(A, v, out, CtC, dot ? dot->partials : nullptr);
             else sfs_applyTiled<T, false><<<g, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, dot ? dot->partials : nullptr);
             if (dot) dot->n = g;
@@ -360,6 +444,34 @@ struct SfsOps : EnergyOps<T> {
     void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {
         ScopedKernel k(ctx, "computeModelCost"); sfs_rows<T, 1><<<grid(), kBlock, 0, ctx.stream>>>(A, delta, out.partials); out.n = grid();
     }
+    // ---- one kernel per PCG iteration (sfs_applyTiled<.., ITER>) ----
+    bool oneKernel = true;              // OPT_AMD_SFS_ONEKERNEL=0: three kernels per iteration (A/B switch)
+    double* rrPartials = nullptr; int nRR = 0; bool prevWasFirst = false;
+    bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
+        if (!oneKernel || !tiledApply || a.pre || this->slab.active) return false;       // this energy does not precondition (pre == nullptr)
+        if (a.ApNew == a.ApOld || a.rNew == a.rOld || a.pNew == a.pOld) return false;     // neighbouring tiles read the old apron while this one writes
+        if (!rrPartials) { HIP_CHECK(hipMalloc((void**)&rrPartials, kMaxPartials * sizeof(double))); owned.push_back(rrPartials); }
+        const bool lmLoop = a.CtC != nullptr;
+        const int g = tileGrid(lmLoop, true);
+        SIterK<T> K{};
+        K.rOld = a.rOld; K.ApOld = a.ApOld; K.pOld = a.pOld; K.rNew = a.rNew; K.pNew = a.pNew; K.delta = a.delta; K.deltaOut = a.deltaOut ? a.deltaOut : a.delta;
+        K.b = a.b; K.q = a.q ? a.q->partials : nullptr; K.first = a.first; K.restart = a.afterReset;
+        K.rrFromPrivate = (!a.first && !a.afterReset && prevWasFirst) ? 1 : 0;
+        K.aNumPrev = a.aNumPrev.partials; K.aDenPrev = a.aDenPrev.partials; K.s2Prev = a.s2Prev.partials; K.s3Prev = a.s3Prev.partials; K.rrPrev = rrPartials;
+        K.nNum = a.aNumPrev.n; K.nDen = a.aDenPrev.n; K.n2 = a.s2Prev.n; K.n3 = a.s3Prev.n; K.nRR = nRR;
+        K.betaNum = a.betaNum.partials; K.betaDen = a.betaDen.partials; K.nBetaNum = a.betaNum.n; K.nBetaDen = a.betaDen.n;
+        K.aNum = a.aNum->partials; K.aDen = a.aDen->partials; K.s2 = a.s2->partials; K.s3 = a.s3->partials; K.rr = rrPartials;
+        {
+            ScopedKernel k(ctx, "PCGIteration");
+            if (lmLoop) sfs_applyTiled<T, true, true><<<g, kBlock, 0, ctx.stream>>>(A, nullptr, a.ApNew, a.CtC, nullptr, K);
+            else sfs_applyTiled<T, false, true><<<g, kBlock, 0, ctx.stream>>>(A, nullptr, a.ApNew, nullptr, nullptr, K);
+        }
+        if (a.first) nRR = g;
+        prevWasFirst = a.first != 0;
+        a.aNum->n = a.aDen->n = a.s2->n = a.s3->n = g;
+        if (a.q) a.q->n = g;
+        return true;
+    }
 };
 
 template <class T> EnergyOps<T>* makeSfs(const unsigned* dims) { return new SfsOps<T>(dims); }
@@ -368,7 +480,7 @@ template <class T> EnergyOps<T>* makeSfs(const unsigned* dims) { return new SfsO
 
 EnergyInfo sfsInfo() {
     EnergyInfo e;
-    e.name = "shape_from_shading"; e.nDims = 2; e.usePreconditioner = false; e.floatOnly = false;
+    e.name = "shape_from_shading"; e.nDims = 2; e.usePreconditioner = false; e.floatOnly = false; e.residualsPerElement = 6;    // E_p, E_g_h, E_g_v, E_s (3)
     e.params = {{ParamDecl::kScalar, "w_p", "float", 0}, {ParamDecl::kScalar, "w_s", "float", 1}, {ParamDecl::kScalar, "w_g", "float", 2},
                 {ParamDecl::kScalar, "f_x", "float", 3}, {ParamDecl::kScalar, "f_y", "float", 4}, {ParamDecl::kScalar, "u_x", "float", 5},
                 {ParamDecl::kScalar, "u_y", "float", 6},

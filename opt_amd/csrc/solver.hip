@@ -297,11 +297,12 @@ struct PcgSolver : SolverBase {
     bool keepReferenceP = false;        // run the (dead) last PCGStep3 so that `p` matches the reference after a step
     std::vector<void*> allocs;
     Reduction redA, redB, redQ, redC;   // alpha denominator, beta numerator, q, cost / init numerator
+    Reduction redQ2;                    // second Q buffer: the LM single-kernel loop enqueues launch k + 1 (which writes Q_k) before the host has read Q_{k-1}
     double* scal = nullptr;             // device: [0],[1] alphaNumerator ping-pong, [2..5] slab totals
     double* scal4[2] = {nullptr, nullptr};   // device: all-reduced {alphaNum, alphaDen, s2, s3} of the single-kernel iteration (slab mode), ping-pong
     int aSlot = 0;
     double* hostBuf = nullptr;          // pinned
-    double* hostBufQ = nullptr; hipEvent_t qEvent = nullptr; int qCount = 0;   // pinned buffer + event of the overlapped q fetch
+    double* hostBufQ = nullptr; hipEvent_t qEvent = nullptr; int qCount = 0; const double* qSrc = nullptr;   // pinned buffer + event of the overlapped q fetch
     T prevCost = 0;
     T trust_region_radius = 0, radius_decrease_factor = 0, min_lm_diagonal = 0, max_lm_diagonal = 0;   // pd.parameters (o.t:933-938)
     hipEvent_t overallStart = nullptr; bool overallOpen = false;
@@ -331,10 +332,13 @@ struct PcgSolver : SolverBase {
         if (const char* e = getenv("OPT_AMD_FUSE")) fuseStep3 = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ONEKERNEL")) oneKernel = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ONEKERNEL_LM")) oneKernelLM = atoi(e) != 0;
-        r2 = allocVec(); if (!lm) Ap2 = allocVec();       // LM uses the A p-free iteration kernel only: no second A p buffer
+        r2 = allocVec(); Ap2 = allocVec();                // second r / A p buffers of the single-kernel iterations (kernels that keep A p in memory read the old one on a halo)
         for (auto& st : setS) for (auto& R : st) R = allocRed();
         if (const char* e = getenv("OPT_AMD_SC1")) storeMode = atoi(e);
-        redA = allocRed(); redB = allocRed(); redQ = allocRed(); redC = allocRed();
+        redA = allocRed(); redB = allocRed(); redC = allocRed();
+        // Q (solver.t:483-485, 1093-1102) is read by the host once per LM iteration and by no kernel: its partials go straight to pinned host memory
+        // (<= 16 KB of posted writes per launch) instead of through a device buffer and a copy kernel per iteration (830 copyBuffer launches, 7 % of config 3's GPU time)
+        for (Reduction* R : {&redQ, &redQ2}) { HIP_CHECK(hipHostMalloc((void**)&R->partials, kMaxPartials * sizeof(double))); memset(R->partials, 0, kMaxPartials * sizeof(double)); R->hostVisible = true; }
         HIP_CHECK(hipMalloc((void**)&scal, 16 * sizeof(double))); HIP_CHECK(hipMemset(scal, 0, 16 * sizeof(double))); allocs.push_back(scal);
         scal4[0] = scal + 8; scal4[1] = scal + 12;
         HIP_CHECK(hipHostMalloc((void**)&hostBuf, kMaxPartials * sizeof(double)));
@@ -344,6 +348,8 @@ struct PcgSolver : SolverBase {
         (void)hipStreamSynchronize(stream);
         for (void* a : allocs) (void)hipFree(a);
         if (hostBuf) (void)hipHostFree(hostBuf);
+        if (redQ.partials) (void)hipHostFree(redQ.partials);
+        if (redQ2.partials) (void)hipHostFree(redQ2.partials);
         if (hostBufQ) { (void)hipHostFree(hostBufQ); (void)hipEventDestroy(qEvent); }
         (void)hipStreamDestroy(stream);
     }
@@ -357,6 +363,7 @@ struct PcgSolver : SolverBase {
             HIP_CHECK(hipStreamSynchronize(stream));
             return hostBuf[0];
         }
+        if (R.hostVisible) { HIP_CHECK(hipStreamSynchronize(stream)); double s = 0; for (int i = 0; i < R.n; ++i) s += R.partials[i]; return s; }
         HIP_CHECK(hipMemcpyAsync(hostBuf, R.partials, R.n * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         double s = 0; for (int i = 0; i < R.n; ++i) s += hostBuf[i];
@@ -369,15 +376,18 @@ struct PcgSolver : SolverBase {
             reduceAcross(&R, 1, scal + 2);
             HIP_CHECK(hipMemcpyAsync(hostBufQ, scal + 2, sizeof(double), hipMemcpyDeviceToHost, stream));
             qCount = 1;
+            qSrc = hostBufQ;
+        } else if (R.hostVisible) {
+            qSrc = R.partials; qCount = R.n;      // the producer wrote pinned host memory: the event is all that is needed
         } else {
             HIP_CHECK(hipMemcpyAsync(hostBufQ, R.partials, R.n * sizeof(double), hipMemcpyDeviceToHost, stream));
-            qCount = R.n;
+            qCount = R.n; qSrc = hostBufQ;
         }
         HIP_CHECK(hipEventRecord(qEvent, stream));
     }
     double endHostSum() {
         HIP_CHECK(hipEventSynchronize(qEvent));
-        double s = 0; for (int i = 0; i < qCount; ++i) s += hostBufQ[i];
+        double s = 0; for (int i = 0; i < qCount; ++i) s += qSrc[i];
         return s;
     }
     // dst[i] = sum over ranks of sum(Rs[i].partials): one launch if the communicator folds the local reduction in (allReducePartials)
@@ -508,7 +518,7 @@ struct PcgSolver : SolverBase {
     // ends with the reference's split Step2 (delta, A delta, r = b - A delta; :1077-1083) on the generic kernels; the next launch then
     // restarts from that r with beta given directly.  Returns false (nothing touched) if the energy has no such kernel.
     bool runSingleKernelLoopLM(const T* preArg, T Q0, T q_tolerance) {
-        if (distributed || traceEnabled || keepReferenceP || !preArg) return false;
+        if (distributed || traceEnabled || keepReferenceP) return false;
         if (!delta2) delta2 = allocVec();                       // zero-filled like delta; every launch that updates delta rewrites all of it
         Reduction prev[4] = {redC, Reduction{}, Reduction{}, Reduction{}};
         int cur = 0;
@@ -517,10 +527,10 @@ struct PcgSolver : SolverBase {
         // One launch from the current state into the alternate buffers (r2, p2, delta2, setS[cur]); adopted later by pointer swaps.
         auto issue = [&](int k, bool restart) -> bool {
             PcgIterArgs<T> a{};
-            a.rOld = r; a.ApOld = Ap_X; a.pOld = p; a.rNew = r2; a.ApNew = Ap_X; a.pNew = p2; a.delta = delta; a.deltaOut = delta2; a.pre = preArg; a.first = k == 0;
+            a.rOld = r; a.ApOld = Ap_X; a.pOld = p; a.rNew = r2; a.ApNew = Ap2; a.pNew = p2; a.delta = delta; a.deltaOut = delta2; a.pre = preArg; a.first = k == 0;
             a.aNumPrev = prev[0]; a.aDenPrev = prev[1]; a.s2Prev = prev[2]; a.s3Prev = prev[3];
             a.aNum = &setS[cur][0]; a.aDen = &setS[cur][1]; a.s2 = &setS[cur][2]; a.s3 = &setS[cur][3];
-            a.CtC = CtC; a.b = b; a.q = &redQ; a.afterReset = restart ? 1 : 0; a.betaNum = bNumDirect; a.betaDen = bDenDirect;
+            a.CtC = CtC; a.b = b; a.q = (k & 1) ? &redQ2 : &redQ; a.afterReset = restart ? 1 : 0; a.betaNum = bNumDirect; a.betaDen = bDenDirect;
             a.lmRadius = trust_region_radius; a.lmMinDiag = min_lm_diagonal; a.lmMaxDiag = max_lm_diagonal;
             issuedRestart = restart;
             return E->pcgIteration(a, ctx);
@@ -530,14 +540,14 @@ struct PcgSolver : SolverBase {
             issued = false;
             // adopt launch lIter
             const bool appliedStep2 = lIter > 0 && !issuedRestart;    // it finished iteration lIter-1 (delta, r, z, p) and summed Q_{lIter-1}
-            std::swap(r, r2); std::swap(p, p2);
+            std::swap(r, r2); std::swap(p, p2); std::swap(Ap_X, Ap2);
             if (appliedStep2) std::swap(delta, delta2);
             for (int i = 0; i < 4; ++i) prev[i] = setS[cur][i];
             cur ^= 1;
             afterReset = false;
             const bool resetNow = ((lIter + 1) % sp.residual_reset_period) == 0;
             if (appliedStep2) {
-                beginHostSum(redQ);
+                beginHostSum((lIter & 1) ? redQ2 : redQ);
                 // The next launch is enqueued before Q is known: it writes only the alternate buffers, so if the test below ends the
                 // linear solve its results are simply never adopted (the fetchQ of solver.t:1098 no longer idles the GPU).
                 if (lIter + 1 < sp.lIterations && !resetNow) { if (!issue(lIter + 1, false)) { fprintf(stderr, "pcgIteration refused mid-loop\n"); exit(1); } issued = true; }

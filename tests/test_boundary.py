@@ -66,8 +66,26 @@ def test_t_reader_rejects_mismatches(opt_lib, tmp_path):
     d = tmp_path / "d"; d.mkdir(); p = d / "image_warping.t"
     p.write_text("-- Array(\"Bogus\", opt_float, {W,H}, 9)\n--[[ Param(\"x\", float, 11) ]]\n" + src.replace(", ", " ,  "))
     ok, msg = opt_lib.check_problem_file(str(p)); assert ok, msg
+    # an edited energy BODY (declarations intact): the reference would compile the edit, hand-written kernels cannot honour it -> refused
+    d = tmp_path / "e"; d.mkdir(); p = d / "image_warping.t"
+    p.write_text(src.replace("Energy(w_fitSqrt * Select(hasTarget, Offset(0,0) - Constraints(0,0), 0.0))", ""))
+    ok, msg = opt_lib.check_problem_file(str(p)); assert not ok and "energy body" in msg
+    d = tmp_path / "f"; d.mkdir(); p = d / "image_warping.t"
+    p.write_text(src.replace("eq(Mask(dx,dy), 0) * inShape", "inShape"))
+    ok, msg = opt_lib.check_problem_file(str(p)); assert not ok and "energy body" in msg
     # missing file
     ok, msg = opt_lib.check_problem_file(str(tmp_path / "nope.t")); assert not ok and "cannot open" in msg
+
+
+def test_energy_body_hash_table_is_current(opt_lib):
+    """Every shipped .t hashes to an entry of opt_amd/csrc/energy_hashes.inc (tools/energy_hashes.py regenerates it after an edit)."""
+    import ctypes
+    L = opt_lib.lib()
+    L.OptAmd_ProblemFileHash.restype = ctypes.c_ulong; L.OptAmd_ProblemFileHash.argtypes = [ctypes.c_char_p]
+    table = open(os.path.join(ROOT, "opt_amd", "csrc", "energy_hashes.inc")).read()
+    for n in opt_lib.registered_energies():
+        h = L.OptAmd_ProblemFileHash(opt_lib.energy_file(n).encode())
+        assert h != 0 and ('{"%s", 0x%016xul' % (n, h)) in table, n
 
 
 def test_no_cpu_fallback_without_device(opt_lib):
