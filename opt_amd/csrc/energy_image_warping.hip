@@ -416,7 +416,8 @@ struct IterK {             // kernel argument block
     // iw_pcgIter2 only.  deltaMode 0: delta += alpha_{k-1} p_{k-1} in every launch.  Paired: 2 = this launch leaves delta alone,
     // 1 = this launch applies the two pending terms alpha_{k-2} p_{k-2} + alpha_{k-1} p_{k-1}, reading p_{k-2} from the pNew buffer
     // just before overwriting it (same thread, same address) -- 12 B/px extra every second launch instead of 24 B/px every launch.
-    int deltaMode; const T* alphaIn; T* alphaOut;   // alpha_{k-2} (written by the previous launch) / where this launch leaves alpha_{k-1}
+    int deltaMode; const T* alphaIn; T* alphaOut;   // alpha_{k-2} (written by the previous launch) / where this launch leaves alpha_{k-1}; [2] of either: the launch's beta
+    int reconP;            // deltaMode 1: rebuild p_{k-2} from the p_{k-1}, r_{k-1} this launch loads anyway instead of reading it (see the kernel)
     // Levenberg-Marquardt variant of iw_pcgIter2 (energy.h PcgIterArgs): CtC, b, the Q partial sums, and the after-reset mode
     const T* CtC; const T* b; double* q; int afterReset; const double* betaNum; int nBetaNum; const double* betaDen; int nBetaDen;
     T* deltaOut;           // where the updated delta is written (== delta: in place)
@@ -684,8 +685,16 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
         const double bNumD = fmax(aNumD - 2.0 * (double)alpha * s2 + (double)alpha * (double)alpha * s3, 0.0);
         beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
     }
-    if (K.alphaOut && blockIdx.x == 0 && threadIdx.x == 0) *K.alphaOut = alpha;
-    const T alpha2 = (K.deltaMode == 1) ? *K.alphaIn : T(0);
+    if (K.alphaOut && blockIdx.x == 0 && threadIdx.x == 0) { K.alphaOut[0] = alpha; K.alphaOut[2] = beta; }
+    const T alpha2 = (K.deltaMode == 1) ? K.alphaIn[0] : T(0);
+    // The deferred term alpha_{k-2} p_{k-2} of an even launch: p_{k-1} = z_{k-1} + beta_{k-2} p_{k-2} was formed by the previous launch from values this
+    // launch has in registers again (p_{k-1} as loaded, z_{k-1} = M r_{k-1}: the same product of the same operands), so
+    // p_{k-2} = (p_{k-1} - z_{k-1}) / beta_{k-2} costs three flops per scalar instead of a 12 B/px read of the p buffer about to be overwritten
+    // (93 -> 81 B/px on even launches).  The subtraction only undoes the one rounding of that fma, an error of the size of the update's own rounding.
+    // beta_{k-2} == 0 (the reference's guard, or an exactly converged solve) leaves nothing to divide by: that launch reads p_{k-2} from memory.
+    const T beta2 = (K.deltaMode == 1 && K.reconP) ? K.alphaIn[2] : T(0);
+    const bool recon = beta2 != T(0);
+    const T invBeta2 = recon ? T(1) / beta2 : T(0);
     const int bx = blockIdx.x % gx, by = blockIdx.x / gx;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int x = bx * kIterStrip2 + wave * kSpan2 + lane - 2;
@@ -769,7 +778,10 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
             const bool own = !IW_OWN_CHECK || (yp >= K.ownBegin && yp < K.ownEnd);
             if (own && !keepR && K.deltaMode != 2) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462), preceded by the deferred term of launch k-1
                 V2<T> d = dO[i]; T da = dA[i];
-                if (K.deltaMode == 1) { const V2<T> q = pO[i]; const T qa = pA[i]; d.x += alpha2 * q.x; d.y += alpha2 * q.y; da += alpha2 * qa; }   // p_{k-2}, about to be overwritten
+                if (K.deltaMode == 1) {
+                    if (recon) { d.x += alpha2 * ((oB.q.ox - oB.mx * oB.rx) * invBeta2); d.y += alpha2 * ((oB.q.oy - oB.my * oB.ry) * invBeta2); da += alpha2 * ((oB.q.a - oB.ma * oB.ra) * invBeta2); }
+                    else { const V2<T> q = pO[i]; const T qa = pA[i]; d.x += alpha2 * q.x; d.y += alpha2 * q.y; da += alpha2 * qa; }   // p_{k-2}, about to be overwritten
+                }
                 d.x += alpha * oB.q.ox; d.y += alpha * oB.q.oy; da += alpha * oB.q.a;
                 st2<kNTS>(dOut, i, d.x, d.y); st1<kNTS>(dAout, i, da);
                 if (LM) {   // Q = 1/2 sum delta . (r + b) with the updated delta and r (solver.t:483-485)
@@ -920,6 +932,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_SLAB_PERIOD")) maxExchangePeriod = std::max(1, atoi(e));
         if (const char* e = getenv("OPT_AMD_FLAG_M")) flagPreconditioner = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_PAIR_DELTA")) pairDelta = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_RECON_P")) reconstructP = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ITER_ROWS")) forceRows = std::max(0, atoi(e));
         HIP_CHECK(hipMalloc((void**)&dNotLattice, sizeof(int)));
     }
@@ -1026,7 +1039,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         return lat ? (flip ? (const void*)iw_pcgIter2<T, true, 1, true, true> : (const void*)iw_pcgIter2<T, true, 1, false, true>)
                    : (flip ? (const void*)iw_pcgIter2<T, false, 1, true, true> : (const void*)iw_pcgIter2<T, false, 1, false, true>);
     }
-    bool flagPreconditioner = true, pairDelta = true;
+    bool flagPreconditioner = true, pairDelta = true, reconstructP = true;
     int iterIndex = 0; bool deferredTerm = false; T* alphaSlots = nullptr;
     T* mc = nullptr; int* dNotLattice = nullptr; bool lattice = false, useLattice = true, useCompactM = true;
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
@@ -1070,12 +1083,12 @@ struct ImageWarpingOps : EnergyOps<T> {
         const bool paired = noAp && pairDelta && !lmLoop;      // LM needs the current delta every iteration for Q
         int deltaMode = 0; const T* alphaIn = nullptr; T* alphaOut = nullptr;
         if (paired) {
-            if (!alphaSlots) HIP_CHECK(hipMalloc((void**)&alphaSlots, 2 * sizeof(T)));
+            if (!alphaSlots) { HIP_CHECK(hipMalloc((void**)&alphaSlots, 4 * sizeof(T))); HIP_CHECK(hipMemsetAsync(alphaSlots, 0, 4 * sizeof(T), ctx.stream)); }   // [0,1] alpha, [2,3] beta, ping-pong
             deltaMode = (iterIndex >= 2 && iterIndex % 2 == 0) ? 1 : 2;           // launch 0 has nothing to apply; odd launches defer
             alphaOut = alphaSlots + (iterIndex & 1); alphaIn = alphaSlots + ((iterIndex & 1) ^ 1);
         }
         deferredTerm = paired && iterIndex >= 1 && iterIndex % 2 == 1;            // after an odd launch alpha_{k-1} p_{k-1} is still owed (pcgFinish)
-        IterK<T> K{a.rOld, a.ApOld, a.pOld, a.rNew, a.ApNew, a.pNew, a.delta, a.pre, a.first, pre == 2 ? mc : nullptr, iterFlip, deltaMode, alphaIn, alphaOut,
+        IterK<T> K{a.rOld, a.ApOld, a.pOld, a.rNew, a.ApNew, a.pNew, a.delta, a.pre, a.first, pre == 2 ? mc : nullptr, iterFlip, deltaMode, alphaIn, alphaOut, reconstructP ? 1 : 0,
                    a.CtC, a.b, a.q ? a.q->partials : nullptr, a.afterReset, a.betaNum.partials, a.betaNum.n, a.betaDen.partials, a.betaDen.n,
                    a.deltaOut ? a.deltaOut : a.delta, a.lmRadius, a.lmMinDiag, a.lmMaxDiag,
                    a.aNumPrev.partials, a.aDenPrev.partials, a.s2Prev.partials, a.s3Prev.partials, a.aNumPrev.n, a.aDenPrev.n, a.s2Prev.n, a.s3Prev.n,
