@@ -81,18 +81,20 @@ struct PartialsIn { const double* p[kMaxVals]; int n[kMaxVals]; };
 __global__ __launch_bounds__(256) void k_mailAllReduce(double* __restrict__ buf, PartialsIn parts, int usePartials, int n, Peers P, int rank, int world, u64 seq,
                                                        long long timeoutTicks, volatile int* hostErr) {
     __shared__ double vals[kMaxVals];
-    __shared__ double wsum[4];
+    __shared__ double wsum[kMaxVals][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (usePartials) {
-        for (int i = 0; i < n; ++i) {
-            double t = 0;
-            for (int k = tid; k < parts.n[i]; k += 256) t += parts.p[i][k];
-            for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-            if (lane == 0) wsum[wave] = t;
-            __syncthreads();
-            if (tid == 0) vals[i] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
-            __syncthreads();
+    if (usePartials) {      // all n arrays in one pass: the loads (L2 misses on what the previous kernel just wrote) are in flight together, one barrier
+        double t[kMaxVals];
+#pragma unroll
+        for (int i = 0; i < kMaxVals; ++i) { t[i] = 0; if (i < n) for (int k = tid; k < parts.n[i]; k += 256) t[i] += parts.p[i][k]; }
+#pragma unroll
+        for (int i = 0; i < kMaxVals; ++i) {
+            for (int off = 32; off > 0; off >>= 1) t[i] += __shfl_down(t[i], off, 64);
+            if (lane == 0) wsum[i][wave] = t[i];
         }
+        __syncthreads();
+        if (tid < n) vals[tid] = ((wsum[tid][0] + wsum[tid][1]) + wsum[tid][2]) + wsum[tid][3];
+        __syncthreads();
     } else {
         if (tid < n) vals[tid] = buf[tid];
         __syncthreads();

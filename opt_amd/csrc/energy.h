@@ -98,9 +98,13 @@ struct EnergyOps {
                                const Reduction& /*bNum*/, const double* /*aNumOld*/, double* /*aNumNext*/, LaunchCtx&) { return false; }
     // Optional: one WHOLE Gauss-Newton PCG iteration as a single kernel (see PcgIterArgs and solver.hip).
     virtual bool pcgIteration(const PcgIterArgs<T>& /*args*/, LaunchCtx&) { return false; }
+    // Slab mode, after a pcgIteration launch with iterStateExchange: which vectors (solver layout) carry the state whose ghost rows the neighbours
+    // must refresh.  0 = the rNew / pNew the launch was given; a kernel set that keeps its loop state in buffers of its own lists them here.
+    virtual int iterExchangeVectors(T** /*out4*/) { return 0; }
     // Called once after the last pcgIteration of a linear solve, before the solver adds the last term alpha p to delta:
     // lets a kernel set that defers part of its delta update apply what is left.  pPrev = the p buffer the last launch read.
-    virtual void pcgFinish(const T* /*pPrev*/, T* /*delta*/, LaunchCtx&) {}
+    // Returns where the search direction of the last launch lives if the kernel set kept it in a buffer of its own (nullptr: in the pNew it was given).
+    virtual const T* pcgFinish(const T* /*pPrev*/, T* /*delta*/, LaunchCtx&) { return nullptr; }
     // Optional block-local solver (kind "patchGaussNewtonGPU", OptAmd.h): one additive-Schwarz sweep of LDS-resident patch PCG solves over
     // a tiling shifted by (fx, fy) patch widths, nPatchIters inner iterations each, applied to the unknowns directly; patchFinish is called
     // after the last sweep of a step and must leave the result in the caller's unknown buffers.  false = the energy has no such kernel.

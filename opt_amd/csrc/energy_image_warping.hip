@@ -418,6 +418,11 @@ struct IterK {             // kernel argument block
     // just before overwriting it (same thread, same address) -- 12 B/px extra every second launch instead of 24 B/px every launch.
     int deltaMode; const T* alphaIn; T* alphaOut;   // alpha_{k-2} (written by the previous launch) / where this launch leaves alpha_{k-1}; [2] of either: the launch's beta
     int reconP;            // deltaMode 1: rebuild p_{k-2} from the p_{k-1}, r_{k-1} this launch loads anyway instead of reading it (see the kernel)
+    // iw_pcgIter2, Gauss-Newton: r is not kept in memory at all.  p_{k-1} = M r_{k-1} + beta_{k-2} p_{k-2} determines r_{k-1} from the last two search
+    // directions, so the state of the loop is a ring of three p buffers: a launch reads p_{k-1} and p_{k-2} (through rOld), rebuilds r_{k-1}, and writes p_k
+    // only: 12 B/px less traffic per launch.  rfree = 0: r in memory (rOld / rNew);  1: rOld holds p_{k-2}, r rebuilt;  2: the first two launches of a
+    // linear solve -- rOld still holds the solver's true r_0, nothing to rebuild, but r is not written either.
+    int rfree;
     // Levenberg-Marquardt variant of iw_pcgIter2 (energy.h PcgIterArgs): CtC, b, the Q partial sums, and the after-reset mode
     const T* CtC; const T* b; double* q; int afterReset; const double* betaNum; int nBetaNum; const double* betaDen; int nBetaDen;
     T* deltaOut;           // where the updated delta is written (== delta: in place)
@@ -692,6 +697,8 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
     // p_{k-2} = (p_{k-1} - z_{k-1}) / beta_{k-2} costs three flops per scalar instead of a 12 B/px read of the p buffer about to be overwritten
     // (93 -> 81 B/px on even launches).  The subtraction only undoes the one rounding of that fma, an error of the size of the update's own rounding.
     // beta_{k-2} == 0 (the reference's guard, or an exactly converged solve) leaves nothing to divide by: that launch reads p_{k-2} from memory.
+    const bool reconR = !LM && K.rfree == 1;
+    const T betaOlder = reconR ? K.alphaIn[2] : T(0);      // the beta of the previous launch: p_{k-1} = M r_{k-1} + betaOlder p_{k-2}
     const T beta2 = (K.deltaMode == 1 && K.reconP) ? K.alphaIn[2] : T(0);
     const bool recon = beta2 != T(0);
     const T invBeta2 = recon ? T(1) / beta2 : T(0);
@@ -713,7 +720,7 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
     // and the neighbour count of the flag byte.  The Offset entries repeat iw_evalJTF's accumulation order, so they are the
     // values the solver's preconditioner vector holds, bit for bit; the Angle entries use |R'(a) n|^2 = 1 exactly where
     // iw_evalJTF rounds cos^2 + sin^2.
-    __shared__ T mTab[16], cTab[16];
+    __shared__ T mTab[16], cTab[16], iTab[16];      // iTab = 1 / M = (1 + sqrt(d))^2 directly (r-free mode)
     if (PRE == 3) {
         if (threadIdx.x < 15) {
             const int t = threadIdx.x, cnt = t < 10 ? t % 5 : t - 10;
@@ -727,7 +734,7 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
                 const T radius = K.lmRadius, unclamped = d * (T(1) / radius), clampMul = (T(1) / gi) / radius;
                 const T c = fmin(fmax(unclamped, K.lmMin * clampMul), K.lmMax * clampMul);
                 cTab[t] = c; mTab[t] = T(1) / (c + radius * unclamped);
-            } else mTab[t] = gi;
+            } else { mTab[t] = gi; iTab[t] = sq * sq; }
         }
         __syncthreads();
     }
@@ -741,11 +748,19 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
         o.q.fw = (w.f & kFit) ? wf2 : T(0);
         o.rx = w.ro.x; o.ry = w.ro.y; o.ra = w.ra;
         if (!(LM && PRE == 3)) { o.cx = w.co.x; o.cy = w.co.y; o.ca = w.ca; }
+        T ix = 1, iy = 1, ia = 1;
         if (PRE == 3) {
             const int cnt = (w.f >> kCountShift) & 7, io = cnt + ((w.f & kFit) ? 5 : 0);
             o.mx = o.my = mTab[io]; o.ma = mTab[10 + cnt];
             if (LM) { o.cx = o.cy = cTab[io]; o.ca = cTab[10 + cnt]; }
-        } else { o.mx = w.mo.x; o.my = (PRE == 2) ? w.mo.x : w.mo.y; o.ma = (PRE == 2) ? w.mo.y : w.ma; }
+            else if (reconR) { ix = iy = iTab[io]; ia = iTab[10 + cnt]; }
+        } else {
+            o.mx = w.mo.x; o.my = (PRE == 2) ? w.mo.x : w.mo.y; o.ma = (PRE == 2) ? w.mo.y : w.ma;
+            if (!LM && PRE != 0 && reconR) { ix = T(1) / o.mx; iy = T(1) / o.my; ia = T(1) / o.ma; }
+        }
+        if (!LM && reconR) {      // r_{k-1} = (p_{k-1} - beta p_{k-2}) / M: w.ro / w.ra were loaded from the p_{k-2} buffer
+            o.rx = (o.q.ox - betaOlder * w.ro.x) * ix; o.ry = (o.q.oy - betaOlder * w.ro.y) * iy; o.ra = (o.q.a - betaOlder * w.ra) * ia;
+        }
     };
     // J^T J at centre c; prev / next are the rows before / after it in sweep order
     auto applyA = [&](const Q<T>& c, const Q<T>& lf, const Q<T>& rt, const Q<T>& prev, const Q<T>& next, T& ox, T& oy, T& oa) {
@@ -780,7 +795,10 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
                 V2<T> d = dO[i]; T da = dA[i];
                 if (K.deltaMode == 1) {
                     if (recon) { d.x += alpha2 * ((oB.q.ox - oB.mx * oB.rx) * invBeta2); d.y += alpha2 * ((oB.q.oy - oB.my * oB.ry) * invBeta2); da += alpha2 * ((oB.q.a - oB.ma * oB.ra) * invBeta2); }
-                    else { const V2<T> q = pO[i]; const T qa = pA[i]; d.x += alpha2 * q.x; d.y += alpha2 * q.y; da += alpha2 * qa; }   // p_{k-2}, about to be overwritten
+                    else {      // p_{k-2} from memory: the p buffer about to be overwritten, or (r-free ring) the buffer read through rOld
+                        const V2<T>* qO = (!LM && K.rfree) ? (const V2<T>*)K.rOld : (const V2<T>*)pO; const T* qA = (!LM && K.rfree) ? K.rOld + 2 * N : (const T*)pA;
+                        const V2<T> q = qO[i]; const T qa = qA[i]; d.x += alpha2 * q.x; d.y += alpha2 * q.y; da += alpha2 * qa;
+                    }
                 }
                 d.x += alpha * oB.q.ox; d.y += alpha * oB.q.oy; da += alpha * oB.q.a;
                 st2<kNTS>(dOut, i, d.x, d.y); st1<kNTS>(dAout, i, da);
@@ -789,7 +807,8 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
                     accQ += (double)(T(0.5) * (d.x * (rx + bo.x))) + (double)(T(0.5) * (d.y * (ry + bo.y))) + (double)(T(0.5) * (da * (ra + ba)));
                 }
             }
-            st2<kNTS>(rO, i, rx, ry); st1<kNTS>(rA, i, ra); st2<kNTS>(pO, i, nC.q.ox, nC.q.oy); st1<kNTS>(pA, i, nC.q.a);
+            if (LM || !K.rfree) { st2<kNTS>(rO, i, rx, ry); st1<kNTS>(rA, i, ra); }
+            st2<kNTS>(pO, i, nC.q.ox, nC.q.oy); st1<kNTS>(pA, i, nC.q.a);
             if (own) accNum += (double)(nC.zx * rx + nC.zy * ry + nC.za * ra);
         }
         Q<T> l2 = nB.lf, r2 = nB.rt;
@@ -933,10 +952,11 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_FLAG_M")) flagPreconditioner = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_PAIR_DELTA")) pairDelta = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_RECON_P")) reconstructP = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_RFREE")) rFree = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ITER_ROWS")) forceRows = std::max(0, atoi(e));
         HIP_CHECK(hipMalloc((void**)&dNotLattice, sizeof(int)));
     }
-    ~ImageWarpingOps() override { (void)hipFree(A.flags); (void)hipFree(A.cs); if (mc) (void)hipFree(mc); if (alphaSlots) (void)hipFree(alphaSlots); (void)hipFree(dNotLattice); }
+    ~ImageWarpingOps() override { for (T* b : ring) if (b) (void)hipFree(b); (void)hipFree(A.flags); (void)hipFree(A.cs); if (mc) (void)hipFree(mc); if (alphaSlots) (void)hipFree(alphaSlots); (void)hipFree(dNotLattice); }
     int flatGrid(long n) const { return (int)std::max<long>(1, std::min<long>((n + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
     void bind(void** p, LaunchCtx& ctx) override {
         A.Offset = (const T*)p[0]; A.Angle = (const T*)p[1]; A.UrShape = (const T*)p[2]; A.Constraints = (const T*)p[3]; A.Mask = (const T*)p[4];
@@ -1039,7 +1059,8 @@ struct ImageWarpingOps : EnergyOps<T> {
         return lat ? (flip ? (const void*)iw_pcgIter2<T, true, 1, true, true> : (const void*)iw_pcgIter2<T, true, 1, false, true>)
                    : (flip ? (const void*)iw_pcgIter2<T, false, 1, true, true> : (const void*)iw_pcgIter2<T, false, 1, false, true>);
     }
-    bool flagPreconditioner = true, pairDelta = true, reconstructP = true;
+    bool flagPreconditioner = true, pairDelta = true, reconstructP = true, rFree = true;
+    T* ring[3] = {nullptr, nullptr, nullptr}; const T* r0Ptr = nullptr; bool lastLoopRfree = false;
     int iterIndex = 0; bool deferredTerm = false; T* alphaSlots = nullptr;
     T* mc = nullptr; int* dNotLattice = nullptr; bool lattice = false, useLattice = true, useCompactM = true;
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
@@ -1081,6 +1102,20 @@ struct ImageWarpingOps : EnergyOps<T> {
         splitRows(rows, gx, cus * occIter[L], gy, rowsPerGroup);
         if (a.first) iterIndex = 0;
         const bool paired = noAp && pairDelta && !lmLoop;      // LM needs the current delta every iteration for Q
+        // r-free loop (IterK::rfree): Gauss-Newton with a preconditioner; slabs then exchange the ghost rows of the two newest p instead of r and p
+        const bool rfreeLoop = paired && rFree && pre != 0;
+        const T *rOldPtr = a.rOld, *pOldPtr = a.pOld; T* pNewPtr = a.pNew; int rfreeFlag = 0;
+        if (rfreeLoop) {
+            const size_t bytes = (size_t)A.W * A.H * 3 * sizeof(T);
+            for (int j = 0; j < 3; ++j) if (!ring[j]) { HIP_CHECK(hipMalloc((void**)&ring[j], bytes)); HIP_CHECK(hipMemsetAsync(ring[j], 0, bytes, ctx.stream)); }
+            if (a.first) r0Ptr = a.rOld;                       // the solver swaps its r buffers after every launch; this one keeps r_0 until launch 1 has read it
+            const int k = iterIndex;
+            pOldPtr = k == 0 ? a.pOld : ring[(k - 1) % 3];     // ring[j % 3] holds p_j
+            rOldPtr = k <= 1 ? r0Ptr : ring[(k - 2) % 3];
+            pNewPtr = ring[k % 3];
+            rfreeFlag = k <= 1 ? 2 : 1;
+        }
+        lastLoopRfree = rfreeLoop;
         int deltaMode = 0; const T* alphaIn = nullptr; T* alphaOut = nullptr;
         if (paired) {
             if (!alphaSlots) { HIP_CHECK(hipMalloc((void**)&alphaSlots, 4 * sizeof(T))); HIP_CHECK(hipMemsetAsync(alphaSlots, 0, 4 * sizeof(T), ctx.stream)); }   // [0,1] alpha, [2,3] beta, ping-pong
@@ -1088,8 +1123,8 @@ struct ImageWarpingOps : EnergyOps<T> {
             alphaOut = alphaSlots + (iterIndex & 1); alphaIn = alphaSlots + ((iterIndex & 1) ^ 1);
         }
         deferredTerm = paired && iterIndex >= 1 && iterIndex % 2 == 1;            // after an odd launch alpha_{k-1} p_{k-1} is still owed (pcgFinish)
-        IterK<T> K{a.rOld, a.ApOld, a.pOld, a.rNew, a.ApNew, a.pNew, a.delta, a.pre, a.first, pre == 2 ? mc : nullptr, iterFlip, deltaMode, alphaIn, alphaOut, reconstructP ? 1 : 0,
-                   a.CtC, a.b, a.q ? a.q->partials : nullptr, a.afterReset, a.betaNum.partials, a.betaNum.n, a.betaDen.partials, a.betaDen.n,
+        IterK<T> K{rOldPtr, a.ApOld, pOldPtr, a.rNew, a.ApNew, pNewPtr, a.delta, a.pre, a.first, pre == 2 ? mc : nullptr, iterFlip, deltaMode, alphaIn, alphaOut, reconstructP ? 1 : 0,
+                   rfreeFlag, a.CtC, a.b, a.q ? a.q->partials : nullptr, a.afterReset, a.betaNum.partials, a.betaNum.n, a.betaDen.partials, a.betaDen.n,
                    a.deltaOut ? a.deltaOut : a.delta, a.lmRadius, a.lmMinDiag, a.lmMaxDiag,
                    a.aNumPrev.partials, a.aDenPrev.partials, a.s2Prev.partials, a.s3Prev.partials, a.aNumPrev.n, a.aDenPrev.n, a.s2Prev.n, a.s3Prev.n,
                    a.aNum->partials, a.aDen->partials, a.s2->partials, a.s3->partials, A.yBegin, A.yEnd};
@@ -1108,12 +1143,25 @@ struct ImageWarpingOps : EnergyOps<T> {
     }
     // After the last launch L-1 of a linear solve.  If it was an odd launch, the term alpha_{L-2} p_{L-2} was deferred: pPrev is the
     // p buffer that launch read (p_{L-2}) and alpha_{L-2} sits in the slot that launch wrote.  The solver then adds alpha_{L-1} p_{L-1}.
-    void pcgFinish(const T* pPrev, T* delta, LaunchCtx& ctx) override {
-        if (!deferredTerm) return;
+    int iterExchangeVectors(T** out) override {      // after launch iterIndex - 1
+        if (!lastLoopRfree || iterIndex < 1) return 0;
+        out[0] = ring[(iterIndex - 1) % 3];
+        if (iterIndex < 2) return 1;                      // launch 1 reads the solver's r_0 (ghost rows exchanged before the loop) and p_0
+        out[1] = ring[(iterIndex - 2) % 3];
+        return 2;
+    }
+    const T* pcgFinish(const T* pPrev, T* delta, LaunchCtx& ctx) override {
+        const T* pLast = nullptr;
+        if (lastLoopRfree && iterIndex >= 1) {      // r-free ring: launch j left p_j in ring[j % 3]
+            pLast = ring[(iterIndex - 1) % 3];
+            if (iterIndex >= 2) pPrev = ring[(iterIndex - 2) % 3];
+        }
+        if (!deferredTerm) return pLast;
         ScopedKernel k(ctx, "PCGStep2_delta");
         const long n = 3L * A.W * A.H;
         iw_axpyDeferred<T><<<flatGrid(n), kBlock, 0, ctx.stream>>>(delta, pPrev, alphaSlots + ((iterIndex - 1) & 1), n);
         deferredTerm = false;
+        return pLast;
     }
     void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {
         ScopedKernel k(ctx, "computeModelCost");

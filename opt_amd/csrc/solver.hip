@@ -486,7 +486,10 @@ struct PcgSolver : SolverBase {
             std::swap(r, r2); std::swap(Ap_X, Ap2); std::swap(p, p2);
             if (distributed && E->iterStateExchange && E->iterExchangeDue) {   // Ap-free kernel: the neighbours' edge rows of r_k and p_k, one grouped exchange
                 std::vector<T*> bases;
-                for (T* v : {r, p}) for (size_t i = 0; i < E->unknowns.size(); ++i) bases.push_back(v + E->unknowns[i].offset);
+                T* vecs[4] = {r, p, nullptr, nullptr};
+                int nv = E->iterExchangeVectors(vecs);
+                if (nv == 0) nv = 2;
+                for (int v = 0; v < nv; ++v) for (size_t i = 0; i < E->unknowns.size(); ++i) bases.push_back(vecs[v] + E->unknowns[i].offset);
                 exchangeRows(bases);
             }
             for (int i = 0; i < 4; ++i) prev[i] = setS[cur][i];
@@ -507,9 +510,10 @@ struct PcgSolver : SolverBase {
             cur ^= 1;
         }
         // the last iteration's delta += alpha p (PCGStep2, solver.t:461-462); r, z, p of that iteration are dead
-        E->pcgFinish(p2, delta, ctx);
+        const T* pLast = E->pcgFinish(p2, delta, ctx);
+        if (!pLast) pLast = p;
         finalizeLocal(prev[0], scal + 2);
-        { ScopedKernel k(ctx, "PCGStep2_delta"); k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, p, nPacks, scal + 2, prev[1].partials, prev[1].n); }
+        { ScopedKernel k(ctx, "PCGStep2_delta"); k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, pLast, nPacks, scal + 2, prev[1].partials, prev[1].n); }
         return true;
     }
     // ---- the same for Levenberg-Marquardt (energy.h PcgIterArgs, LM fields).  Launch k applies Step2 and Step3 of iteration k-1 and

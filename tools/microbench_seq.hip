@@ -77,7 +77,11 @@ __global__ __launch_bounds__(BLOCK) void k(Bufs B, int rowsPerGroup, int gx, int
         if constexpr (PX == 1) {
             if (EVEN) {
                 F2 dd = ((const F2*)B.delta)[i]; float da = B.delta[2 * N + i];
+#ifdef RECON_P     // p_{k-2} rebuilt from p_{k-1}, r_{k-1} (what the kernel does since round 2) instead of read
+                const F2 qq = F2{r.v[3] - r.v[0], r.v[4] - r.v[1]}; const float qa = r.v[5] - r.v[2];
+#else
                 const F2 qq = ((const F2*)B.pOut)[i]; const float qa = B.pOut[2 * N + i];
+#endif
                 dd += 0.25f * qq + 0.125f * F2{r.v[3], r.v[4]}; da += 0.25f * qa + 0.125f * r.v[5];
                 ((F2*)B.delta)[i] = dd; B.delta[2 * N + i] = da;
             }
