@@ -16,7 +16,7 @@ OPT_AMD_COMM=rccl) and every 7th iteration exchange 8 edge rows of r and p with 
 The same JSON line carries
   roofline     : the dominant kernel (`PCGIteration`: ONE launch per PCG iteration doing the work of the reference's PCGStep1 + PCGStep2 +
                  PCGStep3) timed with hipEvents on the solver's stream.  `achieved` = the bytes the kernel has to move (its own byte model,
-                 65 B/pixel: r, p in and out, angle, flags, delta every second launch -- DESIGN.md section 3.1) / average launch time,
+                 53 B/pixel: the last two search directions in, the new one out, angle, flags, delta every second launch -- DESIGN.md section 3.1) / average launch time,
                  `frac` = achieved / 8 TB/s: a physical fraction.  `traffic` = HBM bytes per launch measured with rocprofv3 PMC passes of
                  THIS kernel source (profiles/*_traffic.json carries the source hash; a stale file is ignored), `hbm_frac` = traffic / time / peak.
                  `algorithmic_equiv` keeps SURVEY.md 8(d)'s scale: the reference algorithm's 180 B/pixel (three kernels) over the same time.
@@ -36,10 +36,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_PIXEL = 48 + 96 + 36   # PCGStep1 + PCGStep2 + PCGStep3 of the reference formulation
-# what iw_pcgIter2 has to move per pixel per launch, float: r 12 + p 12 in, r 12 + p 12 out, angle 4, flags 1 = 53;
-# every second launch additionally delta 12 in / 12 out = 24 -> 12 on average (p_{k-2} is rebuilt from p_{k-1} and r_{k-1}, not read);
-# general UrShape: + U 8 + M 8
-MODEL_BYTES_PER_PIXEL = {"lattice": 53 + 12, "general": 53 + 12 + 16}
+# what iw_pcgIter2 has to move per pixel per launch, float, Gauss-Newton: p_{k-1} 12 + p_{k-2} 12 in (r is rebuilt from them),
+# p_k 12 out, angle 4, flags 1 = 41; every second launch additionally delta 12 in / 12 out = 24 -> 12 on average; general UrShape: + U 8 + M 8
+MODEL_BYTES_PER_PIXEL = {"lattice": 41 + 12, "general": 41 + 12 + 16}
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 KERNEL_SOURCES = ["opt_amd/csrc/energy_image_warping.hip", "opt_amd/csrc/solver.hip", "opt_amd/csrc/common.h", "opt_amd/csrc/energy.h", "opt_amd/build.py"]
 

@@ -85,7 +85,10 @@ __global__ __launch_bounds__(BLOCK) void k(Bufs B, int rowsPerGroup, int gx, int
                 dd += 0.25f * qq + 0.125f * F2{r.v[3], r.v[4]}; da += 0.25f * qa + 0.125f * r.v[5];
                 ((F2*)B.delta)[i] = dd; B.delta[2 * N + i] = da;
             }
-            ((F2*)B.rOut)[i] = F2{o[0], o[1]}; B.rOut[2 * N + i] = o[2]; ((F2*)B.pOut)[i] = F2{o[3], o[4]}; B.pOut[2 * N + i] = o[5];
+#ifndef RFREE      // r-free loop (round 2): the two input vectors are p_{k-1}, p_{k-2}, only p_k is written
+            ((F2*)B.rOut)[i] = F2{o[0], o[1]}; B.rOut[2 * N + i] = o[2];
+#endif
+            ((F2*)B.pOut)[i] = F2{o[3], o[4]}; B.pOut[2 * N + i] = o[5];
         } else {
             if (EVEN) {
                 F4 dd = *(const F4*)(B.delta + 2 * i); F2 da = *(const F2*)(B.delta + 2 * N + i);
