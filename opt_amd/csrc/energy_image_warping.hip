@@ -649,6 +649,7 @@ struct OldRow {            // one row of iteration k-1: p_{k-1} and, while still
     Q<T> q;
     T rx, ry, ra, mx, my, ma;
     T cx, cy, ca;
+    T p2x, p2y, p2a;       // r-free loop: p_{k-2} of this pixel as loaded (the deferred delta term of an even launch needs it exactly)
 };
 template <class T>
 struct NewRow {            // one row of iteration k: p_k, z_k, M, and the shifted constant fields of its neighbours
@@ -699,7 +700,8 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
     // beta_{k-2} == 0 (the reference's guard, or an exactly converged solve) leaves nothing to divide by: that launch reads p_{k-2} from memory.
     const bool reconR = !LM && K.rfree == 1;
     const T betaOlder = reconR ? K.alphaIn[2] : T(0);      // the beta of the previous launch: p_{k-1} = M r_{k-1} + betaOlder p_{k-2}
-    const T beta2 = (K.deltaMode == 1 && K.reconP) ? K.alphaIn[2] : T(0);
+    // (In the r-free loop p_{k-2} is an input of the launch anyway -- read through rOld two trips earlier, still in L1 / L2 -- and is simply read again: exact.)
+    const T beta2 = (K.deltaMode == 1 && K.reconP && (!K.rfree || K.reconP == 2)) ? K.alphaIn[2] : T(0);      // reconP == 2: A/B switch (OPT_AMD_RECON_P=2)
     const bool recon = beta2 != T(0);
     const T invBeta2 = recon ? T(1) / beta2 : T(0);
     const int bx = blockIdx.x % gx, by = blockIdx.x / gx;
@@ -758,6 +760,7 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
             o.mx = w.mo.x; o.my = (PRE == 2) ? w.mo.x : w.mo.y; o.ma = (PRE == 2) ? w.mo.y : w.ma;
             if (!LM && PRE != 0 && reconR) { ix = T(1) / o.mx; iy = T(1) / o.my; ia = T(1) / o.ma; }
         }
+        if (!LM && K.rfree) { o.p2x = w.ro.x; o.p2y = w.ro.y; o.p2a = w.ra; }
         if (!LM && reconR) {      // r_{k-1} = (p_{k-1} - beta p_{k-2}) / M: w.ro / w.ra were loaded from the p_{k-2} buffer
             o.rx = (o.q.ox - betaOlder * w.ro.x) * ix; o.ry = (o.q.oy - betaOlder * w.ro.y) * iy; o.ra = (o.q.a - betaOlder * w.ra) * ia;
         }
@@ -794,7 +797,8 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
             if (own && !keepR && K.deltaMode != 2) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462), preceded by the deferred term of launch k-1
                 V2<T> d = dO[i]; T da = dA[i];
                 if (K.deltaMode == 1) {
-                    if (recon) { d.x += alpha2 * ((oB.q.ox - oB.mx * oB.rx) * invBeta2); d.y += alpha2 * ((oB.q.oy - oB.my * oB.ry) * invBeta2); da += alpha2 * ((oB.q.a - oB.ma * oB.ra) * invBeta2); }
+                    if (!LM && K.rfree == 1 && K.reconP != 2) { d.x += alpha2 * oB.p2x; d.y += alpha2 * oB.p2y; da += alpha2 * oB.p2a; }      // p_{k-2} kept from the load: exact
+                    else if (recon) { d.x += alpha2 * ((oB.q.ox - oB.mx * oB.rx) * invBeta2); d.y += alpha2 * ((oB.q.oy - oB.my * oB.ry) * invBeta2); da += alpha2 * ((oB.q.a - oB.ma * oB.ra) * invBeta2); }
                     else {      // p_{k-2} from memory: the p buffer about to be overwritten, or (r-free ring) the buffer read through rOld
                         const V2<T>* qO = (!LM && K.rfree) ? (const V2<T>*)K.rOld : (const V2<T>*)pO; const T* qA = (!LM && K.rfree) ? K.rOld + 2 * N : (const T*)pA;
                         const V2<T> q = qO[i]; const T qa = qA[i]; d.x += alpha2 * q.x; d.y += alpha2 * q.y; da += alpha2 * qa;
@@ -951,7 +955,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_SLAB_PERIOD")) maxExchangePeriod = std::max(1, atoi(e));
         if (const char* e = getenv("OPT_AMD_FLAG_M")) flagPreconditioner = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_PAIR_DELTA")) pairDelta = atoi(e) != 0;
-        if (const char* e = getenv("OPT_AMD_RECON_P")) reconstructP = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_RECON_P")) reconstructP = atoi(e);
         if (const char* e = getenv("OPT_AMD_RFREE")) rFree = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ITER_ROWS")) forceRows = std::max(0, atoi(e));
         HIP_CHECK(hipMalloc((void**)&dNotLattice, sizeof(int)));
@@ -1059,7 +1063,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         return lat ? (flip ? (const void*)iw_pcgIter2<T, true, 1, true, true> : (const void*)iw_pcgIter2<T, true, 1, false, true>)
                    : (flip ? (const void*)iw_pcgIter2<T, false, 1, true, true> : (const void*)iw_pcgIter2<T, false, 1, false, true>);
     }
-    bool flagPreconditioner = true, pairDelta = true, reconstructP = true, rFree = true;
+    bool flagPreconditioner = true, pairDelta = true, rFree = true; int reconstructP = 1;
     T* ring[3] = {nullptr, nullptr, nullptr}; const T* r0Ptr = nullptr; bool lastLoopRfree = false;
     int iterIndex = 0; bool deferredTerm = false; T* alphaSlots = nullptr;
     T* mc = nullptr; int* dNotLattice = nullptr; bool lattice = false, useLattice = true, useCompactM = true;
@@ -1123,7 +1127,7 @@ struct ImageWarpingOps : EnergyOps<T> {
             alphaOut = alphaSlots + (iterIndex & 1); alphaIn = alphaSlots + ((iterIndex & 1) ^ 1);
         }
         deferredTerm = paired && iterIndex >= 1 && iterIndex % 2 == 1;            // after an odd launch alpha_{k-1} p_{k-1} is still owed (pcgFinish)
-        IterK<T> K{rOldPtr, a.ApOld, pOldPtr, a.rNew, a.ApNew, pNewPtr, a.delta, a.pre, a.first, pre == 2 ? mc : nullptr, iterFlip, deltaMode, alphaIn, alphaOut, reconstructP ? 1 : 0,
+        IterK<T> K{rOldPtr, a.ApOld, pOldPtr, a.rNew, a.ApNew, pNewPtr, a.delta, a.pre, a.first, pre == 2 ? mc : nullptr, iterFlip, deltaMode, alphaIn, alphaOut, reconstructP,
                    rfreeFlag, a.CtC, a.b, a.q ? a.q->partials : nullptr, a.afterReset, a.betaNum.partials, a.betaNum.n, a.betaDen.partials, a.betaDen.n,
                    a.deltaOut ? a.deltaOut : a.delta, a.lmRadius, a.lmMinDiag, a.lmMaxDiag,
                    a.aNumPrev.partials, a.aDenPrev.partials, a.s2Prev.partials, a.s3Prev.partials, a.aNumPrev.n, a.aDenPrev.n, a.s2Prev.n, a.s3Prev.n,
