@@ -601,8 +601,17 @@ __global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter(IWArgs<
 #define ITER2_BLOCK 768
 #endif
 constexpr int kIterBlock2 = ITER2_BLOCK;
+// ... for the float unit-lattice kernel (136-142 VGPRs: three waves per SIMD).  The general-UrShape kernel carries U per pixel and the double
+// kernels twice the registers; under the 168-VGPR cap of a 768-thread workgroup they spilled to scratch (36-170 B per lane in float, 300-1000 B
+// in double; the general path ran at half the lattice rate).  Those variants run 512 / 256 threads per workgroup (256 / 512 VGPRs available).
+#ifndef ITER2_BLOCK_GENERAL
+#define ITER2_BLOCK_GENERAL 512
+#endif
+#ifndef ITER2_BLOCK_DOUBLE
+#define ITER2_BLOCK_DOUBLE 256
+#endif
+template <class T, bool LATTICE> struct IterBlk { static constexpr int value = sizeof(T) == 8 ? ITER2_BLOCK_DOUBLE : (LATTICE ? kIterBlock2 : ITER2_BLOCK_GENERAL); };
 constexpr int kSpan2 = kWave - 4;
-constexpr int kIterStrip2 = (kIterBlock2 / kWave) * kSpan2;
 // VALU matters in this kernel (two stencil evaluations per pixel), so its inner loop avoids selects and moves:
 //  * activity is a 0/1 multiplier (`on`), the fit weight a 0/w_fit^2 multiplier (`fw`): an inactive or non-existent
 //    neighbour drops out of an FMA instead of a v_cndmask (its fields are finite: clamped loads, zero-filled DPP edges);
@@ -669,8 +678,9 @@ constexpr bool kSinCosInline = IW_SINCOS_INLINE != 0;
 #endif
 // LM = true: the Levenberg-Marquardt loop (A = J^T J + diag(CtC), Q sums, restart after a residual reset); see energy.h PcgIterArgs.
 template <class T, bool LATTICE, int PRE, bool FLIP, bool LM = false>
-__global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArgs<T> A, IterK<T> K, int rowsPerGroup, int gx, int gy) {
-    __shared__ double scratch[5 * (kIterBlock2 / kWave + 1)];
+__global__ __launch_bounds__((IterBlk<T, LATTICE>::value), ITER_MIN_WAVES) void iw_pcgIter2(IWArgs<T> A, IterK<T> K, int rowsPerGroup, int gx, int gy) {
+    constexpr int kBlk = IterBlk<T, LATTICE>::value, kStripW = (kBlk / kWave) * kSpan2;
+    __shared__ double scratch[5 * (kBlk / kWave + 1)];
     const long N = (long)A.W * A.H;
     T alpha = 0, beta = 0;
     const bool first = K.first != 0;
@@ -706,7 +716,7 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
     const T invBeta2 = recon ? T(1) / beta2 : T(0);
     const int bx = blockIdx.x % gx, by = blockIdx.x / gx;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    const int x = bx * kIterStrip2 + wave * kSpan2 + lane - 2;
+    const int x = bx * kStripW + wave * kSpan2 + lane - 2;
     const bool xok = x >= 0 && x < A.W;
     const bool writer = xok && lane >= 2 && lane < 2 + kSpan2;
     auto phys = [&](int y) { return FLIP ? A.H - 1 - y : y; };   // mirrored row coordinates, see iw_pcgIter (K.flip == FLIP)
@@ -760,7 +770,7 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
             o.mx = w.mo.x; o.my = (PRE == 2) ? w.mo.x : w.mo.y; o.ma = (PRE == 2) ? w.mo.y : w.ma;
             if (!LM && PRE != 0 && reconR) { ix = T(1) / o.mx; iy = T(1) / o.my; ia = T(1) / o.ma; }
         }
-        if (!LM && K.rfree) { o.p2x = w.ro.x; o.p2y = w.ro.y; o.p2a = w.ra; }
+        if (!LM && LATTICE && K.rfree) { o.p2x = w.ro.x; o.p2y = w.ro.y; o.p2a = w.ra; }      // (the general-UrShape kernel has no registers to spare: it reads p_{k-2} again)
         if (!LM && reconR) {      // r_{k-1} = (p_{k-1} - beta p_{k-2}) / M: w.ro / w.ra were loaded from the p_{k-2} buffer
             o.rx = (o.q.ox - betaOlder * w.ro.x) * ix; o.ry = (o.q.oy - betaOlder * w.ro.y) * iy; o.ra = (o.q.a - betaOlder * w.ra) * ia;
         }
@@ -797,7 +807,7 @@ __global__ __launch_bounds__(kIterBlock2, ITER_MIN_WAVES) void iw_pcgIter2(IWArg
             if (own && !keepR && K.deltaMode != 2) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462), preceded by the deferred term of launch k-1
                 V2<T> d = dO[i]; T da = dA[i];
                 if (K.deltaMode == 1) {
-                    if (!LM && K.rfree == 1 && K.reconP != 2) { d.x += alpha2 * oB.p2x; d.y += alpha2 * oB.p2y; da += alpha2 * oB.p2a; }      // p_{k-2} kept from the load: exact
+                    if (!LM && LATTICE && K.rfree == 1 && K.reconP != 2) { d.x += alpha2 * oB.p2x; d.y += alpha2 * oB.p2y; da += alpha2 * oB.p2a; }      // p_{k-2} kept from the load: exact
                     else if (recon) { d.x += alpha2 * ((oB.q.ox - oB.mx * oB.rx) * invBeta2); d.y += alpha2 * ((oB.q.oy - oB.my * oB.ry) * invBeta2); da += alpha2 * ((oB.q.a - oB.ma * oB.ra) * invBeta2); }
                     else {      // p_{k-2} from memory: the p buffer about to be overwritten, or (r-free ring) the buffer read through rOld
                         const V2<T>* qO = (!LM && K.rfree) ? (const V2<T>*)K.rOld : (const V2<T>*)pO; const T* qA = (!LM && K.rfree) ? K.rOld + 2 * N : (const T*)pA;
@@ -1090,9 +1100,10 @@ struct ImageWarpingOps : EnergyOps<T> {
         const int pre = !a.pre ? 0 : (noAp && lattice && flagPreconditioner) ? 3 : lmLoop ? 1 : useCompactM ? 2 : 1;
         const int L = lmLoop ? (lattice ? 14 : 13) : pre == 3 ? 12 : (noAp ? 6 : 0) + (lattice ? 3 : 0) + pre;
         if (a.first) iterFlip = 0;      // every linear solve starts top-down, so a solve is reproducible whatever ran before it
+        const int blk = !noAp ? kIterBlock : sizeof(T) == 8 ? ITER2_BLOCK_DOUBLE : lattice ? kIterBlock2 : ITER2_BLOCK_GENERAL;      // IterBlk<T, LATTICE> of the kernel picked below
         const void* fn = lmLoop ? lmKernel(lattice, pre == 3, iterFlip != 0) : iterKernel(lattice, pre, noAp, iterFlip != 0);
         if (occIter[L] == 0) {
-            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occIter[L], fn, noAp ? kIterBlock2 : kIterBlock, 0));
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occIter[L], fn, blk, 0));
             occIter[L] = std::max(1, std::min(occIter[L], 8));
         }
         if (a.first && pre == 2) {
@@ -1100,7 +1111,7 @@ struct ImageWarpingOps : EnergyOps<T> {
             ScopedKernel k(ctx, "compactPreconditioner");
             iw_compactM<T><<<flatGrid((long)A.W * A.H), kBlock, 0, ctx.stream>>>(a.pre, mc, (long)A.W * A.H);
         }
-        const int gx = divUp(A.W, noAp ? kIterStrip2 : kIterStrip);
+        const int gx = divUp(A.W, noAp ? (blk / kWave) * kSpan2 : kIterStrip);
         const int rows = Ax.yEnd - Ax.yBegin;
         int gy, rowsPerGroup;
         splitRows(rows, gx, cus * occIter[L], gy, rowsPerGroup);
@@ -1136,7 +1147,7 @@ struct ImageWarpingOps : EnergyOps<T> {
             ScopedKernel k(ctx, "PCGIteration");
             int rpg = rowsPerGroup, gxa = gx, gya = gy;
             void* kargs[] = {(void*)&Ax, (void*)&K, (void*)&rpg, (void*)&gxa, (void*)&gya};
-            HIP_CHECK(hipLaunchKernel(fn, dim3(gx * gy), dim3(noAp ? kIterBlock2 : kIterBlock), kargs, 0, ctx.stream));
+            HIP_CHECK(hipLaunchKernel(fn, dim3(gx * gy), dim3(blk), kargs, 0, ctx.stream));
         }
         if (alternateSweep) iterFlip ^= 1;
         ++iterIndex;
