@@ -682,6 +682,18 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE>::value), ITER_MIN_WAVES) void 
     constexpr int kBlk = IterBlk<T, LATTICE>::value, kStripW = (kBlk / kWave) * kSpan2;
     __shared__ double scratch[5 * (kBlk / kWave + 1)];
     const long N = (long)A.W * A.H;
+    const int bx = blockIdx.x % gx, by = blockIdx.x / gx;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int x = bx * kStripW + wave * kSpan2 + lane - 2;
+    const bool xok = x >= 0 && x < A.W;
+    const bool writer = xok && lane >= 2 && lane < 2 + kSpan2;
+    const int lyBegin = FLIP ? A.H - A.yEnd : A.yBegin, lyEnd = FLIP ? A.H - A.yBegin : A.yEnd;     // owned rows (a slab's ghost rows are plain halo here)
+    const int yb = lyBegin + by * rowsPerGroup, ye = min(yb + rowsPerGroup, lyEnd);
+    // The first five rows are requested before anything else: they do not depend on the scalars of the previous launch, so their latency
+    // overlaps the prologue's own memory round trip (the partial sums another kernel just wrote) instead of following it (-1.5 us per launch).
+    const IterRaw<T> raw0 = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb - 2), raw1 = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb - 1);
+    IterRaw<T> rwA = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb), rwB = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb + 1),
+               rwC = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb + 2);
     T alpha = 0, beta = 0;
     const bool first = K.first != 0;
     const bool restart = LM && K.afterReset != 0;      // r and delta are already those of this iteration (split residual reset)
@@ -714,14 +726,7 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE>::value), ITER_MIN_WAVES) void 
     const T beta2 = (K.deltaMode == 1 && K.reconP && (!K.rfree || K.reconP == 2)) ? K.alphaIn[2] : T(0);      // reconP == 2: A/B switch (OPT_AMD_RECON_P=2)
     const bool recon = beta2 != T(0);
     const T invBeta2 = recon ? T(1) / beta2 : T(0);
-    const int bx = blockIdx.x % gx, by = blockIdx.x / gx;
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    const int x = bx * kStripW + wave * kSpan2 + lane - 2;
-    const bool xok = x >= 0 && x < A.W;
-    const bool writer = xok && lane >= 2 && lane < 2 + kSpan2;
     auto phys = [&](int y) { return FLIP ? A.H - 1 - y : y; };   // mirrored row coordinates, see iw_pcgIter (K.flip == FLIP)
-    const int lyBegin = FLIP ? A.H - A.yEnd : A.yBegin, lyEnd = FLIP ? A.H - A.yBegin : A.yEnd;     // owned rows (a slab's ghost rows are plain halo here)
-    const int yb = lyBegin + by * rowsPerGroup, ye = min(yb + rowsPerGroup, lyEnd);
     const T w2 = A.w_reg * A.w_reg, wf2 = A.w_fit * A.w_fit;
     double accDen = 0, accNum = 0, acc2 = 0, acc3 = 0, accQ = 0;
     const bool keepR = first || restart;
@@ -838,11 +843,9 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE>::value), ITER_MIN_WAVES) void 
     };
     OldRow<T> o0, o1, o2;
     NewRow<T> n0{}, n1{}, n2{};
-    makeOld(iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb - 2), o0);
-    makeOld(iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb - 1), o1);
+    makeOld(raw0, o0);
+    makeOld(raw1, o1);
     // trips y = yb-2 .. ye-1 (the first two only build p_k(yb-1), p_k(yb)); three per pass, no branch around a load
-    IterRaw<T> rwA = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb), rwB = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb + 1),
-               rwC = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb + 2);
     for (int y = yb - 2; y < ye; y += 3) {
         if (IW_ROW_SYNC) __syncthreads();
         { const IterRaw<T> w = rwA; rwA = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, y + 5); trip(y, w, o0, o1, o2, n0, n1, n2, true); }

@@ -45,7 +45,7 @@ template <int PX, bool NTL> __device__ __forceinline__ Row<PX> loadRow(const Buf
     return r;
 }
 
-template <int PX, bool EVEN, bool NTL, bool OVERLAP, bool SYNC, int BLOCK, int GEO = 0>
+template <int PX, bool EVEN, bool NTL, bool OVERLAP, bool SYNC, int BLOCK, int GEO = 0, int DEPTH = 3>
 __global__ __launch_bounds__(BLOCK) void k(Bufs B, int rowsPerGroup, int gx, int flipI, float* sink) {
     const bool flip = flipI != 0;
     const int bx = blockIdx.x % gx, by = blockIdx.x / gx;
@@ -101,6 +101,20 @@ __global__ __launch_bounds__(BLOCK) void k(Bufs B, int rowsPerGroup, int gx, int
         }
     };
 #define LD(yy) loadRow<PX, NTL>(B, x, yy, flip)
+    if constexpr (DEPTH == 6) {      // six row buffers in flight, one barrier per six rows
+        Row<PX> a = LD(yb - 2), b = LD(yb - 1), c = LD(yb), d = LD(yb + 1), e = LD(yb + 2), f = LD(yb + 3);
+        for (int y = yb - 2; y < ye; y += 6) {
+            if (SYNC) __syncthreads();
+            { const Row<PX> w = a; a = LD(y + 6); consume(y, w, y >= yb); }
+            { const Row<PX> w = b; b = LD(y + 7); consume(y + 1, w, y + 1 >= yb && y + 1 < ye); }
+            { const Row<PX> w = c; c = LD(y + 8); consume(y + 2, w, y + 2 >= yb && y + 2 < ye); }
+            { const Row<PX> w = d; d = LD(y + 9); consume(y + 3, w, y + 3 >= yb && y + 3 < ye); }
+            { const Row<PX> w = e; e = LD(y + 10); consume(y + 4, w, y + 4 >= yb && y + 4 < ye); }
+            { const Row<PX> w = f; f = LD(y + 11); consume(y + 5, w, y + 5 >= yb && y + 5 < ye); }
+        }
+        if (acc == 12345.678f) sink[0] = acc;
+        return;
+    }
     Row<PX> a = LD(yb - 2), b = LD(yb - 1), c = LD(yb);
     for (int y = yb - 2; y < ye; y += 3) {
         if (SYNC) __syncthreads();
@@ -151,6 +165,23 @@ int main(int argc, char** argv) {
         const int gx = (W + PITCH - 1) / PITCH, gy = cus / gx, rpg = (H + gy - 1) / gy, gy2 = (H + rpg - 1) / rpg;                         \
         seq([&](const Bufs& B, int flip) { k<1, false, NTL, GEO == 0, true, BLOCK, GEO><<<gx * gy2, BLOCK>>>(B, rpg, gx, flip, sink); },    \
             [&](const Bufs& B, int flip) { k<1, true, NTL, GEO == 0, true, BLOCK, GEO><<<gx * gy2, BLOCK>>>(B, rpg, gx, flip, sink); }, true, name); \
+    }
+#define CASED(NTL, BLOCK, DEPTH, SY, name)                                                                                                 \
+    {                                                                                                                                    \
+        const int gx = (W + 720 * BLOCK / 768 - 1) / (720 * BLOCK / 768), gy = cus / gx, rpg = (H + gy - 1) / gy, gy2 = (H + rpg - 1) / rpg;   \
+        seq([&](const Bufs& B, int flip) { k<1, false, NTL, true, SY, BLOCK, 0, DEPTH><<<gx * gy2, BLOCK>>>(B, rpg, gx, flip, sink); },      \
+            [&](const Bufs& B, int flip) { k<1, true, NTL, true, SY, BLOCK, 0, DEPTH><<<gx * gy2, BLOCK>>>(B, rpg, gx, flip, sink); }, true, name); \
+    }
+    if (argc > 1 && argv[1][0] == 'd') {
+        for (int rep = 0; rep < 2; ++rep) {
+            CASED(false, 768, 3, true, "depth 3 (current)   768 thr sync");
+            CASED(false, 768, 6, true, "depth 6             768 thr sync/6 rows");
+            CASED(false, 768, 6, false, "depth 6             768 thr free");
+            CASED(false, 512, 6, true, "depth 6             512 thr sync/6 rows");
+            CASED(false, 1024, 3, true, "depth 3            1024 thr sync");
+            printf("\n");
+        }
+        return 0;
     }
     if (argc > 1) {
         for (int rep = 0; rep < 2; ++rep) {
