@@ -237,6 +237,7 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
     __shared__ double scratch[6 * (kBlock / kWave + 1)];
     __shared__ T sv[VH][VW], s0[VH][VW], s1[VH][VW], s2[VH][VW];      // v, g0, g1, g2 on the tile + 2 apron (index [y+2][x+2])
     __shared__ T sr[ITER ? VH : 1][ITER ? VW : 1];                    // ITER: r_k on the same footprint
+    __shared__ T sp[ITER ? VH : 1][ITER ? VW : 1];                    // ITER: p_{k-1} (the own pixel's delta update needs it)
     T alpha = 0, beta = 0;
     const bool keep = ITER && (K.first != 0 || K.restart != 0);       // r (and, at the start, p) are already those of this iteration
     if (ITER) {
@@ -258,32 +259,73 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
     double accNum = 0, acc2 = 0, acc3 = 0, accRR = 0, accQ = 0;
     __shared__ T sq[5][QH][QW];                                       // gh, gv, s0..s2 row values on the tile + 1 ring (index [y+1][x+1])
     __shared__ uint8_t smr[QH][QW], smc[QH][QW], sok[QH][QW], svalid[QH][QW];
-    const int tilesX = (A.W + TW - 1) / TW, tilesY = (A.H + TH - 1) / TH;
+    const int tilesX = (A.W + TW - 1) / TW, tilesY = (A.H + TH - 1) / TH, nTiles = tilesX * tilesY;
     double acc = 0;
-    for (int t = blockIdx.x; t < tilesX * tilesY; t += gridDim.x) {
+    // Everything a tile needs from global memory is requested one tile AHEAD into registers (`Pre`): the loads of tile t + gridDim.x are in
+    // flight while tile t goes through its three LDS phases, so a workgroup pays the global latency once instead of twice per tile (the
+    // own-pixel inputs of the gather phase -- D_i, CtC, delta, b -- used to be a second dependent round trip at the end of every tile).
+    constexpr int NV = (VW * VH + kBlock - 1) / kBlock, NQ = (QW * QH + kBlock - 1) / kBlock;      // staged pixels per thread: 2 and 2
+    struct Pre { T a[NV], b[NV], c[NV], g0[NV], g1[NV], g2[NV]; T vl[NQ]; uint8_t mr[NQ], mc[NQ]; T Di, ctc, dl, bb; };
+    auto fetch = [&](int t) {
+        Pre P;
         const int x0 = (t % tilesX) * TW, y0 = (t / tilesX) * TH;
-        __syncthreads();                                              // previous tile's readers are done
-        for (int i = threadIdx.x; i < VW * VH; i += kBlock) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = min((int)threadIdx.x + j * kBlock, VW * VH - 1);
             const int lx = i % VW, ly = i / VW, gx = x0 + lx - 2, gy = y0 + ly - 2;
-            const bool in = gx >= 0 && gx < A.W && gy >= 0 && gy < A.H;
-            const long g = in ? (long)gy * A.W + gx : 0;
-            if (ITER) {
-                T rk = 0, pk = 0;
-                if (in) {
-                    const T ro = K.rOld[g], po = K.pOld[g];
-                    rk = keep ? ro : ro - alpha * K.ApOld[g];                                   // PCGStep2 (solver.t:464)
-                    pk = K.first ? po : rk + beta * po;                                         // PCGStep3 with z = r (solver.t:549)
-                    if (lx >= 2 && lx < TW + 2 && ly >= 2 && ly < TH + 2) { K.rNew[g] = rk; K.pNew[g] = pk; }     // this workgroup's own tile
-                }
-                sr[ly][lx] = rk; sv[ly][lx] = pk;
-            } else sv[ly][lx] = in ? v[g] : T(0);
-            s0[ly][lx] = in ? A.g0[g] : T(0); s1[ly][lx] = in ? A.g1[g] : T(0); s2[ly][lx] = in ? A.g2[g] : T(0);
+            const long g = (long)min(max(gy, 0), A.H - 1) * A.W + min(max(gx, 0), A.W - 1);      // clamped: no branch around a load; masked when staged
+            if (ITER) { P.a[j] = K.rOld[g]; P.b[j] = K.pOld[g]; P.c[j] = (K.first || K.restart) ? T(0) : K.ApOld[g]; }
+            else { P.a[j] = v[g]; P.b[j] = 0; P.c[j] = 0; }
+            P.g0[j] = A.g0[g]; P.g1[j] = A.g1[g]; P.g2[j] = A.g2[g];
         }
-        for (int i = threadIdx.x; i < QW * QH; i += kBlock) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int i = min((int)threadIdx.x + j * kBlock, QW * QH - 1);
             const int lx = i % QW, ly = i / QW, gx = x0 + lx - 1, gy = y0 + ly - 1;
-            const bool ok = sfs_interior(A, gx, gy);
-            const long g = ok ? (long)gy * A.W + gx : 0;
-            sok[ly][lx] = ok; smr[ly][lx] = ok ? A.mR[g] : 0; smc[ly][lx] = ok ? A.mC[g] : 0; svalid[ly][lx] = ok && A.valid[g] == T(1);
+            const long g = (long)min(max(gy, 0), A.H - 1) * A.W + min(max(gx, 0), A.W - 1);
+            P.mr[j] = A.mR[g]; P.mc[j] = A.mC[g]; P.vl[j] = A.valid[g];
+        }
+        {
+            const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
+            const long e = (long)min(y0 + ty, A.H - 1) * A.W + min(x0 + tx, A.W - 1);
+            P.Di = A.D_i[e]; P.ctc = LM ? CtC[e] : T(0);
+            P.dl = (ITER && !(K.first || K.restart)) ? K.delta[e] : T(0); P.bb = (ITER && LM && !(K.first || K.restart)) ? K.b[e] : T(0);
+        }
+        return P;
+    };
+    Pre cur = fetch(min((int)blockIdx.x, nTiles - 1));
+    for (int t = blockIdx.x; t < nTiles; t += gridDim.x) {
+        const int x0 = (t % tilesX) * TW, y0 = (t / tilesX) * TH;
+        const Pre nxt = fetch(min(t + (int)gridDim.x, nTiles - 1));   // the last tile is fetched once more instead of branching around the loads
+        __syncthreads();                                              // previous tile's readers are done
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = threadIdx.x + j * kBlock;
+            if (i < VW * VH) {
+                const int lx = i % VW, ly = i / VW, gx = x0 + lx - 2, gy = y0 + ly - 2;
+                const bool in = gx >= 0 && gx < A.W && gy >= 0 && gy < A.H;
+                if (ITER) {
+                    T rk = 0, pk = 0;
+                    if (in) {
+                        const long g = (long)gy * A.W + gx;
+                        const T ro = cur.a[j], po = cur.b[j];
+                        rk = keep ? ro : ro - alpha * cur.c[j];                                     // PCGStep2 (solver.t:464)
+                        pk = K.first ? po : rk + beta * po;                                         // PCGStep3 with z = r (solver.t:549)
+                        if (lx >= 2 && lx < TW + 2 && ly >= 2 && ly < TH + 2) { K.rNew[g] = rk; K.pNew[g] = pk; }     // this workgroup's own tile
+                    }
+                    sr[ly][lx] = rk; sv[ly][lx] = pk; sp[ly][lx] = cur.b[j];
+                } else sv[ly][lx] = in ? cur.a[j] : T(0);
+                s0[ly][lx] = in ? cur.g0[j] : T(0); s1[ly][lx] = in ? cur.g1[j] : T(0); s2[ly][lx] = in ? cur.g2[j] : T(0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int i = threadIdx.x + j * kBlock;
+            if (i < QW * QH) {
+                const int lx = i % QW, ly = i / QW, gx = x0 + lx - 1, gy = y0 + ly - 1;
+                const bool ok = sfs_interior(A, gx, gy);
+                sok[ly][lx] = ok; smr[ly][lx] = ok ? cur.mr[j] : 0; smc[ly][lx] = ok ? cur.mc[j] : 0; svalid[ly][lx] = ok && cur.vl[j] == T(1);
+            }
         }
         __syncthreads();
         // row values at every centre of the tile + ring (sfs_rows<3>): centre (qx, qy) in q coordinates = (qx + 1, qy + 1) in v coordinates
@@ -316,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
             const long e = (long)y * A.W + x;
             const T ve = sv[ty + 2][tx + 2];
             T s = 0;
-            if (A.D_i[e] > T(0)) {
+            if (cur.Di > T(0)) {
                 auto add = [&](T coef, T q) { s += coef * q; };
                 add(A.w_p, A.w_p * ve);
                 // (dx, dy): the row centre relative to this pixel; g arrays are read at the centre c and at c + 1 (gh) / c + W (gv)
@@ -345,8 +387,8 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
                     for (int k = 0; k < 3; ++k) add(wgt * coefK(A, k, x, y), sq[2 + k][qy][qx]);
                 }
             }
-            if (LM) s += CtC[e] * ve;
-            if (!(A.D_i[e] > T(0))) s = 0;
+            if (LM) s += cur.ctc * ve;
+            if (!(cur.Di > T(0))) s = 0;
             out[e] = s;
             acc += (double)(ve * s);
             if (ITER) {
@@ -355,12 +397,13 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
                 accNum += (double)(zk * rk); acc2 += (double)(rk * s); acc3 += (double)(s * s);
                 if (K.first) accRR += (double)(rk * rk);
                 if (!keep) {                                                                    // the rest of PCGStep2 of iteration k-1 for this pixel
-                    const T dl = K.delta[e] + alpha * K.pOld[e];                                // solver.t:461-462
+                    const T dl = cur.dl + alpha * sp[ty + 2][tx + 2];                           // solver.t:461-462
                     K.deltaOut[e] = dl;
-                    if (LM) accQ += (double)(T(0.5) * (dl * (rk + K.b[e])));                    // solver.t:483-485
+                    if (LM) accQ += (double)(T(0.5) * (dl * (rk + cur.bb)));                    // solver.t:483-485
                 }
             }
         }
+        cur = nxt;
     }
     if (ITER) {
         double vv[6] = {acc, accNum, acc2, acc3, accRR, accQ};
