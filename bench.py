@@ -180,6 +180,7 @@ def main():
         job = slab.SlabJob("image_warping", W, H, rank, world, comm=args.comm)
         solver, dev = job.solver, job.params
         comm_ranks = job.comm_ranks()
+        args.comm = job.comm_kind              # "rccl" if the peer communicator was unavailable or failed its self-test on this machine
     else:
         P = wl.image_warping(W, H)
         dev = api.to_device(P)

@@ -293,6 +293,54 @@ int OptComm_PeerConnect(void* c, const char* allHandles) {
     return 1;
 }
 const OptAmd_SlabComm* OptComm_PeerSlabComm(void* c) { return &((PeerCtx*)c)->api; }
+// One all-reduce and one halo exchange with known answers, run once after OptComm_PeerConnect by every rank (collective).  Returns 1 if this rank
+// saw the right values, 0 on a wrong value or a timeout -- it never exits, so the launcher can fall back to RCCL when the peer path does not work
+// on a machine (IPC mapping across devices, coherence of the window memory kind, ...).  Uses a short timeout of its own.
+int OptComm_PeerSelfTest(void* c, double timeoutSeconds) {
+    auto* x = (PeerCtx*)c;
+    const long long keep = x->timeoutTicks;
+    x->timeoutTicks = (long long)((timeoutSeconds > 0 ? timeoutSeconds : 5.0) * 1e8);
+    int ok = 1;
+    double* d = nullptr; float* rows = nullptr;
+    CK_HIP(hipMalloc((void**)&d, 4 * sizeof(double)));
+    const int nf = 4096;                                           // floats per test row block
+    CK_HIP(hipMalloc((void**)&rows, 4 * nf * sizeof(float)));      // [recvUp | sendUp | sendDown | recvDown]
+    double h[4] = {1.0 + x->rank, 10.0 * (1 + x->rank), -1.0, 0.5};
+    CK_HIP(hipMemcpy(d, h, sizeof h, hipMemcpyHostToDevice));
+    PartialsIn pin{};
+    ++x->arSeq;
+    k_mailAllReduce<<<1, 256, 0, 0>>>(d, pin, 0, 4, peersOf(x), x->rank, x->world, x->arSeq, x->timeoutTicks, x->hostErr);
+    CK_HIP(hipDeviceSynchronize());
+    CK_HIP(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
+    const double w = x->world, tri = w * (w + 1) / 2;
+    if (*x->hostErr || h[0] != tri || h[1] != 10.0 * tri || h[2] != -w || h[3] != 0.5 * w) ok = 0;
+    if (ok && x->world > 1 && (size_t)nf * sizeof(float) <= x->stageBytes) {
+        float* hostRows = (float*)malloc(4 * nf * sizeof(float));
+        for (int i = 0; i < 4 * nf; ++i) hostRows[i] = (i / nf == 1 || i / nf == 2) ? (float)(100 * x->rank + i / nf) : -7.f;
+        CK_HIP(hipMemcpy(rows, hostRows, 4 * nf * sizeof(float), hipMemcpyHostToDevice));
+        const void* su[1] = {rows + nf}; const void* sd[1] = {rows + 2 * nf}; void* ru[1] = {rows}; void* rd[1] = {rows + 3 * nf}; const long bytes[1] = {(long)(nf * sizeof(float))};
+        // peerHalo would exit on an error flag: run its two kernels by hand
+        HaloArgs H{}; H.nb = 1; H.sendUp[0] = (const char*)su[0]; H.sendDown[0] = (const char*)sd[0]; H.recvUp[0] = (char*)ru[0]; H.recvDown[0] = (char*)rd[0]; H.bytes[0] = bytes[0]; H.offset[0] = 0;
+        const u64 seq = ++x->haloSeq;
+        const size_t blk = (size_t)(seq % kStageDepth) * x->stageBytes;
+        char* stageUp = x->rank > 0 ? x->stage[x->rank - 1] + (size_t)kStageDepth * x->stageBytes + blk : nullptr;
+        char* stageDown = x->rank < x->world - 1 ? x->stage[x->rank + 1] + blk : nullptr;
+        k_haloPush<<<2, 256, 0, 0>>>(H, peersOf(x), stageUp, stageDown, x->rank, x->world, seq, x->dCounter, x->timeoutTicks, x->hostErr);
+        k_haloPull<<<2, 256, 0, 0>>>(H, peersOf(x), x->stage[x->rank] + blk, x->stage[x->rank] + (size_t)kStageDepth * x->stageBytes + blk, x->rank, x->world, seq, x->dCounter + 1, x->timeoutTicks, x->hostErr);
+        CK_HIP(hipDeviceSynchronize());
+        CK_HIP(hipMemcpy(hostRows, rows, 4 * nf * sizeof(float), hipMemcpyDeviceToHost));
+        if (*x->hostErr) ok = 0;
+        for (int i = 0; i < nf && ok; ++i) {
+            if (x->rank > 0 && hostRows[i] != (float)(100 * (x->rank - 1) + 2)) ok = 0;                       // the rank above sent its "down" rows
+            if (x->rank < x->world - 1 && hostRows[3 * nf + i] != (float)(100 * (x->rank + 1) + 1)) ok = 0;   // the rank below sent its "up" rows
+        }
+        free(hostRows);
+    }
+    *x->hostErr = 0;                 // a failed self-test is reported through the return value, not through the run-time abort
+    x->timeoutTicks = keep;
+    (void)hipFree(d); (void)hipFree(rows);
+    return ok;
+}
 int OptComm_PeerError(void* c) { return *((PeerCtx*)c)->hostErr; }
 // Callers must make sure (barrier) that no peer still uses this rank's window.
 void OptComm_PeerDestroy(void* c) {

@@ -105,6 +105,7 @@ def comm_lib():
         L.OptComm_PeerSlabComm.restype = ctypes.POINTER(api.OptAmd_SlabComm); L.OptComm_PeerSlabComm.argtypes = [vp]
         L.OptComm_PeerError.restype = ci; L.OptComm_PeerError.argtypes = [vp]
         L.OptComm_PeerDestroy.argtypes = [vp]
+        L.OptComm_PeerSelfTest.restype = ci; L.OptComm_PeerSelfTest.argtypes = [vp, ctypes.c_double]
         L.OptComm_CreateThreadWorld.restype = vp; L.OptComm_CreateThreadWorld.argtypes = [ci]
         L.OptComm_DestroyThreadWorld.argtypes = [vp]
         L.OptComm_CreateThreadRank.restype = vp; L.OptComm_CreateThreadRank.argtypes = [vp, ci]
@@ -133,9 +134,21 @@ class PeerComm:
         if timeout_s is None:
             timeout_s = float(os.environ.get("OPT_AMD_PEER_TIMEOUT", "20"))
         self.rank, self.world = rank, world
+
+        def agree(local_ok, what):             # failures are made collective: either every rank goes on or every rank raises (no rank left in a gather)
+            oks = [None] * world
+            if world > 1:
+                dist.all_gather_object(oks, bool(local_ok))
+            else:
+                oks[0] = bool(local_ok)
+            if not all(oks):
+                if self._ctx:
+                    L.OptComm_PeerDestroy(self._ctx)
+                    self._ctx = None
+                raise RuntimeError(f"{what} failed on rank(s) {[r for r, o in enumerate(oks) if not o]}")
+
         self._ctx = L.OptComm_PeerCreate(rank, world, int(stage_bytes), float(timeout_s))
-        if not self._ctx:
-            raise RuntimeError("OptComm_PeerCreate failed (IPC-exportable device memory unavailable)")
+        agree(self._ctx, "OptComm_PeerCreate (IPC-exportable device memory)")
         n = L.OptComm_PeerHandleBytes()
         buf = ctypes.create_string_buffer(n)
         L.OptComm_PeerHandle(self._ctx, buf)
@@ -144,10 +157,16 @@ class PeerComm:
             dist.all_gather_object(handles, bytes(buf.raw))
         else:
             handles[0] = bytes(buf.raw)
-        if not L.OptComm_PeerConnect(self._ctx, b"".join(handles)):
-            raise RuntimeError("OptComm_PeerConnect failed (hipIpcOpenMemHandle)")
+        agree(L.OptComm_PeerConnect(self._ctx, b"".join(handles)), "OptComm_PeerConnect (hipIpcOpenMemHandle)")
         if world > 1:
             dist.barrier()                     # every window is mapped everywhere before the first peer store
+        # one all-reduce and one halo exchange with known answers; every rank must pass (collective verdict), else the caller falls back to RCCL
+        ok = bool(L.OptComm_PeerSelfTest(self._ctx, float(os.environ.get("OPT_AMD_PEER_SELFTEST_TIMEOUT", "5"))))
+        if world > 1:
+            verdicts = [None] * world
+            dist.all_gather_object(verdicts, ok)
+            ok = all(verdicts)
+        self.self_test_ok = ok
         self.mem_kind = {3: "uncached", 1: "fine-grained", 0: "plain"}.get(L.OptComm_PeerMemKind(self._ctx), "?")
 
     def slab_comm(self):
@@ -186,7 +205,21 @@ class SlabJob:
             # the largest exchange moves `ghost` rows of two solver vectors (r and p) per side; rows are W * (unknown scalars per pixel) wide
             scalars = sum(int(np.prod(np.asarray(self.local.params[i]).shape[2:])) or 1 for i in self.local.unknown_slots)
             stage = 2 * ghost * W * scalars * (8 if double else 4) + 4096
-            self._peer = PeerComm(rank, world, stage)
+            try:
+                self._peer = PeerComm(rank, world, stage)
+                usable = self._peer.self_test_ok
+            except RuntimeError as e:                      # no IPC-exportable window / mapping failed: same on every rank (collective calls inside)
+                self._peer, usable = None, False
+                if rank == 0:
+                    print(f"opt_amd.slab: peer communicator unavailable ({e}); falling back to RCCL", flush=True)
+            if not usable:
+                if self._peer is not None:
+                    if rank == 0:
+                        print("opt_amd.slab: peer communicator failed its self-test; falling back to RCCL", flush=True)
+                    self._peer.close()
+                    self._peer = None
+                comm = self.comm_kind = "rccl"
+        if comm == "peer":
             slab_comm = self._peer.slab_comm()
         elif comm == "rccl":
             n = L.OptComm_UniqueIdBytes()

@@ -41,6 +41,7 @@ def _rank_main(rank, world, port, case, q):
     while job.solver.step(job.params):
         costs.append(job.solver.cost())
     torch.cuda.synchronize()
+    assert job.comm_kind == "peer" and job._peer.self_test_ok      # the self-test passed: no silent fall-back to RCCL in this test
     q.put((rank, costs, job.owned_unknowns(), job.layout.row0, job.layout.rows, job._peer.mem_kind, job._peer.error()))
     job.close()
     dist.destroy_process_group()
@@ -94,3 +95,37 @@ def test_peer_mailbox_lm_two_processes():
         np.testing.assert_allclose(res[r][1], c1, rtol=1e-9)
         for a, b in zip(res[r][2], x1):
             assert rel_err(a, b[res[r][3]:res[r][3] + res[r][4]]) < 1e-8
+
+
+def _fallback_main(q):
+    import torch
+    import torch.distributed as dist
+    from opt_amd import slab
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OPT_AMD_FORCE_COMM="1", OPT_AMD_PEER_MEM="99")      # no such memory kind: window allocation fails
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    P = wl.image_warping(64, 40, random_state=3, perturb=0.3)
+    job = slab.SlabJob("image_warping", 64, 40, 0, 1, problem=P.clone(), comm="peer")
+    job.solver.set_parameter("nIterations", 2); job.solver.set_parameter("lIterations", 10)
+    job.solver.init(job.params); costs = [job.solver.cost()]
+    while job.solver.step(job.params):
+        costs.append(job.solver.cost())
+    q.put((job.comm_kind, costs))
+    job.close()
+    dist.destroy_process_group()
+
+
+def test_peer_communicator_falls_back_to_rccl_when_unavailable():
+    """A machine on which the window cannot be allocated / exported / mapped, or whose self-test (one all-reduce and one halo exchange with known
+    answers) fails, runs the same job over RCCL instead of aborting -- the verdict is collective, so no rank is left waiting."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_fallback_main, args=(q,))
+    p.start()
+    kind, costs = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and kind == "rccl"
+    P = wl.image_warping(64, 40, random_state=3, perturb=0.3)
+    c1, _ = _single(P, "gaussNewtonGPU", nIterations=2, lIterations=10)
+    np.testing.assert_allclose(costs, c1, rtol=2e-5)
