@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--cpu-liters", type=int, default=12)
     ap.add_argument("--comm", default=os.environ.get("OPT_AMD_COMM", "peer"), choices=["peer", "rccl"])
     ap.add_argument("--cpu-smoke", action="store_true", help="launcher check without GPUs: ranks rendezvous over gloo and report the world size")
+    ap.add_argument("--share-gpu", action="store_true", help="functional check of the N-rank path on a 1-GPU box: all ranks use device 0, set-up over gloo (timings meaningless)")
     return ap.parse_args()
 
 
@@ -158,9 +159,14 @@ def main():
         return
 
     from opt_amd import api, build, workloads as wl
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if distributed:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if rank == 0 and not os.path.exists(api.LIB_PATH):
         build.build()
     if distributed:
@@ -194,6 +200,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    sync()                                   # ranks enter the first collective of the solve together
     solver.init(dev)
     costs = [solver.cost()]
     for _ in range(args.warmup):
@@ -208,7 +215,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.share_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     cost_final = solver.cost()

@@ -132,7 +132,7 @@ class PeerComm:
             raise ValueError(f"peer communicator supports at most {L.OptComm_PeerMaxWorld()} ranks")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if timeout_s is None:
-            timeout_s = float(os.environ.get("OPT_AMD_PEER_TIMEOUT", "20"))
+            timeout_s = float(os.environ.get("OPT_AMD_PEER_TIMEOUT", "60"))    # ranks may reach their first all-reduce seconds apart (page-in, module load)
         self.rank, self.world = rank, world
 
         def agree(local_ok, what):             # failures are made collective: either every rank goes on or every rank raises (no rank left in a gather)
