@@ -20,6 +20,11 @@ def _run(name, *args, timeout=300):
     return subprocess.run([exe, *map(str, args)], cwd=ROOT, capture_output=True, text=True, timeout=timeout)
 
 
+def _final_costs(stdout):
+    line = stdout.split("Opt GN,Opt LM,CERES")[1].strip().splitlines()[0]
+    return [float(x) if x else None for x in line.split(",")[:2]]
+
+
 def test_minimal_laplacian():
     r = _run("minimal_laplacian")
     assert r.returncode == 0, r.stdout + r.stderr
@@ -39,23 +44,50 @@ def test_create_delete_cycle():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
-def test_image_warping_example_flow(tmp_path):
-    # 256^2, 4 ramp passes x 3 GN x 40 PCG, GN and LM on identical inputs
-    r = _run("image_warping_example", 256, 4, 3, 40)
+def _oracle_warp_ramp(oracle_lib, size, passes, n_it, l_it, kind, double):
+    """The example's flow (examples/image_warping_example.cpp = the reference's main.cpp:98-139) restated on the CPU oracle with the same inputs:
+    the nine markers ramp from source to target over `passes` solves that share the unknowns; returns the final cost."""
+    import numpy as np
+    from opt_amd import workloads as wl
+    from helpers import oracle_solver
+    P = wl.image_warping(size, size, double=double)
+    ft = np.float64 if double else np.float32
+    o = oracle_solver(oracle_lib, P, kind, nIterations=n_it, lIterations=l_it)
+    for i in range(passes):
+        alpha = np.float32(i + 1) / np.float32(passes)
+        for (x0, y0, x1, y1) in wl.CAT512_MARKERS:
+            x, y = x0 * size // 512, y0 * size // 512
+            tx, ty = np.float32(x1 * size // 512), np.float32(y1 * size // 512)
+            P.params[3][y, x] = (ft((np.float32(1) - alpha) * np.float32(x) + alpha * tx), ft((np.float32(1) - alpha) * np.float32(y) + alpha * ty))
+        o.solve(P.params)
+    c = o.cost()
+    o.close()
+    return c
+
+
+def test_image_warping_example_flow(oracle_lib):
+    """256^2, 4 constraint-ramp passes x 3 GN x 40 PCG, Gauss-Newton and Levenberg-Marquardt, in double: the C++ caller's final costs must be the
+    oracle's on the same inputs (LM 1e-8, GN 1e-6), not merely 'in the same basin'; the float run checks the harness output formats."""
+    energy = os.path.join("opt_amd", "energies", "image_warping.t")
+    r = _run("image_warping_example", 256, 4, 3, 40, energy, 1)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "===Image Warping===" in r.stdout and "**Final Costs**" in r.stdout and "Opt GN,Opt LM,CERES" in r.stdout
-    line = r.stdout.split("Opt GN,Opt LM,CERES")[1].strip().splitlines()[0]
-    gn, lm = [float(x) for x in line.split(",")[:2]]
-    assert gn > 0 and lm > 0 and abs(gn - lm) / gn < 0.5                       # both solvers reach the same basin
+    gn, lm = _final_costs(r.stdout)
+    ref_gn = _oracle_warp_ramp(oracle_lib, 256, 4, 3, 40, "gaussNewtonGPU", True)
+    ref_lm = _oracle_warp_ramp(oracle_lib, 256, 4, 3, 40, "LMGPU", True)
+    # LM (damped, well conditioned) agrees to the last bits (1e-16).  Gauss-Newton runs 480 undamped PCG iterations on a nearly singular system,
+    # which amplifies summation-order differences even in double: the plain three-kernel loop ends 4e-8 from the oracle, the one-kernel loop
+    # 7e-8, the r-free loop 2e-7 (measured: 107.09695656 / 107.09696823 / 107.09698571 against 107.09696105).
+    assert abs(gn - ref_gn) <= 1e-6 * ref_gn and abs(lm - ref_lm) <= 1e-8 * ref_lm, (gn, ref_gn, lm, ref_lm)
+    os.remove(os.path.join(ROOT, "results_double.csv"))
+    r = _run("image_warping_example", 256, 2, 2, 20)
+    assert r.returncode == 0, r.stdout + r.stderr
+    gnf, lmf = _final_costs(r.stdout)
+    assert abs(gnf - _oracle_warp_ramp(oracle_lib, 256, 2, 2, 20, "gaussNewtonGPU", False)) <= 1e-5 * gnf
     assert os.path.exists(os.path.join(ROOT, "results_float.csv"))
     rows = open(os.path.join(ROOT, "results_float.csv")).read().strip().splitlines()
-    assert rows[0].startswith("Iter, Opt(GN) Error (float)") and len(rows) > 10
+    assert rows[0].startswith("Iter, Opt(GN) Error (float)") and len(rows) > 5
     os.remove(os.path.join(ROOT, "results_float.csv"))
-
-
-def _final_costs(stdout):
-    line = stdout.split("Opt GN,Opt LM,CERES")[1].strip().splitlines()[0]
-    return [float(x) if x else None for x in line.split(",")[:2]]
 
 
 def test_poisson_example_flow():
