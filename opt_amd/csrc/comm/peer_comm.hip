@@ -5,8 +5,9 @@
 // latency of whatever sits between two launches; an ncclAllReduce of 32 bytes costs a kernel launch plus a multi-hop
 // protocol.  Here every rank maps every other rank's window (hipIpc handles, one process per GPU) and
 //   * all-reduce = ONE small kernel: sum this rank's per-workgroup partials, store the totals into every peer's mailbox slot
-//     (direct peer stores over the pair's own xGMI link), publish a sequence number, spin on the local mailbox until all
-//     ranks' sequence numbers arrived, add the contributions in rank order (deterministic, same bits on every rank);
+//     (direct peer stores over the pair's own xGMI link) as 8-byte words that each carry 4 bytes of payload and the all-reduce's
+//     sequence number -- no separate flag, no fence --, poll the local mailbox until every rank's words carry that number, add
+//     the contributions in rank order (deterministic, same bits on every rank);
 //   * halo exchange = two kernels: push my edge rows into the neighbours' staging buffers + publish, then wait for the
 //     neighbours' rows in my own staging buffers and copy them into the ghost rows + acknowledge (double-buffered staging).
 // No host involvement inside the loop.  Every spin carries a wall-clock timeout that raises an error flag in pinned host
@@ -32,8 +33,10 @@ typedef unsigned long long u64;
 
 // One per rank, in device memory of that rank, mapped by every peer.  Only 8-byte words are used for signalling.
 struct Window {
-    u64 mailSeq[kSlots][kMaxWorld];            // [slot][source rank] = sequence number of the contribution stored there
-    double mail[kSlots][kMaxWorld][kMaxVals];
+    // All-reduce mailbox, "flag-in-data" (the idea of RCCL's LL protocol): every 8-byte word carries 4 bytes of payload and the low 32 bits of the
+    // all-reduce's sequence number, and 8-byte stores are atomic -- so a contribution needs no separate flag, no fence between payload and flag, and
+    // the receiver polls the payload words themselves.  A double travels as two words.  [slot][source rank][2 * value + half]
+    u64 ll[kSlots][kMaxWorld][2 * kMaxVals];
     u64 haloSeq[2];                            // [0]: last exchange pushed by the rank above, [1]: by the rank below
     u64 haloAck[2];                            // [0]: last exchange of MINE the rank above has consumed, [1]: the rank below
     u64 pad[4];
@@ -100,18 +103,35 @@ __global__ __launch_bounds__(256) void k_mailAllReduce(double* __restrict__ buf,
         __syncthreads();
     }
     const int slot = (int)(seq % kSlots);
-    if (tid < world) {                                   // thread t serves peer t: post my contribution there, then wait for t's here
-        Window* w = P.win[tid];
-        for (int i = 0; i < n; ++i) stSysD(&w->mail[slot][rank][i], vals[i]);
-        stSys(&w->mailSeq[slot][rank], seq);              // system-scope release: the values above are visible before the sequence number
-                                                          // (one fence, not two: every memory round trip of this kernel is ~1.5 us on the loop's critical path)
-        if (!waitAtLeast(&P.win[rank]->mailSeq[slot][tid], seq, timeoutTicks)) *hostErr = 1;
+    const unsigned tag = (unsigned)seq;
+    // post: thread (peer t, word w) stores one tagged word into peer t's window -- fire and forget, no fence
+    const int nw = 2 * n;
+    for (int j = tid; j < world * nw; j += 256) {
+        const int t = j / nw, w = j % nw;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(vals[w >> 1]);
+        const unsigned half = (w & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+        __hip_atomic_store(&P.win[t]->ll[slot][rank][w], ((u64)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // receive: thread (source rank r, word w) polls its word in this rank's own window until it carries this all-reduce's tag
+    __shared__ unsigned halves[kMaxWorld][2 * kMaxVals];
+    for (int j = tid; j < world * nw; j += 256) {
+        const int r = j / nw, w = j % nw;
+        const u64* src = &P.win[rank]->ll[slot][r][w];
+        u64 v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned)(v >> 32) != tag) {
+            const long long t0 = wall_clock64();
+            while ((unsigned)((v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) >> 32) != tag) {
+                __builtin_amdgcn_s_sleep(2);
+                if (wall_clock64() - t0 > timeoutTicks) { *hostErr = 1; break; }
+            }
+        }
+        halves[r][w] = (unsigned)v;
     }
     __syncthreads();
     if (tid < n) {
-        const Window* me = P.win[rank];
         double t = 0;
-        for (int r = 0; r < world; ++r) t += ldSysD(&me->mail[slot][r][tid]);     // rank order: identical bits on every rank
+        for (int r = 0; r < world; ++r)      // rank order: identical bits on every rank
+            t += __longlong_as_double((long long)(((unsigned long long)halves[r][2 * tid + 1] << 32) | halves[r][2 * tid]));
         buf[tid] = t;
     }
 }
