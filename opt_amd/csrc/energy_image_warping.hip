@@ -24,11 +24,12 @@
 //  * the grid is sized to be co-resident (one wave of workgroups, rows split evenly) instead of
 //    thousands of 16x16 tiles, so there is no tail and only ~1k partial sums per dot product;
 //  * for Gauss-Newton the whole PCG iteration (the reference's PCGStep1 + PCGStep2 + PCGStep3) is ONE such
-//    kernel.  iw_pcgIter2 -- the default -- also keeps A*p out of memory (it is recomputed from p on a 2-pixel ring),
-//    derives the preconditioner from the flag byte, recomputes (cos, sin) from the angle and pairs the delta updates:
-//    71 B/pixel of HBM traffic per iteration against 180 B/pixel for the three reference kernels.  iw_pcgIter (A*p in
-//    memory, 113-121 B/pixel) remains for slabs with a single ghost row; iw_applyJTJ (with the previous PCGStep3
-//    optionally fused in) serves LM, probes and the OPT_AMD_ONEKERNEL=0 fallback.
+//    kernel.  iw_pcgIter2 -- the default -- keeps neither A*p nor r in memory: A*p is recomputed from p on a 2-pixel ring, r is
+//    rebuilt from the last two search directions (the loop's state is a ring of three p buffers), the preconditioner comes from
+//    the flag byte, (cos, sin) from the angle, and delta is touched every second launch: 53 B/pixel of HBM traffic per iteration
+//    against 180 B/pixel for the three reference kernels.  iw_pcgIter (A*p in memory, 113-121 B/pixel)
+//    remains for slabs with a single ghost row; iw_applyJTJ (with the previous PCGStep3 optionally fused in) serves probes, the
+//    split residual reset of LM and the OPT_AMD_ONEKERNEL=0 fallback.
 #include "energy.h"
 #include <cstdint>
 
@@ -588,9 +589,10 @@ __global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter(IWArgs<
 // read of 118).  Ap_k = J^T J p_k is a pure function of p_k, which the next launch reads anyway, so iw_pcgIter2 recomputes
 // it: launch k reads r_{k-1}, p_{k-1} on a 2-pixel ring, forms Ap_{k-1} on the 1-ring (second stencil evaluation, VALU is
 // idle 80 % of the time in this kernel), then r_k, z_k, p_k there, and Ap_k on its own pixels for the dot products --
-// never written.  State in memory is r, p, delta; per pixel per iteration 24 + 24 + 24 + M 8 + (cos,sin) 8 + flags 1 =
-// 89 B against 118 B (and 180 B for the three reference kernels).  The recomputed Ap_{k-1} is the same instruction
-// sequence on the same inputs as the Ap_{k-1} whose dot products the previous launch reduced.
+// never written.  In this first form the state in memory is r, p, delta: per pixel per iteration 24 + 24 + 24 + M 8 + (cos,sin) 8 +
+// flags 1 = 89 B against 118 B (and 180 B for the three reference kernels); with M from the flag byte, (cos, sin) from the angle, delta
+// paired over two launches and r rebuilt from p_{k-1}, p_{k-2} (IterK::rfree) it is 53 B.  The recomputed Ap_{k-1} is the same
+// instruction sequence on the same inputs as the Ap_{k-1} whose dot products the previous launch reduced.
 // A wave covers 64 consecutive pixels and produces the inner 60 (p_k needs one DPP ring, Ap_k a second).  Rows: a
 // sliding window of three rows of p_{k-1} and three of p_k in registers; trip y turns the freshly loaded row y+2 into
 // Ap_{k-1}(y+1), p_k(y+1) and then Ap_k(y).  With row slabs it needs two ghost rows per side (r and p of the neighbours'
