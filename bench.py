@@ -282,7 +282,7 @@ def main():
         del os.environ["OPT_AMD_LATTICE"]
 
     if rank == 0:
-        out = {"metric": "PCG iters/s, GN solve of image_warping 4096^2", "value": value, "unit": "PCG iters/s", "n_gpus": world,
+        out = {"metric": f"PCG iters/s, GN solve of image_warping {W}^2", "value": value, "unit": "PCG iters/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"image_warping {W}x{H} float, gaussNewtonGPU, {args.liters} PCG iterations per GN step "
