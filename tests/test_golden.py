@@ -69,3 +69,22 @@ def test_hip_matches_golden(path):
     np.testing.assert_allclose(t[:, 2:5], z["trace"][:len(t), 2:5], rtol=1e-7, atol=1e-16 * np.abs(z["trace"][0, 2:5]).max())
     assert rel_err(device_unknowns(P, dev), z["final_unknowns"]) < 1e-9
     g.close()
+
+
+def test_frozen_benchmark_trajectories_are_complete():
+    """tests/golden/bench_costs.json (tests/golden/make_bench_cost.py) holds what bench.py's `parity` field and the GPU tests read: the oracle's cost after
+    0, 1 and 2 Gauss-Newton steps of 400 PCG iterations at 2048^2 and 4096^2, in float and in double; the float-rounding envelope derived from them is
+    what the long-horizon tolerance is made of, so it must be a small positive number, and both precisions must start from the same cost."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    G = json.load(open(os.path.join(root, "tests", "golden", "bench_costs.json")))
+    sys.path.insert(0, root)
+    import bench
+    for size in (2048, 4096):
+        f = G[f"image_warping_{size}x{size}_float_gaussNewtonGPU_400"]["costs"]
+        d = G[f"image_warping_{size}x{size}_double_gaussNewtonGPU_400"]["costs"]
+        assert len(f) == len(d) == 3 and f[0] == d[0] and f[2] < f[1] < f[0] and d[2] < d[1] < d[0]
+        gold, env = bench.golden_cost(size, 400)
+        assert gold == f and env[0] == 0.0 and all(1e-5 < e < 5e-2 for e in env[1:])
+    assert bench.golden_cost(1234, 400) == (None, None)
