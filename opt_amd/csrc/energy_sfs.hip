@@ -259,6 +259,9 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
     double accNum = 0, acc2 = 0, acc3 = 0, accRR = 0, accQ = 0;
     __shared__ T sq[5][QH][QW];                                       // gh, gv, s0..s2 row values on the tile + 1 ring (index [y+1][x+1])
     __shared__ uint8_t smr[QH][QW], smc[QH][QW], sok[QH][QW], svalid[QH][QW];
+    // P(u) coefficients (i_u - u_x) / f_x and (j_u - u_y) / f_y of the tile's columns / rows: one division per column and row of the footprint instead of
+    // ~12 double divisions (~35 instructions each) per pixel in the phases below -- the same quotients, computed once
+    __shared__ T cxTab[VW], cyTab[VH];
     const int tilesX = (A.W + TW - 1) / TW, tilesY = (A.H + TH - 1) / TH, nTiles = tilesX * tilesY;
     double acc = 0;
     // Everything a tile needs from global memory is requested one tile AHEAD into registers (`Pre`): the loads of tile t + gridDim.x are in
@@ -288,15 +291,27 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
         {
             const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
             const long e = (long)min(y0 + ty, A.H - 1) * A.W + min(x0 + tx, A.W - 1);
-            P.Di = A.D_i[e]; P.ctc = LM ? CtC[e] : T(0);
-            P.dl = (ITER && !(K.first || K.restart)) ? K.delta[e] : T(0); P.bb = (ITER && LM && !(K.first || K.restart)) ? K.b[e] : T(0);
+#ifndef SFS_LATE_OWN
+#define SFS_LATE_OWN 1      // 1: the own-pixel inputs of the gather phase are loaded there instead of with the tile (8 fewer live registers; config 3: 42.1 against 42.9 ms); 0 with SFS_PREFETCH
+#endif
+            if (!SFS_LATE_OWN) {
+                P.Di = A.D_i[e]; P.ctc = LM ? CtC[e] : T(0);
+                P.dl = (ITER && !(K.first || K.restart)) ? K.delta[e] : T(0); P.bb = (ITER && LM && !(K.first || K.restart)) ? K.b[e] : T(0);
+            } else { P.Di = 0; P.ctc = 0; P.dl = 0; P.bb = 0; }
         }
         return P;
     };
+#ifndef SFS_PREFETCH
+#define SFS_PREFETCH 0      // 1: request the next tile's global inputs one tile ahead (A/B: 44.1 ms against 42.7 for config 3 -- the 76 extra VGPRs cost a workgroup per CU)
+#endif
     Pre cur = fetch(min((int)blockIdx.x, nTiles - 1));
     for (int t = blockIdx.x; t < nTiles; t += gridDim.x) {
         const int x0 = (t % tilesX) * TW, y0 = (t / tilesX) * TH;
+#if SFS_PREFETCH
         const Pre nxt = fetch(min(t + (int)gridDim.x, nTiles - 1));   // the last tile is fetched once more instead of branching around the loads
+#else
+        if (t != (int)blockIdx.x) cur = fetch(t);
+#endif
         __syncthreads();                                              // previous tile's readers are done
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -327,10 +342,12 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
                 sok[ly][lx] = ok; smr[ly][lx] = ok ? cur.mr[j] : 0; smc[ly][lx] = ok ? cur.mc[j] : 0; svalid[ly][lx] = ok && cur.vl[j] == T(1);
             }
         }
+        if ((int)threadIdx.x < VW) cxTab[threadIdx.x] = coefK(A, 0, x0 + (int)threadIdx.x - 2, 0);
+        else if ((int)threadIdx.x < VW + VH) cyTab[threadIdx.x - VW] = coefK(A, 1, 0, y0 + (int)threadIdx.x - VW - 2);
         __syncthreads();
         // row values at every centre of the tile + ring (sfs_rows<3>): centre (qx, qy) in q coordinates = (qx + 1, qy + 1) in v coordinates
         for (int i = threadIdx.x; i < QW * QH; i += kBlock) {
-            const int qx = i % QW, qy = i / QW, vx = qx + 1, vy = qy + 1, gx = x0 + qx - 1, gy = y0 + qy - 1;
+            const int qx = i % QW, qy = i / QW, vx = qx + 1, vy = qy + 1;
             // Branch-free: every LDS read below is inside the staged footprint for every (qx, qy); the masks (interior / valid) are applied as
             // selects at the end.  (Measured: no faster than the `if (interior) { ... if (valid) { ... } }` form -- 54.7 us per fused launch either way.)
             T jgh, jgv, js[3];
@@ -346,7 +363,10 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
                 for (int k = 0; k < 3; ++k) {
                     T sj = 0;
 #pragma unroll
-                    for (int u = 0; u < 5; ++u) sj += ((u == 0 ? T(4) : T(-1)) * coefK(A, k, gx + ox[u], gy + oy[u])) * sv[vy + oy[u]][vx + ox[u]];
+                    for (int u = 0; u < 5; ++u) {
+                        const T ck = k == 0 ? cxTab[vx + ox[u]] : k == 1 ? cyTab[vy + oy[u]] : T(1);      // coefK(A, k, gx + ox[u], gy + oy[u])
+                        sj += ((u == 0 ? T(4) : T(-1)) * ck) * sv[vy + oy[u]][vx + ox[u]];
+                    }
                     js[k] = (ok && vd) ? A.w_s * sj : T(0);
                 }
             }
@@ -358,6 +378,10 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
         if (x < A.W && y < A.H) {
             const long e = (long)y * A.W + x;
             const T ve = sv[ty + 2][tx + 2];
+            if (SFS_LATE_OWN) {
+                cur.Di = A.D_i[e]; cur.ctc = LM ? CtC[e] : T(0);
+                cur.dl = (ITER && !(K.first || K.restart)) ? K.delta[e] : T(0); cur.bb = (ITER && LM && !(K.first || K.restart)) ? K.b[e] : T(0);
+            }
             T s = 0;
             {   // (branch-free like the row values above; an excluded pixel's sum is discarded by the select below)
                 auto add = [&](T coef, T q) { s += coef * q; };
@@ -385,7 +409,7 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
                     const int qx = tx + 1 + ox[u], qy = ty + 1 + oy[u];
                     const T wgt = svalid[qy][qx] ? A.w_s * (u == 0 ? T(4) : T(-1)) : T(0);
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) add(wgt * coefK(A, k, x, y), sq[2 + k][qy][qx]);
+                    for (int k = 0; k < 3; ++k) add(wgt * (k == 0 ? cxTab[tx + 2] : k == 1 ? cyTab[ty + 2] : T(1)), sq[2 + k][qy][qx]);      // coefK(A, k, x, y)
                 }
             }
             if (LM) s += cur.ctc * ve;
@@ -404,7 +428,9 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
                 }
             }
         }
+#if SFS_PREFETCH
         cur = nxt;
+#endif
     }
     if (ITER) {
         double vv[6] = {acc, accNum, acc2, acc3, accRR, accQ};

@@ -240,16 +240,29 @@ __global__ __launch_bounds__(kBlock) void k_copy(T* __restrict__ dst, const T* _
 }
 
 // PCGComputeCtC + PCGFinalizeDiagonal: solver.t:616-622, 631-664.  On entry CtC holds raw diag(J^T J).
-template <class T>
-__global__ __launch_bounds__(kBlock) void k_finalizeDiagonal(T* __restrict__ CtC, const T* __restrict__ SSq, const T* __restrict__ r, const T* __restrict__ delta,
+// INIT: the kernel also does what PCGInit1's tail does in an LM step before it (k_initFinish: delta = 0, the guarded-inverse preconditioner -- needed only to
+// seed SSq at the first outer iteration, solver.t:635 -- and a p that this kernel overwrites anyway): one pass over the vectors instead of two or three.
+template <class T, bool INIT>
+__global__ __launch_bounds__(kBlock) void k_finalizeDiagonal(T* __restrict__ CtC, T* __restrict__ SSq, const T* __restrict__ r, T* __restrict__ delta,
                                                              T* __restrict__ pre, T* __restrict__ b, T* __restrict__ p, long nPacks, T radius, T minLm, T maxLm,
-                                                             double* __restrict__ dPartials, double* __restrict__ qPartials) {
+                                                             double* __restrict__ dPartials, double* __restrict__ qPartials, int usePre, int graphMode, int saveSSq) {
     __shared__ double scratch[kBlock / kWave + 1];
     constexpr int N = PackN<T>::N;
     const T invRadius = T(1) / radius;
     double accD = 0, accQ = 0;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nPacks; i += (long)gridDim.x * blockDim.x) {
-        Pack<T> C = ((Pack<T>*)CtC)[i], S = ((const Pack<T>*)SSq)[i], R = ((const Pack<T>*)r)[i], D = ((const Pack<T>*)delta)[i], M, P;
+        Pack<T> C = ((Pack<T>*)CtC)[i], R = ((const Pack<T>*)r)[i], S, D, M, P;
+        if (INIT) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                T pr = guardedInvert(usePre ? C.v[k] : T(1));      // k_initFinish
+                if (graphMode && !usePre) pr = T(1);
+                S.v[k] = pr; D.v[k] = T(0);
+            }
+            if (saveSSq) ((Pack<T>*)SSq)[i] = S;                   // PCGSaveSSq (first outer iteration)
+            else S = ((const Pack<T>*)SSq)[i];
+            ((Pack<T>*)delta)[i] = D;
+        } else { S = ((const Pack<T>*)SSq)[i]; D = ((const Pack<T>*)delta)[i]; }
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             T unclamped = C.v[k] * invRadius;                 // computeCtC: diag(J^T J) / radius (o.t:2277-2279)
@@ -341,7 +354,7 @@ struct PcgSolver : SolverBase {
         for (Reduction* R : {&redQ, &redQ2}) { HIP_CHECK(hipHostMalloc((void**)&R->partials, kMaxPartials * sizeof(double))); memset(R->partials, 0, kMaxPartials * sizeof(double)); R->hostVisible = true; }
         HIP_CHECK(hipMalloc((void**)&scal, 16 * sizeof(double))); HIP_CHECK(hipMemset(scal, 0, 16 * sizeof(double))); allocs.push_back(scal);
         scal4[0] = scal + 8; scal4[1] = scal + 12;
-        HIP_CHECK(hipHostMalloc((void**)&hostBuf, kMaxPartials * sizeof(double)));
+        HIP_CHECK(hipHostMalloc((void**)&hostBuf, 2 * kMaxPartials * sizeof(double)));      // room for two reductions read in one go (LM: model cost + new cost)
         E->slab = Slab{};
     }
     ~PcgSolver() override {
@@ -651,22 +664,25 @@ struct PcgSolver : SolverBase {
 
         // PCGInit1 [+ _Graph + _Finish]: the energy produces r = -J^T F and raw diag(J^T J) (parked in CtC)
         E->evalJTF(r, CtC, ctx);
-        {
+        if (!lm) {
             ScopedKernel k(ctx, "PCGInit1_Finish");
             k_initFinish<T><<<streamGrid, kBlock, 0, stream>>>(r, CtC, preconditioner, p, delta, nPacks, E->usePreconditioner ? 1 : 0, E->usesGraph ? 1 : 0, redC.partials);
             redC.n = streamGrid;
         }
         aSlot = 0;
         if (lm) {
-            if (sp.nIter == 0) { ScopedKernel k(ctx, "PCGSaveSSq"); k_copy<T><<<streamGrid, kBlock, 0, stream>>>(SSq, preconditioner, nPad); }
-            {
+            {   // PCGInit1_Finish + (first outer iteration) PCGSaveSSq + PCGFinalizeDiagonal in one pass
                 ScopedKernel k(ctx, "PCGFinalizeDiagonal");
-                k_finalizeDiagonal<T><<<streamGrid, kBlock, 0, stream>>>(CtC, SSq, r, delta, preconditioner, b, p, nPacks, trust_region_radius, min_lm_diagonal,
-                                                                         max_lm_diagonal, redC.partials, redQ.partials);
+                k_finalizeDiagonal<T, true><<<streamGrid, kBlock, 0, stream>>>(CtC, SSq, r, delta, preconditioner, b, p, nPacks, trust_region_radius, min_lm_diagonal,
+                                                                               max_lm_diagonal, redC.partials, redQ.partials, E->usePreconditioner ? 1 : 0,
+                                                                               E->usesGraph ? 1 : 0, sp.nIter == 0 ? 1 : 0);
                 redC.n = streamGrid; redQ.n = streamGrid;
             }
             preArg = E->usePreconditioner ? preconditioner : nullptr;
-            Q0 = (T)hostSum(redQ);   // fetchQ, solver.t:1050
+            // fetchQ, solver.t:1050: Q_0 = 1/2 sum delta . (r + b) with the delta PCGInit1 has just zeroed -- exactly 0 for every finite r, so the
+            // blocking read (one full drain of the stream per outer iteration) is skipped; OPT_AMD_FETCH_Q0=1 performs it
+            static const bool fetchQ0 = [] { const char* e = getenv("OPT_AMD_FETCH_Q0"); return e && atoi(e) != 0; }();
+            Q0 = fetchQ0 ? (T)hostSum(redQ) : T(0);
         }
         finalizeTo(redC, scal + aSlot);   // alphaNumerator = sum r.p
 
@@ -754,17 +770,37 @@ struct PcgSolver : SolverBase {
         T model_cost_change = 0;
         if (lm) {   // solver.t:1108-1113, 819-827
             exchangeVector(delta);
-            E->evalModelCost(delta, redC, ctx);
-            T model_cost = (T)hostSum(redC);
-            if (verbosity > 0) printf(" cost=%f \n model_cost=%f \n", (double)prevCost, (double)model_cost);
-            model_cost_change = prevCost - model_cost;
-            if (verbosity > 0) printf(" model_cost_change=%f \n", (double)model_cost_change);
+            E->evalModelCost(delta, redA, ctx);        // (its own partials buffer: the value is read together with the new cost below)
             imageOp(1);
         }
         imageOp(0);   // PCGLinearUpdate
         exchangeUnknowns();
         E->precompute(ctx);
-        T newCost = computeCost();
+        // The reference reads the model cost, then updates, then reads the new cost (two blocking copies, solver.t:1108-1117).  Neither value steers
+        // anything before both are known, so all of it is enqueued and the stream is drained once.
+        T newCost;
+        if (lm && !distributed) {
+            E->evalCost(redC, ctx);
+            HIP_CHECK(hipMemcpyAsync(hostBuf, redA.partials, redA.n * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(hostBuf + redA.n, redC.partials, redC.n * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            double sm = 0, sc = 0;
+            for (int i = 0; i < redA.n; ++i) sm += hostBuf[i];
+            for (int i = 0; i < redC.n; ++i) sc += hostBuf[redA.n + i];
+            newCost = (T)sc;
+            const T model_cost = (T)sm;
+            if (verbosity > 0) printf(" cost=%f \n model_cost=%f \n", (double)prevCost, (double)model_cost);
+            model_cost_change = prevCost - model_cost;
+            if (verbosity > 0) printf(" model_cost_change=%f \n", (double)model_cost_change);
+        } else {
+            if (lm) {
+                T model_cost = (T)hostSum(redA);
+                if (verbosity > 0) printf(" cost=%f \n model_cost=%f \n", (double)prevCost, (double)model_cost);
+                model_cost_change = prevCost - model_cost;
+                if (verbosity > 0) printf(" model_cost_change=%f \n", (double)model_cost_change);
+            }
+            newCost = computeCost();
+        }
 
         if (lm) {   // solver.t:1119-1157
             T cost_change = prevCost - newCost;
