@@ -250,7 +250,12 @@ __global__ __launch_bounds__(kBlock) void arap_edges(ArapArgs<T> A, const T* __r
 // gathers:  (J^T J p)_O(v) = w sum_{e in out(v)} Jp_e - w sum_{e in in(v)} Jp_e,   (J^T J p)_a(v)_k = -w sum_{e in out(v)} D_{e,k} . Jp_e.
 // Pass 1 writes Jp_e (3 scalars per half-edge), pass 2 is one thread per vertex.  Deterministic (lists are sorted by
 // edge id), no atomics, and the per-vertex kernel of the scatter path is folded into pass 2.
-struct GraphCsr { const int* outOff; const int* outIdx; const int* inOff; const int* inIdx; };
+struct GraphCsr { const int* outOff; const int* outIdx; const int* inOff; const int* inIdx; const int* outNbr = nullptr; const int* inNbr = nullptr; };
+// neighbour vertex of every list slot (tail of an out-edge, head of an in-edge): saves the fused kernel one level of dependent gathers
+__global__ __launch_bounds__(kBlock) void csr_neighbours(const int* __restrict__ v0, const int* __restrict__ v1, int nE, const int* __restrict__ outIdx, const int* __restrict__ inIdx,
+                                                         int* __restrict__ outNbr, int* __restrict__ inNbr) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nE; k += gridDim.x * blockDim.x) { outNbr[k] = v1[outIdx[k]]; inNbr[k] = v0[inIdx[k]]; }
+}
 
 __global__ __launch_bounds__(kBlock) void csr_count(const int* __restrict__ v0, const int* __restrict__ v1, int nE, int* __restrict__ outDeg, int* __restrict__ inDeg) {
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nE; e += gridDim.x * blockDim.x) { atomicAdd(outDeg + v0[e], 1); atomicAdd(inDeg + v1[e], 1); }
@@ -352,6 +357,75 @@ __global__ __launch_bounds__(kBlock) void arap_vertexGather(ArapArgs<T> A, Graph
     if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
 }
 
+// ---- edge pass and vertex gather in ONE launch (round 2) --------------------------------------------------------------------------
+// The two-pass form moves every half-edge's 24-byte record through memory twice more than needed: written by the edge pass, read back as
+// an out-record by its head vertex and as an in-record by its tail vertex (edge pass 240 MB + vertex pass 279 MB per J^T J p at 500 k
+// vertices / 3 M half-edges).  Here the lane that would read a record computes it instead: for its out-edge e = (v -> u) from p_u and the
+// edge's derivative columns D_e, for its in-edge e' = (u' -> v) from p_u', pa_u' and D_e' -- the same expressions as arap_edgeJp, summed in the
+// same lane / shuffle order as arap_vertexGather.  D is kept as 36-byte AoS rows (D9) for this kernel: a gathered in-edge costs one or two cache
+// lines instead of nine plane accesses.  Neighbour p's are gathers that mostly hit L2 (a mesh neighbour is a memory neighbour).
+template <class T>
+__global__ __launch_bounds__(kBlock) void arap_packD(const T* __restrict__ D, T* __restrict__ D9, long nE) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < 9 * nE; i += (long)gridDim.x * blockDim.x) D9[i] = D[(i % 9) * nE + i / 9];
+}
+template <class T>
+__global__ __launch_bounds__(kBlock) void arap_applyFused(ArapArgs<T> A, GraphCsr G, const T* __restrict__ D9, const T* __restrict__ v, T* __restrict__ out,
+                                                          const T* __restrict__ CtC, double* __restrict__ partials) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    double acc = 0;
+    const long offA = 3 * A.N;
+    const int sub = threadIdx.x % kLanesPerVertex, slot = sub;
+    const long nGroups = (A.N + (kBlock / kLanesPerVertex) - 1) / (kBlock / kLanesPerVertex);
+    for (long g = blockIdx.x; g < nGroups; g += gridDim.x) {
+        const long i = g * (kBlock / kLanesPerVertex) + threadIdx.x / kLanesPerVertex;
+        const bool ok = i < A.N;
+        const long iv = ok ? i : 0;
+        const T w = A.w_reg;
+        const V3<T> pv = ld3(v, iv), pav = ld3(v + offA, iv);
+        T s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
+        const int bo = G.outOff[iv], eo = ok ? G.outOff[iv + 1] : bo, bi = G.inOff[iv], ei = ok ? G.inOff[iv + 1] : bi;
+        for (int k = 0; k < max(eo - bo, ei - bi); k += kLanesPerVertex) {
+            const int ko = bo + slot + k, ki = bi + slot + k;
+            const int eOut = ko < eo ? G.outIdx[ko] : -1, eIn = ki < ei ? G.inIdx[ki] : -1;
+            const long e = max(eOut, 0), f = max(eIn, 0);
+            const long u = ko < eo ? G.outNbr[ko] : 0, uIn = ki < ei ? G.inNbr[ki] : 0;      // tail of my out-edge, head of my in-edge (csr_neighbours)
+            const V3<T> pu = ld3(v, u), pq = ld3(v, uIn), paq = ld3(v + offA, uIn);
+            const T* d = D9 + 9 * e; const T* h = D9 + 9 * f;
+            const T wo = eOut >= 0 ? w : T(0), wi = eIn >= 0 ? w : T(0);
+            {   // out-edge (v -> u): J p and D_k . J p  (arap_edgeJp with v0 = v)
+                const T jx = w * (pv.x - pu.x) - w * (d[0] * pav.x + d[3] * pav.y + d[6] * pav.z);
+                const T jy = w * (pv.y - pu.y) - w * (d[1] * pav.x + d[4] * pav.y + d[7] * pav.z);
+                const T jz = w * (pv.z - pu.z) - w * (d[2] * pav.x + d[5] * pav.y + d[8] * pav.z);
+                s0 += wo * jx; s1 += wo * jy; s2 += wo * jz;
+                s3 -= wo * (d[0] * jx + d[1] * jy + d[2] * jz); s4 -= wo * (d[3] * jx + d[4] * jy + d[5] * jz); s5 -= wo * (d[6] * jx + d[7] * jy + d[8] * jz);
+                if (eOut >= 0) acc += (double)(jx * jx + jy * jy + jz * jz);              // sum_u p_u (J^T J p)_u of this edge = |J p|^2 (o.t:2117-2122)
+            }
+            {   // in-edge (u' -> v): only its J p reaches this vertex's Offset row
+                const T jx = w * (pq.x - pv.x) - w * (h[0] * paq.x + h[3] * paq.y + h[6] * paq.z);
+                const T jy = w * (pq.y - pv.y) - w * (h[1] * paq.x + h[4] * paq.y + h[7] * paq.z);
+                const T jz = w * (pq.z - pv.z) - w * (h[2] * paq.x + h[5] * paq.y + h[8] * paq.z);
+                s0 -= wi * jx; s1 -= wi * jy; s2 -= wi * jz;
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < kLanesPerVertex; m <<= 1) {
+            s0 += __shfl_xor(s0, m, kWave); s1 += __shfl_xor(s1, m, kWave); s2 += __shfl_xor(s2, m, kWave);
+            s3 += __shfl_xor(s3, m, kWave); s4 += __shfl_xor(s4, m, kWave); s5 += __shfl_xor(s5, m, kWave);
+        }
+        if (ok && sub == 0) {
+            const bool valid = A.Constraints[3 * i] >= T(-999999.9);
+            const T wf = valid ? A.w_fit : T(0);
+            V3<T> q{wf * wf * pv.x, wf * wf * pv.y, wf * wf * pv.z}, qa{0, 0, 0};
+            if (CtC) { const V3<T> cO = ld3(CtC, i), cA = ld3(CtC + offA, i); q.x += cO.x * pv.x; q.y += cO.y * pv.y; q.z += cO.z * pv.z; qa.x = cA.x * pav.x; qa.y = cA.y * pav.y; qa.z = cA.z * pav.z; }
+            acc += (double)(dot3(pv, q) + dot3(pav, qa));
+            out[3 * i] = q.x + s0; out[3 * i + 1] = q.y + s1; out[3 * i + 2] = q.z + s2;
+            out[offA + 3 * i] = qa.x + s3; out[offA + 3 * i + 1] = qa.y + s4; out[offA + 3 * i + 2] = qa.z + s5;
+        }
+    }
+    double t = blockReduceSum(acc, scratch);
+    if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
+}
+
 // ---- the same for J^T F and diag(J^T J) (once per Gauss-Newton iteration) ---------------------------------------------------------
 // Edge pass: rotation-derivative columns into the D planes (as arap_edges<2>) and one 9-scalar record per half-edge,
 // {w res, w D_k . res, w^2 D_k . D_k}; vertex pass: adds the records of the vertex's out- and in-lists to what arap_vertices<2> wrote.
@@ -419,7 +493,11 @@ struct ArapOps : EnergyOps<T> {
     void* scanTemp = nullptr; size_t scanTempBytes = 0; unsigned long long* dChecksum = nullptr;
     const int *csrV0 = nullptr, *csrV1 = nullptr; int csrNE = -1; unsigned long long csrSum = 0; bool csrValid = false;
     bool useGather = true;   // OPT_AMD_ARAP_GATHER=0: scatter with wave-aggregated atomics instead
+    bool useFused = true;    // OPT_AMD_ARAP_FUSED=0: edge pass + vertex gather as two launches through the record buffer
+    T* D9 = nullptr; long d9Capacity = 0; int* nbr = nullptr;
     ~ArapOps() override {
+        if (D9) (void)hipFree(D9);
+        if (nbr) (void)hipFree(nbr);
         for (void* q : {(void*)A.D, (void*)outOff, (void*)outIdx, (void*)inOff, (void*)inIdx, (void*)cursors, (void*)Jp, scanTemp, (void*)dChecksum}) if (q) (void)hipFree(q);
     }
     void ensureCsr(LaunchCtx& ctx) {
@@ -449,6 +527,9 @@ struct ArapOps : EnergyOps<T> {
         csr_fill<<<ge, kBlock, 0, st>>>(A.v0, A.v1, A.nE, outOff, inOff, outDeg, inDeg, outIdx, inIdx);
         csr_sort<<<vgrid(), kBlock, 0, st>>>(A.N, outOff, outIdx);
         csr_sort<<<vgrid(), kBlock, 0, st>>>(A.N, inOff, inIdx);
+        if (nbr) HIP_CHECK(hipFree(nbr));
+        HIP_CHECK(hipMalloc((void**)&nbr, (size_t)2 * std::max(1, A.nE) * 4));
+        csr_neighbours<<<ge, kBlock, 0, st>>>(A.v0, A.v1, A.nE, outIdx, inIdx, nbr, nbr + std::max(1, A.nE));
         csrV0 = A.v0; csrV1 = A.v1; csrNE = A.nE; csrSum = sum; csrValid = true;
     }
     ArapOps(const unsigned* dims) {
@@ -457,6 +538,7 @@ struct ArapOps : EnergyOps<T> {
         this->addUnknown(2, A.N, 3); this->addUnknown(3, A.N, 3);                // Offset, Angle (:4-5)
         int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (const char* e = getenv("OPT_AMD_ARAP_GATHER")) useGather = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_ARAP_FUSED")) useFused = atoi(e) != 0;
     }
     void bind(void** p, LaunchCtx& ctx) override {
         A.w_fit = (T) * (const float*)p[0]; A.w_reg = (T) * (const float*)p[1];
@@ -484,10 +566,22 @@ struct ArapOps : EnergyOps<T> {
             GraphCsr G{outOff, outIdx, inOff, inIdx};
             { ScopedKernel k(ctx, "PCGInit1_Graph"); arap_edgeJTF<T><<<edgeGrid(A.nE, cus), kBlock, 0, ctx.stream>>>(A, Jp); }
             { ScopedKernel k(ctx, "PCGInit1_Gather"); arap_vertexGatherJTF<T><<<vgrid(), kBlock, 0, ctx.stream>>>(A, G, Jp, r, diag); }
+            if (useFused) {     // the derivative columns of this Gauss-Newton iteration as 36-byte rows for arap_applyFused
+                if (A.nE > d9Capacity) { if (D9) HIP_CHECK(hipFree(D9)); d9Capacity = A.nE; HIP_CHECK(hipMalloc((void**)&D9, (size_t)9 * std::max<long>(1, d9Capacity) * sizeof(T))); }
+                ScopedKernel k(ctx, "packDerivativeRows");
+                arap_packD<T><<<edgeGrid(A.nE, cus), kBlock, 0, ctx.stream>>>(A.D, D9, (long)A.nE);
+            }
         } else { ScopedKernel k(ctx, "PCGInit1_Graph"); arap_edges<T, 2><<<edgeGrid(A.nE, cus), kBlock, 0, ctx.stream>>>(A, nullptr, r, diag, nullptr); }
     }
     void applyJTJ(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) override {
         const int gv = vgrid(), ge = edgeGrid(A.nE, cus);
+        if (useGather && useFused) {
+            GraphCsr G{outOff, outIdx, inOff, inIdx, nbr, nbr + std::max(1, A.nE)};
+            ScopedKernel k(ctx, "PCGStep1");
+            arap_applyFused<T><<<gv, kBlock, 0, ctx.stream>>>(A, G, D9, v, out, CtC, dot ? dot->partials : nullptr);
+            if (dot) dot->n = gv;
+            return;
+        }
         if (useGather) {
             GraphCsr G{outOff, outIdx, inOff, inIdx};
             { ScopedKernel k(ctx, "PCGStep1_Graph"); arap_edgeJp<T><<<ge, kBlock, 0, ctx.stream>>>(A, v, Jp, dot ? dot->partials + gv : nullptr); }
