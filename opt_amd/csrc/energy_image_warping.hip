@@ -1126,7 +1126,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         const bool rfreeLoop = paired && rFree && pre != 0;
         const T *rOldPtr = a.rOld, *pOldPtr = a.pOld; T* pNewPtr = a.pNew; int rfreeFlag = 0;
         if (rfreeLoop) {
-            const size_t bytes = (size_t)A.W * A.H * 3 * sizeof(T);
+            const size_t bytes = ((size_t)A.W * A.H * 3 + 3) / 4 * 4 * sizeof(T);      // padded like the solver's vectors: its flat kernels read whole 16-byte packs of the last p
             for (int j = 0; j < 3; ++j) if (!ring[j]) { HIP_CHECK(hipMalloc((void**)&ring[j], bytes)); HIP_CHECK(hipMemsetAsync(ring[j], 0, bytes, ctx.stream)); }
             if (a.first) r0Ptr = a.rOld;                       // the solver swaps its r buffers after every launch; this one keeps r_0 until launch 1 has read it
             const int k = iterIndex;
