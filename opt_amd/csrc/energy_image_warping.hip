@@ -724,7 +724,8 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE>::value), ITER_MIN_WAVES) void 
     // beta_{k-2} == 0 (the reference's guard, or an exactly converged solve) leaves nothing to divide by: that launch reads p_{k-2} from memory.
     const bool reconR = !LM && K.rfree == 1;
     const T betaOlder = reconR ? K.alphaIn[2] : T(0);      // the beta of the previous launch: p_{k-1} = M r_{k-1} + betaOlder p_{k-2}
-    // (In the r-free loop p_{k-2} is an input of the launch anyway -- read through rOld two trips earlier, still in L1 / L2 -- and is simply read again: exact.)
+    // (This rebuilt term is what runs with OPT_AMD_RFREE=0.  In the r-free loop p_{k-2} is an input of the launch anyway: the lattice kernel keeps it in three
+    // registers from its load, the general kernel -- no registers to spare -- reads it again; both exact.)
     const T beta2 = (K.deltaMode == 1 && K.reconP && (!K.rfree || K.reconP == 2)) ? K.alphaIn[2] : T(0);      // reconP == 2: A/B switch (OPT_AMD_RECON_P=2)
     const bool recon = beta2 != T(0);
     const T invBeta2 = recon ? T(1) / beta2 : T(0);
