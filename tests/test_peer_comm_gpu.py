@@ -86,6 +86,24 @@ def test_peer_mailbox_ranks_as_processes(world, ghost, double):
         assert res[0][1] == res[1][1]                                           # rank-ordered sums: bitwise identical on every rank
 
 
+@pytest.mark.parametrize("world,ghost,double", [(3, 2, True), (4, 8, False), (4, 1, True), (8, 8, False)])
+def test_peer_mailbox_middle_ranks(world, ghost, double):
+    """3 and 4 processes: the middle ranks have a neighbour on BOTH sides (two staging blocks pushed and pulled per exchange, acknowledgements from two
+    peers) and the mailbox carries 3 - 4 contributions per all-reduce -- what every rank but the first and last of an 8-GPU run does."""
+    case = dict(W=70, H=64 if world < 8 else 136, double=double, ghost=ghost, kind="gaussNewtonGPU", n=2, l=14)      # (8, 8): bench.py's rank count and ghost depth
+    P = wl.image_warping(case["W"], case["H"], double=double, random_state=3, mask_fraction=0.06, perturb=0.3)
+    c1, x1 = _single(P, case["kind"], nIterations=case["n"], lIterations=case["l"])
+    res = _run(world, case)
+    tol = 1e-11 if double else 2e-5
+    for r in range(world):
+        _, costs, unk, row0, rows, mem_kind, err = res[r]
+        assert err == 0
+        np.testing.assert_allclose(costs, c1, rtol=tol)
+        assert costs == res[0][1]                                               # bitwise identical on every rank
+        for a, b in zip(unk, x1):
+            assert rel_err(a, b[row0:row0 + rows]) < tol
+
+
 def test_peer_mailbox_lm_two_processes():
     case = dict(W=48, H=40, double=True, ghost=2, kind="LMGPU", n=3, l=12)
     P = wl.image_warping(case["W"], case["H"], double=True, random_state=3, mask_fraction=0.06, perturb=0.3)
