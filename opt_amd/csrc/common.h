@@ -40,6 +40,16 @@ struct Reduction {
     bool hostVisible = false;     // partials live in pinned host memory (zero-copy): a sum only the HOST consumes (LM's Q) needs no copy kernel
 };
 
+// A double delivered to the polling host as two self-validating 8-byte words {tag | low half, tag | high half} in pinned memory (slot 2i, 2i+1 of a
+// host-visible Reduction): each word arrives whole, so the host needs neither an event in the stream nor a fence -- it spins until both words carry
+// the launch's tag.  (The peer communicator's mailbox uses the same word format between GPUs.)
+__device__ __forceinline__ void storeTaggedPartial(double* partials, int i, double v, unsigned tag) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v), t = (unsigned long long)tag << 32;
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(partials) + 2 * (long)i;
+    __hip_atomic_store(w, t | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(w + 1, t | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- wave64 / workgroup reductions -------------------------------------------------------------------
 __device__ __forceinline__ double waveReduceSum(double v) {
 #pragma unroll

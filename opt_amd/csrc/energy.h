@@ -50,6 +50,7 @@ struct PcgIterArgs {
     // afterReset: the previous iteration ended with the split residual reset (solver.t:1077-1083), which already updated delta
     // and r; this launch then only forms p = M r + beta p with beta = sum(betaNum) / sum(betaDen) and applies J^T J.
     const T* CtC = nullptr; const T* b = nullptr; Reduction* q = nullptr;
+    unsigned qTag = 0;                                   // != 0: q is host-visible and its partials are written as tagged word pairs (common.h storeTaggedPartial)
     int afterReset = 0; Reduction betaNum, betaDen;
     T lmRadius = 0, lmMinDiag = 0, lmMaxDiag = 0;        // the scalars of PCGFinalizeDiagonal (solver.t:631-664): an energy whose diag(J^T J) is a known
                                                          // function of per-pixel flags can rebuild CtC and the LM preconditioner from them instead of reading both

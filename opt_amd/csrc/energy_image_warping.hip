@@ -425,7 +425,7 @@ struct IterK {             // kernel argument block
     // linear solve -- rOld still holds the solver's true r_0, nothing to rebuild, but r is not written either.
     int rfree;
     // Levenberg-Marquardt variant of iw_pcgIter2 (energy.h PcgIterArgs): CtC, b, the Q partial sums, and the after-reset mode
-    const T* CtC; const T* b; double* q; int afterReset; const double* betaNum; int nBetaNum; const double* betaDen; int nBetaDen;
+    const T* CtC; const T* b; double* q; unsigned qTag; int afterReset; const double* betaNum; int nBetaNum; const double* betaDen; int nBetaDen;
     T* deltaOut;           // where the updated delta is written (== delta: in place)
     T lmRadius, lmMin, lmMax;   // PRE == 3 with LM: CtC and the LM preconditioner are rebuilt from the flag byte (see the kernel)
     const double *aNumPrev, *aDenPrev, *s2Prev, *s3Prev; int nNum, nDen, n2, n3;
@@ -859,7 +859,7 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE>::value), ITER_MIN_WAVES) void 
     blockReduceSumN<5>(v, scratch);
     if (threadIdx.x == 0) {
         K.aDen[blockIdx.x] = v[0]; K.aNum[blockIdx.x] = v[1]; K.s2[blockIdx.x] = v[2]; K.s3[blockIdx.x] = v[3];
-        if (LM) K.q[blockIdx.x] = v[4];
+        if (LM) { if (K.qTag) storeTaggedPartial(K.q, blockIdx.x, v[4], K.qTag); else K.q[blockIdx.x] = v[4]; }
     }
 }
 
@@ -1145,7 +1145,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         }
         deferredTerm = paired && iterIndex >= 1 && iterIndex % 2 == 1;            // after an odd launch alpha_{k-1} p_{k-1} is still owed (pcgFinish)
         IterK<T> K{rOldPtr, a.ApOld, pOldPtr, a.rNew, a.ApNew, pNewPtr, a.delta, a.pre, a.first, pre == 2 ? mc : nullptr, iterFlip, deltaMode, alphaIn, alphaOut, reconstructP,
-                   rfreeFlag, a.CtC, a.b, a.q ? a.q->partials : nullptr, a.afterReset, a.betaNum.partials, a.betaNum.n, a.betaDen.partials, a.betaDen.n,
+                   rfreeFlag, a.CtC, a.b, a.q ? a.q->partials : nullptr, a.qTag, a.afterReset, a.betaNum.partials, a.betaNum.n, a.betaDen.partials, a.betaDen.n,
                    a.deltaOut ? a.deltaOut : a.delta, a.lmRadius, a.lmMinDiag, a.lmMaxDiag,
                    a.aNumPrev.partials, a.aDenPrev.partials, a.s2Prev.partials, a.s3Prev.partials, a.aNumPrev.n, a.aDenPrev.n, a.s2Prev.n, a.s3Prev.n,
                    a.aNum->partials, a.aDen->partials, a.s2->partials, a.s3->partials, A.yBegin, A.yEnd};

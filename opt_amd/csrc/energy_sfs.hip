@@ -223,7 +223,7 @@ constexpr int kSfsTW = SFS_TW, kSfsTH = SFS_TH;
 // also sums rr_0 = r_0 . r_0 for launch 1's expansion.  Per PCG iteration: one launch instead of three (PCGStep1, PCGStep2, PCGStep3).
 template <class T>
 struct SIterK {
-    const T *rOld, *ApOld, *pOld; T *rNew, *pNew; const T* delta; T* deltaOut; const T* b; double* q;
+    const T *rOld, *ApOld, *pOld; T *rNew, *pNew; const T* delta; T* deltaOut; const T* b; double* q; unsigned qTag;
     int first, restart, rrFromPrivate;
     const double *aNumPrev, *aDenPrev, *s2Prev, *s3Prev, *rrPrev; int nNum, nDen, n2, n3, nRR;
     const double *betaNum, *betaDen; int nBetaNum, nBetaDen;
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
         if (threadIdx.x == 0) {
             K.aDen[blockIdx.x] = vv[0]; K.aNum[blockIdx.x] = vv[1]; K.s2[blockIdx.x] = vv[2]; K.s3[blockIdx.x] = vv[3];
             if (K.first) K.rr[blockIdx.x] = vv[4];
-            if (LM && K.q) K.q[blockIdx.x] = vv[5];
+            if (LM && K.q) { if (K.qTag) storeTaggedPartial(K.q, blockIdx.x, vv[5], K.qTag); else K.q[blockIdx.x] = vv[5]; }
         }
     } else {
         double t = blockReduceSum(acc, scratch);
@@ -525,7 +525,7 @@ struct SfsOps : EnergyOps<T> {
         const int g = tileGrid(lmLoop, true);
         SIterK<T> K{};
         K.rOld = a.rOld; K.ApOld = a.ApOld; K.pOld = a.pOld; K.rNew = a.rNew; K.pNew = a.pNew; K.delta = a.delta; K.deltaOut = a.deltaOut ? a.deltaOut : a.delta;
-        K.b = a.b; K.q = a.q ? a.q->partials : nullptr; K.first = a.first; K.restart = a.afterReset;
+        K.b = a.b; K.q = a.q ? a.q->partials : nullptr; K.qTag = a.qTag; K.first = a.first; K.restart = a.afterReset;
         K.rrFromPrivate = (!a.first && !a.afterReset && prevWasFirst) ? 1 : 0;
         K.aNumPrev = a.aNumPrev.partials; K.aDenPrev = a.aDenPrev.partials; K.s2Prev = a.s2Prev.partials; K.s3Prev = a.s3Prev.partials; K.rrPrev = rrPartials;
         K.nNum = a.aNumPrev.n; K.nDen = a.aDenPrev.n; K.n2 = a.s2Prev.n; K.n3 = a.s3Prev.n; K.nRR = nRR;

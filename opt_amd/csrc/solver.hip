@@ -167,20 +167,28 @@ __global__ __launch_bounds__(kBlock) void k_step2(T* __restrict__ delta, const T
 }
 
 // PCGStep2_1stHalf: solver.t:491-503
+// deltaOut may be delta (in place) or another vector (the caller then decides later which of the two it keeps).  alphaNumerator is either a
+// finished total (aNumTotal, nNum == 0) or partial sums this kernel adds up itself -- the same sumPartials over kBlock threads as
+// k_finalizeSum, so the same bits, one launch less.
 template <class T>
-__global__ __launch_bounds__(kBlock) void k_step2FirstHalf(T* __restrict__ delta, const T* __restrict__ p, long nPacks, const double* __restrict__ aNumTotal,
-                                                           const double* __restrict__ aDenPartials, int nDen) {
+__global__ __launch_bounds__(kBlock) void k_step2FirstHalf(const T* delta, T* deltaOut, const T* __restrict__ p, long nPacks, const double* __restrict__ aNumTotal,
+                                                           const double* __restrict__ aNumPartials, int nNum, const double* __restrict__ aDenPartials, int nDen) {
     __shared__ double scratch[kBlock / kWave + 1];
     constexpr int N = PackN<T>::N;
     const T aDen = (T)sumPartials(aDenPartials, nDen, scratch);
-    const T aNum = (T)aNumTotal[0];
+    const T aNum = nNum > 0 ? (T)sumPartials(aNumPartials, nNum, scratch) : (T)aNumTotal[0];
     const T alpha = (aDen > T(0)) ? aNum / aDen : T(0);
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nPacks; i += (long)gridDim.x * blockDim.x) {
-        Pack<T> D = ((Pack<T>*)delta)[i], P = ((const Pack<T>*)p)[i];
+        Pack<T> D = ((const Pack<T>*)delta)[i], P = ((const Pack<T>*)p)[i];
 #pragma unroll
         for (int k = 0; k < N; ++k) D.v[k] = D.v[k] + alpha * P.v[k];
-        ((Pack<T>*)delta)[i] = D;
+        ((Pack<T>*)deltaOut)[i] = D;
     }
+}
+
+// Completion stamp for PcgSolver::drain(): everything enqueued before it has finished when the host sees the value.
+__global__ void k_stamp(unsigned long long* flag, unsigned long long v) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // PCGStep2_2ndHalf: solver.t:505-534
@@ -311,6 +319,11 @@ struct PcgSolver : SolverBase {
     std::vector<void*> allocs;
     Reduction redA, redB, redQ, redC;   // alpha denominator, beta numerator, q, cost / init numerator
     Reduction redQ2;                    // second Q buffer: the LM single-kernel loop enqueues launch k + 1 (which writes Q_k) before the host has read Q_{k-1}
+    Reduction redQR;                    // pinned: Q of the split residual reset (its own buffer: the reset is enqueued while the host may still poll redQ / redQ2)
+    unsigned long long* stampFlag = nullptr; unsigned long long stampSeq = 0; bool pollSync = true;   // drain(): OPT_AMD_POLL_SYNC=0 -> hipStreamSynchronize
+    Reduction redMH, redCH;             // pinned: model cost / cost partials that only the host sums (no copy kernel between the producer and the read)
+    unsigned launchTag = 0;             // tags of the Q partials the single-kernel LM launches deliver as self-validating words (common.h storeTaggedPartial)
+    bool taggedQ = true;                // OPT_AMD_TAGGED_Q=0: plain partials + an event in the stream (A/B switch)
     double* scal = nullptr;             // device: [0],[1] alphaNumerator ping-pong, [2..5] slab totals
     double* scal4[2] = {nullptr, nullptr};   // device: all-reduced {alphaNum, alphaDen, s2, s3} of the single-kernel iteration (slab mode), ping-pong
     int aSlot = 0;
@@ -351,7 +364,11 @@ struct PcgSolver : SolverBase {
         redA = allocRed(); redB = allocRed(); redC = allocRed();
         // Q (solver.t:483-485, 1093-1102) is read by the host once per LM iteration and by no kernel: its partials go straight to pinned host memory
         // (<= 16 KB of posted writes per launch) instead of through a device buffer and a copy kernel per iteration (830 copyBuffer launches, 7 % of config 3's GPU time)
-        for (Reduction* R : {&redQ, &redQ2}) { HIP_CHECK(hipHostMalloc((void**)&R->partials, kMaxPartials * sizeof(double))); memset(R->partials, 0, kMaxPartials * sizeof(double)); R->hostVisible = true; }
+        // With the single-kernel loop each partial is two tagged words (2 x kMaxPartials slots), which the host polls: no event packet in the stream either.
+        for (Reduction* R : {&redQ, &redQ2, &redQR, &redMH, &redCH}) { HIP_CHECK(hipHostMalloc((void**)&R->partials, 2 * kMaxPartials * sizeof(double))); memset(R->partials, 0, 2 * kMaxPartials * sizeof(double)); R->hostVisible = true; }
+        if (const char* e = getenv("OPT_AMD_TAGGED_Q")) taggedQ = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_POLL_SYNC")) pollSync = atoi(e) != 0;
+        HIP_CHECK(hipHostMalloc((void**)&stampFlag, 64)); *stampFlag = 0;
         HIP_CHECK(hipMalloc((void**)&scal, 16 * sizeof(double))); HIP_CHECK(hipMemset(scal, 0, 16 * sizeof(double))); allocs.push_back(scal);
         scal4[0] = scal + 8; scal4[1] = scal + 12;
         HIP_CHECK(hipHostMalloc((void**)&hostBuf, 2 * kMaxPartials * sizeof(double)));      // room for two reductions read in one go (LM: model cost + new cost)
@@ -363,6 +380,10 @@ struct PcgSolver : SolverBase {
         if (hostBuf) (void)hipHostFree(hostBuf);
         if (redQ.partials) (void)hipHostFree(redQ.partials);
         if (redQ2.partials) (void)hipHostFree(redQ2.partials);
+        if (redMH.partials) (void)hipHostFree(redMH.partials);
+        if (redQR.partials) (void)hipHostFree(redQR.partials);
+        if (stampFlag) (void)hipHostFree(stampFlag);
+        if (redCH.partials) (void)hipHostFree(redCH.partials);
         if (hostBufQ) { (void)hipHostFree(hostBufQ); (void)hipEventDestroy(qEvent); }
         (void)hipStreamDestroy(stream);
     }
@@ -376,7 +397,7 @@ struct PcgSolver : SolverBase {
             HIP_CHECK(hipStreamSynchronize(stream));
             return hostBuf[0];
         }
-        if (R.hostVisible) { HIP_CHECK(hipStreamSynchronize(stream)); double s = 0; for (int i = 0; i < R.n; ++i) s += R.partials[i]; return s; }
+        if (R.hostVisible) { drain(); double s = 0; for (int i = 0; i < R.n; ++i) s += R.partials[i]; return s; }
         HIP_CHECK(hipMemcpyAsync(hostBuf, R.partials, R.n * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         double s = 0; for (int i = 0; i < R.n; ++i) s += hostBuf[i];
@@ -401,6 +422,44 @@ struct PcgSolver : SolverBase {
     double endHostSum() {
         HIP_CHECK(hipEventSynchronize(qEvent));
         double s = 0; for (int i = 0; i < qCount; ++i) s += qSrc[i];
+        return s;
+    }
+    // Everything enqueued so far has finished and what it wrote to pinned memory is readable.  A one-thread kernel stamps a pinned word and the host spins
+    // on it: no barrier packet with a completion signal in the queue and no wake-up through the runtime (the latency-bound LM steps drain twice or more).
+    void drain() {
+        if (!pollSync) { HIP_CHECK(hipStreamSynchronize(stream)); return; }
+        const unsigned long long v = ++stampSeq;
+        k_stamp<<<1, kWave, 0, stream>>>(stampFlag, v);
+        unsigned long spins = 0; int drained = 0;
+        while (__atomic_load_n(stampFlag, __ATOMIC_ACQUIRE) != v) {
+            if ((++spins & 0x3fff) == 0) {
+                const hipError_t e = hipStreamQuery(stream);
+                if (e != hipSuccess && e != hipErrorNotReady) HIP_CHECK(e);
+                if (e == hipSuccess && ++drained > 2) { fprintf(stderr, "Opt(amd): completion stamp %llu never arrived\n", v); exit(1); }
+            }
+            __builtin_ia32_pause();
+        }
+    }
+    // Sum of a host-visible reduction whose producer wrote tagged word pairs: spin on pinned memory until every pair carries `tag`; nothing was put in the
+    // stream for it.  The stream is queried now and then so that a faulted or never-issued producer ends in an error message instead of a hang.
+    double pollTaggedSum(const Reduction& R, unsigned tag) {
+        const unsigned long long* w = reinterpret_cast<const unsigned long long*>(R.partials);
+        double s = 0; unsigned long spins = 0; int drained = 0;
+        for (int i = 0; i < R.n; ++i) {
+            unsigned long long lo, hi;
+            for (;;) {
+                lo = __atomic_load_n(w + 2 * i, __ATOMIC_ACQUIRE); hi = __atomic_load_n(w + 2 * i + 1, __ATOMIC_ACQUIRE);
+                if ((unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag) break;
+                if ((++spins & 0x3fff) == 0) {
+                    const hipError_t e = hipStreamQuery(stream);
+                    if (e != hipSuccess && e != hipErrorNotReady) HIP_CHECK(e);
+                    if (e == hipSuccess && ++drained > 2) { fprintf(stderr, "Opt(amd): Q partial %d of tag %u never arrived\n", i, tag); exit(1); }
+                }
+                __builtin_ia32_pause();
+            }
+            const unsigned long long bits = (lo & 0xffffffffull) | (hi << 32);
+            double v; memcpy(&v, &bits, sizeof v); s += v;
+        }
         return s;
     }
     // dst[i] = sum over ranks of sum(Rs[i].partials): one launch if the communicator folds the local reduction in (allReducePartials)
@@ -457,8 +516,9 @@ struct PcgSolver : SolverBase {
 
     // ---- pieces ---------------------------------------------------------------------------------------
     T computeCost() {   // solver.t:790-797
-        E->evalCost(redC, ctx);
-        return (T)hostSum(redC);
+        Reduction& R = distributed ? redC : redCH;   // single GPU: the partials land in pinned memory and the host sums them after one drain
+        E->evalCost(R, ctx);
+        return (T)hostSum(R);
     }
     void imageOp(int kind) {   // 0: X += delta, 1: prevX = X, 2: X = prevX
         for (size_t i = 0; i < E->unknowns.size(); ++i) {
@@ -526,7 +586,7 @@ struct PcgSolver : SolverBase {
         const T* pLast = E->pcgFinish(p2, delta, ctx);
         if (!pLast) pLast = p;
         finalizeLocal(prev[0], scal + 2);
-        { ScopedKernel k(ctx, "PCGStep2_delta"); k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, pLast, nPacks, scal + 2, prev[1].partials, prev[1].n); }
+        { ScopedKernel k(ctx, "PCGStep2_delta"); k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, delta, pLast, nPacks, scal + 2, nullptr, 0, prev[1].partials, prev[1].n); }
         return true;
     }
     // ---- the same for Levenberg-Marquardt (energy.h PcgIterArgs, LM fields).  Launch k applies Step2 and Step3 of iteration k-1 and
@@ -541,6 +601,7 @@ struct PcgSolver : SolverBase {
         int cur = 0;
         bool afterReset = false, deltaOwed = false, issued = false, issuedRestart = false;
         Reduction bNumDirect{}, bDenDirect{};
+        unsigned tagOf[2] = {0, 0};                                 // tag of the Q partials in redQ / redQ2
         // One launch from the current state into the alternate buffers (r2, p2, delta2, setS[cur]); adopted later by pointer swaps.
         auto issue = [&](int k, bool restart) -> bool {
             PcgIterArgs<T> a{};
@@ -548,6 +609,7 @@ struct PcgSolver : SolverBase {
             a.aNumPrev = prev[0]; a.aDenPrev = prev[1]; a.s2Prev = prev[2]; a.s3Prev = prev[3];
             a.aNum = &setS[cur][0]; a.aDen = &setS[cur][1]; a.s2 = &setS[cur][2]; a.s3 = &setS[cur][3];
             a.CtC = CtC; a.b = b; a.q = (k & 1) ? &redQ2 : &redQ; a.afterReset = restart ? 1 : 0; a.betaNum = bNumDirect; a.betaDen = bDenDirect;
+            if (taggedQ) { if (++launchTag == 0) ++launchTag; a.qTag = tagOf[k & 1] = launchTag; }
             a.lmRadius = trust_region_radius; a.lmMinDiag = min_lm_diagonal; a.lmMaxDiag = max_lm_diagonal;
             issuedRestart = restart;
             return E->pcgIteration(a, ctx);
@@ -563,36 +625,46 @@ struct PcgSolver : SolverBase {
             cur ^= 1;
             afterReset = false;
             const bool resetNow = ((lIter + 1) % sp.residual_reset_period) == 0;
+            // The split residual reset (solver.t:1077-1083) of this iteration: delta += alpha p, then r = b - (J^T J + CtC) delta afresh.
+            auto resetKernels = [&](T* deltaOut) {
+                { ScopedKernel k(ctx, "PCGStep2_1stHalf");
+                  k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, deltaOut, p, nPacks, nullptr, prev[0].partials, prev[0].n, prev[1].partials, prev[1].n); }
+                E->applyJTJ(deltaOut, Adelta, CtC, nullptr, ctx);             // computeAdelta
+                { ScopedKernel k(ctx, "PCGStep2_2ndHalf");
+                  k_step2SecondHalf<T><<<streamGrid, kBlock, 0, stream>>>(deltaOut, r, Adelta, b, preArg, z, nPacks, redB.partials, redQR.partials); }
+                redB.n = streamGrid; redQR.n = streamGrid;
+            };
+            bool resetIssued = false;
             if (appliedStep2) {
-                beginHostSum((lIter & 1) ? redQ2 : redQ);
-                // The next launch is enqueued before Q is known: it writes only the alternate buffers, so if the test below ends the
-                // linear solve its results are simply never adopted (the fetchQ of solver.t:1098 no longer idles the GPU).
-                if (lIter + 1 < sp.lIterations && !resetNow) { if (!issue(lIter + 1, false)) { fprintf(stderr, "pcgIteration refused mid-loop\n"); exit(1); } issued = true; }
-                const T Q1 = (T)endHostSum();
+                if (!taggedQ) beginHostSum((lIter & 1) ? redQ2 : redQ);
+                // What follows is enqueued before Q is known.  The next launch writes only the alternate buffers, and the reset writes delta2, r (dead after
+                // an early-out) and scratch: if the test below ends the linear solve, their results are simply never adopted (the fetchQ of solver.t:1098
+                // no longer idles the GPU).
+                if (resetNow) { resetKernels(delta2); resetIssued = true; }
+                else if (lIter + 1 < sp.lIterations) { if (!issue(lIter + 1, false)) { fprintf(stderr, "pcgIteration refused mid-loop\n"); exit(1); } issued = true; }
+                const T Q1 = (T)(taggedQ ? pollTaggedSum((lIter & 1) ? redQ2 : redQ, tagOf[lIter & 1]) : endHostSum());
                 const T zeta = T(lIter) * (Q1 - Q0) / Q1;
                 if (zeta < q_tolerance) { if (verbosity > 0) printf("zeta=%.18g, breaking at iteration: %d\n", (double)zeta, lIter); return true; }
                 Q0 = Q1;
             }
             deltaOwed = true;                                          // iteration lIter: Step1 done, its Step2 still to come
-            if (resetNow) {                                            // solver.t:1077-1083
-                finalizeLocal(prev[0], scal + 2);
-                { ScopedKernel k(ctx, "PCGStep2_1stHalf"); k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, p, nPacks, scal + 2, prev[1].partials, prev[1].n); }
-                E->applyJTJ(delta, Adelta, CtC, nullptr, ctx);             // computeAdelta
-                { ScopedKernel k(ctx, "PCGStep2_2ndHalf");
-                  k_step2SecondHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, r, Adelta, b, preArg, z, nPacks, redB.partials, redQ.partials); }
-                redB.n = streamGrid; redQ.n = streamGrid;
+            if (resetNow) {
+                if (resetIssued) std::swap(delta, delta2); else resetKernels(delta);
                 deltaOwed = false;
-                const T Q1 = (T)hostSum(redQ);
-                const T zeta = T(lIter + 1) * (Q1 - Q0) / Q1;
-                if (zeta < q_tolerance) { if (verbosity > 0) printf("zeta=%.18g, breaking at iteration: %d\n", (double)zeta, lIter + 1); return true; }
-                Q0 = Q1;
+                // fetchQ (solver.t:1098).  After the last iteration its only effect is the message below: the loop ends either way, so the blocking
+                // read (one drain of the stream per outer iteration when residual_reset_period == lIterations, the default) happens only when someone is listening.
+                if (lIter + 1 < sp.lIterations || verbosity > 0) {
+                    const T Q1 = (T)hostSum(redQR);
+                    const T zeta = T(lIter + 1) * (Q1 - Q0) / Q1;
+                    if (zeta < q_tolerance) { if (verbosity > 0) printf("zeta=%.18g, breaking at iteration: %d\n", (double)zeta, lIter + 1); return true; }
+                    Q0 = Q1;
+                }
                 afterReset = true; bNumDirect = redB; bDenDirect = prev[0];
             }
         }
         if (deltaOwed) {   // the last iteration's delta += alpha p; its r, z, p and Q are dead (the reference's last fetchQ can only break a finished loop)
-            finalizeLocal(prev[0], scal + 2);
             ScopedKernel k(ctx, "PCGStep2_delta");
-            k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, p, nPacks, scal + 2, prev[1].partials, prev[1].n);
+            k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, delta, p, nPacks, nullptr, prev[0].partials, prev[0].n, prev[1].partials, prev[1].n);
         }
         return true;
     }
@@ -724,7 +796,7 @@ struct PcgSolver : SolverBase {
         for (int lIter = 0; !single && lIter < sp.lIterations; ++lIter) {
             const bool reset = lm && ((lIter + 1) % sp.residual_reset_period) == 0;
             if (reset) {   // solver.t:1077-1083
-                { ScopedKernel k(ctx, "PCGStep2_1stHalf"); k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, p, nPacks, scal + aSlot, aDen.partials, aDen.n); }
+                { ScopedKernel k(ctx, "PCGStep2_1stHalf"); k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, delta, p, nPacks, scal + aSlot, nullptr, 0, aDen.partials, aDen.n); }
                 exchangeVector(delta);
                 E->applyJTJ(delta, Adelta, CtC, nullptr, ctx);             // computeAdelta (+_Graph)
                 { ScopedKernel k(ctx, "PCGStep2_2ndHalf");
@@ -745,7 +817,9 @@ struct PcgSolver : SolverBase {
             pendingStep3 = true;   // PCGStep3 of this iteration runs with the next PCGStep1
             const bool more = lIter + 1 < sp.lIterations;
             double qh = 0;
-            if (lm && speculate) {
+            const bool deadFetch = lm && !more && verbosity == 0 && !traceEnabled;   // fetchQ after the last iteration only feeds the "breaking" message
+            if (deadFetch) {
+            } else if (lm && speculate) {
                 beginHostSum(redQ);
                 if (more) stepThreeAndOne();
                 qh = endHostSum();
@@ -753,7 +827,7 @@ struct PcgSolver : SolverBase {
                 if (lm) qh = hostSum(redQ);
                 if (traceEnabled) record(lIter, aDen, bNum, qh);
             }
-            if (lm) {   // solver.t:1093-1102
+            if (lm && !deadFetch) {   // solver.t:1093-1102
                 Q1 = (T)qh;
                 T zeta = T(lIter + 1) * (Q1 - Q0) / Q1;
                 if (zeta < q_tolerance) { if (verbosity > 0) printf("zeta=%.18g, breaking at iteration: %d\n", (double)zeta, lIter + 1); break; }
@@ -770,7 +844,7 @@ struct PcgSolver : SolverBase {
         T model_cost_change = 0;
         if (lm) {   // solver.t:1108-1113, 819-827
             exchangeVector(delta);
-            E->evalModelCost(delta, redA, ctx);        // (its own partials buffer: the value is read together with the new cost below)
+            E->evalModelCost(delta, distributed ? redA : redMH, ctx);   // (its own partials buffer: the value is read together with the new cost below)
             imageOp(1);
         }
         imageOp(0);   // PCGLinearUpdate
@@ -780,13 +854,11 @@ struct PcgSolver : SolverBase {
         // anything before both are known, so all of it is enqueued and the stream is drained once.
         T newCost;
         if (lm && !distributed) {
-            E->evalCost(redC, ctx);
-            HIP_CHECK(hipMemcpyAsync(hostBuf, redA.partials, redA.n * sizeof(double), hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipMemcpyAsync(hostBuf + redA.n, redC.partials, redC.n * sizeof(double), hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
+            E->evalCost(redCH, ctx);                   // both sets of partials are written straight to pinned memory: one drain, no copy kernels
+            drain();
             double sm = 0, sc = 0;
-            for (int i = 0; i < redA.n; ++i) sm += hostBuf[i];
-            for (int i = 0; i < redC.n; ++i) sc += hostBuf[redA.n + i];
+            for (int i = 0; i < redMH.n; ++i) sm += redMH.partials[i];
+            for (int i = 0; i < redCH.n; ++i) sc += redCH.partials[i];
             newCost = (T)sc;
             const T model_cost = (T)sm;
             if (verbosity > 0) printf(" cost=%f \n model_cost=%f \n", (double)prevCost, (double)model_cost);
