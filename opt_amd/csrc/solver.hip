@@ -243,6 +243,10 @@ __global__ __launch_bounds__(kBlock) void k_axpyImage(T* __restrict__ X, const T
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) X[i] = X[i] + d[i];
 }
 template <class T>
+__global__ __launch_bounds__(kBlock) void k_saveAndUpdate(T* __restrict__ X, T* __restrict__ prev, const T* __restrict__ d, long n) {   // prev = X; X += d  (LM: solver.t:1113-1114 in one pass)
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) { const T x = X[i]; prev[i] = x; X[i] = x + d[i]; }
+}
+template <class T>
 __global__ __launch_bounds__(kBlock) void k_copy(T* __restrict__ dst, const T* __restrict__ src, long n) {    // solver.t:559-564, 573-578, 624-629
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
 }
@@ -527,6 +531,7 @@ struct PcgSolver : SolverBase {
             int grid = (int)std::max<long>(1, std::min<long>((cnt + kBlock - 1) / kBlock, 4096));
             T* X = E->unknownPtr((int)i);
             if (kind == 0) { ScopedKernel k(ctx, "PCGLinearUpdate"); k_axpyImage<T><<<grid, kBlock, 0, stream>>>(X, delta + u.offset, cnt); }
+            else if (kind == 3) { ScopedKernel k(ctx, "PCGLinearUpdate"); k_saveAndUpdate<T><<<grid, kBlock, 0, stream>>>(X, prevX + u.offset, delta + u.offset, cnt); }   // 1 then 0
             else if (kind == 1) { ScopedKernel k(ctx, "savePreviousUnknowns"); k_copy<T><<<grid, kBlock, 0, stream>>>(prevX + u.offset, X, cnt); }
             else { ScopedKernel k(ctx, "revertUpdate"); k_copy<T><<<grid, kBlock, 0, stream>>>(X, prevX + u.offset, cnt); }
         }
@@ -626,9 +631,13 @@ struct PcgSolver : SolverBase {
             afterReset = false;
             const bool resetNow = ((lIter + 1) % sp.residual_reset_period) == 0;
             // The split residual reset (solver.t:1077-1083) of this iteration: delta += alpha p, then r = b - (J^T J + CtC) delta afresh.
+            // After the last iteration only delta survives (r, z, the beta numerator and -- unless someone listens for the message -- Q are dead), so the
+            // reference's computeAdelta and second half are not run then.
+            const bool lastAndSilent = lIter + 1 >= sp.lIterations && verbosity == 0;
             auto resetKernels = [&](T* deltaOut) {
                 { ScopedKernel k(ctx, "PCGStep2_1stHalf");
                   k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, deltaOut, p, nPacks, nullptr, prev[0].partials, prev[0].n, prev[1].partials, prev[1].n); }
+                if (lastAndSilent) return;
                 E->applyJTJ(deltaOut, Adelta, CtC, nullptr, ctx);             // computeAdelta
                 { ScopedKernel k(ctx, "PCGStep2_2ndHalf");
                   k_step2SecondHalf<T><<<streamGrid, kBlock, 0, stream>>>(deltaOut, r, Adelta, b, preArg, z, nPacks, redB.partials, redQR.partials); }
@@ -653,7 +662,7 @@ struct PcgSolver : SolverBase {
                 deltaOwed = false;
                 // fetchQ (solver.t:1098).  After the last iteration its only effect is the message below: the loop ends either way, so the blocking
                 // read (one drain of the stream per outer iteration when residual_reset_period == lIterations, the default) happens only when someone is listening.
-                if (lIter + 1 < sp.lIterations || verbosity > 0) {
+                if (!lastAndSilent) {
                     const T Q1 = (T)hostSum(redQR);
                     const T zeta = T(lIter + 1) * (Q1 - Q0) / Q1;
                     if (zeta < q_tolerance) { if (verbosity > 0) printf("zeta=%.18g, breaking at iteration: %d\n", (double)zeta, lIter + 1); return true; }
@@ -756,7 +765,6 @@ struct PcgSolver : SolverBase {
             static const bool fetchQ0 = [] { const char* e = getenv("OPT_AMD_FETCH_Q0"); return e && atoi(e) != 0; }();
             Q0 = fetchQ0 ? (T)hostSum(redQ) : T(0);
         }
-        finalizeTo(redC, scal + aSlot);   // alphaNumerator = sum r.p
 
         // Loop structure: the reference runs Step1, Step2, Step3 per iteration (:1056-1103).  Here Step3 of
         // iteration k is fused into Step1 of iteration k+1 when the energy offers that kernel (it only
@@ -764,6 +772,7 @@ struct PcgSolver : SolverBase {
         bool pendingStep3 = false;
         Reduction bNum;
         const bool single = oneKernel && r2 && (lm ? (oneKernelLM && runSingleKernelLoopLM(preArg, Q0, q_tolerance)) : runSingleKernelLoop(preArg));
+        if (!single) finalizeTo(redC, scal + aSlot);   // alphaNumerator = sum r.p as one device scalar (the single-kernel loops sum the partials in their first launch)
         // Step3 of the previous iteration (when pending) and Step1 of the next one.  None of it touches what survives a q early-out
         // (delta, and p only through the very Step3 the reference also runs before its q test), so in LM it is enqueued BEFORE the
         // host reads q of the current iteration: the blocking fetchQ of solver.t:1098 then overlaps with useful kernels instead of
@@ -795,6 +804,14 @@ struct PcgSolver : SolverBase {
         if (!single && sp.lIterations > 0) stepThreeAndOne();     // Step1 of iteration 0
         for (int lIter = 0; !single && lIter < sp.lIterations; ++lIter) {
             const bool reset = lm && ((lIter + 1) % sp.residual_reset_period) == 0;
+            // After the last iteration only delta survives: r, z, the beta numerator and (unless someone listens for the "breaking" message) Q are dead, so the
+            // last PCGStep2 -- or the last split residual reset -- shrinks to its delta += alpha p.
+            const bool deltaOnly = lIter + 1 >= sp.lIterations && !traceEnabled && !keepReferenceP && (!lm || verbosity == 0);
+            if (deltaOnly) {
+                ScopedKernel k(ctx, "PCGStep2_delta");
+                k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, delta, p, nPacks, scal + aSlot, nullptr, 0, aDen.partials, aDen.n);
+                break;
+            }
             if (reset) {   // solver.t:1077-1083
                 { ScopedKernel k(ctx, "PCGStep2_1stHalf"); k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, delta, p, nPacks, scal + aSlot, nullptr, 0, aDen.partials, aDen.n); }
                 exchangeVector(delta);
@@ -845,9 +862,8 @@ struct PcgSolver : SolverBase {
         if (lm) {   // solver.t:1108-1113, 819-827
             exchangeVector(delta);
             E->evalModelCost(delta, distributed ? redA : redMH, ctx);   // (its own partials buffer: the value is read together with the new cost below)
-            imageOp(1);
-        }
-        imageOp(0);   // PCGLinearUpdate
+            imageOp(3);   // savePreviousUnknowns + PCGLinearUpdate
+        } else imageOp(0);   // PCGLinearUpdate
         exchangeUnknowns();
         E->precompute(ctx);
         // The reference reads the model cost, then updates, then reads the new cost (two blocking copies, solver.t:1108-1117).  Neither value steers
