@@ -1,0 +1,105 @@
+"""GPU parity tests (-m gpu) of the Levenberg-Marquardt inner-loop controls: `residual_reset_period` and `q_tolerance`.
+
+The reference's LM loop (solverGPUGaussNewton.t:1056-1103) ends a PCG iteration either with PCGStep2 or -- every residual_reset_period-th time -- with
+the split residual reset (:1077-1083), and leaves the loop when zeta = k (Q_k - Q_{k-1}) / Q_k drops below q_tolerance (:1093-1102).  The HIP loops move
+the host's part of this off the GPU's critical path: Q arrives as tagged words one launch late, the next launch *or the reset* is enqueued before Q is
+known (and dropped on an early-out: delta is double-buffered), and work whose results die with the loop is not run.  Every combination below is stepped
+side by side with the CPU oracle, which follows the reference's order literally:
+  * reset periods 1, 2, 3, 5, 7 and the default 10 against lIterations 9 / 10 / 12 (reset on the last iteration, mid-loop restarts, none);
+  * q_tolerance at the default, at values that end the loop after a few iterations -- on a reset iteration and next to one -- and at 0 (never);
+  * image_warping float + double (single-kernel LM loop of energy_image_warping.hip), shape_from_shading double (energy_sfs.hip), and
+    poisson_image_editing (no single-kernel LM loop: the generic Step1/Step2 path of solver.hip).
+Costs after every outer step, the trust-region radius and the final unknowns must agree (double 1e-10 / 1e-8 / 1e-9; float 1e-5 on costs).
+"""
+import numpy as np
+import pytest
+
+from opt_amd import api, workloads as wl
+from helpers import device_unknowns, flat_unknowns, hip_solver, oracle_solver, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _side_by_side(oracle_lib, P, nsteps, liters, cost_tol, x_tol, radius_tol, **controls):
+    o = oracle_solver(oracle_lib, P, "LMGPU", nIterations=nsteps, lIterations=liters, **controls)
+    g = hip_solver(P, "LMGPU", nIterations=nsteps, lIterations=liters, **controls)
+    dev = api.to_device(P)
+    Pref = P.clone()
+    o.init(Pref.params); g.init(dev)
+    scale = max(abs(o.cost()), 1e-300)
+    costs = [(o.cost(), g.cost())]
+    while True:
+        a, b = o.step(Pref.params), g.step(dev)
+        assert a == b, (a, b, costs)
+        costs.append((o.cost(), g.cost()))
+        assert abs(g.cost() - o.cost()) <= cost_tol * max(abs(o.cost()), 1e-12 * scale), costs
+        assert abs(g.trust_region_radius() - o.trust_region_radius()) <= radius_tol * o.trust_region_radius(), costs
+        if not a:
+            break
+    if x_tol is not None:
+        assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < x_tol
+    g.close(); o.close()
+    return costs
+
+
+PERIODS = [1, 2, 3, 5, 7, 10]
+QTOLS = [None, 0.0, 0.05, 0.5, 5.0]      # None: the default 1e-4;  0.5 / 5: the loop ends within the first iterations (zeta ~ 1/k early on)
+
+
+@pytest.mark.parametrize("liters", [9, 10, 12])
+@pytest.mark.parametrize("period", PERIODS)
+def test_image_warping_double_reset_periods(oracle_lib, period, liters):
+    P = wl.image_warping(61, 47, double=True, random_state=5, mask_fraction=0.05, perturb=0.4)
+    _side_by_side(oracle_lib, P, 4, liters, 1e-10, 1e-9, 1e-8, residual_reset_period=period)
+
+
+@pytest.mark.parametrize("qtol", QTOLS)
+@pytest.mark.parametrize("period", [1, 2, 3, 10])
+def test_image_warping_double_q_early_out(oracle_lib, period, qtol):
+    P = wl.image_warping(53, 38, double=True, random_state=7, mask_fraction=0.05, perturb=0.4)
+    kw = dict(residual_reset_period=period)
+    if qtol is not None:
+        kw["q_tolerance"] = qtol
+    _side_by_side(oracle_lib, P, 4, 12, 1e-10, 1e-9, 1e-8, **kw)
+
+
+@pytest.mark.parametrize("period,qtol", [(2, None), (3, 0.5), (10, 0.05), (5, 0.0)])
+def test_image_warping_float_controls(oracle_lib, period, qtol):
+    P = wl.image_warping(64, 48, double=False, random_state=9, mask_fraction=0.05, perturb=0.4)
+    kw = dict(residual_reset_period=period)
+    if qtol is not None:
+        kw["q_tolerance"] = qtol
+    _side_by_side(oracle_lib, P, 3, 10, 1e-5, None, 1e-3, **kw)
+
+
+@pytest.mark.parametrize("period,qtol,liters", [(1, None, 6), (2, None, 10), (3, 0.5, 10), (10, None, 10), (10, 0.05, 12), (4, 0.0, 9), (5, 5.0, 10)])
+def test_sfs_double_controls(oracle_lib, period, qtol, liters):
+    P = wl.shape_from_shading(72, 56, double=True, seed=2)
+    kw = dict(residual_reset_period=period)
+    if qtol is not None:
+        kw["q_tolerance"] = qtol
+    _side_by_side(oracle_lib, P, 4, liters, 1e-10, 1e-9, 1e-8, **kw)
+
+
+@pytest.mark.parametrize("period,qtol,liters", [(2, None, 10), (10, None, 10), (3, 0.5, 9), (10, 0.0, 12)])
+def test_poisson_generic_lm_loop_controls(oracle_lib, period, qtol, liters):
+    P = wl.poisson_image_editing(40, 36, seed=4)
+    kw = dict(residual_reset_period=period)
+    if qtol is not None:
+        kw["q_tolerance"] = qtol
+    _side_by_side(oracle_lib, P, 3, liters, 1e-5, None, 1e-3, **kw)
+
+
+def test_verbose_run_takes_the_listening_path(oracle_lib, capfd):
+    """verbosity > 0 keeps the reference's last fetchQ (its only effect is the "breaking at iteration" message): same costs as the silent run."""
+    P = wl.image_warping(48, 40, double=True, random_state=3, perturb=0.3)
+    silent = _side_by_side(oracle_lib, P, 3, 10, 1e-10, 1e-9, 1e-8)
+    g = hip_solver(P, "LMGPU", verbosity=1, nIterations=3, lIterations=10)
+    dev = api.to_device(P)
+    g.init(dev)
+    costs = [g.cost()]
+    while g.step(dev):
+        costs.append(g.cost())
+    costs.append(g.cost())
+    g.close()
+    assert costs[:3] == [c[1] for c in silent][:3]
