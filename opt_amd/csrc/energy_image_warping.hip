@@ -467,6 +467,54 @@ __device__ __forceinline__ IterRaw<T> iw_iterLoad(const IWArgs<T>& A, const Iter
     else { r.dO = ld2<IW_DELTA_NT != 0>((const V2<T>*)K.delta, i); r.dA = ld1<IW_DELTA_NT != 0>(K.delta + 2 * N, i); }     // prefetched with the row (was a load-wait-store inside the row)
     return r;
 }
+// Row addressing of iw_pcgIter2 through buffer descriptors: element (row, x) of an array is  descriptor(base)  +  soffset = row * W * size (+ the offset of
+// the Angle part), one SALU product shared by all arrays of a row  +  voffset = x * size, a per-lane constant of the whole launch.  A load or store then
+// needs no address VALU at all, against a 64-bit multiply-add plus a 64-bit shift-add per array and row with pointers (20 of the kernel's 300 VALU
+// instructions per pixel-row -- and the kernel is VALU-bound on slabs and small images).  Byte offsets are 32-bit: the launcher takes this
+// form only while 3 * W * H * sizeof(V2<T>) / 2 < 2^32.
+#ifndef IW_BUFADDR
+#define IW_BUFADDR 1
+#endif
+typedef unsigned int iw_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned int iw_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t iw_rsrc(const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1 /* 2^32 - 1 bytes */, 0x00020000); }
+__device__ __forceinline__ V2<float> bufLd2(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, const float*) { const iw_u2 w = __builtin_amdgcn_raw_buffer_load_b64(r, (int)v, (int)so, 0); return V2<float>{__uint_as_float(w.x), __uint_as_float(w.y)}; }
+__device__ __forceinline__ V2<double> bufLd2(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, const double*) { const iw_u4 w = __builtin_amdgcn_raw_buffer_load_b128(r, (int)v, (int)so, 0); V2<double> o; __builtin_memcpy(&o, &w, 16); return o; }
+__device__ __forceinline__ float bufLd1(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, const float*) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)v, (int)so, 0)); }
+__device__ __forceinline__ double bufLd1(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, const double*) { const iw_u2 w = __builtin_amdgcn_raw_buffer_load_b64(r, (int)v, (int)so, 0); double o; __builtin_memcpy(&o, &w, 8); return o; }
+__device__ __forceinline__ void bufSt2(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, float x, float y) { __builtin_amdgcn_raw_buffer_store_b64(iw_u2{__float_as_uint(x), __float_as_uint(y)}, r, (int)v, (int)so, 0); }
+__device__ __forceinline__ void bufSt2(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, double x, double y) { const V2<double> o{x, y}; iw_u4 w; __builtin_memcpy(&w, &o, 16); __builtin_amdgcn_raw_buffer_store_b128(w, r, (int)v, (int)so, 0); }
+__device__ __forceinline__ void bufSt1(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, float x) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, (int)v, (int)so, 0); }
+__device__ __forceinline__ void bufSt1(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, double x) { iw_u2 w; __builtin_memcpy(&w, &x, 8); __builtin_amdgcn_raw_buffer_store_b64(w, r, (int)v, (int)so, 0); }
+template <class T>
+struct IterBufs {          // descriptors of the arrays iw_pcgIter2 touches row by row, and the per-lane parts of the offsets
+    __amdgpu_buffer_rsrc_t rOld, pOld, pNew, rNew, delta, deltaOut, angle, flags, mc, pre, ctc, b, ur;
+    unsigned x2, x1, x0;   // x * sizeof(V2<T>), x * sizeof(T), x  (x clamped into the row)
+    unsigned aPart;        // 2 * N * sizeof(T): where the Angle part of a solver vector starts
+};
+// iw_iterLoad for iw_pcgIter2 (no A p, the 4 B angle) in that addressing
+template <class T, bool LATTICE, int PRE, bool LMV>
+__device__ __forceinline__ IterRaw<T> iw_iterLoadBuf(const IWArgs<T>& A, const IterK<T>& K, const IterBufs<T>& B, bool xok, int y) {
+    IterRaw<T> r;
+    r.ok = xok && y >= 0 && y < A.H;
+    const int yc = min(max(y, 0), A.H - 1);
+    const unsigned row = (unsigned)(K.flip ? A.H - 1 - yc : yc) * (unsigned)A.W;      // wave-uniform
+    const unsigned s2 = row * (unsigned)sizeof(V2<T>), s1 = row * (unsigned)sizeof(T), s1a = s1 + B.aPart;
+    const T* tag = nullptr;
+    r.f = __builtin_amdgcn_raw_buffer_load_b8(B.flags, (int)B.x0, (int)row, 0);
+    r.ro = bufLd2(B.rOld, B.x2, s2, tag); r.ra = bufLd1(B.rOld, B.x1, s1a, tag);
+    r.ao = V2<T>{0, 0}; r.aa = 0;
+    r.po = bufLd2(B.pOld, B.x2, s2, tag); r.pa = bufLd1(B.pOld, B.x1, s1a, tag);
+    if (PRE == 3) { r.mo = V2<T>{0, 0}; r.ma = 0; }
+    else if (PRE == 2) { r.mo = bufLd2(B.mc, B.x2, s2, tag); r.ma = 0; }
+    else if (PRE == 1) { r.mo = bufLd2(B.pre, B.x2, s2, tag); r.ma = bufLd1(B.pre, B.x1, s1a, tag); }
+    else { r.mo = V2<T>{1, 1}; r.ma = 1; }
+    if (LMV) { r.co = bufLd2(B.ctc, B.x2, s2, tag); r.ca = bufLd1(B.ctc, B.x1, s1a, tag); } else { r.co = V2<T>{0, 0}; r.ca = 0; }
+    r.cs.x = bufLd1(B.angle, B.x1, s1, tag); r.cs.y = 0;
+    if (LATTICE) r.u = V2<T>{0, 0}; else r.u = bufLd2(B.ur, B.x2, s2, tag);
+    r.dO = V2<T>{0, 0}; r.dA = 0;
+    return r;
+}
 
 #ifndef ITER_MIN_WAVES
 #define ITER_MIN_WAVES 1
@@ -612,7 +660,16 @@ constexpr int kIterBlock2 = ITER2_BLOCK;
 #ifndef ITER2_BLOCK_DOUBLE
 #define ITER2_BLOCK_DOUBLE 256
 #endif
-template <class T, bool LATTICE> struct IterBlk { static constexpr int value = sizeof(T) == 8 ? ITER2_BLOCK_DOUBLE : (LATTICE ? kIterBlock2 : ITER2_BLOCK_GENERAL); };
+// Round 2, after the addresses moved to buffer descriptors and the launch state of the steady-state variants to compile time: the general-UrShape Gauss-Newton
+// kernel with the compact preconditioner (PRE == 2, the path of any non-lattice input) is down to 169-171 VGPRs and fits a 768-thread workgroup with 8-12 B of
+// scratch per lane (60 B in the two start-up launches of a solve): 4096^2 254 -> 234 us, 2048^2 79 -> 67 us per iteration.  Its other variants (full M vector,
+// LM: 200+ VGPRs) stay at 512.
+#ifndef ITER2_BLOCK_GENERAL_GN
+#define ITER2_BLOCK_GENERAL_GN 768
+#endif
+template <class T, bool LATTICE, int PRE = 3, bool LM = false> struct IterBlk {
+    static constexpr int value = sizeof(T) == 8 ? ITER2_BLOCK_DOUBLE : LATTICE ? kIterBlock2 : (PRE == 2 && !LM) ? ITER2_BLOCK_GENERAL_GN : ITER2_BLOCK_GENERAL;
+};
 constexpr int kSpan2 = kWave - 4;
 // VALU matters in this kernel (two stencil evaluations per pixel), so its inner loop avoids selects and moves:
 //  * activity is a 0/1 multiplier (`on`), the fit weight a 0/w_fit^2 multiplier (`fw`): an inactive or non-existent
@@ -679,9 +736,15 @@ constexpr bool kSinCosInline = IW_SINCOS_INLINE != 0;
 #define IW_OWN_CHECK 1      // 0: compile the owned-row tests of the slab mode out (single-GPU A/B of their cost; slabs then need OPT_AMD_SLAB_PERIOD=1)
 #endif
 // LM = true: the Levenberg-Marquardt loop (A = J^T J + diag(CtC), Q sums, restart after a residual reset); see energy.h PcgIterArgs.
-template <class T, bool LATTICE, int PRE, bool FLIP, bool LM = false>
-__global__ __launch_bounds__((IterBlk<T, LATTICE>::value), ITER_MIN_WAVES) void iw_pcgIter2(IWArgs<T> A, IterK<T> K, int rowsPerGroup, int gx, int gy) {
-    constexpr int kBlk = IterBlk<T, LATTICE>::value, kStripW = (kBlk / kWave) * kSpan2;
+// MODE: the launch-to-launch state as a compile-time constant for the steady state of the Gauss-Newton r-free loop, where it only takes two values --
+// 0: read it from K (first launches, LM, r in memory, slabs' A/B switches);  1: rfree == 1, odd launch (delta left alone);  2: rfree == 1, even launch
+// (the two pending delta terms, p_{k-2} from registers).  The kernel is instruction-issue bound (VALU + SALU): every wave-uniform
+// `if` on K.deltaMode / K.rfree / K.first costs scalar compares and a branch per row, and the steady state runs thousands of rows of them.
+template <class T, bool LATTICE, int PRE, bool FLIP, bool LM = false, int MODE = 0>
+__global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAVES) void iw_pcgIter2(IWArgs<T> A, IterK<T> K, int rowsPerGroup, int gx, int gy) {
+    static_assert(MODE == 0 || !LM, "steady-state specialisations are Gauss-Newton only");
+    const int kDeltaMode = MODE == 1 ? 2 : MODE == 2 ? 1 : K.deltaMode, kRfree = MODE ? 1 : K.rfree, kReconP = MODE ? 1 : K.reconP;
+    constexpr int kBlk = IterBlk<T, LATTICE, PRE, LM>::value, kStripW = (kBlk / kWave) * kSpan2;
     __shared__ double scratch[5 * (kBlk / kWave + 1)];
     const long N = (long)A.W * A.H;
     const int bx = blockIdx.x % gx, by = blockIdx.x / gx;
@@ -693,11 +756,23 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE>::value), ITER_MIN_WAVES) void 
     const int yb = lyBegin + by * rowsPerGroup, ye = min(yb + rowsPerGroup, lyEnd);
     // The first five rows are requested before anything else: they do not depend on the scalars of the previous launch, so their latency
     // overlaps the prologue's own memory round trip (the partial sums another kernel just wrote) instead of following it (-1.5 us per launch).
-    const IterRaw<T> raw0 = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb - 2), raw1 = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb - 1);
-    IterRaw<T> rwA = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb), rwB = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb + 1),
-               rwC = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, yb + 2);
+    constexpr bool kBuf = IW_BUFADDR != 0 && kSinCosInline && !kNTL && !kNTS;
+    IterBufs<T> Bf;
+    if (kBuf) {
+        const unsigned xc = (unsigned)min(max(x, 0), A.W - 1);
+        Bf.x2 = xc * (unsigned)sizeof(V2<T>); Bf.x1 = xc * (unsigned)sizeof(T); Bf.x0 = xc; Bf.aPart = (unsigned)(2 * N * (long)sizeof(T));
+        Bf.rOld = iw_rsrc(K.rOld); Bf.pOld = iw_rsrc(K.pOld); Bf.pNew = iw_rsrc(K.pNew); Bf.rNew = iw_rsrc(K.rNew); Bf.delta = iw_rsrc(K.delta); Bf.deltaOut = iw_rsrc(K.deltaOut);
+        Bf.angle = iw_rsrc(A.Angle); Bf.flags = iw_rsrc(A.flags); Bf.mc = iw_rsrc(K.mc); Bf.pre = iw_rsrc(K.pre); Bf.ctc = iw_rsrc(K.CtC); Bf.b = iw_rsrc(K.b); Bf.ur = iw_rsrc(A.UrShape);
+    }
+    auto loadRow = [&](int y) {
+        if constexpr (kBuf) return iw_iterLoadBuf<T, LATTICE, PRE, LM && PRE != 3>(A, K, Bf, xok, y);
+        else return iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, y);
+    };
+    const IterRaw<T> raw0 = loadRow(yb - 2), raw1 = loadRow(yb - 1);
+    IterRaw<T> rwA = loadRow(yb), rwB = loadRow(yb + 1),
+               rwC = loadRow(yb + 2);
     T alpha = 0, beta = 0;
-    const bool first = K.first != 0;
+    const bool first = MODE ? false : K.first != 0;
     const bool restart = LM && K.afterReset != 0;      // r and delta are already those of this iteration (split residual reset)
     if (restart) {
         const double* const ps[2] = {K.betaNum, K.betaDen}; const int ns[2] = {K.nBetaNum, K.nBetaDen}; double o2[2];
@@ -716,17 +791,17 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE>::value), ITER_MIN_WAVES) void 
         beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
     }
     if (K.alphaOut && blockIdx.x == 0 && threadIdx.x == 0) { K.alphaOut[0] = alpha; K.alphaOut[2] = beta; }
-    const T alpha2 = (K.deltaMode == 1) ? K.alphaIn[0] : T(0);
+    const T alpha2 = (kDeltaMode == 1) ? K.alphaIn[0] : T(0);
     // The deferred term alpha_{k-2} p_{k-2} of an even launch: p_{k-1} = z_{k-1} + beta_{k-2} p_{k-2} was formed by the previous launch from values this
     // launch has in registers again (p_{k-1} as loaded, z_{k-1} = M r_{k-1}: the same product of the same operands), so
     // p_{k-2} = (p_{k-1} - z_{k-1}) / beta_{k-2} costs three flops per scalar instead of a 12 B/px read of the p buffer about to be overwritten
     // (93 -> 81 B/px on even launches).  The subtraction only undoes the one rounding of that fma, an error of the size of the update's own rounding.
     // beta_{k-2} == 0 (the reference's guard, or an exactly converged solve) leaves nothing to divide by: that launch reads p_{k-2} from memory.
-    const bool reconR = !LM && K.rfree == 1;
+    const bool reconR = !LM && kRfree == 1;
     const T betaOlder = reconR ? K.alphaIn[2] : T(0);      // the beta of the previous launch: p_{k-1} = M r_{k-1} + betaOlder p_{k-2}
     // (This rebuilt term is what runs with OPT_AMD_RFREE=0.  In the r-free loop p_{k-2} is an input of the launch anyway: the lattice kernel keeps it in three
     // registers from its load, the general kernel -- no registers to spare -- reads it again; both exact.)
-    const T beta2 = (K.deltaMode == 1 && K.reconP && (!K.rfree || K.reconP == 2)) ? K.alphaIn[2] : T(0);      // reconP == 2: A/B switch (OPT_AMD_RECON_P=2)
+    const T beta2 = (kDeltaMode == 1 && kReconP && (!kRfree || kReconP == 2)) ? K.alphaIn[2] : T(0);      // reconP == 2: A/B switch (OPT_AMD_RECON_P=2)
     const bool recon = beta2 != T(0);
     const T invBeta2 = recon ? T(1) / beta2 : T(0);
     auto phys = [&](int y) { return FLIP ? A.H - 1 - y : y; };   // mirrored row coordinates, see iw_pcgIter (K.flip == FLIP)
@@ -778,7 +853,7 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE>::value), ITER_MIN_WAVES) void 
             o.mx = w.mo.x; o.my = (PRE == 2) ? w.mo.x : w.mo.y; o.ma = (PRE == 2) ? w.mo.y : w.ma;
             if (!LM && PRE != 0 && reconR) { ix = T(1) / o.mx; iy = T(1) / o.my; ia = T(1) / o.ma; }
         }
-        if (!LM && LATTICE && K.rfree) { o.p2x = w.ro.x; o.p2y = w.ro.y; o.p2a = w.ra; }      // (the general-UrShape kernel has no registers to spare: it reads p_{k-2} again)
+        if (!LM && LATTICE && kRfree) { o.p2x = w.ro.x; o.p2y = w.ro.y; o.p2a = w.ra; }      // (the general-UrShape kernel has no registers to spare: it reads p_{k-2} again)
         if (!LM && reconR) {      // r_{k-1} = (p_{k-1} - beta p_{k-2}) / M: w.ro / w.ra were loaded from the p_{k-2} buffer
             o.rx = (o.q.ox - betaOlder * w.ro.x) * ix; o.ry = (o.q.oy - betaOlder * w.ro.y) * iy; o.ra = (o.q.a - betaOlder * w.ra) * ia;
         }
@@ -811,26 +886,40 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE>::value), ITER_MIN_WAVES) void 
         if (live && writer && y + 1 >= yb && y + 1 < ye) {
             const int yp = phys(y + 1);
             const long i = (long)yp * A.W + x;
+            const unsigned rowE = (unsigned)yp * (unsigned)A.W, s2 = rowE * (unsigned)sizeof(V2<T>), s1a = rowE * (unsigned)sizeof(T) + Bf.aPart;      // kBuf: wave-uniform row offsets
+            const T* const tag = nullptr;
             const bool own = !IW_OWN_CHECK || (yp >= K.ownBegin && yp < K.ownEnd);
-            if (own && !keepR && K.deltaMode != 2) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462), preceded by the deferred term of launch k-1
-                V2<T> d = dO[i]; T da = dA[i];
-                if (K.deltaMode == 1) {
-                    if (!LM && LATTICE && K.rfree == 1 && K.reconP != 2) { d.x += alpha2 * oB.p2x; d.y += alpha2 * oB.p2y; da += alpha2 * oB.p2a; }      // p_{k-2} kept from the load: exact
+            if (own && !keepR && kDeltaMode != 2) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462), preceded by the deferred term of launch k-1
+                V2<T> d; T da;
+                if (kBuf) { d = bufLd2(Bf.delta, Bf.x2, s2, tag); da = bufLd1(Bf.delta, Bf.x1, s1a, tag); } else { d = dO[i]; da = dA[i]; }
+                if (kDeltaMode == 1) {
+                    if (!LM && LATTICE && kRfree == 1 && kReconP != 2) { d.x += alpha2 * oB.p2x; d.y += alpha2 * oB.p2y; da += alpha2 * oB.p2a; }      // p_{k-2} kept from the load: exact
                     else if (recon) { d.x += alpha2 * ((oB.q.ox - oB.mx * oB.rx) * invBeta2); d.y += alpha2 * ((oB.q.oy - oB.my * oB.ry) * invBeta2); da += alpha2 * ((oB.q.a - oB.ma * oB.ra) * invBeta2); }
                     else {      // p_{k-2} from memory: the p buffer about to be overwritten, or (r-free ring) the buffer read through rOld
-                        const V2<T>* qO = (!LM && K.rfree) ? (const V2<T>*)K.rOld : (const V2<T>*)pO; const T* qA = (!LM && K.rfree) ? K.rOld + 2 * N : (const T*)pA;
-                        const V2<T> q = qO[i]; const T qa = qA[i]; d.x += alpha2 * q.x; d.y += alpha2 * q.y; da += alpha2 * qa;
+                        V2<T> q; T qa;
+                        if (kBuf) { const __amdgpu_buffer_rsrc_t qb = (!LM && kRfree) ? Bf.rOld : Bf.pNew; q = bufLd2(qb, Bf.x2, s2, tag); qa = bufLd1(qb, Bf.x1, s1a, tag); }
+                        else {
+                            const V2<T>* qO = (!LM && kRfree) ? (const V2<T>*)K.rOld : (const V2<T>*)pO; const T* qA = (!LM && kRfree) ? K.rOld + 2 * N : (const T*)pA;
+                            q = qO[i]; qa = qA[i];
+                        }
+                        d.x += alpha2 * q.x; d.y += alpha2 * q.y; da += alpha2 * qa;
                     }
                 }
                 d.x += alpha * oB.q.ox; d.y += alpha * oB.q.oy; da += alpha * oB.q.a;
-                st2<kNTS>(dOut, i, d.x, d.y); st1<kNTS>(dAout, i, da);
+                if (kBuf) { bufSt2(Bf.deltaOut, Bf.x2, s2, d.x, d.y); bufSt1(Bf.deltaOut, Bf.x1, s1a, da); } else { st2<kNTS>(dOut, i, d.x, d.y); st1<kNTS>(dAout, i, da); }
                 if (LM) {   // Q = 1/2 sum delta . (r + b) with the updated delta and r (solver.t:483-485)
-                    const V2<T> bo = ((const V2<T>*)K.b)[i]; const T ba = K.b[2 * N + i];
+                    V2<T> bo; T ba;
+                    if (kBuf) { bo = bufLd2(Bf.b, Bf.x2, s2, tag); ba = bufLd1(Bf.b, Bf.x1, s1a, tag); } else { bo = ((const V2<T>*)K.b)[i]; ba = K.b[2 * N + i]; }
                     accQ += (double)(T(0.5) * (d.x * (rx + bo.x))) + (double)(T(0.5) * (d.y * (ry + bo.y))) + (double)(T(0.5) * (da * (ra + ba)));
                 }
             }
-            if (LM || !K.rfree) { st2<kNTS>(rO, i, rx, ry); st1<kNTS>(rA, i, ra); }
-            st2<kNTS>(pO, i, nC.q.ox, nC.q.oy); st1<kNTS>(pA, i, nC.q.a);
+            if (kBuf) {
+                if (LM || !kRfree) { bufSt2(Bf.rNew, Bf.x2, s2, rx, ry); bufSt1(Bf.rNew, Bf.x1, s1a, ra); }
+                bufSt2(Bf.pNew, Bf.x2, s2, nC.q.ox, nC.q.oy); bufSt1(Bf.pNew, Bf.x1, s1a, nC.q.a);
+            } else {
+                if (LM || !kRfree) { st2<kNTS>(rO, i, rx, ry); st1<kNTS>(rA, i, ra); }
+                st2<kNTS>(pO, i, nC.q.ox, nC.q.oy); st1<kNTS>(pA, i, nC.q.a);
+            }
             if (own) accNum += (double)(nC.zx * rx + nC.zy * ry + nC.za * ra);
         }
         Q<T> l2 = nB.lf, r2 = nB.rt;
@@ -851,9 +940,9 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE>::value), ITER_MIN_WAVES) void 
     // trips y = yb-2 .. ye-1 (the first two only build p_k(yb-1), p_k(yb)); three per pass, no branch around a load
     for (int y = yb - 2; y < ye; y += 3) {
         if (IW_ROW_SYNC) __syncthreads();
-        { const IterRaw<T> w = rwA; rwA = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, y + 5); trip(y, w, o0, o1, o2, n0, n1, n2, true); }
-        { const IterRaw<T> w = rwB; rwB = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, y + 6); trip(y + 1, w, o1, o2, o0, n1, n2, n0, y + 1 < ye); }
-        { const IterRaw<T> w = rwC; rwC = iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, y + 7); trip(y + 2, w, o2, o0, o1, n2, n0, n1, y + 2 < ye); }
+        { const IterRaw<T> w = rwA; rwA = loadRow(y + 5); trip(y, w, o0, o1, o2, n0, n1, n2, true); }
+        { const IterRaw<T> w = rwB; rwB = loadRow(y + 6); trip(y + 1, w, o1, o2, o0, n1, n2, n0, y + 1 < ye); }
+        { const IterRaw<T> w = rwC; rwC = loadRow(y + 7); trip(y + 2, w, o2, o0, o1, n2, n0, n1, y + 2 < ye); }
     }
     double v[5] = {accDen, accNum, acc2, acc3, accQ};
     blockReduceSumN<5>(v, scratch);
@@ -974,6 +1063,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_RECON_P")) reconstructP = atoi(e);
         if (const char* e = getenv("OPT_AMD_RFREE")) rFree = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ITER_ROWS")) forceRows = std::max(0, atoi(e));
+        if (const char* e = getenv("OPT_AMD_ITER_STEADY")) steadyVariants = atoi(e) != 0;
         HIP_CHECK(hipMalloc((void**)&dNotLattice, sizeof(int)));
     }
     ~ImageWarpingOps() override { for (T* b : ring) if (b) (void)hipFree(b); (void)hipFree(A.flags); (void)hipFree(A.cs); if (mc) (void)hipFree(mc); if (alphaSlots) (void)hipFree(alphaSlots); (void)hipFree(dNotLattice); }
@@ -1070,10 +1160,21 @@ struct ImageWarpingOps : EnergyOps<T> {
         return !noAp ? (const void*)iw_pcgIter<T, LAT, PRE> : flip ? (const void*)iw_pcgIter2<T, LAT, PRE, true> : (const void*)iw_pcgIter2<T, LAT, PRE, false>;
     }
     static const void* iterKernel(bool lat, int pre, bool noAp, bool flip) {
-        if (pre == 3) return flip ? (const void*)iw_pcgIter2<T, true, 3, true> : (const void*)iw_pcgIter2<T, true, 3, false>;
+        if (pre == 3) return flip ? (const void*)iw_pcgIter2<T, true, 3, true> : (const void*)iw_pcgIter2<T, true, 3, false>;      // (steady-state variants: steadyKernel)
         return lat ? (pre == 2 ? iterFn<true, 2>(noAp, flip) : pre == 1 ? iterFn<true, 1>(noAp, flip) : iterFn<true, 0>(noAp, flip))
                    : (pre == 2 ? iterFn<false, 2>(noAp, flip) : pre == 1 ? iterFn<false, 1>(noAp, flip) : iterFn<false, 0>(noAp, flip));
     }
+    // iw_pcgIter2<.., MODE>: the r-free steady state with the launch state compiled in (mode 1: odd launch, 2: even launch)
+    template <bool LAT, int PRE> static const void* steadyFn(bool flip, int mode) {
+        if (mode == 1) return flip ? (const void*)iw_pcgIter2<T, LAT, PRE, true, false, 1> : (const void*)iw_pcgIter2<T, LAT, PRE, false, false, 1>;
+        return flip ? (const void*)iw_pcgIter2<T, LAT, PRE, true, false, 2> : (const void*)iw_pcgIter2<T, LAT, PRE, false, false, 2>;
+    }
+    static const void* steadyKernel(bool lat, int pre, bool flip, int mode) {      // the two paths the benchmark line reports: unit lattice (flag-byte M) and general UrShape (compact M)
+        if (lat && pre == 3) return steadyFn<true, 3>(flip, mode);
+        if (!lat && pre == 2) return steadyFn<false, 2>(flip, mode);
+        return nullptr;
+    }
+    bool steadyVariants = true;      // OPT_AMD_ITER_STEADY=0: always the kernel that reads the launch state from its arguments (A/B switch)
     static const void* lmKernel(bool lat, bool tables, bool flip) {
         if (lat && tables) return flip ? (const void*)iw_pcgIter2<T, true, 3, true, true> : (const void*)iw_pcgIter2<T, true, 3, false, true>;
         return lat ? (flip ? (const void*)iw_pcgIter2<T, true, 1, true, true> : (const void*)iw_pcgIter2<T, true, 1, false, true>)
@@ -1085,6 +1186,9 @@ struct ImageWarpingOps : EnergyOps<T> {
     T* mc = nullptr; int* dNotLattice = nullptr; bool lattice = false, useLattice = true, useCompactM = true;
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
         const bool noAp = recomputeAp && (!this->slab.active || this->slab.ghost >= 2);      // iw_pcgIter2: Ap recomputed instead of stored
+        // iw_pcgIter2 addresses its arrays through buffer descriptors with 32-bit byte offsets (IW_BUFADDR): a solver vector of 4 GiB or more (float: beyond
+        // 18900^2 pixels) takes the three-kernel loop instead
+        if (IW_BUFADDR && noAp && (unsigned long long)A.W * A.H * 3ull * sizeof(T) >= (1ull << 32)) return false;
         const bool lmLoop = a.CtC != nullptr;
         if (lmLoop && (!noAp || !a.pre || this->slab.active)) return false;      // LM: only the A p-free kernel has the variant (single GPU)
         this->iterStateExchange = noAp;     // slab mode: r and p ghost rows come from the neighbours after a launch (iw_pcgIter: Ap before it)
@@ -1106,7 +1210,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         const int pre = !a.pre ? 0 : (noAp && lattice && flagPreconditioner) ? 3 : lmLoop ? 1 : useCompactM ? 2 : 1;
         const int L = lmLoop ? (lattice ? 14 : 13) : pre == 3 ? 12 : (noAp ? 6 : 0) + (lattice ? 3 : 0) + pre;
         if (a.first) iterFlip = 0;      // every linear solve starts top-down, so a solve is reproducible whatever ran before it
-        const int blk = !noAp ? kIterBlock : sizeof(T) == 8 ? ITER2_BLOCK_DOUBLE : lattice ? kIterBlock2 : ITER2_BLOCK_GENERAL;      // IterBlk<T, LATTICE> of the kernel picked below
+        const int blk = !noAp ? kIterBlock : sizeof(T) == 8 ? ITER2_BLOCK_DOUBLE : lattice ? kIterBlock2 : (pre == 2 && !lmLoop) ? ITER2_BLOCK_GENERAL_GN : ITER2_BLOCK_GENERAL;      // IterBlk<T, LATTICE, PRE, LM> of the kernel picked below
         const void* fn = lmLoop ? lmKernel(lattice, pre == 3, iterFlip != 0) : iterKernel(lattice, pre, noAp, iterFlip != 0);
         if (occIter[L] == 0) {
             HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occIter[L], fn, blk, 0));
@@ -1153,7 +1257,10 @@ struct ImageWarpingOps : EnergyOps<T> {
             ScopedKernel k(ctx, "PCGIteration");
             int rpg = rowsPerGroup, gxa = gx, gya = gy;
             void* kargs[] = {(void*)&Ax, (void*)&K, (void*)&rpg, (void*)&gxa, (void*)&gya};
-            HIP_CHECK(hipLaunchKernel(fn, dim3(gx * gy), dim3(blk), kargs, 0, ctx.stream));
+            const void* fnL = fn;      // same workgroup size and grid; the steady-state variants only drop the tests of the launch state
+            if (steadyVariants && !lmLoop && noAp && rfreeFlag == 1 && !a.first && reconstructP != 2 && (deltaMode == 1 || deltaMode == 2))
+                if (const void* f = steadyKernel(lattice, pre, iterFlip != 0, deltaMode == 2 ? 1 : 2)) fnL = f;
+            HIP_CHECK(hipLaunchKernel(fnL, dim3(gx * gy), dim3(blk), kargs, 0, ctx.stream));
         }
         if (alternateSweep) iterFlip ^= 1;
         ++iterIndex;
