@@ -475,6 +475,9 @@ __device__ __forceinline__ IterRaw<T> iw_iterLoad(const IWArgs<T>& A, const Iter
 #ifndef IW_BUFADDR
 #define IW_BUFADDR 1
 #endif
+#ifndef IW_REGCOPY
+#define IW_REGCOPY 1      // see regCopy
+#endif
 typedef unsigned int iw_u2 __attribute__((ext_vector_type(2)));
 typedef unsigned int iw_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t iw_rsrc(const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1 /* 2^32 - 1 bytes */, 0x00020000); }
@@ -743,6 +746,9 @@ constexpr bool kSinCosInline = IW_SINCOS_INLINE != 0;
 template <class T, bool LATTICE, int PRE, bool FLIP, bool LM = false, int MODE = 0>
 __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAVES) void iw_pcgIter2(IWArgs<T> A, IterK<T> K, int rowsPerGroup, int gx, int gy) {
     static_assert(MODE == 0 || !LM, "steady-state specialisations are Gauss-Newton only");
+    // (Measured and dropped: modes that read (cos a, sin a) from the 8 B/px table instead of the 4 B/px angle + inline sincos -- 206 instead of 235 VALU
+    // instructions per row -- run at exactly the same rate up to 4096x1024 / 2048^2 and 6 % slower at 4096^2: the kernel follows its memory skeleton at
+    // every size, profiles/r02j_issue_bound.md.)
     const int kDeltaMode = MODE == 1 ? 2 : MODE == 2 ? 1 : K.deltaMode, kRfree = MODE ? 1 : K.rfree, kReconP = MODE ? 1 : K.reconP;
     constexpr int kBlk = IterBlk<T, LATTICE, PRE, LM>::value, kStripW = (kBlk / kWave) * kSpan2;
     __shared__ double scratch[5 * (kBlk / kWave + 1)];
@@ -834,7 +840,17 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAV
         __syncthreads();
     }
 
-    auto makeOld = [&](const IterRaw<T>& w, OldRow<T>& o) {
+    auto makeOld = [&](const IterRaw<T>& wRaw, OldRow<T>& o) {
+        // The fields that enter the row window unchanged go through a real register move (regCopy above: round 1 found this for cos/sin, U and M in the older
+        // kernels; in the r-free kernel it is p_{k-1}, p_{k-2} and the flag byte that pass through).  Otherwise the window field *is* the load's destination
+        // register, the next request for the buffer needs another one, and the compiler restores the names with copies at the back-edge -- copies of registers
+        // whose loads were issued a moment ago: `s_waitcnt vmcnt(0)` once per pass, the whole prefetch drained every third row.
+        IterRaw<T> w = wRaw;
+        if (IW_REGCOPY) {
+            w.po.x = regCopy(wRaw.po.x); w.po.y = regCopy(wRaw.po.y); w.pa = regCopy(wRaw.pa);
+            w.ro.x = regCopy(wRaw.ro.x); w.ro.y = regCopy(wRaw.ro.y); w.ra = regCopy(wRaw.ra);
+            w.f = regCopy(wRaw.f);
+        }
         o.q.ox = w.po.x; o.q.oy = w.po.y; o.q.a = w.pa;
         if (kSinCosInline) { T sn, cn; sincosT(w.cs.x, &sn, &cn); o.q.c = cn; o.q.s = sn; }      // the same sincos as iw_cossin: same values
         else { o.q.c = w.cs.x; o.q.s = w.cs.y; }
@@ -868,9 +884,25 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAV
     };
     // One trip: the freshly loaded row y+2 -> Ap_{k-1}(y+1), r_k, z_k, p_k (y+1) -> Ap_k(y).
     // oA, oB = p_{k-1} rows y, y+1 (oC receives y+2);  nA, nB = p_k rows y-1, y (nC receives y+1)
-    auto trip = [&](int y, const IterRaw<T>& raw, const OldRow<T>& oA, const OldRow<T>& oB, OldRow<T>& oC,
-                    const NewRow<T>& nA, const NewRow<T>& nB, NewRow<T>& nC, bool live) {
-        makeOld(raw, oC);
+    // The delta of the row a trip updates (y + 1) is requested one trip ahead, before that trip's prefetch of a raw row: by the time it is used a whole trip
+    // has passed and the wait leaves the younger requests in flight, where a request at the point of use is the newest one and its wait (vmcnt(0)) drains
+    // the whole queue once per row.  Every launch of the LM loop and the even launches of the Gauss-Newton steady state (MODE 2) update delta in every
+    // trip and take this form (three named delta buffers rotating with the trips, like the raw rows); the others read it where they use it.
+    constexpr bool kDeltaEarly = kBuf && (MODE == 2 || LM);
+    struct DeltaPre { V2<T> o; T a; };
+    auto loadDelta = [&](int y1) {
+        DeltaPre d{V2<T>{0, 0}, 0};
+        if constexpr (kDeltaEarly) {
+            const int yc = min(max(y1, 0), A.H - 1);
+            const unsigned rowE = (unsigned)(FLIP ? A.H - 1 - yc : yc) * (unsigned)A.W;
+            const T* const tag = nullptr;
+            d.o = bufLd2(Bf.delta, Bf.x2, rowE * (unsigned)sizeof(V2<T>), tag); d.a = bufLd1(Bf.delta, Bf.x1, rowE * (unsigned)sizeof(T) + Bf.aPart, tag);
+            __builtin_amdgcn_sched_barrier(0);      // a side effect as far as code motion is concerned: the two requests stay here instead of being sunk into the branch that uses them
+        }
+        return d;
+    };
+    auto trip = [&](int y, const OldRow<T>& oA, const OldRow<T>& oB, const OldRow<T>& oC,
+                    const NewRow<T>& nA, const NewRow<T>& nB, NewRow<T>& nC, bool live, const DeltaPre& dPre) {
         nC.q = oB.q;
         dppShiftConst<true, LATTICE>(oB.q, nC.lf); dppShiftConst<false, LATTICE>(oB.q, nC.rt);
         Q<T> lf = nC.lf, rt = nC.rt;
@@ -891,7 +923,8 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAV
             const bool own = !IW_OWN_CHECK || (yp >= K.ownBegin && yp < K.ownEnd);
             if (own && !keepR && kDeltaMode != 2) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462), preceded by the deferred term of launch k-1
                 V2<T> d; T da;
-                if (kBuf) { d = bufLd2(Bf.delta, Bf.x2, s2, tag); da = bufLd1(Bf.delta, Bf.x1, s1a, tag); } else { d = dO[i]; da = dA[i]; }
+                if (kDeltaEarly) { d = dPre.o; da = dPre.a; }
+                else if (kBuf) { d = bufLd2(Bf.delta, Bf.x2, s2, tag); da = bufLd1(Bf.delta, Bf.x1, s1a, tag); } else { d = dO[i]; da = dA[i]; }
                 if (kDeltaMode == 1) {
                     if (!LM && LATTICE && kRfree == 1 && kReconP != 2) { d.x += alpha2 * oB.p2x; d.y += alpha2 * oB.p2y; da += alpha2 * oB.p2a; }      // p_{k-2} kept from the load: exact
                     else if (recon) { d.x += alpha2 * ((oB.q.ox - oB.mx * oB.rx) * invBeta2); d.y += alpha2 * ((oB.q.oy - oB.my * oB.ry) * invBeta2); da += alpha2 * ((oB.q.a - oB.ma * oB.ra) * invBeta2); }
@@ -937,12 +970,14 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAV
     NewRow<T> n0{}, n1{}, n2{};
     makeOld(raw0, o0);
     makeOld(raw1, o1);
+    DeltaPre dlA = loadDelta(yb - 1), dlB = dlA, dlC = dlA;      // (trip yb - 2 updates no row; its delta is a dummy)
     // trips y = yb-2 .. ye-1 (the first two only build p_k(yb-1), p_k(yb)); three per pass, no branch around a load
     for (int y = yb - 2; y < ye; y += 3) {
         if (IW_ROW_SYNC) __syncthreads();
-        { const IterRaw<T> w = rwA; rwA = loadRow(y + 5); trip(y, w, o0, o1, o2, n0, n1, n2, true); }
-        { const IterRaw<T> w = rwB; rwB = loadRow(y + 6); trip(y + 1, w, o1, o2, o0, n1, n2, n0, y + 1 < ye); }
-        { const IterRaw<T> w = rwC; rwC = loadRow(y + 7); trip(y + 2, w, o2, o0, o1, n2, n0, n1, y + 2 < ye); }
+        // a raw row is consumed into the row window before its buffer is requested again; the request still precedes the trip's arithmetic
+        { makeOld(rwA, o2); dlB = loadDelta(y + 2); rwA = loadRow(y + 5); trip(y, o0, o1, o2, n0, n1, n2, true, dlA); }
+        { makeOld(rwB, o0); dlC = loadDelta(y + 3); rwB = loadRow(y + 6); trip(y + 1, o1, o2, o0, n1, n2, n0, y + 1 < ye, dlB); }
+        { makeOld(rwC, o1); dlA = loadDelta(y + 4); rwC = loadRow(y + 7); trip(y + 2, o2, o0, o1, n2, n0, n1, y + 2 < ye, dlC); }
     }
     double v[5] = {accDen, accNum, acc2, acc3, accQ};
     blockReduceSumN<5>(v, scratch);

@@ -6,7 +6,7 @@ for e in "$@"; do
 env $e python - <<PY
 import time, torch
 from opt_amd import api, workloads as wl
-for (W,H) in [(4096,512),(4096,1024),(2048,2048),(4096,4096)]:
+for (W,H) in [(4096,512),(4096,1024),(2048,2048),(4096,2048),(4096,4096)]:
     P = wl.image_warping(W,H); dev = api.to_device(P)
     s = api.Solver(api.energy_file("image_warping"), "gaussNewtonGPU", (W,H))
     s.set_parameter("nIterations", 4); s.set_parameter("lIterations", 400)

@@ -13,7 +13,10 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 typedef float F2 __attribute__((ext_vector_type(2)));
 typedef float F4 __attribute__((ext_vector_type(4)));
-constexpr int W = 4096, H = 4096;
+#ifndef H_ROWS
+#define H_ROWS 4096
+#endif
+constexpr int W = 4096, H = H_ROWS;      // -DH_ROWS=528: a 1/8 slab of 4096^2 (+ ghost rows)
 constexpr long N = (long)W * H;
 
 struct Bufs { const float* rIn; const float* pIn; float* rOut; float* pOut; float* delta; const float* angle; const uint8_t* flags; };
