@@ -20,6 +20,9 @@ The same JSON line carries
                  `frac` = achieved / 8 TB/s: a physical fraction.  `traffic` = HBM bytes per launch measured with rocprofv3 PMC passes of
                  THIS kernel source (profiles/*_traffic.json carries the source hash; a stale file is ignored), `hbm_frac` = traffic / time / peak.
                  `algorithmic_equiv` keeps SURVEY.md 8(d)'s scale: the reference algorithm's 180 B/pixel (three kernels) over the same time.
+                 N > 1: after the timed steps the same job runs two more steps with per-kernel hipEvents switched on (OptAmd_PlanSetTiming); rank 0 reports
+                 its own slab's kernel (model bytes of its rows / its launch time) and `per_iteration_ms`: the difference is the communicator (all-reduce
+                 every iteration, halo exchange every 7th) plus launch gaps -- on a real multi-GPU box that is the xGMI cost per iteration.
   cpu_baseline : the CPU oracle (a port, not the reference) timed on a bounded sample on the host cores (rank 0, N = 1 only).
   parity       : cost after the first step next to the frozen oracle value for this workload (tests/golden/bench_costs.json).
 """
@@ -191,7 +194,8 @@ def main():
         P = wl.image_warping(W, H)
         dev = api.to_device(P)
         solver = api.Solver(api.energy_file("image_warping"), "gaussNewtonGPU", (W, H))
-    solver.set_parameter("nIterations", total_steps)
+    extra_steps = 2 if (distributed and not args.no_extras) else 0      # the roofline leg of a multi-GPU job runs on the same plan, after the timed steps
+    solver.set_parameter("nIterations", total_steps + extra_steps)
     solver.set_parameter("lIterations", args.liters)
 
     def sync():
@@ -236,6 +240,29 @@ def main():
     # ---- roofline leg: per-kernel hipEvent timing on the solver's stream, and the general-UrShape path beside it ----------
     roofline, general = None, None
     sha = kernel_src_sha16()
+    if distributed and extra_steps:
+        # N > 1: the same job goes on for two more steps with per-kernel hipEvents switched on (OptAmd_PlanSetTiming); every rank steps (the all-reduces are
+        # collective), rank 0 reports its own slab.  The communicator's kernels (mail-box all-reduce, halo push / pull) are launched by libOptComm and are not in
+        # the table: they are what separates the slab's kernel time from ms_per_step / lIterations.
+        solver.set_timing(True)
+        for _ in range(extra_steps):
+            solver.step(dev)
+        sync()
+        kt = solver.kernel_timings()
+        if rank == 0 and "PCGIteration" in kt:
+            cnt, tot = kt["PCGIteration"]
+            avg_s = tot / cnt * 1e-3
+            rows = job.layout.rows
+            model = MODEL_BYTES_PER_PIXEL["lattice"]
+            achieved = model * W * rows / avg_s / 1e9
+            roofline = {"bound": "hbm", "kernel": "PCGIteration = iw_pcgIter2 on this rank's slab (PCGStep1+2+3 in one launch)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None, "hbm_achieved": None, "hbm_frac": None,
+                        "avg_kernel_ms": avg_s * 1e3, "launches": cnt, "model_bytes_per_pixel": model, "model_bytes_per_launch": model * W * rows,
+                        "slab_rows": rows, "ghost_rows": job.layout.ghost,
+                        "per_iteration_ms": dt / args.steps / args.liters * 1e3,
+                        "note": "rank 0's slab; achieved = the kernel's byte model over its rows / its average launch time; per_iteration_ms - avg_kernel_ms = communicator "
+                                "kernels (all-reduce every iteration, halo exchange every ghost - 1 iterations) + launch gaps",
+                        "kernel_avg_ms": {k: v[1] / v[0] for k, v in kt.items()}}
     if not distributed and not args.no_extras:
         solver.close()
         del dev

@@ -70,6 +70,11 @@ double OptAmd_PlanTrustRegionRadius(Opt_Plan* plan);
 /* hipEvent timing of one kernel name since the last Opt_ProblemInit (requires
  * collectPerKernelTimingInfo).  Returns 0 if the name was never launched. */
 int OptAmd_PlanKernelTiming(Opt_Plan* plan, const char* kernel, long* count, double* total_ms);
+/* Switch the per-kernel hipEvent timing of a plan on or off between steps (what
+ * Opt_InitializationParameters.collectPerKernelTimingInfo fixes at plan time; the reference has no such call).
+ * The totals restart from zero.  bench.py times its steps without the events and then turns them on for the
+ * roofline leg of the same multi-GPU job. */
+void OptAmd_PlanSetTiming(Opt_Plan* plan, int enable);
 /* Number of distinct kernel names timed, and the i-th name. */
 int OptAmd_PlanKernelCount(Opt_Plan* plan);
 const char* OptAmd_PlanKernelName(Opt_Plan* plan, int i);

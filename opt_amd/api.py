@@ -22,7 +22,7 @@ OPT_SYMBOLS = ["Opt_NewState", "Opt_ProblemDefine", "Opt_ProblemDelete", "Opt_Pr
                "Opt_SetSolverParameter", "Opt_ProblemSolve", "Opt_ProblemInit", "Opt_ProblemStep", "Opt_ProblemCurrentCost"]
 OPTAMD_SYMBOLS = ["OptAmd_Version", "OptAmd_EnergyCount", "OptAmd_EnergyName", "OptAmd_PlanNumUnknownScalars", "OptAmd_PlanVector",
                   "OptAmd_EvalJTF", "OptAmd_ApplyJTJ", "OptAmd_EvalCost", "OptAmd_PlanEnableTrace", "OptAmd_PlanTraceRows",
-                  "OptAmd_PlanGetTrace", "OptAmd_PlanTrustRegionRadius", "OptAmd_PlanKernelTiming", "OptAmd_PlanKernelCount",
+                  "OptAmd_PlanGetTrace", "OptAmd_PlanTrustRegionRadius", "OptAmd_PlanKernelTiming", "OptAmd_PlanSetTiming", "OptAmd_PlanKernelCount",
                   "OptAmd_PlanKernelName", "OptAmd_PlanSetSlab", "OptAmd_CheckProblemFile", "OptAmd_ProblemFileHash"]
 
 
@@ -74,6 +74,7 @@ def lib():
     L.OptAmd_PlanTraceRows.restype = cl; L.OptAmd_PlanTraceRows.argtypes = [vp]
     L.OptAmd_PlanGetTrace.restype = None; L.OptAmd_PlanGetTrace.argtypes = [vp, vp]
     L.OptAmd_PlanTrustRegionRadius.restype = cd; L.OptAmd_PlanTrustRegionRadius.argtypes = [vp]
+    L.OptAmd_PlanSetTiming.restype = None; L.OptAmd_PlanSetTiming.argtypes = [vp, ci]
     L.OptAmd_PlanKernelTiming.restype = ci; L.OptAmd_PlanKernelTiming.argtypes = [vp, cp, ctypes.POINTER(cl), ctypes.POINTER(cd)]
     L.OptAmd_PlanKernelCount.restype = ci; L.OptAmd_PlanKernelCount.argtypes = [vp]
     L.OptAmd_PlanKernelName.restype = cp; L.OptAmd_PlanKernelName.argtypes = [vp, ci]
@@ -222,6 +223,10 @@ class Solver:
 
     def trust_region_radius(self):
         return lib().OptAmd_PlanTrustRegionRadius(self.plan)
+
+    def set_timing(self, on):
+        """Per-kernel hipEvent timing on / off from the next launch on (totals restart)."""
+        lib().OptAmd_PlanSetTiming(self.plan, 1 if on else 0)
 
     def kernel_timings(self):
         """{kernel name: (count, total_ms)} since the last init (needs timing=True)."""

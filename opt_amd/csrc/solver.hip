@@ -929,6 +929,11 @@ struct PcgSolver : SolverBase {
     }
 
     double cost() const override { return (double)prevCost; }   // solver.t:1179-1182
+    void setTiming(bool on) override {      // per-kernel hipEvents from the next launch on (what collectPerKernelTimingInfo sets at plan time)
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (overallOpen) { timer.pool.push_back(overallStart); overallOpen = false; }
+        timer.reset(); timer.enabled = on; ctx.timer = on ? &timer : nullptr;
+    }
     long numUnknownScalars() const override { return n; }
     double trustRegionRadius() const override { return (double)trust_region_radius; }
     void* vector(const std::string& nm) override {
