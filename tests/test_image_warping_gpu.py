@@ -276,3 +276,34 @@ def test_lm_single_kernel_loop_matches_three_kernel_loop(double, monkeypatch):
     np.testing.assert_allclose(res["1"][0], res["0"][0], rtol=1e-9 if double else 1e-5)
     np.testing.assert_allclose(res["1"][1], res["0"][1], rtol=1e-7 if double else 1e-3)
     assert rel_err(res["1"][2], res["0"][2]) < (1e-8 if double else 1e-4)
+
+
+def test_timing_can_be_switched_on_between_steps():
+    """OptAmd_PlanSetTiming: per-kernel hipEvents from the next launch on, totals restart; the solve itself is unaffected (bench.py uses it for the
+    roofline leg of a multi-GPU job: timed steps without events, then two steps with them on the same plan)."""
+    P = wl.image_warping(96, 64, random_state=2, perturb=0.3)
+    ref = hip_solver(P, "gaussNewtonGPU", nIterations=4, lIterations=6)
+    dev_ref = api.to_device(P)
+    ref.init(dev_ref)
+    want = []
+    while ref.step(dev_ref):
+        want.append(ref.cost())
+    ref.close()
+
+    g = hip_solver(P, "gaussNewtonGPU", nIterations=4, lIterations=6)
+    dev = api.to_device(P)
+    g.init(dev)
+    assert g.step(dev)
+    assert g.kernel_timings().get("PCGIteration", (0, 0.0))[0] == 0        # nothing was timed
+    got = [g.cost()]
+    g.set_timing(True)
+    assert g.step(dev)
+    got.append(g.cost())
+    kt = g.kernel_timings()
+    assert kt["PCGIteration"][0] == 6 and kt["PCGIteration"][1] > 0           # exactly the launches of this step
+    g.set_timing(False)
+    assert g.step(dev)
+    got.append(g.cost())
+    assert g.kernel_timings().get("PCGIteration", (0, 0.0))[0] == 0        # totals restart when the switch is flipped
+    g.close()
+    assert got == want[:3]
