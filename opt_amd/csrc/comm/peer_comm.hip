@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256) void k_mailAllReduce(double* __restrict__ buf,
                                                        long long timeoutTicks, volatile int* hostErr) {
     __shared__ double vals[kMaxVals];
     __shared__ double wsum[kMaxVals][4];
+    __shared__ int timedOut;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) timedOut = 0;      // (ordered before its use by the barriers of the summation phase below)
     if (usePartials) {      // all n arrays in one pass: the loads (L2 misses on what the previous kernel just wrote) are in flight together, one barrier
         double t[kMaxVals];
 #pragma unroll
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void k_mailAllReduce(double* __restrict__ buf,
             const long long t0 = wall_clock64();
             while ((unsigned)((v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) >> 32) != tag) {
                 __builtin_amdgcn_s_sleep(2);
-                if (wall_clock64() - t0 > timeoutTicks) { *hostErr = 1; break; }
+                if (wall_clock64() - t0 > timeoutTicks) { *hostErr = 1; timedOut = 1; break; }
             }
         }
         halves[r][w] = (unsigned)v;
@@ -132,7 +134,8 @@ __global__ __launch_bounds__(256) void k_mailAllReduce(double* __restrict__ buf,
         double t = 0;
         for (int r = 0; r < world; ++r)      // rank order: identical bits on every rank
             t += __longlong_as_double((long long)(((unsigned long long)halves[r][2 * tid + 1] << 32) | halves[r][2 * tid]));
-        buf[tid] = t;
+        // a peer never answered: the sum is poisoned rather than left looking like a result (the host sees the flag at its next call, SlabJob.close() at the latest)
+        buf[tid] = timedOut ? __longlong_as_double(0x7ff8000000000000ll) : t;
     }
 }
 

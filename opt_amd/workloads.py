@@ -30,7 +30,8 @@ class Problem:
                        self.double, dict(self.meta))
 
 
-def image_warping(W, H=None, double=False, random_state=None, mask_fraction=0.0, perturb=0.0, jitter_urshape=0.0):
+def image_warping(W, H=None, double=False, random_state=None, mask_fraction=0.0, perturb=0.0, jitter_urshape=0.0,
+                  fit_fraction=0.0, w_fit_sqrt=None, w_reg_sqrt=None):
     """examples/image_warping/src/CombinedSolver.h:110-207 + main.cpp:98-108, constraint ramp alpha=1.
 
     random_state/mask_fraction/perturb > 0 give the randomised variant used by the parity tests
@@ -69,9 +70,49 @@ def image_warping(W, H=None, double=False, random_state=None, mask_fraction=0.0,
             extra = rng.random((H, W)) < 0.05
             constraints[extra] = (urshape[extra] + 3.0 * rng.standard_normal((int(extra.sum()), 2))).astype(ft)
             constraints[extra] = np.abs(constraints[extra])
-    w_fit = np.array(np.sqrt(np.float32(100.0)), dtype=np.float32)     # CombinedSolver.h:126-130
-    w_reg = np.array(np.sqrt(np.float32(0.01)), dtype=np.float32)
+    if fit_fraction > 0:
+        rng2 = np.random.default_rng(1234 if random_state is None else random_state + 1)
+        extra = rng2.random((H, W)) < fit_fraction
+        constraints[extra] = np.abs(urshape[extra] + 2.0 * rng2.standard_normal((int(extra.sum()), 2))).astype(ft)
+    w_fit = np.array(np.sqrt(np.float32(100.0)) if w_fit_sqrt is None else w_fit_sqrt, dtype=np.float32)     # CombinedSolver.h:126-130
+    w_reg = np.array(np.sqrt(np.float32(0.01)) if w_reg_sqrt is None else w_reg_sqrt, dtype=np.float32)
     return Problem("image_warping", (W, H), [offset, angle, urshape, constraints, mask, w_fit, w_reg], (0, 1), double)
+
+
+def image_warping_rows(W, H, lo, hi, double=False):
+    """Rows [lo, hi) of image_warping(W, H) (the deterministic variant: no random_state) without building the whole image -- what one rank of
+    a multi-GPU slab job needs (its rows + ghost rows; opt_amd/slab.py).  Rows outside [0, H) are zero-filled with Mask = 255, exactly what
+    slab.split_problem makes of the global problem.  dims = (W, hi - lo)."""
+    ft = np.float64 if double else np.float32
+    n = hi - lo
+    glo, ghi = max(lo, 0), min(hi, H)
+    inside = slice(glo - lo, ghi - lo)
+    ys_g = np.arange(glo, ghi, dtype=ft)
+    xs, ys = np.meshgrid(np.arange(W, dtype=ft), ys_g)
+    urshape = np.zeros((n, W, 2), dtype=ft)
+    urshape[inside] = np.stack([xs, ys], axis=-1)
+    offset = urshape.copy()
+    angle = np.zeros((n, W), dtype=ft)
+    mask = np.zeros((n, W), dtype=ft)
+    if lo < 0:
+        mask[:-lo] = 255
+    if hi > H:
+        mask[n - (hi - H):] = 255
+    constraints = np.zeros((n, W, 2), dtype=ft)
+    constraints[inside] = -1.0
+    for gy in (0, H - 1):                                  # border rows pinned to themselves
+        if glo <= gy < ghi:
+            constraints[gy - lo] = urshape[gy - lo]
+    constraints[inside, 0, :] = urshape[inside, 0, :]
+    constraints[inside, -1, :] = urshape[inside, -1, :]
+    sx, sy = W / 512.0, H / 512.0
+    for (x0, y0, x1, y1) in CAT512_MARKERS:
+        x, y = int(x0 * sx), int(y0 * sy)
+        if 0 <= x < W and glo <= y < ghi:
+            constraints[y - lo, x] = (int(x1 * sx), int(y1 * sy))
+    w_fit = np.array(np.sqrt(np.float32(100.0)), dtype=np.float32)
+    w_reg = np.array(np.sqrt(np.float32(0.01)), dtype=np.float32)
+    return Problem("image_warping", (W, n), [offset, angle, urshape, constraints, mask, w_fit, w_reg], (0, 1), double)
 
 
 def poisson_image_editing(W, H=None, double=False, seed=0):

@@ -13,6 +13,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libopt_oracle.so")
 _lib = None
+# OPT_ORACLE_VARIANT=fma: the control build with fused multiply-adds (oracle/Makefile); only tests/golden/make_horizon_costs.py uses it
+if os.environ.get("OPT_ORACLE_VARIANT") == "fma":
+    _LIB_PATH = os.path.join(_HERE, "libopt_oracle_fma.so")
 
 
 def build(force=False):
@@ -21,7 +24,7 @@ def build(force=False):
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
         for f in ("oracle_capi.cpp", "solver.hpp", "energies.hpp", "sfs.hpp", "dual.hpp")
     ):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "libopt_oracle.so"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", os.path.basename(_LIB_PATH)])
     return _LIB_PATH
 
 

@@ -47,8 +47,11 @@ def test_shipped_energy_files_match_registry(opt_lib):
 
 def test_t_reader_rejects_mismatches(opt_lib, tmp_path):
     src = open(opt_lib.energy_file("image_warping")).read()
-    # unknown energy (file stem selects the kernel set)
-    p = tmp_path / "my_new_energy.t"; p.write_text(src)
+    # the file stem selects the kernel set; a KNOWN body saved under another name resolves by its content hash (reference o.t:840-853 loads
+    # whatever path it is given); an unknown name with an unknown body has no kernel set
+    p = tmp_path / "my_warp.t"; p.write_text(src)
+    ok, msg = opt_lib.check_problem_file(str(p)); assert ok and "image_warping" in msg, msg
+    p = tmp_path / "my_new_energy.t"; p.write_text(src.replace("eq(Mask(dx,dy), 0) * inShape", "inShape"))
     ok, msg = opt_lib.check_problem_file(str(p)); assert not ok and "no hand-written kernel set" in msg
     # binding index moved
     d = tmp_path / "a"; d.mkdir(); p = d / "image_warping.t"

@@ -276,3 +276,20 @@ def test_bench_launcher_spawns_the_requested_ranks():
     env["WORLD_SIZE"] = "1"
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cpu-smoke"], env=env, capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "must agree" in bad.stderr
+
+
+@pytest.mark.parametrize("W,H,world,ghost", [(40, 64, 8, 8), (33, 50, 3, 2), (16, 16, 1, 4), (24, 41, 4, 5)])
+def test_rank_local_workload_equals_the_slab_of_the_global_one(W, H, world, ghost):
+    """bench.py's ranks build only their own rows (workloads.image_warping_rows; 8192^2 would be 2 GB of host arrays per rank otherwise):
+    bit-identical to split_problem of the global problem, for every rank, float and double."""
+    from opt_amd import slab, workloads as wl
+    for dbl in (False, True):
+        P = wl.image_warping(W, H, double=dbl)
+        for r in range(world):
+            lay = slab.SlabLayout(W, H, r, world, ghost)
+            a = slab.split_problem(P, lay)
+            b = wl.image_warping_rows(W, H, lay.row0 - ghost, lay.row0 + lay.rows + ghost, double=dbl)
+            assert a.dims == b.dims and a.unknown_slots == b.unknown_slots
+            for x, y in zip(a.params, b.params):
+                assert np.asarray(x).dtype == np.asarray(y).dtype
+                np.testing.assert_array_equal(np.asarray(x), np.asarray(y))

@@ -1,0 +1,131 @@
+#!/usr/bin/env python
+"""Long-horizon parity experiment: how far do the HIP PCG loops drift from the oracle as the number of PCG
+iterations per Gauss-Newton step grows, and is the reformulated ("r-free") loop any worse than the reference-ordered one?
+
+Three HIP loops on identical inputs, one Gauss-Newton step each, lIterations in {20, 50, 100, 200, 400}, float and double:
+
+  ref-order : OPT_AMD_ONEKERNEL=0 -- the reference's sequence (PCGStep1, PCGStep2, PCGStep3 as separate passes, r and A p stored, beta numerator summed
+              directly from z.r: solverGPUGaussNewton.t:421-550)
+  r-stored  : OPT_AMD_RFREE=0     -- one launch per iteration, A p recomputed, beta by expansion, r kept in memory
+  r-free    : default             -- additionally r rebuilt from the last two search directions (the benchmarked loop)
+
+against the frozen oracle costs of tests/golden/horizon_costs.json, with |oracle plain - oracle fma| (the same CPU restatement compiled with and without
+fused multiply-adds, horizon_costs_fma.json) beside them as the yardstick of what rounding alone does at that horizon.
+
+    python tools/horizon_parity.py [--out gpurun_out/horizon] [--families horizon adversarial]
+
+Writes <out>.json and <out>.md (copy the latter to profiles/).  tests/test_horizon_gpu.py asserts the envelope on the same data.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+HORIZONS = [20, 50, 100, 200, 400]
+LOOPS = {"ref-order": {"OPT_AMD_ONEKERNEL": "0"}, "r-stored": {"OPT_AMD_RFREE": "0"}, "r-free": {}}
+ADVERSARIAL = dict(fit_fraction=0.002, w_fit_sqrt=100.0, w_reg_sqrt=0.01, random_state=5)      # = tests/golden/make_horizon_costs.py
+ADVERSARIAL_SIZE = 1024
+
+
+def problem(family, dbl):
+    from opt_amd import workloads as wl
+    if family == "horizon":
+        return wl.image_warping(2048, 2048, double=dbl)
+    return wl.image_warping(ADVERSARIAL_SIZE, ADVERSARIAL_SIZE, double=dbl, **ADVERSARIAL)
+
+
+def hip_cost(family, dbl, liters, env, steps=1):
+    """Cost after `steps` Gauss-Newton steps of `liters` PCG iterations through the C ABI, with the A/B switches of `env` set while the plan is made."""
+    import torch
+    from opt_amd import api
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        P = problem(family, dbl)
+        dev = api.to_device(P)
+        s = api.Solver(api.energy_file("image_warping"), "gaussNewtonGPU", P.dims, double=dbl)
+        s.set_parameter("nIterations", steps); s.set_parameter("lIterations", liters)
+        s.init(dev)
+        costs = [s.cost()]
+        for _ in range(steps):
+            s.step(dev)
+            costs.append(s.cost())
+        torch.cuda.synchronize()
+        s.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return costs
+
+
+def load_gold():
+    G = json.load(open(os.path.join(GOLD, "horizon_costs.json")))
+    fma_path = os.path.join(GOLD, "horizon_costs_fma.json")
+    F = json.load(open(fma_path)) if os.path.exists(fma_path) else {}
+    return G, F
+
+
+def experiment(families=("horizon", "adversarial"), precisions=("float", "double"), horizons=HORIZONS):
+    G, F = load_gold()
+    rows = []
+    for fam in families:
+        size = 2048 if fam == "horizon" else ADVERSARIAL_SIZE
+        for prec in precisions:
+            dbl = prec == "double"
+            for L in horizons:
+                key = f"{fam}_{size}_{prec}_{L}"
+                if key not in G:
+                    continue
+                ref = G[key]["costs"][1]
+                row = {"family": fam, "size": size, "precision": prec, "liters": L, "oracle": ref}
+                other = "double" if prec == "float" else "float"
+                ko = f"{fam}_{size}_{other}_{L}"
+                if ko in G:
+                    row["oracle_float_vs_double"] = abs(G[f"{fam}_{size}_float_{L}"]["costs"][1] - G[f"{fam}_{size}_double_{L}"]["costs"][1]) / abs(G[f"{fam}_{size}_double_{L}"]["costs"][1])
+                if key in F:
+                    row["oracle_fma"] = F[key]["costs"][1]
+                    row["oracle_plain_vs_fma"] = abs(F[key]["costs"][1] - ref) / abs(ref)
+                for name, env in LOOPS.items():
+                    c = hip_cost(fam, dbl, L, env)[1]
+                    row[name] = c
+                    row[name + "_rel"] = abs(c - ref) / abs(ref)
+                row["rfree_vs_rstored"] = abs(row["r-free"] - row["r-stored"]) / abs(row["r-stored"])
+                rows.append(row)
+                print(json.dumps(row), flush=True)
+    return rows
+
+
+def markdown(rows):
+    out = ["| family | precision | PCG iterations | oracle cost | ref-order HIP | r-stored HIP | r-free HIP | r-free vs r-stored | oracle plain vs fma | oracle float vs double |",
+           "|---|---|---|---|---|---|---|---|---|---|"]
+    f = lambda v: "n/a" if v is None else f"{v:.2e}"
+    for r in rows:
+        out.append(f"| {r['family']} {r['size']}² | {r['precision']} | {r['liters']} | {r['oracle']:.9g} | {f(r['ref-order_rel'])} | {f(r['r-stored_rel'])} | {f(r['r-free_rel'])} | "
+                   f"{f(r['rfree_vs_rstored'])} | {f(r.get('oracle_plain_vs_fma'))} | {f(r.get('oracle_float_vs_double'))} |")
+    return "\n".join(out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "horizon"))
+    ap.add_argument("--families", nargs="+", default=["horizon", "adversarial"])
+    ap.add_argument("--precisions", nargs="+", default=["float", "double"])
+    args = ap.parse_args()
+    rows = experiment(args.families, args.precisions)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(rows, open(args.out + ".json", "w"), indent=1)
+    md = ("# |cost - oracle| / oracle after ONE Gauss-Newton step, by PCG horizon (image_warping, gaussNewtonGPU)\n\n"
+          "Columns 5-7: the three HIP loops against the frozen oracle of the same precision; column 9: the oracle against itself compiled with fused\n"
+          "multiply-adds (rounding alone); column 10: float oracle against double oracle.  tools/horizon_parity.py, tests/test_horizon_gpu.py.\n\n" + markdown(rows) + "\n")
+    open(args.out + ".md", "w").write(md)
+    print(md)
+
+
+if __name__ == "__main__":
+    main()
