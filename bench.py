@@ -318,6 +318,18 @@ def main():
                           "source": "tests/golden/horizon_costs.json solve8_* (oracle, generated offline by tests/golden/make_horizon_costs.py)"})
         if comm_error():
             solve["comm_error"] = comm_error()
+        # the reference's DEFAULT solver parameters (solverGPUGaussNewton.t:26-39: nIterations = 10, lIterations = 10): here the once-per-step kernels
+        # (bind, PCGInit1, update, cost) weigh as much as the ten PCG launches between them
+        for slot in unknown_slots:
+            dev[slot].copy_(torch.from_numpy(host0[slot]))
+        solver.set_parameter("nIterations", 10); solver.set_parameter("lIterations", 10)
+        sync()
+        t1 = time.perf_counter()
+        solver.solve(dev)
+        sync()
+        ddt = max_over_ranks(time.perf_counter() - t1)
+        solve["reference_default_10x10"] = {"solve_ms": ddt * 1e3, "ms_per_gn_step": ddt * 1e2, "pcg_iters_per_s": 100 / ddt, "final_energy": solver.cost()}
+        solver.set_parameter("lIterations", args.liters)
 
     # ---- the general kernel (arbitrary UrShape: + U and a compact preconditioner, 69 B/pixel) on the same input -----------------------
     general = None

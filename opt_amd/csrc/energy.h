@@ -97,6 +97,14 @@ struct EnergyOps {
     // the generic PCGStep3 followed by applyJTJ).
     virtual bool applyJTJFused(const T* /*pOld*/, const T* /*z*/, T* /*pNew*/, T* /*out*/, const T* /*CtC*/, Reduction* /*dot*/,
                                const Reduction& /*bNum*/, const double* /*aNumOld*/, double* /*aNumNext*/, LaunchCtx&) { return false; }
+    // Optional (Gauss-Newton, single GPU): PCGInit1 and PCGInit1_Finish (solver.t:361-419) in one go -- r = -J^T F, p = M r with the guarded-inverse Jacobi
+    // preconditioner, delta = 0, aNum0 = partial sums of r.p -- for a kernel set whose pcgIteration needs neither the diag nor the preconditioner vector.
+    // Returning true promises that pcgIteration will accept the loop that follows.  false: the solver runs evalJTF + its own flat pass.
+    virtual bool evalJTFInit(T* /*r*/, T* /*p*/, T* /*delta*/, long /*nPad*/, Reduction& /*aNum0*/, LaunchCtx&) { return false; }
+    // Optional: the end of a single-kernel Gauss-Newton loop in one pass over the unknowns -- whatever pcgFinish would still add to delta, the last iteration's
+    // delta += alpha p (alpha = sum aNum / sum aDen, guarded) and PCGLinearUpdate X += delta.  delta itself is dead afterwards and need not be written.
+    // true: the unknowns are updated (the solver skips pcgFinish, the last PCGStep2 and PCGLinearUpdate).
+    virtual bool finishUpdate(const T* /*pPrev*/, const T* /*pLast*/, const T* /*delta*/, const Reduction& /*aNum*/, const Reduction& /*aDen*/, LaunchCtx&) { return false; }
     // Optional: one WHOLE Gauss-Newton PCG iteration as a single kernel (see PcgIterArgs and solver.hip).
     virtual bool pcgIteration(const PcgIterArgs<T>& /*args*/, LaunchCtx&) { return false; }
     // Slab mode, after a pcgIteration launch with iterStateExchange: which vectors (solver layout) carry the state whose ghost rows the neighbours

@@ -392,6 +392,253 @@ __global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __re
     if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
 }
 
+// ---- the once-per-Gauss-Newton-step passes as row-marching kernels (round 3) ------------------------------------------------------
+// iw_flags / iw_checkLattice / iw_cossin / iw_evalJTF / k_initFinish / iw_cost above are one-thread-per-pixel kernels that gather their four
+// neighbours through L1 / L2: 0.22-0.39 of the HBM peak, together 0.93 ms per Gauss-Newton step at 4096^2 -- 1.4 % of a step of 400 PCG iterations but a
+// third of a step with the reference's default of 10 (solverGPUGaussNewton.t:26-39).  The kernels below do the same work in the marching layout of
+// iw_applyJTJ: a workgroup owns a 248-pixel column strip and a contiguous range of rows, a lane keeps rows y-1, y, y+1 of its column in registers, left
+// and right neighbours are DPP shifts, every input row is fetched once:
+//   iw_bindMarch  : flags (Mask, Constraints -> 1 byte) and the unit-lattice verdict of UrShape in one pass (21 B/px in, 1 out); the verdict goes to
+//                   pinned host memory, nothing blocks;
+//   iw_jtfMarch   : PCGInit1 + PCGInit1_Finish (solver.t:361-419): r = -J^T F, p = M r, sum r.p -- and, for a general UrShape, the compact Jacobi
+//                   preconditioner {M_O, M_a} the iteration kernel reads; sincos inline, no (cos, sin) table, no diag / preconditioner vectors written;
+//   iw_costMarch  : computeCost (solver.t:580-592).
+// Each reproduces the expressions of the kernel it replaces term by term (same operands, same order), so the values are the same up to the order of
+// the double partial sums.  Used on a single GPU; slabs keep the older kernels.
+template <class T>
+struct MPx {               // one pixel of the 3-row window
+    T ox, oy;              // Offset
+    T c, s;                // cos / sin of Angle
+    T ux, uy;              // UrShape (dead on a unit lattice)
+    int f;                 // flag byte; 0 if the pixel does not exist
+};
+template <bool RIGHT, bool LATTICE, class T> __device__ __forceinline__ MPx<T> dppShiftM(const MPx<T>& p) {
+    MPx<T> q;
+    q.ox = dppShift<RIGHT>(p.ox); q.oy = dppShift<RIGHT>(p.oy); q.c = dppShift<RIGHT>(p.c); q.s = dppShift<RIGHT>(p.s); q.f = dppShift<RIGHT>(p.f);
+    if (LATTICE) { q.ux = 0; q.uy = 0; } else { q.ux = dppShift<RIGHT>(p.ux); q.uy = dppShift<RIGHT>(p.uy); }
+    return q;
+}
+template <class T> struct MRaw { V2<T> o, u, cc; T a; int f, ok; };
+template <class T, bool LATTICE, bool NEEDC>
+__device__ __forceinline__ MRaw<T> iw_marchLoad(const IWArgs<T>& A, bool xok, int x, int y) {
+    MRaw<T> r;
+    r.ok = xok && y >= 0 && y < A.H;
+    const long i = (long)min(max(y, 0), A.H - 1) * A.W + min(max(x, 0), A.W - 1);      // clamped: always a valid address, gated by r.ok
+    r.f = A.flags[i];
+    r.o = ((const V2<T>*)A.Offset)[i]; r.a = A.Angle[i];
+    if (LATTICE) r.u = V2<T>{0, 0}; else r.u = ((const V2<T>*)A.UrShape)[i];
+    if (NEEDC) r.cc = ((const V2<T>*)A.Constraints)[i]; else r.cc = V2<T>{0, 0};
+    return r;
+}
+template <class T, bool LATTICE>
+__device__ __forceinline__ MPx<T> iw_marchCombine(const MRaw<T>& r) {
+    MPx<T> p;
+    p.ox = r.o.x; p.oy = r.o.y;
+    sincosT(r.a, &p.s, &p.c);                     // the same sincos as iw_cossin: the values the table would hold
+    if (LATTICE) { p.ux = 0; p.uy = 0; } else { p.ux = r.u.x; p.uy = r.u.y; }
+    p.f = r.ok ? r.f : 0;
+    return p;
+}
+// workgroup -> (column strip, row range) as in iw_applyJTJ
+struct MarchGeo { int x, yb, ye; bool xok, writer; };
+template <class T>
+__device__ __forceinline__ MarchGeo marchGeo(const IWArgs<T>& A, int rowsPerGroup, int gx, int gy) {
+    MarchGeo g;
+    const int bx = blockIdx.x % gx, by = blockIdx.x / gx;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    g.x = bx * kStrip + wave * kSpan + lane - 1;
+    g.xok = g.x >= 0 && g.x < A.W;
+    g.writer = g.xok && lane >= 1 && lane <= kSpan;
+    g.yb = A.yBegin + by * rowsPerGroup;
+    g.ye = min(g.yb + rowsPerGroup, A.yEnd);
+    if (by >= gy) g.yb = g.ye = A.yEnd;
+    return g;
+}
+
+// flags + lattice verdict.  notLattice: pinned host word, zeroed by the host before the launch; any workgroup that finds a violation stores 1.
+template <class T, bool CHECK>
+__global__ __launch_bounds__(kBlock) void iw_bindMarch(IWArgs<T> A, int* __restrict__ notLattice, int rowsPerGroup, int gx, int gy) {
+    const MarchGeo g = marchGeo(A, rowsPerGroup, gx, gy);
+    struct R { T m; V2<T> c, u; int ok; };
+    auto load = [&](int y) {
+        R r;
+        r.ok = g.xok && y >= 0 && y < A.H && (A.gy0 + y) >= 0 && (A.gy0 + y) < A.Hg;      // the pixel exists in the (global) image
+        const long i = (long)min(max(y, 0), A.H - 1) * A.W + min(max(g.x, 0), A.W - 1);
+        r.m = A.Mask[i]; r.c = ((const V2<T>*)A.Constraints)[i];
+        if (CHECK) r.u = ((const V2<T>*)A.UrShape)[i]; else r.u = V2<T>{0, 0};
+        return r;
+    };
+    struct P { int act, fit, ok; T ux, uy; };
+    auto combine = [&](const R& r) {
+        P p;
+        p.ok = r.ok; p.act = (r.ok && r.m == T(0)) ? 1 : 0;                               // eq(Mask,0)  (image_warping.t:11,17)
+        p.fit = (r.c.x >= T(0) && r.c.y >= T(0)) ? 1 : 0;                                 // All(greatereq(C,0)) (:22)
+        p.ux = r.u.x; p.uy = r.u.y;
+        return p;
+    };
+    P up = combine(load(g.yb - 1)), cur = combine(load(g.yb));
+    bool bad = false;
+    auto row = [&](int y, const R& rdn, bool live) {
+        const P dn = combine(rdn);
+        const int aR = dppShift<false>(cur.act), aL = dppShift<true>(cur.act);
+        const int cnt = aR + aL + dn.act + up.act;
+        if (CHECK) {
+            const T rx = dppShift<false>(cur.ux), ry = dppShift<false>(cur.uy);
+            const int rok = dppShift<false>(cur.ok);
+            if (g.writer && live && cur.ok) {
+                if (rok && g.x + 1 < A.W) bad |= !(cur.ux - rx == T(-1) && cur.uy - ry == T(0));
+                if (dn.ok) bad |= !(cur.ux - dn.ux == T(0) && cur.uy - dn.uy == T(-1));
+            }
+        }
+        if (g.writer && live) A.flags[(long)y * A.W + g.x] = (uint8_t)((cur.act ? kActive : 0) | (cur.fit ? kFit : 0) | (cnt << kCountShift));
+        up = cur; cur = dn;
+    };
+    R rA = load(g.yb + 1), rB;
+    for (int y = g.yb; y < g.ye; y += 2) {
+        if (IW_ROW_SYNC) __syncthreads();
+        rB = load(y + 2);
+        row(y, rA, true);
+        rA = load(y + 3);
+        row(y + 1, rB, y + 1 < g.ye);
+    }
+    if (CHECK && __any(bad) && (threadIdx.x & (kWave - 1)) == 0) __hip_atomic_store(notLattice, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// r = -J^T F, p = guardedInvert(diag J^T J) r, partial sums of r.p; LATTICE = false additionally writes the compact preconditioner {M_O, M_a}
+template <class T, bool LATTICE>
+__global__ __launch_bounds__(kBlock) void iw_jtfMarch(IWArgs<T> A, T* __restrict__ r, T* __restrict__ p, T* __restrict__ mc, double* __restrict__ partials,
+                                                      int rowsPerGroup, int gx, int gy) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    const MarchGeo g = marchGeo(A, rowsPerGroup, gx, gy);
+    const long N = (long)A.W * A.H;
+    V2<T>* rO = (V2<T>*)r; T* ra = r + 2 * N; V2<T>* pO = (V2<T>*)p; T* pa = p + 2 * N;
+    const T w = A.w_reg;
+    double acc = 0;
+    MPx<T> up = iw_marchCombine<T, LATTICE>(iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, g.yb - 1));
+    MRaw<T> rawCur = iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, g.yb);
+    MPx<T> cur = iw_marchCombine<T, LATTICE>(rawCur);
+    V2<T> ccCur = rawCur.cc;
+    T Fx, Fy, Fa, Pxy, Pa;
+    auto pair = [&](const MPx<T>& c, const MPx<T>& n, T dux, T duy) {       // iw_evalJTF's loop body for one direction; (dux, duy) = U_c - U_n on a unit lattice
+        if (!(n.f & kActive)) return;
+        const T ux = LATTICE ? dux : c.ux - n.ux, uy = LATTICE ? duy : c.uy - n.uy;
+        const T ex = w * ((c.ox - n.ox) - (c.c * ux - c.s * uy));
+        const T ey = w * ((c.oy - n.oy) - (c.s * ux + c.c * uy));
+        const T hx = w * ((n.ox - c.ox) + (n.c * ux - n.s * uy));
+        const T hy = w * ((n.oy - c.oy) + (n.s * ux + n.c * uy));
+        Fx += w * ex - w * hx; Fy += w * ey - w * hy;
+        const T Dx = -c.s * ux - c.c * uy, Dy = c.c * ux - c.s * uy;
+        Fa += -(w * Dx) * ex - (w * Dy) * ey;
+        Pxy += w * w + w * w;
+        Pa += (w * Dx) * (w * Dx) + (w * Dy) * (w * Dy);
+    };
+    auto row = [&](int y, const MRaw<T>& rdn, bool live) {
+        const MPx<T> dn = iw_marchCombine<T, LATTICE>(rdn);
+        const MPx<T> lf = dppShiftM<true, LATTICE>(cur), rt = dppShiftM<false, LATTICE>(cur);
+        Fx = 0; Fy = 0; Fa = 0; Pxy = 0; Pa = 0;
+        if (cur.f & kActive) {
+            pair(cur, rt, T(-1), T(0)); pair(cur, lf, T(1), T(0)); pair(cur, dn, T(0), T(-1)); pair(cur, up, T(0), T(1));
+            if (cur.f & kFit) {
+                Fx += A.w_fit * (A.w_fit * (cur.ox - ccCur.x)); Fy += A.w_fit * (A.w_fit * (cur.oy - ccCur.y));
+                Pxy += A.w_fit * A.w_fit;
+            }
+        }
+        if (g.writer && live) {
+            const long i = (long)y * A.W + g.x;
+            const T r0 = -Fx, r1 = -Fy, r2 = -Fa;
+            const T sO = T(1) + sqrt(Pxy), sA = T(1) + sqrt(Pa);
+            const T mO = T(1) / (sO * sO), mA = T(1) / (sA * sA);         // solver.hip guardedInvert (solver.t:323-332)
+            const T p0 = mO * r0, p1 = mO * r1, p2 = mA * r2;
+            rO[i] = V2<T>{r0, r1}; ra[i] = r2;
+            pO[i] = V2<T>{p0, p1}; pa[i] = p2;
+            if (!LATTICE) ((V2<T>*)mc)[i] = V2<T>{mO, mA};
+            acc += (double)(r0 * p0) + (double)(r1 * p1) + (double)(r2 * p2);
+        }
+        up = cur; cur = dn; ccCur = rdn.cc;
+    };
+    MRaw<T> rA = iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, g.yb + 1), rB;
+    for (int y = g.yb; y < g.ye; y += 2) {
+        if (IW_ROW_SYNC) __syncthreads();
+        rB = iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, y + 2);
+        row(y, rA, true);
+        rA = iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, y + 3);
+        row(y + 1, rB, y + 1 < g.ye);
+    }
+    const double t = blockReduceSum(acc, scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// 1/2 sum r^2 over the non-excluded pixels of the workgroup's rows (iw_cost's expressions)
+template <class T, bool LATTICE>
+__global__ __launch_bounds__(kBlock) void iw_costMarch(IWArgs<T> A, double* __restrict__ partials, int rowsPerGroup, int gx, int gy) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    const MarchGeo g = marchGeo(A, rowsPerGroup, gx, gy);
+    double acc = 0;
+    MPx<T> up = iw_marchCombine<T, LATTICE>(iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, g.yb - 1));
+    MRaw<T> rawCur = iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, g.yb);
+    MPx<T> cur = iw_marchCombine<T, LATTICE>(rawCur);
+    V2<T> ccCur = rawCur.cc;
+    T e;
+    auto pair = [&](const MPx<T>& c, const MPx<T>& n, T dux, T duy) {
+        if (!(n.f & kActive)) return;
+        const T ux = LATTICE ? dux : c.ux - n.ux, uy = LATTICE ? duy : c.uy - n.uy;
+        const T ex = A.w_reg * ((c.ox - n.ox) - (c.c * ux - c.s * uy));
+        const T ey = A.w_reg * ((c.oy - n.oy) - (c.s * ux + c.c * uy));
+        e += ex * ex + ey * ey;
+    };
+    auto row = [&](int y, const MRaw<T>& rdn, bool live) {
+        const MPx<T> dn = iw_marchCombine<T, LATTICE>(rdn);
+        const MPx<T> lf = dppShiftM<true, LATTICE>(cur), rt = dppShiftM<false, LATTICE>(cur);
+        e = 0;
+        if (cur.f & kActive) {       // excluded pixel: its residuals are not part of the cost (solver.t:583)
+            pair(cur, rt, T(-1), T(0)); pair(cur, lf, T(1), T(0)); pair(cur, dn, T(0), T(-1)); pair(cur, up, T(0), T(1));
+            if (cur.f & kFit) {
+                const T fx = A.w_fit * (cur.ox - ccCur.x), fy = A.w_fit * (cur.oy - ccCur.y);
+                e += fx * fx + fy * fy;
+            }
+        }
+        if (g.writer && live) acc += (double)(T(0.5) * e);
+        up = cur; cur = dn; ccCur = rdn.cc;
+    };
+    MRaw<T> rA = iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, g.yb + 1), rB;
+    for (int y = g.yb; y < g.ye; y += 2) {
+        if (IW_ROW_SYNC) __syncthreads();
+        rB = iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, y + 2);
+        row(y, rA, true);
+        rA = iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, y + 3);
+        row(y + 1, rB, y + 1 < g.ye);
+    }
+    const double t = blockReduceSum(acc, scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// End of a Gauss-Newton linear solve in one pass over the unknowns: the deferred term of the paired delta update (if owed), the last PCGStep2's
+// delta += alpha p (solver.t:461-462) and PCGLinearUpdate X += delta (:552-557) -- X = X + ((delta [+ a2 p2]) + a1 p1), the reference's order of
+// additions.  delta itself is dead after the update and is not written back.  a1 = alphaNum / alphaDen of the last launch (guarded like PCGStep2's).
+template <class T>
+__global__ __launch_bounds__(kBlock) void iw_finishUpdate(T* __restrict__ XO, T* __restrict__ XA, const T* __restrict__ delta, const T* __restrict__ p1, const T* __restrict__ p2,
+                                                          const T* __restrict__ alpha2, long N, const double* __restrict__ aNumPartials, int nNum,
+                                                          const double* __restrict__ aDenPartials, int nDen) {
+    __shared__ double scratch[2 * (kBlock / kWave + 1)];
+    const double* const ps[2] = {aNumPartials, aDenPartials}; const int ns[2] = {nNum, nDen}; double o2[2];
+    sumPartialsN<2>(ps, ns, scratch, o2);
+    const T aNum = (T)o2[0], aDen = (T)o2[1];
+    const T a1 = (aDen > T(0)) ? aNum / aDen : T(0);
+    const T a2 = p2 ? alpha2[0] : T(0);
+    const V2<T>* dO = (const V2<T>*)delta; const T* dA = delta + 2 * N;
+    const V2<T>* qO = (const V2<T>*)p1; const T* qA = p1 + 2 * N;
+    const V2<T>* sO = (const V2<T>*)p2; const T* sA = p2 ? p2 + 2 * N : nullptr;
+    V2<T>* xO = (V2<T>*)XO;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+        V2<T> d = dO[i]; T da = dA[i];
+        const V2<T> q = qO[i]; const T qa = qA[i];
+        const V2<T> x = xO[i]; const T xa = XA[i];
+        if (p2) { const V2<T> s = sO[i]; const T sa = sA[i]; d.x = d.x + a2 * s.x; d.y = d.y + a2 * s.y; da = da + a2 * sa; }
+        d.x = d.x + a1 * q.x; d.y = d.y + a1 * q.y; da = da + a1 * qa;
+        xO[i] = V2<T>{x.x + d.x, x.y + d.y}; XA[i] = xa + da;
+    }
+}
+
 // ---- one whole PCG iteration per launch (energy.h PcgIterArgs) --------------------------------------------------
 // Same marching / DPP / prefetch structure as iw_applyJTJ; per pixel it additionally applies the previous
 // iteration's PCGStep2 and PCGStep3 before the stencil, so the PCG loop is ONE kernel per iteration moving
@@ -1099,9 +1346,13 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_RFREE")) rFree = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ITER_ROWS")) forceRows = std::max(0, atoi(e));
         if (const char* e = getenv("OPT_AMD_ITER_STEADY")) steadyVariants = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_MARCH_INIT")) marchKernels = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_FUSED_FINISH")) fusedFinish = atoi(e) != 0;
         HIP_CHECK(hipMalloc((void**)&dNotLattice, sizeof(int)));
+        HIP_CHECK(hipHostMalloc((void**)&hNotLattice, 64)); *hNotLattice = 0;
+        HIP_CHECK(hipEventCreateWithFlags(&bindEvent, hipEventDisableTiming));
     }
-    ~ImageWarpingOps() override { for (T* b : ring) if (b) (void)hipFree(b); (void)hipFree(A.flags); (void)hipFree(A.cs); if (mc) (void)hipFree(mc); if (alphaSlots) (void)hipFree(alphaSlots); (void)hipFree(dNotLattice); }
+    ~ImageWarpingOps() override { (void)hipHostFree(hNotLattice); (void)hipEventDestroy(bindEvent); for (T* b : ring) if (b) (void)hipFree(b); (void)hipFree(A.flags); (void)hipFree(A.cs); if (mc) (void)hipFree(mc); if (alphaSlots) (void)hipFree(alphaSlots); (void)hipFree(dNotLattice); }
     int flatGrid(long n) const { return (int)std::max<long>(1, std::min<long>((n + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
     void bind(void** p, LaunchCtx& ctx) override {
         A.Offset = (const T*)p[0]; A.Angle = (const T*)p[1]; A.UrShape = (const T*)p[2]; A.Constraints = (const T*)p[3]; A.Mask = (const T*)p[4];
@@ -1109,8 +1360,22 @@ struct ImageWarpingOps : EnergyOps<T> {
         const Slab& s = this->slab;
         if (s.active) { A.yBegin = s.yBegin; A.yEnd = s.yEnd; A.gy0 = s.gy0; A.Hg = s.Hg; }
         else { A.yBegin = 0; A.yEnd = A.H; A.gy0 = 0; A.Hg = A.H; }
+        if (!s.active && marchKernels) {
+            // one marching pass: flag bytes + the unit-lattice verdict, which lands in pinned memory and is read when it is first needed (resolveLattice) --
+            // nothing blocks here.  Until then `lattice` keeps the previous bind's verdict as a hint (false before the first).
+            ScopedKernel k(ctx, "bindFlags");
+            if (verdictPending) resolveLattice();      // (two binds without a consumer in between: the older verdict is not needed any more, but its event is)
+            *hNotLattice = 0;
+            int gx, gy, rpg; marchGrid(A.yEnd - A.yBegin, gx, gy, rpg);
+            if (useLattice) iw_bindMarch<T, true><<<gx * gy, kBlock, 0, ctx.stream>>>(A, hNotLattice, rpg, gx, gy);
+            else iw_bindMarch<T, false><<<gx * gy, kBlock, 0, ctx.stream>>>(A, hNotLattice, rpg, gx, gy);
+            HIP_CHECK(hipEventRecord(bindEvent, ctx.stream));
+            verdictPending = useLattice;
+            if (!useLattice) lattice = false;
+            return;
+        }
         { ScopedKernel k(ctx, "bindFlags"); iw_flags<T><<<flatGrid((long)A.W * A.H), kBlock, 0, ctx.stream>>>(A); }
-        lattice = false;
+        lattice = false; verdictPending = false;
         if (useLattice) {
             ScopedKernel k(ctx, "checkLattice");
             int h = 1;
@@ -1122,8 +1387,63 @@ struct ImageWarpingOps : EnergyOps<T> {
         }
     }
     T* unknownPtr(int img) const override { return const_cast<T*>(img == 0 ? A.Offset : A.Angle); }
+    // ---- marching once-per-step kernels (single GPU) -----------------------------------------------------------------------------
+    bool marchKernels = true, fusedFinish = true;      // OPT_AMD_MARCH_INIT=0 / OPT_AMD_FUSED_FINISH=0: the older one-thread-per-pixel passes (A/B switches)
+    int* hNotLattice = nullptr; hipEvent_t bindEvent = nullptr; bool verdictPending = false;
+    int occMarch = 0;
+    void marchGrid(int rows, int& gx, int& gy, int& rowsPerGroup) {
+        if (occMarch == 0) {      // 256-thread workgroups, ~60 VGPRs: the co-resident count of the widest of the marching kernels
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occMarch, (const void*)iw_jtfMarch<T, false>, kBlock, 0));
+            occMarch = std::max(1, std::min(occMarch, 8));
+        }
+        gx = divUp(A.W, kStrip);
+        splitRows(rows, gx, cus * occMarch, gy, rowsPerGroup);
+    }
+    // The verdict of the last iw_bindMarch: waits for that kernel only (an event), not for what was enqueued behind it.
+    bool resolveLattice() {
+        if (verdictPending) {
+            HIP_CHECK(hipEventSynchronize(bindEvent));
+            lattice = __atomic_load_n(hNotLattice, __ATOMIC_ACQUIRE) == 0;
+            verdictPending = false;
+        }
+        return lattice;
+    }
+    bool fastGN() const {      // the conditions under which pcgIteration runs the A p-free single-kernel loop with M from the flag byte or the compact {M_O, M_a}
+        return marchKernels && !this->slab.active && recomputeAp && useCompactM && flagPreconditioner &&
+               !(IW_BUFADDR && (unsigned long long)A.W * A.H * 3ull * sizeof(T) >= (1ull << 32));
+    }
+    T *initR = nullptr, *initP = nullptr; Reduction* initRed = nullptr; bool initHint = false, mcFresh = false;
+    void launchJtf(bool lat, LaunchCtx& ctx) {
+        ScopedKernel k(ctx, "PCGInit1");
+        int gx, gy, rpg; marchGrid(A.yEnd - A.yBegin, gx, gy, rpg);
+        if (!lat && !mc) HIP_CHECK(hipMalloc((void**)&mc, (size_t)A.W * A.H * 2 * sizeof(T)));
+        if (lat) iw_jtfMarch<T, true><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, nullptr, initRed->partials, rpg, gx, gy);
+        else iw_jtfMarch<T, false><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, mc, initRed->partials, rpg, gx, gy);
+        initRed->n = gx * gy;
+        mcFresh = !lat;
+    }
+    // PCGInit1 + PCGInit1_Finish for the Gauss-Newton single-kernel loop: r = -J^T F, p = M r, delta = 0, partial sums of r.p -- one marching kernel and a
+    // memset instead of cos/sin table + gather kernel + flat pass (and no diag / preconditioner vectors: the loop takes M from the flag byte or from `mc`).
+    // The kernel variant follows the lattice verdict of the previous bind while this bind's is still in flight; pcgIteration checks it before its first launch.
+    bool evalJTFInit(T* r, T* p, T* delta, long nPad, Reduction& aNum0, LaunchCtx& ctx) override {
+        if (!fastGN()) return false;
+        initR = r; initP = p; initRed = &aNum0; initHint = lattice;
+        launchJtf(initHint, ctx);
+        { ScopedKernel k(ctx, "PCGInit1_Finish"); HIP_CHECK(hipMemsetAsync(delta, 0, (size_t)nPad * sizeof(T), ctx.stream)); }
+        initPending = true;
+        return true;
+    }
+    bool initPending = false;
     void evalCost(Reduction& out, LaunchCtx& ctx) override {
         ScopedKernel k(ctx, "computeCost");
+        if (!this->slab.active && marchKernels) {
+            const bool lat = resolveLattice();
+            int gx, gy, rpg; marchGrid(A.yEnd - A.yBegin, gx, gy, rpg);
+            if (lat) iw_costMarch<T, true><<<gx * gy, kBlock, 0, ctx.stream>>>(A, out.partials, rpg, gx, gy);
+            else iw_costMarch<T, false><<<gx * gy, kBlock, 0, ctx.stream>>>(A, out.partials, rpg, gx, gy);
+            out.n = gx * gy;
+            return;
+        }
         const int g = flatGrid((long)A.W * (A.yEnd - A.yBegin));
         iw_cost<T><<<g, kBlock, 0, ctx.stream>>>(A, out.partials);
         out.n = g;
@@ -1225,6 +1545,13 @@ struct ImageWarpingOps : EnergyOps<T> {
         // 18900^2 pixels) takes the three-kernel loop instead
         if (IW_BUFADDR && noAp && (unsigned long long)A.W * A.H * 3ull * sizeof(T) >= (1ull << 32)) return false;
         const bool lmLoop = a.CtC != nullptr;
+        if (a.first) {
+            resolveLattice();                          // this bind's verdict (the marching bind does not block for it)
+            if (initPending) {                         // evalJTFInit ran on the previous verdict: a lattice variant on an input that is none has to be redone
+                if (initHint && !lattice) launchJtf(false, ctx);
+                initPending = false;
+            } else mcFresh = false;                    // r, M came from the generic PCGInit1: `mc` (if any) is stale
+        }
         if (lmLoop && (!noAp || !a.pre || this->slab.active)) return false;      // LM: only the A p-free kernel has the variant (single GPU)
         this->iterStateExchange = noAp;     // slab mode: r and p ghost rows come from the neighbours after a launch (iw_pcgIter: Ap before it)
         // With g >= 2 ghost rows whose r and p are current to depth v, a launch can also update the ghost rows to depth v - 1 (their A p needs one
@@ -1251,7 +1578,7 @@ struct ImageWarpingOps : EnergyOps<T> {
             HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occIter[L], fn, blk, 0));
             occIter[L] = std::max(1, std::min(occIter[L], 8));
         }
-        if (a.first && pre == 2) {
+        if (a.first && pre == 2 && !mcFresh) {
             if (!mc) HIP_CHECK(hipMalloc((void**)&mc, (size_t)A.W * A.H * 2 * sizeof(T)));
             ScopedKernel k(ctx, "compactPreconditioner");
             iw_compactM<T><<<flatGrid((long)A.W * A.H), kBlock, 0, ctx.stream>>>(a.pre, mc, (long)A.W * A.H);
@@ -1325,6 +1652,21 @@ struct ImageWarpingOps : EnergyOps<T> {
         iw_axpyDeferred<T><<<flatGrid(n), kBlock, 0, ctx.stream>>>(delta, pPrev, alphaSlots + ((iterIndex - 1) & 1), n);
         deferredTerm = false;
         return pLast;
+    }
+    // Last delta terms + X += delta in one pass (iw_finishUpdate).  pPrev / pLast: the solver's buffers of the last two search directions, used unless the
+    // r-free ring holds them.
+    bool finishUpdate(const T* pPrev, const T* pLast, const T* delta, const Reduction& aNum, const Reduction& aDen, LaunchCtx& ctx) override {
+        if (!fusedFinish || !marchKernels || this->slab.active) return false;
+        if (lastLoopRfree && iterIndex >= 1) {
+            pLast = ring[(iterIndex - 1) % 3];
+            if (iterIndex >= 2) pPrev = ring[(iterIndex - 2) % 3];
+        }
+        ScopedKernel k(ctx, "PCGLinearUpdate");
+        const long N = (long)A.W * A.H;
+        iw_finishUpdate<T><<<flatGrid(N), kBlock, 0, ctx.stream>>>(const_cast<T*>(A.Offset), const_cast<T*>(A.Angle), delta, pLast, deferredTerm ? pPrev : nullptr,
+                                                                   alphaSlots ? alphaSlots + ((iterIndex - 1) & 1) : nullptr, N, aNum.partials, aNum.n, aDen.partials, aDen.n);
+        deferredTerm = false;
+        return true;
     }
     void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {
         ScopedKernel k(ctx, "computeModelCost");

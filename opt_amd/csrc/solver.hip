@@ -328,6 +328,7 @@ struct PcgSolver : SolverBase {
     bool oneKernelLM = true;            // OPT_AMD_ONEKERNEL_LM=0: the same switch for the Levenberg-Marquardt loop only
     Reduction setS[2][4];               // ping-pong {alphaNum, alphaDen, s2, s3} of the single-kernel iteration
     int storeMode = 0;                  // OPT_AMD_SC1=0..4: store flavours of PCGStep2 (see k_step2), A/B switch
+    bool unknownsUpdated = false;       // this step's PCGLinearUpdate was folded into the end of the PCG loop (EnergyOps::finishUpdate)
     bool keepReferenceP = false;        // run the (dead) last PCGStep3 so that `p` matches the reference after a step
     std::vector<void*> allocs;
     Reduction redA, redB, redQ, redC;   // alpha denominator, beta numerator, q, cost / init numerator
@@ -610,7 +611,9 @@ struct PcgSolver : SolverBase {
             }
             cur ^= 1;
         }
-        // the last iteration's delta += alpha p (PCGStep2, solver.t:461-462); r, z, p of that iteration are dead
+        // the last iteration's delta += alpha p (PCGStep2, solver.t:461-462); r, z, p of that iteration are dead.  A kernel set may fold it, its own
+        // deferred terms and PCGLinearUpdate into one pass over the unknowns (EnergyOps::finishUpdate).
+        if (!distributed && !traceEnabled && sp.lIterations > 0 && E->finishUpdate(p2, p, delta, prev[0], prev[1], ctx)) { unknownsUpdated = true; return true; }
         const T* pLast = E->pcgFinish(p2, delta, ctx);
         if (!pLast) pLast = p;
         finalizeLocal(prev[0], scal + 2);
@@ -766,9 +769,12 @@ struct PcgSolver : SolverBase {
         if (sp.nIter >= sp.nIterations) { cleanup(); return 0; }
         const T* preArg = E->usePreconditioner ? preconditioner : nullptr;   // solver.t:467-470: pre = 1 unless the energy preconditions
 
-        // PCGInit1 [+ _Graph + _Finish]: the energy produces r = -J^T F and raw diag(J^T J) (parked in CtC)
-        E->evalJTF(r, CtC, ctx);
-        if (!lm) {
+        // PCGInit1 [+ _Graph + _Finish]: the energy produces r = -J^T F and raw diag(J^T J) (parked in CtC) -- or, for the Gauss-Newton single-kernel loop on
+        // one GPU, r, p = M r, delta = 0 and the partial sums of r.p directly (EnergyOps::evalJTFInit)
+        unknownsUpdated = false;
+        const bool fusedInit = !lm && !distributed && oneKernel && r2 && sp.lIterations > 0 && E->evalJTFInit(r, p, delta, nPad, redC, ctx);
+        if (!fusedInit) E->evalJTF(r, CtC, ctx);
+        if (!lm && !fusedInit) {
             ScopedKernel k(ctx, "PCGInit1_Finish");
             k_initFinish<T><<<streamGrid, kBlock, 0, stream>>>(r, CtC, preconditioner, p, delta, nPacks, E->usePreconditioner ? 1 : 0, E->usesGraph ? 1 : 0, redC.partials);
             redC.n = streamGrid;
@@ -795,6 +801,7 @@ struct PcgSolver : SolverBase {
         bool pendingStep3 = false;
         Reduction bNum;
         const bool single = oneKernel && r2 && (lm ? (oneKernelLM && runSingleKernelLoopLM(preArg, Q0, q_tolerance)) : runSingleKernelLoop(preArg));
+        if (fusedInit && !single) { fprintf(stderr, "Opt(amd): the kernel set accepted evalJTFInit but refused the single-kernel loop\n"); exit(1); }
         if (!single) finalizeTo(redC, scal + aSlot);   // alphaNumerator = sum r.p as one device scalar (the single-kernel loops sum the partials in their first launch)
         // Step3 of the previous iteration (when pending) and Step1 of the next one.  None of it touches what survives a q early-out
         // (delta, and p only through the very Step3 the reference also runs before its q test), so in LM it is enqueued BEFORE the
@@ -886,7 +893,7 @@ struct PcgSolver : SolverBase {
             exchangeVector(delta);
             E->evalModelCost(delta, distributed ? redA : redMH, ctx);   // (its own partials buffer: the value is read together with the new cost below)
             imageOp(3);   // savePreviousUnknowns + PCGLinearUpdate
-        } else imageOp(0);   // PCGLinearUpdate
+        } else if (!unknownsUpdated) imageOp(0);   // PCGLinearUpdate
         exchangeUnknowns();
         E->precompute(ctx);
         // The reference reads the model cost, then updates, then reads the new cost (two blocking copies, solver.t:1108-1117).  Neither value steers
