@@ -178,6 +178,8 @@ def main():
     from opt_amd import api, build, workloads as wl
     if args.share_gpu:
         local_rank = 0
+        # all ranks on one GPU: their iteration kernels poll each other's posted sums, so together they must fit the chip (opt_amd/csrc/energy_image_warping.hip splitRows)
+        os.environ.setdefault("OPT_AMD_ITER_MAXWG", str(max(1, 224 // max(1, world))))
     torch.cuda.set_device(local_rank)
     if distributed:
         if args.share_gpu:

@@ -97,17 +97,43 @@ typedef struct OptAmd_SlabComm {
                          const long* bytes, void* stream);
     /* in-place sum all-reduce of n doubles in device memory */
     void (*allReduceSum)(void* ctx, double* deviceBuf, int n, void* stream);
-    /* Optional (may be NULL): the same all-reduce fed with per-workgroup partial sums -- value i = sum over ranks of
-     * sum(partials[i][0 .. counts[i])) -- written to out[0 .. n) on every rank; lets an implementation fold the local
-     * reduction into its own kernel (one launch between two PCG iterations instead of two).  n <= 8. */
-    void (*allReducePartials)(void* ctx, const double* const* partials, const int* counts, int n, double* out, void* stream);
 } OptAmd_SlabComm;
+
+/* Where a device-side consumer finds the result of a POSTED all-reduce (OptAmd_SlabCommExt.allReducePost): a mailbox in this rank's own device memory
+ * into which every rank (this one included) stores its contribution as self-validating 8-byte words -- word [source rank * stride + 2 * value + half]
+ * = (tag << 32) | 32 bits of the double's payload, each stored whole.  The consumer polls until all `world` x 2n words carry `tag` and adds the
+ * contributions in rank order (the same bits on every rank).  Polls are bounded by `timeoutTicks` of the device's wall clock (100 MHz); on expiry the
+ * consumer stores 1 to *errFlag (pinned host memory, checked by the communicator at its next call) and continues with NaN. */
+typedef struct OptAmd_MailRef {
+    const unsigned long long* words;
+    int world, stride;
+    unsigned tag;
+    long long timeoutTicks;
+    int* errFlag;
+} OptAmd_MailRef;
+
+/* Optional accelerations of a communicator; any member may be NULL.  `size` must be sizeof(OptAmd_SlabCommExt) as the caller compiled it (a library
+ * built against a longer struct reads no member beyond it), and the struct must be zero-initialised before the members are set. */
+typedef struct OptAmd_SlabCommExt {
+    unsigned long size;
+    /* The all-reduce of allReduceSum fed with per-workgroup partial sums -- value i = sum over ranks of sum(partials[i][0 .. counts[i])) -- written to
+     * out[0 .. n) on every rank; lets an implementation fold the local reduction into its own kernel (one launch between two PCG iterations instead of
+     * two).  n <= 8. */
+    void (*allReducePartials)(void* ctx, const double* const* partials, const int* counts, int n, double* out, void* stream);
+    /* The same sums, POSTED only: the local reduction and the stores into every rank's mailbox are enqueued on `stream`, nobody waits; *ref tells a
+     * kernel enqueued behind it where to poll (OptAmd_MailRef).  The PCG iteration kernel then starts -- launch latency, first row loads -- while the
+     * contributions are still crossing the links, instead of behind a kernel that waited for them.  Returns 0 if unavailable.  n <= 8.  At most two
+     * posted all-reduces may be outstanding (the mailbox has four slots). */
+    int (*allReducePost)(void* ctx, const double* const* partials, const int* counts, int n, OptAmd_MailRef* ref, void* stream);
+} OptAmd_SlabCommExt;
 /* Attach a slab description to a plan created with dims {W, rows + 2*g}: g >= 1 ghost rows above and below the `rows` owned
  * rows (g is inferred from the plan's height).  g = 1 is enough for every kernel set; with g >= 2 image_warping runs its
  * PCG iteration without the A*p vector in memory (the neighbours' g edge rows of r and p are exchanged instead of one
  * row of A*p), and that exchange is needed only every g - 1 iterations because the kernel keeps the ghost rows it still
  * needs current by itself.  Must precede Opt_ProblemInit. */
 int OptAmd_PlanSetSlab(Opt_Plan* plan, long row0, long rows, long globalHeight, const OptAmd_SlabComm* comm);
+/* Optional, after OptAmd_PlanSetSlab: hand the plan a communicator's accelerated entry points (same ctx as the OptAmd_SlabComm).  Returns 1 if accepted. */
+int OptAmd_PlanSetSlabExt(Opt_Plan* plan, const OptAmd_SlabCommExt* ext);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ OPT_SYMBOLS = ["Opt_NewState", "Opt_ProblemDefine", "Opt_ProblemDelete", "Opt_Pr
 OPTAMD_SYMBOLS = ["OptAmd_Version", "OptAmd_EnergyCount", "OptAmd_EnergyName", "OptAmd_PlanNumUnknownScalars", "OptAmd_PlanVector",
                   "OptAmd_EvalJTF", "OptAmd_ApplyJTJ", "OptAmd_EvalCost", "OptAmd_PlanEnableTrace", "OptAmd_PlanTraceRows",
                   "OptAmd_PlanGetTrace", "OptAmd_PlanTrustRegionRadius", "OptAmd_PlanKernelTiming", "OptAmd_PlanSetTiming", "OptAmd_PlanKernelCount",
-                  "OptAmd_PlanKernelName", "OptAmd_PlanSetSlab", "OptAmd_CheckProblemFile", "OptAmd_ProblemFileHash"]
+                  "OptAmd_PlanKernelName", "OptAmd_PlanSetSlab", "OptAmd_PlanSetSlabExt", "OptAmd_CheckProblemFile", "OptAmd_ProblemFileHash"]
 
 
 class Opt_InitializationParameters(ctypes.Structure):
@@ -39,7 +39,11 @@ ALLREDUCE_PARTIALS_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(c
 
 class OptAmd_SlabComm(ctypes.Structure):
     _fields_ = [("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("world", ctypes.c_int),
-                ("haloExchange", HALO_FN), ("allReduceSum", ALLREDUCE_FN), ("allReducePartials", ALLREDUCE_PARTIALS_FN)]
+                ("haloExchange", HALO_FN), ("allReduceSum", ALLREDUCE_FN)]
+
+
+class OptAmd_SlabCommExt(ctypes.Structure):      # include/OptAmd.h: optional accelerations, versioned by its leading size field
+    _fields_ = [("size", ctypes.c_ulong), ("allReducePartials", ALLREDUCE_PARTIALS_FN), ("allReducePost", ctypes.c_void_p)]
 
 
 def lib():
@@ -79,6 +83,7 @@ def lib():
     L.OptAmd_PlanKernelCount.restype = ci; L.OptAmd_PlanKernelCount.argtypes = [vp]
     L.OptAmd_PlanKernelName.restype = cp; L.OptAmd_PlanKernelName.argtypes = [vp, ci]
     L.OptAmd_PlanSetSlab.restype = ci; L.OptAmd_PlanSetSlab.argtypes = [vp, cl, cl, cl, ctypes.POINTER(OptAmd_SlabComm)]
+    L.OptAmd_PlanSetSlabExt.restype = ci; L.OptAmd_PlanSetSlabExt.argtypes = [vp, ctypes.POINTER(OptAmd_SlabCommExt)]
     L.OptAmd_CheckProblemFile.restype = ci; L.OptAmd_CheckProblemFile.argtypes = [cp, cp, ci]
     _lib = L
     return L

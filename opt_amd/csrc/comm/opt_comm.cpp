@@ -101,7 +101,7 @@ void* OptComm_CreateRccl(const char* uniqueId, int rank, int world) {
     auto* x = new RcclCtx; x->rank = rank; x->world = world;
     ncclUniqueId id; memcpy(&id, uniqueId, sizeof(id));
     CK_NCCL(ncclCommInitRank(&x->comm, world, id, rank));
-    x->api = OptAmd_SlabComm{x, rank, world, rcclHalo, rcclAllReduce, nullptr};
+    x->api = OptAmd_SlabComm{x, rank, world, rcclHalo, rcclAllReduce};
     return x;
 }
 const OptAmd_SlabComm* OptComm_RcclSlabComm(void* c) { return &((RcclCtx*)c)->api; }
@@ -112,7 +112,7 @@ void* OptComm_CreateThreadWorld(int world) { return new ThreadWorld(world); }
 void OptComm_DestroyThreadWorld(void* w) { delete (ThreadWorld*)w; }
 void* OptComm_CreateThreadRank(void* world, int rank) {
     auto* x = new ThreadCtx; x->W = (ThreadWorld*)world; x->rank = rank;
-    x->api = OptAmd_SlabComm{x, rank, x->W->world, thrHalo, thrAllReduce, nullptr};
+    x->api = OptAmd_SlabComm{x, rank, x->W->world, thrHalo, thrAllReduce};
     return x;
 }
 const OptAmd_SlabComm* OptComm_ThreadSlabComm(void* c) { return &((ThreadCtx*)c)->api; }

@@ -56,6 +56,7 @@ struct PeerCtx {
     long long timeoutTicks;        // wall_clock64 ticks (100 MHz)
     int memKind;                   // 3 uncached, 1 fine-grained, 0 plain hipMalloc
     OptAmd_SlabComm api;
+    OptAmd_SlabCommExt ext;
 };
 
 __device__ __forceinline__ u64 ldSys(const u64* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -139,6 +140,35 @@ __global__ __launch_bounds__(256) void k_mailAllReduce(double* __restrict__ buf,
     }
 }
 
+// ---- post-only all-reduce (OptAmd_SlabCommExt.allReducePost): the first half of k_mailAllReduce -- sum this rank's partials, store the tagged words into
+// every rank's mailbox (this rank's included) -- and nothing else.  The consumer (the next PCG iteration kernel's prologue) polls the words in its own
+// window, so its launch and first loads overlap the flight of the contributions instead of following a kernel that waited for them.
+__global__ __launch_bounds__(256) void k_mailPost(PartialsIn parts, int n, Peers P, int rank, int world, u64 seq) {
+    __shared__ double vals[kMaxVals];
+    __shared__ double wsum[kMaxVals][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double t[kMaxVals];
+#pragma unroll
+    for (int i = 0; i < kMaxVals; ++i) { t[i] = 0; if (i < n) for (int k = tid; k < parts.n[i]; k += 256) t[i] += parts.p[i][k]; }
+#pragma unroll
+    for (int i = 0; i < kMaxVals; ++i) {
+        for (int off = 32; off > 0; off >>= 1) t[i] += __shfl_down(t[i], off, 64);
+        if (lane == 0) wsum[i][wave] = t[i];
+    }
+    __syncthreads();
+    if (tid < n) vals[tid] = ((wsum[tid][0] + wsum[tid][1]) + wsum[tid][2]) + wsum[tid][3];      // the same order as k_mailAllReduce: the same bits
+    __syncthreads();
+    const int slot = (int)(seq % kSlots);
+    const unsigned tag = (unsigned)seq;
+    const int nw = 2 * n;
+    for (int j = tid; j < world * nw; j += 256) {
+        const int tr = j / nw, w = j % nw;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(vals[w >> 1]);
+        const unsigned half = (w & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+        __hip_atomic_store(&P.win[tr]->ll[slot][rank][w], ((u64)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ---- halo exchange -------------------------------------------------------------------------------------------------------------------
 struct HaloArgs {
     int nb;
@@ -211,7 +241,7 @@ __global__ __launch_bounds__(256) void k_haloPull(HaloArgs H, Peers P, const cha
 void checkErr(PeerCtx* x, const char* where) {
     const int e = *x->hostErr;
     if (e) {
-        fprintf(stderr, "OptComm(peer) rank %d: timeout waiting for a peer (%s; code %d: 1 = all-reduce, 2 = halo ack, 3 = halo rows) -- a rank died or fell out of step\n",
+        fprintf(stderr, "OptComm(peer) rank %d: timeout waiting for a peer (%s; code %d: 1 = all-reduce, 2 = halo ack, 3 = halo rows, 4 = posted all-reduce polled by the iteration kernel) -- a rank died or fell out of step\n",
                 x->rank, where, e);
         exit(3);
     }
@@ -231,6 +261,19 @@ void peerAllReducePartials(void* c, const double* const* parts, const int* count
     PartialsIn pin{};
     for (int i = 0; i < n && i < kMaxVals; ++i) { pin.p[i] = parts[i]; pin.n[i] = counts[i]; }
     peerAllReduceImpl((PeerCtx*)c, out, &pin, n, (hipStream_t)stream);
+}
+int peerAllReducePost(void* c, const double* const* parts, const int* counts, int n, OptAmd_MailRef* ref, void* stream) {
+    auto* x = (PeerCtx*)c;
+    checkErr(x, "allReducePost");
+    if (n > kMaxVals || !ref) return 0;
+    PartialsIn pin{};
+    for (int i = 0; i < n; ++i) { pin.p[i] = parts[i]; pin.n[i] = counts[i]; }
+    const u64 seq = ++x->arSeq;
+    k_mailPost<<<1, 256, 0, (hipStream_t)stream>>>(pin, n, peersOf(x), x->rank, x->world, seq);
+    CK_HIP(hipGetLastError());
+    ref->words = &x->win[x->rank]->ll[seq % kSlots][0][0];
+    ref->world = x->world; ref->stride = 2 * kMaxVals; ref->tag = (unsigned)seq; ref->timeoutTicks = x->timeoutTicks; ref->errFlag = (int*)x->hostErr;
+    return 1;
 }
 void peerHalo(void* c, int nb, const void* const* su, const void* const* sd, void* const* ru, void* const* rd, const long* bytes, void* stream) {
     auto* x = (PeerCtx*)c; hipStream_t s = (hipStream_t)stream;
@@ -296,7 +339,11 @@ void* OptComm_PeerCreate(int rank, int world, long stageBytes, double timeoutSec
     CK_HIP(hipHostMalloc((void**)&x->hostErr, sizeof(int), hipHostMallocMapped));
     *x->hostErr = 0;
     x->timeoutTicks = (long long)((timeoutSeconds > 0 ? timeoutSeconds : 20.0) * 1e8);       // wall_clock64 runs at 100 MHz
-    x->api = OptAmd_SlabComm{x, rank, world, peerHalo, peerAllReduce, peerAllReducePartials};
+    x->api = OptAmd_SlabComm{x, rank, world, peerHalo, peerAllReduce};
+    x->ext = OptAmd_SlabCommExt{};
+    x->ext.size = sizeof(OptAmd_SlabCommExt); x->ext.allReducePartials = peerAllReducePartials;
+    if (const char* e = getenv("OPT_AMD_PEER_POST")) { if (atoi(e) != 0) x->ext.allReducePost = peerAllReducePost; }      // A/B switch; default below
+    else x->ext.allReducePost = peerAllReducePost;
     return x;
 }
 void OptComm_PeerHandle(void* c, char* out) { memcpy(out, &((PeerCtx*)c)->handle, sizeof(hipIpcMemHandle_t)); }
@@ -316,6 +363,7 @@ int OptComm_PeerConnect(void* c, const char* allHandles) {
     return 1;
 }
 const OptAmd_SlabComm* OptComm_PeerSlabComm(void* c) { return &((PeerCtx*)c)->api; }
+const OptAmd_SlabCommExt* OptComm_PeerSlabCommExt(void* c) { return &((PeerCtx*)c)->ext; }
 // One all-reduce and one halo exchange with known answers, run once after OptComm_PeerConnect by every rank (collective).  Returns 1 if this rank
 // saw the right values, 0 on a wrong value or a timeout -- it never exits, so the launcher can fall back to RCCL when the peer path does not work
 // on a machine (IPC mapping across devices, coherence of the window memory kind, ...).  Uses a short timeout of its own.

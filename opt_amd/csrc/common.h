@@ -124,6 +124,45 @@ __device__ __forceinline__ void blockReduceSumN(double (&v)[K], double* scratch)
     __syncthreads();
 }
 
+// The K sums of a POSTED all-reduce (OptAmd_MailRef, include/OptAmd.h): every rank's contribution arrives in this rank's mailbox as tagged 8-byte words;
+// thread (source rank r, word w) polls its word until it carries the tag, then K threads add the contributions in rank order -- the same bits on every
+// rank and in every workgroup.  A poll that outlasts the time-out raises the communicator's error flag and yields NaN.  scratch: >= world * 2K unsigned +
+// K doubles (the caller's reduction scratch is reused).  K <= 8, world * 2K <= blockDim.
+struct MailRefDev { const unsigned long long* words; int world, stride; unsigned tag; long long timeoutTicks; int* errFlag; };
+template <int K>
+__device__ __forceinline__ void pollMailSums(const MailRefDev& M, double* scratch, double (&out)[K]) {
+    unsigned* halves = reinterpret_cast<unsigned*>(scratch + K + 1);
+    int* bad = reinterpret_cast<int*>(scratch + K);
+    const int tid = threadIdx.x + threadIdx.y * blockDim.x, nw = 2 * K;
+    if (tid == 0) *bad = 0;
+    __syncthreads();
+    if (tid < M.world * nw) {
+        const int r = tid / nw, w = tid % nw;
+        const unsigned long long* src = M.words + (long)r * M.stride + w;
+        unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned)(v >> 32) != M.tag) {
+            const long long t0 = wall_clock64();
+            while ((unsigned)((v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) >> 32) != M.tag) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > M.timeoutTicks) { *bad = 1; break; }
+            }
+        }
+        halves[tid] = (unsigned)v;
+    }
+    __syncthreads();
+    if (tid < K) {
+        double t = 0;
+        for (int r = 0; r < M.world; ++r)
+            t += __longlong_as_double((long long)(((unsigned long long)halves[r * nw + 2 * tid + 1] << 32) | halves[r * nw + 2 * tid]));
+        if (*bad) { t = __longlong_as_double(0x7ff8000000000000ll); if (tid == 0 && blockIdx.x == 0) __hip_atomic_store(M.errFlag, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+        scratch[tid] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[k] = scratch[k];
+    __syncthreads();
+}
+
 // ---- per-kernel hipEvent timing (reference util.t:404-511) ---------------------------------------------
 struct KernelTimer {
     bool enabled = false;

@@ -6,6 +6,7 @@
 // kernels so it can pick its own tiling, LDS staging and reduction shape.
 #pragma once
 #include "common.h"
+#include "../../include/OptAmd.h"
 
 namespace optamd {
 
@@ -54,6 +55,9 @@ struct PcgIterArgs {
     int afterReset = 0; Reduction betaNum, betaDen;
     T lmRadius = 0, lmMinDiag = 0, lmMaxDiag = 0;        // the scalars of PCGFinalizeDiagonal (solver.t:631-664): an energy whose diag(J^T J) is a known
                                                          // function of per-pixel flags can rebuild CtC and the LM preconditioner from them instead of reading both
+    // Slab mode with a communicator that posts its all-reduces (OptAmd_SlabCommExt.allReducePost): the four sums of the previous launch are not in
+    // aNumPrev .. s3Prev but in flight to this rank's mailbox; the kernel's prologue polls them there (mail.words != nullptr; value order aNum, aDen, s2, s3).
+    OptAmd_MailRef mail = {nullptr, 0, 0, 0, 0, nullptr};
     T* deltaOut = nullptr;                               // if set, the updated delta goes here instead of in place (lets the solver enqueue
                                                          // the next launch before it has read Q: an early-out then still finds the old delta)
 };
@@ -75,6 +79,7 @@ struct EnergyOps {
     Slab slab;
     bool iterStateExchange = false;   // set by pcgIteration: in slab mode the solver exchanges the ghost rows of r and p after a launch (else of Ap before it)
     bool iterExchangeDue = true;      // ... and whether that exchange is needed after THIS launch (deep ghost zones let a kernel skip some)
+    bool iterTakesMail = false;       // set by pcgIteration: its kernels can read the previous launch's sums from a posted all-reduce (PcgIterArgs::mail)
     virtual ~EnergyOps() {}
     void addUnknown(int param, long elems, int channels) {
         unknowns.push_back({param, elems, channels, nScalars});

@@ -644,6 +644,14 @@ __global__ __launch_bounds__(kBlock) void iw_finishUpdate(T* __restrict__ XO, T*
 // iteration's PCGStep2 and PCGStep3 before the stencil, so the PCG loop is ONE kernel per iteration moving
 // r 12 + Ap 12 + p 12 + delta 12 + pre 12 (8 compact) + (cos,sin) 8 + U 8 (0 on a lattice) + flags 1 in and r, p, delta, Ap 48 out = 113-125 B/pixel
 // (three reference kernels: 180 B/pixel algorithmic).
+// The sums behind the expanded beta numerator  sum M (r - alpha Ap)^2 = [sum M r^2] - 2 alpha [sum M r Ap] + alpha^2 [sum M Ap^2]  must be CONSISTENT to far below
+// float precision: when the residual collapses in one iteration (stiff fit pixels: beta ~ 1e-8) the three terms cancel to eight digits, and products
+// rounded to float -- or a z = fl(M r) rounded before it enters two of the three sums -- leave an error of ~1e-9 sum M r^2, i.e. tens of per cent of
+// beta (round 3: profiles/r03_horizon_parity.md, adversarial family: 4.6e-2 of cost after 20 iterations against 4e-4 for the three-kernel loop).  So every
+// term is formed from the same M, r, Ap in double, where a product of two floats is exact: the expansion then equals the direct sum of the reference's
+// PCGStep2 up to the rounding of z and r themselves (1e-7 relative, no amplification).
+template <class T> __device__ __forceinline__ double dprod3(T m, T a, T b) { return ((double)m * (double)a) * (double)b; }
+
 template <class T>
 struct IterRaw {           // one pixel's loads, untouched (any ALU op here would force a wait before the loop back-edge)
     V2<T> ro, ao, po, mo, cs, u, dO; T ra, aa, pa, ma, dA;   // r, Ap, p, pre (Offset part / Angle part), table, UrShape, delta
@@ -654,6 +662,7 @@ template <class T>
 struct IterPx {            // what the stencil needs (Px) + what the sums / stores need
     Px<T> p;               // p_new, cos/sin, U, flags
     T zx, zy, za;          // z = M r_new
+    T rx, ry, ra;          // r_new (the expansion sums use M, r, Ap themselves: dprod3)
     T mx, my, ma;          // M
 };
 template <class T>
@@ -680,6 +689,7 @@ struct IterK {             // kernel argument block
     // iw_pcgIter2 in slab mode: the launch may update r and p on some ghost rows too (A.yBegin / A.yEnd then include them) so that the
     // neighbours' rows are needed only every few launches; the sums and delta stay on the owned rows [ownBegin, ownEnd) (image rows)
     int ownBegin, ownEnd;
+    MailRefDev mail;       // slab mode, posted all-reduce: where the prologue polls the previous launch's four sums (words == nullptr: they are in aNumPrev .. s3Prev)
 };
 
 // PRE: 0 = identity preconditioner, 1 = the solver's 3-channel one (12 B/px), 2 = compact {M_O, M_a} (8 B/px).  A template
@@ -821,6 +831,7 @@ __global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter(IWArgs<
         const T rx = first ? w.ro.x : w.ro.x - alpha * w.ao.x, ry = first ? w.ro.y : w.ro.y - alpha * w.ao.y, ra = first ? w.ra : w.ra - alpha * w.aa;
         q.mx = regCopy(w.mo.x); q.my = (PRE == 2) ? q.mx : regCopy(w.mo.y); q.ma = regCopy((PRE == 2) ? w.mo.y : w.ma);
         q.zx = q.mx * rx; q.zy = q.my * ry; q.za = q.ma * ra;
+        q.rx = rx; q.ry = ry; q.ra = ra;
         q.p.ox = q.zx + beta * w.po.x; q.p.oy = q.zy + beta * w.po.y; q.p.a = q.za + beta * w.pa;
         q.p.c = regCopy(w.cs.x); q.p.s = regCopy(w.cs.y); q.p.f = w.ok ? w.f : 0;
         if (LATTICE) { q.p.ux = 0; q.p.uy = 0; } else { q.p.ux = regCopy(w.u.x); q.p.uy = regCopy(w.u.y); }
@@ -833,7 +844,7 @@ __global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter(IWArgs<
                     if (IW_DELTA_LATE) { const V2<T> d = dO[i]; const T da = dA[i]; st2<kNTS>(dO, i, d.x + alpha * w.po.x, d.y + alpha * w.po.y); st1<kNTS>(dA, i, da + alpha * w.pa); }
                     else { st2<kNTS>(dO, i, w.dO.x + alpha * w.po.x, w.dO.y + alpha * w.po.y); st1<kNTS>(dA, i, w.dA + alpha * w.pa); }
                 }
-                accNum += (double)(q.zx * rx + q.zy * ry + q.za * ra);
+                accNum += dprod3(q.mx, rx, rx) + dprod3(q.my, ry, ry) + dprod3(q.ma, ra, ra);
             }
         }
         return q;
@@ -859,8 +870,8 @@ __global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter(IWArgs<
         ox = act ? ox : T(0); oy = act ? oy : T(0); oa = act ? oa : T(0);
         if (writer && live) {
             accDen += (double)(cur.p.ox * ox + cur.p.oy * oy + cur.p.a * oa);
-            acc2 += (double)(cur.zx * ox + cur.zy * oy + cur.za * oa);
-            acc3 += (double)((cur.mx * ox) * ox + (cur.my * oy) * oy + (cur.ma * oa) * oa);
+            acc2 += dprod3(cur.mx, cur.rx, ox) + dprod3(cur.my, cur.ry, oy) + dprod3(cur.ma, cur.ra, oa);
+            acc3 += dprod3(cur.mx, ox, ox) + dprod3(cur.my, oy, oy) + dprod3(cur.ma, oa, oa);
             st2<kNTS>(aO, i, ox, oy); st1<kNTS>(aA, i, oa);
         }
         up = cur; cur = dn;
@@ -972,7 +983,7 @@ struct OldRow {            // one row of iteration k-1: p_{k-1} and, while still
 template <class T>
 struct NewRow {            // one row of iteration k: p_k, z_k, M, and the shifted constant fields of its neighbours
     Q<T> q;
-    T zx, zy, za, mx, my, ma;
+    T rx, ry, ra, mx, my, ma;      // r_k and M (z_k = M r_k is consumed where it is formed; the sums use M, r, Ap themselves: dprod3)
     T cx, cy, ca;          // CtC (LM)
     Q<T> lf, rt;           // only c, s, (ux, uy,) on are kept here
 };
@@ -1034,7 +1045,10 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAV
         beta = (bDen > T(0)) ? bNum / bDen : T(0);     // solver.t:544-547
     } else if (!first) {
         const double* const ps[4] = {K.aNumPrev, K.aDenPrev, K.s2Prev, K.s3Prev}; const int ns[4] = {K.nNum, K.nDen, K.n2, K.n3}; double o4[4];
-        sumPartialsN<4>(ps, ns, scratch, o4);          // the four sums of the previous launch, loads in flight together
+        if (!LM && K.mail.words) {                     // slab mode: the sums were posted to this rank's mailbox by every rank and may still be in flight
+            __shared__ double mailScr[4 + 1 + 64];
+            pollMailSums<4>(K.mail, mailScr, o4);
+        } else sumPartialsN<4>(ps, ns, scratch, o4);   // the four sums of the previous launch, loads in flight together
         const double aNumD = o4[0], aDenD = o4[1], s2 = o4[2], s3 = o4[3];
         const T aNum = (T)aNumD, aDen = (T)aDenD;
         alpha = (aDen > T(0)) ? aNum / aDen : T(0);
@@ -1160,8 +1174,9 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAV
         const T rx = keepR ? oB.rx : oB.rx - alpha * ax, ry = keepR ? oB.ry : oB.ry - alpha * ay, ra = keepR ? oB.ra : oB.ra - alpha * aa;   // Step2
         nC.mx = oB.mx; nC.my = oB.my; nC.ma = oB.ma;
         nC.cx = oB.cx; nC.cy = oB.cy; nC.ca = oB.ca;
-        nC.zx = nC.mx * rx; nC.zy = nC.my * ry; nC.za = nC.ma * ra;
-        nC.q.ox = nC.zx + beta * oB.q.ox; nC.q.oy = nC.zy + beta * oB.q.oy; nC.q.a = nC.za + beta * oB.q.a;                               // Step3
+        nC.rx = rx; nC.ry = ry; nC.ra = ra;
+        const T zx = nC.mx * rx, zy = nC.my * ry, za = nC.ma * ra;
+        nC.q.ox = zx + beta * oB.q.ox; nC.q.oy = zy + beta * oB.q.oy; nC.q.a = za + beta * oB.q.a;                                        // Step3
         if (live && writer && y + 1 >= yb && y + 1 < ye) {
             const int yp = phys(y + 1);
             const long i = (long)yp * A.W + x;
@@ -1200,7 +1215,7 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAV
                 if (LM || !kRfree) { st2<kNTS>(rO, i, rx, ry); st1<kNTS>(rA, i, ra); }
                 st2<kNTS>(pO, i, nC.q.ox, nC.q.oy); st1<kNTS>(pA, i, nC.q.a);
             }
-            if (own) accNum += (double)(nC.zx * rx + nC.zy * ry + nC.za * ra);
+            if (own) accNum += dprod3(nC.mx, rx, rx) + dprod3(nC.my, ry, ry) + dprod3(nC.ma, ra, ra);
         }
         Q<T> l2 = nB.lf, r2 = nB.rt;
         dppShiftVec<true>(nB.q, l2); dppShiftVec<false>(nB.q, r2);
@@ -1209,8 +1224,8 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAV
         if (LM) { ox += nB.cx * nB.q.ox; oy += nB.cy * nB.q.oy; oa += nB.ca * nB.q.a; }
         if (live && writer && y >= yb && (!IW_OWN_CHECK || (phys(y) >= K.ownBegin && phys(y) < K.ownEnd))) {
             accDen += (double)(nB.q.ox * ox + nB.q.oy * oy + nB.q.a * oa);
-            acc2 += (double)(nB.zx * ox + nB.zy * oy + nB.za * oa);
-            acc3 += (double)((nB.mx * ox) * ox + (nB.my * oy) * oy + (nB.ma * oa) * oa);
+            acc2 += dprod3(nB.mx, nB.rx, ox) + dprod3(nB.my, nB.ry, oy) + dprod3(nB.ma, nB.ra, oa);
+            acc3 += dprod3(nB.mx, ox, ox) + dprod3(nB.my, oy, oy) + dprod3(nB.ma, oa, oa);
         }
     };
     OldRow<T> o0, o1, o2;
@@ -1346,6 +1361,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_RFREE")) rFree = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ITER_ROWS")) forceRows = std::max(0, atoi(e));
         if (const char* e = getenv("OPT_AMD_ITER_STEADY")) steadyVariants = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_ITER_MAXWG")) maxWorkgroups = std::max(1, atoi(e));
         if (const char* e = getenv("OPT_AMD_MARCH_INIT")) marchKernels = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_FUSED_FINISH")) fusedFinish = atoi(e) != 0;
         HIP_CHECK(hipMalloc((void**)&dNotLattice, sizeof(int)));
@@ -1458,7 +1474,12 @@ struct ImageWarpingOps : EnergyOps<T> {
     // row groups).  The kernels have no inter-workgroup synchronisation, so any split is valid; the switch exists so that small test
     // images run the marching loop in the regime of the benchmark (4096^2: 98 rows per workgroup) -- tests/test_steady_state_gpu.py.
     int forceRows = 0;
+    // OPT_AMD_ITER_MAXWG=n: no row-marching launch uses more than n workgroups.  For ranks that SHARE one GPU (tests, bench.py --share-gpu): an iteration
+    // kernel that polls a posted all-reduce in its prologue must be co-resident with the peers' kernels it is waiting for, which holds on one GPU per rank
+    // and on a shared GPU only while all ranks' workgroups together fit the chip.
+    int maxWorkgroups = 1 << 30;
     void splitRows(int rows, int gx, int target, int& gy, int& rowsPerGroup) const {
+        target = std::max(gx, std::min(target, maxWorkgroups));
         gy = std::max(1, std::min(std::min(rows, target / gx), kMaxPartials / gx));
         rowsPerGroup = divUp(rows, gy);
         if (forceRows > 0) rowsPerGroup = std::max(divUp(rows, std::max(1, kMaxPartials / gx)), std::min(rows, forceRows));
@@ -1535,7 +1556,10 @@ struct ImageWarpingOps : EnergyOps<T> {
         return lat ? (flip ? (const void*)iw_pcgIter2<T, true, 1, true, true> : (const void*)iw_pcgIter2<T, true, 1, false, true>)
                    : (flip ? (const void*)iw_pcgIter2<T, false, 1, true, true> : (const void*)iw_pcgIter2<T, false, 1, false, true>);
     }
-    bool flagPreconditioner = true, pairDelta = true, rFree = true; int reconstructP = 1;
+    bool flagPreconditioner = true, pairDelta = true, rFree = true;
+    // OPT_AMD_RECON_P=1 (r in memory only): rebuild the deferred p_{k-2} as (p_{k-1} - M r_{k-1}) / beta_{k-2} instead of reading it -- 12 B/px less, but a division by a beta that a
+    // collapsing residual makes ~1e-8 (round 3, adversarial family: 3.5e-11 in double where every other loop holds 1e-15); off by default, the r-free loop keeps p_{k-2} in registers.
+    int reconstructP = 0;
     T* ring[3] = {nullptr, nullptr, nullptr}; const T* r0Ptr = nullptr; bool lastLoopRfree = false;
     int iterIndex = 0; bool deferredTerm = false; T* alphaSlots = nullptr;
     T* mc = nullptr; int* dNotLattice = nullptr; bool lattice = false, useLattice = true, useCompactM = true;
@@ -1554,6 +1578,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         }
         if (lmLoop && (!noAp || !a.pre || this->slab.active)) return false;      // LM: only the A p-free kernel has the variant (single GPU)
         this->iterStateExchange = noAp;     // slab mode: r and p ghost rows come from the neighbours after a launch (iw_pcgIter: Ap before it)
+        this->iterTakesMail = noAp && !lmLoop;   // iw_pcgIter2's prologue can poll a posted all-reduce
         // With g >= 2 ghost rows whose r and p are current to depth v, a launch can also update the ghost rows to depth v - 1 (their A p needs one
         // more row on either side) and its sums need depth 2; so after an exchange at depth g the slab runs g - 1 launches before it needs the
         // neighbours again, launch j = 1 .. g - 1 of the period updating g - j ghost rows (none in the last one: they are about to be overwritten).
@@ -1614,7 +1639,8 @@ struct ImageWarpingOps : EnergyOps<T> {
                    rfreeFlag, a.CtC, a.b, a.q ? a.q->partials : nullptr, a.qTag, a.afterReset, a.betaNum.partials, a.betaNum.n, a.betaDen.partials, a.betaDen.n,
                    a.deltaOut ? a.deltaOut : a.delta, a.lmRadius, a.lmMinDiag, a.lmMaxDiag,
                    a.aNumPrev.partials, a.aDenPrev.partials, a.s2Prev.partials, a.s3Prev.partials, a.aNumPrev.n, a.aDenPrev.n, a.s2Prev.n, a.s3Prev.n,
-                   a.aNum->partials, a.aDen->partials, a.s2->partials, a.s3->partials, A.yBegin, A.yEnd};
+                   a.aNum->partials, a.aDen->partials, a.s2->partials, a.s3->partials, A.yBegin, A.yEnd,
+                   MailRefDev{a.mail.words, a.mail.world, a.mail.stride, a.mail.tag, a.mail.timeoutTicks, a.mail.errFlag}};
         {
             ScopedKernel k(ctx, "PCGIteration");
             int rpg = rowsPerGroup, gxa = gx, gya = gy;

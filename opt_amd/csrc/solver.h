@@ -41,6 +41,7 @@ struct SolverBase {
     virtual double evalCost(void** params) = 0;
     virtual double trustRegionRadius() const = 0;
     virtual int setSlab(long row0, long rows, long globalHeight, const OptAmd_SlabComm* comm) = 0;
+    virtual int setSlabExt(const OptAmd_SlabCommExt* ext) = 0;
     virtual void setTiming(bool on) = 0;                        // OptAmd_PlanSetTiming
     bool setParameter(const char* name, const void* value);   // solver.t:1205-1221
 };

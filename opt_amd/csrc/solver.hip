@@ -13,6 +13,7 @@
 //    rotation written by workgroup 0 of Step3.
 #include "solver.h"
 #include <cmath>
+#include <cstddef>
 #include <cstring>
 
 // a polite spin: pause on x86, yield on arm64, nothing elsewhere
@@ -347,6 +348,7 @@ struct PcgSolver : SolverBase {
     T trust_region_radius = 0, radius_decrease_factor = 0, min_lm_diagonal = 0, max_lm_diagonal = 0;   // pd.parameters (o.t:933-938)
     hipEvent_t overallStart = nullptr; bool overallOpen = false;
     OptAmd_SlabComm comm{};
+    OptAmd_SlabCommExt commExt{};       // the communicator's optional fast paths (OptAmd_PlanSetSlabExt); all null unless set
     bool distributed = false;
 
     T* allocVec() {
@@ -492,10 +494,10 @@ struct PcgSolver : SolverBase {
     }
     // dst[i] = sum over ranks of sum(Rs[i].partials): one launch if the communicator folds the local reduction in (allReducePartials)
     void reduceAcross(const Reduction* Rs, int cnt, double* dst) {
-        if (comm.allReducePartials) {
+        if (commExt.allReducePartials) {
             const double* ps[8]; int ns[8];
             for (int i = 0; i < cnt; ++i) { ps[i] = Rs[i].partials; ns[i] = Rs[i].n; }
-            comm.allReducePartials(comm.ctx, ps, ns, cnt, dst, (void*)stream);
+            commExt.allReducePartials(comm.ctx, ps, ns, cnt, dst, (void*)stream);
             return;
         }
         if (cnt == 4) {
@@ -578,11 +580,13 @@ struct PcgSolver : SolverBase {
             prev[0] = forConsumers(redC, 0);
         }
         int cur = 0;
+        OptAmd_MailRef mail{nullptr, 0, 0, 0, 0, nullptr};      // where the next launch finds the previous launch's sums if they were posted, not reduced
         for (int lIter = 0; lIter < sp.lIterations; ++lIter) {
             PcgIterArgs<T> a{};
             a.rOld = r; a.ApOld = Ap_X; a.pOld = p; a.rNew = r2; a.ApNew = Ap2; a.pNew = p2; a.delta = delta; a.pre = preArg; a.first = lIter == 0;
             a.aNumPrev = prev[0]; a.aDenPrev = prev[1]; a.s2Prev = prev[2]; a.s3Prev = prev[3];
             a.aNum = &setS[cur][0]; a.aDen = &setS[cur][1]; a.s2 = &setS[cur][2]; a.s3 = &setS[cur][3];
+            a.mail = mail;
             if (distributed && lIter > 0 && !E->iterStateExchange) exchangeVector(Ap_X);   // kernel with Ap in memory: r and p ghost rows are kept current by the kernel itself
             if (!E->pcgIteration(a, ctx)) { if (lIter == 0) return false; fprintf(stderr, "pcgIteration refused mid-loop\n"); exit(1); }
             std::swap(r, r2); std::swap(Ap_X, Ap2); std::swap(p, p2);
@@ -595,10 +599,22 @@ struct PcgSolver : SolverBase {
                 exchangeRows(bases);
             }
             for (int i = 0; i < 4; ++i) prev[i] = setS[cur][i];
+            mail = OptAmd_MailRef{nullptr, 0, 0, 0, 0, nullptr};
             if (distributed) {   // one all-reduce of the four sums (ping-pong destination, like the partial sets it replaces)
-                double* tot = scal4[cur];
-                reduceAcross(setS[cur], 4, tot);
-                for (int i = 0; i < 4; ++i) { prev[i].partials = tot + i; prev[i].n = 1; }
+                // If the communicator can POST it and the next launch's prologue can poll the mailbox, nothing waits between the two launches: the
+                // contributions cross the links while the next kernel is being launched and requests its first rows.  The last iteration's sums are needed
+                // by the flat kernel that closes the loop: those take the complete all-reduce.
+                bool posted = false;
+                if (commExt.allReducePost && E->iterTakesMail && lIter + 1 < sp.lIterations && !traceEnabled) {
+                    const double* ps[4]; int ns[4];
+                    for (int i = 0; i < 4; ++i) { ps[i] = setS[cur][i].partials; ns[i] = setS[cur][i].n; }
+                    posted = commExt.allReducePost(comm.ctx, ps, ns, 4, &mail, (void*)stream) != 0;
+                }
+                if (!posted) {
+                    double* tot = scal4[cur];
+                    reduceAcross(setS[cur], 4, tot);
+                    for (int i = 0; i < 4; ++i) { prev[i].partials = tot + i; prev[i].n = 1; }
+                }
             }
             if (traceEnabled) {
                 const double aNum = hostSumLocal(prev[0]), aDen = hostSumLocal(prev[1]), s2 = hostSumLocal(prev[2]), s3 = hostSumLocal(prev[3]);
@@ -1006,7 +1022,18 @@ struct PcgSolver : SolverBase {
         const long g = (localH - rows) / 2;
         if (g < 1 || rows + 2 * g != localH) return 0;
         E->slab.active = true; E->slab.ghost = (int)g; E->slab.yBegin = (int)g; E->slab.yEnd = (int)(rows + g); E->slab.gy0 = (int)(row0 - g); E->slab.Hg = (int)globalHeight;
-        comm = *c; distributed = c->world > 1 || getenv("OPT_AMD_FORCE_COMM") != nullptr;   // the env switch lets a 1-rank test drive the comm callbacks
+        comm = *c; commExt = OptAmd_SlabCommExt{};
+        distributed = c->world > 1 || getenv("OPT_AMD_FORCE_COMM") != nullptr;   // the env switch lets a 1-rank test drive the comm callbacks
+        return 1;
+    }
+    int setSlabExt(const OptAmd_SlabCommExt* e) override {      // only the members the caller's struct actually has are read
+        if (!e || !E->slab.active) return 0;
+        commExt = OptAmd_SlabCommExt{};
+        const size_t have = (size_t)e->size;
+        auto has = [&](size_t off, size_t sz) { return have >= off + sz; };
+        if (has(offsetof(OptAmd_SlabCommExt, allReducePartials), sizeof(e->allReducePartials))) commExt.allReducePartials = e->allReducePartials;
+        if (has(offsetof(OptAmd_SlabCommExt, allReducePost), sizeof(e->allReducePost))) commExt.allReducePost = e->allReducePost;
+        commExt.size = sizeof(OptAmd_SlabCommExt);
         return 1;
     }
 };

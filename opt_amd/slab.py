@@ -103,6 +103,7 @@ def comm_lib():
         L.OptComm_PeerMemKind.restype = ci; L.OptComm_PeerMemKind.argtypes = [vp]
         L.OptComm_PeerConnect.restype = ci; L.OptComm_PeerConnect.argtypes = [vp, ctypes.c_char_p]
         L.OptComm_PeerSlabComm.restype = ctypes.POINTER(api.OptAmd_SlabComm); L.OptComm_PeerSlabComm.argtypes = [vp]
+        L.OptComm_PeerSlabCommExt.restype = ctypes.POINTER(api.OptAmd_SlabCommExt); L.OptComm_PeerSlabCommExt.argtypes = [vp]
         L.OptComm_PeerError.restype = ci; L.OptComm_PeerError.argtypes = [vp]
         L.OptComm_PeerDestroy.argtypes = [vp]
         L.OptComm_PeerSelfTest.restype = ci; L.OptComm_PeerSelfTest.argtypes = [vp, ctypes.c_double]
@@ -115,10 +116,12 @@ def comm_lib():
     return _comm
 
 
-def attach_slab(solver, layout, slab_comm_ptr):
+def attach_slab(solver, layout, slab_comm_ptr, ext_ptr=None):
     ok = api.lib().OptAmd_PlanSetSlab(solver.plan, layout.row0, layout.rows, layout.H, slab_comm_ptr)
     if not ok:
         raise RuntimeError("this energy's kernel set does not support slab tiling")
+    if ext_ptr is not None:                      # the communicator's optional fast paths (OptAmd_SlabCommExt)
+        api.lib().OptAmd_PlanSetSlabExt(solver.plan, ext_ptr)
 
 
 class PeerComm:
@@ -172,6 +175,9 @@ class PeerComm:
     def slab_comm(self):
         return comm_lib().OptComm_PeerSlabComm(self._ctx)
 
+    def slab_comm_ext(self):
+        return comm_lib().OptComm_PeerSlabCommExt(self._ctx)
+
     def error(self):
         return comm_lib().OptComm_PeerError(self._ctx)
 
@@ -223,8 +229,9 @@ class SlabJob:
                     self._peer.close()
                     self._peer = None
                 comm = self.comm_kind = "rccl"
+        slab_ext = None
         if comm == "peer":
-            slab_comm = self._peer.slab_comm()
+            slab_comm, slab_ext = self._peer.slab_comm(), self._peer.slab_comm_ext()
         elif comm == "rccl":
             n = L.OptComm_UniqueIdBytes()
             buf = ctypes.create_string_buffer(n)
@@ -239,7 +246,7 @@ class SlabJob:
         else:
             raise ValueError(f"unknown comm {comm!r}")
         self.solver = api.Solver(api.energy_file(energy), kind, (W, self.layout.local_H), double=double)
-        attach_slab(self.solver, self.layout, slab_comm)
+        attach_slab(self.solver, self.layout, slab_comm, slab_ext)
 
     def comm_ranks(self):
         """How many ranks the communicator itself sees (ncclCommCount for RCCL; the mapped windows for the peer communicator)."""

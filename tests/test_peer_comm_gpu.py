@@ -30,6 +30,10 @@ def _rank_main(rank, world, port, case, q):
     import torch.distributed as dist
     from opt_amd import slab
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OPT_AMD_PEER_TIMEOUT="8")
+    # ranks SHARING one GPU: the iteration kernel polls the posted all-reduce in its prologue, so all ranks' kernels must be co-resident (on one GPU per rank they
+    # trivially are): cap every rank's grid so that together they fit the chip's 256 CUs
+    os.environ["OPT_AMD_ITER_MAXWG"] = str(max(1, 224 // world))
+    os.environ.update(case.get("env", {}))
     if world == 1:
         os.environ["OPT_AMD_FORCE_COMM"] = "1"
     torch.cuda.set_device(0)                                   # all ranks share the box's one GPU
@@ -102,6 +106,21 @@ def test_peer_mailbox_middle_ranks(world, ghost, double):
         assert costs == res[0][1]                                               # bitwise identical on every rank
         for a, b in zip(unk, x1):
             assert rel_err(a, b[row0:row0 + rows]) < tol
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_posted_allreduce_equals_the_waited_one(world):
+    """Round 3: the per-iteration all-reduce is POSTED (k_mailPost) and the next iteration kernel's prologue polls this rank's mailbox
+    (OptAmd_SlabCommExt.allReducePost, common.h pollMailSums) instead of a kernel waiting between two launches.  Same contributions, same rank order of the
+    additions: the cost trajectory must be bitwise the one of the waited all-reduce (OPT_AMD_PEER_POST=0), on every rank."""
+    out = {}
+    for post in ("1", "0"):
+        case = dict(W=70, H=96, double=False, ghost=8, kind="gaussNewtonGPU", n=2, l=30, env={"OPT_AMD_PEER_POST": post})
+        res = _run(world, case)
+        assert all(res[r][6] == 0 for r in range(world))
+        assert all(res[r][1] == res[0][1] for r in range(world))
+        out[post] = res[0][1]
+    assert out["1"] == out["0"], out
 
 
 def test_peer_mailbox_lm_two_processes():

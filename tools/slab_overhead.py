@@ -21,7 +21,9 @@ def run(mode, W, H, liters, steps):
         s = api.Solver(api.energy_file("image_warping"), "gaussNewtonGPU", (W, H))
         job = None
     else:
-        job = slab.SlabJob("image_warping", W, H, 0, 1, comm=mode)
+        # "peer": the all-reduce is posted and polled by the next iteration kernel's prologue (round 3); "peer-wait": a kernel between two launches waits for it (round 2)
+        os.environ["OPT_AMD_PEER_POST"] = "0" if mode == "peer-wait" else "1"
+        job = slab.SlabJob("image_warping", W, H, 0, 1, comm="peer" if mode.startswith("peer") else mode)
         s, dev = job.solver, job.params
     s.set_parameter("nIterations", steps + 1); s.set_parameter("lIterations", liters)
     s.init(dev); s.step(dev)
@@ -45,8 +47,9 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     out = {}
-    for (W, H) in [(4096, 512), (4096, 1024), (4096, 2048), (8192, 1024)]:
-        for mode in ("plain", "peer", "rccl"):
+    sizes = [(4096, 512), (4096, 1024), (4096, 2048), (8192, 1024)] if "--all" in sys.argv else [(4096, 512), (8192, 1024)]
+    for (W, H) in sizes:
+        for mode in ("plain", "peer", "peer-wait", "rccl"):
             us = run(mode, W, H, 400, 3)
             out[f"{W}x{H}_{mode}"] = us
             print(f"{W}x{H:5d} {mode:5s}: {us:7.1f} us per PCG iteration", flush=True)
