@@ -124,6 +124,18 @@ __device__ __forceinline__ void blockReduceSumN(double (&v)[K], double* scratch)
     __syncthreads();
 }
 
+// ---- whole-wave shifts --------------------------------------------------------------------------------------
+// DPP whole-wave shifts (gfx9 family): wave_shr:1 gives lane i the value of lane i-1, wave_shl:1 of lane i+1;
+// lanes shifted in from outside the wave read 0 (bound_ctrl).  One v_mov_b32_dpp per 32-bit word, no LDS.
+template <bool RIGHT> __device__ __forceinline__ int dppShift(int v) {
+    return RIGHT ? __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true) : __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true);
+}
+template <bool RIGHT> __device__ __forceinline__ float dppShift(float v) { return __int_as_float(dppShift<RIGHT>(__float_as_int(v))); }
+template <bool RIGHT> __device__ __forceinline__ double dppShift(double v) {
+    const int lo = dppShift<RIGHT>(__double2loint(v)), hi = dppShift<RIGHT>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 // The K sums of a POSTED all-reduce (OptAmd_MailRef, include/OptAmd.h): every rank's contribution arrives in this rank's mailbox as tagged 8-byte words;
 // thread (source rank r, word w) polls its word until it carries the tag, then K threads add the contributions in rank order -- the same bits on every
 // rank and in every workgroup.  A poll that outlasts the time-out raises the communicator's error flag and yields NaN.  scratch: >= world * 2K unsigned +

@@ -195,16 +195,6 @@ struct Raw {        // one pixel's loads, not yet combined (keeps the loads inde
     int f, ok;      // raw flag byte; ok = the pixel exists (known without the load)
 };
 
-// DPP whole-wave shifts (gfx9 family): wave_shr:1 gives lane i the value of lane i-1, wave_shl:1 of lane i+1;
-// lanes shifted in from outside the wave read 0 (bound_ctrl).  One v_mov_b32_dpp per 32-bit word, no LDS.
-template <bool RIGHT> __device__ __forceinline__ int dppShift(int v) {
-    return RIGHT ? __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true) : __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true);
-}
-template <bool RIGHT> __device__ __forceinline__ float dppShift(float v) { return __int_as_float(dppShift<RIGHT>(__float_as_int(v))); }
-template <bool RIGHT> __device__ __forceinline__ double dppShift(double v) {
-    const int lo = dppShift<RIGHT>(__double2loint(v)), hi = dppShift<RIGHT>(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
 template <bool RIGHT, class T> __device__ __forceinline__ Px<T> dppShiftPx(const Px<T>& p) {
     Px<T> q;
     q.ox = dppShift<RIGHT>(p.ox); q.oy = dppShift<RIGHT>(p.oy); q.a = dppShift<RIGHT>(p.a); q.c = dppShift<RIGHT>(p.c); q.s = dppShift<RIGHT>(p.s);
@@ -650,7 +640,10 @@ __global__ __launch_bounds__(kBlock) void iw_finishUpdate(T* __restrict__ XO, T*
 // beta (round 3: profiles/r03_horizon_parity.md, adversarial family: 4.6e-2 of cost after 20 iterations against 4e-4 for the three-kernel loop).  So every
 // term is formed from the same M, r, Ap in double, where a product of two floats is exact: the expansion then equals the direct sum of the reference's
 // PCGStep2 up to the rounding of z and r themselves (1e-7 relative, no amplification).
-template <class T> __device__ __forceinline__ double dprod3(T m, T a, T b) { return ((double)m * (double)a) * (double)b; }
+#ifndef IW_EXACT_SUMS
+#define IW_EXACT_SUMS 1      // 0: products in opt_float (round 2), A/B builds only (opt_amd/build.py build_variant)
+#endif
+template <class T> __device__ __forceinline__ double dprod3(T m, T a, T b) { return IW_EXACT_SUMS ? ((double)m * (double)a) * (double)b : (double)((m * a) * b); }
 
 template <class T>
 struct IterRaw {           // one pixel's loads, untouched (any ALU op here would force a wait before the loop back-edge)

@@ -446,6 +446,178 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
     }
 }
 
+// ---- the same PCG iteration as a ROW-MARCHING kernel (round 3) ---------------------------------------------------------------------------------
+// sfs_applyTiled<.., ITER> is latency-bound: three barrier-separated LDS phases per 32 x 8 tile, a 36 x 12 footprint staged for 256 outputs (1.7 x), 0.49 of
+// the HBM peak on a problem that sits in the Infinity Cache.  sfs_pcgMarch does the same work in the layout of image_warping's iteration
+// kernel: a wave owns 64 consecutive columns (the inner 60 are outputs; two halo lanes per side, because a pixel's gather reads row values on its 1-ring and
+// those read p_k on their 1-ring) and marches down a range of rows, a lane keeping four staged rows of its column, two rows of dB.v and three rows of the five
+// row values in registers.  Vertical neighbours cost nothing, horizontal ones are DPP wave shifts; there is no LDS staging and no barrier in the loop.
+// Trip Y stages row Y (PCGStep2 + PCGStep3 of the previous iteration: r_k, p_k, and for the rows the workgroup owns the stores of r_k, p_k, delta and the Q
+// sum), forms b(Y) = dB_I(., Y) . p_k, the five row values (J p_k)_r of the centres of row Y - 1, and the gather of row Y - 2 -- the expressions of
+// sfs_applyTiled in the same order, so the results are the tiled kernel's bit for bit.
+template <class T> struct SRaw { T r, p, ap, g0, g1, g2, vl, di, ctc, dl, bb; int mr, mc; };
+template <class T> struct SRow {
+    T v, rk;               // p_k (what J^T J is applied to), r_k
+    T g0, g1, g2, ctc;     // dB_I / d{d0, d1, d2} (0 outside the image), CtC
+    int mr, mc;            // edge masks, 0 unless the pixel is an interior row centre
+    int ok, valid, ex;     // interior row centre; ... whose regularisation rows are on; D_i > 0 (the unknown is not excluded)
+};
+template <class T> struct SQ { T gh, gv, s0, s1, s2; };
+#ifndef SFS_MARCH_WAVES
+#define SFS_MARCH_WAVES 2
+#endif
+constexpr int kSfsMarchBlock = SFS_MARCH_WAVES * kWave, kSfsSpan = kWave - 4;
+template <class T, bool LM>
+__global__ __launch_bounds__(kSfsMarchBlock) void sfs_pcgMarch(SArgs<T> A, T* __restrict__ out, const T* __restrict__ CtC, SIterK<T> K, int rowsPerGroup, int gx, int gy, int gyPerXcd) {
+    __shared__ double scratch[6 * (kSfsMarchBlock / kWave + 1)];
+    T alpha = 0, beta = 0;
+    const bool keep = K.first != 0 || K.restart != 0;              // r (and, at the start, p) are already those of this iteration
+    if (K.restart) {
+        const double* const ps[2] = {K.betaNum, K.betaDen}; const int ns[2] = {K.nBetaNum, K.nBetaDen}; double o2[2];
+        sumPartialsN<2>(ps, ns, scratch, o2);
+        const T bNum = (T)o2[0], bDen = (T)o2[1];
+        beta = (bDen > T(0)) ? bNum / bDen : T(0);                 // solver.t:544-547
+    } else if (!K.first) {
+        const double* const ps[5] = {K.aNumPrev, K.aDenPrev, K.s2Prev, K.s3Prev, K.rrPrev}; const int ns[5] = {K.nNum, K.nDen, K.n2, K.n3, K.rrFromPrivate ? K.nRR : 0}; double o5[5];
+        sumPartialsN<5>(ps, ns, scratch, o5);
+        const T aNum = (T)o5[0], aDen = (T)o5[1];
+        alpha = (aDen > T(0)) ? aNum / aDen : T(0);                // solver.t:456-459
+        const double rr = K.rrFromPrivate ? o5[4] : o5[0];
+        const double bNumD = fmax(rr - 2.0 * (double)alpha * o5[2] + (double)alpha * (double)alpha * o5[3], 0.0);
+        beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
+    }
+    // workgroup -> (column strip, row group); the 8 XCDs take contiguous ranges of row groups, so that the halo rows two vertically adjacent workgroups both
+    // stage are served by one L2
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int by = xcd * gyPerXcd + slot / gx, bx = slot % gx;
+    const bool idle = by >= gy || slot / gx >= gyPerXcd;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int x = bx * (kSfsMarchBlock / kWave) * kSfsSpan + wave * kSfsSpan + lane - 2;
+    const bool xin = x >= 0 && x < A.W;
+    const bool writer = xin && lane >= 2 && lane < 2 + kSfsSpan;
+    const int yb = idle ? A.H : by * rowsPerGroup, ye = idle ? A.H : min(yb + rowsPerGroup, A.H);
+    const int xc = min(max(x, 0), A.W - 1);
+    const T cxc = coefK(A, 0, x, 0), cxl = coefK(A, 0, x - 1, 0), cxr = coefK(A, 0, x + 1, 0);      // P(u) coefficients of this column and its neighbours
+    double acc = 0, accNum = 0, acc2 = 0, acc3 = 0, accRR = 0, accQ = 0;
+
+    auto load = [&](int y) {      // clamped addresses: no branch around a load, masked when staged
+        SRaw<T> w;
+        const long g = (long)min(max(y, 0), A.H - 1) * A.W + xc;
+        w.r = K.rOld[g]; w.p = K.pOld[g]; w.ap = K.ApOld[g];
+        w.g0 = A.g0[g]; w.g1 = A.g1[g]; w.g2 = A.g2[g]; w.vl = A.valid[g]; w.mr = A.mR[g]; w.mc = A.mC[g];
+        w.di = A.D_i[g]; w.ctc = LM ? CtC[g] : T(0); w.dl = K.delta[g]; w.bb = LM ? K.b[g] : T(0);
+        return w;
+    };
+    auto stage = [&](const SRaw<T>& w, int y) {
+        SRow<T> n;
+        const bool in = xin && y >= 0 && y < A.H;
+        T rk = 0, pk = 0;
+        if (in) {
+            rk = keep ? w.r : w.r - alpha * w.ap;                                      // PCGStep2 (solver.t:464)
+            pk = K.first ? w.p : rk + beta * w.p;                                      // PCGStep3 with z = r (solver.t:549)
+        }
+        n.v = pk; n.rk = rk;
+        n.g0 = in ? w.g0 : T(0); n.g1 = in ? w.g1 : T(0); n.g2 = in ? w.g2 : T(0); n.ctc = w.ctc;
+        const bool ok = in && sfs_interior(A, x, y);
+        n.ok = ok; n.mr = ok ? w.mr : 0; n.mc = ok ? w.mc : 0; n.valid = ok && w.vl == T(1);
+        n.ex = in && w.di > T(0);
+        if (writer && y >= yb && y < ye) {                                             // this workgroup's own rows
+            const long g = (long)y * A.W + x;
+            K.rNew[g] = rk; K.pNew[g] = pk;
+            if (!keep) {                                                               // the rest of PCGStep2 of iteration k-1 for this pixel
+                const T dl = w.dl + alpha * w.p;                                       // solver.t:461-462
+                K.deltaOut[g] = dl;
+                if (LM) accQ += (double)(T(0.5) * (dl * (rk + w.bb)));                 // solver.t:483-485
+            }
+        }
+        return n;
+    };
+    auto cyOf = [&](int y) { return coefK(A, 1, 0, y); };
+
+    // rows y+2, y+1, y, y-1 of the output row y; b = dB_I . v of rows y+2 / y+1; row values of rows y+1, y, y-1
+    SRow<T> R1{}, R2{}, R3{};
+    SQ<T> q2{}, q3{};
+    T b1 = 0, cy1 = 0, cy2 = 0;
+    SRaw<T> raw = load(yb - 2);
+    for (int Y = yb - 2; Y < ye + 2; ++Y) {
+        const SRaw<T> cur = raw;
+        raw = load(Y + 1);                                                             // the next row is in flight while this one is worked on
+        const SRow<T> n = stage(cur, Y);
+        const T cyN = cyOf(Y);
+        // b(., Y) = g1 v + g0 v(x-1) + g2 v(y-1)                                      (sfs_rows<3>'s `base`)
+        const T vL = dppShift<true>(n.v);
+        const T bY = n.g1 * n.v + n.g0 * vL + n.g2 * R1.v;
+        // row values at the centres of row Y - 1 (R1)
+        SQ<T> qn;
+        {
+            const T right = dppShift<false>(b1);
+            qn.gh = R1.ok ? A.w_g * (T)R1.mr * (b1 - right) : T(0);
+            qn.gv = R1.ok ? A.w_g * (T)R1.mc * (b1 - bY) : T(0);
+            const T v1l = dppShift<true>(R1.v), v1r = dppShift<false>(R1.v);
+            T js[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const T c0 = k == 0 ? cxc : k == 1 ? cy1 : T(1), cl = k == 0 ? cxl : k == 1 ? cy1 : T(1), cu = k == 0 ? cxc : k == 1 ? cy2 : T(1),
+                        cr = k == 0 ? cxr : k == 1 ? cy1 : T(1), cd = k == 0 ? cxc : k == 1 ? cyN : T(1);
+                T sj = 0;
+                sj += (T(4) * c0) * R1.v; sj += (T(-1) * cl) * v1l; sj += (T(-1) * cu) * R2.v; sj += (T(-1) * cr) * v1r; sj += (T(-1) * cd) * n.v;
+                js[k] = R1.valid ? A.w_s * sj : T(0);
+            }
+            qn.s0 = js[0]; qn.s1 = js[1]; qn.s2 = js[2];
+        }
+        // gather of row y = Y - 2 (centre row R2; row values qn at y + 1, q2 at y, q3 at y - 1)
+        {
+            const int y = Y - 2;
+            const T ve = R2.v;
+            T s = 0;
+            auto add = [&](T coef, T q) { s += coef * q; };
+            add(A.w_p, A.w_p * ve);
+            const T g0r = dppShift<false>(R2.g0);
+            const int mrR = dppShift<false>(R2.mr), mrL = dppShift<true>(R2.mr), okR = dppShift<false>(R2.ok), okL = dppShift<true>(R2.ok);
+            const int mr1L = dppShift<true>(R1.mr), ok1L = dppShift<true>(R1.ok);
+            const int mcR = dppShift<false>(R2.mc), mc3R = dppShift<false>(R3.mc), ok3R = dppShift<false>(R3.ok);
+            { const T m = A.w_g * (T)R2.mr; T coef = m * (R2.g1 - g0r); coef = R2.ok ? coef : T(0); add(coef, q2.gh); }                       // gh, centre (x, y)
+            { const T m = A.w_g * (T)mrR; T coef = m * g0r; coef = okR ? coef : T(0); add(coef, dppShift<false>(q2.gh)); }                     // (x+1, y)
+            { const T m = A.w_g * (T)R1.mr; T coef = m * R1.g2; coef = R1.ok ? coef : T(0); add(coef, qn.gh); }                                 // (x, y+1)
+            { const T m = A.w_g * (T)mrL; T coef = -(m * R2.g1); coef = okL ? coef : T(0); add(coef, dppShift<true>(q2.gh)); }                  // (x-1, y)
+            { const T m = A.w_g * (T)mr1L; T coef = -(m * R1.g2); coef = ok1L ? coef : T(0); add(coef, dppShift<true>(qn.gh)); }                // (x-1, y+1)
+            { const T m = A.w_g * (T)R2.mc; T coef = m * (R2.g1 - R1.g2); coef = R2.ok ? coef : T(0); add(coef, q2.gv); }                       // gv, centre (x, y)
+            { const T m = A.w_g * (T)mcR; T coef = m * g0r; coef = okR ? coef : T(0); add(coef, dppShift<false>(q2.gv)); }                     // (x+1, y)
+            { const T m = A.w_g * (T)R1.mc; T coef = m * R1.g2; coef = R1.ok ? coef : T(0); add(coef, qn.gv); }                                 // (x, y+1)
+            { const T m = A.w_g * (T)R3.mc; T coef = -(m * R2.g1); coef = R3.ok ? coef : T(0); add(coef, q3.gv); }                              // (x, y-1)
+            { const T m = A.w_g * (T)mc3R; T coef = -(m * g0r); coef = ok3R ? coef : T(0); add(coef, dppShift<false>(q3.gv)); }                 // (x+1, y-1)
+            const int vR = dppShift<false>(R2.valid), vLft = dppShift<true>(R2.valid);
+            auto reg = [&](int valid, T w4, T a0, T a1, T a2) {
+                const T wgt = valid ? A.w_s * w4 : T(0);
+                add(wgt * cxc, a0); add(wgt * cy2, a1); add(wgt * T(1), a2);
+            };
+            reg(R2.valid, T(4), q2.s0, q2.s1, q2.s2);
+            reg(vR, T(-1), dppShift<false>(q2.s0), dppShift<false>(q2.s1), dppShift<false>(q2.s2));
+            reg(vLft, T(-1), dppShift<true>(q2.s0), dppShift<true>(q2.s1), dppShift<true>(q2.s2));
+            reg(R1.valid, T(-1), qn.s0, qn.s1, qn.s2);
+            reg(R3.valid, T(-1), q3.s0, q3.s1, q3.s2);
+            if (LM) s += R2.ctc * ve;
+            if (!R2.ex) s = 0;
+            if (writer && y >= yb && y < ye) {
+                out[(long)y * A.W + x] = s;
+                acc += (double)(ve * s);
+                const T rk = R2.rk;
+                const T zk = K.first ? ve : rk;                                        // launch 0: alphaNumerator_0 = r_0 . p_0 (the reference's start)
+                accNum += (double)(zk * rk); acc2 += (double)(rk * s); acc3 += (double)(s * s);
+                if (K.first) accRR += (double)(rk * rk);
+            }
+        }
+        R3 = R2; R2 = R1; R1 = n; q3 = q2; q2 = qn; b1 = bY; cy2 = cy1; cy1 = cyN;
+    }
+    double vv[6] = {acc, accNum, acc2, acc3, accRR, accQ};
+    blockReduceSumN<6>(vv, scratch);
+    if (threadIdx.x == 0) {
+        K.aDen[blockIdx.x] = vv[0]; K.aNum[blockIdx.x] = vv[1]; K.s2[blockIdx.x] = vv[2]; K.s3[blockIdx.x] = vv[3];
+        if (K.first) K.rr[blockIdx.x] = vv[4];
+        if (LM && K.q) { if (K.qTag) storeTaggedPartial(K.q, blockIdx.x, vv[5], K.qTag); else K.q[blockIdx.x] = vv[5]; }
+    }
+}
+
 template <class T>
 struct SfsOps : EnergyOps<T> {
     SArgs<T> A{};
@@ -463,6 +635,8 @@ struct SfsOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_SFS_TILED")) tiledApply = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_SFS_ONEKERNEL")) oneKernel = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_SFS_GRID")) gridOverride = atoi(e);
+        if (const char* e = getenv("OPT_AMD_SFS_MARCH")) marchIter = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_SFS_MARCH_GRID")) marchGridOverride = atoi(e);
     }
     ~SfsOps() override { for (void* p : owned) (void)hipFree(p); }
     int grid() const { return (int)std::max<long>(1, std::min<long>(((long)A.W * A.H + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
@@ -516,13 +690,31 @@ struct SfsOps : EnergyOps<T> {
     }
     // ---- one kernel per PCG iteration (sfs_applyTiled<.., ITER>) ----
     bool oneKernel = true;              // OPT_AMD_SFS_ONEKERNEL=0: three kernels per iteration (A/B switch)
+    bool marchIter = true;              // OPT_AMD_SFS_MARCH=0: the LDS-tiled iteration kernel of round 2 (A/B switch)
+    int occMarch[2] = {0, 0}, marchGridOverride = 0;
     double* rrPartials = nullptr; int nRR = 0; bool prevWasFirst = false;
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
         if (!oneKernel || !tiledApply || a.pre || this->slab.active) return false;       // this energy does not precondition (pre == nullptr)
         if (a.ApNew == a.ApOld || a.rNew == a.rOld || a.pNew == a.pOld) return false;     // neighbouring tiles read the old apron while this one writes
         if (!rrPartials) { HIP_CHECK(hipMalloc((void**)&rrPartials, kMaxPartials * sizeof(double))); owned.push_back(rrPartials); }
         const bool lmLoop = a.CtC != nullptr;
-        const int g = tileGrid(lmLoop, true);
+        int g = tileGrid(lmLoop, true);
+        // the marching kernel's grid: column strips of kSfsSpan columns per wave x row groups sized to be co-resident, 8 XCD-contiguous ranges of row groups
+        int mgx = 0, mgy = 0, mRows = 0, mPer = 0;
+        if (marchIter) {
+            int& o = occMarch[lmLoop];
+            if (o == 0) {
+                const void* fn = lmLoop ? (const void*)sfs_pcgMarch<T, true> : (const void*)sfs_pcgMarch<T, false>;
+                HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, fn, kSfsMarchBlock, 0));
+                o = std::max(1, std::min(o, 16));
+            }
+            mgx = divUp(A.W, (kSfsMarchBlock / kWave) * kSfsSpan);
+            const int target = marchGridOverride > 0 ? marchGridOverride : cus * o;
+            mgy = std::max(1, std::min(std::min(A.H, target / mgx), (kMaxPartials / 2 - 8 * mgx) / mgx));
+            mRows = divUp(A.H, mgy); mgy = divUp(A.H, mRows);
+            mPer = divUp(mgy, 8);
+            g = 8 * mPer * mgx;
+        }
         SIterK<T> K{};
         K.rOld = a.rOld; K.ApOld = a.ApOld; K.pOld = a.pOld; K.rNew = a.rNew; K.pNew = a.pNew; K.delta = a.delta; K.deltaOut = a.deltaOut ? a.deltaOut : a.delta;
         K.b = a.b; K.q = a.q ? a.q->partials : nullptr; K.qTag = a.qTag; K.first = a.first; K.restart = a.afterReset;
@@ -533,7 +725,11 @@ struct SfsOps : EnergyOps<T> {
         K.aNum = a.aNum->partials; K.aDen = a.aDen->partials; K.s2 = a.s2->partials; K.s3 = a.s3->partials; K.rr = rrPartials;
         {
             ScopedKernel k(ctx, "PCGIteration");
-            if (lmLoop) sfs_applyTiled<T, true, true><<<g, kBlock, 0, ctx.stream>>>(A, nullptr, a.ApNew, a.CtC, nullptr, K);
+            if (marchIter) {
+                if (lmLoop) sfs_pcgMarch<T, true><<<g, kSfsMarchBlock, 0, ctx.stream>>>(A, a.ApNew, a.CtC, K, mRows, mgx, mgy, mPer);
+                else sfs_pcgMarch<T, false><<<g, kSfsMarchBlock, 0, ctx.stream>>>(A, a.ApNew, nullptr, K, mRows, mgx, mgy, mPer);
+            }
+            else if (lmLoop) sfs_applyTiled<T, true, true><<<g, kBlock, 0, ctx.stream>>>(A, nullptr, a.ApNew, a.CtC, nullptr, K);
             else sfs_applyTiled<T, false, true><<<g, kBlock, 0, ctx.stream>>>(A, nullptr, a.ApNew, nullptr, nullptr, K);
         }
         if (a.first) nRR = g;
