@@ -112,6 +112,17 @@ typedef struct OptAmd_MailRef {
     int* errFlag;
 } OptAmd_MailRef;
 
+/* The producer side of a posted all-reduce when the PRODUCER KERNEL performs the post itself (OptAmd_SlabCommExt.allReducePlan): the kernel's workgroups
+ * write their partial sums as usual, take a ticket from *ticket (device-scope atomic add, zero when the kernel starts); the workgroup that draws the last
+ * one adds up all partials (256 threads, the order of the communicator's own post kernel) and stores value i of its n sums as the two tagged words
+ * dst[t][2 i], dst[t][2 i + 1] = (tag << 32) | payload half into the mailbox of every rank t < world, then resets *ticket to 0. */
+typedef struct OptAmd_MailPost {
+    unsigned long long* dst[16];
+    int world;
+    unsigned tag;
+    unsigned* ticket;
+} OptAmd_MailPost;
+
 /* Optional accelerations of a communicator; any member may be NULL.  `size` must be sizeof(OptAmd_SlabCommExt) as the caller compiled it (a library
  * built against a longer struct reads no member beyond it), and the struct must be zero-initialised before the members are set. */
 typedef struct OptAmd_SlabCommExt {
@@ -125,6 +136,11 @@ typedef struct OptAmd_SlabCommExt {
      * contributions are still crossing the links, instead of behind a kernel that waited for them.  Returns 0 if unavailable.  n <= 8.  At most two
      * posted all-reduces may be outstanding (the mailbox has four slots). */
     int (*allReducePost)(void* ctx, const double* const* partials, const int* counts, int n, OptAmd_MailRef* ref, void* stream);
+    /* The same without any kernel of the communicator's: reserves the next all-reduce and describes it -- *post for the kernel that produces the n sums
+     * (it posts them itself from its last workgroup, OptAmd_MailPost), *ref for the kernel that consumes them.  Between two PCG iteration kernels there is
+     * then nothing at all.  Returns 0 if unavailable.  The reserved all-reduce MUST be carried out by a kernel enqueued before the next call of any entry point
+     * of this communicator. */
+    int (*allReducePlan)(void* ctx, int n, OptAmd_MailPost* post, OptAmd_MailRef* ref);
 } OptAmd_SlabCommExt;
 /* Attach a slab description to a plan created with dims {W, rows + 2*g}: g >= 1 ghost rows above and below the `rows` owned
  * rows (g is inferred from the plan's height).  g = 1 is enough for every kernel set; with g >= 2 image_warping runs its

@@ -275,6 +275,18 @@ int peerAllReducePost(void* c, const double* const* parts, const int* counts, in
     ref->world = x->world; ref->stride = 2 * kMaxVals; ref->tag = (unsigned)seq; ref->timeoutTicks = x->timeoutTicks; ref->errFlag = (int*)x->hostErr;
     return 1;
 }
+int peerAllReducePlan(void* c, int n, OptAmd_MailPost* post, OptAmd_MailRef* ref) {
+    auto* x = (PeerCtx*)c;
+    checkErr(x, "allReducePlan");
+    if (n > kMaxVals || !post || !ref) return 0;
+    const u64 seq = ++x->arSeq;
+    const int slot = (int)(seq % kSlots);
+    for (int t = 0; t < kMaxWorld; ++t) post->dst[t] = t < x->world ? &x->win[t]->ll[slot][x->rank][0] : nullptr;
+    post->world = x->world; post->tag = (unsigned)seq; post->ticket = x->dCounter + 2;
+    ref->words = &x->win[x->rank]->ll[slot][0][0];
+    ref->world = x->world; ref->stride = 2 * kMaxVals; ref->tag = (unsigned)seq; ref->timeoutTicks = x->timeoutTicks; ref->errFlag = (int*)x->hostErr;
+    return 1;
+}
 void peerHalo(void* c, int nb, const void* const* su, const void* const* sd, void* const* ru, void* const* rd, const long* bytes, void* stream) {
     auto* x = (PeerCtx*)c; hipStream_t s = (hipStream_t)stream;
     checkErr(x, "haloExchange");
@@ -334,8 +346,8 @@ void* OptComm_PeerCreate(int rank, int world, long stageBytes, double timeoutSec
     CK_HIP(hipDeviceSynchronize());
     x->win[rank] = (Window*)x->base;
     x->stage[rank] = (char*)x->base + (sizeof(Window) + 255) / 256 * 256;
-    CK_HIP(hipMalloc((void**)&x->dCounter, 2 * sizeof(unsigned int)));
-    CK_HIP(hipMemset(x->dCounter, 0, 2 * sizeof(unsigned int)));
+    CK_HIP(hipMalloc((void**)&x->dCounter, 4 * sizeof(unsigned int)));      // [0], [1]: last-block counters of the halo kernels; [2]: ticket of in-kernel posts
+    CK_HIP(hipMemset(x->dCounter, 0, 4 * sizeof(unsigned int)));
     CK_HIP(hipHostMalloc((void**)&x->hostErr, sizeof(int), hipHostMallocMapped));
     *x->hostErr = 0;
     x->timeoutTicks = (long long)((timeoutSeconds > 0 ? timeoutSeconds : 20.0) * 1e8);       // wall_clock64 runs at 100 MHz
@@ -344,6 +356,8 @@ void* OptComm_PeerCreate(int rank, int world, long stageBytes, double timeoutSec
     x->ext.size = sizeof(OptAmd_SlabCommExt); x->ext.allReducePartials = peerAllReducePartials;
     if (const char* e = getenv("OPT_AMD_PEER_POST")) { if (atoi(e) != 0) x->ext.allReducePost = peerAllReducePost; }      // A/B switch; default below
     else x->ext.allReducePost = peerAllReducePost;
+    if (const char* e = getenv("OPT_AMD_PEER_PLAN")) { if (atoi(e) != 0) x->ext.allReducePlan = peerAllReducePlan; }      // A/B switch; default below
+    else if (x->ext.allReducePost) x->ext.allReducePlan = peerAllReducePlan;
     return x;
 }
 void OptComm_PeerHandle(void* c, char* out) { memcpy(out, &((PeerCtx*)c)->handle, sizeof(hipIpcMemHandle_t)); }

@@ -175,6 +175,46 @@ __device__ __forceinline__ void pollMailSums(const MailRefDev& M, double* scratc
     __syncthreads();
 }
 
+// The producer side (OptAmd_MailPost): called by every workgroup of a kernel after thread 0 has stored the workgroup's K partial sums partials[k][blockIdx.x].
+// The workgroup that draws the last ticket sums the gridDim.x partials of each array with its first 256 threads -- the arithmetic of the communicator's own
+// post kernel (k_mailPost), hence the same bits -- and stores the tagged words into every rank's mailbox.  blockDim >= 256.
+struct MailPostDev { unsigned long long* dst[16]; int world; unsigned tag; unsigned* ticket; };
+template <int K>
+__device__ __forceinline__ void postMailSums(const MailPostDev& P, double* const (&partials)[K], double* scratch /* >= 5 K doubles */) {
+    __shared__ int isLast;
+    const int tid = threadIdx.x + threadIdx.y * blockDim.x;
+    if (tid == 0) {
+        // release the partials (agent scope: the other workgroups may sit on other XCDs with their own L2), take a ticket, acquire what the earlier tickets released
+        const unsigned t = __hip_atomic_fetch_add(P.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        isLast = t == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!isLast) return;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);                   // every thread of the last workgroup, not only the ticket holder
+    const int lane = tid & (kWave - 1), wave = tid >> 6, n = gridDim.x;
+    double t[K];
+    if (tid < 256) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            t[k] = 0;
+            for (int i = tid; i < n; i += 256) t[k] += __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)(partials[k] + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) { t[k] = waveReduceSum(t[k]); if (lane == 0) scratch[k * 4 + wave] = t[k]; }
+    }
+    __syncthreads();
+    if (tid < K) scratch[4 * K + tid] = ((scratch[tid * 4] + scratch[tid * 4 + 1]) + scratch[tid * 4 + 2]) + scratch[tid * 4 + 3];
+    __syncthreads();
+    const int nw = 2 * K;
+    if (tid < P.world * nw) {
+        const int r = tid / nw, w = tid % nw;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(scratch[4 * K + (w >> 1)]);
+        const unsigned half = (w & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+        __hip_atomic_store(P.dst[r] + w, ((unsigned long long)P.tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (tid == 0) __hip_atomic_store(P.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next launch (ordered by the kernel boundary)
+}
+
 // ---- per-kernel hipEvent timing (reference util.t:404-511) ---------------------------------------------
 struct KernelTimer {
     bool enabled = false;

@@ -58,6 +58,9 @@ struct PcgIterArgs {
     // Slab mode with a communicator that posts its all-reduces (OptAmd_SlabCommExt.allReducePost): the four sums of the previous launch are not in
     // aNumPrev .. s3Prev but in flight to this rank's mailbox; the kernel's prologue polls them there (mail.words != nullptr; value order aNum, aDen, s2, s3).
     OptAmd_MailRef mail = {nullptr, 0, 0, 0, 0, nullptr};
+    // ... and, if the communicator can plan a post (allReducePlan), THIS launch posts its own four sums from its last workgroup (post.world != 0): no kernel
+    // of the communicator's between two iterations.
+    OptAmd_MailPost post = {};
     T* deltaOut = nullptr;                               // if set, the updated delta goes here instead of in place (lets the solver enqueue
                                                          // the next launch before it has read Q: an early-out then still finds the old delta)
 };
@@ -80,6 +83,8 @@ struct EnergyOps {
     bool iterStateExchange = false;   // set by pcgIteration: in slab mode the solver exchanges the ghost rows of r and p after a launch (else of Ap before it)
     bool iterExchangeDue = true;      // ... and whether that exchange is needed after THIS launch (deep ghost zones let a kernel skip some)
     bool iterTakesMail = false;       // set by pcgIteration: its kernels can read the previous launch's sums from a posted all-reduce (PcgIterArgs::mail)
+    // Before the first launch of a loop: would pcgIteration's kernels carry out a planned post themselves and poll the mailbox (PcgIterArgs::post / mail)?
+    virtual bool iterPostsItself(bool /*lm*/) const { return false; }
     virtual ~EnergyOps() {}
     void addUnknown(int param, long elems, int channels) {
         unknowns.push_back({param, elems, channels, nScalars});

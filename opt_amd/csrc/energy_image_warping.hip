@@ -683,6 +683,7 @@ struct IterK {             // kernel argument block
     // neighbours' rows are needed only every few launches; the sums and delta stay on the owned rows [ownBegin, ownEnd) (image rows)
     int ownBegin, ownEnd;
     MailRefDev mail;       // slab mode, posted all-reduce: where the prologue polls the previous launch's four sums (words == nullptr: they are in aNumPrev .. s3Prev)
+    MailPostDev post;      // ... and where this launch's last workgroup posts its own four sums (world == 0: it does not)
 };
 
 // PRE: 0 = identity preconditioner, 1 = the solver's 3-channel one (12 B/px), 2 = compact {M_O, M_a} (8 B/px).  A template
@@ -1240,6 +1241,10 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAV
         K.aDen[blockIdx.x] = v[0]; K.aNum[blockIdx.x] = v[1]; K.s2[blockIdx.x] = v[2]; K.s3[blockIdx.x] = v[3];
         if (LM) { if (K.qTag) storeTaggedPartial(K.q, blockIdx.x, v[4], K.qTag); else K.q[blockIdx.x] = v[4]; }
     }
+    if (!LM && K.post.world) {      // slab mode: the last workgroup to finish posts the four sums (order of the consumer's poll: aNum, aDen, s2, s3) to every rank's mailbox
+        double* const parts[4] = {K.aNum, K.aDen, K.s2, K.s3};
+        postMailSums<4>(K.post, parts, scratch);
+    }
 }
 
 // delta += alpha[0] * p over n scalars (the deferred term left over when the PCG loop ends on an odd launch)
@@ -1633,7 +1638,9 @@ struct ImageWarpingOps : EnergyOps<T> {
                    a.deltaOut ? a.deltaOut : a.delta, a.lmRadius, a.lmMinDiag, a.lmMaxDiag,
                    a.aNumPrev.partials, a.aDenPrev.partials, a.s2Prev.partials, a.s3Prev.partials, a.aNumPrev.n, a.aDenPrev.n, a.s2Prev.n, a.s3Prev.n,
                    a.aNum->partials, a.aDen->partials, a.s2->partials, a.s3->partials, A.yBegin, A.yEnd,
-                   MailRefDev{a.mail.words, a.mail.world, a.mail.stride, a.mail.tag, a.mail.timeoutTicks, a.mail.errFlag}};
+                   MailRefDev{a.mail.words, a.mail.world, a.mail.stride, a.mail.tag, a.mail.timeoutTicks, a.mail.errFlag}, MailPostDev{}};
+        for (int t = 0; t < 16; ++t) K.post.dst[t] = a.post.dst[t];
+        K.post.world = a.post.world; K.post.tag = a.post.tag; K.post.ticket = a.post.ticket;
         {
             ScopedKernel k(ctx, "PCGIteration");
             int rpg = rowsPerGroup, gxa = gx, gya = gy;
@@ -1693,6 +1700,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         iw_modelCost<T><<<g, kBlock, 0, ctx.stream>>>(A, delta, out.partials);
         out.n = g;
     }
+    bool iterPostsItself(bool lmLoop) const override { return !lmLoop && recomputeAp && this->slab.active && this->slab.ghost >= 2 && (sizeof(T) == 4 ? true : true); }
     bool supportsSlab() const override { return true; }
     long rowScalars(int img) const override { return (long)A.W * (img == 0 ? 2 : 1); }
 };

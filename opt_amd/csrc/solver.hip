@@ -587,6 +587,11 @@ struct PcgSolver : SolverBase {
             a.aNumPrev = prev[0]; a.aDenPrev = prev[1]; a.s2Prev = prev[2]; a.s3Prev = prev[3];
             a.aNum = &setS[cur][0]; a.aDen = &setS[cur][1]; a.s2 = &setS[cur][2]; a.s3 = &setS[cur][3];
             a.mail = mail;
+            // the all-reduce of THIS launch's sums, carried out by the launch itself if the communicator can plan it and the kernel set can post
+            bool planned = false;
+            OptAmd_MailRef nextMail{nullptr, 0, 0, 0, 0, nullptr};
+            if (distributed && commExt.allReducePlan && lIter + 1 < sp.lIterations && !traceEnabled && E->iterPostsItself(false))
+                planned = commExt.allReducePlan(comm.ctx, 4, &a.post, &nextMail) != 0;
             if (distributed && lIter > 0 && !E->iterStateExchange) exchangeVector(Ap_X);   // kernel with Ap in memory: r and p ghost rows are kept current by the kernel itself
             if (!E->pcgIteration(a, ctx)) { if (lIter == 0) return false; fprintf(stderr, "pcgIteration refused mid-loop\n"); exit(1); }
             std::swap(r, r2); std::swap(Ap_X, Ap2); std::swap(p, p2);
@@ -604,8 +609,9 @@ struct PcgSolver : SolverBase {
                 // If the communicator can POST it and the next launch's prologue can poll the mailbox, nothing waits between the two launches: the
                 // contributions cross the links while the next kernel is being launched and requests its first rows.  The last iteration's sums are needed
                 // by the flat kernel that closes the loop: those take the complete all-reduce.
-                bool posted = false;
-                if (commExt.allReducePost && E->iterTakesMail && lIter + 1 < sp.lIterations && !traceEnabled) {
+                bool posted = planned;
+                if (planned) mail = nextMail;
+                if (!posted && commExt.allReducePost && E->iterTakesMail && lIter + 1 < sp.lIterations && !traceEnabled) {
                     const double* ps[4]; int ns[4];
                     for (int i = 0; i < 4; ++i) { ps[i] = setS[cur][i].partials; ns[i] = setS[cur][i].n; }
                     posted = commExt.allReducePost(comm.ctx, ps, ns, 4, &mail, (void*)stream) != 0;
@@ -1033,6 +1039,7 @@ struct PcgSolver : SolverBase {
         auto has = [&](size_t off, size_t sz) { return have >= off + sz; };
         if (has(offsetof(OptAmd_SlabCommExt, allReducePartials), sizeof(e->allReducePartials))) commExt.allReducePartials = e->allReducePartials;
         if (has(offsetof(OptAmd_SlabCommExt, allReducePost), sizeof(e->allReducePost))) commExt.allReducePost = e->allReducePost;
+        if (has(offsetof(OptAmd_SlabCommExt, allReducePlan), sizeof(e->allReducePlan))) commExt.allReducePlan = e->allReducePlan;
         commExt.size = sizeof(OptAmd_SlabCommExt);
         return 1;
     }

@@ -23,6 +23,7 @@ def run(mode, W, H, liters, steps):
     else:
         # "peer": the all-reduce is posted and polled by the next iteration kernel's prologue (round 3); "peer-wait": a kernel between two launches waits for it (round 2)
         os.environ["OPT_AMD_PEER_POST"] = "0" if mode == "peer-wait" else "1"
+        os.environ["OPT_AMD_PEER_PLAN"] = "1" if mode == "peer" else "0"          # "peer": the iteration kernel's last workgroup posts; "peer-post": a one-workgroup kernel posts
         job = slab.SlabJob("image_warping", W, H, 0, 1, comm="peer" if mode.startswith("peer") else mode)
         s, dev = job.solver, job.params
     s.set_parameter("nIterations", steps + 1); s.set_parameter("lIterations", liters)
@@ -49,7 +50,7 @@ def main():
     out = {}
     sizes = [(4096, 512), (4096, 1024), (4096, 2048), (8192, 1024)] if "--all" in sys.argv else [(4096, 512), (8192, 1024)]
     for (W, H) in sizes:
-        for mode in ("plain", "peer", "peer-wait", "rccl"):
+        for mode in ("plain", "peer", "peer-post", "peer-wait", "rccl"):
             us = run(mode, W, H, 400, 3)
             out[f"{W}x{H}_{mode}"] = us
             print(f"{W}x{H:5d} {mode:5s}: {us:7.1f} us per PCG iteration", flush=True)
