@@ -314,9 +314,12 @@ def main():
         if gf:
             rel = abs(final - gf[-1]) / abs(gf[-1])
             envd = abs(gf[-1] - gd[-1]) / abs(gd[-1]) if gd else None
+            # the float oracle's own cost goes UP on some Gauss-Newton steps once the solve has reached its rounding floor: the largest such increase is the noise
+            # every float implementation carries in its final energy (tests/test_horizon_gpu.py)
+            noise = max([0.0] + [(b - a) / a for a, b in zip(gf[1:], gf[2:]) if b > a])
             solve.update({"final_energy_oracle_float": gf[-1], "final_energy_oracle_double": gd[-1] if gd else None, "rel_err_vs_oracle_float": rel,
-                          "oracle_float_vs_double": envd, "within_contract_1e-5": rel <= 1e-5,
-                          "within_float_rounding_envelope": (rel <= max(1e-5, 2.0 * envd)) if envd is not None else None,
+                          "oracle_float_vs_double": envd, "oracle_float_step_to_step_increase": noise, "within_contract_1e-5": rel <= 1e-5,
+                          "within_float_noise_floor": rel <= max(1e-5, noise, 2.0 * envd if envd is not None else 0.0),
                           "source": "tests/golden/horizon_costs.json solve8_* (oracle, generated offline by tests/golden/make_horizon_costs.py)"})
         if comm_error():
             solve["comm_error"] = comm_error()

@@ -356,8 +356,10 @@ void* OptComm_PeerCreate(int rank, int world, long stageBytes, double timeoutSec
     x->ext.size = sizeof(OptAmd_SlabCommExt); x->ext.allReducePartials = peerAllReducePartials;
     if (const char* e = getenv("OPT_AMD_PEER_POST")) { if (atoi(e) != 0) x->ext.allReducePost = peerAllReducePost; }      // A/B switch; default below
     else x->ext.allReducePost = peerAllReducePost;
-    if (const char* e = getenv("OPT_AMD_PEER_PLAN")) { if (atoi(e) != 0) x->ext.allReducePlan = peerAllReducePlan; }      // A/B switch; default below
-    else if (x->ext.allReducePost) x->ext.allReducePlan = peerAllReducePlan;
+    // allReducePlan (the iteration kernel's last workgroup posts; no kernel of ours between two iterations) is OFF unless OPT_AMD_PEER_PLAN=1: measured on one GPU
+    // (tools/slab_overhead.py, profiles/r03_slab_overhead_posted_allreduce.txt) the device-scope release / acquire around the ticket costs more than the
+    // one-workgroup post kernel it removes -- 4096 x 512 slab: 36.6 us per iteration against 34.3 (k_mailPost) and 36.1 (round 2's waiting all-reduce); plain: 30.4
+    if (const char* e = getenv("OPT_AMD_PEER_PLAN")) { if (atoi(e) != 0) x->ext.allReducePlan = peerAllReducePlan; }
     return x;
 }
 void OptComm_PeerHandle(void* c, char* out) { memcpy(out, &((PeerCtx*)c)->handle, sizeof(hipIpcMemHandle_t)); }

@@ -32,6 +32,7 @@ struct SArgs {
     T w_p, w_s, w_g, f_x, f_y, u_x, u_y, L[9];
     const T* X; const T* D_i; const T* Im; const uint8_t* mR; const uint8_t* mC;
     T *B_I, *g0, *g1, *g2, *valid;     // ComputedArrays + gradient images
+    uint8_t* fl;                       // bit 0: D_i > 0 (the unknown is not excluded), bit 1: valid == 1 -- one byte for the marching iteration kernel instead of two doubles
     T* q;                              // 5 row values per pixel: [gh, gv, s0, s1, s2] planes
 };
 
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(kBlock) void sfs_precompute(SArgs<T> A) {
             vl = v ? T(1) : T(0);
         }
         A.B_I[e] = bi; A.g0[e] = g0; A.g1[e] = g1; A.g2[e] = g2; A.valid[e] = vl;
+        A.fl[e] = (uint8_t)((A.D_i[e] > T(0) ? 1 : 0) | (vl == T(1) ? 2 : 0));
     }
 }
 
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
 // Trip Y stages row Y (PCGStep2 + PCGStep3 of the previous iteration: r_k, p_k, and for the rows the workgroup owns the stores of r_k, p_k, delta and the Q
 // sum), forms b(Y) = dB_I(., Y) . p_k, the five row values (J p_k)_r of the centres of row Y - 1, and the gather of row Y - 2 -- the expressions of
 // sfs_applyTiled in the same order, so the results are the tiled kernel's bit for bit.
-template <class T> struct SRaw { T r, p, ap, g0, g1, g2, vl, di, ctc, dl, bb; int mr, mc; };
+template <class T> struct SRaw { T r, p, ap, g0, g1, g2, ctc, dl, bb; int mr, mc, fl; };
 template <class T> struct SRow {
     T v, rk;               // p_k (what J^T J is applied to), r_k
     T g0, g1, g2, ctc;     // dB_I / d{d0, d1, d2} (0 outside the image), CtC
@@ -500,12 +502,15 @@ __global__ __launch_bounds__(kSfsMarchBlock) void sfs_pcgMarch(SArgs<T> A, T* __
     const T cxc = coefK(A, 0, x, 0), cxl = coefK(A, 0, x - 1, 0), cxr = coefK(A, 0, x + 1, 0);      // P(u) coefficients of this column and its neighbours
     double acc = 0, accNum = 0, acc2 = 0, acc3 = 0, accRR = 0, accQ = 0;
 
-    auto load = [&](int y) {      // clamped addresses: no branch around a load, masked when staged
+    // Clamped addresses, masked when staged.  What only the workgroup's own rows need -- CtC, delta, b -- is read from row 0 on the halo rows (the same few cache
+    // lines every time: L1 / L2 hits, no branch around a load): a halo row (4 of 14-23 per workgroup) costs 51 B per pixel of memory traffic instead of 75.
+    auto load = [&](int y) {
         SRaw<T> w;
         const long g = (long)min(max(y, 0), A.H - 1) * A.W + xc;
         w.r = K.rOld[g]; w.p = K.pOld[g]; w.ap = K.ApOld[g];
-        w.g0 = A.g0[g]; w.g1 = A.g1[g]; w.g2 = A.g2[g]; w.vl = A.valid[g]; w.mr = A.mR[g]; w.mc = A.mC[g];
-        w.di = A.D_i[g]; w.ctc = LM ? CtC[g] : T(0); w.dl = K.delta[g]; w.bb = LM ? K.b[g] : T(0);
+        w.g0 = A.g0[g]; w.g1 = A.g1[g]; w.g2 = A.g2[g]; w.fl = A.fl[g]; w.mr = A.mR[g]; w.mc = A.mC[g];
+        const long go = (y >= yb && y < ye) ? g : (long)xc;
+        w.ctc = LM ? CtC[go] : T(0); w.dl = K.delta[go]; w.bb = LM ? K.b[go] : T(0);
         return w;
     };
     auto stage = [&](const SRaw<T>& w, int y) {
@@ -519,8 +524,8 @@ __global__ __launch_bounds__(kSfsMarchBlock) void sfs_pcgMarch(SArgs<T> A, T* __
         n.v = pk; n.rk = rk;
         n.g0 = in ? w.g0 : T(0); n.g1 = in ? w.g1 : T(0); n.g2 = in ? w.g2 : T(0); n.ctc = w.ctc;
         const bool ok = in && sfs_interior(A, x, y);
-        n.ok = ok; n.mr = ok ? w.mr : 0; n.mc = ok ? w.mc : 0; n.valid = ok && w.vl == T(1);
-        n.ex = in && w.di > T(0);
+        n.ok = ok; n.mr = ok ? w.mr : 0; n.mc = ok ? w.mc : 0; n.valid = ok && (w.fl & 2) != 0;
+        n.ex = in && (w.fl & 1) != 0;
         if (writer && y >= yb && y < ye) {                                             // this workgroup's own rows
             const long g = (long)y * A.W + x;
             K.rNew[g] = rk; K.pNew[g] = pk;
@@ -638,6 +643,7 @@ struct SfsOps : EnergyOps<T> {
         T** imgs[5] = {&A.B_I, &A.g0, &A.g1, &A.g2, &A.valid};
         for (auto pp : imgs) { HIP_CHECK(hipMalloc((void**)pp, n * sizeof(T))); HIP_CHECK(hipMemset(*pp, 0, n * sizeof(T))); owned.push_back(*pp); }
         HIP_CHECK(hipMalloc((void**)&A.q, 5 * n * sizeof(T))); owned.push_back(A.q);
+        HIP_CHECK(hipMalloc((void**)&A.fl, n)); HIP_CHECK(hipMemset(A.fl, 0, n)); owned.push_back(A.fl);
         int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (const char* e = getenv("OPT_AMD_SFS_TILED")) tiledApply = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_SFS_ONEKERNEL")) oneKernel = atoi(e) != 0;
@@ -716,7 +722,10 @@ struct SfsOps : EnergyOps<T> {
                 o = std::max(1, std::min(o, 16));
             }
             mgx = divUp(A.W, (kSfsMarchBlock / kWave) * kSfsSpan);
-            const int target = marchGridOverride > 0 ? marchGridOverride : cus * o;
+            // Rows per workgroup against workgroups in flight: every workgroup stages 4 halo rows on top of its own, and the kernel is bound by what it moves
+            // (measured at 1024^2 double LM, us per iteration: 1024 workgroups of 10 rows 44.0, 768 x 13 rows 41.6, 512 x 19 rows 42.1, 256 x 37 rows 59.3), so
+            // the default takes three quarters of the co-resident count.
+            const int target = marchGridOverride > 0 ? marchGridOverride : std::max(1, cus * o * 3 / 4);
             mgy = std::max(1, std::min(std::min(A.H, target / mgx), (kMaxPartials / 2 - 8 * mgx) / mgx));
             mRows = divUp(A.H, mgy); mgy = divUp(A.H, mRows);
             mPer = divUp(mgy, 8);
