@@ -469,8 +469,11 @@ template <class T> struct SQ { T gh, gv, s0, s1, s2; };
 #define SFS_MARCH_WAVES 2
 #endif
 constexpr int kSfsMarchBlock = SFS_MARCH_WAVES * kWave, kSfsSpan = kWave - 4;
+#ifndef SFS_MARCH_MINWAVES
+#define SFS_MARCH_MINWAVES 1      // waves per SIMD the register allocation must leave room for (3: at most 168 VGPRs -- the double kernel then spills; A/B builds)
+#endif
 template <class T, bool LM>
-__global__ __launch_bounds__(kSfsMarchBlock) void sfs_pcgMarch(SArgs<T> A, T* __restrict__ out, const T* __restrict__ CtC, SIterK<T> K, int rowsPerGroup, int gx, int gy, int gyPerXcd) {
+__global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMarch(SArgs<T> A, T* __restrict__ out, const T* __restrict__ CtC, SIterK<T> K, int rowsPerGroup, int gx, int gy, int gyPerXcd) {
     __shared__ double scratch[6 * (kSfsMarchBlock / kWave + 1)];
     T alpha = 0, beta = 0;
     const bool keep = K.first != 0 || K.restart != 0;              // r (and, at the start, p) are already those of this iteration
@@ -611,15 +614,25 @@ __global__ __launch_bounds__(kSfsMarchBlock) void sfs_pcgMarch(SArgs<T> A, T* __
         }
         R3 = R2; R2 = R1; R1 = n; q3 = q2; q2 = qn; b1 = bY; cy2 = cy1; cy1 = cyN;
     };
-    // Two trips per pass with two named row buffers, each requested one trip before it is consumed and consumed completely before it is requested again: no
-    // register copies of in-flight loads at the back-edge (a copy of a just-requested buffer costs an s_waitcnt vmcnt(0) per trip: 3.3 us instead of ~1 us).
-    // An odd trip count runs one trip past the end: clamped loads, nothing stored or summed (its rows are outside [yb, ye)).
-    SRaw<T> rA = load(yb - 2), rB;
-    for (int Y = yb - 2; Y < ye + 2; Y += 2) {
-        rB = load(Y + 1);
-        trip(Y, rA);
-        rA = load(Y + 2);
-        trip(Y + 1, rB);
+    // Named row buffers, each requested one (two) trips before it is consumed and consumed completely before it is requested again: no register copies of in-flight
+    // loads at the back-edge (a copy of a just-requested buffer costs an s_waitcnt vmcnt(0) per trip; every wait in this loop is counted).
+    // A trip count that is no multiple of the unroll runs past the end: clamped loads, nothing stored or summed (those rows are outside [yb, ye)).
+#ifndef SFS_MARCH_DEPTH
+#define SFS_MARCH_DEPTH 1      // rows in flight ahead of the one being worked on.  2 (three buffers, 237 VGPRs) measured no faster than 1 (two buffers, 215): 41.1-41.7 us per iteration against 39.4-40.0
+#endif
+    if (SFS_MARCH_DEPTH == 2) {
+        SRaw<T> rA = load(yb - 2), rB = load(yb - 1), rC;
+        for (int Y = yb - 2; Y < ye + 2; Y += 3) {
+            rC = load(Y + 2); trip(Y, rA);
+            rA = load(Y + 3); trip(Y + 1, rB);
+            rB = load(Y + 4); trip(Y + 2, rC);
+        }
+    } else {
+        SRaw<T> rA = load(yb - 2), rB;
+        for (int Y = yb - 2; Y < ye + 2; Y += 2) {
+            rB = load(Y + 1); trip(Y, rA);
+            rA = load(Y + 2); trip(Y + 1, rB);
+        }
     }
     double vv[6] = {acc, accNum, acc2, acc3, accRR, accQ};
     blockReduceSumN<6>(vv, scratch);

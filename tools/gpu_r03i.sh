@@ -1,0 +1,9 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r03i; mkdir -p $O
+for i in 1 2 3; do
+  OPT_AMD_CONFIG=config3 python tools/bench_configs.py 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('march 2w', d['wall_s'], d['kernel_avg_us'].get('PCGIteration'))"
+  OPT_AMD_LIB=$PWD/opt_amd/lib/libOpt_sfs3w.so OPT_AMD_CONFIG=config3 python tools/bench_configs.py 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('march 3w', d['wall_s'], d['kernel_avg_us'].get('PCGIteration'))"
+done
+timeout 1100 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider > $O/pytest.log 2>&1
+echo "pytest rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" $O/pytest.log | sed 's/ - .*//' | tail -30
