@@ -541,7 +541,7 @@ __global__ __launch_bounds__(kBlock) void iw_jtfMarch(IWArgs<T> A, T* __restrict
             const T p0 = mO * r0, p1 = mO * r1, p2 = mA * r2;
             rO[i] = V2<T>{r0, r1}; ra[i] = r2;
             pO[i] = V2<T>{p0, p1}; pa[i] = p2;
-            if (!LATTICE) ((V2<T>*)mc)[i] = V2<T>{mO, mA};
+            if (!LATTICE) mc[i] = mA;      // the compact preconditioner of the general kernel: M_a only (M_O comes from the flag byte, see iw_pcgIter2)
             acc += (double)(r0 * p0) + (double)(r1 * p1) + (double)(r2 * p2);
         }
         up = cur; cur = dn; ccCur = rdn.cc;
@@ -699,7 +699,7 @@ __device__ __forceinline__ IterRaw<T> iw_iterLoad(const IWArgs<T>& A, const Iter
     r.ao = ld2<kNTL>((const V2<T>*)K.ApOld, i); r.aa = ld1<kNTL>(K.ApOld + 2 * N, i);
     r.po = ld2<kNTL>((const V2<T>*)K.pOld, i); r.pa = ld1<kNTL>(K.pOld + 2 * N, i);
     if (PRE == 3) { r.mo = V2<T>{0, 0}; r.ma = 0; }
-    else if (PRE == 2) { r.mo = ld2<kNTL>((const V2<T>*)K.mc, i); r.ma = 0; }
+    else if (PRE == 2) { r.mo = V2<T>{0, 0}; r.ma = ld1<kNTL>(K.mc, i); }      // compact: M_a only (4 B/px); M_O from the flag byte
     else if (PRE == 1) { r.mo = ld2<kNTL>((const V2<T>*)K.pre, i); r.ma = ld1<kNTL>(K.pre + 2 * N, i); }
     else { r.mo = V2<T>{1, 1}; r.ma = 1; }
     if (LMV) { r.co = ld2<kNTL>((const V2<T>*)K.CtC, i); r.ca = ld1<kNTL>(K.CtC + 2 * N, i); } else { r.co = V2<T>{0, 0}; r.ca = 0; }
@@ -760,7 +760,7 @@ __device__ __forceinline__ IterRaw<T> iw_iterLoadBuf(const IWArgs<T>& A, const I
     r.ao = V2<T>{0, 0}; r.aa = 0;
     r.po = bufLd2(B.pOld, B.x2, s2, tag); r.pa = bufLd1(B.pOld, B.x1, s1a, tag);
     if (PRE == 3) { r.mo = V2<T>{0, 0}; r.ma = 0; }
-    else if (PRE == 2) { r.mo = bufLd2(B.mc, B.x2, s2, tag); r.ma = 0; }
+    else if (PRE == 2) { r.mo = V2<T>{0, 0}; r.ma = bufLd1(B.mc, B.x1, s1, tag); }      // compact: M_a only (4 B/px); M_O from the flag byte
     else if (PRE == 1) { r.mo = bufLd2(B.pre, B.x2, s2, tag); r.ma = bufLd1(B.pre, B.x1, s1a, tag); }
     else { r.mo = V2<T>{1, 1}; r.ma = 1; }
     if (LMV) { r.co = bufLd2(B.ctc, B.x2, s2, tag); r.ca = bufLd1(B.ctc, B.x1, s1a, tag); } else { r.co = V2<T>{0, 0}; r.ca = 0; }
@@ -823,7 +823,8 @@ __global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter(IWArgs<
     auto combine = [&](const IterRaw<T>& w, int y, bool own) {
         IterPx<T> q;
         const T rx = first ? w.ro.x : w.ro.x - alpha * w.ao.x, ry = first ? w.ro.y : w.ro.y - alpha * w.ao.y, ra = first ? w.ra : w.ra - alpha * w.aa;
-        q.mx = regCopy(w.mo.x); q.my = (PRE == 2) ? q.mx : regCopy(w.mo.y); q.ma = regCopy((PRE == 2) ? w.mo.y : w.ma);
+        static_assert(PRE != 2 && PRE != 3, "iw_pcgIter streams the full preconditioner vector (PRE 1) or none (PRE 0)");
+        q.mx = regCopy(w.mo.x); q.my = regCopy(w.mo.y); q.ma = regCopy(w.ma);
         q.zx = q.mx * rx; q.zy = q.my * ry; q.za = q.ma * ra;
         q.rx = rx; q.ry = ry; q.ra = ra;
         q.p.ox = q.zx + beta * w.po.x; q.p.oy = q.zy + beta * w.po.y; q.p.a = q.za + beta * w.pa;
@@ -1077,7 +1078,9 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAV
     // values the solver's preconditioner vector holds, bit for bit; the Angle entries use |R'(a) n|^2 = 1 exactly where
     // iw_evalJTF rounds cos^2 + sin^2.
     __shared__ T mTab[16], cTab[16], iTab[16];      // iTab = 1 / M = (1 + sqrt(d))^2 directly (r-free mode)
-    if (PRE == 3) {
+    // PRE == 2 (general UrShape): diag(J^T J) of the OFFSET part does not depend on UrShape at all (2 w^2 per active neighbour + w_fit^2), so M_O comes from the same
+    // table for any input and only M_a is streamed: 4 B/px instead of 8 (round 3; 69 -> 65 B/px)
+    if (PRE == 3 || PRE == 2) {
         if (threadIdx.x < 15) {
             const int t = threadIdx.x, cnt = t < 10 ? t % 5 : t - 10;
             const T w = A.w_reg;
@@ -1120,8 +1123,12 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAV
             o.mx = o.my = mTab[io]; o.ma = mTab[10 + cnt];
             if (LM) { o.cx = o.cy = cTab[io]; o.ca = cTab[10 + cnt]; }
             else if (reconR) { ix = iy = iTab[io]; ia = iTab[10 + cnt]; }
+        } else if (PRE == 2) {
+            const int cnt = (w.f >> kCountShift) & 7, io = cnt + ((w.f & kFit) ? 5 : 0);
+            o.mx = o.my = mTab[io]; o.ma = w.ma;
+            if (!LM && reconR) { ix = iy = iTab[io]; ia = T(1) / o.ma; }
         } else {
-            o.mx = w.mo.x; o.my = (PRE == 2) ? w.mo.x : w.mo.y; o.ma = (PRE == 2) ? w.mo.y : w.ma;
+            o.mx = w.mo.x; o.my = w.mo.y; o.ma = w.ma;
             if (!LM && PRE != 0 && reconR) { ix = T(1) / o.mx; iy = T(1) / o.my; ia = T(1) / o.ma; }
         }
         if (!LM && LATTICE && kRfree) { o.p2x = w.ro.x; o.p2y = w.ro.y; o.p2a = w.ra; }      // (the general-UrShape kernel has no registers to spare: it reads p_{k-2} again)
@@ -1254,11 +1261,10 @@ __global__ __launch_bounds__(kBlock) void iw_axpyDeferred(T* __restrict__ delta,
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) delta[i] = delta[i] + a * p[i];
 }
 
-// {M_O, M_a} per pixel from the solver's 3-channel preconditioner (its two Offset channels are equal for this energy)
+// M_a per pixel from the solver's 3-channel preconditioner (the Angle part of the vector; only there so that `mc` has one meaning whoever fills it)
 template <class T>
 __global__ __launch_bounds__(kBlock) void iw_compactM(const T* __restrict__ pre, T* __restrict__ mc, long N) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x)
-        ((V2<T>*)mc)[i] = V2<T>{pre[2 * i], pre[2 * N + i]};
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) mc[i] = pre[2 * N + i];
 }
 // Is UrShape a unit lattice (U(x,y) - U(x+1,y) == (-1,0) and U(x,y) - U(x,y+1) == (0,-1) exactly)?  The reference
 // example always passes the pixel grid itself (examples/image_warping/src/CombinedSolver.h:161-172); any other input
@@ -1430,7 +1436,7 @@ struct ImageWarpingOps : EnergyOps<T> {
     void launchJtf(bool lat, LaunchCtx& ctx) {
         ScopedKernel k(ctx, "PCGInit1");
         int gx, gy, rpg; marchGrid(A.yEnd - A.yBegin, gx, gy, rpg);
-        if (!lat && !mc) HIP_CHECK(hipMalloc((void**)&mc, (size_t)A.W * A.H * 2 * sizeof(T)));
+        if (!lat && !mc) HIP_CHECK(hipMalloc((void**)&mc, (size_t)A.W * A.H * sizeof(T)));
         if (lat) iw_jtfMarch<T, true><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, nullptr, initRed->partials, rpg, gx, gy);
         else iw_jtfMarch<T, false><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, mc, initRed->partials, rpg, gx, gy);
         initRed->n = gx * gy;
@@ -1531,7 +1537,8 @@ struct ImageWarpingOps : EnergyOps<T> {
     int iterFlip = 0; bool alternateSweep = true, recomputeAp = true;
     int sinceExchange = 0, maxExchangePeriod = 1 << 20;      // OPT_AMD_SLAB_PERIOD=1: exchange after every launch whatever the ghost depth (A/B switch)
     template <bool LAT, int PRE> static const void* iterFn(bool noAp, bool flip) {
-        return !noAp ? (const void*)iw_pcgIter<T, LAT, PRE> : flip ? (const void*)iw_pcgIter2<T, LAT, PRE, true> : (const void*)iw_pcgIter2<T, LAT, PRE, false>;
+        if constexpr (PRE == 2) return flip ? (const void*)iw_pcgIter2<T, LAT, PRE, true> : (const void*)iw_pcgIter2<T, LAT, PRE, false>;      // (the compact M exists for the A p-free kernel only)
+        else return !noAp ? (const void*)iw_pcgIter<T, LAT, PRE> : flip ? (const void*)iw_pcgIter2<T, LAT, PRE, true> : (const void*)iw_pcgIter2<T, LAT, PRE, false>;
     }
     static const void* iterKernel(bool lat, int pre, bool noAp, bool flip) {
         if (pre == 3) return flip ? (const void*)iw_pcgIter2<T, true, 3, true> : (const void*)iw_pcgIter2<T, true, 3, false>;      // (steady-state variants: steadyKernel)
@@ -1592,7 +1599,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         }
         IWArgs<T> Ax = A;                   // what the kernel sees: the rows it updates
         Ax.yBegin = std::max(0, A.yBegin - ext); Ax.yEnd = std::min(A.H, A.yEnd + ext);
-        const int pre = !a.pre ? 0 : (noAp && lattice && flagPreconditioner) ? 3 : lmLoop ? 1 : useCompactM ? 2 : 1;
+        const int pre = !a.pre ? 0 : (noAp && lattice && flagPreconditioner) ? 3 : lmLoop ? 1 : (useCompactM && noAp) ? 2 : 1;
         const int L = lmLoop ? (lattice ? 14 : 13) : pre == 3 ? 12 : (noAp ? 6 : 0) + (lattice ? 3 : 0) + pre;
         if (a.first) iterFlip = 0;      // every linear solve starts top-down, so a solve is reproducible whatever ran before it
         const int blk = !noAp ? kIterBlock : sizeof(T) == 8 ? ITER2_BLOCK_DOUBLE : lattice ? kIterBlock2 : (pre == 2 && !lmLoop) ? ITER2_BLOCK_GENERAL_GN : ITER2_BLOCK_GENERAL;      // IterBlk<T, LATTICE, PRE, LM> of the kernel picked below
@@ -1602,7 +1609,7 @@ struct ImageWarpingOps : EnergyOps<T> {
             occIter[L] = std::max(1, std::min(occIter[L], 8));
         }
         if (a.first && pre == 2 && !mcFresh) {
-            if (!mc) HIP_CHECK(hipMalloc((void**)&mc, (size_t)A.W * A.H * 2 * sizeof(T)));
+            if (!mc) HIP_CHECK(hipMalloc((void**)&mc, (size_t)A.W * A.H * sizeof(T)));
             ScopedKernel k(ctx, "compactPreconditioner");
             iw_compactM<T><<<flatGrid((long)A.W * A.H), kBlock, 0, ctx.stream>>>(a.pre, mc, (long)A.W * A.H);
         }
