@@ -615,12 +615,13 @@ __global__ __launch_bounds__(kBlock) void iw_finishUpdate(T* __restrict__ XO, T*
     const T aNum = (T)o2[0], aDen = (T)o2[1];
     const T a1 = (aDen > T(0)) ? aNum / aDen : T(0);
     const T a2 = p2 ? alpha2[0] : T(0);
-    const V2<T>* dO = (const V2<T>*)delta; const T* dA = delta + 2 * N;
+    const V2<T>* dO = (const V2<T>*)delta; const T* dA = delta ? delta + 2 * N : nullptr;      // delta == nullptr: it stands for 0 (no launch of the loop has written it)
     const V2<T>* qO = (const V2<T>*)p1; const T* qA = p1 + 2 * N;
     const V2<T>* sO = (const V2<T>*)p2; const T* sA = p2 ? p2 + 2 * N : nullptr;
     V2<T>* xO = (V2<T>*)XO;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
-        V2<T> d = dO[i]; T da = dA[i];
+        V2<T> d{0, 0}; T da = 0;
+        if (delta) { d = dO[i]; da = dA[i]; }
         const V2<T> q = qO[i]; const T qa = qA[i];
         const V2<T> x = xO[i]; const T xa = XA[i];
         if (p2) { const V2<T> s = sO[i]; const T sa = sA[i]; d.x = d.x + a2 * s.x; d.y = d.y + a2 * s.y; da = da + a2 * sa; }
@@ -684,6 +685,7 @@ struct IterK {             // kernel argument block
     int ownBegin, ownEnd;
     MailRefDev mail;       // slab mode, posted all-reduce: where the prologue polls the previous launch's four sums (words == nullptr: they are in aNumPrev .. s3Prev)
     MailPostDev post;      // ... and where this launch's last workgroup posts its own four sums (world == 0: it does not)
+    int deltaZero;         // the delta buffer has not been written since PCGInit1 and stands for 0 (evalJTFInit skips the memset); honoured by the MODE 0 kernels only
 };
 
 // PRE: 0 = identity preconditioner, 1 = the solver's 3-channel one (12 B/px), 2 = compact {M_O, M_a} (8 B/px).  A template
@@ -1188,6 +1190,7 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAV
                 V2<T> d; T da;
                 if (kDeltaEarly) { d = dPre.o; da = dPre.a; }
                 else if (kBuf) { d = bufLd2(Bf.delta, Bf.x2, s2, tag); da = bufLd1(Bf.delta, Bf.x1, s1a, tag); } else { d = dO[i]; da = dA[i]; }
+                if (MODE == 0 && K.deltaZero) { d.x = 0; d.y = 0; da = 0; }      // first delta update of a linear solve whose PCGInit1 left the buffer untouched
                 if (kDeltaMode == 1) {
                     if (!LM && LATTICE && kRfree == 1 && kReconP != 2) { d.x += alpha2 * oB.p2x; d.y += alpha2 * oB.p2y; da += alpha2 * oB.p2a; }      // p_{k-2} kept from the load: exact
                     else if (recon) { d.x += alpha2 * ((oB.q.ox - oB.mx * oB.rx) * invBeta2); d.y += alpha2 * ((oB.q.oy - oB.my * oB.ry) * invBeta2); da += alpha2 * ((oB.q.a - oB.ma * oB.ra) * invBeta2); }
@@ -1449,11 +1452,13 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (!fastGN()) return false;
         initR = r; initP = p; initRed = &aNum0; initHint = lattice;
         launchJtf(initHint, ctx);
-        { ScopedKernel k(ctx, "PCGInit1_Finish"); HIP_CHECK(hipMemsetAsync(delta, 0, (size_t)nPad * sizeof(T), ctx.stream)); }
+        // delta = 0 (PCGInit1, solver.t:389) is not written: the first launch of the loop that updates delta takes it as 0 (IterK::deltaZero), and
+        // finishUpdate / pcgFinish do the same if no launch did (lIterations <= 2) -- 12 B/px of memset less per Gauss-Newton step
+        (void)nPad; initDelta = delta; deltaZero = true;
         initPending = true;
         return true;
     }
-    bool initPending = false;
+    bool initPending = false, deltaZero = false; T* initDelta = nullptr;
     void evalCost(Reduction& out, LaunchCtx& ctx) override {
         ScopedKernel k(ctx, "computeCost");
         if (!this->slab.active && marchKernels) {
@@ -1648,12 +1653,14 @@ struct ImageWarpingOps : EnergyOps<T> {
                    MailRefDev{a.mail.words, a.mail.world, a.mail.stride, a.mail.tag, a.mail.timeoutTicks, a.mail.errFlag}, MailPostDev{}};
         for (int t = 0; t < 16; ++t) K.post.dst[t] = a.post.dst[t];
         K.post.world = a.post.world; K.post.tag = a.post.tag; K.post.ticket = a.post.ticket;
+        K.deltaZero = 0;
+        if (deltaZero && !a.first && deltaMode != 2 && !lmLoop) { K.deltaZero = 1; deltaZero = false; }      // this launch writes every pixel's delta: from here on the buffer is real
         {
             ScopedKernel k(ctx, "PCGIteration");
             int rpg = rowsPerGroup, gxa = gx, gya = gy;
             void* kargs[] = {(void*)&Ax, (void*)&K, (void*)&rpg, (void*)&gxa, (void*)&gya};
             const void* fnL = fn;      // same workgroup size and grid; the steady-state variants only drop the tests of the launch state
-            if (steadyVariants && !lmLoop && noAp && rfreeFlag == 1 && !a.first && reconstructP != 2 && (deltaMode == 1 || deltaMode == 2))
+            if (steadyVariants && !lmLoop && noAp && rfreeFlag == 1 && !a.first && reconstructP != 2 && (deltaMode == 1 || deltaMode == 2) && !K.deltaZero)
                 if (const void* f = steadyKernel(lattice, pre, iterFlip != 0, deltaMode == 2 ? 1 : 2)) fnL = f;
             HIP_CHECK(hipLaunchKernel(fnL, dim3(gx * gy), dim3(blk), kargs, 0, ctx.stream));
         }
@@ -1674,6 +1681,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         return 2;
     }
     const T* pcgFinish(const T* pPrev, T* delta, LaunchCtx& ctx) override {
+        if (deltaZero) { HIP_CHECK(hipMemsetAsync(delta, 0, ((size_t)A.W * A.H * 3 + 3) / 4 * 4 * sizeof(T), ctx.stream)); deltaZero = false; }      // the generic tail reads it
         const T* pLast = nullptr;
         if (lastLoopRfree && iterIndex >= 1) {      // r-free ring: launch j left p_j in ring[j % 3]
             pLast = ring[(iterIndex - 1) % 3];
@@ -1696,9 +1704,9 @@ struct ImageWarpingOps : EnergyOps<T> {
         }
         ScopedKernel k(ctx, "PCGLinearUpdate");
         const long N = (long)A.W * A.H;
-        iw_finishUpdate<T><<<flatGrid(N), kBlock, 0, ctx.stream>>>(const_cast<T*>(A.Offset), const_cast<T*>(A.Angle), delta, pLast, deferredTerm ? pPrev : nullptr,
+        iw_finishUpdate<T><<<flatGrid(N), kBlock, 0, ctx.stream>>>(const_cast<T*>(A.Offset), const_cast<T*>(A.Angle), deltaZero ? nullptr : delta, pLast, deferredTerm ? pPrev : nullptr,
                                                                    alphaSlots ? alphaSlots + ((iterIndex - 1) & 1) : nullptr, N, aNum.partials, aNum.n, aDen.partials, aDen.n);
-        deferredTerm = false;
+        deferredTerm = false; deltaZero = false;
         return true;
     }
     void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {

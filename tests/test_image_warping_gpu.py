@@ -199,7 +199,7 @@ def test_lattice_fast_path_matches_the_general_path(monkeypatch):
 RAGGED = [(1, 1), (2, 1), (1, 6), (3, 3), (59, 2), (60, 5), (61, 3), (63, 4), (64, 2), (65, 7), (119, 3), (121, 6), (719, 2), (720, 3), (721, 5), (1441, 4), (7, 301)]
 
 
-@pytest.mark.parametrize("liters", [1, 2, 7, 8])
+@pytest.mark.parametrize("liters", [1, 2, 3, 7, 8])
 @pytest.mark.parametrize("W,H", RAGGED)
 def test_iteration_kernel_on_ragged_sizes(oracle_lib, W, H, liters):
     """The single-kernel PCG iteration tiles an image into 60-pixel wave spans (720-pixel strips), keeps a 2-pixel ring and marches
@@ -220,6 +220,31 @@ def test_iteration_kernel_on_ragged_sizes(oracle_lib, W, H, liters):
             break
     assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < 1e-9
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("jitter", [0.0, 0.05])
+@pytest.mark.parametrize("liters", [1, 2, 3, 6, 9])
+def test_marching_step_kernels_equal_the_flat_ones(monkeypatch, jitter, liters):
+    """Round 3: the once-per-Gauss-Newton-step passes of image_warping (bind + lattice verdict, PCGInit1 + PCGInit1_Finish without a delta memset, the fused end-of-loop
+    update X += delta [+ deferred terms], computeCost) run as row-marching kernels on one GPU; OPT_AMD_MARCH_INIT=0 / OPT_AMD_FUSED_FINISH=0 keep the flat
+    one-thread-per-pixel passes.  Same expressions: three Gauss-Newton steps must agree to rounding (the order of the double partial sums differs), for launch counts
+    on either side of the paired delta update and of the first launch that writes delta, on a unit lattice and on a general UrShape."""
+    outs = {}
+    for name, env in {"march": {}, "flat-init": {"OPT_AMD_MARCH_INIT": "0"}, "flat-finish": {"OPT_AMD_FUSED_FINISH": "0"}}.items():
+        for k in ("OPT_AMD_MARCH_INIT", "OPT_AMD_FUSED_FINISH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        P = wl.image_warping(301, 215, double=True, random_state=11, mask_fraction=0.07, perturb=0.3, jitter_urshape=jitter)
+        g = hip_solver(P, nIterations=3, lIterations=liters)
+        dev = api.to_device(P)
+        g.init(dev); costs = [g.cost()]
+        while g.step(dev):
+            costs.append(g.cost())
+        outs[name] = (costs, device_unknowns(P, dev)); g.close()
+    for name in ("flat-init", "flat-finish"):
+        np.testing.assert_allclose(outs["march"][0], outs[name][0], rtol=1e-11)
+        assert rel_err(outs["march"][1], outs[name][1]) < 1e-11
 
 
 @pytest.mark.parametrize("double", [False, True])
