@@ -14,6 +14,6 @@ timeout 200 rocprofv3 --pmc WRITE_SIZE -f csv -d $out/pmc_write -o p -- $B > $ou
 # The counters are folded into profiles/<tag>_traffic.json on the box first, so that the bench line below carries the traffic measured for this very tree
 # (bench.py accepts a traffic file only if its kernel-source hash matches).
 python tools/summarize_profile.py $out profiles/$tag > $out/summarize.log 2>&1
-timeout 600 python bench.py > $out/bench.json 2> $out/bench.err
+timeout 600 python bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
 timeout 600 python tools/bench_configs.py > $out/configs.json 2> $out/configs.err
 tail -c 600 $out/bench.json
