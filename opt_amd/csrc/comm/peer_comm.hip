@@ -15,6 +15,7 @@
 //
 // The reference has no multi-GPU path; this is north_star work.
 #include "../../../include/OptAmd.h"
+#include "../common.h"      // pollMailSums: the consumer side of a posted all-reduce, as the iteration kernels run it (self-test only)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -167,6 +168,14 @@ __global__ __launch_bounds__(256) void k_mailPost(PartialsIn parts, int n, Peers
         const unsigned half = (w & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
         __hip_atomic_store(&P.win[tr]->ll[slot][rank][w], ((u64)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// self-test of the posted path: what an iteration kernel's prologue does with a MailRef
+__global__ __launch_bounds__(256) void k_mailPollTest(optamd::MailRefDev M, double* __restrict__ out) {
+    __shared__ double scr[4 + 1 + 64];
+    double o4[4];
+    optamd::pollMailSums<4>(M, scr, o4);
+    if (threadIdx.x < 4) out[threadIdx.x] = o4[threadIdx.x];
 }
 
 // ---- halo exchange -------------------------------------------------------------------------------------------------------------------
@@ -422,6 +431,30 @@ int OptComm_PeerSelfTest(void* c, double timeoutSeconds) {
             if (x->rank < x->world - 1 && hostRows[3 * nf + i] != (float)(100 * (x->rank + 1) + 1)) ok = 0;   // the rank below sent its "up" rows
         }
         free(hostRows);
+    }
+    // The posted all-reduce (k_mailPost + a consumer that polls this rank's mailbox like an iteration kernel's prologue): a machine on which it does not deliver the
+    // right sums keeps the waiting all-reduce (the communicator stays usable), it does not fall back to RCCL.
+    if (ok && x->ext.allReducePost) {
+        double hp[12], *dp = nullptr, *dout = nullptr;
+        for (int i = 0; i < 4; ++i) for (int k = 0; k < 3; ++k) hp[3 * i + k] = (i + 1) * (1.0 + x->rank) + 0.5 * k;
+        CK_HIP(hipMalloc((void**)&dp, sizeof hp)); CK_HIP(hipMalloc((void**)&dout, 4 * sizeof(double)));
+        CK_HIP(hipMemcpy(dp, hp, sizeof hp, hipMemcpyHostToDevice));
+        const double* parts[4] = {dp, dp + 3, dp + 6, dp + 9}; const int counts[4] = {3, 3, 3, 3};
+        OptAmd_MailRef ref{};
+        bool good = peerAllReducePost(x, parts, counts, 4, &ref, nullptr) != 0;
+        if (good) {
+            k_mailPollTest<<<1, 256, 0, 0>>>(optamd::MailRefDev{ref.words, ref.world, ref.stride, ref.tag, ref.timeoutTicks, ref.errFlag}, dout);
+            CK_HIP(hipDeviceSynchronize());
+            double got[4]; CK_HIP(hipMemcpy(got, dout, sizeof got, hipMemcpyDeviceToHost));
+            const double tri2 = x->world * (x->world + 1.0) / 2.0;
+            for (int i = 0; i < 4; ++i) if (got[i] != 3.0 * (i + 1) * tri2 + 1.5 * x->world) good = false;
+            if (*x->hostErr) good = false;
+        }
+        if (!good) {
+            fprintf(stderr, "OptComm(peer) rank %d: the posted all-reduce failed its self-test; using the waiting all-reduce\n", x->rank);
+            x->ext.allReducePost = nullptr; x->ext.allReducePlan = nullptr;
+        }
+        (void)hipFree(dp); (void)hipFree(dout);
     }
     *x->hostErr = 0;                 // a failed self-test is reported through the return value, not through the run-time abort
     x->timeoutTicks = keep;
