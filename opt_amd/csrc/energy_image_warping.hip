@@ -970,6 +970,46 @@ __device__ __forceinline__ void iw_pairQ(const Q<T>& c, const Q<T>& n, T& ax, T&
     ax += n.on * (jcx - jnx); ay += n.on * (jcy - jny);
     aa -= n.on * (Dcx * jcx + Dcy * jcy);
 }
+// ---- each pair of residuals is formed ONCE (round 3) -----------------------------------------------------------------------------------------------
+// iw_pairQ evaluates, for centre c and neighbour n, the residual centred at c towards n and the one centred at n towards c -- and the pixel n, when it is the
+// centre, evaluates the same two residuals again from its side: jc' = jn, jn' = jc, D_{n,-d} = Dn bit for bit (a - b = -(b - a) and a product keeps its value
+// when both factors change sign).  So the pair is formed once, by the end that comes first in lane / sweep order, which also leaves what the other end needs:
+//   jc' - jn' = -(jc - jn)   and   D_{n,-d} . jc' = Dn . jn.
+// The right-hand pair of lane x is the left-hand pair of lane x + 1 (three DPP moves instead of the neighbour's three vector fields and 13 VALU instructions); the
+// pair towards the next row of the march is the pair towards the previous row one trip later (three registers per stencil evaluation).  Accumulation order and
+// every accumulated value are those of iw_pairQ: the result is the same bits, ~34 of ~250 VALU instructions per pixel-row less -- which pays where the kernel is
+// issue-bound (2048^2, slabs: profiles/r03l_iteration_kernel_sq_counters.md), not at 4096^2.
+#ifndef IW_SHARE_PAIRS
+#define IW_SHARE_PAIRS 1
+#endif
+template <class T> struct PairOut { T dx, dy, tn; };      // (jc - jn).x, (jc - jn).y, Dn . jn
+template <int DX, int DY, bool LATTICE, class T>
+__device__ __forceinline__ PairOut<T> iw_pairFull(const Q<T>& c, const Q<T>& n, T& ax, T& ay, T& aa) {
+    T Dcx, Dcy, Dnx, Dny;
+    if (LATTICE) {       // U_c - U_n = -(DX, DY)
+        Dcx = DX ? T(DX) * c.s : T(DY) * c.c;   Dcy = DX ? T(-DX) * c.c : T(DY) * c.s;
+        Dnx = DX ? T(-DX) * n.s : T(-DY) * n.c; Dny = DX ? T(DX) * n.c : T(-DY) * n.s;
+    } else {
+        const T ux = c.ux - n.ux, uy = c.uy - n.uy;
+        Dcx = -c.s * ux - c.c * uy; Dcy = c.c * ux - c.s * uy;
+        Dnx = n.s * ux + n.c * uy;  Dny = -n.c * ux + n.s * uy;
+    }
+    const T dx = c.ox - n.ox, dy = c.oy - n.oy;
+    const T jcx = dx - Dcx * c.a, jcy = dy - Dcy * c.a;
+    const T jnx = -dx - Dnx * n.a, jny = -dy - Dny * n.a;
+    PairOut<T> o;
+    o.dx = jcx - jnx; o.dy = jcy - jny;
+    o.tn = Dnx * jnx + Dny * jny;
+    ax += n.on * o.dx; ay += n.on * o.dy;
+    aa -= n.on * (Dcx * jcx + Dcy * jcy);
+    return o;
+}
+// the same pair seen from its far end: `o` is what the neighbour's evaluation left, nOn that neighbour's activity
+template <class T>
+__device__ __forceinline__ void iw_pairInherited(const PairOut<T>& o, T nOn, T& ax, T& ay, T& aa) {
+    ax -= nOn * o.dx; ay -= nOn * o.dy;
+    aa -= nOn * o.tn;
+}
 template <class T>
 struct OldRow {            // one row of iteration k-1: p_{k-1} and, while still needed, r_{k-1}, M and (LM) CtC
     Q<T> q;
@@ -1139,13 +1179,23 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAV
         }
     };
     // J^T J at centre c; prev / next are the rows before / after it in sweep order
-    auto applyA = [&](const Q<T>& c, const Q<T>& lf, const Q<T>& rt, const Q<T>& prev, const Q<T>& next, T& ox, T& oy, T& oa) {
-        const Q<T>& below = FLIP ? prev : next; const Q<T>& above = FLIP ? next : prev;     // image rows y+1 / y-1
+    // `vert`: in, what the previous trip's evaluation of this stream left for the pair (prev, c); out, the same for (c, next)
+    auto applyA = [&](const Q<T>& c, const Q<T>& lf, const Q<T>& rt, const Q<T>& prev, const Q<T>& next, PairOut<T>& vert, T& ox, T& oy, T& oa) {
         T ax = 0, ay = 0, aa = 0;
-        iw_pairQ<1, 0, LATTICE>(c, rt, ax, ay, aa); iw_pairQ<-1, 0, LATTICE>(c, lf, ax, ay, aa);
-        iw_pairQ<0, 1, LATTICE>(c, below, ax, ay, aa); iw_pairQ<0, -1, LATTICE>(c, above, ax, ay, aa);
+        if (IW_SHARE_PAIRS) {      // rt (formed), lf (lane x-1's rt pair), then image row y+1 and y-1: one of them formed, the other left by the previous trip
+            const PairOut<T> hr = iw_pairFull<1, 0, LATTICE>(c, rt, ax, ay, aa);
+            PairOut<T> hl; hl.dx = dppShift<true>(hr.dx); hl.dy = dppShift<true>(hr.dy); hl.tn = dppShift<true>(hr.tn);
+            iw_pairInherited(hl, lf.on, ax, ay, aa);
+            if (!FLIP) { const PairOut<T> vn = iw_pairFull<0, 1, LATTICE>(c, next, ax, ay, aa); iw_pairInherited(vert, prev.on, ax, ay, aa); vert = vn; }
+            else { iw_pairInherited(vert, prev.on, ax, ay, aa); vert = iw_pairFull<0, -1, LATTICE>(c, next, ax, ay, aa); }
+        } else {
+            const Q<T>& below = FLIP ? prev : next; const Q<T>& above = FLIP ? next : prev;     // image rows y+1 / y-1
+            iw_pairQ<1, 0, LATTICE>(c, rt, ax, ay, aa); iw_pairQ<-1, 0, LATTICE>(c, lf, ax, ay, aa);
+            iw_pairQ<0, 1, LATTICE>(c, below, ax, ay, aa); iw_pairQ<0, -1, LATTICE>(c, above, ax, ay, aa);
+        }
         ox = c.on * (w2 * ax + c.fw * c.ox); oy = c.on * (w2 * ay + c.fw * c.oy); oa = c.on * (w2 * aa);
     };
+    PairOut<T> vOld{0, 0, 0}, vNew{0, 0, 0};      // the vertical pairs the two stencil evaluations of a trip inherit (p_{k-1} rows / p_k rows)
     // One trip: the freshly loaded row y+2 -> Ap_{k-1}(y+1), r_k, z_k, p_k (y+1) -> Ap_k(y).
     // oA, oB = p_{k-1} rows y, y+1 (oC receives y+2);  nA, nB = p_k rows y-1, y (nC receives y+1)
     // The delta of the row a trip updates (y + 1) is requested one trip ahead, before that trip's prefetch of a raw row: by the time it is used a whole trip
@@ -1168,11 +1218,14 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAV
     auto trip = [&](int y, const OldRow<T>& oA, const OldRow<T>& oB, const OldRow<T>& oC,
                     const NewRow<T>& nA, const NewRow<T>& nB, NewRow<T>& nC, bool live, const DeltaPre& dPre) {
         nC.q = oB.q;
-        dppShiftConst<true, LATTICE>(oB.q, nC.lf); dppShiftConst<false, LATTICE>(oB.q, nC.rt);
+        if (IW_SHARE_PAIRS) { nC.lf = Q<T>{}; nC.lf.on = dppShift<true>(oB.q.on); }     // of the left neighbour only its activity is needed: its pair comes ready-made
+        else dppShiftConst<true, LATTICE>(oB.q, nC.lf);
+        dppShiftConst<false, LATTICE>(oB.q, nC.rt);
         Q<T> lf = nC.lf, rt = nC.rt;
-        dppShiftVec<true>(oB.q, lf); dppShiftVec<false>(oB.q, rt);
+        if (!IW_SHARE_PAIRS) dppShiftVec<true>(oB.q, lf);
+        dppShiftVec<false>(oB.q, rt);
         T ax, ay, aa;
-        applyA(oB.q, lf, rt, oA.q, oC.q, ax, ay, aa);                                   // Step1 of iteration k-1 again
+        applyA(oB.q, lf, rt, oA.q, oC.q, vOld, ax, ay, aa);                             // Step1 of iteration k-1 again
         if (LM) { ax += oB.cx * oB.q.ox; ay += oB.cy * oB.q.oy; aa += oB.ca * oB.q.a; }                                                       // + CtC p (o.t:2076-2082)
         const T rx = keepR ? oB.rx : oB.rx - alpha * ax, ry = keepR ? oB.ry : oB.ry - alpha * ay, ra = keepR ? oB.ra : oB.ra - alpha * aa;   // Step2
         nC.mx = oB.mx; nC.my = oB.my; nC.ma = oB.ma;
@@ -1222,9 +1275,10 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAV
             if (own) accNum += dprod3(nC.mx, rx, rx) + dprod3(nC.my, ry, ry) + dprod3(nC.ma, ra, ra);
         }
         Q<T> l2 = nB.lf, r2 = nB.rt;
-        dppShiftVec<true>(nB.q, l2); dppShiftVec<false>(nB.q, r2);
+        if (!IW_SHARE_PAIRS) dppShiftVec<true>(nB.q, l2);
+        dppShiftVec<false>(nB.q, r2);
         T ox, oy, oa;
-        applyA(nB.q, l2, r2, nA.q, nC.q, ox, oy, oa);                                   // Step1 of iteration k
+        applyA(nB.q, l2, r2, nA.q, nC.q, vNew, ox, oy, oa);                             // Step1 of iteration k
         if (LM) { ox += nB.cx * nB.q.ox; oy += nB.cy * nB.q.oy; oa += nB.ca * nB.q.a; }
         if (live && writer && y >= yb && (!IW_OWN_CHECK || (phys(y) >= K.ownBegin && phys(y) < K.ownEnd))) {
             accDen += (double)(nB.q.ox * ox + nB.q.oy * oy + nB.q.a * oa);
@@ -1236,6 +1290,7 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAV
     NewRow<T> n0{}, n1{}, n2{};
     makeOld(raw0, o0);
     makeOld(raw1, o1);
+    if (IW_SHARE_PAIRS) { T t0 = 0, t1 = 0, t2 = 0; vOld = iw_pairFull<0, FLIP ? -1 : 1, LATTICE>(o0.q, o1.q, t0, t1, t2); }      // the pair (row yb-2, row yb-1) the first trip inherits
     DeltaPre dlA = loadDelta(yb - 1), dlB = dlA, dlC = dlA;      // (trip yb - 2 updates no row; its delta is a dummy)
     // trips y = yb-2 .. ye-1 (the first two only build p_k(yb-1), p_k(yb)); three per pass, no branch around a load
     for (int y = yb - 2; y < ye; y += 3) {
