@@ -52,13 +52,23 @@ template <class T> __device__ __forceinline__ bool sfs_dv(const SArgs<T>& A, int
 
 template <class T>
 __global__ __launch_bounds__(kBlock) void sfs_precompute(SArgs<T> A) {
+    // Branch-free loads (round 3): a border pixel reads the addresses of the interior pixel (1,1) and masks the results, so the thirteen loads of a pixel are in flight
+    // together instead of queued behind `if (interior)` / `if (D_i > 0 ...)` (31 -> see DESIGN.md 3.3); the arithmetic and its order are unchanged.
     const long N = (long)A.W * A.H;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < N; e += (long)gridDim.x * blockDim.x) {
         const int x = (int)(e % A.W), y = (int)(e / A.W);
+        const bool in1 = sfs_interior(A, x, y);
+        const long c = in1 ? e : (long)A.W + 1;      // (A.W >= 3 && A.H >= 3 whenever an interior pixel exists; otherwise the clamp below keeps the address valid)
+        const long cc = min(max(c, (long)0), N - 1), cl = min(max(c - 1, (long)0), N - 1), cr = min(max(c + 1, (long)0), N - 1),
+                   cu = min(max(c - A.W, (long)0), N - 1), cd = min(max(c + A.W, (long)0), N - 1);
+        const T X1 = A.X[cc], X0 = A.X[cl], Xr = A.X[cr], X2 = A.X[cu], Xd = A.X[cd];
+        const T D1 = A.D_i[cc], D0 = A.D_i[cl], Dr = A.D_i[cr], D2 = A.D_i[cu], Dd = A.D_i[cd];
+        const T I1 = A.Im[cc], I0 = A.Im[cl], I2 = A.Im[cu];
+        const T Dself = A.D_i[e];
         T bi = 0, g0 = 0, g1 = 0, g2 = 0, vl = 0;
-        if (sfs_interior(A, x, y)) {
-            if (sfs_dv(A, x - 1, y) && sfs_dv(A, x, y) && sfs_dv(A, x, y - 1)) {
-                const D3<T> d0{A.X[e - 1], 1, 0, 0}, d1{A.X[e], 0, 1, 0}, d2{A.X[e - A.W], 0, 0, 1};
+        if (in1) {
+            if (D0 > T(0) && D1 > T(0) && D2 > T(0)) {
+                const D3<T> d0{X0, 1, 0, 0}, d1{X1, 0, 1, 0}, d2{X2, 0, 0, 1};
                 const T i = (T)x, j = (T)y;
                 D3<T> nx = (d2 * (d1 - d0)) / A.f_y;
                 D3<T> ny = (d0 * (d1 - d2)) / A.f_x;
@@ -68,16 +78,16 @@ __global__ __launch_bounds__(kBlock) void sfs_precompute(SArgs<T> A) {
                 D3<T> B = A.L[1] * ny + A.L[2] * nz + A.L[3] * nx + A.L[4] * (nx * ny) + A.L[5] * (ny * nz) +
                           A.L[6] * (-(nx * nx) - ny * ny + T(2) * (nz * nz)) + A.L[7] * (nz * nx) + A.L[8] * (nx * nx - ny * ny);
                 B.v += A.L[0];
-                const T Iv = A.Im[e] * T(0.5) + T(0.25) * (A.Im[e - 1] + A.Im[e - A.W]);
+                const T Iv = I1 * T(0.5) + T(0.25) * (I0 + I2);
                 bi = B.v - Iv; g0 = B.a; g1 = B.b; g2 = B.c;
             }
-            bool v = sfs_dv(A, x, y) && sfs_dv(A, x, y - 1) && sfs_dv(A, x, y + 1) && sfs_dv(A, x - 1, y) && sfs_dv(A, x + 1, y);
-            const T thr = T(0.01), xc = A.X[e];
-            v = v && fabs(xc - A.X[e - A.W]) < thr && fabs(xc - A.X[e + A.W]) < thr && fabs(xc - A.X[e - 1]) < thr && fabs(xc - A.X[e + 1]) < thr;
+            bool v = D1 > T(0) && D2 > T(0) && Dd > T(0) && D0 > T(0) && Dr > T(0);
+            const T thr = T(0.01);
+            v = v && fabs(X1 - X2) < thr && fabs(X1 - Xd) < thr && fabs(X1 - X0) < thr && fabs(X1 - Xr) < thr;
             vl = v ? T(1) : T(0);
         }
         A.B_I[e] = bi; A.g0[e] = g0; A.g1[e] = g1; A.g2[e] = g2; A.valid[e] = vl;
-        A.fl[e] = (uint8_t)((A.D_i[e] > T(0) ? 1 : 0) | (vl == T(1) ? 2 : 0));
+        A.fl[e] = (uint8_t)((Dself > T(0) ? 1 : 0) | (vl == T(1) ? 2 : 0));
     }
 }
 
