@@ -326,8 +326,8 @@ def main():
         if gf:
             rel = abs(final - gf[-1]) / abs(gf[-1])
             envd = abs(gf[-1] - gd[-1]) / abs(gd[-1]) if gd else None
-            # the float oracle's own cost goes UP on some Gauss-Newton steps once the solve has reached its rounding floor: the largest such increase is the noise
-            # every float implementation carries in its final energy (tests/test_horizon_gpu.py)
+            # yardsticks (tests/test_horizon_gpu.py): the oracle's own cost goes UP on some Gauss-Newton steps of this solve (inexact 400-iteration PCG solves, no line
+            # search; in float and in double alike), the float and the double oracle end apart, and one 400-iteration step re-rounded (fma build) differs by `yard`
             noise = max([0.0] + [(b - a) / a for a, b in zip(gf[1:], gf[2:]) if b > a])
             yard = rerounding_yardstick()
             solve.update({"final_energy_oracle_float": gf[-1], "final_energy_oracle_double": gd[-1] if gd else None, "rel_err_vs_oracle_float": rel,

@@ -147,9 +147,10 @@ def test_metric_solve_8x400_final_energy(size, precision):
     s.close()
     other = G.get(f"solve8_{size}_{'float' if dbl else 'double'}")
     env = abs(other["costs"][-1] - ref[-1]) / abs(ref[-1]) if other else 0.0
-    # The float solve reaches its rounding floor after three steps: the float ORACLE's own cost then goes UP on every second Gauss-Newton step (2048^2: 5574 ->
-    # 5593, 5493 -> 5521, 5450 -> 5464) -- something an exact Gauss-Newton step on this energy does not do.  The largest such increase is the size of the noise any
-    # float implementation (the reference's atomics included) carries in its final energy; the HIP solve must end within it (measured: 1.1e-3 against 5.1e-3).
+    # Yardsticks for the end of an 8-step solve.  (1) The float and the double oracle end 3e-3 apart at 2048^2 (5464.44 / 5448.30).  (2) The outer iteration itself is
+    # not monotone here -- a Gauss-Newton step with a 400-iteration PCG solve and no line search: the oracle's cost goes UP on every second step from the fourth on, in
+    # float (5574 -> 5593, 5493 -> 5521, 5450 -> 5464) and in double alike (5587 -> 5592, 5491 -> 5518) -- so where exactly a trajectory stands after step 8 depends on
+    # sub-per-cent differences of the earlier steps; the largest such increase (5e-3) is taken as the scale.
     noise = max([0.0] + [(b - a) / a for a, b in zip(ref[1:], ref[2:]) if b > a])
     # ... and where the solve has not reached that floor yet (4096^2: still descending after 8 steps) the trajectories parted in the first step already: the
     # re-rounding yardstick of one step (the fma build of the oracle against the plain one, largest over the horizons: 2.6e-3 float, 7.8e-4 double at 2048^2)
