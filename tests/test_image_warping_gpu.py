@@ -247,6 +247,34 @@ def test_marching_step_kernels_equal_the_flat_ones(monkeypatch, jitter, liters):
         assert rel_err(outs["march"][1], outs[name][1]) < 1e-11
 
 
+def test_urshape_leaves_the_lattice_between_two_steps(oracle_lib):
+    """The marching PCGInit1 of step n runs on the lattice verdict of step n - 1's bind while its own bind's verdict is in flight; a caller that moves UrShape off the
+    unit lattice between two Opt_ProblemStep calls (in place, same buffers) makes that guess wrong: the lattice variant has to be redone as the general one before the first
+    PCG launch (ImageWarpingOps::pcgIteration).  Both steps against the oracle, which is given the same edit; then back onto the lattice for a third step."""
+    import torch
+    P = wl.image_warping(150, 97, double=True, random_state=21, mask_fraction=0.05, perturb=0.3)
+    o = oracle_solver(oracle_lib, P, nIterations=3, lIterations=9)
+    g = hip_solver(P, nIterations=3, lIterations=9)
+    dev = api.to_device(P)
+    Pref = P.clone()
+    o.init(Pref.params); g.init(dev)
+    assert o.step(Pref.params) and g.step(dev)
+    assert abs(g.cost() - o.cost()) <= 1e-10 * abs(o.cost())
+    rng = np.random.default_rng(5)
+    lattice = np.array(Pref.params[2], copy=True)
+    jit = 0.03 * rng.standard_normal(Pref.params[2].shape)
+    Pref.params[2][...] = lattice + jit                               # UrShape (binding index 2), in place on both sides
+    dev[2].copy_(torch.from_numpy(lattice + jit).cuda())
+    assert o.step(Pref.params) and g.step(dev)
+    assert abs(g.cost() - o.cost()) <= 1e-10 * abs(o.cost())
+    Pref.params[2][...] = lattice
+    dev[2].copy_(torch.from_numpy(lattice).cuda())
+    o.step(Pref.params); g.step(dev)
+    assert abs(g.cost() - o.cost()) <= 1e-10 * abs(o.cost())
+    assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < 1e-9
+    g.close(); o.close()
+
+
 @pytest.mark.parametrize("double", [False, True])
 def test_real_cat_mask(oracle_lib, double):
     """image_warping on the reference example's own mask (examples/data/cat512_mask.png sampled every 4th pixel,
