@@ -1272,7 +1272,6 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAV
                 if (LM || !kRfree) { st2<kNTS>(rO, i, rx, ry); st1<kNTS>(rA, i, ra); }
                 st2<kNTS>(pO, i, nC.q.ox, nC.q.oy); st1<kNTS>(pA, i, nC.q.a);
             }
-            if (own) accNum += dprod3(nC.mx, rx, rx) + dprod3(nC.my, ry, ry) + dprod3(nC.ma, ra, ra);
         }
         Q<T> l2 = nB.lf, r2 = nB.rt;
         if (!IW_SHARE_PAIRS) dppShiftVec<true>(nB.q, l2);
@@ -1282,8 +1281,16 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAV
         if (LM) { ox += nB.cx * nB.q.ox; oy += nB.cy * nB.q.oy; oa += nB.ca * nB.q.a; }
         if (live && writer && y >= yb && (!IW_OWN_CHECK || (phys(y) >= K.ownBegin && phys(y) < K.ownEnd))) {
             accDen += (double)(nB.q.ox * ox + nB.q.oy * oy + nB.q.a * oa);
-            acc2 += dprod3(nB.mx, nB.rx, ox) + dprod3(nB.my, nB.ry, oy) + dprod3(nB.ma, nB.ra, oa);
-            acc3 += dprod3(nB.mx, ox, ox) + dprod3(nB.my, oy, oy) + dprod3(nB.ma, oa, oa);
+            // sum M r^2, sum M r Ap, sum M Ap^2 of this row from shared double factors (dprod3's arithmetic: ((double)M * (double)r) * (double)r etc.; sum M r^2 used to be
+            // taken where r_k is formed, one trip earlier -- the same rows in the same order, 8 conversions / products per row less)
+            {
+                const double mx = (double)nB.mx, my = (double)nB.my, ma = (double)nB.ma;
+                const double rx = (double)nB.rx, ry = (double)nB.ry, ra = (double)nB.ra, ax = (double)ox, ay = (double)oy, az = (double)oa;
+                const double mrx = mx * rx, mry = my * ry, mra = ma * ra;
+                accNum += mrx * rx + mry * ry + mra * ra;
+                acc2 += mrx * ax + mry * ay + mra * az;
+                acc3 += (mx * ax) * ax + (my * ay) * ay + (ma * az) * az;
+            }
         }
     };
     OldRow<T> o0, o1, o2;
