@@ -467,9 +467,9 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
 // Trip Y stages row Y (PCGStep2 + PCGStep3 of the previous iteration: r_k, p_k, and for the rows the workgroup owns the stores of r_k, p_k, delta and the Q
 // sum), forms b(Y) = dB_I(., Y) . p_k, the five row values (J p_k)_r of the centres of row Y - 1, and the gather of row Y - 2 -- the expressions of
 // sfs_applyTiled in the same order, so the results are the tiled kernel's bit for bit.
-template <class T> struct SRaw { T r, p, ap, g0, g1, g2, ctc, dl, bb; int mr, mc, fl; };
+template <class T> struct SRaw { T r, p, ap, g0, g1, g2, ctc, dl, bb; int mr, mc, fl; };      // JTF mode: r = X, p = B_I, dl = D_i
 template <class T> struct SRow {
-    T v, rk;               // p_k (what J^T J is applied to), r_k
+    T v, rk;               // p_k (what J^T J is applied to), r_k        (JTF mode: X, B_I)
     T g0, g1, g2, ctc;     // dB_I / d{d0, d1, d2} (0 outside the image), CtC
     int mr, mc;            // edge masks, 0 unless the pixel is an interior row centre
     int ok, valid, ex;     // interior row centre; ... whose regularisation rows are on; D_i > 0 (the unknown is not excluded)
@@ -482,12 +482,16 @@ constexpr int kSfsMarchBlock = SFS_MARCH_WAVES * kWave, kSfsSpan = kWave - 4;
 #ifndef SFS_MARCH_MINWAVES
 #define SFS_MARCH_MINWAVES 1      // waves per SIMD the register allocation must leave room for (3: at most 168 VGPRs -- the double kernel then spills; A/B builds)
 #endif
-template <class T, bool LM>
-__global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMarch(SArgs<T> A, T* __restrict__ out, const T* __restrict__ CtC, SIterK<T> K, int rowsPerGroup, int gx, int gy, int gyPerXcd) {
+// JTF = true turns the same march into PCGInit1 (sfs_rows<2> + sfs_gather<JTF> in one launch): the staged vector is X itself, b is the stored B_I instead of dB_I . v, the
+// row values are the residuals (in sfs_rows' association), the gather also sums the squared coefficients: out = -J^T F, diag = diag(J^T J).  No sums, no PCG state.
+template <class T, bool LM, bool JTF = false>
+__global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMarch(SArgs<T> A, T* __restrict__ out, const T* __restrict__ CtC, SIterK<T> K, int rowsPerGroup, int gx, int gy, int gyPerXcd,
+                                                                                   T* __restrict__ diag = nullptr) {
     __shared__ double scratch[6 * (kSfsMarchBlock / kWave + 1)];
     T alpha = 0, beta = 0;
-    const bool keep = K.first != 0 || K.restart != 0;              // r (and, at the start, p) are already those of this iteration
-    if (K.restart) {
+    const bool keep = JTF || K.first != 0 || K.restart != 0;       // r (and, at the start, p) are already those of this iteration
+    if (JTF) {
+    } else if (K.restart) {
         const double* const ps[2] = {K.betaNum, K.betaDen}; const int ns[2] = {K.nBetaNum, K.nBetaDen}; double o2[2];
         sumPartialsN<2>(ps, ns, scratch, o2);
         const T bNum = (T)o2[0], bDen = (T)o2[1];
@@ -520,9 +524,10 @@ __global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMar
     auto load = [&](int y) {
         SRaw<T> w;
         const long g = (long)min(max(y, 0), A.H - 1) * A.W + xc;
-        w.r = K.rOld[g]; w.p = K.pOld[g]; w.ap = K.ApOld[g];
         w.g0 = A.g0[g]; w.g1 = A.g1[g]; w.g2 = A.g2[g]; w.fl = A.fl[g]; w.mr = A.mR[g]; w.mc = A.mC[g];
         const long go = (y >= yb && y < ye) ? g : (long)xc;
+        if (JTF) { w.r = A.X[g]; w.p = A.B_I[g]; w.ap = 0; w.ctc = 0; w.dl = A.D_i[go]; w.bb = 0; return w; }
+        w.r = K.rOld[g]; w.p = K.pOld[g]; w.ap = K.ApOld[g];
         w.ctc = LM ? CtC[go] : T(0); w.dl = K.delta[go]; w.bb = LM ? K.b[go] : T(0);
         return w;
     };
@@ -530,16 +535,17 @@ __global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMar
         SRow<T> n;
         const bool in = xin && y >= 0 && y < A.H;
         T rk = 0, pk = 0;
-        if (in) {
+        if (JTF) { pk = in ? w.r : T(0); rk = in ? w.p : T(0); n.ctc = w.dl; }        // X, B_I; the own pixel's D_i rides in the ctc slot
+        else if (in) {
             rk = keep ? w.r : w.r - alpha * w.ap;                                      // PCGStep2 (solver.t:464)
             pk = K.first ? w.p : rk + beta * w.p;                                      // PCGStep3 with z = r (solver.t:549)
         }
         n.v = pk; n.rk = rk;
-        n.g0 = in ? w.g0 : T(0); n.g1 = in ? w.g1 : T(0); n.g2 = in ? w.g2 : T(0); n.ctc = w.ctc;
+        n.g0 = in ? w.g0 : T(0); n.g1 = in ? w.g1 : T(0); n.g2 = in ? w.g2 : T(0); if (!JTF) n.ctc = w.ctc;
         const bool ok = in && sfs_interior(A, x, y);
         n.ok = ok; n.mr = ok ? w.mr : 0; n.mc = ok ? w.mc : 0; n.valid = ok && (w.fl & 2) != 0;
         n.ex = in && (w.fl & 1) != 0;
-        if (writer && y >= yb && y < ye) {                                             // this workgroup's own rows
+        if (!JTF && writer && y >= yb && y < ye) {                                     // this workgroup's own rows
             const long g = (long)y * A.W + x;
             K.rNew[g] = rk; K.pNew[g] = pk;
             if (!keep) {                                                               // the rest of PCGStep2 of iteration k-1 for this pixel
@@ -561,13 +567,18 @@ __global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMar
         const T cyN = cyOf(Y);
         // b(., Y) = g1 v + g0 v(x-1) + g2 v(y-1)                                      (sfs_rows<3>'s `base`)
         const T vL = dppShift<true>(n.v);
-        const T bY = n.g1 * n.v + n.g0 * vL + n.g2 * R1.v;
+        const T bY = JTF ? n.rk : n.g1 * n.v + n.g0 * vL + n.g2 * R1.v;
         // row values at the centres of row Y - 1 (R1)
         SQ<T> qn;
         {
             const T right = dppShift<false>(b1);
-            qn.gh = R1.ok ? A.w_g * (T)R1.mr * (b1 - right) : T(0);
-            qn.gv = R1.ok ? A.w_g * (T)R1.mc * (b1 - bY) : T(0);
+            if (JTF) {      // sfs_rows<2>: w_g * ((B_I(c) - B_I(c + e)) * mask)
+                qn.gh = R1.ok ? A.w_g * ((b1 - right) * (T)R1.mr) : T(0);
+                qn.gv = R1.ok ? A.w_g * ((b1 - bY) * (T)R1.mc) : T(0);
+            } else {
+                qn.gh = R1.ok ? A.w_g * (T)R1.mr * (b1 - right) : T(0);
+                qn.gv = R1.ok ? A.w_g * (T)R1.mc * (b1 - bY) : T(0);
+            }
             const T v1l = dppShift<true>(R1.v), v1r = dppShift<false>(R1.v);
             T js[3];
 #pragma unroll
@@ -584,9 +595,9 @@ __global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMar
         {
             const int y = Y - 2;
             const T ve = R2.v;
-            T s = 0;
-            auto add = [&](T coef, T q) { s += coef * q; };
-            add(A.w_p, A.w_p * ve);
+            T s = 0, dsum = 0;
+            auto add = [&](T coef, T q) { s += coef * q; if (JTF) dsum += coef * coef; };
+            add(A.w_p, JTF ? A.w_p * (ve - R2.ctc) : A.w_p * ve);      // the fitting row: w_p (X - D_i) / w_p v
             const T g0r = dppShift<false>(R2.g0);
             const int mrR = dppShift<false>(R2.mr), mrL = dppShift<true>(R2.mr), okR = dppShift<false>(R2.ok), okL = dppShift<true>(R2.ok);
             const int mr1L = dppShift<true>(R1.mr), ok1L = dppShift<true>(R1.ok);
@@ -611,6 +622,9 @@ __global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMar
             reg(vLft, T(-1), dppShift<true>(q2.s0), dppShift<true>(q2.s1), dppShift<true>(q2.s2));
             reg(R1.valid, T(-1), qn.s0, qn.s1, qn.s2);
             reg(R3.valid, T(-1), q3.s0, q3.s1, q3.s2);
+            if (JTF) {
+                if (writer && y >= yb && y < ye) { out[(long)y * A.W + x] = R2.ex ? -s : -T(0); diag[(long)y * A.W + x] = R2.ex ? dsum : T(0); }
+            } else {
             if (LM) s += R2.ctc * ve;
             if (!R2.ex) s = 0;
             if (writer && y >= yb && y < ye) {
@@ -620,6 +634,7 @@ __global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMar
                 const T zk = K.first ? ve : rk;                                        // launch 0: alphaNumerator_0 = r_0 . p_0 (the reference's start)
                 accNum += (double)(zk * rk); acc2 += (double)(rk * s); acc3 += (double)(s * s);
                 if (K.first) accRR += (double)(rk * rk);
+            }
             }
         }
         R3 = R2; R2 = R1; R1 = n; q3 = q2; q2 = qn; b1 = bY; cy2 = cy1; cy1 = cyN;
@@ -644,6 +659,7 @@ __global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMar
             rA = load(Y + 2); trip(Y + 1, rB);
         }
     }
+    if (JTF) return;
     double vv[6] = {acc, accNum, acc2, acc3, accRR, accQ};
     blockReduceSumN<6>(vv, scratch);
     if (threadIdx.x == 0) {
@@ -651,6 +667,82 @@ __global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMar
         if (K.first) K.rr[blockIdx.x] = vv[4];
         if (LM && K.q) { if (K.qTag) storeTaggedPartial(K.q, blockIdx.x, vv[5], K.qTag); else K.q[blockIdx.x] = vv[5]; }
     }
+}
+
+// ---- computeCost / computeModelCost as a march (round 3): sfs_rows<0 / 1>'s expressions, centre row Y - 1 from the rows Y - 2 .. Y of X (and of delta) held in registers ---------
+template <class T, bool MODEL>
+__global__ __launch_bounds__(kSfsMarchBlock) void sfs_costMarch(SArgs<T> A, const T* __restrict__ dl, double* __restrict__ partials, int rowsPerGroup, int gx, int gy, int gyPerXcd) {
+    __shared__ double scratch[kSfsMarchBlock / kWave + 1];
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int by = xcd * gyPerXcd + slot / gx, bx = slot % gx;
+    const bool idle = by >= gy || slot / gx >= gyPerXcd;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int x = bx * (kSfsMarchBlock / kWave) * kSfsSpan + wave * kSfsSpan + lane - 2;
+    const bool xin = x >= 0 && x < A.W;
+    const bool writer = xin && lane >= 2 && lane < 2 + kSfsSpan;
+    const int yb = idle ? A.H : by * rowsPerGroup, ye = idle ? A.H : min(yb + rowsPerGroup, A.H);
+    const int xc = min(max(x, 0), A.W - 1);
+    const T cxc = coefK(A, 0, x, 0), cxl = coefK(A, 0, x - 1, 0), cxr = coefK(A, 0, x + 1, 0);
+    struct Raw { T X, B, Di, d, g0, g1, g2; int fl, mr, mc; };
+    struct Row { T X, B, Di, d, db; int mr, mc, ok, valid, ex; };      // db = dB_I . delta of the row (MODEL)
+    auto load = [&](int y) {
+        Raw w;
+        const long g = (long)min(max(y, 0), A.H - 1) * A.W + xc;
+        w.X = A.X[g]; w.B = A.B_I[g]; w.Di = A.D_i[g]; w.fl = A.fl[g]; w.mr = A.mR[g]; w.mc = A.mC[g];
+        if (MODEL) { w.d = dl[g]; w.g0 = A.g0[g]; w.g1 = A.g1[g]; w.g2 = A.g2[g]; } else { w.d = 0; w.g0 = 0; w.g1 = 0; w.g2 = 0; }
+        return w;
+    };
+    double acc = 0;
+    Row R1{}, R2{};
+    T cy1 = 0, cy2 = 0;
+    auto trip = [&](int Y, const Raw& w) {
+        Row n;
+        const bool in = xin && Y >= 0 && Y < A.H;
+        n.X = in ? w.X : T(0); n.B = in ? w.B : T(0); n.Di = w.Di; n.d = in ? w.d : T(0);
+        const bool ok = in && sfs_interior(A, x, Y);
+        n.ok = ok; n.mr = ok ? w.mr : 0; n.mc = ok ? w.mc : 0; n.valid = ok && (w.fl & 2) != 0; n.ex = in && (w.fl & 1) != 0;
+        const T cyN = coefK(A, 1, 0, Y);
+        n.db = 0;
+        if (MODEL) { const T dL = dppShift<true>(n.d); n.db = (in ? w.g1 : T(0)) * n.d + (in ? w.g0 : T(0)) * dL + (in ? w.g2 : T(0)) * R1.d; }      // sfs_rows' `base`
+        // centre row Y - 1 (R1); rows Y - 2 (R2) and Y (n) around it
+        {
+            const int y = Y - 1;
+            T rp = 0, jp = 0;
+            if (R1.ex) { rp = A.w_p * (R1.X - R1.Di); if (MODEL) jp = A.w_p * R1.d; }
+            const T bR = dppShift<false>(R1.B);
+            T rgh = R1.ok ? A.w_g * ((R1.B - bR) * (T)R1.mr) : T(0), rgv = R1.ok ? A.w_g * ((R1.B - n.B) * (T)R1.mc) : T(0);
+            T jgh = 0, jgv = 0;
+            if (MODEL) {
+                const T dbR = dppShift<false>(R1.db);
+                jgh = R1.ok ? A.w_g * (T)R1.mr * (R1.db - dbR) : T(0); jgv = R1.ok ? A.w_g * (T)R1.mc * (R1.db - n.db) : T(0);
+            }
+            const T xl = dppShift<true>(R1.X), xr = dppShift<false>(R1.X);
+            T dlf = 0, drt = 0;
+            if (MODEL) { dlf = dppShift<true>(R1.d); drt = dppShift<false>(R1.d); }
+            T rs[3], js[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const T c0 = k == 0 ? cxc : k == 1 ? cy1 : T(1), cl = k == 0 ? cxl : k == 1 ? cy1 : T(1), cu = k == 0 ? cxc : k == 1 ? cy2 : T(1),
+                        cr = k == 0 ? cxr : k == 1 ? cy1 : T(1), cd = k == 0 ? cxc : k == 1 ? cyN : T(1);
+                T sr = 0, sj = 0;
+                sr += (T(4) * c0) * R1.X; sr += (T(-1) * cl) * xl; sr += (T(-1) * cu) * R2.X; sr += (T(-1) * cr) * xr; sr += (T(-1) * cd) * n.X;
+                if (MODEL) { sj += (T(4) * c0) * R1.d; sj += (T(-1) * cl) * dlf; sj += (T(-1) * cu) * R2.d; sj += (T(-1) * cr) * drt; sj += (T(-1) * cd) * n.d; }
+                rs[k] = R1.valid ? A.w_s * sr : T(0); js[k] = R1.valid ? A.w_s * sj : T(0);
+            }
+            if (R1.ex && writer && y >= yb && y < ye) {      // rows centred on excluded pixels are not part of the cost (solver.t:583, 669)
+                const T a = rp + jp, b = rgh + jgh, c = rgv + jgv, d0 = rs[0] + js[0], d1 = rs[1] + js[1], d2 = rs[2] + js[2];
+                acc += (double)(T(0.5) * (a * a + b * b + c * c + d0 * d0 + d1 * d1 + d2 * d2));
+            }
+        }
+        R2 = R1; R1 = n; cy2 = cy1; cy1 = cyN;
+    };
+    Raw rA = load(yb - 1), rB;
+    for (int Y = yb - 1; Y < ye + 1; Y += 2) {
+        rB = load(Y + 1); trip(Y, rA);
+        rA = load(Y + 2); trip(Y + 1, rB);
+    }
+    const double t = blockReduceSum(acc, scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
 template <class T>
@@ -673,6 +765,8 @@ struct SfsOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_SFS_GRID")) gridOverride = atoi(e);
         if (const char* e = getenv("OPT_AMD_SFS_MARCH")) marchIter = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_SFS_MARCH_GRID")) marchGridOverride = atoi(e);
+        if (const char* e = getenv("OPT_AMD_SFS_MARCH_JTF")) marchJtf = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_SFS_MARCH_COST")) marchCost = atoi(e) != 0;
     }
     ~SfsOps() override { for (void* p : owned) (void)hipFree(p); }
     int grid() const { return (int)std::max<long>(1, std::min<long>(((long)A.W * A.H + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
@@ -685,8 +779,22 @@ struct SfsOps : EnergyOps<T> {
     }
     T* unknownPtr(int) const override { return const_cast<T*>(A.X); }
     void precompute(LaunchCtx& ctx) override { ScopedKernel k(ctx, "precompute"); sfs_precompute<T><<<grid(), kBlock, 0, ctx.stream>>>(A); }
-    void evalCost(Reduction& out, LaunchCtx& ctx) override { ScopedKernel k(ctx, "computeCost"); sfs_rows<T, 0><<<grid(), kBlock, 0, ctx.stream>>>(A, nullptr, out.partials); out.n = grid(); }
+    void evalCost(Reduction& out, LaunchCtx& ctx) override {
+        ScopedKernel k(ctx, "computeCost");
+        if (marchIter && marchCost) {
+            int gx, gy, rows, per; marchGrid(false, gx, gy, rows, per);
+            sfs_costMarch<T, false><<<8 * per * gx, kSfsMarchBlock, 0, ctx.stream>>>(A, nullptr, out.partials, rows, gx, gy, per); out.n = 8 * per * gx;
+            return;
+        }
+        sfs_rows<T, 0><<<grid(), kBlock, 0, ctx.stream>>>(A, nullptr, out.partials); out.n = grid();
+    }
     void evalJTF(T* r, T* diag, LaunchCtx& ctx) override {
+        if (marchIter && marchJtf) {      // rows + gather in one marching launch (round 3)
+            ScopedKernel k(ctx, "PCGInit1");
+            int gx, gy, rows, per; marchGrid(false, gx, gy, rows, per);
+            sfs_pcgMarch<T, false, true><<<8 * per * gx, kSfsMarchBlock, 0, ctx.stream>>>(A, r, nullptr, SIterK<T>{}, rows, gx, gy, per, diag);
+            return;
+        }
         { ScopedKernel k(ctx, "PCGInit1_rows"); sfs_rows<T, 2><<<grid(), kBlock, 0, ctx.stream>>>(A, nullptr, nullptr); }
         { ScopedKernel k(ctx, "PCGInit1"); sfs_gather<T, true, false><<<grid(), kBlock, 0, ctx.stream>>>(A, nullptr, r, diag, nullptr, nullptr); }
     }
@@ -722,12 +830,36 @@ struct SfsOps : EnergyOps<T> {
         if (dot) dot->n = grid();
     }
     void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {
-        ScopedKernel k(ctx, "computeModelCost"); sfs_rows<T, 1><<<grid(), kBlock, 0, ctx.stream>>>(A, delta, out.partials); out.n = grid();
+        ScopedKernel k(ctx, "computeModelCost");
+        if (marchIter && marchCost) {
+            int gx, gy, rows, per; marchGrid(false, gx, gy, rows, per);
+            sfs_costMarch<T, true><<<8 * per * gx, kSfsMarchBlock, 0, ctx.stream>>>(A, delta, out.partials, rows, gx, gy, per); out.n = 8 * per * gx;
+            return;
+        }
+        sfs_rows<T, 1><<<grid(), kBlock, 0, ctx.stream>>>(A, delta, out.partials); out.n = grid();
     }
     // ---- one kernel per PCG iteration (sfs_applyTiled<.., ITER>) ----
     bool oneKernel = true;              // OPT_AMD_SFS_ONEKERNEL=0: three kernels per iteration (A/B switch)
     bool marchIter = true;              // OPT_AMD_SFS_MARCH=0: the LDS-tiled iteration kernel of round 2 (A/B switch)
+    bool marchJtf = true;               // OPT_AMD_SFS_MARCH_JTF=0: PCGInit1 as rows pass + gather pass
+    bool marchCost = true;              // OPT_AMD_SFS_MARCH_COST=0: computeCost / computeModelCost as the flat rows pass
     int occMarch[2] = {0, 0}, marchGridOverride = 0;
+    // grid of the marching kernels: column strips of kSfsSpan columns per wave x row groups, 8 XCD-contiguous ranges of row groups
+    void marchGrid(bool lmLoop, int& mgx, int& mgy, int& mRows, int& mPer) {
+        int& o = occMarch[lmLoop];
+        if (o == 0) {
+            const void* fn = lmLoop ? (const void*)sfs_pcgMarch<T, true> : (const void*)sfs_pcgMarch<T, false>;
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, fn, kSfsMarchBlock, 0));
+            o = std::max(1, std::min(o, 16));
+        }
+        mgx = divUp(A.W, (kSfsMarchBlock / kWave) * kSfsSpan);
+        // Rows per workgroup against workgroups in flight: every workgroup stages 4 halo rows on top of its own (measured at 1024^2 double LM, us per iteration:
+        // 1024 workgroups of 10 rows 44.0, 768 x 13 rows 41.6, 512 x 19 rows 42.1, 256 x 37 rows 59.3): the default takes three quarters of the co-resident count.
+        const int target = marchGridOverride > 0 ? marchGridOverride : std::max(1, cus * o * 3 / 4);
+        mgy = std::max(1, std::min(std::min(A.H, target / mgx), (kMaxPartials / 2 - 8 * mgx) / mgx));
+        mRows = divUp(A.H, mgy); mgy = divUp(A.H, mRows);
+        mPer = divUp(mgy, 8);
+    }
     double* rrPartials = nullptr; int nRR = 0; bool prevWasFirst = false;
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
         if (!oneKernel || !tiledApply || a.pre || this->slab.active) return false;       // this energy does not precondition (pre == nullptr)
@@ -737,23 +869,7 @@ struct SfsOps : EnergyOps<T> {
         int g = tileGrid(lmLoop, true);
         // the marching kernel's grid: column strips of kSfsSpan columns per wave x row groups sized to be co-resident, 8 XCD-contiguous ranges of row groups
         int mgx = 0, mgy = 0, mRows = 0, mPer = 0;
-        if (marchIter) {
-            int& o = occMarch[lmLoop];
-            if (o == 0) {
-                const void* fn = lmLoop ? (const void*)sfs_pcgMarch<T, true> : (const void*)sfs_pcgMarch<T, false>;
-                HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, fn, kSfsMarchBlock, 0));
-                o = std::max(1, std::min(o, 16));
-            }
-            mgx = divUp(A.W, (kSfsMarchBlock / kWave) * kSfsSpan);
-            // Rows per workgroup against workgroups in flight: every workgroup stages 4 halo rows on top of its own, and the kernel is bound by what it moves
-            // (measured at 1024^2 double LM, us per iteration: 1024 workgroups of 10 rows 44.0, 768 x 13 rows 41.6, 512 x 19 rows 42.1, 256 x 37 rows 59.3), so
-            // the default takes three quarters of the co-resident count.
-            const int target = marchGridOverride > 0 ? marchGridOverride : std::max(1, cus * o * 3 / 4);
-            mgy = std::max(1, std::min(std::min(A.H, target / mgx), (kMaxPartials / 2 - 8 * mgx) / mgx));
-            mRows = divUp(A.H, mgy); mgy = divUp(A.H, mRows);
-            mPer = divUp(mgy, 8);
-            g = 8 * mPer * mgx;
-        }
+        if (marchIter) { marchGrid(lmLoop, mgx, mgy, mRows, mPer); g = 8 * mPer * mgx; }
         SIterK<T> K{};
         K.rOld = a.rOld; K.ApOld = a.ApOld; K.pOld = a.pOld; K.rNew = a.rNew; K.pNew = a.pNew; K.delta = a.delta; K.deltaOut = a.deltaOut ? a.deltaOut : a.delta;
         K.b = a.b; K.q = a.q ? a.q->partials : nullptr; K.qTag = a.qTag; K.first = a.first; K.restart = a.afterReset;
