@@ -65,6 +65,15 @@ struct PcgIterArgs {
                                                          // the next launch before it has read Q: an early-out then still finds the old delta)
 };
 
+// Arguments of EnergyOps::evalJTFInitLM: what PCGInit1 + PCGSaveSSq + PCGFinalizeDiagonal (solver.t:361-419, 624-664; solver.hip k_finalizeDiagonal<T, true>) read and write.
+template <class T>
+struct LmInitArgs {
+    T *CtC, *SSq, *r, *delta, *pre, *b, *p;
+    T radius, minLm, maxLm;
+    int saveSSq;                    // first outer iteration: SSq <- guardedInvert(diag) (or of 1 without preconditioner)
+    Reduction *rDotP, *q;           // partial sums of r . p (the first alphaNumerator) and of Q_0 (exactly 0)
+};
+
 // Everything the solver needs from an energy.  T = opt_float (float or double).
 // Contract shared by all implementations:
 //  * solver vectors are laid out like the unknown vector: unknown images in declaration order, AoS,
@@ -111,6 +120,10 @@ struct EnergyOps {
     // preconditioner, delta = 0, aNum0 = partial sums of r.p -- for a kernel set whose pcgIteration needs neither the diag nor the preconditioner vector.
     // Returning true promises that pcgIteration will accept the loop that follows.  false: the solver runs evalJTF + its own flat pass.
     virtual bool evalJTFInit(T* /*r*/, T* /*p*/, T* /*delta*/, long /*nPad*/, Reduction& /*aNum0*/, LaunchCtx&) { return false; }
+    // Optional (Levenberg-Marquardt, single GPU): PCGInit1 and everything k_finalizeDiagonal<T, true> does after it, in the energy's own J^T F kernel -- r = -J^T F,
+    // CtC = clamped diag(J^T J) / radius, the LM preconditioner, b = r, p = M r, delta = 0, SSq (first outer iteration), partial sums of r . p.  false: the solver
+    // runs evalJTF and its flat pass.
+    virtual bool evalJTFInitLM(const LmInitArgs<T>& /*args*/, LaunchCtx&) { return false; }
     // Optional: the end of a single-kernel Gauss-Newton loop in one pass over the unknowns -- whatever pcgFinish would still add to delta, the last iteration's
     // delta += alpha p (alpha = sum aNum / sum aDen, guarded) and PCGLinearUpdate X += delta.  delta itself is dead afterwards and need not be written.
     // true: the unknowns are updated (the solver skips pcgFinish, the last PCGStep2 and PCGLinearUpdate).

@@ -484,9 +484,12 @@ constexpr int kSfsMarchBlock = SFS_MARCH_WAVES * kWave, kSfsSpan = kWave - 4;
 #endif
 // JTF = true turns the same march into PCGInit1 (sfs_rows<2> + sfs_gather<JTF> in one launch): the staged vector is X itself, b is the stored B_I instead of dB_I . v, the
 // row values are the residuals (in sfs_rows' association), the gather also sums the squared coefficients: out = -J^T F, diag = diag(J^T J).  No sums, no PCG state.
+// With `fin.CtC` set the JTF march also does what k_finalizeDiagonal<T, true> does after PCGInit1 in an LM step (this energy: no preconditioner, no graph): SSq, delta = 0,
+// the clamped CtC, the LM preconditioner, b = r, p = M r and the partial sums of r . p -- the same expressions on the value the gather has just produced.
+template <class T> struct SFin { T *CtC, *SSq, *delta, *pre, *b, *p; T radius, minLm, maxLm; int saveSSq; double *dPart, *qPart; };
 template <class T, bool LM, bool JTF = false>
 __global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMarch(SArgs<T> A, T* __restrict__ out, const T* __restrict__ CtC, SIterK<T> K, int rowsPerGroup, int gx, int gy, int gyPerXcd,
-                                                                                   T* __restrict__ diag = nullptr) {
+                                                                                   T* __restrict__ diag = nullptr, SFin<T> fin = SFin<T>{}) {
     __shared__ double scratch[6 * (kSfsMarchBlock / kWave + 1)];
     T alpha = 0, beta = 0;
     const bool keep = JTF || K.first != 0 || K.restart != 0;       // r (and, at the start, p) are already those of this iteration
@@ -623,7 +626,29 @@ __global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMar
             reg(R1.valid, T(-1), qn.s0, qn.s1, qn.s2);
             reg(R3.valid, T(-1), q3.s0, q3.s1, q3.s2);
             if (JTF) {
-                if (writer && y >= yb && y < ye) { out[(long)y * A.W + x] = R2.ex ? -s : -T(0); diag[(long)y * A.W + x] = R2.ex ? dsum : T(0); }
+                if (writer && y >= yb && y < ye) {
+                    const long e = (long)y * A.W + x;
+                    const T r0 = R2.ex ? -s : -T(0), dg = R2.ex ? dsum : T(0);
+                    out[e] = r0;
+                    if (fin.CtC) {      // k_finalizeDiagonal<T, true> with usePre = 0, graphMode = 0
+                        const T s1 = T(1) + sqrt(T(1));
+                        T S = T(1) / (s1 * s1);                               // guardedInvert(1)
+                        if (fin.saveSSq) fin.SSq[e] = S; else S = fin.SSq[e];
+                        fin.delta[e] = T(0);
+                        const T invRadius = T(1) / fin.radius;
+                        const T unclamped = dg * invRadius;                   // computeCtC: diag(J^T J) / radius (o.t:2277-2279)
+                        const T invS = T(1) / S;
+                        const T clampMul = invS / fin.radius;
+                        const T lo = fin.minLm * clampMul, hi = fin.maxLm * clampMul;
+                        const T c = fmin(fmax(unclamped, lo), hi);
+                        fin.CtC[e] = c;
+                        const T m = T(1) / (c + fin.radius * unclamped);
+                        fin.pre[e] = m;
+                        const T pp = m * r0;
+                        fin.p[e] = pp; fin.b[e] = r0;
+                        acc += (double)(r0 * pp);
+                    } else diag[e] = dg;
+                }
             } else {
             if (LM) s += R2.ctc * ve;
             if (!R2.ex) s = 0;
@@ -659,7 +684,13 @@ __global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMar
             rA = load(Y + 2); trip(Y + 1, rB);
         }
     }
-    if (JTF) return;
+    if (JTF) {
+        if (fin.CtC) {
+            const double t = blockReduceSum(acc, scratch);
+            if (threadIdx.x == 0) { fin.dPart[blockIdx.x] = t; fin.qPart[blockIdx.x] = 0.0; }
+        }
+        return;
+    }
     double vv[6] = {acc, accNum, acc2, acc3, accRR, accQ};
     blockReduceSumN<6>(vv, scratch);
     if (threadIdx.x == 0) {
@@ -767,6 +798,7 @@ struct SfsOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_SFS_MARCH_GRID")) marchGridOverride = atoi(e);
         if (const char* e = getenv("OPT_AMD_SFS_MARCH_JTF")) marchJtf = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_SFS_MARCH_COST")) marchCost = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_SFS_MARCH_FIN")) marchFin = atoi(e) != 0;
     }
     ~SfsOps() override { for (void* p : owned) (void)hipFree(p); }
     int grid() const { return (int)std::max<long>(1, std::min<long>(((long)A.W * A.H + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
@@ -798,6 +830,17 @@ struct SfsOps : EnergyOps<T> {
         { ScopedKernel k(ctx, "PCGInit1_rows"); sfs_rows<T, 2><<<grid(), kBlock, 0, ctx.stream>>>(A, nullptr, nullptr); }
         { ScopedKernel k(ctx, "PCGInit1"); sfs_gather<T, true, false><<<grid(), kBlock, 0, ctx.stream>>>(A, nullptr, r, diag, nullptr, nullptr); }
     }
+    bool evalJTFInitLM(const LmInitArgs<T>& a, LaunchCtx& ctx) override {
+        if (!(marchIter && marchJtf && marchFin) || this->slab.active) return false;
+        ScopedKernel k(ctx, "PCGInit1");
+        int gx, gy, rows, per; marchGrid(false, gx, gy, rows, per);
+        const int g = 8 * per * gx;
+        SFin<T> fin{a.CtC, a.SSq, a.delta, a.pre, a.b, a.p, a.radius, a.minLm, a.maxLm, a.saveSSq, a.rDotP->partials, a.q->partials};
+        sfs_pcgMarch<T, false, true><<<g, kSfsMarchBlock, 0, ctx.stream>>>(A, a.r, nullptr, SIterK<T>{}, rows, gx, gy, per, nullptr, fin);
+        a.rDotP->n = g; a.q->n = g;
+        return true;
+    }
+    bool marchFin = true;       // OPT_AMD_SFS_MARCH_FIN=0: PCGFinalizeDiagonal as the solver's flat pass
     bool tiledApply = true;     // OPT_AMD_SFS_TILED=0: rows pass + gather pass through the q planes
     // Grid of the tiled kernels: every workgroup loops over tiles, so the grid is capped at what is co-resident (LDS-limited: 4-5 workgroups per CU);
     // with more, the last round of workgroups runs on a partly empty chip (2048 workgroups on 1280 slots: 1.6 rounds).  OPT_AMD_SFS_GRID overrides (A/B).

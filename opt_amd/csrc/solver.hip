@@ -795,7 +795,12 @@ struct PcgSolver : SolverBase {
         // one GPU, r, p = M r, delta = 0 and the partial sums of r.p directly (EnergyOps::evalJTFInit)
         unknownsUpdated = false;
         const bool fusedInit = !lm && !distributed && oneKernel && r2 && sp.lIterations > 0 && E->evalJTFInit(r, p, delta, nPad, redC, ctx);
-        if (!fusedInit) E->evalJTF(r, CtC, ctx);
+        bool fusedInitLM = false;
+        if (lm && !distributed) {
+            LmInitArgs<T> la{CtC, SSq, r, delta, preconditioner, b, p, trust_region_radius, min_lm_diagonal, max_lm_diagonal, sp.nIter == 0 ? 1 : 0, &redC, &redQ};
+            fusedInitLM = E->evalJTFInitLM(la, ctx);
+        }
+        if (!fusedInit && !fusedInitLM) E->evalJTF(r, CtC, ctx);
         if (!lm && !fusedInit) {
             ScopedKernel k(ctx, "PCGInit1_Finish");
             k_initFinish<T><<<streamGrid, kBlock, 0, stream>>>(r, CtC, preconditioner, p, delta, nPacks, E->usePreconditioner ? 1 : 0, E->usesGraph ? 1 : 0, redC.partials);
@@ -803,7 +808,7 @@ struct PcgSolver : SolverBase {
         }
         aSlot = 0;
         if (lm) {
-            {   // PCGInit1_Finish + (first outer iteration) PCGSaveSSq + PCGFinalizeDiagonal in one pass
+            if (!fusedInitLM) {   // PCGInit1_Finish + (first outer iteration) PCGSaveSSq + PCGFinalizeDiagonal in one pass
                 ScopedKernel k(ctx, "PCGFinalizeDiagonal");
                 k_finalizeDiagonal<T, true><<<streamGrid, kBlock, 0, stream>>>(CtC, SSq, r, delta, preconditioner, b, p, nPacks, trust_region_radius, min_lm_diagonal,
                                                                                max_lm_diagonal, redC.partials, redQ.partials, E->usePreconditioner ? 1 : 0,

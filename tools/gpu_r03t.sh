@@ -5,5 +5,5 @@ timeout 900 python -m pytest tests/test_lm_controls_gpu.py tests/test_energies_g
 echo "pytest rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" $O/pytest.log | sed 's/ - .*//' | tail -10; grep -E "^E " $O/pytest.log | head -8
 for i in 1 2; do
   OPT_AMD_CONFIG=config3 python tools/bench_configs.py 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('march all', d['wall_s'], d['cost_final'], d['kernel_avg_us'])"
-  OPT_AMD_SFS_MARCH_COST=0 OPT_AMD_CONFIG=config3 python tools/bench_configs.py 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('flat cost', d['wall_s'], d['cost_final'], d['kernel_avg_us'].get('computeCost'), d['kernel_avg_us'].get('computeModelCost'))"
+  OPT_AMD_SFS_MARCH_FIN=0 OPT_AMD_CONFIG=config3 python tools/bench_configs.py 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('flat fin ', d['wall_s'], d['cost_final'], d['kernel_avg_us'].get('PCGInit1'), d['kernel_avg_us'].get('PCGFinalizeDiagonal'))"
 done
