@@ -247,6 +247,38 @@ def test_marching_step_kernels_equal_the_flat_ones(monkeypatch, jitter, liters):
         assert rel_err(outs["march"][1], outs[name][1]) < 1e-11
 
 
+SWITCHES = [{"OPT_AMD_RFREE": "0"}, {"OPT_AMD_RFREE": "0", "OPT_AMD_RECON_P": "1"}, {"OPT_AMD_PAIR_DELTA": "0"}, {"OPT_AMD_RECOMPUTE_AP": "0"}, {"OPT_AMD_FLAG_M": "0"},
+            {"OPT_AMD_COMPACT_M": "0"}, {"OPT_AMD_ITER_STEADY": "0"}, {"OPT_AMD_SWEEP": "0"}, {"OPT_AMD_ONEKERNEL": "0"}, {"OPT_AMD_ONEKERNEL": "0", "OPT_AMD_FUSE": "0"},
+            {"OPT_AMD_PAIR_DELTA": "0", "OPT_AMD_RFREE": "0"}, {"OPT_AMD_MARCH_INIT": "0", "OPT_AMD_RFREE": "0"}]
+
+
+@pytest.mark.parametrize("jitter", [0.0, 0.04])
+@pytest.mark.parametrize("liters", [2, 9])
+def test_development_switches_keep_the_result(monkeypatch, jitter, liters):
+    """INTEGRATION.md section 6 lists environment switches that select the alternative code paths the measurements compare (r in memory, unpaired delta, A p in
+    memory, preconditioner vector instead of flag byte / compact M_a, generic instead of steady-state kernel variants, three-kernel loop ...).  Every one of them must
+    solve the same problem: two Gauss-Newton steps in double against the default path, on a unit lattice and on a general UrShape, for a launch count on either side of the
+    first delta-writing launch."""
+    def run(env):
+        for k in {k for sw in SWITCHES for k in sw}:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        P = wl.image_warping(233, 140, double=True, random_state=9, mask_fraction=0.06, perturb=0.3, jitter_urshape=jitter)
+        g = hip_solver(P, nIterations=2, lIterations=liters)
+        dev = api.to_device(P)
+        g.init(dev); costs = [g.cost()]
+        while g.step(dev):
+            costs.append(g.cost())
+        out = (costs, device_unknowns(P, dev)); g.close()
+        return out
+    ref = run({})
+    for sw in SWITCHES:
+        got = run(sw)
+        np.testing.assert_allclose(got[0], ref[0], rtol=1e-9, err_msg=str(sw))
+        assert rel_err(got[1], ref[1]) < 1e-8, sw
+
+
 def test_urshape_leaves_the_lattice_between_two_steps(oracle_lib):
     """The marching PCGInit1 of step n runs on the lattice verdict of step n - 1's bind while its own bind's verdict is in flight; a caller that moves UrShape off the
     unit lattice between two Opt_ProblemStep calls (in place, same buffers) makes that guess wrong: the lattice variant has to be redone as the general one before the first
