@@ -368,11 +368,17 @@ template <class T>
 __global__ __launch_bounds__(kBlock) void arap_packD(const T* __restrict__ D, T* __restrict__ D9, long nE) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < 9 * nE; i += (long)gridDim.x * blockDim.x) D9[i] = D[(i % 9) * nE + i / 9];
 }
+// S.r != nullptr (round 3): the launch is the Step1 half of a TWO-kernel PCG iteration (arap_flatStep + this one; EnergyOps::pcgIteration).  Besides p . A p it then sums, at the
+// lane that owns the vertex, what the expanded beta numerator of the next flat pass needs -- sum M r^2, sum M r . A p, sum M (A p)^2, every term from M, r, A p themselves in double
+// (exact products of floats; see energy_image_warping.hip dprod3) -- so that PCGStep2 and PCGStep3 become one flat pass without a reduction between them.
+template <class T> __device__ __forceinline__ double arap_dprod3(T m, T a, T b) { return ((double)m * (double)a) * (double)b; }
+struct ArapIterSums { const void* r; const void* M; double *aNum, *s2, *s3; };
 template <class T>
 __global__ __launch_bounds__(kBlock) void arap_applyFused(ArapArgs<T> A, GraphCsr G, const T* __restrict__ D9, const T* __restrict__ v, T* __restrict__ out,
-                                                          const T* __restrict__ CtC, double* __restrict__ partials) {
-    __shared__ double scratch[kBlock / kWave + 1];
-    double acc = 0;
+                                                          const T* __restrict__ CtC, double* __restrict__ partials, ArapIterSums S = ArapIterSums{nullptr, nullptr, nullptr, nullptr, nullptr}) {
+    __shared__ double scratch[4 * (kBlock / kWave + 1)];
+    double acc = 0, accNum = 0, acc2 = 0, acc3 = 0;
+    const T* rv = (const T*)S.r; const T* Mv = (const T*)S.M;
     const long offA = 3 * A.N;
     const int sub = threadIdx.x % kLanesPerVertex, slot = sub;
     const long nGroups = (A.N + (kBlock / kLanesPerVertex) - 1) / (kBlock / kLanesPerVertex);
@@ -382,6 +388,8 @@ __global__ __launch_bounds__(kBlock) void arap_applyFused(ArapArgs<T> A, GraphCs
         const long iv = ok ? i : 0;
         const T w = A.w_reg;
         const V3<T> pv = ld3(v, iv), pav = ld3(v + offA, iv);
+        V3<T> rO{0, 0, 0}, rA{0, 0, 0}, mO{0, 0, 0}, mA{0, 0, 0};
+        if (rv) { rO = ld3(rv, iv); rA = ld3(rv + offA, iv); mO = ld3(Mv, iv); mA = ld3(Mv + offA, iv); }      // requested before the edge walk: known from the vertex index alone
         T s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
         const int bo = G.outOff[iv], eo = ok ? G.outOff[iv + 1] : bo, bi = G.inOff[iv], ei = ok ? G.inOff[iv + 1] : bi;
         for (int k = 0; k < max(eo - bo, ei - bi); k += kLanesPerVertex) {
@@ -418,13 +426,56 @@ __global__ __launch_bounds__(kBlock) void arap_applyFused(ArapArgs<T> A, GraphCs
             V3<T> q{wf * wf * pv.x, wf * wf * pv.y, wf * wf * pv.z}, qa{0, 0, 0};
             if (CtC) { const V3<T> cO = ld3(CtC, i), cA = ld3(CtC + offA, i); q.x += cO.x * pv.x; q.y += cO.y * pv.y; q.z += cO.z * pv.z; qa.x = cA.x * pav.x; qa.y = cA.y * pav.y; qa.z = cA.z * pav.z; }
             acc += (double)(dot3(pv, q) + dot3(pav, qa));
-            out[3 * i] = q.x + s0; out[3 * i + 1] = q.y + s1; out[3 * i + 2] = q.z + s2;
-            out[offA + 3 * i] = qa.x + s3; out[offA + 3 * i + 1] = qa.y + s4; out[offA + 3 * i + 2] = qa.z + s5;
+            const V3<T> oO{q.x + s0, q.y + s1, q.z + s2}, oA{qa.x + s3, qa.y + s4, qa.z + s5};
+            out[3 * i] = oO.x; out[3 * i + 1] = oO.y; out[3 * i + 2] = oO.z;
+            out[offA + 3 * i] = oA.x; out[offA + 3 * i + 1] = oA.y; out[offA + 3 * i + 2] = oA.z;
+            if (rv) {
+                accNum += arap_dprod3(mO.x, rO.x, rO.x) + arap_dprod3(mO.y, rO.y, rO.y) + arap_dprod3(mO.z, rO.z, rO.z) + arap_dprod3(mA.x, rA.x, rA.x) + arap_dprod3(mA.y, rA.y, rA.y) + arap_dprod3(mA.z, rA.z, rA.z);
+                acc2 += arap_dprod3(mO.x, rO.x, oO.x) + arap_dprod3(mO.y, rO.y, oO.y) + arap_dprod3(mO.z, rO.z, oO.z) + arap_dprod3(mA.x, rA.x, oA.x) + arap_dprod3(mA.y, rA.y, oA.y) + arap_dprod3(mA.z, rA.z, oA.z);
+                acc3 += arap_dprod3(mO.x, oO.x, oO.x) + arap_dprod3(mO.y, oO.y, oO.y) + arap_dprod3(mO.z, oO.z, oO.z) + arap_dprod3(mA.x, oA.x, oA.x) + arap_dprod3(mA.y, oA.y, oA.y) + arap_dprod3(mA.z, oA.z, oA.z);
+            }
         }
+    }
+    if (rv) {
+        double vv[4] = {acc, accNum, acc2, acc3};
+        blockReduceSumN<4>(vv, scratch);
+        if (threadIdx.x == 0) { if (partials) partials[blockIdx.x] = vv[0]; S.aNum[blockIdx.x] = vv[1]; S.s2[blockIdx.x] = vv[2]; S.s3[blockIdx.x] = vv[3]; }
+        return;
     }
     double t = blockReduceSum(acc, scratch);
     if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
 }
+
+// PCGStep2 + PCGStep3 of iteration k-1 as ONE flat pass (solver.t:446-489, 537-550): alpha from the previous gather's sums, beta from their expansion
+//   sum M (r - alpha A p)^2 = aNum - 2 alpha s2 + alpha^2 s3   (all in double, clamped at 0 like the direct sum it replaces; energy.h PcgIterArgs),
+// then delta += alpha p, r -= alpha A p, z = M r, p = z + beta p -- no reduction in this kernel, none between Step2 and Step3.
+template <class T>
+__global__ __launch_bounds__(kBlock) void arap_flatStep(T* __restrict__ delta, const T* __restrict__ pOld, const T* __restrict__ rOld, const T* __restrict__ Ap, const T* __restrict__ M,
+                                                        T* __restrict__ rNew, T* __restrict__ pNew, long n4, const double* aNumP, int nNum, const double* aDenP, int nDen,
+                                                        const double* s2P, int n2, const double* s3P, int n3) {
+    __shared__ double scratch[4 * (kBlock / kWave + 1)];
+    const double* const ps[4] = {aNumP, aDenP, s2P, s3P}; const int ns[4] = {nNum, nDen, n2, n3}; double o4[4];
+    sumPartialsN<4>(ps, ns, scratch, o4);
+    const T aNum = (T)o4[0], aDen = (T)o4[1];
+    const T alpha = (aDen > T(0)) ? aNum / aDen : T(0);                                  // solver.t:456-459
+    const double bNumD = fmax(o4[0] - 2.0 * (double)alpha * o4[2] + (double)alpha * (double)alpha * o4[3], 0.0);
+    const T beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);                               // solver.t:544-547
+    constexpr int NP = 16 / sizeof(T);                                                   // scalars per 16-byte pack
+    typedef T VP __attribute__((ext_vector_type(NP)));
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        VP d = ((const VP*)delta)[i]; const VP p = ((const VP*)pOld)[i], r = ((const VP*)rOld)[i], a = ((const VP*)Ap)[i], m = ((const VP*)M)[i];
+        VP rn, pn;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            d[k] = d[k] + alpha * p[k];
+            rn[k] = r[k] - alpha * a[k];
+            const T z = m[k] * rn[k];
+            pn[k] = z + beta * p[k];
+        }
+        ((VP*)delta)[i] = d; ((VP*)rNew)[i] = rn; ((VP*)pNew)[i] = pn;
+    }
+}
+
 
 // ---- the same for J^T F and diag(J^T J) (once per Gauss-Newton iteration) ---------------------------------------------------------
 // Edge pass: rotation-derivative columns into the D planes (as arap_edges<2>) and one 9-scalar record per half-edge,
@@ -539,6 +590,7 @@ struct ArapOps : EnergyOps<T> {
         int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (const char* e = getenv("OPT_AMD_ARAP_GATHER")) useGather = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ARAP_FUSED")) useFused = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_ARAP_ITER")) fusedIter = atoi(e) != 0;
     }
     void bind(void** p, LaunchCtx& ctx) override {
         A.w_fit = (T) * (const float*)p[0]; A.w_reg = (T) * (const float*)p[1];
@@ -591,6 +643,32 @@ struct ArapOps : EnergyOps<T> {
             { ScopedKernel k(ctx, "PCGStep1_Graph"); arap_edges<T, 3><<<ge, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, dot ? dot->partials + gv : nullptr); }
         }
         if (dot) dot->n = gv + ge;
+    }
+    // ---- two kernels per Gauss-Newton PCG iteration instead of three (round 3): [PCGStep2 + PCGStep3 of iteration k-1 as one flat pass] + [PCGStep1 of iteration k with the sums of the
+    // expanded beta numerator].  Correct (all ARAP parity tests pass with it, final cost of config 4 equal to 8e-8) and MEASURED SLOWER, for the third time in three formulations:
+    // the flat part drops from 35.5 to 27.6 us per iteration, but the gather -- bound by how many dependent offset -> index -> record chains are in flight -- pays 13 us for
+    // the owner lane's r and M (requested before the edge walk) and its three extra sums (74 -> 87 us): config 4 217 -> 234 ms.  Off unless OPT_AMD_ARAP_ITER=1.
+    bool fusedIter = false;
+    bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
+        if (!fusedIter || !useGather || !useFused || a.CtC || !a.pre || this->slab.active) return false;
+        const long n = 6 * A.N, nPad = (n + 3) / 4 * 4, nPacks = nPad * (long)sizeof(T) / 16;
+        if (a.first) {      // the solver adopts rNew / pNew after every launch: the start state moves there unchanged
+            HIP_CHECK(hipMemcpyAsync(a.rNew, a.rOld, nPad * sizeof(T), hipMemcpyDeviceToDevice, ctx.stream));
+            HIP_CHECK(hipMemcpyAsync(a.pNew, a.pOld, nPad * sizeof(T), hipMemcpyDeviceToDevice, ctx.stream));
+        } else {
+            ScopedKernel k(ctx, "PCGStep2+PCGStep3");
+            const int g = (int)std::max<long>(1, std::min<long>((nPacks + kBlock - 1) / kBlock, (long)cus * 8));
+            arap_flatStep<T><<<g, kBlock, 0, ctx.stream>>>(a.delta, a.pOld, a.rOld, a.ApOld, a.pre, a.rNew, a.pNew, nPacks, a.aNumPrev.partials, a.aNumPrev.n, a.aDenPrev.partials, a.aDenPrev.n,
+                                                          a.s2Prev.partials, a.s2Prev.n, a.s3Prev.partials, a.s3Prev.n);
+        }
+        {
+            const int gv = vgrid();
+            GraphCsr G{outOff, outIdx, inOff, inIdx, nbr, nbr + std::max(1, A.nE)};
+            ScopedKernel k(ctx, "PCGStep1");
+            arap_applyFused<T><<<gv, kBlock, 0, ctx.stream>>>(A, G, D9, a.pNew, a.ApNew, nullptr, a.aDen->partials, ArapIterSums{a.rNew, a.pre, a.aNum->partials, a.s2->partials, a.s3->partials});
+            a.aNum->n = a.aDen->n = a.s2->n = a.s3->n = gv;
+        }
+        return true;
     }
     void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {
         const int gv = vgrid(), ge = edgeGrid(A.nE, cus);
