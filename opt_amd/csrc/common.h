@@ -155,7 +155,7 @@ __device__ __forceinline__ void pollMailSums(const MailRefDev& M, double* scratc
         if ((unsigned)(v >> 32) != M.tag) {
             const long long t0 = wall_clock64();
             while ((unsigned)((v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) >> 32) != M.tag) {
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(4);      // ~0.1 us between looks: one wave of every workgroup of the launch polls the same few hundred bytes while the peers' stores are landing
                 if (wall_clock64() - t0 > M.timeoutTicks) { *bad = 1; break; }
             }
         }
