@@ -124,7 +124,7 @@ def _rerounding_yardstick(precision):
     return max(ys) if ys else 0.0
 
 
-@pytest.mark.parametrize("size,precision", [(2048, "float"), (2048, "double"), (4096, "float")])
+@pytest.mark.parametrize("size,precision", [(2048, "float"), (2048, "double"), (4096, "float"), (4096, "double")])
 def test_metric_solve_8x400_final_energy(size, precision):
     """The metric's solve (examples/image_warping/src/main.cpp:113-114: nIterations 8, lIterations 400) from the initial guess through Opt_ProblemSolve,
     final energy against the frozen oracle run of the same precision.  Tolerance: the largest of the contract, twice the float-vs-double oracle distance
