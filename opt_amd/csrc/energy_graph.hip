@@ -477,6 +477,195 @@ __global__ __launch_bounds__(kBlock) void arap_flatStep(T* __restrict__ delta, c
 }
 
 
+// ---- round 3: J^T J p on a SYMMETRIC graph from one record per vertex ---------------------------------------------------------------------------
+// arap_applyFused is bound by the number of dependent index -> record chains in flight: per half-edge slot it follows outIdx / inIdx / outNbr / inNbr (16 B), two 36-byte
+// derivative rows and three 12-byte vectors of the neighbour, 3-5 cache lines.  A mesh carries every edge in both directions (examples/shared/OptGraph.h builds v0 -> v1 for
+// every neighbour of every vertex), so the in-edges of v are the reversed out-edges of v: (u -> v) exists exactly as often as (v -> u) -- checked per vertex when the edge
+// lists are built (csr_symmetric), any other graph keeps arap_applyFused.  Then one walk of the out-list serves both directions, and everything the walk needs from a
+// neighbour u -- p_u, pa_u and the sines / cosines of its angles, from which its derivative columns D_k(u -> v) = dR3/da_k(a_u) (U_u - U_v) follow in ~60 flops instead of a
+// 36-byte row -- is ONE 64-byte record (one cache line); the slot itself is 16 contiguous bytes {U_v - U_u, u}.  Per half-edge pair: 80 B in two lines instead of ~190 B in
+// seven.  The expressions are arap_edgeJp's / arap_rot's (same association: J p = w (p_v0 - p_v1) - w (D_0 pa.x + D_1 pa.y + D_2 pa.z)), the in-edge terms are summed in
+// out-list order.
+template <class T> struct alignas(16) ArapSlot { T ux, uy, uz; int nbr; };
+template <class T> struct alignas(16) ArapRec { T px, py, pz, ax, ay, az, sa, ca, sb, cb, sg, cg, pad0, pad1, pad2, pad3; };
+template <class T> struct ArapCoef { T a0, a1, a2, a3, a4, a5, b0, b1, b2, b3, b4, b5, b6, b7, b8, c0, c1, c2, c3, c4, c5; };
+// the non-zero entries of dR3/d alpha, d beta, d gamma (arap_rot's coefficients, same products)
+template <class T>
+__device__ __forceinline__ ArapCoef<T> arap_coef(T sa, T ca, T sb, T cb, T sg, T cg) {
+    ArapCoef<T> c;
+    c.a0 = sg * sa + cg * sb * ca;  c.a1 = sg * ca - cg * sb * sa;
+    c.a2 = -cg * sa + sg * sb * ca; c.a3 = -cg * ca - sg * sb * sa;
+    c.a4 = cb * ca;                 c.a5 = -cb * sa;
+    c.b0 = -cg * sb; c.b1 = cg * cb * sa; c.b2 = cg * cb * ca;
+    c.b3 = -sg * sb; c.b4 = sg * cb * sa; c.b5 = sg * cb * ca;
+    c.b6 = -cb;      c.b7 = -sb * sa;     c.b8 = -sb * ca;
+    c.c0 = -sg * cb; c.c1 = -cg * ca - sg * sb * sa; c.c2 = cg * sa - sg * sb * ca;
+    c.c3 = cg * cb;  c.c4 = -sg * ca + cg * sb * sa; c.c5 = sg * sa + cg * sb * ca;
+    return c;
+}
+template <class T>
+__device__ __forceinline__ void arap_cols(const ArapCoef<T>& c, const V3<T>& u, V3<T>& D0, V3<T>& D1, V3<T>& D2) {
+    D0.x = c.a0 * u.y + c.a1 * u.z; D0.y = c.a2 * u.y + c.a3 * u.z; D0.z = c.a4 * u.y + c.a5 * u.z;
+    D1.x = c.b0 * u.x + c.b1 * u.y + c.b2 * u.z; D1.y = c.b3 * u.x + c.b4 * u.y + c.b5 * u.z; D1.z = c.b6 * u.x + c.b7 * u.y + c.b8 * u.z;
+    D2.x = c.c0 * u.x + c.c1 * u.y + c.c2 * u.z; D2.y = c.c3 * u.x + c.c4 * u.y + c.c5 * u.z; D2.z = 0;
+}
+// per vertex: is the multiset of out-neighbours the multiset of in-neighbours?  (quadratic in the degree; lists longer than 64 are declared asymmetric)
+__global__ __launch_bounds__(kBlock) void csr_symmetric(long N, const int* __restrict__ outOff, const int* __restrict__ outNbr, const int* __restrict__ inOff, const int* __restrict__ inNbr,
+                                                        int* __restrict__ notSym) {
+    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < N; v += (long)gridDim.x * blockDim.x) {
+        const int bo = outOff[v], eo = outOff[v + 1], bi = inOff[v], ei = inOff[v + 1];
+        bool bad = (eo - bo) != (ei - bi) || (eo - bo) > 64;
+        for (int j = bo; j < eo && !bad; ++j) {
+            const int x = outNbr[j];
+            int co = 0, ci = 0;
+            for (int k = bo; k < eo; ++k) co += outNbr[k] == x;
+            for (int k = bi; k < ei; ++k) ci += inNbr[k] == x;
+            bad = co != ci;
+        }
+        if (bad) *notSym = 1;
+    }
+}
+template <class T>
+__global__ __launch_bounds__(kBlock) void arap_buildSlots(ArapArgs<T> A, const int* __restrict__ outIdx, ArapSlot<T>* __restrict__ slots) {
+    for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < A.nE; k += (long)gridDim.x * blockDim.x) {
+        const int e = outIdx[k];
+        const long a0 = A.v0[e], a1 = A.v1[e];
+        const V3<T> U0 = ld3(A.UrShape, a0), U1 = ld3(A.UrShape, a1);
+        slots[k] = ArapSlot<T>{U0.x - U1.x, U0.y - U1.y, U0.z - U1.z, (int)a1};
+    }
+}
+// once per Gauss-Newton iteration: the sines and cosines of every vertex's angles (the p part of the record is written by arap_packRec / arap_step3Rec)
+template <class T>
+__global__ __launch_bounds__(kBlock) void arap_buildRecTrig(ArapArgs<T> A, ArapRec<T>* __restrict__ rec) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < A.N; i += (long)gridDim.x * blockDim.x) {
+        const V3<T> a = ld3(A.Angle, i);
+        T sa, ca, sb, cb, sg, cg;
+        sincosT(a.x, &sa, &ca); sincosT(a.y, &sb, &cb); sincosT(a.z, &sg, &cg);
+        ArapRec<T>& r = rec[i];
+        r.sa = sa; r.ca = ca; r.sb = sb; r.cb = cb; r.sg = sg; r.cg = cg; r.pad0 = r.pad1 = r.pad2 = r.pad3 = 0;
+    }
+}
+template <class T>
+__global__ __launch_bounds__(kBlock) void arap_packRec(const T* __restrict__ v, ArapRec<T>* __restrict__ rec, long N) {
+    const long offA = 3 * N;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+        const V3<T> p = ld3(v, i), pa = ld3(v + offA, i);
+        ArapRec<T>& r = rec[i];
+        r.px = p.x; r.py = p.y; r.pz = p.z; r.ax = pa.x; r.ay = pa.y; r.az = pa.z;
+    }
+}
+// PCGStep3 (k_step3 in solver.hip: solver.t:537-550) writing the new search direction to the solver's vector AND to the records.  VEC: four vertices per thread, whole
+// 16-byte packs of the vectors (N a multiple of 4: both halves of the vectors start on a 16-byte boundary); else one vertex per thread.
+template <class T, bool VEC>
+__global__ __launch_bounds__(kBlock) void arap_step3Rec(const T* __restrict__ z, const T* __restrict__ pOld, T* __restrict__ pNew, ArapRec<T>* __restrict__ rec, long N,
+                                                        const double* __restrict__ bNumPartials, int nB, const double* __restrict__ aNumOld, double* __restrict__ aNumNext) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    const double bSum = sumPartials(bNumPartials, nB, scratch);
+    const T rDotzNew = (T)bSum, rDotzOld = (T)aNumOld[0];
+    const T beta = (rDotzOld > T(0)) ? rDotzNew / rDotzOld : T(0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) aNumNext[0] = bSum;
+    const long offA = 3 * N;
+    if (VEC) {
+        constexpr int NP = 16 / sizeof(T), PK = 12 / NP;      // scalars per pack, packs per four vertices of one half
+        typedef T VP __attribute__((ext_vector_type(NP)));
+        for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < N / 4; q += (long)gridDim.x * blockDim.x) {
+            T no[12], na[12];
+#pragma unroll
+            for (int k = 0; k < PK; ++k) {
+                const VP zo = ((const VP*)(z + 12 * q))[k], po = ((const VP*)(pOld + 12 * q))[k], za = ((const VP*)(z + offA + 12 * q))[k], pa = ((const VP*)(pOld + offA + 12 * q))[k];
+                VP o, a;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) { o[j] = zo[j] + beta * po[j]; a[j] = za[j] + beta * pa[j]; no[k * NP + j] = o[j]; na[k * NP + j] = a[j]; }
+                ((VP*)(pNew + 12 * q))[k] = o; ((VP*)(pNew + offA + 12 * q))[k] = a;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ArapRec<T>& r = rec[4 * q + j];
+                r.px = no[3 * j]; r.py = no[3 * j + 1]; r.pz = no[3 * j + 2]; r.ax = na[3 * j]; r.ay = na[3 * j + 1]; r.az = na[3 * j + 2];
+            }
+        }
+        return;
+    }
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+        const V3<T> zo = ld3(z, i), za = ld3(z + offA, i), po = ld3(pOld, i), pa = ld3(pOld + offA, i);
+        const V3<T> no{zo.x + beta * po.x, zo.y + beta * po.y, zo.z + beta * po.z}, na{za.x + beta * pa.x, za.y + beta * pa.y, za.z + beta * pa.z};
+        pNew[3 * i] = no.x; pNew[3 * i + 1] = no.y; pNew[3 * i + 2] = no.z;
+        pNew[offA + 3 * i] = na.x; pNew[offA + 3 * i + 1] = na.y; pNew[offA + 3 * i + 2] = na.z;
+        ArapRec<T>& r = rec[i];
+        r.px = no.x; r.py = no.y; r.pz = no.z; r.ax = na.x; r.ay = na.y; r.az = na.z;
+    }
+}
+// LANES lanes share a vertex (each walks every LANES-th slot of its out-list); the kernel is bound by its arithmetic (two sets of derivative columns per slot), so fewer
+// lanes per vertex -- less of a wave spent on the per-vertex part and on idle lanes of short lists -- is faster as long as the lists' slots still arrive coalesced.
+#ifndef ARAP_SYM_LANES
+#define ARAP_SYM_LANES 2
+#endif
+// PVEC (A/B): p and pa of a vertex are read from the solver's vector (two 12-byte pieces) instead of the record -- three cache lines per neighbour instead of one, but PCGStep3
+// stays the generic flat kernel and writes no records.
+template <class T, int LANES, bool PVEC>
+__global__ __launch_bounds__(kBlock) void arap_applySym(ArapArgs<T> A, const int* __restrict__ outOff, const ArapSlot<T>* __restrict__ slots, const ArapRec<T>* __restrict__ rec,
+                                                        const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ CtC, double* __restrict__ partials) {
+    __shared__ double scratch[kBlock / kWave + 1];
+    double acc = 0;
+    const long offA = 3 * A.N;
+    const int sub = threadIdx.x % LANES;
+    const long nGroups = (A.N + (kBlock / LANES) - 1) / (kBlock / LANES);
+    for (long g = blockIdx.x; g < nGroups; g += gridDim.x) {       // uniform trip count: the shuffles below need whole waves
+        const long i = g * (kBlock / LANES) + threadIdx.x / LANES;
+        const bool ok = i < A.N;
+        const long iv = ok ? i : 0;
+        const T w = A.w_reg;
+        ArapRec<T> me = rec[iv];
+        if (PVEC) { const V3<T> a = ld3(v, iv), b = ld3(v + offA, iv); me.px = a.x; me.py = a.y; me.pz = a.z; me.ax = b.x; me.ay = b.y; me.az = b.z; }
+        const int bo = outOff[iv], eo = ok ? outOff[iv + 1] : bo;
+        const V3<T> pv{me.px, me.py, me.pz}, pav{me.ax, me.ay, me.az};
+        const ArapCoef<T> cv = arap_coef(me.sa, me.ca, me.sb, me.cb, me.sg, me.cg);
+        T s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
+        for (int k = bo + sub; k < eo; k += LANES) {
+            const ArapSlot<T> sl = slots[k];
+            ArapRec<T> nb = rec[sl.nbr];
+            if (PVEC) { const V3<T> a = ld3(v, (long)sl.nbr), b = ld3(v + offA, (long)sl.nbr); nb.px = a.x; nb.py = a.y; nb.pz = a.z; nb.ax = b.x; nb.ay = b.y; nb.az = b.z; }
+            const V3<T> u{sl.ux, sl.uy, sl.uz}, un{-sl.ux, -sl.uy, -sl.uz};
+            V3<T> D0, D1, D2;
+            arap_cols(cv, u, D0, D1, D2);
+            {   // out-edge (v -> u): J p and D_k . J p  (arap_edgeJp with v0 = v)
+                const T jx = w * (pv.x - nb.px) - w * (D0.x * pav.x + D1.x * pav.y + D2.x * pav.z);
+                const T jy = w * (pv.y - nb.py) - w * (D0.y * pav.x + D1.y * pav.y + D2.y * pav.z);
+                const T jz = w * (pv.z - nb.pz) - w * (D0.z * pav.x + D1.z * pav.y + D2.z * pav.z);
+                s0 += w * jx; s1 += w * jy; s2 += w * jz;
+                s3 -= w * (D0.x * jx + D0.y * jy + D0.z * jz); s4 -= w * (D1.x * jx + D1.y * jy + D1.z * jz); s5 -= w * (D2.x * jx + D2.y * jy + D2.z * jz);
+                acc += (double)(jx * jx + jy * jy + jz * jz);              // sum_u p_u (J^T J p)_u of this edge = |J p|^2 (o.t:2117-2122)
+            }
+            {   // its reverse (u -> v): only its J p reaches this vertex's Offset row
+                const ArapCoef<T> cu = arap_coef(nb.sa, nb.ca, nb.sb, nb.cb, nb.sg, nb.cg);
+                V3<T> E0, E1, E2;
+                arap_cols(cu, un, E0, E1, E2);
+                const T jx = w * (nb.px - pv.x) - w * (E0.x * nb.ax + E1.x * nb.ay + E2.x * nb.az);
+                const T jy = w * (nb.py - pv.y) - w * (E0.y * nb.ax + E1.y * nb.ay + E2.y * nb.az);
+                const T jz = w * (nb.pz - pv.z) - w * (E0.z * nb.ax + E1.z * nb.ay + E2.z * nb.az);
+                s0 -= w * jx; s1 -= w * jy; s2 -= w * jz;
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < LANES; m <<= 1) {
+            s0 += __shfl_xor(s0, m, kWave); s1 += __shfl_xor(s1, m, kWave); s2 += __shfl_xor(s2, m, kWave);
+            s3 += __shfl_xor(s3, m, kWave); s4 += __shfl_xor(s4, m, kWave); s5 += __shfl_xor(s5, m, kWave);
+        }
+        if (ok && sub == 0) {
+            // per-vertex ("centred") part: fitting term and, for LM, CtC p  -- what arap_vertices<3> computes
+            const bool valid = A.Constraints[3 * i] >= T(-999999.9);
+            const T wf = valid ? A.w_fit : T(0);
+            V3<T> q{wf * wf * pv.x, wf * wf * pv.y, wf * wf * pv.z}, qa{0, 0, 0};
+            if (CtC) { const V3<T> cO = ld3(CtC, i), cA = ld3(CtC + offA, i); q.x += cO.x * pv.x; q.y += cO.y * pv.y; q.z += cO.z * pv.z; qa.x = cA.x * pav.x; qa.y = cA.y * pav.y; qa.z = cA.z * pav.z; }
+            acc += (double)(dot3(pv, q) + dot3(pav, qa));
+            out[3 * i] = q.x + s0; out[3 * i + 1] = q.y + s1; out[3 * i + 2] = q.z + s2;
+            out[offA + 3 * i] = qa.x + s3; out[offA + 3 * i + 1] = qa.y + s4; out[offA + 3 * i + 2] = qa.z + s5;
+        }
+    }
+    double t = blockReduceSum(acc, scratch);
+    if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
+}
+
 // ---- the same for J^T F and diag(J^T J) (once per Gauss-Newton iteration) ---------------------------------------------------------
 // Edge pass: rotation-derivative columns into the D planes (as arap_edges<2>) and one 9-scalar record per half-edge,
 // {w res, w D_k . res, w^2 D_k . D_k}; vertex pass: adds the records of the vertex's out- and in-lists to what arap_vertices<2> wrote.
@@ -546,9 +735,14 @@ struct ArapOps : EnergyOps<T> {
     bool useGather = true;   // OPT_AMD_ARAP_GATHER=0: scatter with wave-aggregated atomics instead
     bool useFused = true;    // OPT_AMD_ARAP_FUSED=0: edge pass + vertex gather as two launches through the record buffer
     T* D9 = nullptr; long d9Capacity = 0; int* nbr = nullptr;
+    // symmetric-graph path (arap_applySym): out-list slots {U_v - U_u, u}, one record per vertex; OPT_AMD_ARAP_SYM=0 keeps arap_applyFused
+    bool useSym = true, symGraph = false;
+    ArapSlot<T>* slots = nullptr; ArapRec<T>* rec = nullptr; int* dNotSym = nullptr;
+    bool symPath() const { return useGather && useFused && useSym && symGraph; }
     ~ArapOps() override {
         if (D9) (void)hipFree(D9);
         if (nbr) (void)hipFree(nbr);
+        for (void* q : {(void*)slots, (void*)rec, (void*)dNotSym}) if (q) (void)hipFree(q);
         for (void* q : {(void*)A.D, (void*)outOff, (void*)outIdx, (void*)inOff, (void*)inIdx, (void*)cursors, (void*)Jp, scanTemp, (void*)dChecksum}) if (q) (void)hipFree(q);
     }
     void ensureCsr(LaunchCtx& ctx) {
@@ -581,6 +775,23 @@ struct ArapOps : EnergyOps<T> {
         if (nbr) HIP_CHECK(hipFree(nbr));
         HIP_CHECK(hipMalloc((void**)&nbr, (size_t)2 * std::max(1, A.nE) * 4));
         csr_neighbours<<<ge, kBlock, 0, st>>>(A.v0, A.v1, A.nE, outIdx, inIdx, nbr, nbr + std::max(1, A.nE));
+        // does every edge come with its reverse (per vertex: out-neighbours == in-neighbours as multisets)?  Then J^T J p walks the out-lists only (arap_applySym)
+        symGraph = false;
+        if (useSym && useFused) {
+            if (!dNotSym) HIP_CHECK(hipMalloc((void**)&dNotSym, 4));
+            HIP_CHECK(hipMemsetAsync(dNotSym, 0, 4, st));
+            csr_symmetric<<<vgrid(), kBlock, 0, st>>>(A.N, outOff, nbr, inOff, nbr + std::max(1, A.nE), dNotSym);
+            int bad = 1;
+            HIP_CHECK(hipMemcpyAsync(&bad, dNotSym, 4, hipMemcpyDeviceToHost, st)); HIP_CHECK(hipStreamSynchronize(st));
+            symGraph = bad == 0;
+            for (void* q : {(void*)slots, (void*)rec}) if (q) HIP_CHECK(hipFree(q));
+            slots = nullptr; rec = nullptr;
+            if (symGraph) {
+                HIP_CHECK(hipMalloc((void**)&slots, (size_t)std::max(1, A.nE) * sizeof(ArapSlot<T>)));
+                HIP_CHECK(hipMalloc((void**)&rec, (size_t)std::max<long>(1, A.N) * sizeof(ArapRec<T>)));
+                HIP_CHECK(hipMemsetAsync(rec, 0, (size_t)std::max<long>(1, A.N) * sizeof(ArapRec<T>), st));
+            }
+        }
         csrV0 = A.v0; csrV1 = A.v1; csrNE = A.nE; csrSum = sum; csrValid = true;
     }
     ArapOps(const unsigned* dims) {
@@ -591,6 +802,9 @@ struct ArapOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_ARAP_GATHER")) useGather = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ARAP_FUSED")) useFused = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ARAP_ITER")) fusedIter = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_ARAP_SYM")) useSym = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_ARAP_SYM_LANES")) symLanes = atoi(e);
+        if (const char* e = getenv("OPT_AMD_ARAP_SYM_PVEC")) symPvec = atoi(e) != 0;
     }
     void bind(void** p, LaunchCtx& ctx) override {
         A.w_fit = (T) * (const float*)p[0]; A.w_reg = (T) * (const float*)p[1];
@@ -603,6 +817,10 @@ struct ArapOps : EnergyOps<T> {
             HIP_CHECK(hipMemset(A.D, 0, (size_t)9 * dCapacity * sizeof(T)));
         }
         if (useGather) ensureCsr(ctx);
+        if (symPath()) {      // UrShape is an input of the solve: the slots' U_v - U_u are rebuilt whenever the parameters are (re)bound
+            ScopedKernel k(ctx, "buildEdgeSlots");
+            arap_buildSlots<T><<<edgeGrid(A.nE, cus), kBlock, 0, ctx.stream>>>(A, outIdx, slots);
+        }
     }
     T* unknownPtr(int img) const override { return const_cast<T*>(img == 0 ? A.Offset : A.Angle); }
     int vgrid() const { static const int cap = getenv("OPT_AMD_ARAP_VGRID") ? atoi(getenv("OPT_AMD_ARAP_VGRID")) : kMaxPartials / 2; return (int)std::max<long>(1, std::min<long>((A.N + kBlock - 1) / kBlock, cap)); }
@@ -618,7 +836,11 @@ struct ArapOps : EnergyOps<T> {
             GraphCsr G{outOff, outIdx, inOff, inIdx};
             { ScopedKernel k(ctx, "PCGInit1_Graph"); arap_edgeJTF<T><<<edgeGrid(A.nE, cus), kBlock, 0, ctx.stream>>>(A, Jp); }
             { ScopedKernel k(ctx, "PCGInit1_Gather"); arap_vertexGatherJTF<T><<<vgrid(), kBlock, 0, ctx.stream>>>(A, G, Jp, r, diag); }
-            if (useFused) {     // the derivative columns of this Gauss-Newton iteration as 36-byte rows for arap_applyFused
+            if (symPath()) {    // the sines / cosines of this Gauss-Newton iteration's angles, one record per vertex, for arap_applySym
+                ScopedKernel k(ctx, "vertexRecords");
+                arap_buildRecTrig<T><<<vgrid(), kBlock, 0, ctx.stream>>>(A, rec);
+            }
+            if (useFused && (!symPath() || fusedIter)) {     // the derivative columns of this Gauss-Newton iteration as 36-byte rows for arap_applyFused
                 if (A.nE > d9Capacity) { if (D9) HIP_CHECK(hipFree(D9)); d9Capacity = A.nE; HIP_CHECK(hipMalloc((void**)&D9, (size_t)9 * std::max<long>(1, d9Capacity) * sizeof(T))); }
                 ScopedKernel k(ctx, "packDerivativeRows");
                 arap_packD<T><<<edgeGrid(A.nE, cus), kBlock, 0, ctx.stream>>>(A.D, D9, (long)A.nE);
@@ -627,6 +849,12 @@ struct ArapOps : EnergyOps<T> {
     }
     void applyJTJ(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) override {
         const int gv = vgrid(), ge = edgeGrid(A.nE, cus);
+        if (symPath()) {
+            if (!symPvec) { ScopedKernel k(ctx, "packVertexRecords"); arap_packRec<T><<<gv, kBlock, 0, ctx.stream>>>(v, rec, A.N); }
+            ScopedKernel k(ctx, "PCGStep1");
+            launchSym(v, out, CtC, dot, ctx);
+            return;
+        }
         if (useGather && useFused) {
             GraphCsr G{outOff, outIdx, inOff, inIdx, nbr, nbr + std::max(1, A.nE)};
             ScopedKernel k(ctx, "PCGStep1");
@@ -643,6 +871,42 @@ struct ArapOps : EnergyOps<T> {
             { ScopedKernel k(ctx, "PCGStep1_Graph"); arap_edges<T, 3><<<ge, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, dot ? dot->partials + gv : nullptr); }
         }
         if (dot) dot->n = gv + ge;
+    }
+    int symLanes = ARAP_SYM_LANES;      // OPT_AMD_ARAP_SYM_LANES=1|2|4|8 (A/B switch)
+    bool symPvec = false;               // OPT_AMD_ARAP_SYM_PVEC=1 (A/B switch, see arap_applySym)
+    int symGrid() const {               // all workgroups resident at once (4 per CU): a second, partial round of workgroups costs more than the longer grid-stride loops
+        static const int cap = getenv("OPT_AMD_ARAP_VGRID") ? atoi(getenv("OPT_AMD_ARAP_VGRID")) : 0;
+        const long groups = (A.N + kBlock / symLanes - 1) / (kBlock / symLanes);
+        return (int)std::max<long>(1, std::min<long>(groups, cap > 0 ? cap : std::min<long>(4L * cus, kMaxPartials / 2)));
+    }
+    template <bool PVEC> void launchSymP(const T* v, T* out, const T* CtC, double* part, int g, LaunchCtx& ctx) {
+        switch (symLanes) {
+            case 1: arap_applySym<T, 1, PVEC><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part); break;
+            case 4: arap_applySym<T, 4, PVEC><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part); break;
+            case 8: arap_applySym<T, 8, PVEC><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part); break;
+            default: arap_applySym<T, 2, PVEC><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part); break;
+        }
+    }
+    void launchSym(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) {
+        const int g = symGrid();
+        double* part = dot ? dot->partials : nullptr;
+        if (symPvec) launchSymP<true>(v, out, CtC, part, g, ctx); else launchSymP<false>(v, out, CtC, part, g, ctx);
+        if (dot) dot->n = g;
+    }
+    // PCGStep3 of the previous iteration + PCGStep1 (symmetric-graph path): the flat pass that forms p = z + beta p also writes it into the vertex records the gather reads
+    bool applyJTJFused(const T* pOld, const T* z, T* pNew, T* out, const T* CtC, Reduction* dot, const Reduction& bNum, const double* aNumOld, double* aNumNext, LaunchCtx& ctx) override {
+        if (!symPath() || symPvec) return false;
+        {
+            ScopedKernel k(ctx, "PCGStep3");
+            static const int step3Vec = getenv("OPT_AMD_ARAP_STEP3_VEC") ? atoi(getenv("OPT_AMD_ARAP_STEP3_VEC")) : 0;      // measured: four vertices per thread 23.3 us, one 20.8 us (500 k vertices)
+            const bool vec = step3Vec && A.N % 4 == 0 && ((uintptr_t)z | (uintptr_t)pOld | (uintptr_t)pNew) % 16 == 0;
+            const int g3 = (int)std::max<long>(1, std::min<long>((A.N / (vec ? 4 : 1) + kBlock - 1) / kBlock, (long)cus * 8));
+            if (vec) arap_step3Rec<T, true><<<g3, kBlock, 0, ctx.stream>>>(z, pOld, pNew, rec, A.N, bNum.partials, bNum.n, aNumOld, aNumNext);
+            else arap_step3Rec<T, false><<<g3, kBlock, 0, ctx.stream>>>(z, pOld, pNew, rec, A.N, bNum.partials, bNum.n, aNumOld, aNumNext);
+        }
+        ScopedKernel k(ctx, "PCGStep1");
+        launchSym(pNew, out, CtC, dot, ctx);
+        return true;
     }
     // ---- two kernels per Gauss-Newton PCG iteration instead of three (round 3): [PCGStep2 + PCGStep3 of iteration k-1 as one flat pass] + [PCGStep1 of iteration k with the sums of the
     // expanded beta numerator].  Correct (all ARAP parity tests pass with it, final cost of config 4 equal to 8e-8) and MEASURED SLOWER, for the third time in three formulations:

@@ -218,6 +218,64 @@ def test_arap_two_kernel_iteration_matches_three_kernel_loop(double, monkeypatch
     assert rel_err(res["1"][1], res["0"][1]) < (1e-8 if double else 2e-5)
 
 
+@pytest.mark.parametrize("grid", [(41, 29), (40, 30)])      # vertex counts 1189 (one vertex per thread in PCGStep3) and 1200 (a multiple of 4: whole 16-byte packs)
+@pytest.mark.parametrize("kind", ["gaussNewtonGPU", "LMGPU"])
+@pytest.mark.parametrize("double", [False, True])
+def test_arap_symmetric_graph_path_matches_edge_list_path(double, kind, grid, monkeypatch):
+    """Round 3: on a graph that carries every edge in both directions (every mesh of the reference's examples) J^T J p walks the out-lists only and reads one 64-byte record
+    per neighbour (arap_applySym, PCGStep3 writing the records); OPT_AMD_ARAP_SYM=0 keeps the edge-list gather (arap_applyFused).  Same trajectory, and the timer table shows
+    which kernels ran."""
+    P = wl.arap_mesh_deformation(grid[0], grid[1], double=double, seed=5, perturb=0.01)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("OPT_AMD_ARAP_SYM", mode)
+        g = hip_solver(P, kind, timing=True, nIterations=3, lIterations=40)
+        dev = api.to_device(P)
+        g.init(dev); c = [g.cost()]
+        while g.step(dev):
+            c.append(g.cost())
+        res[mode] = (c, device_unknowns(P, dev), g.kernel_timings()); g.close()
+    assert "vertexRecords" in res["1"][2] and "vertexRecords" not in res["0"][2]
+    assert "packDerivativeRows" in res["0"][2] and "packDerivativeRows" not in res["1"][2]
+    # (float: three steps of 40 iterations take the cost from 2.2 to 3e-4 -- residuals of 1e-4 formed from coordinates of order 1 carry four digits)
+    # ... and the float LM trajectory magnifies rounding differences (its double run agrees to 1e-8; each path is compared with the oracle in test_trajectory)
+    np.testing.assert_allclose(res["1"][0], res["0"][0], rtol=1e-9 if double else 1e-5, atol=0 if double else 2e-7 * res["0"][0][0])      # a float cost is not resolved below ~1e-7 of the sums it started from
+    assert rel_err(res["1"][1], res["0"][1]) < (1e-8 if double else (5e-3 if kind == "LMGPU" else 2e-5))
+
+
+@pytest.mark.parametrize("double", [False, True])
+def test_arap_asymmetric_graph_keeps_the_edge_list_path(oracle_lib, double):
+    """A graph with half-edges whose reverse is missing (the API accepts any edge list) must not take the symmetric-graph shortcut: stages and trajectory against the oracle."""
+    import torch
+    P = wl.arap_mesh_deformation(23, 17, double=double, seed=3, perturb=0.01)
+    heads, tails = P.params[7], P.params[8]
+    keep = np.ones(len(heads), dtype=bool)
+    keep[np.arange(5, len(heads), 7)] = False            # every seventh half-edge dropped: most of them leave their reverse behind
+    P.params[7] = np.ascontiguousarray(heads[keep]); P.params[8] = np.ascontiguousarray(tails[keep])
+    P.params[6] = np.array(int(keep.sum()), dtype=np.int32)
+    tol = 1e-11 if double else 3e-5
+    o = oracle_solver(oracle_lib, P); g = hip_solver(P, timing=True)
+    dev = api.to_device(P)
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(o.n).astype(o.dtype)
+    Av_ref = o.apply_jtj(P.params, v)
+    Av_gpu, _ = g.apply_jtj(dev, torch.from_numpy(v).cuda())
+    assert rel_err(Av_gpu.cpu().numpy(), Av_ref) < tol
+    assert "packVertexRecords" not in g.kernel_timings()
+    g.close(); o.close()
+    kw = dict(nIterations=3, lIterations=12)
+    o = oracle_solver(oracle_lib, P, "gaussNewtonGPU", **kw); g = hip_solver(P, "gaussNewtonGPU", **kw)
+    Pref = P.clone(); dev = api.to_device(P)
+    o.init(Pref.params); g.init(dev)
+    while True:
+        a, b = o.step(Pref.params), g.step(dev)
+        assert a == b
+        assert abs(g.cost() - o.cost()) <= (1e-10 if double else 1e-5) * abs(o.cost())
+        if not a:
+            break
+    g.close(); o.close()
+
+
 def test_arap_path_is_deterministic():
     """The ARAP kernel set uses no atomics (edge pass -> records, vertex pass gathers sorted lists) for J^T F as well as J^T J p:
     two solves of the same problem give the same bits (the reference's scatter kernels do not)."""

@@ -155,8 +155,12 @@ def test_metric_solve_8x400_final_energy(size, precision):
     # ... and where the solve has not reached that floor yet (4096^2: still descending after 8 steps) the trajectories parted in the first step already: the
     # re-rounding yardstick of one step (the fma build of the oracle against the plain one, largest over the horizons: 2.6e-3 float, 7.8e-4 double at 2048^2)
     yard = _rerounding_yardstick(precision)
-    tol = max(FLOOR[precision], 2.0 * env, noise, yard)
+    # ... and, where it is frozen, the same yardstick taken on THIS solve: the fma build of the oracle run through the same 8 x 400 solve (make_horizon_costs.py --families
+    # solve8 --variant fma), largest relative distance from the plain build over the eight steps (a difference that opened at an earlier step need not close again)
+    fma = _gold("horizon_costs_fma.json").get(key)
+    yard8 = max(abs(a - b) / abs(b) for a, b in zip(fma["costs"][1:], ref[1:])) if fma else 0.0
+    tol = max(FLOOR[precision], 2.0 * env, noise, yard, yard8)
     rel = abs(final - ref[-1]) / abs(ref[-1])
     print(f"solve8 {size} {precision}: hip {final!r} oracle {ref[-1]!r} rel {rel:.3e} (float-vs-double oracle {env:.3e}, oracle's own step-to-step increases {noise:.3e}, "
-          f"re-rounding yardstick of one step {yard:.3e})")
-    assert rel <= tol, (final, ref, env, noise, yard)
+          f"re-rounding yardstick of one step at 2048^2 {yard:.3e}, of this solve {yard8:.3e})")
+    assert rel <= tol, (final, ref, env, noise, yard, yard8)
