@@ -602,7 +602,7 @@ __global__ __launch_bounds__(kBlock) void arap_step3Rec(const T* __restrict__ z,
 #endif
 // PVEC (A/B): p and pa of a vertex are read from the solver's vector (two 12-byte pieces) instead of the record -- three cache lines per neighbour instead of one, but PCGStep3
 // stays the generic flat kernel and writes no records.
-template <class T, int LANES, bool PVEC>
+template <class T, int LANES, bool PVEC, int BATCH>
 __global__ __launch_bounds__(kBlock) void arap_applySym(ArapArgs<T> A, const int* __restrict__ outOff, const ArapSlot<T>* __restrict__ slots, const ArapRec<T>* __restrict__ rec,
                                                         const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ CtC, double* __restrict__ partials) {
     __shared__ double scratch[kBlock / kWave + 1];
@@ -621,29 +621,41 @@ __global__ __launch_bounds__(kBlock) void arap_applySym(ArapArgs<T> A, const int
         const V3<T> pv{me.px, me.py, me.pz}, pav{me.ax, me.ay, me.az};
         const ArapCoef<T> cv = arap_coef(me.sa, me.ca, me.sb, me.cb, me.sg, me.cg);
         T s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
-        for (int k = bo + sub; k < eo; k += LANES) {
-            const ArapSlot<T> sl = slots[k];
-            ArapRec<T> nb = rec[sl.nbr];
-            if (PVEC) { const V3<T> a = ld3(v, (long)sl.nbr), b = ld3(v + offA, (long)sl.nbr); nb.px = a.x; nb.py = a.y; nb.pz = a.z; nb.ax = b.x; nb.ay = b.y; nb.az = b.z; }
-            const V3<T> u{sl.ux, sl.uy, sl.uz}, un{-sl.ux, -sl.uy, -sl.uz};
-            V3<T> D0, D1, D2;
-            arap_cols(cv, u, D0, D1, D2);
-            {   // out-edge (v -> u): J p and D_k . J p  (arap_edgeJp with v0 = v)
-                const T jx = w * (pv.x - nb.px) - w * (D0.x * pav.x + D1.x * pav.y + D2.x * pav.z);
-                const T jy = w * (pv.y - nb.py) - w * (D0.y * pav.x + D1.y * pav.y + D2.y * pav.z);
-                const T jz = w * (pv.z - nb.pz) - w * (D0.z * pav.x + D1.z * pav.y + D2.z * pav.z);
-                s0 += w * jx; s1 += w * jy; s2 += w * jz;
-                s3 -= w * (D0.x * jx + D0.y * jy + D0.z * jz); s4 -= w * (D1.x * jx + D1.y * jy + D1.z * jz); s5 -= w * (D2.x * jx + D2.y * jy + D2.z * jz);
-                acc += (double)(jx * jx + jy * jy + jz * jz);              // sum_u p_u (J^T J p)_u of this edge = |J p|^2 (o.t:2117-2122)
+        // BATCH slots of a lane are requested together, then their BATCH records, then the arithmetic: the slot -> record chain is two memory round trips, and a lane that
+        // walks its three slots one after the other pays them three times (a slot past the end of the list repeats the last valid one with weight 0)
+        for (int k0 = bo + sub; k0 < eo; k0 += LANES * BATCH) {
+            ArapSlot<T> sl[BATCH]; ArapRec<T> nbs[BATCH]; T wm[BATCH];
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) { const int kk = k0 + j * LANES; wm[j] = kk < eo ? w : T(0); sl[j] = slots[min(kk, eo - 1)]; }
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                nbs[j] = rec[sl[j].nbr];
+                if (PVEC) { const V3<T> a = ld3(v, (long)sl[j].nbr), b = ld3(v + offA, (long)sl[j].nbr); nbs[j].px = a.x; nbs[j].py = a.y; nbs[j].pz = a.z; nbs[j].ax = b.x; nbs[j].ay = b.y; nbs[j].az = b.z; }
             }
-            {   // its reverse (u -> v): only its J p reaches this vertex's Offset row
-                const ArapCoef<T> cu = arap_coef(nb.sa, nb.ca, nb.sb, nb.cb, nb.sg, nb.cg);
-                V3<T> E0, E1, E2;
-                arap_cols(cu, un, E0, E1, E2);
-                const T jx = w * (nb.px - pv.x) - w * (E0.x * nb.ax + E1.x * nb.ay + E2.x * nb.az);
-                const T jy = w * (nb.py - pv.y) - w * (E0.y * nb.ax + E1.y * nb.ay + E2.y * nb.az);
-                const T jz = w * (nb.pz - pv.z) - w * (E0.z * nb.ax + E1.z * nb.ay + E2.z * nb.az);
-                s0 -= w * jx; s1 -= w * jy; s2 -= w * jz;
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                const ArapRec<T>& nb = nbs[j];
+                const T wj = wm[j];
+                const V3<T> u{sl[j].ux, sl[j].uy, sl[j].uz}, un{-sl[j].ux, -sl[j].uy, -sl[j].uz};
+                V3<T> D0, D1, D2;
+                arap_cols(cv, u, D0, D1, D2);
+                {   // out-edge (v -> u): J p and D_k . J p  (arap_edgeJp with v0 = v)
+                    const T jx = w * (pv.x - nb.px) - w * (D0.x * pav.x + D1.x * pav.y + D2.x * pav.z);
+                    const T jy = w * (pv.y - nb.py) - w * (D0.y * pav.x + D1.y * pav.y + D2.y * pav.z);
+                    const T jz = w * (pv.z - nb.pz) - w * (D0.z * pav.x + D1.z * pav.y + D2.z * pav.z);
+                    s0 += wj * jx; s1 += wj * jy; s2 += wj * jz;
+                    s3 -= wj * (D0.x * jx + D0.y * jy + D0.z * jz); s4 -= wj * (D1.x * jx + D1.y * jy + D1.z * jz); s5 -= wj * (D2.x * jx + D2.y * jy + D2.z * jz);
+                    if (wj != T(0)) acc += (double)(jx * jx + jy * jy + jz * jz);              // sum_u p_u (J^T J p)_u of this edge = |J p|^2 (o.t:2117-2122)
+                }
+                {   // its reverse (u -> v): only its J p reaches this vertex's Offset row
+                    const ArapCoef<T> cu = arap_coef(nb.sa, nb.ca, nb.sb, nb.cb, nb.sg, nb.cg);
+                    V3<T> E0, E1, E2;
+                    arap_cols(cu, un, E0, E1, E2);
+                    const T jx = w * (nb.px - pv.x) - w * (E0.x * nb.ax + E1.x * nb.ay + E2.x * nb.az);
+                    const T jy = w * (nb.py - pv.y) - w * (E0.y * nb.ax + E1.y * nb.ay + E2.y * nb.az);
+                    const T jz = w * (nb.pz - pv.z) - w * (E0.z * nb.ax + E1.z * nb.ay + E2.z * nb.az);
+                    s0 -= wj * jx; s1 -= wj * jy; s2 -= wj * jz;
+                }
             }
         }
 #pragma unroll
@@ -805,6 +817,7 @@ struct ArapOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_ARAP_SYM")) useSym = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ARAP_SYM_LANES")) symLanes = atoi(e);
         if (const char* e = getenv("OPT_AMD_ARAP_SYM_PVEC")) symPvec = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_ARAP_SYM_BATCH")) symBatch = atoi(e);
     }
     void bind(void** p, LaunchCtx& ctx) override {
         A.w_fit = (T) * (const float*)p[0]; A.w_reg = (T) * (const float*)p[1];
@@ -879,12 +892,21 @@ struct ArapOps : EnergyOps<T> {
         const long groups = (A.N + kBlock / symLanes - 1) / (kBlock / symLanes);
         return (int)std::max<long>(1, std::min<long>(groups, cap > 0 ? cap : std::min<long>(4L * cus, kMaxPartials / 2)));
     }
-    template <bool PVEC> void launchSymP(const T* v, T* out, const T* CtC, double* part, int g, LaunchCtx& ctx) {
+    int symBatch = 4;                   // OPT_AMD_ARAP_SYM_BATCH=1|2|3|4: slots a lane requests together (a mesh vertex has ~6 neighbours: 3 per lane at two lanes per vertex); measured 31.0 / 34.9 / 32.6 / 29.3 us
+    template <bool PVEC, int BATCH> void launchSymPB(const T* v, T* out, const T* CtC, double* part, int g, LaunchCtx& ctx) {
         switch (symLanes) {
-            case 1: arap_applySym<T, 1, PVEC><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part); break;
-            case 4: arap_applySym<T, 4, PVEC><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part); break;
-            case 8: arap_applySym<T, 8, PVEC><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part); break;
-            default: arap_applySym<T, 2, PVEC><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part); break;
+            case 1: arap_applySym<T, 1, PVEC, BATCH><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part); break;
+            case 4: arap_applySym<T, 4, PVEC, BATCH><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part); break;
+            case 8: arap_applySym<T, 8, PVEC, BATCH><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part); break;
+            default: arap_applySym<T, 2, PVEC, BATCH><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part); break;
+        }
+    }
+    template <bool PVEC> void launchSymP(const T* v, T* out, const T* CtC, double* part, int g, LaunchCtx& ctx) {
+        switch (symBatch) {
+            case 1: launchSymPB<PVEC, 1>(v, out, CtC, part, g, ctx); break;
+            case 2: launchSymPB<PVEC, 2>(v, out, CtC, part, g, ctx); break;
+            case 3: launchSymPB<PVEC, 3>(v, out, CtC, part, g, ctx); break;
+            default: launchSymPB<PVEC, 4>(v, out, CtC, part, g, ctx); break;
         }
     }
     void launchSym(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) {
