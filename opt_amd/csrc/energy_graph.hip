@@ -554,9 +554,10 @@ __global__ __launch_bounds__(kBlock) void arap_packRec(const T* __restrict__ v, 
         r.px = p.x; r.py = p.y; r.pz = p.z; r.ax = pa.x; r.ay = pa.y; r.az = pa.z;
     }
 }
-// PCGStep3 (k_step3 in solver.hip: solver.t:537-550) writing the new search direction to the solver's vector AND to the records.  VEC: four vertices per thread, whole
-// 16-byte packs of the vectors (N a multiple of 4: both halves of the vectors start on a 16-byte boundary); else one vertex per thread.
-template <class T, bool VEC>
+// PCGStep3 (k_step3 in solver.hip: solver.t:537-550) writing the new search direction to the solver's vector AND to the records.  21 us at 500 k vertices against 13 us for the
+// generic pass: the 24-byte record pieces at a 64-byte stride are what costs -- four vertices per thread with 16-byte vector accesses (23 us), coalesced packs staged through LDS
+// to the thread that owns the record (21 us) and records whose p half fills a 32-byte sector of its own (21 us, gather 45 -> 49 us) were measured and dropped.
+template <class T>
 __global__ __launch_bounds__(kBlock) void arap_step3Rec(const T* __restrict__ z, const T* __restrict__ pOld, T* __restrict__ pNew, ArapRec<T>* __restrict__ rec, long N,
                                                         const double* __restrict__ bNumPartials, int nB, const double* __restrict__ aNumOld, double* __restrict__ aNumNext) {
     __shared__ double scratch[kBlock / kWave + 1];
@@ -565,27 +566,6 @@ __global__ __launch_bounds__(kBlock) void arap_step3Rec(const T* __restrict__ z,
     const T beta = (rDotzOld > T(0)) ? rDotzNew / rDotzOld : T(0);
     if (blockIdx.x == 0 && threadIdx.x == 0) aNumNext[0] = bSum;
     const long offA = 3 * N;
-    if (VEC) {
-        constexpr int NP = 16 / sizeof(T), PK = 12 / NP;      // scalars per pack, packs per four vertices of one half
-        typedef T VP __attribute__((ext_vector_type(NP)));
-        for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < N / 4; q += (long)gridDim.x * blockDim.x) {
-            T no[12], na[12];
-#pragma unroll
-            for (int k = 0; k < PK; ++k) {
-                const VP zo = ((const VP*)(z + 12 * q))[k], po = ((const VP*)(pOld + 12 * q))[k], za = ((const VP*)(z + offA + 12 * q))[k], pa = ((const VP*)(pOld + offA + 12 * q))[k];
-                VP o, a;
-#pragma unroll
-                for (int j = 0; j < NP; ++j) { o[j] = zo[j] + beta * po[j]; a[j] = za[j] + beta * pa[j]; no[k * NP + j] = o[j]; na[k * NP + j] = a[j]; }
-                ((VP*)(pNew + 12 * q))[k] = o; ((VP*)(pNew + offA + 12 * q))[k] = a;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ArapRec<T>& r = rec[4 * q + j];
-                r.px = no[3 * j]; r.py = no[3 * j + 1]; r.pz = no[3 * j + 2]; r.ax = na[3 * j]; r.ay = na[3 * j + 1]; r.az = na[3 * j + 2];
-            }
-        }
-        return;
-    }
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
         const V3<T> zo = ld3(z, i), za = ld3(z + offA, i), po = ld3(pOld, i), pa = ld3(pOld + offA, i);
         const V3<T> no{zo.x + beta * po.x, zo.y + beta * po.y, zo.z + beta * po.z}, na{za.x + beta * pa.x, za.y + beta * pa.y, za.z + beta * pa.z};
@@ -918,14 +898,7 @@ struct ArapOps : EnergyOps<T> {
     // PCGStep3 of the previous iteration + PCGStep1 (symmetric-graph path): the flat pass that forms p = z + beta p also writes it into the vertex records the gather reads
     bool applyJTJFused(const T* pOld, const T* z, T* pNew, T* out, const T* CtC, Reduction* dot, const Reduction& bNum, const double* aNumOld, double* aNumNext, LaunchCtx& ctx) override {
         if (!symPath() || symPvec) return false;
-        {
-            ScopedKernel k(ctx, "PCGStep3");
-            static const int step3Vec = getenv("OPT_AMD_ARAP_STEP3_VEC") ? atoi(getenv("OPT_AMD_ARAP_STEP3_VEC")) : 0;      // measured: four vertices per thread 23.3 us, one 20.8 us (500 k vertices)
-            const bool vec = step3Vec && A.N % 4 == 0 && ((uintptr_t)z | (uintptr_t)pOld | (uintptr_t)pNew) % 16 == 0;
-            const int g3 = (int)std::max<long>(1, std::min<long>((A.N / (vec ? 4 : 1) + kBlock - 1) / kBlock, (long)cus * 8));
-            if (vec) arap_step3Rec<T, true><<<g3, kBlock, 0, ctx.stream>>>(z, pOld, pNew, rec, A.N, bNum.partials, bNum.n, aNumOld, aNumNext);
-            else arap_step3Rec<T, false><<<g3, kBlock, 0, ctx.stream>>>(z, pOld, pNew, rec, A.N, bNum.partials, bNum.n, aNumOld, aNumNext);
-        }
+        { ScopedKernel k(ctx, "PCGStep3"); arap_step3Rec<T><<<vgrid(), kBlock, 0, ctx.stream>>>(z, pOld, pNew, rec, A.N, bNum.partials, bNum.n, aNumOld, aNumNext); }
         ScopedKernel k(ctx, "PCGStep1");
         launchSym(pNew, out, CtC, dot, ctx);
         return true;
