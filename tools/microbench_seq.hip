@@ -17,7 +17,16 @@ typedef float F4 __attribute__((ext_vector_type(4)));
 #define H_ROWS 4096
 #endif
 constexpr int W = 4096, H = H_ROWS;      // -DH_ROWS=528: a 1/8 slab of 4096^2 (+ ghost rows)
+// -DSTRIPMAJOR: every vector stored strip by strip (720-pixel column strips, the workgroup's own: [strip][row][x in strip]) instead of row by row, so that a workgroup's
+// streams are contiguous in memory from its first row to its last (the halo lanes of the edge waves read the neighbouring strip's storage)
+#ifdef STRIPMAJOR
+constexpr int kStripPx = 720, kStrips = (W + kStripPx - 1) / kStripPx;
+constexpr long N = (long)kStrips * kStripPx * H;
+__device__ __forceinline__ long pxIndex(int x, int yphys) { const int s = x / kStripPx; return ((long)s * H + yphys) * kStripPx + (x - s * kStripPx); }
+#else
 constexpr long N = (long)W * H;
+__device__ __forceinline__ long pxIndex(int x, int yphys) { return (long)yphys * W + x; }
+#endif
 
 struct Bufs { const float* rIn; const float* pIn; float* rOut; float* pOut; float* delta; const float* angle; const uint8_t* flags; };
 template <int PX> struct Row { float v[6 * PX]; float ang[PX]; int f; };
@@ -25,7 +34,7 @@ template <int PX> struct Row { float v[6 * PX]; float ang[PX]; int f; };
 template <int PX, bool NTL> __device__ __forceinline__ Row<PX> loadRow(const Bufs& B, int x, int y, bool flip) {
     Row<PX> r;
     const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - PX);
-    const long i = (long)(flip ? H - 1 - yc : yc) * W + xc;
+    const long i = pxIndex(xc, flip ? H - 1 - yc : yc);
     if constexpr (PX == 1) {
         const F2 a = NTL ? __builtin_nontemporal_load((const F2*)B.rIn + i) : ((const F2*)B.rIn)[i];
         const float b = NTL ? __builtin_nontemporal_load(B.rIn + 2 * N + i) : B.rIn[2 * N + i];
@@ -74,7 +83,7 @@ __global__ __launch_bounds__(BLOCK) void k(Bufs B, int rowsPerGroup, int gx, int
         for (int k2 = 0; k2 < PX; ++k2) s += r.ang[k2];
         acc += s;
         if (!(writer && live)) return;
-        const long i = (long)(flip ? H - 1 - y : y) * W + xs;
+        const long i = pxIndex(xs, flip ? H - 1 - y : y);
         float o[6 * PX];
         for (int k2 = 0; k2 < 6 * PX; ++k2) o[k2] = r.v[k2] * 0.5f + s;
         if constexpr (PX == 1) {
@@ -174,6 +183,14 @@ int main(int argc, char** argv) {
         const int gx = (W + 720 * BLOCK / 768 - 1) / (720 * BLOCK / 768), gy = cus / gx, rpg = (H + gy - 1) / gy, gy2 = (H + rpg - 1) / rpg;   \
         seq([&](const Bufs& B, int flip) { k<1, false, NTL, true, SY, BLOCK, 0, DEPTH><<<gx * gy2, BLOCK>>>(B, rpg, gx, flip, sink); },      \
             [&](const Bufs& B, int flip) { k<1, true, NTL, true, SY, BLOCK, 0, DEPTH><<<gx * gy2, BLOCK>>>(B, rpg, gx, flip, sink); }, true, name); \
+    }
+    if (argc > 1 && argv[1][0] == 's') {      // the current kernel's shape only (plain loads): row-major against -DSTRIPMAJOR builds
+        for (int rep = 0; rep < 3; ++rep) {
+            CASE(1, false, true, true, 768, 1, true, "1 px/lane  --  overlap  sync  768 thr  alt sweep   (= current kernel)");
+            CASE(1, false, true, true, 768, 1, false, "1 px/lane  --  overlap  sync  768 thr  same sweep");
+            CASE(1, false, true, false, 768, 1, true, "1 px/lane  --  overlap  free  768 thr  alt sweep");
+        }
+        return 0;
     }
     if (argc > 1 && argv[1][0] == 'd') {
         for (int rep = 0; rep < 2; ++rep) {
