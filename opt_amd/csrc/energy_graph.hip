@@ -279,7 +279,10 @@ __global__ __launch_bounds__(kBlock) void csr_checksum(const int* __restrict__ v
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nE; e += gridDim.x * blockDim.x)
         acc += ((unsigned long long)(unsigned)v0[e] * 0x9E3779B97F4A7C15ull + (unsigned long long)(unsigned)v1[e] * 0xC2B2AE3D27D4EB4Full) ^ ((unsigned long long)e * 0x165667B19E3779F9ull);
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
-    if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(out, acc);
+    __shared__ unsigned long long part[kBlock / kWave];      // one atomic per workgroup: 12 000 wave-level atomics on one address took 100 us per bind
+    if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long t = 0; for (int w = 0; w < kBlock / kWave; ++w) t += part[w]; atomicAdd(out, t); }
 }
 
 template <class T>
@@ -584,13 +587,20 @@ __global__ __launch_bounds__(kBlock) void arap_step3Rec(const T* __restrict__ z,
 // stays the generic flat kernel and writes no records.
 template <class T, int LANES, bool PVEC, int BATCH>
 __global__ __launch_bounds__(kBlock) void arap_applySym(ArapArgs<T> A, const int* __restrict__ outOff, const ArapSlot<T>* __restrict__ slots, const ArapRec<T>* __restrict__ rec,
-                                                        const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ CtC, double* __restrict__ partials) {
-    __shared__ double scratch[kBlock / kWave + 1];
-    double acc = 0;
+                                                        const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ CtC, double* __restrict__ partials, int xcd, ArapIterSums S) {
+    __shared__ double scratch[4 * (kBlock / kWave + 1)];
+    double acc = 0, accNum = 0, acc2 = 0, acc3 = 0;      // S.r != nullptr: the Step1 half of a two-kernel PCG iteration, see arap_applyFused
+    const T* rv = (const T*)S.r; const T* Mv = (const T*)S.M;
     const long offA = 3 * A.N;
     const int sub = threadIdx.x % LANES;
     const long nGroups = (A.N + (kBlock / LANES) - 1) / (kBlock / LANES);
-    for (long g = blockIdx.x; g < nGroups; g += gridDim.x) {       // uniform trip count: the shuffles below need whole waves
+    // XCD-aware order (xcd != 0; the grid is a multiple of 8): workgroups are dealt round-robin to the 8 XCDs, each with its own L2, and a record is read by its vertex and by
+    // its ~6 neighbours -- which in a mesh's vertex order sit a row of vertices apart.  With consecutive groups on consecutive workgroups every XCD fetches its own copy of most
+    // records (157 MB of L2 misses per launch where slots + records + outputs are 100 MB); here XCD x walks the x-th eighth of the vertices, so the copies meet in one L2.
+    const long perXcd = (nGroups + 7) / 8, wgPerXcd = gridDim.x / 8;
+    const long gFirst = xcd ? (long)(blockIdx.x % 8) * perXcd + blockIdx.x / 8 : blockIdx.x, gStep = xcd ? wgPerXcd : gridDim.x;
+    const long gEnd = xcd ? min(nGroups, (long)(blockIdx.x % 8 + 1) * perXcd) : nGroups;
+    for (long g = gFirst; g < gEnd; g += gStep) {       // (trip counts differ between workgroups only: the shuffles below need whole waves, not whole grids)
         const long i = g * (kBlock / LANES) + threadIdx.x / LANES;
         const bool ok = i < A.N;
         const long iv = ok ? i : 0;
@@ -598,6 +608,8 @@ __global__ __launch_bounds__(kBlock) void arap_applySym(ArapArgs<T> A, const int
         ArapRec<T> me = rec[iv];
         if (PVEC) { const V3<T> a = ld3(v, iv), b = ld3(v + offA, iv); me.px = a.x; me.py = a.y; me.pz = a.z; me.ax = b.x; me.ay = b.y; me.az = b.z; }
         const int bo = outOff[iv], eo = ok ? outOff[iv + 1] : bo;
+        V3<T> rO{0, 0, 0}, rA{0, 0, 0}, mO{0, 0, 0}, mA{0, 0, 0};
+        if (rv && sub == 0) { rO = ld3(rv, iv); rA = ld3(rv + offA, iv); mO = ld3(Mv, iv); mA = ld3(Mv + offA, iv); }      // requested before the walk: known from the vertex index alone
         const V3<T> pv{me.px, me.py, me.pz}, pav{me.ax, me.ay, me.az};
         const ArapCoef<T> cv = arap_coef(me.sa, me.ca, me.sb, me.cb, me.sg, me.cg);
         T s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
@@ -650,12 +662,72 @@ __global__ __launch_bounds__(kBlock) void arap_applySym(ArapArgs<T> A, const int
             V3<T> q{wf * wf * pv.x, wf * wf * pv.y, wf * wf * pv.z}, qa{0, 0, 0};
             if (CtC) { const V3<T> cO = ld3(CtC, i), cA = ld3(CtC + offA, i); q.x += cO.x * pv.x; q.y += cO.y * pv.y; q.z += cO.z * pv.z; qa.x = cA.x * pav.x; qa.y = cA.y * pav.y; qa.z = cA.z * pav.z; }
             acc += (double)(dot3(pv, q) + dot3(pav, qa));
-            out[3 * i] = q.x + s0; out[3 * i + 1] = q.y + s1; out[3 * i + 2] = q.z + s2;
-            out[offA + 3 * i] = qa.x + s3; out[offA + 3 * i + 1] = qa.y + s4; out[offA + 3 * i + 2] = qa.z + s5;
+            const V3<T> oO{q.x + s0, q.y + s1, q.z + s2}, oA{qa.x + s3, qa.y + s4, qa.z + s5};
+            out[3 * i] = oO.x; out[3 * i + 1] = oO.y; out[3 * i + 2] = oO.z;
+            out[offA + 3 * i] = oA.x; out[offA + 3 * i + 1] = oA.y; out[offA + 3 * i + 2] = oA.z;
+            if (rv) {
+                accNum += arap_dprod3(mO.x, rO.x, rO.x) + arap_dprod3(mO.y, rO.y, rO.y) + arap_dprod3(mO.z, rO.z, rO.z) + arap_dprod3(mA.x, rA.x, rA.x) + arap_dprod3(mA.y, rA.y, rA.y) + arap_dprod3(mA.z, rA.z, rA.z);
+                acc2 += arap_dprod3(mO.x, rO.x, oO.x) + arap_dprod3(mO.y, rO.y, oO.y) + arap_dprod3(mO.z, rO.z, oO.z) + arap_dprod3(mA.x, rA.x, oA.x) + arap_dprod3(mA.y, rA.y, oA.y) + arap_dprod3(mA.z, rA.z, oA.z);
+                acc3 += arap_dprod3(mO.x, oO.x, oO.x) + arap_dprod3(mO.y, oO.y, oO.y) + arap_dprod3(mO.z, oO.z, oO.z) + arap_dprod3(mA.x, oA.x, oA.x) + arap_dprod3(mA.y, oA.y, oA.y) + arap_dprod3(mA.z, oA.z, oA.z);
+            }
         }
+    }
+    if (rv) {
+        double vv[4] = {acc, accNum, acc2, acc3};
+        blockReduceSumN<4>(vv, scratch);
+        if (threadIdx.x == 0) { if (partials) partials[blockIdx.x] = vv[0]; S.aNum[blockIdx.x] = vv[1]; S.s2[blockIdx.x] = vv[2]; S.s3[blockIdx.x] = vv[3]; }
+        return;
     }
     double t = blockReduceSum(acc, scratch);
     if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
+}
+
+// PCGStep2 + PCGStep3 (arap_flatStep) for the record path: a workgroup takes 256 consecutive vertices = 3 * 256 / NP 16-byte packs of the Offset half and as many of the Angle
+// half (N a multiple of 4: both halves start on a pack boundary), updates delta, r, p pack by pack, and passes the new p through LDS to the thread that owns the vertex's record.
+template <class T>
+__global__ __launch_bounds__(kBlock) void arap_flatStepRec(T* __restrict__ delta, const T* __restrict__ pOld, const T* __restrict__ rOld, const T* __restrict__ Ap, const T* __restrict__ M,
+                                                           T* __restrict__ rNew, T* __restrict__ pNew, ArapRec<T>* __restrict__ rec, long N, const double* aNumP, int nNum, const double* aDenP, int nDen,
+                                                           const double* s2P, int n2, const double* s3P, int n3) {
+    __shared__ double scratch[4 * (kBlock / kWave + 1)];
+    constexpr int NP = 16 / sizeof(T), PACKS = 3 * kBlock / NP;
+    typedef T VP __attribute__((ext_vector_type(NP)));
+    __shared__ T tile[2][3 * kBlock];
+    const double* const ps[4] = {aNumP, aDenP, s2P, s3P}; const int ns[4] = {nNum, nDen, n2, n3}; double o4[4];
+    sumPartialsN<4>(ps, ns, scratch, o4);
+    const T aNum = (T)o4[0], aDen = (T)o4[1];
+    const T alpha = (aDen > T(0)) ? aNum / aDen : T(0);                                  // solver.t:456-459
+    const double bNumD = fmax(o4[0] - 2.0 * (double)alpha * o4[2] + (double)alpha * (double)alpha * o4[3], 0.0);
+    const T beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);                               // solver.t:544-547
+    const long offA = 3 * N, nTiles = (N + kBlock - 1) / kBlock, packsPerHalf = 3 * N / NP;
+    for (long t = blockIdx.x; t < nTiles; t += gridDim.x) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < 2 * PACKS; q += kBlock) {
+            const int half = q >= PACKS, j = half ? q - PACKS : q;
+            const long pk = t * PACKS + j;
+            if (pk < packsPerHalf) {
+                const long base = (half ? offA : 0) + pk * NP;
+                VP d = *(const VP*)(delta + base);
+                const VP p = *(const VP*)(pOld + base), r = *(const VP*)(rOld + base), a = *(const VP*)(Ap + base), m = *(const VP*)(M + base);
+                VP rn, pn;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    d[k] = d[k] + alpha * p[k];
+                    rn[k] = r[k] - alpha * a[k];
+                    const T z = m[k] * rn[k];
+                    pn[k] = z + beta * p[k];
+                    tile[half][j * NP + k] = pn[k];
+                }
+                *(VP*)(delta + base) = d; *(VP*)(rNew + base) = rn; *(VP*)(pNew + base) = pn;
+            }
+        }
+        __syncthreads();
+        const long i = t * kBlock + threadIdx.x;
+        if (i < N) {
+            ArapRec<T>& rr = rec[i];
+            rr.px = tile[0][3 * threadIdx.x]; rr.py = tile[0][3 * threadIdx.x + 1]; rr.pz = tile[0][3 * threadIdx.x + 2];
+            rr.ax = tile[1][3 * threadIdx.x]; rr.ay = tile[1][3 * threadIdx.x + 1]; rr.az = tile[1][3 * threadIdx.x + 2];
+        }
+    }
 }
 
 // ---- the same for J^T F and diag(J^T J) (once per Gauss-Newton iteration) ---------------------------------------------------------
@@ -793,11 +865,13 @@ struct ArapOps : EnergyOps<T> {
         int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (const char* e = getenv("OPT_AMD_ARAP_GATHER")) useGather = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ARAP_FUSED")) useFused = atoi(e) != 0;
-        if (const char* e = getenv("OPT_AMD_ARAP_ITER")) fusedIter = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_ARAP_ITER")) { fusedIter = atoi(e) != 0; fusedIterEnv = atoi(e) != 0; }
         if (const char* e = getenv("OPT_AMD_ARAP_SYM")) useSym = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ARAP_SYM_LANES")) symLanes = atoi(e);
         if (const char* e = getenv("OPT_AMD_ARAP_SYM_PVEC")) symPvec = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ARAP_SYM_BATCH")) symBatch = atoi(e);
+        if (const char* e = getenv("OPT_AMD_ARAP_SYM_XCD")) symXcd = atoi(e);
+        if (const char* e = getenv("OPT_AMD_ARAP_VGRID")) symGridCap = atoi(e);
     }
     void bind(void** p, LaunchCtx& ctx) override {
         A.w_fit = (T) * (const float*)p[0]; A.w_reg = (T) * (const float*)p[1];
@@ -868,32 +942,35 @@ struct ArapOps : EnergyOps<T> {
     int symLanes = ARAP_SYM_LANES;      // OPT_AMD_ARAP_SYM_LANES=1|2|4|8 (A/B switch)
     bool symPvec = false;               // OPT_AMD_ARAP_SYM_PVEC=1 (A/B switch, see arap_applySym)
     int symGrid() const {               // all workgroups resident at once (4 per CU): a second, partial round of workgroups costs more than the longer grid-stride loops
-        static const int cap = getenv("OPT_AMD_ARAP_VGRID") ? atoi(getenv("OPT_AMD_ARAP_VGRID")) : 0;
+        const int cap = symGridCap;
         const long groups = (A.N + kBlock / symLanes - 1) / (kBlock / symLanes);
         return (int)std::max<long>(1, std::min<long>(groups, cap > 0 ? cap : std::min<long>(4L * cus, kMaxPartials / 2)));
     }
+    int symGridCap = 0;                 // OPT_AMD_ARAP_VGRID (read per plan)
+    int symXcd = 1;                     // OPT_AMD_ARAP_SYM_XCD=0: consecutive vertex groups on consecutive workgroups (A/B switch, see arap_applySym)
     int symBatch = 4;                   // OPT_AMD_ARAP_SYM_BATCH=1|2|3|4: slots a lane requests together (a mesh vertex has ~6 neighbours: 3 per lane at two lanes per vertex); measured 31.0 / 34.9 / 32.6 / 29.3 us
-    template <bool PVEC, int BATCH> void launchSymPB(const T* v, T* out, const T* CtC, double* part, int g, LaunchCtx& ctx) {
+    template <bool PVEC, int BATCH> void launchSymPB(const T* v, T* out, const T* CtC, double* part, int g, LaunchCtx& ctx, const ArapIterSums& S) {
         switch (symLanes) {
-            case 1: arap_applySym<T, 1, PVEC, BATCH><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part); break;
-            case 4: arap_applySym<T, 4, PVEC, BATCH><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part); break;
-            case 8: arap_applySym<T, 8, PVEC, BATCH><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part); break;
-            default: arap_applySym<T, 2, PVEC, BATCH><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part); break;
+            case 1: arap_applySym<T, 1, PVEC, BATCH><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part, symXcd && g % 8 == 0, S); break;
+            case 4: arap_applySym<T, 4, PVEC, BATCH><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part, symXcd && g % 8 == 0, S); break;
+            case 8: arap_applySym<T, 8, PVEC, BATCH><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part, symXcd && g % 8 == 0, S); break;
+            default: arap_applySym<T, 2, PVEC, BATCH><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part, symXcd && g % 8 == 0, S); break;
         }
     }
-    template <bool PVEC> void launchSymP(const T* v, T* out, const T* CtC, double* part, int g, LaunchCtx& ctx) {
+    template <bool PVEC> void launchSymP(const T* v, T* out, const T* CtC, double* part, int g, LaunchCtx& ctx, const ArapIterSums& S) {
         switch (symBatch) {
-            case 1: launchSymPB<PVEC, 1>(v, out, CtC, part, g, ctx); break;
-            case 2: launchSymPB<PVEC, 2>(v, out, CtC, part, g, ctx); break;
-            case 3: launchSymPB<PVEC, 3>(v, out, CtC, part, g, ctx); break;
-            default: launchSymPB<PVEC, 4>(v, out, CtC, part, g, ctx); break;
+            case 1: launchSymPB<PVEC, 1>(v, out, CtC, part, g, ctx, S); break;
+            case 2: launchSymPB<PVEC, 2>(v, out, CtC, part, g, ctx, S); break;
+            case 3: launchSymPB<PVEC, 3>(v, out, CtC, part, g, ctx, S); break;
+            default: launchSymPB<PVEC, 4>(v, out, CtC, part, g, ctx, S); break;
         }
     }
-    void launchSym(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) {
+    int launchSym(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx, const ArapIterSums& S = ArapIterSums{nullptr, nullptr, nullptr, nullptr, nullptr}) {
         const int g = symGrid();
         double* part = dot ? dot->partials : nullptr;
-        if (symPvec) launchSymP<true>(v, out, CtC, part, g, ctx); else launchSymP<false>(v, out, CtC, part, g, ctx);
+        if (symPvec) launchSymP<true>(v, out, CtC, part, g, ctx, S); else launchSymP<false>(v, out, CtC, part, g, ctx, S);
         if (dot) dot->n = g;
+        return g;
     }
     // PCGStep3 of the previous iteration + PCGStep1 (symmetric-graph path): the flat pass that forms p = z + beta p also writes it into the vertex records the gather reads
     bool applyJTJFused(const T* pOld, const T* z, T* pNew, T* out, const T* CtC, Reduction* dot, const Reduction& bNum, const double* aNumOld, double* aNumNext, LaunchCtx& ctx) override {
@@ -907,8 +984,29 @@ struct ArapOps : EnergyOps<T> {
     // expanded beta numerator].  Correct (all ARAP parity tests pass with it, final cost of config 4 equal to 8e-8) and MEASURED SLOWER, for the third time in three formulations:
     // the flat part drops from 35.5 to 27.6 us per iteration, but the gather -- bound by how many dependent offset -> index -> record chains are in flight -- pays 13 us for
     // the owner lane's r and M (requested before the edge walk) and its three extra sums (74 -> 87 us): config 4 217 -> 234 ms.  Off unless OPT_AMD_ARAP_ITER=1.
-    bool fusedIter = false;
+    // On the symmetric-graph path (round 3, later) the balance is the other way round: arap_applySym is bound by HBM traffic, not by chains, the owner lane's r and M are 24 MB
+    // on top of 170, and the flat pass (arap_flatStepRec: delta, r, p and the records in one go) replaces 22 + 21 us of PCGStep2 and PCGStep3 -- there it is the default
+    // (OPT_AMD_ARAP_ITER=0 switches it off).
+    bool fusedIter = false; int fusedIterEnv = -1;
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
+        if (symPath() && !symPvec && fusedIterEnv != 0 && !a.CtC && a.pre && !this->slab.active && A.N % 4 == 0 &&
+            ((uintptr_t)a.delta | (uintptr_t)a.pOld | (uintptr_t)a.rOld | (uintptr_t)a.ApOld | (uintptr_t)a.pre | (uintptr_t)a.rNew | (uintptr_t)a.pNew) % 16 == 0) {
+            const long n = 6 * A.N, nPad = (n + 3) / 4 * 4;
+            if (a.first) {      // the solver adopts rNew / pNew after every launch: the start state moves there unchanged
+                HIP_CHECK(hipMemcpyAsync(a.rNew, a.rOld, nPad * sizeof(T), hipMemcpyDeviceToDevice, ctx.stream));
+                HIP_CHECK(hipMemcpyAsync(a.pNew, a.pOld, nPad * sizeof(T), hipMemcpyDeviceToDevice, ctx.stream));
+                ScopedKernel k(ctx, "packVertexRecords"); arap_packRec<T><<<vgrid(), kBlock, 0, ctx.stream>>>(a.pNew, rec, A.N);
+            } else {
+                ScopedKernel k(ctx, "PCGStep2+PCGStep3");
+                const int g = (int)std::max<long>(1, std::min<long>((A.N + kBlock - 1) / kBlock, (long)cus * 8));
+                arap_flatStepRec<T><<<g, kBlock, 0, ctx.stream>>>(a.delta, a.pOld, a.rOld, a.ApOld, a.pre, a.rNew, a.pNew, rec, A.N, a.aNumPrev.partials, a.aNumPrev.n, a.aDenPrev.partials, a.aDenPrev.n,
+                                                                 a.s2Prev.partials, a.s2Prev.n, a.s3Prev.partials, a.s3Prev.n);
+            }
+            ScopedKernel k(ctx, "PCGStep1");
+            const int g = launchSym(a.pNew, a.ApNew, nullptr, a.aDen, ctx, ArapIterSums{a.rNew, a.pre, a.aNum->partials, a.s2->partials, a.s3->partials});
+            a.aNum->n = a.aDen->n = a.s2->n = a.s3->n = g;
+            return true;
+        }
         if (!fusedIter || !useGather || !useFused || a.CtC || !a.pre || this->slab.active) return false;
         const long n = 6 * A.N, nPad = (n + 3) / 4 * 4, nPacks = nPad * (long)sizeof(T) / 16;
         if (a.first) {      // the solver adopts rNew / pNew after every launch: the start state moves there unchanged
