@@ -136,6 +136,20 @@ def golden_solve8(size):
     return (fl["costs"] if fl else None), (db["costs"] if db else None)
 
 
+def rerounding_yardstick_solve8(size, precision="float"):
+    """The same yardstick taken on the metric's own solve: the fma build of the oracle through the 8 x 400 solve against the plain build, largest relative
+    distance over the eight steps (tests/golden/make_horizon_costs.py --families solve8 --variant fma); None if not frozen."""
+    try:
+        G = json.load(open(os.path.join(ROOT, "tests", "golden", "horizon_costs.json")))
+        F = json.load(open(os.path.join(ROOT, "tests", "golden", "horizon_costs_fma.json")))
+    except OSError:
+        return None
+    k = f"solve8_{size}_{precision}"
+    if k not in G or k not in F:
+        return None
+    return max(abs(a - b) / abs(b) for a, b in zip(F[k]["costs"][1:], G[k]["costs"][1:]))
+
+
 def rerounding_yardstick():
     """What re-rounding the same algorithm does to the cost after ONE step: the oracle compiled with fused multiply-adds against the plain build, largest over the
     frozen horizons (2048^2 float; tests/golden/horizon_costs*.json, tests/test_horizon_gpu.py)."""
@@ -330,9 +344,10 @@ def main():
             # search; in float and in double alike), the float and the double oracle end apart, and one 400-iteration step re-rounded (fma build) differs by `yard`
             noise = max([0.0] + [(b - a) / a for a, b in zip(gf[1:], gf[2:]) if b > a])
             yard = rerounding_yardstick()
-            solve.update({"final_energy_oracle_float": gf[-1], "final_energy_oracle_double": gd[-1] if gd else None, "rel_err_vs_oracle_float": rel,
+            yard8 = rerounding_yardstick_solve8(W)
+            solve.update({"oracle_plain_vs_fma_this_solve": yard8,"final_energy_oracle_float": gf[-1], "final_energy_oracle_double": gd[-1] if gd else None, "rel_err_vs_oracle_float": rel,
                           "oracle_float_vs_double": envd, "oracle_float_step_to_step_increase": noise, "oracle_plain_vs_fma_one_step": yard,
-                          "within_contract_1e-5": rel <= 1e-5, "within_rerounding_envelope": rel <= max(1e-5, noise, yard, 2.0 * envd if envd is not None else 0.0),
+                          "within_contract_1e-5": rel <= 1e-5, "within_rerounding_envelope": rel <= max(1e-5, noise, yard, yard8 or 0.0, 2.0 * envd if envd is not None else 0.0),
                           "source": "tests/golden/horizon_costs.json solve8_* (oracle, generated offline by tests/golden/make_horizon_costs.py)"})
         if comm_error():
             solve["comm_error"] = comm_error()
