@@ -174,7 +174,12 @@ struct VolumetricE {
 
 template <class T> EnergyOps<T>* makeFlow(const unsigned* dims) { return new StencilOps<T, OpticalFlowE<T>>(dims, false); }
 template <class T> EnergyOps<T>* makeIntrinsic(const unsigned* dims) { return new StencilOps<T, IntrinsicE<T>>(dims, false); }
-template <class T> EnergyOps<T>* makeVolumetric(const unsigned* dims) { return new StencilOps<T, VolumetricE<T>>(dims, true); }
+// OPT_AMD_VOLUMETRIC_ARAP=0: the functor engine; default: ARAP's kernel set on the lattice graph (energy.h makeVolumetricOnArap -- the same energy, 151 -> ... ms at 96^3)
+template <class T> EnergyOps<T>* makeVolumetric(const unsigned* dims) {
+    const char* e = getenv("OPT_AMD_VOLUMETRIC_ARAP");
+    if ((!e || atoi(e) != 0) && (unsigned long long)dims[0] * dims[1] * dims[2] < (1ull << 28)) return makeVolumetricOnArap<T>(dims);      // (6 |V| half-edges in 32-bit indices)
+    return new StencilOps<T, VolumetricE<T>>(dims, true);
+}
 
 }  // namespace
 

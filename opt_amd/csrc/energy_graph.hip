@@ -1036,10 +1036,45 @@ struct ArapOps : EnergyOps<T> {
     }
 };
 
+// volumetric_mesh_deformation (examples/volumetric_mesh_deformation/volumetric_mesh_deformation.t:1-20) on ARAP's kernels: every in-bounds lattice neighbour n of voxel c, in the
+// .t's stencil order (+x, -x, +y, -y, +z, -z), is the half-edge (c -> n) -- Select(InBounds(0,0,0), Select(InBounds(n), edge, 0), 0) keeps exactly the edges between existing voxels --
+// and the parameter slots are those of the volumetric .t re-ordered into ARAP's.  The lattice graph is symmetric, so J^T J p runs on the record gather (arap_applySym).
+template <class T>
+struct VolumetricArapOps : ArapOps<T> {
+    int* dv0 = nullptr; int* dv1 = nullptr; int nEdges = 0;
+    static const unsigned* count(const unsigned* dims) { static thread_local unsigned n[1]; n[0] = dims[0] * dims[1] * dims[2]; return n; }
+    explicit VolumetricArapOps(const unsigned* dims) : ArapOps<T>(count(dims)) {
+        const int W = (int)dims[0], H = (int)dims[1], D = (int)dims[2];
+        std::vector<int> v0, v1;
+        v0.reserve((size_t)6 * W * H * D); v1.reserve((size_t)6 * W * H * D);
+        static const int off[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+        for (int z = 0; z < D; ++z) for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+            const int c = (z * H + y) * W + x;
+            for (const auto& o : off) {
+                const int xx = x + o[0], yy = y + o[1], zz = z + o[2];
+                if (xx < 0 || xx >= W || yy < 0 || yy >= H || zz < 0 || zz >= D) continue;
+                v0.push_back(c); v1.push_back((zz * H + yy) * W + xx);
+            }
+        }
+        nEdges = (int)v0.size();
+        HIP_CHECK(hipMalloc((void**)&dv0, std::max<size_t>(1, v0.size()) * sizeof(int))); HIP_CHECK(hipMalloc((void**)&dv1, std::max<size_t>(1, v1.size()) * sizeof(int)));
+        HIP_CHECK(hipMemcpy(dv0, v0.data(), v0.size() * sizeof(int), hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(dv1, v1.data(), v1.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    ~VolumetricArapOps() override { (void)hipFree(dv0); (void)hipFree(dv1); }
+    void bind(void** p, LaunchCtx& ctx) override {      // volumetric: Offset, Angle, UrShape, Constraints, w_fitSqrt, w_regSqrt  ->  ARAP: w_fit, w_reg, Offset, Angle, UrShape, Constraints, |E|, v0, v1
+        void* q[9] = {p[4], p[5], p[0], p[1], p[2], p[3], &nEdges, dv0, dv1};
+        ArapOps<T>::bind(q, ctx);
+    }
+};
+
 template <class T> EnergyOps<T>* makeCF(const unsigned* dims) { return new CurveFittingOps<T>(dims); }
 template <class T> EnergyOps<T>* makeArap(const unsigned* dims) { return new ArapOps<T>(dims); }
 
 }  // namespace
+
+template <class T> EnergyOps<T>* makeVolumetricOnArap(const unsigned* dims) { return new VolumetricArapOps<T>(dims); }
+template EnergyOps<float>* makeVolumetricOnArap<float>(const unsigned*);
+template EnergyOps<double>* makeVolumetricOnArap<double>(const unsigned*);
 
 EnergyInfo curveFittingInfo() {
     EnergyInfo e;
