@@ -278,6 +278,37 @@ def test_arap_asymmetric_graph_keeps_the_edge_list_path(oracle_lib, double):
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("mode", ["0", "1"])
+@pytest.mark.parametrize("double", [False, True])
+def test_volumetric_on_both_kernel_sets(oracle_lib, double, mode, monkeypatch):
+    """volumetric_mesh_deformation is ARAP on the 6-neighbour lattice graph and runs on ARAP's kernel set by default (OPT_AMD_VOLUMETRIC_ARAP=1: generated half-edge list,
+    record gather, two-kernel iteration); 0 keeps the stencil functor engine.  Both against the oracle's own (stencil) statement of the energy: J^T J p and a GN trajectory."""
+    import torch
+    monkeypatch.setenv("OPT_AMD_VOLUMETRIC_ARAP", mode)
+    P = wl.volumetric_mesh_deformation(8, 6, 4, double=double, seed=5, perturb=0.05)      # 192 voxels: a multiple of 4, the two-kernel iteration's form
+    tol = 1e-11 if double else 3e-5
+    o = oracle_solver(oracle_lib, P); g = hip_solver(P, timing=True)
+    dev = api.to_device(P)
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(o.n).astype(o.dtype)
+    Av_ref = o.apply_jtj(P.params, v)
+    Av_gpu, _ = g.apply_jtj(dev, torch.from_numpy(v).cuda())
+    assert rel_err(Av_gpu.cpu().numpy(), Av_ref) < tol
+    assert ("packVertexRecords" in g.kernel_timings()) == (mode == "1")
+    g.close(); o.close()
+    kw = dict(nIterations=3, lIterations=12)
+    o = oracle_solver(oracle_lib, P, "gaussNewtonGPU", **kw); g = hip_solver(P, "gaussNewtonGPU", **kw)
+    Pref = P.clone(); dev = api.to_device(P)
+    o.init(Pref.params); g.init(dev)
+    while True:
+        a, b = o.step(Pref.params), g.step(dev)
+        assert a == b
+        assert abs(g.cost() - o.cost()) <= (1e-10 if double else 1e-5) * abs(o.cost())
+        if not a:
+            break
+    g.close(); o.close()
+
+
 def test_arap_path_is_deterministic():
     """The ARAP kernel set uses no atomics (edge pass -> records, vertex pass gathers sorted lists) for J^T F as well as J^T J p:
     two solves of the same problem give the same bits (the reference's scatter kernels do not)."""
