@@ -170,8 +170,4 @@ struct EnergyInfo {
 };
 const std::vector<EnergyInfo>& energyRegistry();
 
-// volumetric_mesh_deformation is arap_mesh_deformation on the 6-neighbour lattice graph (the same fit and regularisation residuals, volumetric_mesh_deformation.t against
-// arap_mesh_deformation.t): this factory (energy_graph.hip) runs it on ARAP's kernel set over a half-edge list generated from the lattice dimensions.
-template <class T> EnergyOps<T>* makeVolumetricOnArap(const unsigned* dims);
-
 }  // namespace optamd

@@ -2,6 +2,7 @@
 // volumetric_mesh_deformation -- SURVEY.md 8(f) rank 3.  Each functor restates the residuals of its reference .t once,
 // against a scalar type S that the engine instantiates as T or as a dual number.
 #include "stencil_engine.h"
+#include "graph_common.h"      // makeVolumetricOnArap
 
 namespace optamd {
 namespace {
@@ -174,7 +175,7 @@ struct VolumetricE {
 
 template <class T> EnergyOps<T>* makeFlow(const unsigned* dims) { return new StencilOps<T, OpticalFlowE<T>>(dims, false); }
 template <class T> EnergyOps<T>* makeIntrinsic(const unsigned* dims) { return new StencilOps<T, IntrinsicE<T>>(dims, false); }
-// OPT_AMD_VOLUMETRIC_ARAP=0: the functor engine; default: ARAP's kernel set on the lattice graph (energy.h makeVolumetricOnArap -- the same energy, 151 -> ... ms at 96^3)
+// OPT_AMD_VOLUMETRIC_ARAP=0: the functor engine; default: ARAP's kernel set on the lattice graph (graph_common.h makeVolumetricOnArap -- the same energy, 151 -> ... ms at 96^3)
 template <class T> EnergyOps<T>* makeVolumetric(const unsigned* dims) {
     const char* e = getenv("OPT_AMD_VOLUMETRIC_ARAP");
     if ((!e || atoi(e) != 0) && (unsigned long long)dims[0] * dims[1] * dims[2] < (1ull << 28)) return makeVolumetricOnArap<T>(dims);      // (6 |V| half-edges in 32-bit indices)

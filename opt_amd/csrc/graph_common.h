@@ -1,6 +1,7 @@
 // Pieces shared by the graph kernel sets (energy_graph.hip: curveFitting, ARAP; graph_engine.h: the functor-driven ones).
 #pragma once
 #include "common.h"
+#include "energy.h"
 
 namespace optamd {
 
@@ -26,5 +27,9 @@ template <class T> __device__ __forceinline__ void plainAtomicAdd(T* addr, T val
 
 // workgroups of an edge pass: its partial sums take the upper half of a Reduction, the vertex pass the lower half
 inline int edgeGrid(long nE, int cus) { return (int)std::max<long>(1, std::min<long>((nE + kBlock - 1) / kBlock, std::min<long>(kMaxPartials / 2, (long)cus * 8))); }
+
+// volumetric_mesh_deformation is arap_mesh_deformation on the 6-neighbour lattice graph (the same fit and regularisation residuals, volumetric_mesh_deformation.t against
+// arap_mesh_deformation.t): this factory (energy_graph.hip) runs it on ARAP's kernel set over a half-edge list generated from the lattice dimensions.
+template <class T> EnergyOps<T>* makeVolumetricOnArap(const unsigned* dims);
 
 }  // namespace optamd
