@@ -25,6 +25,11 @@
 #ifndef DELTA_LDS
 #define DELTA_LDS 1
 #endif
+//   DELTA_ATOMIC 1 (with DELTA_LDS 0): delta += alpha p as a no-return hardware float atomic per scalar (one lane per address: deterministic; no registers, no exposed latency;
+//                the 25 MB of delta mostly stay in the L2s)
+#ifndef DELTA_ATOMIC
+#define DELTA_ATOMIC 0
+#endif
 constexpr int W = 4096, H = 512, ROWS = 16, BLOCK = 512, TILE_W = 256, TILE_H = 32;
 constexpr long N = (long)W * H;
 
@@ -48,7 +53,7 @@ __device__ __forceinline__ void pairQ(const Q& c, const Q& n, float& ax, float& 
 }
 
 __global__ __launch_bounds__(BLOCK) void k_onchip(const float* __restrict__ pIn, const float* __restrict__ rIn, const float* __restrict__ angle, const uint8_t* __restrict__ flags,
-                                                  float* __restrict__ pOut, double* __restrict__ sums, int iters, float alpha, float beta, float w2, float wf2) {
+                                                  float* __restrict__ pOut, float* __restrict__ deltaG, double* __restrict__ sums, int iters, float alpha, float beta, float w2, float wf2) {
     extern __shared__ float lds[];                    // delta: [row][component][thread]  (conflict-free), then the two 16-entry preconditioner tables
     float* dl = lds;                                  // [ROWS * 3][BLOCK] if DELTA_LDS
     float* apl = lds + (DELTA_LDS ? ROWS * 3 * BLOCK : 0);      // [ROWS * 3][BLOCK] if AP_LDS
@@ -83,6 +88,7 @@ __global__ __launch_bounds__(BLOCK) void k_onchip(const float* __restrict__ pIn,
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 if (DELTA_LDS) { float* d = dl + (y * 3 + c) * BLOCK + threadIdx.x; *d = *d + alpha * p[y][c]; }
+                if (DELTA_ATOMIC) { const long i = (long)(y0 + y) * W + x; unsafeAtomicAdd(c < 2 ? deltaG + 2 * i + c : deltaG + 2 * N + i, alpha * p[y][c]); }
                 r[y][c] = r[y][c] - alpha * (AP_LDS ? apl[(y * 3 + c) * BLOCK + threadIdx.x] : ap[AP_LDS ? 0 : y][c]);
                 p[y][c] = m[c] * r[y][c] + beta * p[y][c];
             }
@@ -124,7 +130,8 @@ __global__ __launch_bounds__(BLOCK) void k_onchip(const float* __restrict__ pIn,
 
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 200;
-    float *pIn, *rIn, *angle, *pOut; uint8_t* flags; double* sums;
+    float *pIn, *rIn, *angle, *pOut, *deltaG; uint8_t* flags; double* sums;
+    CHECK(hipMalloc(&deltaG, 3 * N * 4)); CHECK(hipMemset(deltaG, 0, 3 * N * 4));
     CHECK(hipMalloc(&pIn, 3 * N * 4)); CHECK(hipMalloc(&rIn, 3 * N * 4)); CHECK(hipMalloc(&angle, N * 4)); CHECK(hipMalloc(&pOut, N * 4)); CHECK(hipMalloc(&flags, N)); CHECK(hipMalloc(&sums, 64));
     std::vector<float> h(3 * N); std::vector<uint8_t> hf(N);
     for (long i = 0; i < 3 * N; ++i) h[i] = 1e-3f * (float)((i * 2654435761u) % 1000) - 0.5f;
@@ -132,7 +139,7 @@ int main(int argc, char** argv) {
     for (long i = 0; i < N; ++i) hf[i] = (uint8_t)(1 | ((i % 97 == 0) ? 2 : 0) | (4 << 2));
     CHECK(hipMemcpy(flags, hf.data(), N, hipMemcpyHostToDevice));
     const size_t ldsBytes = (size_t)((DELTA_LDS ? ROWS * 3 * BLOCK : 0) + (AP_LDS ? ROWS * 3 * BLOCK : 0) + 32) * sizeof(float);
-    printf("CS_REGS=%d AP_LDS=%d DELTA_LDS=%d\n", CS_REGS, AP_LDS, DELTA_LDS);
+    printf("CS_REGS=%d AP_LDS=%d DELTA_LDS=%d DELTA_ATOMIC=%d\n", CS_REGS, AP_LDS, DELTA_LDS, DELTA_ATOMIC);
     CHECK(hipFuncSetAttribute((const void*)k_onchip, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
     const int grid = (W / TILE_W) * (H / TILE_H);
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -142,7 +149,7 @@ int main(int argc, char** argv) {
         for (int k = 0; k < 2; ++k) {      // two launch lengths: the difference is free of the load / store ends of the kernel
             const int n = k ? iters : iters / 2;
             CHECK(hipEventRecord(e0));
-            k_onchip<<<grid, BLOCK, ldsBytes>>>(pIn, rIn, angle, flags, pOut, sums, n, 1e-3f, 0.5f, 1.0f, 0.25f);
+            k_onchip<<<grid, BLOCK, ldsBytes>>>(pIn, rIn, angle, flags, pOut, deltaG, sums, n, 1e-3f, 0.5f, 1.0f, 0.25f);
             CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); CHECK(hipGetLastError());
             CHECK(hipEventElapsedTime(&ms[k], e0, e1));
         }
