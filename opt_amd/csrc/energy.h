@@ -130,6 +130,14 @@ struct EnergyOps {
     virtual bool finishUpdate(const T* /*pPrev*/, const T* /*pLast*/, const T* /*delta*/, const Reduction& /*aNum*/, const Reduction& /*aDen*/, LaunchCtx&) { return false; }
     // Optional: one WHOLE Gauss-Newton PCG iteration as a single kernel (see PcgIterArgs and solver.hip).
     virtual bool pcgIteration(const PcgIterArgs<T>& /*args*/, LaunchCtx&) { return false; }
+    // Optional (Gauss-Newton, single GPU): the WHOLE linear solve -- lIterations PCG iterations (solverGPUGaussNewton.t:1056-1092) from r = r_0, p = M r_0 as PCGInit1
+    // left them, then PCGLinearUpdate X += delta -- as one persistent launch that keeps the loop state on chip (iw_onchip.h).  r0 and p0 are only read; delta
+    // receives sum alpha_k p_k; traceDev (or nullptr) receives alphaNum, alphaDen, s2, s3 of every iteration (4 doubles each; beta numerator by expansion as
+    // in PcgIterArgs).  false: the problem does not fit the chip or the kernel set has no such kernel -- nothing was touched.
+    virtual bool pcgSolveOnChip(const T* /*r0*/, const T* /*p0*/, T* /*delta*/, int /*lIterations*/, double* /*traceDev*/, LaunchCtx&) { return false; }
+    // After the stream has drained: did a wait inside the last on-chip solve time out (another tenant on the GPU kept its workgroups from being co-resident)?
+    // Then the unknowns were left untouched, the kernel set has switched the path off for this plan, and the caller redoes the linear solve.
+    virtual bool onChipFailed() { return false; }
     // Slab mode, after a pcgIteration launch with iterStateExchange: which vectors (solver layout) carry the state whose ghost rows the neighbours
     // must refresh.  0 = the rNew / pNew the launch was given; a kernel set that keeps its loop state in buffers of its own lists them here.
     virtual int iterExchangeVectors(T** /*out4*/) { return 0; }

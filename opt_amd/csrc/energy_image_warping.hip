@@ -31,12 +31,13 @@
 //    remains for slabs with a single ghost row; iw_applyJTJ (with the previous PCGStep3 optionally fused in) serves probes, the
 //    split residual reset of LM and the OPT_AMD_ONEKERNEL=0 fallback.
 #include "energy.h"
+#include "iw_device.h"
+#include "iw_onchip.h"
 #include <cstdint>
 
 namespace optamd {
 namespace {
 
-template <class T> struct V2 { T x, y; };
 
 template <class T>
 struct IWArgs {
@@ -49,8 +50,6 @@ struct IWArgs {
     T* cs;                    // (cos a, sin a) per pixel
 };
 
-constexpr uint8_t kActive = 1, kFit = 2;
-constexpr int kCountShift = 2;       // bits 2..4: number of active 4-neighbours (0..4) of an active pixel
 
 // once per Init/Step: fold Mask / Constraints / global bounds into one byte per pixel
 template <class T>
@@ -936,14 +935,6 @@ constexpr int kSpan2 = kWave - 4;
 //  * the sweep direction is a template parameter; the row windows are rotated by name over three trips per loop
 //    pass (three prefetch buffers), so no register copies are needed at the back-edge;
 //  * the shifted cos / sin / on of a row are kept from its first use (centre of Ap_{k-1}) for its second (centre of Ap_k).
-template <class T>
-struct Q {            // one pixel of a row held in registers
-    T ox, oy, a;      // the vector (p_{k-1} or p_k)
-    T c, s;           // cos/sin of the pixel's angle
-    T ux, uy;         // UrShape (dead on a unit lattice)
-    T on;             // 1 if the pixel exists and is not excluded, else 0
-    T fw;             // w_fit^2 if its fit residual is on, else 0
-};
 template <bool RIGHT, bool LATTICE, class T> __device__ __forceinline__ void dppShiftConst(const Q<T>& p, Q<T>& q) {   // the fields that do not change between p_{k-1} and p_k
     q.c = dppShift<RIGHT>(p.c); q.s = dppShift<RIGHT>(p.s); q.on = dppShift<RIGHT>(p.on);
     if (LATTICE) { q.ux = 0; q.uy = 0; } else { q.ux = dppShift<RIGHT>(p.ux); q.uy = dppShift<RIGHT>(p.uy); }
@@ -951,64 +942,6 @@ template <bool RIGHT, bool LATTICE, class T> __device__ __forceinline__ void dpp
 }
 template <bool RIGHT, class T> __device__ __forceinline__ void dppShiftVec(const Q<T>& p, Q<T>& q) {
     q.ox = dppShift<RIGHT>(p.ox); q.oy = dppShift<RIGHT>(p.oy); q.a = dppShift<RIGHT>(p.a);
-}
-// the two residuals shared by centre c and its neighbour n in direction (DX, DY) (see iw_pair)
-template <int DX, int DY, bool LATTICE, class T>
-__device__ __forceinline__ void iw_pairQ(const Q<T>& c, const Q<T>& n, T& ax, T& ay, T& aa) {
-    T Dcx, Dcy, Dnx, Dny;
-    if (LATTICE) {       // U_c - U_n = -(DX, DY)
-        Dcx = DX ? T(DX) * c.s : T(DY) * c.c;   Dcy = DX ? T(-DX) * c.c : T(DY) * c.s;
-        Dnx = DX ? T(-DX) * n.s : T(-DY) * n.c; Dny = DX ? T(DX) * n.c : T(-DY) * n.s;
-    } else {
-        const T ux = c.ux - n.ux, uy = c.uy - n.uy;
-        Dcx = -c.s * ux - c.c * uy; Dcy = c.c * ux - c.s * uy;
-        Dnx = n.s * ux + n.c * uy;  Dny = -n.c * ux + n.s * uy;
-    }
-    const T dx = c.ox - n.ox, dy = c.oy - n.oy;
-    const T jcx = dx - Dcx * c.a, jcy = dy - Dcy * c.a;
-    const T jnx = -dx - Dnx * n.a, jny = -dy - Dny * n.a;
-    ax += n.on * (jcx - jnx); ay += n.on * (jcy - jny);
-    aa -= n.on * (Dcx * jcx + Dcy * jcy);
-}
-// ---- each pair of residuals is formed ONCE (round 3) -----------------------------------------------------------------------------------------------
-// iw_pairQ evaluates, for centre c and neighbour n, the residual centred at c towards n and the one centred at n towards c -- and the pixel n, when it is the
-// centre, evaluates the same two residuals again from its side: jc' = jn, jn' = jc, D_{n,-d} = Dn bit for bit (a - b = -(b - a) and a product keeps its value
-// when both factors change sign).  So the pair is formed once, by the end that comes first in lane / sweep order, which also leaves what the other end needs:
-//   jc' - jn' = -(jc - jn)   and   D_{n,-d} . jc' = Dn . jn.
-// The right-hand pair of lane x is the left-hand pair of lane x + 1 (three DPP moves instead of the neighbour's three vector fields and 13 VALU instructions); the
-// pair towards the next row of the march is the pair towards the previous row one trip later (three registers per stencil evaluation).  Accumulation order and
-// every accumulated value are those of iw_pairQ: the result is the same bits, ~34 of ~250 VALU instructions per pixel-row less -- which pays where the kernel is
-// issue-bound (2048^2, slabs: profiles/r03l_iteration_kernel_sq_counters.md), not at 4096^2.
-#ifndef IW_SHARE_PAIRS
-#define IW_SHARE_PAIRS 1
-#endif
-template <class T> struct PairOut { T dx, dy, tn; };      // (jc - jn).x, (jc - jn).y, Dn . jn
-template <int DX, int DY, bool LATTICE, class T>
-__device__ __forceinline__ PairOut<T> iw_pairFull(const Q<T>& c, const Q<T>& n, T& ax, T& ay, T& aa) {
-    T Dcx, Dcy, Dnx, Dny;
-    if (LATTICE) {       // U_c - U_n = -(DX, DY)
-        Dcx = DX ? T(DX) * c.s : T(DY) * c.c;   Dcy = DX ? T(-DX) * c.c : T(DY) * c.s;
-        Dnx = DX ? T(-DX) * n.s : T(-DY) * n.c; Dny = DX ? T(DX) * n.c : T(-DY) * n.s;
-    } else {
-        const T ux = c.ux - n.ux, uy = c.uy - n.uy;
-        Dcx = -c.s * ux - c.c * uy; Dcy = c.c * ux - c.s * uy;
-        Dnx = n.s * ux + n.c * uy;  Dny = -n.c * ux + n.s * uy;
-    }
-    const T dx = c.ox - n.ox, dy = c.oy - n.oy;
-    const T jcx = dx - Dcx * c.a, jcy = dy - Dcy * c.a;
-    const T jnx = -dx - Dnx * n.a, jny = -dy - Dny * n.a;
-    PairOut<T> o;
-    o.dx = jcx - jnx; o.dy = jcy - jny;
-    o.tn = Dnx * jnx + Dny * jny;
-    ax += n.on * o.dx; ay += n.on * o.dy;
-    aa -= n.on * (Dcx * jcx + Dcy * jcy);
-    return o;
-}
-// the same pair seen from its far end: `o` is what the neighbour's evaluation left, nOn that neighbour's activity
-template <class T>
-__device__ __forceinline__ void iw_pairInherited(const PairOut<T>& o, T nOn, T& ax, T& ay, T& aa) {
-    ax -= nOn * o.dx; ay -= nOn * o.dy;
-    aa -= nOn * o.tn;
 }
 template <class T>
 struct OldRow {            // one row of iteration k-1: p_{k-1} and, while still needed, r_{k-1}, M and (LM) CtC
@@ -1433,11 +1366,16 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_ITER_MAXWG")) maxWorkgroups = std::max(1, atoi(e));
         if (const char* e = getenv("OPT_AMD_MARCH_INIT")) marchKernels = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_FUSED_FINISH")) fusedFinish = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_ONCHIP")) ocEnabled = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_ONCHIP_ROWS")) ocForceRows = std::max(0, atoi(e));
+        if (const char* e = getenv("OPT_AMD_ONCHIP_FLAT")) ocFlatMax = std::max(0, atoi(e));
+        if (const char* e = getenv("OPT_AMD_ONCHIP_FAIL_AT")) ocFailAt = atoi(e);      // test hook: see OnchipArgs::failAt
+        if (const char* e = getenv("OPT_AMD_ONCHIP_TIMEOUT_MS")) ocTimeoutTicks = std::max(1, atoi(e)) * 100000LL;
         HIP_CHECK(hipMalloc((void**)&dNotLattice, sizeof(int)));
         HIP_CHECK(hipHostMalloc((void**)&hNotLattice, 64)); *hNotLattice = 0;
         HIP_CHECK(hipEventCreateWithFlags(&bindEvent, hipEventDisableTiming));
     }
-    ~ImageWarpingOps() override { (void)hipHostFree(hNotLattice); (void)hipEventDestroy(bindEvent); for (T* b : ring) if (b) (void)hipFree(b); (void)hipFree(A.flags); (void)hipFree(A.cs); if (mc) (void)hipFree(mc); if (alphaSlots) (void)hipFree(alphaSlots); (void)hipFree(dNotLattice); }
+    ~ImageWarpingOps() override { if (ocS.slots) { (void)hipFree(ocS.slots); (void)hipFree(ocS.groupSlots); (void)hipFree(ocS.inbox); (void)hipFree(ocS.bad); (void)hipHostFree(ocS.hostErr); } (void)hipHostFree(hNotLattice); (void)hipEventDestroy(bindEvent); for (T* b : ring) if (b) (void)hipFree(b); (void)hipFree(A.flags); (void)hipFree(A.cs); if (mc) (void)hipFree(mc); if (alphaSlots) (void)hipFree(alphaSlots); (void)hipFree(dNotLattice); }
     int flatGrid(long n) const { return (int)std::max<long>(1, std::min<long>((n + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
     void bind(void** p, LaunchCtx& ctx) override {
         A.Offset = (const T*)p[0]; A.Angle = (const T*)p[1]; A.UrShape = (const T*)p[2]; A.Constraints = (const T*)p[3]; A.Mask = (const T*)p[4];
@@ -1769,6 +1707,83 @@ struct ImageWarpingOps : EnergyOps<T> {
         iw_finishUpdate<T><<<flatGrid(N), kBlock, 0, ctx.stream>>>(const_cast<T*>(A.Offset), const_cast<T*>(A.Angle), deltaZero ? nullptr : delta, pLast, deferredTerm ? pPrev : nullptr,
                                                                    alphaSlots ? alphaSlots + ((iterIndex - 1) & 1) : nullptr, N, aNum.partials, aNum.n, aDen.partials, aDen.n);
         deferredTerm = false; deltaZero = false;
+        return true;
+    }
+    // ---- the whole linear solve on chip (iw_onchip.h): unit lattice, Gauss-Newton, single GPU, tiles <= CUs ------------------------------------------
+    // OPT_AMD_ONCHIP=0 switches it off (the one A/B switch of the path); OPT_AMD_ONCHIP_ROWS=r forces the variant with r rows per lane (tests run every
+    // variant on small images); OPT_AMD_ONCHIP_FLAT=n: grids of up to n workgroups sum flat instead of through the two-level tree (same bits either way).
+    struct OcVariant { int rows; bool apLds, deltaGlb; const void* fn; size_t lds; int occ; };
+    std::vector<OcVariant> ocVariants;
+    bool ocEnabled = true, ocFailed = false, ocLaunched = false;
+    int ocForceRows = 0, ocFlatMax = 32, ocFailAt = -1; long long ocTimeoutTicks = 2000LL * 100000;      // 2 s of the 100 MHz wall clock
+    OnchipSync ocS{}; unsigned ocSeq = 1; size_t ocInboxBytes = 0, ocSlotBytes = 0, ocGroupBytes = 0;
+    void ocInit() {
+        if (!ocVariants.empty()) return;
+        if constexpr (sizeof(T) == 4) {
+            ocVariants.push_back({4, false, false, (const void*)iw_onchipPcg<T, 4, false, false>, OcLds<T>::total(4, false), 0});
+            ocVariants.push_back({8, false, false, (const void*)iw_onchipPcg<T, 8, false, false>, OcLds<T>::total(8, false), 0});
+            ocVariants.push_back({16, true, true, (const void*)iw_onchipPcg<T, 16, true, true>, OcLds<T>::total(16, true), 0});
+        } else {
+            ocVariants.push_back({4, false, false, (const void*)iw_onchipPcg<T, 4, false, false>, OcLds<T>::total(4, false), 0});
+            ocVariants.push_back({8, true, true, (const void*)iw_onchipPcg<T, 8, true, true>, OcLds<T>::total(8, true), 0});
+        }
+        for (auto& v : ocVariants) {
+            HIP_CHECK(hipFuncSetAttribute(v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v.occ, v.fn, kOcBlock, v.lds) != hipSuccess) v.occ = 0;
+            v.occ = std::min(v.occ, 1);      // one workgroup per CU: the co-residency the in-kernel waits rely on does not depend on how the dispatcher packs CUs
+        }
+    }
+    bool pcgSolveOnChip(const T* r0, const T* p0, T* delta, int L, double* traceDev, LaunchCtx& ctx) override {
+        if (!ocEnabled || ocFailed || this->slab.active || !marchKernels || L <= 0) return false;
+        resolveLattice();
+        if (initPending && initHint && !lattice) { launchJtf(false, ctx); initHint = false; }      // PCGInit1 ran on the previous bind's verdict (see pcgIteration)
+        if (!lattice) return false;
+        ocInit();
+        const int tX = divUp(A.W, kOcTileW);
+        const OcVariant* V = nullptr; int tY = 0;
+        for (const auto& v : ocVariants) {
+            if (ocForceRows && v.rows != ocForceRows) continue;
+            tY = divUp(A.H, kOcWavesY * v.rows);
+            if (v.occ >= 1 && (long)tX * tY <= std::min(cus * v.occ, kOcMaxTiles)) { V = &v; break; }
+        }
+        if (!V) return false;
+        const int G = tX * tY;
+        if (!ocS.slots) {      // sized for this plan's image once (the dimensions of a plan are fixed); zero = no tag
+            const int maxRows = ocVariants.front().rows;
+            const int gMax = std::min(kOcMaxTiles, tX * divUp(A.H, kOcWavesY * maxRows));
+            ocS.stride = 3L * kOcTileW * (long)(sizeof(T) / 4);
+            ocSlotBytes = sizeof(oc_u64) * 2 * (size_t)gMax * 8; ocGroupBytes = sizeof(oc_u64) * 2 * (size_t)divUp(gMax, kOcGroup) * 8;
+            ocInboxBytes = sizeof(oc_u64) * 2 * (size_t)gMax * 4 * (size_t)ocS.stride;
+            HIP_CHECK(hipMalloc((void**)&ocS.slots, ocSlotBytes)); HIP_CHECK(hipMalloc((void**)&ocS.groupSlots, ocGroupBytes)); HIP_CHECK(hipMalloc((void**)&ocS.inbox, ocInboxBytes));
+            HIP_CHECK(hipMalloc((void**)&ocS.bad, sizeof(int))); HIP_CHECK(hipHostMalloc((void**)&ocS.hostErr, 64)); *ocS.hostErr = 0;
+            HIP_CHECK(hipMemsetAsync(ocS.bad, 0, sizeof(int), ctx.stream));
+            ocSeq = 0xE0000001u;      // forces the clearing below
+        }
+        if (ocSeq > 0xE0000000u || ocSeq + (unsigned)L > 0xE0000000u) {      // tags never repeat: start over on cleared buffers long before the counter wraps
+            HIP_CHECK(hipMemsetAsync(ocS.slots, 0, ocSlotBytes, ctx.stream)); HIP_CHECK(hipMemsetAsync(ocS.groupSlots, 0, ocGroupBytes, ctx.stream));
+            HIP_CHECK(hipMemsetAsync(ocS.inbox, 0, ocInboxBytes, ctx.stream));
+            ocSeq = 2;
+        }
+        OnchipArgs<T> K{A.W, A.H, tX, tY, G, r0, p0, A.Angle, A.flags, delta, A.w_fit, A.w_reg, L, ocSeq, G <= ocFlatMax ? 1 : 0, ocS, traceDev, ocTimeoutTicks, ocFailAt};
+        ocSeq += (unsigned)L;
+        {
+            ScopedKernel k(ctx, "PCGSolveOnChip");
+            void* kargs[] = {(void*)&K};
+            HIP_CHECK(hipLaunchKernel(V->fn, dim3(G), dim3(kOcBlock), kargs, V->lds, ctx.stream));
+        }
+        {
+            ScopedKernel k(ctx, "PCGLinearUpdate");
+            const long N = (long)A.W * A.H;
+            iw_applyDelta<T><<<flatGrid(N), kBlock, 0, ctx.stream>>>(const_cast<T*>(A.Offset), const_cast<T*>(A.Angle), delta, N, ocS.bad, ocS.hostErr);
+        }
+        ocLaunched = true;
+        return true;
+    }
+    bool onChipFailed() override {
+        if (!ocLaunched) return false;
+        ocLaunched = false;
+        if (__atomic_load_n(ocS.hostErr, __ATOMIC_ACQUIRE) == 0) return false;
+        ocFailed = true;
         return true;
     }
     void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {

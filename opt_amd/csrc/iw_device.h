@@ -1,0 +1,83 @@
+// Device primitives of the image_warping kernel sets (energy_image_warping.hip: the streaming kernels; iw_onchip.h: the on-chip linear solve).
+// Energy: reference examples/image_warping/image_warping.t:1-23; derivation in the header of energy_image_warping.hip.
+#pragma once
+#include "common.h"
+#include <cstdint>
+
+namespace optamd {
+namespace {
+
+template <class T> struct V2 { T x, y; };
+
+// flag byte per pixel (iw_flags / iw_bindMarch): bit0 pixel exists and Mask == 0; bit1 fit constraint valid; bits 2-4 number of active 4-neighbours
+constexpr uint8_t kActive = 1, kFit = 2;
+constexpr int kCountShift = 2;       // bits 2..4: number of active 4-neighbours (0..4) of an active pixel
+
+template <class T>
+struct Q {            // one pixel of a row held in registers
+    T ox, oy, a;      // the vector (p_{k-1} or p_k)
+    T c, s;           // cos/sin of the pixel's angle
+    T ux, uy;         // UrShape (dead on a unit lattice)
+    T on;             // 1 if the pixel exists and is not excluded, else 0
+    T fw;             // w_fit^2 if its fit residual is on, else 0
+};
+// the two residuals shared by centre c and its neighbour n in direction (DX, DY) (see iw_pair)
+template <int DX, int DY, bool LATTICE, class T>
+__device__ __forceinline__ void iw_pairQ(const Q<T>& c, const Q<T>& n, T& ax, T& ay, T& aa) {
+    T Dcx, Dcy, Dnx, Dny;
+    if (LATTICE) {       // U_c - U_n = -(DX, DY)
+        Dcx = DX ? T(DX) * c.s : T(DY) * c.c;   Dcy = DX ? T(-DX) * c.c : T(DY) * c.s;
+        Dnx = DX ? T(-DX) * n.s : T(-DY) * n.c; Dny = DX ? T(DX) * n.c : T(-DY) * n.s;
+    } else {
+        const T ux = c.ux - n.ux, uy = c.uy - n.uy;
+        Dcx = -c.s * ux - c.c * uy; Dcy = c.c * ux - c.s * uy;
+        Dnx = n.s * ux + n.c * uy;  Dny = -n.c * ux + n.s * uy;
+    }
+    const T dx = c.ox - n.ox, dy = c.oy - n.oy;
+    const T jcx = dx - Dcx * c.a, jcy = dy - Dcy * c.a;
+    const T jnx = -dx - Dnx * n.a, jny = -dy - Dny * n.a;
+    ax += n.on * (jcx - jnx); ay += n.on * (jcy - jny);
+    aa -= n.on * (Dcx * jcx + Dcy * jcy);
+}
+// ---- each pair of residuals is formed ONCE (round 3) -----------------------------------------------------------------------------------------------
+// iw_pairQ evaluates, for centre c and neighbour n, the residual centred at c towards n and the one centred at n towards c -- and the pixel n, when it is the
+// centre, evaluates the same two residuals again from its side: jc' = jn, jn' = jc, D_{n,-d} = Dn bit for bit (a - b = -(b - a) and a product keeps its value
+// when both factors change sign).  So the pair is formed once, by the end that comes first in lane / sweep order, which also leaves what the other end needs:
+//   jc' - jn' = -(jc - jn)   and   D_{n,-d} . jc' = Dn . jn.
+// The right-hand pair of lane x is the left-hand pair of lane x + 1 (three DPP moves instead of the neighbour's three vector fields and 13 VALU instructions); the
+// pair towards the next row of the march is the pair towards the previous row one trip later (three registers per stencil evaluation).  Accumulation order and
+// every accumulated value are those of iw_pairQ: the result is the same bits, ~34 of ~250 VALU instructions per pixel-row less -- which pays where the kernel is
+// issue-bound (2048^2, slabs: profiles/r03l_iteration_kernel_sq_counters.md), not at 4096^2.
+#ifndef IW_SHARE_PAIRS
+#define IW_SHARE_PAIRS 1
+#endif
+template <class T> struct PairOut { T dx, dy, tn; };      // (jc - jn).x, (jc - jn).y, Dn . jn
+template <int DX, int DY, bool LATTICE, class T>
+__device__ __forceinline__ PairOut<T> iw_pairFull(const Q<T>& c, const Q<T>& n, T& ax, T& ay, T& aa) {
+    T Dcx, Dcy, Dnx, Dny;
+    if (LATTICE) {       // U_c - U_n = -(DX, DY)
+        Dcx = DX ? T(DX) * c.s : T(DY) * c.c;   Dcy = DX ? T(-DX) * c.c : T(DY) * c.s;
+        Dnx = DX ? T(-DX) * n.s : T(-DY) * n.c; Dny = DX ? T(DX) * n.c : T(-DY) * n.s;
+    } else {
+        const T ux = c.ux - n.ux, uy = c.uy - n.uy;
+        Dcx = -c.s * ux - c.c * uy; Dcy = c.c * ux - c.s * uy;
+        Dnx = n.s * ux + n.c * uy;  Dny = -n.c * ux + n.s * uy;
+    }
+    const T dx = c.ox - n.ox, dy = c.oy - n.oy;
+    const T jcx = dx - Dcx * c.a, jcy = dy - Dcy * c.a;
+    const T jnx = -dx - Dnx * n.a, jny = -dy - Dny * n.a;
+    PairOut<T> o;
+    o.dx = jcx - jnx; o.dy = jcy - jny;
+    o.tn = Dnx * jnx + Dny * jny;
+    ax += n.on * o.dx; ay += n.on * o.dy;
+    aa -= n.on * (Dcx * jcx + Dcy * jcy);
+    return o;
+}
+// the same pair seen from its far end: `o` is what the neighbour's evaluation left, nOn that neighbour's activity
+template <class T>
+__device__ __forceinline__ void iw_pairInherited(const PairOut<T>& o, T nOn, T& ax, T& ay, T& aa) {
+    ax -= nOn * o.dx; ay -= nOn * o.dy;
+    aa -= nOn * o.tn;
+}
+}  // namespace
+}  // namespace optamd

@@ -399,11 +399,13 @@ struct PcgSolver : SolverBase {
         if (redMH.partials) (void)hipHostFree(redMH.partials);
         if (redQR.partials) (void)hipHostFree(redQR.partials);
         if (stampFlag) (void)hipHostFree(stampFlag);
+        if (onChipTrace) (void)hipFree(onChipTrace);
         if (redCH.partials) (void)hipHostFree(redCH.partials);
         if (hostBufQ) { (void)hipHostFree(hostBufQ); (void)hipEventDestroy(qEvent); }
         (void)hipStreamDestroy(stream);
     }
 
+    bool onChipOk = true, usedOnChip = false; double* onChipTrace = nullptr; int onChipTraceCap = 0;      // EnergyOps::pcgSolveOnChip
     // ---- reductions ---------------------------------------------------------------------------------
     // Host value of a reduction (blocking D2H like the reference's computeCost / fetchQ, solver.t:790-814)
     double hostSum(const Reduction& R) {
@@ -574,6 +576,30 @@ struct PcgSolver : SolverBase {
 
     // ---- PCG loop as one kernel per iteration (energy.h PcgIterArgs); returns false if the energy has no such kernel ----
     bool runSingleKernelLoop(const T* preArg) {
+        // The whole linear solve as one persistent launch with the loop state on chip, if the kernel set has one and the problem fits (iw_onchip.h);
+        // it ends with PCGLinearUpdate.  A traced solve gets its per-iteration scalars from the kernel (beta numerator by expansion, as below).
+        if (!distributed && preArg && onChipOk && sp.lIterations > 0) {
+            double* tr = nullptr;
+            if (traceEnabled) {
+                if (onChipTraceCap < sp.lIterations) { if (onChipTrace) HIP_CHECK(hipFree(onChipTrace)); onChipTraceCap = sp.lIterations; HIP_CHECK(hipMalloc((void**)&onChipTrace, sizeof(double) * 4 * onChipTraceCap)); }
+                tr = onChipTrace;
+            }
+            if (E->pcgSolveOnChip(r, p, delta, sp.lIterations, tr, ctx)) {
+                usedOnChip = true; unknownsUpdated = true;
+                if (traceEnabled) {
+                    std::vector<double> h(4 * (size_t)sp.lIterations);
+                    HIP_CHECK(hipMemcpyAsync(h.data(), onChipTrace, sizeof(double) * h.size(), hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipStreamSynchronize(stream));
+                    for (int k = 0; k < sp.lIterations; ++k) {
+                        const double aNum = h[4 * k], aDen = h[4 * k + 1], s2 = h[4 * k + 2], s3 = h[4 * k + 3];
+                        const T al = ((T)aDen > T(0)) ? (T)aNum / (T)aDen : T(0);
+                        const double bNum = std::fmax(aNum - 2.0 * (double)al * s2 + (double)al * (double)al * s3, 0.0);
+                        trace.insert(trace.end(), {(double)sp.nIter, (double)k, aNum, aDen, bNum, 0.0});
+                    }
+                }
+                return true;
+            }
+        }
         Reduction prev[4] = {redC, Reduction{}, Reduction{}, Reduction{}};   // alphaNum_0 = sum r.p from PCGInit1
         if (distributed) {   // ghost rows of r_0, M and p_0 (written as 0 by evalJTF / PCGInit1_Finish) come from the slab neighbours once
             exchangeVector(r); exchangeVector(p); if (preArg) exchangeVector(preconditioner);
@@ -947,6 +973,18 @@ struct PcgSolver : SolverBase {
             newCost = computeCost();
         }
 
+        if (usedOnChip) {      // (the stream has drained: the cost was read)
+            usedOnChip = false;
+            if (E->onChipFailed()) {
+                fprintf(stderr, "Opt(amd): a wait inside the on-chip PCG kernel timed out (its workgroups were not co-resident: is the GPU shared?); the unknowns were left untouched, "
+                                "this linear solve is redone with the streaming kernels and the plan stays on them\n");
+                onChipOk = false; unknownsUpdated = false;
+                if (!runSingleKernelLoop(preArg)) { fprintf(stderr, "Opt(amd): the streaming loop refused the redo\n"); exit(1); }
+                if (!unknownsUpdated) imageOp(0);
+                E->precompute(ctx);
+                newCost = computeCost();
+            }
+        }
         if (lm) {   // solver.t:1119-1157
             T cost_change = prevCost - newCost;
             T relative_decrease = cost_change / model_cost_change;

@@ -28,6 +28,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _streaming_kernels_under_test(monkeypatch):
+    """These tests exercise the streaming (one launch per PCG iteration) kernels; small unit-lattice images would otherwise take the on-chip
+    linear solve (iw_onchip.h, tests/test_onchip_gpu.py)."""
+    monkeypatch.setenv("OPT_AMD_ONCHIP", "0")
+
 FLOOR = {"float": 1e-5, "double": 1e-12}      # the contract: below it nothing needs explaining
 
 

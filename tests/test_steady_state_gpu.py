@@ -22,6 +22,13 @@ from helpers import device_unknowns, flat_unknowns, hip_solver, oracle_solver, r
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _streaming_kernels_under_test(monkeypatch):
+    """These tests exercise the streaming (one launch per PCG iteration) kernels; small unit-lattice images would otherwise take the on-chip
+    linear solve (iw_onchip.h, tests/test_onchip_gpu.py)."""
+    monkeypatch.setenv("OPT_AMD_ONCHIP", "0")
+
 THREADS = max(1, min(os.cpu_count() or 1, 64))
 HERE = os.path.dirname(os.path.abspath(__file__))
 
