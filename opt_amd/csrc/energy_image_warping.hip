@@ -1715,7 +1715,7 @@ struct ImageWarpingOps : EnergyOps<T> {
     struct OcVariant { int rows; bool apLds, deltaGlb; const void* fn; size_t lds; int occ; };
     std::vector<OcVariant> ocVariants;
     bool ocEnabled = true, ocFailed = false, ocLaunched = false;
-    int ocForceRows = 0, ocFlatMax = 32, ocFailAt = -1; long long ocTimeoutTicks = 2000LL * 100000;      // 2 s of the 100 MHz wall clock
+    int ocForceRows = 0, ocFlatMax = 32, ocFailAt = -1; long long* ocProf = nullptr; long long ocTimeoutTicks = 2000LL * 100000;      // 2 s of the 100 MHz wall clock
     OnchipSync ocS{}; unsigned ocSeq = 1; size_t ocInboxBytes = 0, ocSlotBytes = 0, ocGroupBytes = 0;
     void ocInit() {
         if (!ocVariants.empty()) return;
@@ -1758,13 +1758,16 @@ struct ImageWarpingOps : EnergyOps<T> {
             HIP_CHECK(hipMalloc((void**)&ocS.bad, sizeof(int))); HIP_CHECK(hipHostMalloc((void**)&ocS.hostErr, 64)); *ocS.hostErr = 0;
             HIP_CHECK(hipMemsetAsync(ocS.bad, 0, sizeof(int), ctx.stream));
             ocSeq = 0xE0000001u;      // forces the clearing below
+#if OC_PROFILE
+            if (getenv("OPT_AMD_ONCHIP_PROFILE")) { HIP_CHECK(hipMalloc((void**)&ocProf, sizeof(long long) * 8 * kOcMaxTiles)); }
+#endif
         }
         if (ocSeq > 0xE0000000u || ocSeq + (unsigned)L > 0xE0000000u) {      // tags never repeat: start over on cleared buffers long before the counter wraps
             HIP_CHECK(hipMemsetAsync(ocS.slots, 0, ocSlotBytes, ctx.stream)); HIP_CHECK(hipMemsetAsync(ocS.groupSlots, 0, ocGroupBytes, ctx.stream));
             HIP_CHECK(hipMemsetAsync(ocS.inbox, 0, ocInboxBytes, ctx.stream));
             ocSeq = 2;
         }
-        OnchipArgs<T> K{A.W, A.H, tX, tY, G, r0, p0, A.Angle, A.flags, delta, A.w_fit, A.w_reg, L, ocSeq, G <= ocFlatMax ? 1 : 0, ocS, traceDev, ocTimeoutTicks, ocFailAt};
+        OnchipArgs<T> K{A.W, A.H, tX, tY, G, r0, p0, A.Angle, A.flags, delta, A.w_fit, A.w_reg, L, ocSeq, G <= ocFlatMax ? 1 : 0, ocS, traceDev, ocTimeoutTicks, ocProf, ocFailAt};
         ocSeq += (unsigned)L;
         {
             ScopedKernel k(ctx, "PCGSolveOnChip");
@@ -1777,6 +1780,21 @@ struct ImageWarpingOps : EnergyOps<T> {
             iw_applyDelta<T><<<flatGrid(N), kBlock, 0, ctx.stream>>>(const_cast<T*>(A.Offset), const_cast<T*>(A.Angle), delta, N, ocS.bad, ocS.hostErr);
         }
         ocLaunched = true;
+#if OC_PROFILE
+        if (ocProf) {      // development builds: where an iteration's time goes, mean and maximum over the workgroups
+            std::vector<long long> h((size_t)G * 8);
+            HIP_CHECK(hipStreamSynchronize(ctx.stream));
+            HIP_CHECK(hipMemcpy(h.data(), ocProf, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            const char* names[6] = {"publish+barrier", "halo wait", "stencil", "reduce+post", "sum wait", "update"};
+            fprintf(stderr, "on-chip profile %dx%d rows=%d G=%d L=%d (us per iteration, mean / max over workgroups):", A.W, A.H, V->rows, G, L);
+            for (int ph = 0; ph < 6; ++ph) {
+                double mean = 0, mx = 0;
+                for (int w = 0; w < G; ++w) { const double v = h[(size_t)w * 8 + ph] * 0.01 / L; mean += v / G; mx = std::max(mx, v); }
+                fprintf(stderr, "  %s %.2f / %.2f", names[ph], mean, mx);
+            }
+            fprintf(stderr, "\n");
+        }
+#endif
         return true;
     }
     bool onChipFailed() override {

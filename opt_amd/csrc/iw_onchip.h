@@ -51,6 +51,7 @@ struct OnchipArgs {
     OnchipSync S;
     double* trace;                      // [L][4] = alphaNum, alphaDen, s2, s3 of every iteration (written by workgroup 0), or nullptr
     long long timeoutTicks;
+    long long* prof;                    // OC_PROFILE builds: [G][8] ticks per phase, else nullptr
     int failAt;                         // test hook (OPT_AMD_ONCHIP_FAIL_AT): workgroup 0 raises `bad` in this iteration as a timed-out wait would; -1: never
 };
 
@@ -112,6 +113,17 @@ template <class T> struct OcLds {
     static constexpr size_t tail() { return (4 * kOcWaves + kOcGroup * 4 + 8) * sizeof(double) + (kOcMaxTiles * 8 + kOcGroup * 8) * sizeof(unsigned) + 16 * sizeof(T) + 16; }
     static constexpr size_t total(int rows, bool apLds) { return ap(rows, apLds) + rowHalo() + 2 * side(rows) + stage(rows) + tail(); }
 };
+
+// Development builds (opt_amd/build.py build_variant with OC_PROFILE=1; tools/onchip_bench.py --profile): thread 0 of every workgroup accumulates the wall-clock
+// ticks (100 MHz) it spends in each phase of an iteration and leaves them in K.prof[workgroup][8].
+#ifndef OC_PROFILE
+#define OC_PROFILE 0
+#endif
+#if OC_PROFILE
+#define OC_MARK(i) do { if (tid == 0) { const long long t_ = wall_clock64(); ocProf[i] += t_ - ocPrev; ocPrev = t_; } } while (0)
+#else
+#define OC_MARK(i) do { } while (0)
+#endif
 
 template <class T, int ROWS, bool AP_LDS, bool DELTA_GLB>
 __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
@@ -200,10 +212,21 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
     };
     auto haloQ = [&](const T (&h)[3], T c, T s, T on) { Q<T> q{}; q.ox = h[0]; q.oy = h[1]; q.a = h[2]; q.c = c; q.s = s; q.on = on; return q; };
     const int sideSel = lane == kWave - 1 ? 1 : 0;       // lane 63 looks right, lane 0 (and, unused, everyone else) left
+    // Per-lane base addresses, so that every row's access is base + a compile-time offset (the DS instructions' immediate): with the row inside the index
+    // expression the compiler keeps one address register per row and array -- 32 of them, spilled and reloaded at L2 latency in every row of the stencil.
+    const OcH4<T>* const mySideP = sideP + (wave * ROWS) * 2 + sideSel;
+    const OcH4<T>* const mySideC = sideC + (wave * ROWS) * 2 + sideSel;
+    T* const myAp = apL + tid;
     const int nGroups = (K.G + kOcGroup - 1) / kOcGroup;
     const bool hasUp = ty > 0, hasDown = ty + 1 < K.tilesY, hasLeft = tx > 0, hasRight = tx + 1 < K.tilesX;
     bool failed = false;
 
+#if OC_PROFILE
+    __shared__ long long ocProf[8];
+    long long ocPrev = wall_clock64();
+    if (tid < 8) ocProf[tid] = 0;
+    __syncthreads();
+#endif
     int pix0 = yBase * K.W + x;      // index of the lane's first pixel (may lie outside the image: only used where the pixel exists)
     for (int k = 0; k < K.L; ++k) {
         // Everything derived from the flag bytes and the pixel index (activity and fit multipliers, table addresses, row addresses, bounds predicates) is
@@ -218,43 +241,47 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
         oc_u64* const boxPar = K.S.inbox + (long)par * K.G * 4 * K.S.stride;
         auto box = [&](int tile, int sd) { return boxPar + ((long)tile * 4 + sd) * K.S.stride; };      // sd: 0 from above, 1 from below, 2 from the left, 3 from the right
 
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
         // ---- hand the edges of p_k to the neighbours: LDS inside the workgroup, tagged words between workgroups --------------------------------
-        if (wy > 0) { T* h = rowHalo + ((wave - kOcWavesX) * 2 + 1) * 3 * kWave; h[lane] = p[0][0]; h[kWave + lane] = p[0][1]; h[2 * kWave + lane] = p[0][2]; }
-        else if (hasUp) { oc_u64* d = box(g - K.tilesX, 1); ocSend(d, wx * kWave + lane, p[0][0], tag); ocSend(d, kOcTileW + wx * kWave + lane, p[0][1], tag); ocSend(d, 2 * kOcTileW + wx * kWave + lane, p[0][2], tag); }
-        if (wy + 1 < kOcWavesY) { T* h = rowHalo + ((wave + kOcWavesX) * 2 + 0) * 3 * kWave; h[lane] = p[ROWS - 1][0]; h[kWave + lane] = p[ROWS - 1][1]; h[2 * kWave + lane] = p[ROWS - 1][2]; }
-        else if (hasDown) { oc_u64* d = box(g + K.tilesX, 0); ocSend(d, wx * kWave + lane, p[ROWS - 1][0], tag); ocSend(d, kOcTileW + wx * kWave + lane, p[ROWS - 1][1], tag); ocSend(d, 2 * kOcTileW + wx * kWave + lane, p[ROWS - 1][2], tag); }
-        if (lane == 0) {
+        if (wy > 0) { T* h = rowHalo + ((wave - kOcWavesX) * 2 + 1) * 3 * kWave; h[ln] = p[0][0]; h[kWave + ln] = p[0][1]; h[2 * kWave + ln] = p[0][2]; }
+        else if (hasUp) { oc_u64* d = box(g - K.tilesX, 1); ocSend(d, wx * kWave + ln, p[0][0], tag); ocSend(d, kOcTileW + wx * kWave + ln, p[0][1], tag); ocSend(d, 2 * kOcTileW + wx * kWave + ln, p[0][2], tag); }
+        if (wy + 1 < kOcWavesY) { T* h = rowHalo + ((wave + kOcWavesX) * 2 + 0) * 3 * kWave; h[ln] = p[ROWS - 1][0]; h[kWave + ln] = p[ROWS - 1][1]; h[2 * kWave + ln] = p[ROWS - 1][2]; }
+        else if (hasDown) { oc_u64* d = box(g + K.tilesX, 0); ocSend(d, wx * kWave + ln, p[ROWS - 1][0], tag); ocSend(d, kOcTileW + wx * kWave + ln, p[ROWS - 1][1], tag); ocSend(d, 2 * kOcTileW + wx * kWave + ln, p[ROWS - 1][2], tag); }
+        if (ln == 0) {
             if (wx > 0) {
 #pragma unroll
-                for (int j = 0; j < ROWS; ++j) { OcH4<T> v; v.v[0] = p[j][0]; v.v[1] = p[j][1]; v.v[2] = p[j][2]; v.v[3] = 0; sideP[((wave - 1) * ROWS + j) * 2 + 1] = v; }
+                for (int j = 0; j < ROWS; ++j) { OcH4<T> v; v.v[0] = p[j][0]; v.v[1] = p[j][1]; v.v[2] = p[j][2]; v.v[3] = 0; (sideP + ((wave - 1) * ROWS) * 2 + 1)[j * 2] = v; }
             } else if (hasLeft) {
 #pragma unroll
-                for (int j = 0; j < ROWS; ++j) { stage[(wave * ROWS + j) * 3 + 0] = p[j][0]; stage[(wave * ROWS + j) * 3 + 1] = p[j][1]; stage[(wave * ROWS + j) * 3 + 2] = p[j][2]; }
+                for (int j = 0; j < ROWS; ++j) { T* st = stage + wave * ROWS * 3; st[j * 3 + 0] = p[j][0]; st[j * 3 + 1] = p[j][1]; st[j * 3 + 2] = p[j][2]; }
             }
         }
-        if (lane == kWave - 1) {
+        if (ln == kWave - 1) {
             if (wx + 1 < kOcWavesX) {
 #pragma unroll
-                for (int j = 0; j < ROWS; ++j) { OcH4<T> v; v.v[0] = p[j][0]; v.v[1] = p[j][1]; v.v[2] = p[j][2]; v.v[3] = 0; sideP[((wave + 1) * ROWS + j) * 2 + 0] = v; }
+                for (int j = 0; j < ROWS; ++j) { OcH4<T> v; v.v[0] = p[j][0]; v.v[1] = p[j][1]; v.v[2] = p[j][2]; v.v[3] = 0; (sideP + ((wave + 1) * ROWS) * 2)[j * 2] = v; }
             } else if (hasRight) {
 #pragma unroll
-                for (int j = 0; j < ROWS; ++j) { stage[(wave * ROWS + j) * 3 + 0] = p[j][0]; stage[(wave * ROWS + j) * 3 + 1] = p[j][1]; stage[(wave * ROWS + j) * 3 + 2] = p[j][2]; }
+                for (int j = 0; j < ROWS; ++j) { T* st = stage + wave * ROWS * 3; st[j * 3 + 0] = p[j][0]; st[j * 3 + 1] = p[j][1]; st[j * 3 + 2] = p[j][2]; }
             }
         }
-        // a tile-edge wave's column leaves with one lane per scalar (the LDS operations of one wave execute in order: the staged values are there)
-        if (wx == 0 && hasLeft && lane < 3 * ROWS) ocSend(box(g - 1, 3), wy * ROWS * 3 + lane, stage[wave * ROWS * 3 + lane], tag);
-        if (wx == kOcWavesX - 1 && hasRight && lane < 3 * ROWS) ocSend(box(g + 1, 2), wy * ROWS * 3 + lane, stage[wave * ROWS * 3 + lane], tag);
+        // a tile-edge wave's column leaves with one ln per scalar (the LDS operations of one wave execute in order: the staged values are there)
+        if (wx == 0 && hasLeft && ln < 3 * ROWS) ocSend(box(g - 1, 3), wy * ROWS * 3 + ln, stage[wave * ROWS * 3 + ln], tag);
+        if (wx == kOcWavesX - 1 && hasRight && ln < 3 * ROWS) ocSend(box(g + 1, 2), wy * ROWS * 3 + ln, stage[wave * ROWS * 3 + ln], tag);
         __syncthreads();
+        OC_MARK(0);
 
         // ---- collect this wave's halo ----------------------------------------------------------------------------------------------------------
         T ht[3] = {0, 0, 0}, hb[3] = {0, 0, 0};
-        if (wy > 0) { const T* h = rowHalo + (wave * 2 + 0) * 3 * kWave; ht[0] = h[lane]; ht[1] = h[kWave + lane]; ht[2] = h[2 * kWave + lane]; }
-        else if (hasUp) { const oc_u64* s = box(g, 0); ocRecv(s, wx * kWave + lane, tag, bad, to, ht[0]); ocRecv(s, kOcTileW + wx * kWave + lane, tag, bad, to, ht[1]); ocRecv(s, 2 * kOcTileW + wx * kWave + lane, tag, bad, to, ht[2]); }
-        if (wy + 1 < kOcWavesY) { const T* h = rowHalo + (wave * 2 + 1) * 3 * kWave; hb[0] = h[lane]; hb[1] = h[kWave + lane]; hb[2] = h[2 * kWave + lane]; }
-        else if (hasDown) { const oc_u64* s = box(g, 1); ocRecv(s, wx * kWave + lane, tag, bad, to, hb[0]); ocRecv(s, kOcTileW + wx * kWave + lane, tag, bad, to, hb[1]); ocRecv(s, 2 * kOcTileW + wx * kWave + lane, tag, bad, to, hb[2]); }
-        if (wx == 0 && hasLeft && lane < 3 * ROWS) { T v; ocRecv(box(g, 2), wy * ROWS * 3 + lane, tag, bad, to, v); sideP[(wave * ROWS + lane / 3) * 2 + 0].v[lane % 3] = v; }
-        if (wx == kOcWavesX - 1 && hasRight && lane < 3 * ROWS) { T v; ocRecv(box(g, 3), wy * ROWS * 3 + lane, tag, bad, to, v); sideP[(wave * ROWS + lane / 3) * 2 + 1].v[lane % 3] = v; }
+        if (wy > 0) { const T* h = rowHalo + (wave * 2 + 0) * 3 * kWave; ht[0] = h[ln]; ht[1] = h[kWave + ln]; ht[2] = h[2 * kWave + ln]; }
+        else if (hasUp) { const oc_u64* s = box(g, 0); ocRecv(s, wx * kWave + ln, tag, bad, to, ht[0]); ocRecv(s, kOcTileW + wx * kWave + ln, tag, bad, to, ht[1]); ocRecv(s, 2 * kOcTileW + wx * kWave + ln, tag, bad, to, ht[2]); }
+        if (wy + 1 < kOcWavesY) { const T* h = rowHalo + (wave * 2 + 1) * 3 * kWave; hb[0] = h[ln]; hb[1] = h[kWave + ln]; hb[2] = h[2 * kWave + ln]; }
+        else if (hasDown) { const oc_u64* s = box(g, 1); ocRecv(s, wx * kWave + ln, tag, bad, to, hb[0]); ocRecv(s, kOcTileW + wx * kWave + ln, tag, bad, to, hb[1]); ocRecv(s, 2 * kOcTileW + wx * kWave + ln, tag, bad, to, hb[2]); }
+        if (wx == 0 && hasLeft && ln < 3 * ROWS) { T v; ocRecv(box(g, 2), wy * ROWS * 3 + ln, tag, bad, to, v); sideP[(wave * ROWS + ln / 3) * 2 + 0].v[ln % 3] = v; }
+        if (wx == kOcWavesX - 1 && hasRight && ln < 3 * ROWS) { T v; ocRecv(box(g, 3), wy * ROWS * 3 + ln, tag, bad, to, v); sideP[(wave * ROWS + ln / 3) * 2 + 1].v[ln % 3] = v; }
 
+        OC_MARK(1);
         // ---- PCGStep1: A p_k on the lane's pixels, with the four sums ----------------------------------------------------------------------------
         // One row per scheduling region (sched_barrier): left to itself the scheduler interleaves the unrolled rows until the live temporaries fill the
         // register budget and beyond.  The wave-edge halo of row j + 1 is requested before row j's arithmetic.
@@ -263,11 +290,11 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
             Q<T> prevQ = haloQ(ht, tc, ts, ton), curQ = rowQ(0);
             PairOut<T> vert;
             { T t0 = 0, t1 = 0, t2 = 0; vert = iw_pairFull<0, 1, true>(prevQ, curQ, t0, t1, t2); }      // the pair (row above, row 0) that row 0 inherits
-            OcH4<T> spN = sideP[(wave * ROWS + 0) * 2 + sideSel], scN = sideC[(wave * ROWS + 0) * 2 + sideSel];
+            OcH4<T> spN = mySideP[0], scN = mySideC[0];
 #pragma unroll
             for (int j = 0; j < ROWS; ++j) {
                 const OcH4<T> sp = spN, sc = scN;
-                if (j + 1 < ROWS) { spN = sideP[(wave * ROWS + j + 1) * 2 + sideSel]; scN = sideC[(wave * ROWS + j + 1) * 2 + sideSel]; }
+                if (j + 1 < ROWS) { spN = mySideP[(j + 1) * 2]; scN = mySideC[(j + 1) * 2]; }
                 const unsigned f = flagOf(j);
                 const int cnt = (int)((f >> kCountShift) & 7u), io = cnt + ((f & kFit) ? 5 : 0);
                 const T moT = mTab[io], maT = mTab[10 + cnt];
@@ -291,7 +318,7 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
                 T ox = curQ.on * (w2 * ax + curQ.fw * curQ.ox), oy = curQ.on * (w2 * ay + curQ.fw * curQ.oy), oa = curQ.on * (w2 * aa);
                 // (values pinned here: pure arithmetic otherwise sinks out of its scheduling region -- all rows' DPP results then wait, live, for one block of arithmetic at the end)
                 asm volatile("" : "+v"(ox), "+v"(oy), "+v"(oa));
-                if (AP_LDS) { apL[(j * 3 + 0) * kOcBlock + tid] = ox; apL[(j * 3 + 1) * kOcBlock + tid] = oy; apL[(j * 3 + 2) * kOcBlock + tid] = oa; }
+                if (AP_LDS) { myAp[(j * 3 + 0) * kOcBlock] = ox; myAp[(j * 3 + 1) * kOcBlock] = oy; myAp[(j * 3 + 2) * kOcBlock] = oa; }
                 else { ap[AP_LDS ? 0 : j][0] = ox; ap[AP_LDS ? 0 : j][1] = oy; ap[AP_LDS ? 0 : j][2] = oa; }
                 {   // the sums of iw_pcgIter2, term for term: p.Ap from float products, the three expansion sums from exact double products of M, r, A p
                     const double mo = (double)moT, ma = (double)maT;
@@ -312,36 +339,41 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
         // pixel index of the lane's row j, or 0 (a valid address whose value is not used) where the pixel does not exist
         auto rowExists = [&](int j) { return xin && pix0 + j * K.W < (int)N; };      // (x < W: then y < H is the same as pixel index < N)
         auto rowIndex = [&](int j) { return rowExists(j) ? pix0 + j * K.W : 0; };
-        T dN[CH][3];
-        auto loadDelta = [&](int c0, T (&d)[CH][3]) {
+        // With delta in memory (ROWS = 16), ALL of the lane's delta is requested here, before the wait for the sums: the stencil's temporaries are dead, so the
+        // 3 ROWS registers are free, and the reads (L2-resident lines this lane wrote one iteration ago) complete while the grid-wide sum is in flight.
+        T dG[DELTA_GLB ? ROWS : 1][3];
+        if (DELTA_GLB && k > 0) {
 #pragma unroll
-            for (int jj = 0; jj < CH; ++jj) {
-                const int i = rowIndex(c0 + jj);
+            for (int j = 0; j < ROWS; ++j) {
+                const int i = rowIndex(j);
                 const V2<T> dv = ((const V2<T>*)K.delta)[i];
-                d[jj][0] = dv.x; d[jj][1] = dv.y; d[jj][2] = (K.delta + 2 * N)[i];
+                dG[DELTA_GLB ? j : 0][0] = dv.x; dG[DELTA_GLB ? j : 0][1] = dv.y; dG[DELTA_GLB ? j : 0][2] = (K.delta + 2 * N)[i];
             }
-        };
-        if (DELTA_GLB && k > 0) loadDelta(0, dN);
+        }
         __builtin_amdgcn_sched_barrier(0);
+        OC_MARK(2);
 
         // ---- the grid-wide sums -------------------------------------------------------------------------------------------------------------------
         {
+            int tq = tid;      // (opaque per iteration, like fl / pix0 above: the addresses below are recomputed, not kept in registers across the whole loop)
+            asm volatile("" : "+v"(tq));
             double v4[4] = {accNum, accDen, acc2, acc3};
 #pragma unroll
             for (int q = 0; q < 4; ++q) { v4[q] = waveReduceSum(v4[q]); if (lane == 0) red[q * kOcWaves + wave] = v4[q]; }
             __syncthreads();
             oc_u64* const slotPar = K.S.slots + (long)par * K.G * 8;
-            if (tid < 8) {
+            if (tq < 8) {
                 double s = 0;
-                for (int w = 0; w < kOcWaves; ++w) s += red[(tid >> 1) * kOcWaves + w];
+                for (int w = 0; w < kOcWaves; ++w) s += red[(tq >> 1) * kOcWaves + w];
                 const oc_u64 b = (oc_u64)__double_as_longlong(s);
-                ocStore(slotPar + (long)g * 8 + tid, tag, (tid & 1) ? (unsigned)(b >> 32) : (unsigned)b);
+                ocStore(slotPar + (long)g * 8 + tq, tag, (tq & 1) ? (unsigned)(b >> 32) : (unsigned)b);
             }
+            OC_MARK(3);
             if (K.flat) {      // small grids: every workgroup reads every slot and forms the group totals itself (same order as the tree: same bits)
-                for (int i = tid; i < K.G * 8; i += kOcBlock) W1[i] = ocAwait(slotPar + i, tag, bad, to);
+                for (int i = tq; i < K.G * 8; i += kOcBlock) W1[i] = ocAwait(slotPar + i, tag, bad, to);
                 __syncthreads();
-                if (tid < nGroups * 4) {
-                    const int q = tid & 3, grp = tid >> 2, n = min(kOcGroup, K.G - grp * kOcGroup);
+                if (tq < nGroups * 4) {
+                    const int q = tq & 3, grp = tq >> 2, n = min(kOcGroup, K.G - grp * kOcGroup);
                     double s = 0;
                     for (int m = 0; m < n; ++m) s += ocJoin(W1[(grp * kOcGroup + m) * 8 + 2 * q], W1[(grp * kOcGroup + m) * 8 + 2 * q + 1]);
                     GS[grp * 4 + q] = s;
@@ -351,25 +383,26 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
                 oc_u64* const topPar = K.S.groupSlots + (long)par * nGroups * 8;
                 if ((g % kOcGroup) == 0) {      // the group's first workgroup adds its group's slots and posts the total
                     const int grp = g / kOcGroup, n = min(kOcGroup, K.G - grp * kOcGroup);
-                    if (tid < n * 8) W1[tid] = ocAwait(slotPar + (long)grp * kOcGroup * 8 + tid, tag, bad, to);
+                    if (tq < n * 8) W1[tq] = ocAwait(slotPar + (long)grp * kOcGroup * 8 + tq, tag, bad, to);
                     __syncthreads();
-                    if (tid < 8) {
-                        const int q = tid >> 1;
+                    if (tq < 8) {
+                        const int q = tq >> 1;
                         double s = 0;
                         for (int m = 0; m < n; ++m) s += ocJoin(W1[m * 8 + 2 * q], W1[m * 8 + 2 * q + 1]);
                         const oc_u64 b = (oc_u64)__double_as_longlong(s);
-                        ocStore(topPar + (long)grp * 8 + tid, tag, (tid & 1) ? (unsigned)(b >> 32) : (unsigned)b);
+                        ocStore(topPar + (long)grp * 8 + tq, tag, (tq & 1) ? (unsigned)(b >> 32) : (unsigned)b);
                     }
                 }
-                if (tid < nGroups * 8) W2[tid] = ocAwait(topPar + tid, tag, bad, to);
+                if (tq < nGroups * 8) W2[tq] = ocAwait(topPar + tq, tag, bad, to);
                 __syncthreads();
-                if (tid < nGroups * 4) { const int q = tid & 3, grp = tid >> 2; GS[grp * 4 + q] = ocJoin(W2[grp * 8 + 2 * q], W2[grp * 8 + 2 * q + 1]); }
+                if (tq < nGroups * 4) { const int q = tq & 3, grp = tq >> 2; GS[grp * 4 + q] = ocJoin(W2[grp * 8 + 2 * q], W2[grp * 8 + 2 * q + 1]); }
                 __syncthreads();
             }
-            if (tid < 4) { double s = 0; for (int grp = 0; grp < nGroups; ++grp) s += GS[grp * 4 + tid]; TOT[tid] = s; }
-            if (tid == 0) reinterpret_cast<int*>(TOT + 4)[0] = __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tq < 4) { double s = 0; for (int grp = 0; grp < nGroups; ++grp) s += GS[grp * 4 + tq]; TOT[tq] = s; }
+            if (tq == 0) reinterpret_cast<int*>(TOT + 4)[0] = __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
         }
+        OC_MARK(4);
         const double aNumD = TOT[0], aDenD = TOT[1], s2 = TOT[2], s3 = TOT[3];
         if (reinterpret_cast<const int*>(TOT + 4)[0]) { failed = true; break; }      // uniform over the workgroup: a wait timed out somewhere
         if (K.trace && g == 0 && tid == 0) { K.trace[4 * k] = aNumD; K.trace[4 * k + 1] = aDenD; K.trace[4 * k + 2] = s2; K.trace[4 * k + 3] = s3; }
@@ -387,15 +420,14 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
             T dC[CH][3];
 #pragma unroll
             for (int jj = 0; jj < CH; ++jj) {
-                if (DELTA_GLB) { dC[jj][0] = (k == 0) ? T(0) : dN[jj][0]; dC[jj][1] = (k == 0) ? T(0) : dN[jj][1]; dC[jj][2] = (k == 0) ? T(0) : dN[jj][2]; }
+                if (DELTA_GLB) { dC[jj][0] = (k == 0) ? T(0) : dG[DELTA_GLB ? c0 + jj : 0][0]; dC[jj][1] = (k == 0) ? T(0) : dG[DELTA_GLB ? c0 + jj : 0][1]; dC[jj][2] = (k == 0) ? T(0) : dG[DELTA_GLB ? c0 + jj : 0][2]; }
                 else { dC[jj][0] = dl[DELTA_GLB ? 0 : c0 + jj][0]; dC[jj][1] = dl[DELTA_GLB ? 0 : c0 + jj][1]; dC[jj][2] = dl[DELTA_GLB ? 0 : c0 + jj][2]; }
             }
-            if (DELTA_GLB && k > 0 && c0 + CH < ROWS) loadDelta(c0 + CH, dN);
             T aC[CH][3];
 #pragma unroll
             for (int jj = 0; jj < CH; ++jj)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) aC[jj][c] = AP_LDS ? apL[((c0 + jj) * 3 + c) * kOcBlock + tid] : ap[AP_LDS ? 0 : c0 + jj][c];
+                for (int c = 0; c < 3; ++c) aC[jj][c] = AP_LDS ? myAp[((c0 + jj) * 3 + c) * kOcBlock] : ap[AP_LDS ? 0 : c0 + jj][c];
 #pragma unroll
             for (int jj = 0; jj < CH; ++jj) {
                 const int j = c0 + jj;
@@ -419,7 +451,12 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        OC_MARK(5);
     }
+#if OC_PROFILE
+    __syncthreads();
+    if (tid < 8 && K.prof) K.prof[(long)g * 8 + tid] = ocProf[tid];
+#endif
     if (!DELTA_GLB && !failed) {
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
