@@ -1715,7 +1715,7 @@ struct ImageWarpingOps : EnergyOps<T> {
     struct OcVariant { int rows; bool apLds, deltaGlb; const void* fn; size_t lds; int occ; };
     std::vector<OcVariant> ocVariants;
     bool ocEnabled = true, ocFailed = false, ocLaunched = false;
-    int ocForceRows = 0, ocFlatMax = 32, ocFailAt = -1; long long* ocProf = nullptr; long long ocTimeoutTicks = 2000LL * 100000;      // 2 s of the 100 MHz wall clock
+    int ocForceRows = 0, ocFlatMax = 256, ocFailAt = -1; long long* ocProf = nullptr; long long ocTimeoutTicks = 2000LL * 100000;      // 2 s of the 100 MHz wall clock
     OnchipSync ocS{}; unsigned ocSeq = 1; size_t ocInboxBytes = 0, ocSlotBytes = 0, ocGroupBytes = 0;
     void ocInit() {
         if (!ocVariants.empty()) return;
@@ -1724,8 +1724,7 @@ struct ImageWarpingOps : EnergyOps<T> {
             ocVariants.push_back({8, false, false, (const void*)iw_onchipPcg<T, 8, false, false>, OcLds<T>::total(8, false), 0});
             ocVariants.push_back({16, true, true, (const void*)iw_onchipPcg<T, 16, true, true>, OcLds<T>::total(16, true), 0});
         } else {
-            ocVariants.push_back({4, false, false, (const void*)iw_onchipPcg<T, 4, false, false>, OcLds<T>::total(4, false), 0});
-            ocVariants.push_back({8, true, true, (const void*)iw_onchipPcg<T, 8, true, true>, OcLds<T>::total(8, true), 0});
+            ocVariants.push_back({4, false, false, (const void*)iw_onchipPcg<T, 4, false, false>, OcLds<T>::total(4, false), 0});      // (double: up to 2048 pixels per CU)
         }
         for (auto& v : ocVariants) {
             HIP_CHECK(hipFuncSetAttribute(v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
@@ -1759,7 +1758,7 @@ struct ImageWarpingOps : EnergyOps<T> {
             HIP_CHECK(hipMemsetAsync(ocS.bad, 0, sizeof(int), ctx.stream));
             ocSeq = 0xE0000001u;      // forces the clearing below
 #if OC_PROFILE
-            if (getenv("OPT_AMD_ONCHIP_PROFILE")) { HIP_CHECK(hipMalloc((void**)&ocProf, sizeof(long long) * 8 * kOcMaxTiles)); }
+            if (getenv("OPT_AMD_ONCHIP_PROFILE")) { HIP_CHECK(hipMalloc((void**)&ocProf, sizeof(long long) * kOcWaves * 16 * kOcMaxTiles)); }
 #endif
         }
         if (ocSeq > 0xE0000000u || ocSeq + (unsigned)L > 0xE0000000u) {      // tags never repeat: start over on cleared buffers long before the counter wraps
@@ -1781,18 +1780,25 @@ struct ImageWarpingOps : EnergyOps<T> {
         }
         ocLaunched = true;
 #if OC_PROFILE
-        if (ocProf) {      // development builds: where an iteration's time goes, mean and maximum over the workgroups
-            std::vector<long long> h((size_t)G * 8);
+        if (ocProf) {      // development builds: where an iteration's time goes, per wave of a workgroup, mean over the workgroups
+            std::vector<long long> h((size_t)G * kOcWaves * 16);
             HIP_CHECK(hipStreamSynchronize(ctx.stream));
             HIP_CHECK(hipMemcpy(h.data(), ocProf, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-            const char* names[6] = {"publish+barrier", "halo wait", "stencil", "reduce+post", "sum wait", "update"};
-            fprintf(stderr, "on-chip profile %dx%d rows=%d G=%d L=%d (us per iteration, mean / max over workgroups):", A.W, A.H, V->rows, G, L);
-            for (int ph = 0; ph < 6; ++ph) {
-                double mean = 0, mx = 0;
-                for (int w = 0; w < G; ++w) { const double v = h[(size_t)w * 8 + ph] * 0.01 / L; mean += v / G; mx = std::max(mx, v); }
-                fprintf(stderr, "  %s %.2f / %.2f", names[ph], mean, mx);
+            const char* names[9] = {"stencil", "send", "wave-sums", "barrier", "inbox", "grid-sum", "delta-req", "halo-upd", "update"};
+            fprintf(stderr, "on-chip profile %dx%d rows=%d G=%d L=%d (us per iteration, mean over workgroups; one line per wave)\n   wave", A.W, A.H, V->rows, G, L);
+            for (int ph = 0; ph < 9; ++ph) fprintf(stderr, " %9s", names[ph]);
+            fprintf(stderr, "     total\n");
+            for (int w = 0; w < kOcWaves; ++w) {
+                fprintf(stderr, "   %4d", w);
+                double tot = 0;
+                for (int ph = 0; ph < 9; ++ph) {
+                    double mean = 0;
+                    for (int b = 0; b < G; ++b) mean += h[((size_t)b * kOcWaves + w) * 16 + ph] * 0.01 / L / G;
+                    tot += mean;
+                    fprintf(stderr, " %9.2f", mean);
+                }
+                fprintf(stderr, " %9.2f\n", tot);
             }
-            fprintf(stderr, "\n");
         }
 #endif
         return true;

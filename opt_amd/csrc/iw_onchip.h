@@ -10,10 +10,11 @@
 //   A p             in registers (ROWS <= 8) or LDS (ROWS = 16, 96 KB),
 //   delta           in registers, or -- ROWS = 16 -- in the solver's delta vector, read-modify-written once per iteration (the 3 MB per XCD stay in its L2),
 //   cos / sin, flag byte of every pixel in registers,
-// and synchronises the grid twice per iteration with 8-byte {payload, tag} words (one relaxed agent-scope store each, no fences, no cache write-backs;
+// and synchronises the grid ONCE per iteration with 8-byte {payload, tag} words (one relaxed agent-scope store each, no fences, no cache write-backs;
 // MI355X_MICROARCH.md "handoff-1to1" / "allgather"; measured in tools/microbench_gridsync.hip):
-//   halo   a workgroup's tile is 256 x 2 ROWS pixels (8 waves: 4 across, 2 down).  Wave-edge rows and columns of p_k travel through LDS inside a workgroup
-//          and through per-tile inboxes in global memory between workgroups;
+//   halo   a workgroup's tile is 256 x 2 ROWS pixels (8 waves: 4 across, 2 down).  Every wave keeps p and r of the one-pixel ring around its pixels itself
+//          and receives only the A p of those pixels -- through LDS inside a workgroup, through per-tile inboxes in global memory between workgroups --
+//          posted TOGETHER with the partial sums, so the hand-over rides on the wait for the sums (see the kernel's header);
 //   sum    the four sums of the iteration (alphaDen = p.Ap, alphaNum = sum M r^2, s2 = sum M r.Ap, s3 = sum M Ap^2; beta by expansion as in iw_pcgIter2,
 //          energy.h PcgIterArgs) as a two-level tree: 16 workgroups per group, group totals posted by the group's first workgroup, every workgroup adds the
 //          group totals in group order -- the same bits everywhere, so alpha and beta agree on the whole grid without a broadcast.
@@ -87,6 +88,43 @@ __device__ __forceinline__ void ocRecv(const oc_u64* box, int idx, unsigned tag,
     const unsigned lo = ocAwait(box + 2 * idx, tag, bad, to), hi = ocAwait(box + 2 * idx + 1, tag, bad, to);
     v = __longlong_as_double((long long)(((oc_u64)hi << 32) | lo));
 }
+// Three scalars of one halo pixel at once: all requests are in flight together (one fabric round trip when the words are already there, not three).
+__device__ __forceinline__ void ocRecv3(const oc_u64* box, int i0, int i1, int i2, unsigned tag, int* bad, long long to, float (&v)[3]) {
+    const oc_u64 *p0 = box + i0, *p1 = box + i1, *p2 = box + i2;
+    oc_u64 a = ocLoad(p0), b = ocLoad(p1), c = ocLoad(p2);
+    if ((unsigned)(a >> 32) != tag || (unsigned)(b >> 32) != tag || (unsigned)(c >> 32) != tag) {
+        const long long t0 = wall_clock64();
+        unsigned spins = 0;
+        for (;;) {
+            __builtin_amdgcn_s_sleep(1);
+            a = ocLoad(p0); b = ocLoad(p1); c = ocLoad(p2);
+            if ((unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag && (unsigned)(c >> 32) == tag) break;
+            if ((++spins & 31u) == 0) {
+                if (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if (wall_clock64() - t0 > to) { __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+    }
+    v[0] = __uint_as_float((unsigned)a); v[1] = __uint_as_float((unsigned)b); v[2] = __uint_as_float((unsigned)c);
+}
+__device__ __forceinline__ void ocRecv3(const oc_u64* box, int i0, int i1, int i2, unsigned tag, int* bad, long long to, double (&v)[3]) {
+    const oc_u64* q[6] = {box + 2 * i0, box + 2 * i0 + 1, box + 2 * i1, box + 2 * i1 + 1, box + 2 * i2, box + 2 * i2 + 1};
+    oc_u64 w[6];
+    auto fetch = [&]() { bool ok = true; for (int i = 0; i < 6; ++i) w[i] = ocLoad(q[i]); for (int i = 0; i < 6; ++i) ok = ok && (unsigned)(w[i] >> 32) == tag; return ok; };
+    if (!fetch()) {
+        const long long t0 = wall_clock64();
+        unsigned spins = 0;
+        for (;;) {
+            __builtin_amdgcn_s_sleep(1);
+            if (fetch()) break;
+            if ((++spins & 31u) == 0) {
+                if (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if (wall_clock64() - t0 > to) { __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+    }
+    for (int i = 0; i < 3; ++i) v[i] = __longlong_as_double((long long)((w[2 * i + 1] << 32) | (w[2 * i] & 0xffffffffull)));
+}
 __device__ __forceinline__ double ocJoin(unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((oc_u64)hi << 32) | lo)); }
 
 // Whole-wave shifts that KEEP `old` in the lane whose source lies outside the wave (bound_ctrl off): lane 0 of fromLeft / lane 63 of fromRight receive the
@@ -102,39 +140,64 @@ __device__ __forceinline__ double ocFromRight(double old, double v) {
     return __hiloint2double(ocFromRight(__double2hiint(old), __double2hiint(v)), ocFromRight(__double2loint(old), __double2loint(v)));
 }
 
-template <class T> struct __attribute__((aligned(16))) OcH4 { T v[4]; };      // {ox, oy, a, -} or {cos, sin, on, -} of one halo pixel
+template <class T> struct __attribute__((aligned(16))) OcH4 { T v[4]; };      // {ox, oy, a, -} of p, r or A p, or {cos, sin, on, flag byte} of one halo pixel
+
+__device__ __forceinline__ float ocFma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double ocFma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// Sum over the wave, valid in lane 63: prefix sums inside the rows of 16 lanes (row_shr 1, 2, 4, 8), then row 0 -> 1 and 2 -> 3 (row_bcast:15), then rows 0-1 -> 2-3
+// (row_bcast:31).  13 DPP moves + 6 adds per double on the VALU, against six ds_bpermute round trips for the __shfl_down tree (1.2 us per iteration for four sums).
+template <int CTRL, int ROWMASK> __device__ __forceinline__ double ocDppAdd(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, true), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, true);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ocWaveSum63(double v) {
+    v = ocDppAdd<0x111, 0xf>(v); v = ocDppAdd<0x112, 0xf>(v); v = ocDppAdd<0x114, 0xf>(v); v = ocDppAdd<0x118, 0xf>(v);      // lane 15 of every row: the row's sum
+    v = ocDppAdd<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v = ocDppAdd<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
 
 // LDS carve-up (bytes), shared by the kernel and the launcher
 template <class T> struct OcLds {
     static constexpr size_t ap(int rows, bool apLds) { return apLds ? (size_t)rows * 3 * kOcBlock * sizeof(T) : 0; }
-    static constexpr size_t rowHalo() { return (size_t)kOcWaves * 2 * 3 * kWave * sizeof(T); }
+    static constexpr size_t row() { return (size_t)kOcWaves * 2 * 3 * kWave * sizeof(T); }
+    static constexpr size_t rows3(bool apLds) { return (apLds ? 2 : 3) * row(); }      // p and r of the halo rows; their A p only when it cannot be read from apL
     static constexpr size_t side(int rows) { return (size_t)kOcWaves * rows * 2 * sizeof(OcH4<T>); }
-    static constexpr size_t stage(int rows) { return ((size_t)kOcWaves * rows * 3 * sizeof(T) + 15) / 16 * 16; }
     static constexpr size_t tail() { return (4 * kOcWaves + kOcGroup * 4 + 8) * sizeof(double) + (kOcMaxTiles * 8 + kOcGroup * 8) * sizeof(unsigned) + 16 * sizeof(T) + 16; }
-    static constexpr size_t total(int rows, bool apLds) { return ap(rows, apLds) + rowHalo() + 2 * side(rows) + stage(rows) + tail(); }
+    static constexpr size_t total(int rows, bool apLds) { return ap(rows, apLds) + rows3(apLds) + 5 * side(rows) + tail(); }
 };
 
-// Development builds (opt_amd/build.py build_variant with OC_PROFILE=1; tools/onchip_bench.py --profile): thread 0 of every workgroup accumulates the wall-clock
-// ticks (100 MHz) it spends in each phase of an iteration and leaves them in K.prof[workgroup][8].
+// Development builds (opt_amd/build.py build_variant with OC_PROFILE=1; tools/onchip_bench.py under OPT_AMD_ONCHIP_PROFILE=1): thread 0 of every workgroup
+// accumulates the wall-clock ticks (100 MHz) it spends in each phase of an iteration and leaves them in K.prof[workgroup][8].
 #ifndef OC_PROFILE
 #define OC_PROFILE 0
 #endif
 #if OC_PROFILE
-#define OC_MARK(i) do { if (tid == 0) { const long long t_ = wall_clock64(); ocProf[i] += t_ - ocPrev; ocPrev = t_; } } while (0)
+#define OC_MARK(i) do { if (lane == 0) { const long long t_ = wall_clock64(); ocProf[wave * 16 + (i)] += t_ - ocPrev; ocPrev = t_; } } while (0)
 #else
 #define OC_MARK(i) do { } while (0)
 #endif
 
+// ONE grid-wide wait per iteration.  A tile keeps p and r of its own pixels AND of the one-pixel ring around every wave (rows above / below: registers, lane-aligned;
+// columns left / right: LDS, one lane per halo pixel).  After the stencil a wave hands the A p of its edge pixels to whoever holds them as halo -- the neighbouring
+// wave through LDS, the neighbouring tile through its inbox -- together with the workgroup's partial sums; after the one wait everybody applies PCGStep2 / PCGStep3
+// to its own pixels and to its halo copies with the same alpha, beta and the same explicitly fused operations: owner and halo holder get the same bits, and the
+// new search direction never has to travel.
 template <class T, int ROWS, bool AP_LDS, bool DELTA_GLB>
 __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
-    static_assert(3 * ROWS <= kWave, "a wave hands its edge column over with one lane per scalar");
+    static_assert(2 * ROWS <= kWave, "one lane per halo pixel of the two side columns");
     extern __shared__ __attribute__((aligned(16))) unsigned char ocLds[];
     T* apL = reinterpret_cast<T*>(ocLds);                                                       // [ROWS * 3][512]: conflict-free [row][component][thread]
-    T* rowHalo = reinterpret_cast<T*>(ocLds + OcLds<T>::ap(ROWS, AP_LDS));                      // [wave][0 = from above, 1 = from below][3][64]
-    OcH4<T>* sideP = reinterpret_cast<OcH4<T>*>(reinterpret_cast<unsigned char*>(rowHalo) + OcLds<T>::rowHalo());      // [wave][row][0 = from the left, 1 = from the right]
-    OcH4<T>* sideC = sideP + kOcWaves * ROWS * 2;                                               // the same pixels' cos, sin, on (constant over the solve)
-    T* stage = reinterpret_cast<T*>(sideC + kOcWaves * ROWS * 2);                               // [wave][ROWS * 3]: the edge column a tile-edge wave sends out
-    double* red = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(stage) + OcLds<T>::stage(ROWS));          // [4][waves]
+    T* rowP = reinterpret_cast<T*>(ocLds + OcLds<T>::ap(ROWS, AP_LDS));                         // [wave][0 = above, 1 = below][3][64]: p of the halo rows (lane-aligned)
+    T* rowR = rowP + kOcWaves * 2 * 3 * kWave;                                                  // their r
+    T* rowA = rowR + kOcWaves * 2 * 3 * kWave;                                                  // their A p, written by the neighbouring wave (only without apL: with it the holder reads the owner's A p there)
+    OcH4<T>* sideP = reinterpret_cast<OcH4<T>*>(reinterpret_cast<unsigned char*>(rowP) + OcLds<T>::rows3(AP_LDS));      // [wave][row][0 = left, 1 = right]: p of the halo columns
+    OcH4<T>* sideR = sideP + kOcWaves * ROWS * 2;                                               // r of the same pixels
+    OcH4<T>* sideC = sideR + kOcWaves * ROWS * 2;                                               // their cos, sin, on, flag byte (constant over the solve)
+    OcH4<T>* sideA = sideC + kOcWaves * ROWS * 2;                                               // their A p, written by the neighbouring wave's edge lane
+    OcH4<T>* stageA = sideA + kOcWaves * ROWS * 2;                                              // [wave][row][0 = lane 0's, 1 = lane 63's]: edge A p on its way to another tile
+    double* red = reinterpret_cast<double*>(stageA + kOcWaves * ROWS * 2);                      // [4][waves]
     double* GS = red + 4 * kOcWaves;                                                            // [groups][4]
     double* TOT = GS + kOcGroup * 4;                                                            // [4] + the bad flag
     unsigned* W1 = reinterpret_cast<unsigned*>(TOT + 8);                                        // [<= 256 workgroups][8]
@@ -159,16 +222,20 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
         const T sq = T(1) + sqrt(d);
         mTab[t] = T(1) / (sq * sq);
     }
-    // cos, sin, activity of a pixel that may lie outside the image (then: inactive)
-    auto pixelConst = [&](int xx, int yy, T& c, T& s, T& on) {
+    // p_0, r_0, cos, sin, activity and flag byte of a pixel that may lie outside the image (then: zeros, inactive)
+    auto loadPixel = [&](int xx, int yy, T (&pp)[3], T (&rr)[3], T& c, T& s, T& on, unsigned& f) {
         const bool ok = xx >= 0 && xx < K.W && yy >= 0 && yy < K.H;
         const long i = ok ? (long)yy * K.W + xx : 0;
-        const int f = K.flags[i];
+        f = ok ? (unsigned)K.flags[i] : 0u;
+        const V2<T> po = ((const V2<T>*)K.p0)[i], ro = ((const V2<T>*)K.r0)[i];
+        const T pa = K.p0[2 * N + i], ra = K.r0[2 * N + i];
+        pp[0] = ok ? po.x : T(0); pp[1] = ok ? po.y : T(0); pp[2] = ok ? pa : T(0);
+        rr[0] = ok ? ro.x : T(0); rr[1] = ok ? ro.y : T(0); rr[2] = ok ? ra : T(0);
         sincosT(K.Angle[i], &s, &c);
-        on = (ok && (f & kActive)) ? T(1) : T(0);
+        on = (f & kActive) ? T(1) : T(0);
     };
 
-    // ---- the lane's ROWS pixels ---------------------------------------------------------------------------------------------------------------
+    // ---- the lane's ROWS pixels, the halo rows above and below them, and (lane = side * ROWS + row) the halo columns of the wave ---------------------
     T p[ROWS][3], r[ROWS][3], cs[ROWS][2];
     T dl[DELTA_GLB ? 1 : ROWS][3], ap[AP_LDS ? 1 : ROWS][3];
     unsigned fl[(ROWS + 3) / 4];
@@ -176,29 +243,35 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
     for (int j = 0; j < (ROWS + 3) / 4; ++j) fl[j] = 0;
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
-        const int y = yBase + j;
-        const bool ok = xin && y < K.H;
-        const long i = ok ? (long)y * K.W + x : 0;
-        const unsigned f = ok ? (unsigned)K.flags[i] : 0u;
-        const V2<T> po = ((const V2<T>*)K.p0)[i], ro = ((const V2<T>*)K.r0)[i];
-        const T pa = K.p0[2 * N + i], ra = K.r0[2 * N + i];
-        p[j][0] = ok ? po.x : T(0); p[j][1] = ok ? po.y : T(0); p[j][2] = ok ? pa : T(0);
-        r[j][0] = ok ? ro.x : T(0); r[j][1] = ok ? ro.y : T(0); r[j][2] = ok ? ra : T(0);
-        sincosT(K.Angle[i], &cs[j][1], &cs[j][0]);
+        unsigned f; T on;
+        loadPixel(x, yBase + j, p[j], r[j], cs[j][0], cs[j][1], on, f);
         fl[j >> 2] |= f << (8 * (j & 3));
         if (!DELTA_GLB) { dl[DELTA_GLB ? 0 : j][0] = 0; dl[DELTA_GLB ? 0 : j][1] = 0; dl[DELTA_GLB ? 0 : j][2] = 0; }
     }
-    // the rows above and below the wave's rows at this lane's column, and (lane = side * ROWS + row) the columns left and right of the wave
     T tc, ts, ton, bc, bs, bon;
-    pixelConst(x, yBase - 1, tc, ts, ton);
-    pixelConst(x, yBase + ROWS, bc, bs, bon);
-    if (lane < 2 * ROWS) {
-        const int sd = lane / ROWS, row = lane % ROWS;
-        OcH4<T> c4; c4.v[3] = 0;
-        pixelConst(sd ? x0 + kWave : x0 - 1, yBase + row, c4.v[0], c4.v[1], c4.v[2]);
-        sideC[(wave * ROWS + row) * 2 + sd] = c4;
+    unsigned fh;      // flag bytes of the halo pixels above (bits 0-7) and below (8-15)
+    T* const myRowP = rowP + (wave * 2) * 3 * kWave + lane;      // + side * 3 * 64 + component * 64
+    T* const myRowR = rowR + (wave * 2) * 3 * kWave + lane;
+    {
+        unsigned ft, fb; T pp[3], rr[3];
+        loadPixel(x, yBase - 1, pp, rr, tc, ts, ton, ft);
+        myRowP[0] = pp[0]; myRowP[kWave] = pp[1]; myRowP[2 * kWave] = pp[2]; myRowR[0] = rr[0]; myRowR[kWave] = rr[1]; myRowR[2 * kWave] = rr[2];
+        loadPixel(x, yBase + ROWS, pp, rr, bc, bs, bon, fb);
+        myRowP[3 * kWave] = pp[0]; myRowP[4 * kWave] = pp[1]; myRowP[5 * kWave] = pp[2]; myRowR[3 * kWave] = rr[0]; myRowR[4 * kWave] = rr[1]; myRowR[5 * kWave] = rr[2];
+        fh = ft | (fb << 8);
+    }
+    const bool haloLane = lane < 2 * ROWS;
+    const int hSide = haloLane ? lane / ROWS : 0, hRow = haloLane ? lane % ROWS : 0;
+    if (haloLane) {
+        OcH4<T> p4, r4, c4; unsigned f;
+        T pp[3], rr[3];
+        loadPixel(hSide ? x0 + kWave : x0 - 1, yBase + hRow, pp, rr, c4.v[0], c4.v[1], c4.v[2], f);
+        p4.v[0] = pp[0]; p4.v[1] = pp[1]; p4.v[2] = pp[2]; p4.v[3] = 0; r4.v[0] = rr[0]; r4.v[1] = rr[1]; r4.v[2] = rr[2]; r4.v[3] = 0;
+        c4.v[3] = (T)f;      // (0 .. 255: exact in either precision)
+        const int h = (wave * ROWS + hRow) * 2 + hSide;
+        sideP[h] = p4; sideR[h] = r4; sideC[h] = c4;
         OcH4<T> z4; z4.v[0] = z4.v[1] = z4.v[2] = z4.v[3] = 0;
-        sideP[(wave * ROWS + row) * 2 + sd] = z4;         // stays 0 where the image (or the tile grid) ends
+        sideA[h] = z4; stageA[h] = z4;      // A p of a halo pixel beyond the tile grid stays 0
     }
     __syncthreads();
 
@@ -211,20 +284,29 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
         return q;
     };
     auto haloQ = [&](const T (&h)[3], T c, T s, T on) { Q<T> q{}; q.ox = h[0]; q.oy = h[1]; q.a = h[2]; q.c = c; q.s = s; q.on = on; return q; };
+    auto mOf = [&](unsigned f, T& mo, T& ma) { const int cnt = (int)((f >> kCountShift) & 7u), io = cnt + ((f & kFit) ? 5 : 0); mo = mTab[io]; ma = mTab[10 + cnt]; };
     const int sideSel = lane == kWave - 1 ? 1 : 0;       // lane 63 looks right, lane 0 (and, unused, everyone else) left
     // Per-lane base addresses, so that every row's access is base + a compile-time offset (the DS instructions' immediate): with the row inside the index
     // expression the compiler keeps one address register per row and array -- 32 of them, spilled and reloaded at L2 latency in every row of the stencil.
     const OcH4<T>* const mySideP = sideP + (wave * ROWS) * 2 + sideSel;
     const OcH4<T>* const mySideC = sideC + (wave * ROWS) * 2 + sideSel;
     T* const myAp = apL + tid;
+    // where the A p of this lane's pixels goes if the lane is a wave edge (lane 0: to whoever holds the column as its right halo; lane 63: as its left halo):
+    // the neighbouring wave's sideA, or -- at a tile edge -- this wave's stageA, from where one lane per halo pixel sends it to the neighbouring tile
+    const bool edgeLane = lane == 0 || lane == kWave - 1;
+    OcH4<T>* const edgeDst = lane == 0 ? (wx > 0 ? sideA + ((wave - 1) * ROWS) * 2 + 1 : stageA + (wave * ROWS) * 2 + 0)
+                                       : (wx + 1 < kOcWavesX ? sideA + ((wave + 1) * ROWS) * 2 + 0 : stageA + (wave * ROWS) * 2 + 1);
     const int nGroups = (K.G + kOcGroup - 1) / kOcGroup;
     const bool hasUp = ty > 0, hasDown = ty + 1 < K.tilesY, hasLeft = tx > 0, hasRight = tx + 1 < K.tilesX;
+    // the halo column this lane looks after: handed over inside the workgroup, by another tile, or by nobody (the image ends)
+    const bool hIntra = haloLane && (hSide == 0 ? wx > 0 : wx + 1 < kOcWavesX);
+    const bool hInter = haloLane && !hIntra && (hSide == 0 ? hasLeft : hasRight);
     bool failed = false;
 
 #if OC_PROFILE
-    __shared__ long long ocProf[8];
+    __shared__ long long ocProf[kOcWaves * 16];
     long long ocPrev = wall_clock64();
-    if (tid < 8) ocProf[tid] = 0;
+    if (tid < kOcWaves * 16) ocProf[tid] = 0;
     __syncthreads();
 #endif
     int pix0 = yBase * K.W + x;      // index of the lane's first pixel (may lie outside the image: only used where the pixel exists)
@@ -234,60 +316,21 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
         // per iteration, so each use recomputes its two or three instructions.
 #pragma unroll
         for (int j = 0; j < (ROWS + 3) / 4; ++j) asm volatile("" : "+v"(fl[j]));
-        asm volatile("" : "+v"(pix0));
+        asm volatile("" : "+v"(pix0), "+v"(fh));
         const unsigned tag = K.tag0 + (unsigned)k;
         const int par = (int)(tag & 1u);
         if (k == K.failAt && g == 0 && tid == 0) __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         oc_u64* const boxPar = K.S.inbox + (long)par * K.G * 4 * K.S.stride;
         auto box = [&](int tile, int sd) { return boxPar + ((long)tile * 4 + sd) * K.S.stride; };      // sd: 0 from above, 1 from below, 2 from the left, 3 from the right
 
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        // ---- hand the edges of p_k to the neighbours: LDS inside the workgroup, tagged words between workgroups --------------------------------
-        if (wy > 0) { T* h = rowHalo + ((wave - kOcWavesX) * 2 + 1) * 3 * kWave; h[ln] = p[0][0]; h[kWave + ln] = p[0][1]; h[2 * kWave + ln] = p[0][2]; }
-        else if (hasUp) { oc_u64* d = box(g - K.tilesX, 1); ocSend(d, wx * kWave + ln, p[0][0], tag); ocSend(d, kOcTileW + wx * kWave + ln, p[0][1], tag); ocSend(d, 2 * kOcTileW + wx * kWave + ln, p[0][2], tag); }
-        if (wy + 1 < kOcWavesY) { T* h = rowHalo + ((wave + kOcWavesX) * 2 + 0) * 3 * kWave; h[ln] = p[ROWS - 1][0]; h[kWave + ln] = p[ROWS - 1][1]; h[2 * kWave + ln] = p[ROWS - 1][2]; }
-        else if (hasDown) { oc_u64* d = box(g + K.tilesX, 0); ocSend(d, wx * kWave + ln, p[ROWS - 1][0], tag); ocSend(d, kOcTileW + wx * kWave + ln, p[ROWS - 1][1], tag); ocSend(d, 2 * kOcTileW + wx * kWave + ln, p[ROWS - 1][2], tag); }
-        if (ln == 0) {
-            if (wx > 0) {
-#pragma unroll
-                for (int j = 0; j < ROWS; ++j) { OcH4<T> v; v.v[0] = p[j][0]; v.v[1] = p[j][1]; v.v[2] = p[j][2]; v.v[3] = 0; (sideP + ((wave - 1) * ROWS) * 2 + 1)[j * 2] = v; }
-            } else if (hasLeft) {
-#pragma unroll
-                for (int j = 0; j < ROWS; ++j) { T* st = stage + wave * ROWS * 3; st[j * 3 + 0] = p[j][0]; st[j * 3 + 1] = p[j][1]; st[j * 3 + 2] = p[j][2]; }
-            }
-        }
-        if (ln == kWave - 1) {
-            if (wx + 1 < kOcWavesX) {
-#pragma unroll
-                for (int j = 0; j < ROWS; ++j) { OcH4<T> v; v.v[0] = p[j][0]; v.v[1] = p[j][1]; v.v[2] = p[j][2]; v.v[3] = 0; (sideP + ((wave + 1) * ROWS) * 2)[j * 2] = v; }
-            } else if (hasRight) {
-#pragma unroll
-                for (int j = 0; j < ROWS; ++j) { T* st = stage + wave * ROWS * 3; st[j * 3 + 0] = p[j][0]; st[j * 3 + 1] = p[j][1]; st[j * 3 + 2] = p[j][2]; }
-            }
-        }
-        // a tile-edge wave's column leaves with one ln per scalar (the LDS operations of one wave execute in order: the staged values are there)
-        if (wx == 0 && hasLeft && ln < 3 * ROWS) ocSend(box(g - 1, 3), wy * ROWS * 3 + ln, stage[wave * ROWS * 3 + ln], tag);
-        if (wx == kOcWavesX - 1 && hasRight && ln < 3 * ROWS) ocSend(box(g + 1, 2), wy * ROWS * 3 + ln, stage[wave * ROWS * 3 + ln], tag);
-        __syncthreads();
-        OC_MARK(0);
-
-        // ---- collect this wave's halo ----------------------------------------------------------------------------------------------------------
-        T ht[3] = {0, 0, 0}, hb[3] = {0, 0, 0};
-        if (wy > 0) { const T* h = rowHalo + (wave * 2 + 0) * 3 * kWave; ht[0] = h[ln]; ht[1] = h[kWave + ln]; ht[2] = h[2 * kWave + ln]; }
-        else if (hasUp) { const oc_u64* s = box(g, 0); ocRecv(s, wx * kWave + ln, tag, bad, to, ht[0]); ocRecv(s, kOcTileW + wx * kWave + ln, tag, bad, to, ht[1]); ocRecv(s, 2 * kOcTileW + wx * kWave + ln, tag, bad, to, ht[2]); }
-        if (wy + 1 < kOcWavesY) { const T* h = rowHalo + (wave * 2 + 1) * 3 * kWave; hb[0] = h[ln]; hb[1] = h[kWave + ln]; hb[2] = h[2 * kWave + ln]; }
-        else if (hasDown) { const oc_u64* s = box(g, 1); ocRecv(s, wx * kWave + ln, tag, bad, to, hb[0]); ocRecv(s, kOcTileW + wx * kWave + ln, tag, bad, to, hb[1]); ocRecv(s, 2 * kOcTileW + wx * kWave + ln, tag, bad, to, hb[2]); }
-        if (wx == 0 && hasLeft && ln < 3 * ROWS) { T v; ocRecv(box(g, 2), wy * ROWS * 3 + ln, tag, bad, to, v); sideP[(wave * ROWS + ln / 3) * 2 + 0].v[ln % 3] = v; }
-        if (wx == kOcWavesX - 1 && hasRight && ln < 3 * ROWS) { T v; ocRecv(box(g, 3), wy * ROWS * 3 + ln, tag, bad, to, v); sideP[(wave * ROWS + ln / 3) * 2 + 1].v[ln % 3] = v; }
-
-        OC_MARK(1);
         // ---- PCGStep1: A p_k on the lane's pixels, with the four sums ----------------------------------------------------------------------------
         // One row per scheduling region (sched_barrier): left to itself the scheduler interleaves the unrolled rows until the live temporaries fill the
         // register budget and beyond.  The wave-edge halo of row j + 1 is requested before row j's arithmetic.
         double accDen = 0, accNum = 0, acc2 = 0, acc3 = 0;
+        T aFirst[3], aLast[3];      // A p of the wave's first and last row: what the waves above and below hold as halo
         {
-            Q<T> prevQ = haloQ(ht, tc, ts, ton), curQ = rowQ(0);
+            const T pt[3] = {myRowP[0], myRowP[kWave], myRowP[2 * kWave]};
+            Q<T> prevQ = haloQ(pt, tc, ts, ton), curQ = rowQ(0);
             PairOut<T> vert;
             { T t0 = 0, t1 = 0, t2 = 0; vert = iw_pairFull<0, 1, true>(prevQ, curQ, t0, t1, t2); }      // the pair (row above, row 0) that row 0 inherits
             OcH4<T> spN = mySideP[0], scN = mySideC[0];
@@ -295,22 +338,22 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
             for (int j = 0; j < ROWS; ++j) {
                 const OcH4<T> sp = spN, sc = scN;
                 if (j + 1 < ROWS) { spN = mySideP[(j + 1) * 2]; scN = mySideC[(j + 1) * 2]; }
-                const unsigned f = flagOf(j);
-                const int cnt = (int)((f >> kCountShift) & 7u), io = cnt + ((f & kFit) ? 5 : 0);
-                const T moT = mTab[io], maT = mTab[10 + cnt];
-                const Q<T> nextQ = (j + 1 < ROWS) ? rowQ(j + 1 < ROWS ? j + 1 : j) : haloQ(hb, bc, bs, bon);
+                T moT, maT; mOf(flagOf(j), moT, maT);
+                T pb[3] = {0, 0, 0};
+                if (j + 1 == ROWS) { pb[0] = myRowP[3 * kWave]; pb[1] = myRowP[4 * kWave]; pb[2] = myRowP[5 * kWave]; }
+                const Q<T> nextQ = (j + 1 < ROWS) ? rowQ(j + 1 < ROWS ? j + 1 : j) : haloQ(pb, bc, bs, bon);
                 T ax = 0, ay = 0, aa = 0;
                 {
-                    Q<T> rt{};
-                    rt.ox = ocFromRight(sp.v[0], curQ.ox); rt.oy = ocFromRight(sp.v[1], curQ.oy); rt.a = ocFromRight(sp.v[2], curQ.a);
-                    rt.c = ocFromRight(sc.v[0], curQ.c); rt.s = ocFromRight(sc.v[1], curQ.s); rt.on = ocFromRight(sc.v[2], curQ.on);
-                    iw_pairQ<1, 0, true>(curQ, rt, ax, ay, aa);
+                    Q<T> rq{};
+                    rq.ox = ocFromRight(sp.v[0], curQ.ox); rq.oy = ocFromRight(sp.v[1], curQ.oy); rq.a = ocFromRight(sp.v[2], curQ.a);
+                    rq.c = ocFromRight(sc.v[0], curQ.c); rq.s = ocFromRight(sc.v[1], curQ.s); rq.on = ocFromRight(sc.v[2], curQ.on);
+                    iw_pairQ<1, 0, true>(curQ, rq, ax, ay, aa);
                 }
                 {
-                    Q<T> lf{};
-                    lf.ox = ocFromLeft(sp.v[0], curQ.ox); lf.oy = ocFromLeft(sp.v[1], curQ.oy); lf.a = ocFromLeft(sp.v[2], curQ.a);
-                    lf.c = ocFromLeft(sc.v[0], curQ.c); lf.s = ocFromLeft(sc.v[1], curQ.s); lf.on = ocFromLeft(sc.v[2], curQ.on);
-                    iw_pairQ<-1, 0, true>(curQ, lf, ax, ay, aa);
+                    Q<T> lq{};
+                    lq.ox = ocFromLeft(sp.v[0], curQ.ox); lq.oy = ocFromLeft(sp.v[1], curQ.oy); lq.a = ocFromLeft(sp.v[2], curQ.a);
+                    lq.c = ocFromLeft(sc.v[0], curQ.c); lq.s = ocFromLeft(sc.v[1], curQ.s); lq.on = ocFromLeft(sc.v[2], curQ.on);
+                    iw_pairQ<-1, 0, true>(curQ, lq, ax, ay, aa);
                 }
                 const PairOut<T> vn = iw_pairFull<0, 1, true>(curQ, nextQ, ax, ay, aa);      // towards the next row: formed here, inherited there
                 iw_pairInherited(vert, prevQ.on, ax, ay, aa);
@@ -320,6 +363,9 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
                 asm volatile("" : "+v"(ox), "+v"(oy), "+v"(oa));
                 if (AP_LDS) { myAp[(j * 3 + 0) * kOcBlock] = ox; myAp[(j * 3 + 1) * kOcBlock] = oy; myAp[(j * 3 + 2) * kOcBlock] = oa; }
                 else { ap[AP_LDS ? 0 : j][0] = ox; ap[AP_LDS ? 0 : j][1] = oy; ap[AP_LDS ? 0 : j][2] = oa; }
+                if (!AP_LDS && j == 0) { aFirst[0] = ox; aFirst[1] = oy; aFirst[2] = oa; }
+                if (j == ROWS - 1) { aLast[0] = ox; aLast[1] = oy; aLast[2] = oa; }
+                if (edgeLane) { OcH4<T> e; e.v[0] = ox; e.v[1] = oy; e.v[2] = oa; e.v[3] = 0; edgeDst[j * 2] = e; }
                 {   // the sums of iw_pcgIter2, term for term: p.Ap from float products, the three expansion sums from exact double products of M, r, A p
                     const double mo = (double)moT, ma = (double)maT;
                     accDen += (double)(curQ.ox * ox + curQ.oy * oy + curQ.a * oa);
@@ -334,33 +380,48 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // the delta of the first rows is requested before the wait for the sums: it does not depend on them
-        constexpr int CH = ROWS < 4 ? ROWS : 4;      // rows per chunk of the update below
-        // pixel index of the lane's row j, or 0 (a valid address whose value is not used) where the pixel does not exist
-        auto rowExists = [&](int j) { return xin && pix0 + j * K.W < (int)N; };      // (x < W: then y < H is the same as pixel index < N)
-        auto rowIndex = [&](int j) { return rowExists(j) ? pix0 + j * K.W : 0; };
-        // With delta in memory (ROWS = 16), ALL of the lane's delta is requested here, before the wait for the sums: the stencil's temporaries are dead, so the
-        // 3 ROWS registers are free, and the reads (L2-resident lines this lane wrote one iteration ago) complete while the grid-wide sum is in flight.
-        T dG[DELTA_GLB ? ROWS : 1][3];
-        if (DELTA_GLB && k > 0) {
-#pragma unroll
-            for (int j = 0; j < ROWS; ++j) {
-                const int i = rowIndex(j);
-                const V2<T> dv = ((const V2<T>*)K.delta)[i];
-                dG[DELTA_GLB ? j : 0][0] = dv.x; dG[DELTA_GLB ? j : 0][1] = dv.y; dG[DELTA_GLB ? j : 0][2] = (K.delta + 2 * N)[i];
+        OC_MARK(0);      // stencil
+        // ---- hand the edge A p to whoever holds those pixels as halo: LDS inside the workgroup, tagged words between workgroups ----------------------------
+        {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            if (AP_LDS && wy == 0 && hasUp) { aFirst[0] = myAp[0]; aFirst[1] = myAp[kOcBlock]; aFirst[2] = myAp[2 * kOcBlock]; }      // (not held across the 16 rows)
+            if (wy > 0) { if (!AP_LDS) { T* h = rowA + ((wave - kOcWavesX) * 2 + 1) * 3 * kWave; h[ln] = aFirst[0]; h[kWave + ln] = aFirst[1]; h[2 * kWave + ln] = aFirst[2]; } }
+            else if (hasUp) { oc_u64* d = box(g - K.tilesX, 1); ocSend(d, wx * kWave + ln, aFirst[0], tag); ocSend(d, kOcTileW + wx * kWave + ln, aFirst[1], tag); ocSend(d, 2 * kOcTileW + wx * kWave + ln, aFirst[2], tag); }
+            if (wy + 1 < kOcWavesY) { if (!AP_LDS) { T* h = rowA + ((wave + kOcWavesX) * 2 + 0) * 3 * kWave; h[ln] = aLast[0]; h[kWave + ln] = aLast[1]; h[2 * kWave + ln] = aLast[2]; } }
+            else if (hasDown) { oc_u64* d = box(g + K.tilesX, 0); ocSend(d, wx * kWave + ln, aLast[0], tag); ocSend(d, kOcTileW + wx * kWave + ln, aLast[1], tag); ocSend(d, 2 * kOcTileW + wx * kWave + ln, aLast[2], tag); }
+            // a tile-edge wave's column leaves with one lane per pixel (the LDS operations of one wave execute in order: what lane 0 / 63 staged above is there)
+            if (haloLane && ((hSide == 0 && wx == 0 && hasLeft) || (hSide == 1 && wx == kOcWavesX - 1 && hasRight))) {
+                const OcH4<T> e = stageA[(wave * ROWS + hRow) * 2 + hSide];
+                oc_u64* d = hSide == 0 ? box(g - 1, 3) : box(g + 1, 2);
+                const int idx = (wy * ROWS + hRow) * 3;
+                ocSend(d, idx, e.v[0], tag); ocSend(d, idx + 1, e.v[1], tag); ocSend(d, idx + 2, e.v[2], tag);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        OC_MARK(2);
+        OC_MARK(1);      // edge hand-over sends
 
-        // ---- the grid-wide sums -------------------------------------------------------------------------------------------------------------------
+        // ---- the grid-wide sums; the A p handed over inside the workgroup is collected behind the first barrier ----------------------------------------------
+        T at[3] = {0, 0, 0}, ab[3] = {0, 0, 0}, as[3] = {0, 0, 0};      // A p of the halo pixels above / below the lane's column, and of the halo pixel this lane looks after
         {
             int tq = tid;      // (opaque per iteration, like fl / pix0 above: the addresses below are recomputed, not kept in registers across the whole loop)
             asm volatile("" : "+v"(tq));
             double v4[4] = {accNum, accDen, acc2, acc3};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { v4[q] = waveReduceSum(v4[q]); if (lane == 0) red[q * kOcWaves + wave] = v4[q]; }
+            for (int q = 0; q < 4; ++q) { v4[q] = ocWaveSum63(v4[q]); if (lane == kWave - 1) red[q * kOcWaves + wave] = v4[q]; }
+            OC_MARK(2);      // wave sums
             __syncthreads();
+            OC_MARK(3);      // barrier: the slowest wave's stencil
+            {
+                const int ln = tq & (kWave - 1);      // (shadowed below: same value)
+                if (AP_LDS) {      // the owner's A p itself: the last row of the wave above (4 waves = 256 threads back), the first row of the wave below
+                    if (wy > 0) { const T* h = apL + ((ROWS - 1) * 3) * kOcBlock + (tq - kOcWavesX * kWave); at[0] = h[0]; at[1] = h[kOcBlock]; at[2] = h[2 * kOcBlock]; }
+                    if (wy + 1 < kOcWavesY) { const T* h = apL + (tq + kOcWavesX * kWave); ab[0] = h[0]; ab[1] = h[kOcBlock]; ab[2] = h[2 * kOcBlock]; }
+                } else {
+                    if (wy > 0) { const T* h = rowA + (wave * 2 + 0) * 3 * kWave; at[0] = h[ln]; at[1] = h[kWave + ln]; at[2] = h[2 * kWave + ln]; }
+                    if (wy + 1 < kOcWavesY) { const T* h = rowA + (wave * 2 + 1) * 3 * kWave; ab[0] = h[ln]; ab[1] = h[kWave + ln]; ab[2] = h[2 * kWave + ln]; }
+                }
+                if (hIntra) { const OcH4<T> e = sideA[(wave * ROWS + hRow) * 2 + hSide]; as[0] = e.v[0]; as[1] = e.v[1]; as[2] = e.v[2]; }
+            }
             oc_u64* const slotPar = K.S.slots + (long)par * K.G * 8;
             if (tq < 8) {
                 double s = 0;
@@ -368,9 +429,43 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
                 const oc_u64 b = (oc_u64)__double_as_longlong(s);
                 ocStore(slotPar + (long)g * 8 + tq, tag, (tq & 1) ? (unsigned)(b >> 32) : (unsigned)b);
             }
-            OC_MARK(3);
-            if (K.flat) {      // small grids: every workgroup reads every slot and forms the group totals itself (same order as the tree: same bits)
-                for (int i = tq; i < K.G * 8; i += kOcBlock) W1[i] = ocAwait(slotPar + i, tag, bad, to);
+            const int ln = tq & (kWave - 1);
+            const bool leader = !K.flat && (g % kOcGroup) == 0;
+            // What other tiles handed over was posted before their sums and arrives before the totals can: it is collected FIRST, inside the wait for the sums
+            // (a request costs a fabric round trip even when the words are there).  Only a group's first workgroup, on whose total 15 others wait, sums first.
+            auto collectInbox = [&]() {
+                if (wy == 0 && hasUp) ocRecv3(box(g, 0), wx * kWave + ln, kOcTileW + wx * kWave + ln, 2 * kOcTileW + wx * kWave + ln, tag, bad, to, at);
+                if (wy == kOcWavesY - 1 && hasDown) ocRecv3(box(g, 1), wx * kWave + ln, kOcTileW + wx * kWave + ln, 2 * kOcTileW + wx * kWave + ln, tag, bad, to, ab);
+                if (hInter) { const int idx = (wy * ROWS + hRow) * 3; ocRecv3(box(g, hSide == 0 ? 2 : 3), idx, idx + 1, idx + 2, tag, bad, to, as); }
+            };
+            if (!leader) collectInbox();
+            OC_MARK(4);      // inbox
+            if (K.flat) {      // every workgroup reads every slot and forms the group totals itself (same order as the tree: same bits); a lane's (up to 4) requests are in flight together
+                constexpr int kPer = kOcMaxTiles * 8 / kOcBlock;
+                oc_u64 w[kPer];
+                const int nW = K.G * 8;
+                auto fetch = [&]() {
+                    bool ok = true;
+#pragma unroll
+                    for (int u = 0; u < kPer; ++u) { const int i = tq + u * kOcBlock; w[u] = ocLoad(slotPar + (i < nW ? i : tq)); }
+#pragma unroll
+                    for (int u = 0; u < kPer; ++u) ok = ok && (unsigned)(w[u] >> 32) == tag;
+                    return ok;
+                };
+                if (tq < nW && !fetch()) {
+                    const long long t0 = wall_clock64();
+                    unsigned spins = 0;
+                    for (;;) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (fetch()) break;
+                        if ((++spins & 31u) == 0) {
+                            if (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                            if (wall_clock64() - t0 > to) { __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kPer; ++u) { const int i = tq + u * kOcBlock; if (i < nW) W1[i] = (unsigned)w[u]; }
                 __syncthreads();
                 if (tq < nGroups * 4) {
                     const int q = tq & 3, grp = tq >> 2, n = min(kOcGroup, K.G - grp * kOcGroup);
@@ -392,6 +487,7 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
                         const oc_u64 b = (oc_u64)__double_as_longlong(s);
                         ocStore(topPar + (long)grp * 8 + tq, tag, (tq & 1) ? (unsigned)(b >> 32) : (unsigned)b);
                     }
+                    collectInbox();
                 }
                 if (tq < nGroups * 8) W2[tq] = ocAwait(topPar + tq, tag, bad, to);
                 __syncthreads();
@@ -401,8 +497,26 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
             if (tq < 4) { double s = 0; for (int grp = 0; grp < nGroups; ++grp) s += GS[grp * 4 + tq]; TOT[tq] = s; }
             if (tq == 0) reinterpret_cast<int*>(TOT + 4)[0] = __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
+            OC_MARK(5);      // grid-wide sum
         }
-        OC_MARK(4);
+        // With delta in memory (ROWS = 16) it is read in chunks of CH rows, one chunk ahead of the update: the first request goes out HERE, behind the wait for
+        // the sums, and returns (lines this lane wrote one iteration ago, still in its XCD's L2) while the halo copies are updated.  (All 48 values requested
+        // before the wait held 48 more registers over the sum, and every scratch reload in between waited for all of them: vmcnt counts in order.)
+        constexpr int CH = ROWS < 4 ? ROWS : 4;
+        auto rowExists = [&](int j) { return xin && pix0 + j * K.W < (int)N; };      // (x < W: then y < H is the same as pixel index < N)
+        auto rowIndex = [&](int j) { return rowExists(j) ? pix0 + j * K.W : 0; };     // 0: a valid address whose value is not used
+        T dN[CH][3];
+        auto requestDelta = [&](int c0) {
+#pragma unroll
+            for (int jj = 0; jj < CH; ++jj) {
+                const int i = rowIndex(c0 + jj);
+                const V2<T> dv = ((const V2<T>*)K.delta)[i];
+                dN[jj][0] = dv.x; dN[jj][1] = dv.y; dN[jj][2] = (K.delta + 2 * N)[i];
+            }
+        };
+        if (DELTA_GLB && k > 0) requestDelta(0);
+        __builtin_amdgcn_sched_barrier(0);
+        OC_MARK(6);      // delta requests
         const double aNumD = TOT[0], aDenD = TOT[1], s2 = TOT[2], s3 = TOT[3];
         if (reinterpret_cast<const int*>(TOT + 4)[0]) { failed = true; break; }      // uniform over the workgroup: a wait timed out somewhere
         if (K.trace && g == 0 && tid == 0) { K.trace[4 * k] = aNumD; K.trace[4 * k + 1] = aDenD; K.trace[4 * k + 2] = s2; K.trace[4 * k + 3] = s3; }
@@ -414,15 +528,36 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
         const bool last = k + 1 == K.L;
 
         // ---- PCGStep2 + PCGStep3: delta += alpha p;  r -= alpha A p;  p = M r + beta p  (after the last iteration only delta survives) ----------------
-        // CH rows per scheduling region; with delta in memory the next chunk's delta is in flight while this one is updated.
+        // The same three fused operations on the halo copies: the bits of the pixel's owner.  CH rows per scheduling region.
+        if (!last) {
+            T mo, ma, hr[6], hp[6], hm[6];      // the halo pixels above (0..2) and below (3..5) the lane's column: all reads first, then the arithmetic, then the writes
+#pragma unroll
+            for (int u = 0; u < 6; ++u) { hr[u] = myRowR[u * kWave]; hp[u] = myRowP[u * kWave]; }
+            mOf(fh & 0xffu, mo, ma); hm[0] = mo; hm[1] = mo; hm[2] = ma;
+            mOf((fh >> 8) & 0xffu, mo, ma); hm[3] = mo; hm[4] = mo; hm[5] = ma;
+#pragma unroll
+            for (int u = 0; u < 6; ++u) { hr[u] = ocFma(-alpha, u < 3 ? at[u % 3] : ab[u % 3], hr[u]); hp[u] = ocFma(beta, hp[u], hm[u] * hr[u]); }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) { myRowR[u * kWave] = hr[u]; myRowP[u * kWave] = hp[u]; }
+            if (haloLane) {
+                const int h = (wave * ROWS + hRow) * 2 + hSide;
+                OcH4<T> p4 = sideP[h], r4 = sideR[h];
+                mOf((unsigned)sideC[h].v[3], mo, ma);
+                r4.v[0] = ocFma(-alpha, as[0], r4.v[0]); r4.v[1] = ocFma(-alpha, as[1], r4.v[1]); r4.v[2] = ocFma(-alpha, as[2], r4.v[2]);
+                p4.v[0] = ocFma(beta, p4.v[0], mo * r4.v[0]); p4.v[1] = ocFma(beta, p4.v[1], mo * r4.v[1]); p4.v[2] = ocFma(beta, p4.v[2], ma * r4.v[2]);
+                sideP[h] = p4; sideR[h] = r4;
+            }
+        }
+        OC_MARK(7);      // halo update (mark 7)
 #pragma unroll
         for (int c0 = 0; c0 < ROWS; c0 += CH) {
             T dC[CH][3];
 #pragma unroll
             for (int jj = 0; jj < CH; ++jj) {
-                if (DELTA_GLB) { dC[jj][0] = (k == 0) ? T(0) : dG[DELTA_GLB ? c0 + jj : 0][0]; dC[jj][1] = (k == 0) ? T(0) : dG[DELTA_GLB ? c0 + jj : 0][1]; dC[jj][2] = (k == 0) ? T(0) : dG[DELTA_GLB ? c0 + jj : 0][2]; }
+                if (DELTA_GLB) { dC[jj][0] = (k == 0) ? T(0) : dN[jj][0]; dC[jj][1] = (k == 0) ? T(0) : dN[jj][1]; dC[jj][2] = (k == 0) ? T(0) : dN[jj][2]; }
                 else { dC[jj][0] = dl[DELTA_GLB ? 0 : c0 + jj][0]; dC[jj][1] = dl[DELTA_GLB ? 0 : c0 + jj][1]; dC[jj][2] = dl[DELTA_GLB ? 0 : c0 + jj][2]; }
             }
+            if (DELTA_GLB && k > 0 && c0 + CH < ROWS) requestDelta(c0 + CH);
             T aC[CH][3];
 #pragma unroll
             for (int jj = 0; jj < CH; ++jj)
@@ -431,16 +566,14 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
 #pragma unroll
             for (int jj = 0; jj < CH; ++jj) {
                 const int j = c0 + jj;
-                const unsigned f = flagOf(j);
-                const int cnt = (int)((f >> kCountShift) & 7u), io = cnt + ((f & kFit) ? 5 : 0);
-                const T m[3] = {mTab[io], mTab[io], mTab[10 + cnt]};
+                T mo, ma; mOf(flagOf(j), mo, ma);
+                const T m[3] = {mo, mo, ma};
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    dC[jj][c] = dC[jj][c] + alpha * p[j][c];
+                    dC[jj][c] = ocFma(alpha, p[j][c], dC[jj][c]);
                     if (!last) {
-                        r[j][c] = r[j][c] - alpha * aC[jj][c];
-                        const T z = m[c] * r[j][c];
-                        p[j][c] = z + beta * p[j][c];
+                        r[j][c] = ocFma(-alpha, aC[jj][c], r[j][c]);
+                        p[j][c] = ocFma(beta, p[j][c], m[c] * r[j][c]);
                     }
                 }
                 if (DELTA_GLB) {
@@ -451,11 +584,11 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        OC_MARK(5);
+        OC_MARK(8);      // own update
     }
 #if OC_PROFILE
     __syncthreads();
-    if (tid < 8 && K.prof) K.prof[(long)g * 8 + tid] = ocProf[tid];
+    if (tid < kOcWaves * 16 && K.prof) K.prof[(long)g * kOcWaves * 16 + tid] = ocProf[tid];
 #endif
     if (!DELTA_GLB && !failed) {
 #pragma unroll
