@@ -46,7 +46,7 @@ ALGO_BYTES_PER_PIXEL = 48 + 96 + 36   # PCGStep1 + PCGStep2 + PCGStep3 of the re
 # p_k 12 out, angle 4, flags 1 = 41; every second launch additionally delta 12 in / 12 out = 24 -> 12 on average; general UrShape: + U 8 + M_a 4
 MODEL_BYTES_PER_PIXEL = {"lattice": 41 + 12, "general": 41 + 12 + 8 + 4}      # general UrShape: + U 8 + M_a 4 (M_O from the flag byte, round 3)
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-KERNEL_SOURCES = ["opt_amd/csrc/energy_image_warping.hip", "opt_amd/csrc/solver.hip", "opt_amd/csrc/common.h", "opt_amd/csrc/energy.h", "opt_amd/build.py"]
+KERNEL_SOURCES = ["opt_amd/csrc/energy_image_warping.hip", "opt_amd/csrc/iw_device.h", "opt_amd/csrc/iw_onchip.h", "opt_amd/csrc/solver.hip", "opt_amd/csrc/common.h", "opt_amd/csrc/energy.h", "opt_amd/build.py"]
 
 
 def kernel_src_sha16():
@@ -170,6 +170,75 @@ def measured_traffic(sha):
         if tj.get("bench_kernel") == "PCGIteration" and tj.get("kernel_src_sha16") == sha:
             return tj["hbm_bytes_per_launch"], os.path.basename(cand)
     return None, None
+
+
+def _pcg_rate(api, wl, torch, W, H, liters, onchip, steps=3):
+    os.environ["OPT_AMD_ONCHIP"] = "1" if onchip else "0"
+    try:
+        P = wl.image_warping(W, H)
+        g = api.Solver(api.energy_file(P.energy), "gaussNewtonGPU", P.dims)
+        g.set_parameter("nIterations", steps + 1); g.set_parameter("lIterations", liters)
+        dev = api.to_device(P)
+        g.init(dev); g.step(dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.step(dev)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        g.close()
+        return dt
+    finally:
+        del os.environ["OPT_AMD_ONCHIP"]
+
+
+def onchip_table(api, wl, torch, liters):
+    """PCG iterations/s where the whole linear solve runs as one persistent launch with its state on chip -- the reference's own input sizes (512^2:
+    examples/image_warping/src/main.cpp:98-134; the SFS fixture's 640x480), 1024^2, and 2 M pixels = 1/8 of the metric's 4096^2 -- next to the streaming
+    loop (one launch per PCG iteration, OPT_AMD_ONCHIP=0) on the same box."""
+    rows = []
+    for W, H in [(512, 512), (640, 480), (1024, 1024), (2048, 1024), (4096, 512)]:
+        t_on, t_st = _pcg_rate(api, wl, torch, W, H, liters, True), _pcg_rate(api, wl, torch, W, H, liters, False)
+        rows.append({"image": f"{W}x{H}", "pixels": W * H, "onchip_us_per_iter": 1e6 * t_on / liters, "onchip_pcg_iters_per_s": liters / t_on,
+                     "streaming_us_per_iter": 1e6 * t_st / liters, "streaming_pcg_iters_per_s": liters / t_st, "speedup": t_st / t_on})
+    return {"what": "image_warping float, Gauss-Newton steps of %d PCG iterations, wall time per step / %d; on-chip = iw_onchipPcg (one launch per linear solve), "
+                    "streaming = iw_pcgIter2 (one launch per PCG iteration)" % (liters, liters),
+            "sizes": rows, "onchip_4096x512_us_per_iter": rows[-1]["onchip_us_per_iter"], "streaming_4096x512_us_per_iter": rows[-1]["streaming_us_per_iter"]}
+
+
+def reference_example_flows():
+    """The reference's example programs as a user runs them, through the C++ callers of the C ABI (examples/*.cpp): image_warping 512^2, 19 constraint passes x 8
+    Gauss-Newton x 400 PCG (examples/image_warping/src/main.cpp:110-134; GN and LM on identical inputs), and shape_from_shading 640x480 double LM 60 x 10
+    (examples/shape_from_shading/src/main.cpp:27-38) on a procedural surface with the fixture's parameters.  Solver time = sum of the per-step wall times the
+    harness records (its results CSV)."""
+    import re
+    out = {}
+    exe = os.path.join(ROOT, "examples", "bin", "image_warping_example")
+    sfs = os.path.join(ROOT, "examples", "bin", "sfs_example")
+    if not (os.path.exists(exe) and os.path.exists(sfs)):
+        return None
+
+    def run(cmd, env_extra):
+        env = dict(os.environ); env.update(env_extra)
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        return r.returncode, r.stdout
+
+    for name, extra in (("onchip", {}), ("streaming", {"OPT_AMD_ONCHIP": "0"})):
+        rc, txt = run([exe, "512", "19", "8", "400"], extra)
+        m = re.search(r"total solver time: GN ([0-9.]+) ms, LM ([0-9.]+) ms", txt)
+        c = re.search(r"Opt GN,Opt LM,CERES\s*\n([-+0-9.eE]+),([-+0-9.eE]+),", txt)
+        out["image_warping_512_19x8x400_" + name] = {"rc": rc, "gn_ms": float(m.group(1)) if m else None, "lm_ms": float(m.group(2)) if m else None,
+                                                      "final_cost_gn": float(c.group(1)) if c else None, "final_cost_lm": float(c.group(2)) if c else None}
+    rc, txt = run([sfs, "-", "640", os.path.join(ROOT, "opt_amd", "energies", "shape_from_shading.t"), "480"], {})
+    m = re.search(r"total solver time: ([0-9.]+) ms", txt)
+    c = re.search(r"Opt GN,Opt LM,CERES\s*\n,([-+0-9.eE]+),", txt)
+    out["shape_from_shading_640x480_60x10_double_lm"] = {"rc": rc, "lm_ms": float(m.group(1)) if m else None, "final_cost_lm": float(c.group(1)) if c else None}
+    for f in ("results_float.csv", "results_double.csv"):
+        try:
+            os.remove(os.path.join(ROOT, f))
+        except OSError:
+            pass
+    return out
 
 
 def main():
@@ -387,6 +456,13 @@ def main():
         del dev3
         del os.environ["OPT_AMD_LATTICE"]
 
+    # ---- the on-chip linear solve (opt_amd/csrc/iw_onchip.h) at the sizes it exists for, against the streaming loop on the same box ---------------------
+    onchip = None
+    flows = None
+    if not distributed and not args.no_extras:
+        onchip = onchip_table(api, wl, torch, args.liters)
+        flows = reference_example_flows()
+
     # ---- CPU leg last: the GPU work sits at the front of the run in one block ------------------------------------------------------------
     cpu = None
     if rank == 0 and not distributed and not args.no_cpu_baseline:
@@ -402,7 +478,7 @@ def main():
                           "step": "one Opt_ProblemStep (1 GN iteration)"},
                "gn_solve": solve, "gn_solve_ms": solve["gn_solve_ms"] if solve else None,
                "cost_initial": costs[0], "cost_final": cost_final, "parity": parity, "comm_ranks": comm_ranks,
-               "kernel_src_sha16": sha, "roofline": roofline, "general_urshape": general, "cpu_baseline": cpu}
+               "kernel_src_sha16": sha, "roofline": roofline, "general_urshape": general, "onchip": onchip, "reference_example_flows": flows, "cpu_baseline": cpu}
         print(json.dumps(out))
     if distributed:
         job.close()

@@ -3,7 +3,7 @@
 // Input: either the reference's fixture set -- pass the prefix of `<prefix>_targetIntensity.imagedump`,
 // `_targetDepth`, `_initialUnknown`, `_maskEdgeMap` and `<prefix>.SFSSolverParameters` -- or, without arguments, a
 // procedural surface lit with the fixture's spherical-harmonics coefficients.
-//   usage: sfs_example [prefix | -] [size=512] [energy.t]
+//   usage: sfs_example [prefix | -] [width=512] [energy.t] [height=width]      (640 x 480: the size of the reference's fixture, examples/data/shape_from_shading)
 #include "common.h"
 #include <cmath>
 #include <cstring>
@@ -38,6 +38,7 @@ int main(int argc, char** argv) {
     const std::string prefix = argc > 1 ? argv[1] : "-";
     int W = argc > 2 ? atoi(argv[2]) : 512, H = W;
     const std::string energy = argc > 3 ? argv[3] : "opt_amd/energies/shape_from_shading.t";
+    if (argc > 4) H = atoi(argv[4]);
     float wts[3] = {100.f, 100.f, 1.f}, fx = 574.0529f, fy = 574.0528f, ux = 320.f, uy = 240.f;
     float L[9] = {0.6908f, 0.0446f, 0.0181f, -0.1773f, -0.0407f, 0.1447f, 0.0239f, -0.2466f, 0.0058f};
     std::vector<double> X, D, Im;

@@ -499,22 +499,23 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
             __syncthreads();
             OC_MARK(5);      // grid-wide sum
         }
-        // With delta in memory (ROWS = 16) it is read in chunks of CH rows, one chunk ahead of the update: the first request goes out HERE, behind the wait for
+        // With delta in memory (ROWS = 16) it is read in chunks of CH rows, two chunks ahead of the update: the first request goes out HERE, behind the wait for
         // the sums, and returns (lines this lane wrote one iteration ago, still in its XCD's L2) while the halo copies are updated.  (All 48 values requested
         // before the wait held 48 more registers over the sum, and every scratch reload in between waited for all of them: vmcnt counts in order.)
         constexpr int CH = ROWS < 4 ? ROWS : 4;
         auto rowExists = [&](int j) { return xin && pix0 + j * K.W < (int)N; };      // (x < W: then y < H is the same as pixel index < N)
         auto rowIndex = [&](int j) { return rowExists(j) ? pix0 + j * K.W : 0; };     // 0: a valid address whose value is not used
-        T dN[CH][3];
-        auto requestDelta = [&](int c0) {
+        constexpr int NCH = (ROWS + CH - 1) / CH;
+        T dN[DELTA_GLB ? NCH : 1][CH][3];      // (fully unrolled below: every chunk has its own registers, live from its request to its use -- two chunks at a time)
+        auto requestDelta = [&](int c) {
 #pragma unroll
             for (int jj = 0; jj < CH; ++jj) {
-                const int i = rowIndex(c0 + jj);
+                const int i = rowIndex(c * CH + jj);
                 const V2<T> dv = ((const V2<T>*)K.delta)[i];
-                dN[jj][0] = dv.x; dN[jj][1] = dv.y; dN[jj][2] = (K.delta + 2 * N)[i];
+                dN[DELTA_GLB ? c : 0][jj][0] = dv.x; dN[DELTA_GLB ? c : 0][jj][1] = dv.y; dN[DELTA_GLB ? c : 0][jj][2] = (K.delta + 2 * N)[i];
             }
         };
-        if (DELTA_GLB && k > 0) requestDelta(0);
+        if (DELTA_GLB && k > 0) { requestDelta(0); if (NCH > 1) requestDelta(NCH > 1 ? 1 : 0); }
         __builtin_amdgcn_sched_barrier(0);
         OC_MARK(6);      // delta requests
         const double aNumD = TOT[0], aDenD = TOT[1], s2 = TOT[2], s3 = TOT[3];
@@ -554,10 +555,10 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
             T dC[CH][3];
 #pragma unroll
             for (int jj = 0; jj < CH; ++jj) {
-                if (DELTA_GLB) { dC[jj][0] = (k == 0) ? T(0) : dN[jj][0]; dC[jj][1] = (k == 0) ? T(0) : dN[jj][1]; dC[jj][2] = (k == 0) ? T(0) : dN[jj][2]; }
+                if (DELTA_GLB) { const int c = DELTA_GLB ? c0 / CH : 0; dC[jj][0] = (k == 0) ? T(0) : dN[c][jj][0]; dC[jj][1] = (k == 0) ? T(0) : dN[c][jj][1]; dC[jj][2] = (k == 0) ? T(0) : dN[c][jj][2]; }
                 else { dC[jj][0] = dl[DELTA_GLB ? 0 : c0 + jj][0]; dC[jj][1] = dl[DELTA_GLB ? 0 : c0 + jj][1]; dC[jj][2] = dl[DELTA_GLB ? 0 : c0 + jj][2]; }
             }
-            if (DELTA_GLB && k > 0 && c0 + CH < ROWS) requestDelta(c0 + CH);
+            if (DELTA_GLB && k > 0 && c0 / CH + 2 < NCH) requestDelta(c0 / CH + 2 < NCH ? c0 / CH + 2 : 0);
             T aC[CH][3];
 #pragma unroll
             for (int jj = 0; jj < CH; ++jj)

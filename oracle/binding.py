@@ -46,6 +46,7 @@ def lib():
         L.OptOracle_CurrentCost.restype = cd
         L.OptOracle_CurrentCost.argtypes = [vp]
         L.OptOracle_SetThreads.argtypes = [vp, ci]
+        L.OptOracle_SetReduction.argtypes = [vp, ci, ctypes.c_uint]
         L.OptOracle_NumUnknownScalars.restype = cl
         L.OptOracle_NumUnknownScalars.argtypes = [vp]
         L.OptOracle_GetVector.restype = ci
@@ -106,6 +107,11 @@ class OracleSolver:
     def set_threads(self, n):
         """OpenMP threads for the timed CPU baseline (row bands); parity tests keep the default of 1."""
         lib().OptOracle_SetThreads(self._h, int(n))
+
+    def set_reduction(self, mode, seed=0):
+        """0: long-double sums rounded once (default).  1: the reference's own reduction arithmetic -- opt_float terms per element, the 32-lane
+        shfl.down tree per warp, one opt_float atomicAdd per warp in an order drawn from `seed` (oracle/solver.hpp header)."""
+        lib().OptOracle_SetReduction(self._h, int(mode), int(seed))
 
     def init(self, params):
         a, self._keep = _param_array(params)

@@ -74,6 +74,12 @@ void OptOracle_Init(void* hv, void** params) { auto* h = (Handle*)hv; if (h->dbl
 int OptOracle_Step(void* hv, void** params) { auto* h = (Handle*)hv; return h->dbl ? h->sd->step(params) : h->sf->step(params); }
 void OptOracle_Solve(void* hv, void** params) { OptOracle_Init(hv, params); while (OptOracle_Step(hv, params)) {} }   // o.t:2548-2551
 double OptOracle_CurrentCost(void* hv) { auto* h = (Handle*)hv; return h->dbl ? (double)h->sd->prevCost : (double)h->sf->prevCost; }
+// reductionMode 1: the reference's warp tree + unordered opt_float atomics, the order drawn from `seed` (solver.hpp header)
+void OptOracle_SetReduction(void* hv, int mode, unsigned seed) {
+    auto* h = (Handle*)hv;
+    if (h->dbl) { h->sd->reductionMode = mode; h->sd->reductionSeed = seed; h->sd->reductionCount = 0; }
+    else { h->sf->reductionMode = mode; h->sf->reductionSeed = seed; h->sf->reductionCount = 0; }
+}
 void OptOracle_SetThreads(void* hv, int n) { auto* h = (Handle*)hv; if (h->dbl) h->sd->threads = n; else h->sf->threads = n; }
 long OptOracle_NumUnknownScalars(void* hv) { auto* h = (Handle*)hv; return h->dbl ? h->ed->nScalars : h->ef->nScalars; }
 

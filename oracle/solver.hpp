@@ -22,8 +22,15 @@
 //   exclude .............................. o.t:2452-2455 ; residual zeroed outside its bbox: o.t:1895-1936
 //
 // Reductions: the reference sums opt_float partials with warp shuffles + same-address atomics in an
-// unspecified order (util.t:612-623, solver.t:312-317).  The oracle accumulates every global sum in
-// long double and rounds once to opt_float -- the "some order, no accumulated error" limit.
+// unspecified order (util.t:612-623, solver.t:312-317).  Two modes:
+//   reductionMode 0 (default): every global sum accumulated in long double and rounded once to opt_float -- the "some order, no
+//       accumulated error" limit;
+//   reductionMode 1 ("reference order"): the reference's own arithmetic -- one opt_float term per element of the index space
+//       (`p(idx):dot(Ap)`, `z:dot(r)`, `fmap.cost(idx)`), summed inside every 32-lane warp by the shfl.down tree of util.t:612-623 (a warp is
+//       32 consecutive threads of a 16 x 16 block, x fastest: a 16 x 2 pixel patch; util.t:781-797), then ONE opt_float atomicAdd per warp
+//       on a zeroed scalar (solverGPUGaussNewton.t:312-317, 580-592) in an order the hardware does not define -- modelled as a seeded random
+//       permutation of the warps.  Two seeds are two legal runs of the reference; how far apart they land after N PCG iterations is the
+//       reproducibility of the reference against ITSELF (tests/golden/make_reference_order_spread.py, profiles/r04_reference_order_spread.md).
 //
 // PARITY STATUS: the reference path is Terra/Lua JIT-compiled to PTX and cannot be built or run in this
 // environment, and the reference ships no golden vectors.  This restatement is pinned by (i) the
@@ -112,6 +119,7 @@ struct Solver {
     int verbosity = 0;
     mutable std::vector<T> scratchAcc;
     int threads = 1;   // > 1: OpenMP over row bands (timed CPU baseline only; parity tests run single-threaded)
+    int reductionMode = 0; unsigned reductionSeed = 0; mutable unsigned long reductionCount = 0;   // see the header: 1 = the reference's warp tree + unordered float atomics
 
     Solver(Energy<T>* e, bool useLM) : E(e), lm(useLM) {
         long n = E->nScalars;
@@ -128,6 +136,53 @@ struct Solver {
             }
     }
     static T guardedInvert(T x) { T s = T(1) + std::sqrt(x); return T(1) / (s * s); }   // solver.t:323-332
+
+    // ---- reductionMode 1: warp tree (util.t:612-623) + one opt_float atomicAdd per warp in a seeded random order (solver.t:312-317) ----
+    bool referenceOrder() const { return reductionMode == 1 && !E->usesGraph && E->rowWidth() > 0; }
+    T reduceReferenceOrder(const std::vector<T>& perElem) const {
+        const long W = E->rowWidth(), n = (long)perElem.size(), H = n / W;
+        const long bxN = (W + 15) / 16, byN = (H + 15) / 16;
+        std::vector<T> warps((size_t)(bxN * byN * 8));
+#pragma omp parallel for num_threads(threads) if (threads > 1)
+        for (long b = 0; b < bxN * byN; ++b) {
+            const long bx = b % bxN, by = b / bxN;
+            for (int w = 0; w < 8; ++w) {
+                T v[32];
+                for (int lane = 0; lane < 32; ++lane) {      // thread (tx, ty) of the block, linear id = ty * 16 + tx; out-of-range threads contribute 0 (PCGStep1's `var d = 0`)
+                    const long x = bx * 16 + (lane & 15), y = by * 16 + w * 2 + (lane >> 4);
+                    v[lane] = (x < W && y < H) ? perElem[(size_t)(y * W + x)] : T(0);
+                }
+                for (int off = 16; off > 0; off >>= 1)       // val = val + __shfl_down(val, offset): lane 0's dependency cone
+                    for (int lane = 0; lane < off; ++lane) v[lane] = v[lane] + v[lane + off];
+                warps[(size_t)(b * 8 + w)] = v[0];
+            }
+        }
+        // the atomics: a random permutation of the warps (Fisher-Yates on a 64-bit LCG stream keyed by the seed and the reduction's ordinal)
+        unsigned long long st = 0x9E3779B97F4A7C15ull * (reductionSeed + 1) + 0xD1B54A32D192ED03ull * (++reductionCount);
+        auto next = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (unsigned long long)(st >> 33); };
+        for (size_t i = warps.size(); i > 1; --i) { const size_t j = (size_t)(next() % i); std::swap(warps[i - 1], warps[j]); }
+        T s = 0;
+        for (T x : warps) s = s + x;
+        return s;
+    }
+    // one opt_float per element: term(e), evaluated in parallel, then reduced as above
+    template <class F> T reducePerElement(F&& term) const {
+        const long n = E->nCentered();
+        std::vector<T> perElem((size_t)n);
+#pragma omp parallel for num_threads(threads) if (threads > 1)
+        for (long e = 0; e < n; ++e) perElem[(size_t)e] = term(e);
+        return reduceReferenceOrder(perElem);
+    }
+    // unknownElement dot product at element e (all unknown images live on the same index space): sum over images, channels of a * c
+    T elemDot(const std::vector<T>& a, const std::vector<T>& c, long e) const {
+        T s = 0;
+        for (size_t img = 0; img < E->unkElems.size(); ++img) {
+            const long ch = E->unkChannels[img], base = E->unkOffset[img] + e * ch;
+            if (!active[base]) return T(0);
+            for (long k = 0; k < ch; ++k) s = s + a[base + k] * c[base + k];
+        }
+        return s;
+    }
 
     template <class F> void forEachInstance(bool skipExcludedCentres, F&& f) const {
         Inst<T> buf[MAXR];
@@ -180,6 +235,14 @@ struct Solver {
 
     // cost = sum over non-excluded elements of 1/2 sum_k r_k^2  (solver.t:580-592, 715-725; o.t:2375-2385)
     T computeCost() const {
+        if (referenceOrder())      // computeCost kernel, solver.t:580-592: cost = fmap.cost(idx), warpReduce, lane 0 atomicAdd
+            return reducePerElement([&](long e) {
+                if (E->excludedCentered(e)) return T(0);
+                Inst<T> buf[MAXR];
+                const int k = E->evalCentered(e, buf);
+                T c = 0; for (int i = 0; i < k; ++i) c += buf[i].val * buf[i].val;
+                return T(0.5) * c;
+            });
         std::vector<long double> bands;
         forEachInstanceBanded(true, [&](const Inst<T>* in, int k, long double* s) {
             T c = 0; for (int i = 0; i < k; ++i) c += in[i].val * in[i].val;
@@ -235,6 +298,7 @@ struct Solver {
         }
     }
     T dotActive(const std::vector<T>& a, const std::vector<T>& c) const {
+        if (referenceOrder()) return reducePerElement([&](long e) { return elemDot(a, c, e); });      // d = pd.p(idx):dot(tmp), solver.t:429
         long double s = 0;
 #pragma omp parallel for reduction(+ : s) num_threads(threads) if (threads > 1)
         for (long i = 0; i < E->nScalars; ++i) if (active[i]) s += (long double)(a[i] * c[i]);
@@ -310,6 +374,7 @@ struct Solver {
             }
         }
         aNum = (T)d;
+        if (referenceOrder()) aNum = reducePerElement([&](long e) { return elemDot(r, p, e); });      // d = residuum:dot(p), solver.t:391
     }
     void computeCtC() {   // solver.t:616-622, 739-744 ; o.t:2255-2316 (true diag(JtJ)/radius, independent of usepreconditioner)
         std::vector<T> acc(E->nScalars, T(0));
@@ -359,6 +424,14 @@ struct Solver {
             if (lm) qq += (long double)(T(0.5) * (dl * (rr + b[i])));
         }
         bNum = (T)bn; if (lm) q = (T)qq;
+        if (referenceOrder()) {      // betaNum = z:dot(r); q = 0.5 * delta:dot(r + b)  (solver.t:478-485)
+            bNum = reducePerElement([&](long e) { return elemDot(z, r, e); });
+            if (lm) {
+                std::vector<T> rb(r.size());
+                for (size_t i = 0; i < r.size(); ++i) rb[i] = r[i] + b[i];
+                q = reducePerElement([&](long e) { return T(0.5) * elemDot(delta, rb, e); });
+            }
+        }
     }
     void pcgStep2Split() {   // solver.t:491-534 + computeAdelta :566-571, 708-713
         T a = alpha();
