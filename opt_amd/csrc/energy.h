@@ -138,6 +138,9 @@ struct EnergyOps {
     // After the stream has drained: did a wait inside the last on-chip solve time out (another tenant on the GPU kept its workgroups from being co-resident)?
     // Then the unknowns were left untouched, the kernel set has switched the path off for this plan, and the caller redoes the linear solve.
     virtual bool onChipFailed() { return false; }
+    // Slab mode, before the loop: will pcgIteration accept the launches?  (The solver refreshes the ghost rows of r_0, p_0 and M for that loop only: the
+    // three-kernel loop relies on r being 0 on ghost rows -- its flat sums run over them.)
+    virtual bool slabIterationAvailable() const { return true; }
     // Slab mode, after a pcgIteration launch with iterStateExchange: which vectors (solver layout) carry the state whose ghost rows the neighbours
     // must refresh.  0 = the rNew / pNew the launch was given; a kernel set that keeps its loop state in buffers of its own lists them here.
     virtual int iterExchangeVectors(T** /*out4*/) { return 0; }

@@ -4,1345 +4,39 @@
 // offset) and a_c (angle); for the 4 stencil directions n
 //     r_reg[c,n] = w_reg * v(c,n) * [ (O_c - O_{c+n}) - R(a_c)(U_c - U_{c+n}) ],  v = InBounds(c+n) & Mask_{c+n}=0 & Mask_c=0
 //     r_fit[c]   = w_fit * [C_c >= 0] * (O_c - C_c)
-// cost = 1/2 sum r^2 over non-masked pixels (Exclude, :11).  The kernels below are the hand-derived
+// cost = 1/2 sum r^2 over non-masked pixels (Exclude, :11).  The kernels are the hand-derived
 // counterparts of what Opt's generator emits from that file (o.t:2029-2089 applyJTJ, :2129-2172 evalJTF,
 // :2375-2385 cost, :2174-2225 modelcost); with D_{c,n} = R'(a_c)(U_c - U_{c+n}):
 //     J p  at (c,n)      : Jp = w [ (pO_c - pO_{c+n}) - D_{c,n} pa_c ]
 //     (J^T J p)_O(c)     = w_fit^2 f_c pO_c + w sum_n v [ Jp(c,n) - Jp(c+n,-n) ]
 //     (J^T J p)_a(c)     = - w sum_n v D_{c,n} . Jp(c,n)
 //
-// MI355X design.  Every kernel here is HBM-bound (applyJTJ moves 48 B/pixel
-// algorithmically at ~150 flop/pixel, 3 flop/B against a ridge of ~20).  So:
-//  * the three per-pixel inputs that only gate terms (Mask: 4 B, Constraints: 8 B) are folded once per
-//    solve step into a 1-byte flag image, and cos/sin(a) is tabulated once per Gauss-Newton iteration,
-//    so the PCG loop's applyJTJ reads 12 (p) + 8 (cos,sin) + 8 (U) + 1 (flags) and writes 12 B/pixel
-//    instead of gathering five arrays through five neighbours;
-//  * the stencil kernels march down the image: a workgroup owns a column strip (62 output pixels per wave)
-//    and a contiguous range of rows, each lane keeps the rows y-1, y, y+1 of its column in registers, so
-//    vertical neighbours cost no memory traffic at all and each row is fetched from HBM once (plus 2 halo
-//    rows per workgroup); horizontal neighbours are whole-wave DPP shifts of registers (no LDS);
-//  * the grid is sized to be co-resident (one wave of workgroups, rows split evenly) instead of
-//    thousands of 16x16 tiles, so there is no tail and only ~1k partial sums per dot product;
-//  * for Gauss-Newton the whole PCG iteration (the reference's PCGStep1 + PCGStep2 + PCGStep3) is ONE such
-//    kernel.  iw_pcgIter2 -- the default -- keeps neither A*p nor r in memory: A*p is recomputed from p on a 2-pixel ring, r is
-//    rebuilt from the last two search directions (the loop's state is a ring of three p buffers), the preconditioner comes from
-//    the flag byte, (cos, sin) from the angle, and delta is touched every second launch: 53 B/pixel of HBM traffic per iteration
-//    against 180 B/pixel for the three reference kernels.  iw_pcgIter (A*p in memory, 113-121 B/pixel)
-//    remains for slabs with a single ghost row; iw_applyJTJ (with the previous PCGStep3 optionally fused in) serves probes, the
-//    split residual reset of LM and the OPT_AMD_ONEKERNEL=0 fallback.
+// Where the kernels live (all HBM-bound streaming / stencil work, ~3 flop/B: no MFMA anywhere):
+//   iw_device.h   pixel record, the residual-pair arithmetic, buffer-descriptor addressing
+//   iw_step.h     what runs once per Gauss-Newton step (flags + lattice verdict, PCGInit1, cost, update) and iw_applyJTJ (probes, LM reset, three-kernel loop)
+//   iw_iter.h     iw_pcgIter2: one launch per PCG iteration, 53 B/pixel (the reference's three kernels: 180) -- images that do not fit the chip, row slabs, LM
+//   iw_onchip.h   iw_onchipPcg: the whole linear solve as one persistent launch with its state in registers / LDS -- images of up to 2 M pixels
+// This file is the host side: which kernel runs when.
 #include "energy.h"
 #include "iw_device.h"
+#include "iw_step.h"
+#include "iw_iter.h"
 #include "iw_onchip.h"
 #include <cstdint>
 
 namespace optamd {
 namespace {
 
-
-template <class T>
-struct IWArgs {
-    int W, H;                 // local image (incl. ghost rows in slab mode)
-    int yBegin, yEnd;         // owned rows
-    int gy0, Hg;              // global row of local row 0, global height
-    const T* Offset; const T* Angle; const T* UrShape; const T* Constraints; const T* Mask;
-    T w_fit, w_reg;
-    uint8_t* flags;           // bit0: pixel exists and Mask == 0 ; bit1: fit constraint valid ; bits 2-4: number of active 4-neighbours
-    T* cs;                    // (cos a, sin a) per pixel
-};
-
-
-// once per Init/Step: fold Mask / Constraints / global bounds into one byte per pixel
-template <class T>
-__global__ __launch_bounds__(kBlock) void iw_flags(IWArgs<T> A) {
-    const long N = (long)A.W * A.H;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
-        const int y = (int)(i / A.W), x = (int)(i % A.W), gy = A.gy0 + y;
-        uint8_t f = 0;
-        if (gy >= 0 && gy < A.Hg && A.Mask[i] == T(0)) f |= kActive;                          // eq(Mask,0)  (image_warping.t:11,17)
-        if (A.Constraints[2 * i] >= T(0) && A.Constraints[2 * i + 1] >= T(0)) f |= kFit;      // All(greatereq(C,0)) (:22)
-        // how many regularisation residuals v(c,n) are on: with it the Jacobi preconditioner of the Offset part (and, on a
-        // unit lattice, of the Angle part) is a function of this byte alone and need not be streamed (iw_pcgIter2, PRE == 3)
-        int cnt = 0;
-        const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};
-        for (int n = 0; n < 4; ++n) {
-            const int nx = x + dx[n], ny = y + dy[n], ngy = A.gy0 + ny;
-            if (nx >= 0 && nx < A.W && ny >= 0 && ny < A.H && ngy >= 0 && ngy < A.Hg && A.Mask[(long)ny * A.W + nx] == T(0)) ++cnt;
-        }
-        A.flags[i] = f | (uint8_t)(cnt << kCountShift);
-    }
-}
-// once per Gauss-Newton iteration: (cos a, sin a)
-template <class T>
-__global__ __launch_bounds__(kBlock) void iw_cossin(IWArgs<T> A) {
-    const long N = (long)A.W * A.H;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
-        T s, c; sincosT(A.Angle[i], &s, &c);
-        ((V2<T>*)A.cs)[i] = V2<T>{c, s};
-    }
-}
-
-template <class T> __device__ __forceinline__ bool ownedRow(const IWArgs<T>& A, int y) { return y >= A.yBegin && y < A.yEnd; }
-
-// ---- cost -----------------------------------------------------------------------------------------------
-template <class T>
-__global__ __launch_bounds__(kBlock) void iw_cost(IWArgs<T> A, double* __restrict__ partials) {
-    __shared__ double scratch[kBlock / kWave + 1];
-    const long rows = A.yEnd - A.yBegin, N = rows * A.W;
-    const V2<T>* O = (const V2<T>*)A.Offset; const V2<T>* U = (const V2<T>*)A.UrShape; const V2<T>* C = (const V2<T>*)A.Constraints;
-    double acc = 0;
-    for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < N; j += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(j % A.W), y = A.yBegin + (int)(j / A.W);
-        const long i = (long)y * A.W + x;
-        const uint8_t f = A.flags[i];
-        if (!(f & kActive)) continue;   // excluded pixel: its residuals are not part of the cost (solver.t:583)
-        T s, c; sincosT(A.Angle[i], &s, &c);
-        const V2<T> o = O[i], u = U[i];
-        T e = 0;
-        const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int nx = x + dx[n], ny = y + dy[n];
-            if (nx < 0 || nx >= A.W || ny < 0 || ny >= A.H) continue;
-            const long ni = (long)ny * A.W + nx;
-            if (!(A.flags[ni] & kActive)) continue;
-            const V2<T> on = O[ni], un = U[ni];
-            const T ux = u.x - un.x, uy = u.y - un.y;
-            const T ex = A.w_reg * ((o.x - on.x) - (c * ux - s * uy));
-            const T ey = A.w_reg * ((o.y - on.y) - (s * ux + c * uy));
-            e += ex * ex + ey * ey;
-        }
-        if (f & kFit) {
-            const V2<T> cc = C[i];
-            const T fx = A.w_fit * (o.x - cc.x), fy = A.w_fit * (o.y - cc.y);
-            e += fx * fx + fy * fy;
-        }
-        acc += (double)(T(0.5) * e);
-    }
-    double t = blockReduceSum(acc, scratch);
-    if (threadIdx.x == 0) partials[blockIdx.x] = t;
-}
-
-// ---- evalJTF: r = -J^T F, diag = diag(J^T J) ---------------------------------------------------------------
-template <class T>
-__global__ __launch_bounds__(kBlock) void iw_evalJTF(IWArgs<T> A, T* __restrict__ r, T* __restrict__ diag) {
-    const long N = (long)A.W * A.H;
-    const V2<T>* O = (const V2<T>*)A.Offset; const V2<T>* U = (const V2<T>*)A.UrShape; const V2<T>* C = (const V2<T>*)A.Constraints;
-    const V2<T>* CS = (const V2<T>*)A.cs;
-    V2<T>* rO = (V2<T>*)r; T* ra = r + 2 * N; V2<T>* dO = (V2<T>*)diag; T* da = diag + 2 * N;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % A.W), y = (int)(i / A.W);
-        const uint8_t f = A.flags[i];
-        T Fx = 0, Fy = 0, Fa = 0, Pxy = 0, Pa = 0;
-        if ((f & kActive) && ownedRow(A, y)) {
-            const V2<T> o = O[i], u = U[i], cs = CS[i];
-            const T w = A.w_reg;
-            const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int nx = x + dx[n], ny = y + dy[n];
-                if (nx < 0 || nx >= A.W || ny < 0 || ny >= A.H) continue;
-                const long ni = (long)ny * A.W + nx;
-                if (!(A.flags[ni] & kActive)) continue;
-                const V2<T> on = O[ni], un = U[ni], csn = CS[ni];
-                const T ux = u.x - un.x, uy = u.y - un.y;
-                // residual centred here, towards n
-                const T ex = w * ((o.x - on.x) - (cs.x * ux - cs.y * uy));
-                const T ey = w * ((o.y - on.y) - (cs.y * ux + cs.x * uy));
-                // residual centred at the neighbour, towards here: -(O_c - O_n) + R(a_n)(U_c - U_n)
-                const T gx = w * ((on.x - o.x) + (csn.x * ux - csn.y * uy));
-                const T gy = w * ((on.y - o.y) + (csn.y * ux + csn.x * uy));
-                Fx += w * ex - w * gx; Fy += w * ey - w * gy;
-                const T Dx = -cs.y * ux - cs.x * uy, Dy = cs.x * ux - cs.y * uy;   // R'(a)(U_c - U_n)
-                Fa += -(w * Dx) * ex - (w * Dy) * ey;
-                Pxy += w * w + w * w;
-                Pa += (w * Dx) * (w * Dx) + (w * Dy) * (w * Dy);
-            }
-            if (f & kFit) {
-                const V2<T> cc = C[i];
-                Fx += A.w_fit * (A.w_fit * (o.x - cc.x)); Fy += A.w_fit * (A.w_fit * (o.y - cc.y));
-                Pxy += A.w_fit * A.w_fit;
-            }
-        }
-        rO[i] = V2<T>{-Fx, -Fy}; ra[i] = -Fa;
-        dO[i] = V2<T>{Pxy, Pxy}; da[i] = Pa;
-    }
-}
-
-// ---- applyJTJ (PCGStep1), optionally with the previous iteration's PCGStep3 fused in -----------------------------
-// Row-marching stencil: see the header comment.  With FUSE the kernel first forms the new search direction
-// p = z + beta p (reference PCGStep3, solverGPUGaussNewton.t:537-550) for every pixel it touches -- the
-// rows it owns plus its two halo rows -- writes it for the owned rows into a SECOND p buffer (in-place
-// would race with the neighbouring workgroup's halo reads), and applies J^T J to it.  That removes one
-// kernel and the re-read of p per PCG iteration.
-//
-// Lane layout: a wave covers 64 consecutive pixels of a row but only its inner 62 lanes produce output;
-// lanes 0 and 63 are the horizontal halo (neighbouring waves overlap by 2 pixels).  Left / right
-// neighbours are then whole-wave DPP shifts of registers -- no LDS, no divergent edge loads -- at the price
-// of 3 % redundant lanes.  Rows are fetched two ahead of use (raw registers, combined late) so that a
-// wave always has a full row of loads in flight while it computes.
-template <class T>
-struct Px {
-    T ox, oy, a;    // v at this pixel (Offset part, Angle part)
-    T c, s;         // cos/sin of the pixel's angle
-    T ux, uy;       // UrShape
-    int f;          // flags (0 if the pixel does not exist)
-};
-template <class T, bool FUSE>
-struct Raw {        // one pixel's loads, not yet combined (keeps the loads independent of any ALU work)
-    V2<T> o, cs, u; T a;
-    V2<T> zo; T za;
-    int f, ok;      // raw flag byte; ok = the pixel exists (known without the load)
-};
-
-template <bool RIGHT, class T> __device__ __forceinline__ Px<T> dppShiftPx(const Px<T>& p) {
-    Px<T> q;
-    q.ox = dppShift<RIGHT>(p.ox); q.oy = dppShift<RIGHT>(p.oy); q.a = dppShift<RIGHT>(p.a); q.c = dppShift<RIGHT>(p.c); q.s = dppShift<RIGHT>(p.s);
-    q.ux = dppShift<RIGHT>(p.ux); q.uy = dppShift<RIGHT>(p.uy); q.f = dppShift<RIGHT>(p.f);
-    return q;
-}
-
-// A real register copy the compiler cannot fold.  The marching kernels pass some loaded fields (cos/sin, U, M) through
-// unchanged for three rows; left to itself the compiler keeps them in the registers the load wrote, has to rotate the
-// prefetch buffers with v_movs at the loop back-edge, and a v_mov of a register whose load is still in flight costs an
-// s_waitcnt there -- the prefetch drains every trip.  Copying once, where the data is consumed anyway, frees the raw
-// registers so the next prefetch lands in the same ones and the back-edge carries no waits.
-__device__ __forceinline__ float regCopy(float v) { float r; asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(v)); return r; }
-__device__ __forceinline__ int regCopy(int v) { int r; asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(v)); return r; }
-__device__ __forceinline__ double regCopy(double v) { return __hiloint2double(regCopy(__double2hiint(v)), regCopy(__double2loint(v))); }
-
-template <class T>
-struct FuseArgs {            // the PCGStep3 inputs when fused (see k_step3 in solver.hip)
-    const T* z; T* vNew;
-    const double* bNumPartials; int nB;
-    const double* aNumOld; double* aNumNext;
-};
-
-// streaming (non-temporal) accesses for the once-per-kernel vectors; see solver.hip ldnt/stnt
-template <class T> struct Vec2T;
-template <> struct Vec2T<float> { typedef float type __attribute__((ext_vector_type(2))); };
-template <> struct Vec2T<double> { typedef double type __attribute__((ext_vector_type(2))); };
-template <bool NT, class T> __device__ __forceinline__ V2<T> ld2(const V2<T>* p, long i) {
-    if (NT) { const typename Vec2T<T>::type v = __builtin_nontemporal_load((const typename Vec2T<T>::type*)p + i); return V2<T>{v.x, v.y}; }
-    return p[i];
-}
-template <bool NT, class T> __device__ __forceinline__ T ld1(const T* p, long i) { return NT ? __builtin_nontemporal_load(p + i) : p[i]; }
-template <bool NT, class T> __device__ __forceinline__ void st2(V2<T>* p, long i, T x, T y) {
-    if (NT) { typename Vec2T<T>::type v; v.x = x; v.y = y; __builtin_nontemporal_store(v, (typename Vec2T<T>::type*)p + i); }
-    else p[i] = V2<T>{x, y};
-}
-template <bool NT, class T> __device__ __forceinline__ void st1(T* p, long i, T x) { if (NT) __builtin_nontemporal_store(x, p + i); else p[i] = x; }
-// Measured (interleaved A/B on one box, opt_amd/build.py::build_variant).  Non-temporal LOADS: round 1 saw +4 % at 4096^2 on one box;
-// round 2 (tools/size_ab.sh, gpurun_out r02b) finds them equal at 4096^2 (246 us either way) and slower wherever the working set is near
-// the 256 MB Infinity Cache -- 4096x512 (one of 8 slabs): 44.4 -> 37.0 us per iteration without nt, 4096x1024: 73.5 -> 69.5,
-// 2048^2: 69.1 -> 66.2 -- so plain loads are the default.  nt STORES on the 4-8 B/lane outputs cost 15 %; XCD-aware strip mapping 8 %.
-#ifndef IW_NT_LOAD
-#define IW_NT_LOAD 0
-#endif
-#ifndef IW_ROW_SYNC
-#define IW_ROW_SYNC 1
-#endif
-#ifndef IW_NT_STORE
-#define IW_NT_STORE 0
-#endif
-constexpr bool kNTL = IW_NT_LOAD != 0, kNTS = IW_NT_STORE != 0;   // measured: nt on these 4-8 B/lane accesses costs 25% (fused 250 -> 315 us at 4096^2); 16 B/lane streams in solver.hip keep it
-
-template <class T, bool FUSE>
-__device__ __forceinline__ Raw<T, FUSE> iw_loadRaw(const IWArgs<T>& A, const V2<T>* __restrict__ vO, const T* __restrict__ va, const V2<T>* __restrict__ zO,
-                                                   const T* __restrict__ za, bool xok, int x, int y) {
-    // Branch-free: out-of-image pixels read a clamped (valid) address and get flag 0; every use of the other
-    // fields is gated by the flag through selects, so their values never matter.
-    Raw<T, FUSE> r;
-    const bool ok = xok && y >= 0 && y < A.H;
-    const long i = (long)min(max(y, 0), A.H - 1) * A.W + min(max(x, 0), A.W - 1);
-    r.f = A.flags[i]; r.ok = ok;      // NOT `ok ? f : 0` here: any ALU op on a loaded value forces its s_waitcnt before the loop back-edge
-    r.o = ld2<kNTL>(vO, i); r.a = ld1<kNTL>(va, i); r.cs = ld2<kNTL>((const V2<T>*)A.cs, i); r.u = ld2<kNTL>((const V2<T>*)A.UrShape, i);
-    if (FUSE) { r.zo = ld2<kNTL>(zO, i); r.za = ld1<kNTL>(za, i); } else { r.zo = V2<T>{0, 0}; r.za = 0; }
-    return r;
-}
-template <class T, bool FUSE>
-__device__ __forceinline__ Px<T> iw_combine(const Raw<T, FUSE>& r, T beta) {
-    Px<T> p;
-    p.ox = r.o.x; p.oy = r.o.y; p.a = r.a;
-    if (FUSE) { p.ox = r.zo.x + beta * p.ox; p.oy = r.zo.y + beta * p.oy; p.a = r.za + beta * p.a; }   // PCGStep3
-    p.c = regCopy(r.cs.x); p.s = regCopy(r.cs.y); p.ux = regCopy(r.u.x); p.uy = regCopy(r.u.y); p.f = r.ok ? r.f : 0;
-    if (!FUSE) { p.ox = regCopy(p.ox); p.oy = regCopy(p.oy); p.a = regCopy(p.a); }
-    return p;
-}
-
-// accumulate the two residuals shared by centre c and neighbour n (the one centred at c and the one centred at n)
-template <class T>
-__device__ __forceinline__ void iw_pair(const Px<T>& c, const Px<T>& n, T& accOx, T& accOy, T& accA) {
-    const bool on = (n.f & kActive) != 0;                              // v(c,n); the centre's own flag is applied by the caller
-    const T ux = c.ux - n.ux, uy = c.uy - n.uy;
-    const T Dcx = -c.s * ux - c.c * uy, Dcy = c.c * ux - c.s * uy;     // R'(a_c)(U_c - U_n)
-    const T Dnx = n.s * ux + n.c * uy, Dny = -n.c * ux + n.s * uy;     // R'(a_n)(U_n - U_c)
-    const T jcx = (c.ox - n.ox) - Dcx * c.a, jcy = (c.oy - n.oy) - Dcy * c.a;   // J p of the residual centred at c  (/w)
-    const T jnx = (n.ox - c.ox) - Dnx * n.a, jny = (n.oy - c.oy) - Dny * n.a;   // J p of the residual centred at n  (/w)
-    accOx += on ? jcx - jnx : T(0); accOy += on ? jcy - jny : T(0);   // selects, not branches: the kernel stays straight-line
-    accA -= on ? Dcx * jcx + Dcy * jcy : T(0);
-}
-
-// The same two residuals when UrShape is a unit lattice (U_c - U_{c+n} = -n exactly): nothing of U is needed and the
-// derivative columns collapse to +-(sin, cos) permutations.  Same arithmetic as iw_pair up to FMA contraction.
-template <int DX, int DY, class T>
-__device__ __forceinline__ void iw_pairLattice(const Px<T>& c, const Px<T>& n, T& accOx, T& accOy, T& accA, T sy = T(1)) {
-    const bool on = (n.f & kActive) != 0;
-    const T ux = T(-DX), uy = T(-DY) * sy;      // sy = -1 when the kernel sweeps the image bottom-up (rows mirrored)
-    const T Dcx = -c.s * ux - c.c * uy, Dcy = c.c * ux - c.s * uy;
-    const T Dnx = n.s * ux + n.c * uy, Dny = -n.c * ux + n.s * uy;
-    const T jcx = (c.ox - n.ox) - Dcx * c.a, jcy = (c.oy - n.oy) - Dcy * c.a;
-    const T jnx = (n.ox - c.ox) - Dnx * n.a, jny = (n.oy - c.oy) - Dny * n.a;
-    accOx += on ? jcx - jnx : T(0); accOy += on ? jcy - jny : T(0);
-    accA -= on ? Dcx * jcx + Dcy * jcy : T(0);
-}
-
-constexpr int kSpan = kWave - 2;                    // output pixels per wave per row
-constexpr int kStrip = (kBlock / kWave) * kSpan;    // output pixels per workgroup per row (248)
-
-template <class T, bool LM, bool FUSE>
-__global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ CtC,
-                                                      double* __restrict__ partials, int rowsPerGroup, int gx, int gy, int xcdMap, FuseArgs<T> F) {
-    __shared__ double scratch[kBlock / kWave + 1];
-    // Workgroup -> (strip bx, row group by).  The dispatcher places workgroup b on XCD b % 8, each XCD with its own L2
-    // (MI355X_MICROARCH.md); with xcdMap the 8 XCDs take whole row groups, so the strips of one row group -- which
-    // share cache lines at their 248-pixel seams and the 2 overlap pixels -- hit the same L2 instead of fetching the
-    // seam lines from HBM twice.  Purely a locality choice: any mapping gives the same result.
-    int bx, by;
-    if (xcdMap) { const int id = blockIdx.x, xcd = id & 7, slot = id >> 3; by = (slot / gx) * 8 + xcd; bx = slot % gx; }
-    else { bx = blockIdx.x % gx; by = blockIdx.x / gx; }
-    const bool idle = by >= gy;
-    const long N = (long)A.W * A.H;
-    const V2<T>* vO = (const V2<T>*)v; const T* va = v + 2 * N;
-    const V2<T>* zO = (const V2<T>*)F.z; const T* za = F.z + 2 * N;
-    V2<T>* nO = (V2<T>*)F.vNew; T* na = F.vNew + 2 * N;
-    V2<T>* outO = (V2<T>*)out; T* outA = out + 2 * N;
-    T beta = 0;
-    if (FUSE) {   // solver.t:541-547
-        const double bSum = sumPartials(F.bNumPartials, F.nB, scratch);
-        const T rDotzNew = (T)bSum, rDotzOld = (T)F.aNumOld[0];
-        beta = (rDotzOld > T(0)) ? rDotzNew / rDotzOld : T(0);
-        if (blockIdx.x == 0 && threadIdx.x == 0) F.aNumNext[0] = bSum;   // alphaNumerator <- betaNumerator (:1091)
-    }
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    const int x = bx * kStrip + wave * kSpan + lane - 1;
-    const bool xok = x >= 0 && x < A.W;
-    const bool writer = xok && lane >= 1 && lane <= kSpan;       // inner lanes own their pixel; lanes 0 / 63 are halo
-    const int yb = idle ? A.yEnd : A.yBegin + by * rowsPerGroup;
-    const int ye = idle ? A.yEnd : min(yb + rowsPerGroup, A.yEnd);
-    const T w2 = A.w_reg * A.w_reg, wf2 = A.w_fit * A.w_fit;
-    double acc = 0;
-
-    Px<T> up = iw_combine<T, FUSE>(iw_loadRaw<T, FUSE>(A, vO, va, zO, za, xok, x, yb - 1), beta);
-    Px<T> cur = iw_combine<T, FUSE>(iw_loadRaw<T, FUSE>(A, vO, va, zO, za, xok, x, yb), beta);
-    if (FUSE && writer && yb < ye) {
-        const long i = (long)yb * A.W + x;
-        st2<kNTS>(nO, i, cur.ox, cur.oy); st1<kNTS>(na, i, cur.a);
-        if (yb - 1 >= 0 && yb == A.yBegin) { const long j = i - A.W; st2<kNTS>(nO, j, up.ox, up.oy); st1<kNTS>(na, j, up.a); }   // ghost row above (slab mode)
-    }
-    // one row: `rdn` holds the raw loads of row y+1 (issued one iteration earlier)
-    auto row = [&](int y, const Raw<T, FUSE>& rdn, bool live) {
-        const Px<T> dn = iw_combine<T, FUSE>(rdn, beta);
-        const long i = (long)y * A.W + x;
-        if (FUSE && writer && live && y + 1 < A.H && (y + 1 < ye || y + 1 == A.yEnd)) { const long j = i + A.W; st2<kNTS>(nO, j, dn.ox, dn.oy); st1<kNTS>(na, j, dn.a); }
-        const Px<T> lf = dppShiftPx<true>(cur), rt = dppShiftPx<false>(cur);
-        T ax = 0, ay = 0, aa = 0;
-        iw_pair(cur, rt, ax, ay, aa);
-        iw_pair(cur, lf, ax, ay, aa);
-        iw_pair(cur, dn, ax, ay, aa);
-        iw_pair(cur, up, ax, ay, aa);
-        T rx = w2 * ax, ry = w2 * ay, ra = w2 * aa;
-        const bool fit = (cur.f & kFit) != 0;
-        rx += fit ? wf2 * cur.ox : T(0); ry += fit ? wf2 * cur.oy : T(0);
-        if (LM) {
-            const long ic = (writer && live) ? i : 0;
-            const V2<T> cO = ((const V2<T>*)CtC)[ic];
-            rx += cO.x * cur.ox; ry += cO.y * cur.oy; ra += CtC[2 * N + ic] * cur.a;
-        }
-        const bool act = (cur.f & kActive) != 0;       // excluded / non-existent centre: row of J^T J is 0 (solver.t:424)
-        rx = act ? rx : T(0); ry = act ? ry : T(0); ra = act ? ra : T(0);
-        if (writer && live) {
-            acc += (double)(cur.ox * rx + cur.oy * ry + cur.a * ra);
-            st2<kNTS>(outO, i, rx, ry); st1<kNTS>(outA, i, ra);
-        }
-        up = cur; cur = dn;
-    };
-    // Two rows per trip, no branch around a load: a load inside a conditional block makes the compiler drain the whole
-    // queue (s_waitcnt vmcnt(0)) where the paths merge, which would serialise the prefetch.  An odd last row runs as a
-    // predicated no-op (clamped addresses, nothing stored or summed).
-    Raw<T, FUSE> rA = iw_loadRaw<T, FUSE>(A, vO, va, zO, za, xok, x, yb + 1), rB;
-    for (int y = yb; y < ye; y += 2) {
-        if (IW_ROW_SYNC) __syncthreads();   // keep the 4 waves of a strip on the same rows: their shared seam lines then hit L2
-        rB = iw_loadRaw<T, FUSE>(A, vO, va, zO, za, xok, x, y + 2);
-        row(y, rA, true);
-        rA = iw_loadRaw<T, FUSE>(A, vO, va, zO, za, xok, x, y + 3);
-        row(y + 1, rB, y + 1 < ye);
-    }
-    double t = blockReduceSum(acc, scratch);
-    if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
-}
-
-// ---- the once-per-Gauss-Newton-step passes as row-marching kernels (round 3) ------------------------------------------------------
-// iw_flags / iw_checkLattice / iw_cossin / iw_evalJTF / k_initFinish / iw_cost above are one-thread-per-pixel kernels that gather their four
-// neighbours through L1 / L2: 0.22-0.39 of the HBM peak, together 0.93 ms per Gauss-Newton step at 4096^2 -- 1.4 % of a step of 400 PCG iterations but a
-// third of a step with the reference's default of 10 (solverGPUGaussNewton.t:26-39).  The kernels below do the same work in the marching layout of
-// iw_applyJTJ: a workgroup owns a 248-pixel column strip and a contiguous range of rows, a lane keeps rows y-1, y, y+1 of its column in registers, left
-// and right neighbours are DPP shifts, every input row is fetched once:
-//   iw_bindMarch  : flags (Mask, Constraints -> 1 byte) and the unit-lattice verdict of UrShape in one pass (21 B/px in, 1 out); the verdict goes to
-//                   pinned host memory, nothing blocks;
-//   iw_jtfMarch   : PCGInit1 + PCGInit1_Finish (solver.t:361-419): r = -J^T F, p = M r, sum r.p -- and, for a general UrShape, the compact Jacobi
-//                   preconditioner {M_O, M_a} the iteration kernel reads; sincos inline, no (cos, sin) table, no diag / preconditioner vectors written;
-//   iw_costMarch  : computeCost (solver.t:580-592).
-// Each reproduces the expressions of the kernel it replaces term by term (same operands, same order), so the values are the same up to the order of
-// the double partial sums.  Used on a single GPU; slabs keep the older kernels.
-template <class T>
-struct MPx {               // one pixel of the 3-row window
-    T ox, oy;              // Offset
-    T c, s;                // cos / sin of Angle
-    T ux, uy;              // UrShape (dead on a unit lattice)
-    int f;                 // flag byte; 0 if the pixel does not exist
-};
-template <bool RIGHT, bool LATTICE, class T> __device__ __forceinline__ MPx<T> dppShiftM(const MPx<T>& p) {
-    MPx<T> q;
-    q.ox = dppShift<RIGHT>(p.ox); q.oy = dppShift<RIGHT>(p.oy); q.c = dppShift<RIGHT>(p.c); q.s = dppShift<RIGHT>(p.s); q.f = dppShift<RIGHT>(p.f);
-    if (LATTICE) { q.ux = 0; q.uy = 0; } else { q.ux = dppShift<RIGHT>(p.ux); q.uy = dppShift<RIGHT>(p.uy); }
-    return q;
-}
-template <class T> struct MRaw { V2<T> o, u, cc; T a; int f, ok; };
-template <class T, bool LATTICE, bool NEEDC>
-__device__ __forceinline__ MRaw<T> iw_marchLoad(const IWArgs<T>& A, bool xok, int x, int y) {
-    MRaw<T> r;
-    r.ok = xok && y >= 0 && y < A.H;
-    const long i = (long)min(max(y, 0), A.H - 1) * A.W + min(max(x, 0), A.W - 1);      // clamped: always a valid address, gated by r.ok
-    r.f = A.flags[i];
-    r.o = ((const V2<T>*)A.Offset)[i]; r.a = A.Angle[i];
-    if (LATTICE) r.u = V2<T>{0, 0}; else r.u = ((const V2<T>*)A.UrShape)[i];
-    if (NEEDC) r.cc = ((const V2<T>*)A.Constraints)[i]; else r.cc = V2<T>{0, 0};
-    return r;
-}
-template <class T, bool LATTICE>
-__device__ __forceinline__ MPx<T> iw_marchCombine(const MRaw<T>& r) {
-    MPx<T> p;
-    p.ox = r.o.x; p.oy = r.o.y;
-    sincosT(r.a, &p.s, &p.c);                     // the same sincos as iw_cossin: the values the table would hold
-    if (LATTICE) { p.ux = 0; p.uy = 0; } else { p.ux = r.u.x; p.uy = r.u.y; }
-    p.f = r.ok ? r.f : 0;
-    return p;
-}
-// workgroup -> (column strip, row range) as in iw_applyJTJ
-struct MarchGeo { int x, yb, ye; bool xok, writer; };
-template <class T>
-__device__ __forceinline__ MarchGeo marchGeo(const IWArgs<T>& A, int rowsPerGroup, int gx, int gy) {
-    MarchGeo g;
-    const int bx = blockIdx.x % gx, by = blockIdx.x / gx;
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    g.x = bx * kStrip + wave * kSpan + lane - 1;
-    g.xok = g.x >= 0 && g.x < A.W;
-    g.writer = g.xok && lane >= 1 && lane <= kSpan;
-    g.yb = A.yBegin + by * rowsPerGroup;
-    g.ye = min(g.yb + rowsPerGroup, A.yEnd);
-    if (by >= gy) g.yb = g.ye = A.yEnd;
-    return g;
-}
-
-// flags + lattice verdict.  notLattice: pinned host word, zeroed by the host before the launch; any workgroup that finds a violation stores 1.
-template <class T, bool CHECK>
-__global__ __launch_bounds__(kBlock) void iw_bindMarch(IWArgs<T> A, int* __restrict__ notLattice, int rowsPerGroup, int gx, int gy) {
-    const MarchGeo g = marchGeo(A, rowsPerGroup, gx, gy);
-    struct R { T m; V2<T> c, u; int ok; };
-    auto load = [&](int y) {
-        R r;
-        r.ok = g.xok && y >= 0 && y < A.H && (A.gy0 + y) >= 0 && (A.gy0 + y) < A.Hg;      // the pixel exists in the (global) image
-        const long i = (long)min(max(y, 0), A.H - 1) * A.W + min(max(g.x, 0), A.W - 1);
-        r.m = A.Mask[i]; r.c = ((const V2<T>*)A.Constraints)[i];
-        if (CHECK) r.u = ((const V2<T>*)A.UrShape)[i]; else r.u = V2<T>{0, 0};
-        return r;
-    };
-    struct P { int act, fit, ok; T ux, uy; };
-    auto combine = [&](const R& r) {
-        P p;
-        p.ok = r.ok; p.act = (r.ok && r.m == T(0)) ? 1 : 0;                               // eq(Mask,0)  (image_warping.t:11,17)
-        p.fit = (r.c.x >= T(0) && r.c.y >= T(0)) ? 1 : 0;                                 // All(greatereq(C,0)) (:22)
-        p.ux = r.u.x; p.uy = r.u.y;
-        return p;
-    };
-    P up = combine(load(g.yb - 1)), cur = combine(load(g.yb));
-    bool bad = false;
-    auto row = [&](int y, const R& rdn, bool live) {
-        const P dn = combine(rdn);
-        const int aR = dppShift<false>(cur.act), aL = dppShift<true>(cur.act);
-        const int cnt = aR + aL + dn.act + up.act;
-        if (CHECK) {
-            const T rx = dppShift<false>(cur.ux), ry = dppShift<false>(cur.uy);
-            const int rok = dppShift<false>(cur.ok);
-            if (g.writer && live && cur.ok) {
-                if (rok && g.x + 1 < A.W) bad |= !(cur.ux - rx == T(-1) && cur.uy - ry == T(0));
-                if (dn.ok) bad |= !(cur.ux - dn.ux == T(0) && cur.uy - dn.uy == T(-1));
-            }
-        }
-        if (g.writer && live) A.flags[(long)y * A.W + g.x] = (uint8_t)((cur.act ? kActive : 0) | (cur.fit ? kFit : 0) | (cnt << kCountShift));
-        up = cur; cur = dn;
-    };
-    R rA = load(g.yb + 1), rB;
-    for (int y = g.yb; y < g.ye; y += 2) {
-        if (IW_ROW_SYNC) __syncthreads();
-        rB = load(y + 2);
-        row(y, rA, true);
-        rA = load(y + 3);
-        row(y + 1, rB, y + 1 < g.ye);
-    }
-    if (CHECK && __any(bad) && (threadIdx.x & (kWave - 1)) == 0) __hip_atomic_store(notLattice, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// r = -J^T F, p = guardedInvert(diag J^T J) r, partial sums of r.p; LATTICE = false additionally writes the compact preconditioner {M_O, M_a}
-template <class T, bool LATTICE>
-__global__ __launch_bounds__(kBlock) void iw_jtfMarch(IWArgs<T> A, T* __restrict__ r, T* __restrict__ p, T* __restrict__ mc, double* __restrict__ partials,
-                                                      int rowsPerGroup, int gx, int gy) {
-    __shared__ double scratch[kBlock / kWave + 1];
-    const MarchGeo g = marchGeo(A, rowsPerGroup, gx, gy);
-    const long N = (long)A.W * A.H;
-    V2<T>* rO = (V2<T>*)r; T* ra = r + 2 * N; V2<T>* pO = (V2<T>*)p; T* pa = p + 2 * N;
-    const T w = A.w_reg;
-    double acc = 0;
-    MPx<T> up = iw_marchCombine<T, LATTICE>(iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, g.yb - 1));
-    MRaw<T> rawCur = iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, g.yb);
-    MPx<T> cur = iw_marchCombine<T, LATTICE>(rawCur);
-    V2<T> ccCur = rawCur.cc;
-    T Fx, Fy, Fa, Pxy, Pa;
-    auto pair = [&](const MPx<T>& c, const MPx<T>& n, T dux, T duy) {       // iw_evalJTF's loop body for one direction; (dux, duy) = U_c - U_n on a unit lattice
-        if (!(n.f & kActive)) return;
-        const T ux = LATTICE ? dux : c.ux - n.ux, uy = LATTICE ? duy : c.uy - n.uy;
-        const T ex = w * ((c.ox - n.ox) - (c.c * ux - c.s * uy));
-        const T ey = w * ((c.oy - n.oy) - (c.s * ux + c.c * uy));
-        const T hx = w * ((n.ox - c.ox) + (n.c * ux - n.s * uy));
-        const T hy = w * ((n.oy - c.oy) + (n.s * ux + n.c * uy));
-        Fx += w * ex - w * hx; Fy += w * ey - w * hy;
-        const T Dx = -c.s * ux - c.c * uy, Dy = c.c * ux - c.s * uy;
-        Fa += -(w * Dx) * ex - (w * Dy) * ey;
-        Pxy += w * w + w * w;
-        Pa += (w * Dx) * (w * Dx) + (w * Dy) * (w * Dy);
-    };
-    auto row = [&](int y, const MRaw<T>& rdn, bool live) {
-        const MPx<T> dn = iw_marchCombine<T, LATTICE>(rdn);
-        const MPx<T> lf = dppShiftM<true, LATTICE>(cur), rt = dppShiftM<false, LATTICE>(cur);
-        Fx = 0; Fy = 0; Fa = 0; Pxy = 0; Pa = 0;
-        if (cur.f & kActive) {
-            pair(cur, rt, T(-1), T(0)); pair(cur, lf, T(1), T(0)); pair(cur, dn, T(0), T(-1)); pair(cur, up, T(0), T(1));
-            if (cur.f & kFit) {
-                Fx += A.w_fit * (A.w_fit * (cur.ox - ccCur.x)); Fy += A.w_fit * (A.w_fit * (cur.oy - ccCur.y));
-                Pxy += A.w_fit * A.w_fit;
-            }
-        }
-        if (g.writer && live) {
-            const long i = (long)y * A.W + g.x;
-            const T r0 = -Fx, r1 = -Fy, r2 = -Fa;
-            const T sO = T(1) + sqrt(Pxy), sA = T(1) + sqrt(Pa);
-            const T mO = T(1) / (sO * sO), mA = T(1) / (sA * sA);         // solver.hip guardedInvert (solver.t:323-332)
-            const T p0 = mO * r0, p1 = mO * r1, p2 = mA * r2;
-            rO[i] = V2<T>{r0, r1}; ra[i] = r2;
-            pO[i] = V2<T>{p0, p1}; pa[i] = p2;
-            if (!LATTICE) mc[i] = mA;      // the compact preconditioner of the general kernel: M_a only (M_O comes from the flag byte, see iw_pcgIter2)
-            acc += (double)(r0 * p0) + (double)(r1 * p1) + (double)(r2 * p2);
-        }
-        up = cur; cur = dn; ccCur = rdn.cc;
-    };
-    MRaw<T> rA = iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, g.yb + 1), rB;
-    for (int y = g.yb; y < g.ye; y += 2) {
-        if (IW_ROW_SYNC) __syncthreads();
-        rB = iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, y + 2);
-        row(y, rA, true);
-        rA = iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, y + 3);
-        row(y + 1, rB, y + 1 < g.ye);
-    }
-    const double t = blockReduceSum(acc, scratch);
-    if (threadIdx.x == 0) partials[blockIdx.x] = t;
-}
-
-// 1/2 sum r^2 over the non-excluded pixels of the workgroup's rows (iw_cost's expressions)
-template <class T, bool LATTICE>
-__global__ __launch_bounds__(kBlock) void iw_costMarch(IWArgs<T> A, double* __restrict__ partials, int rowsPerGroup, int gx, int gy) {
-    __shared__ double scratch[kBlock / kWave + 1];
-    const MarchGeo g = marchGeo(A, rowsPerGroup, gx, gy);
-    double acc = 0;
-    MPx<T> up = iw_marchCombine<T, LATTICE>(iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, g.yb - 1));
-    MRaw<T> rawCur = iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, g.yb);
-    MPx<T> cur = iw_marchCombine<T, LATTICE>(rawCur);
-    V2<T> ccCur = rawCur.cc;
-    T e;
-    auto pair = [&](const MPx<T>& c, const MPx<T>& n, T dux, T duy) {
-        if (!(n.f & kActive)) return;
-        const T ux = LATTICE ? dux : c.ux - n.ux, uy = LATTICE ? duy : c.uy - n.uy;
-        const T ex = A.w_reg * ((c.ox - n.ox) - (c.c * ux - c.s * uy));
-        const T ey = A.w_reg * ((c.oy - n.oy) - (c.s * ux + c.c * uy));
-        e += ex * ex + ey * ey;
-    };
-    auto row = [&](int y, const MRaw<T>& rdn, bool live) {
-        const MPx<T> dn = iw_marchCombine<T, LATTICE>(rdn);
-        const MPx<T> lf = dppShiftM<true, LATTICE>(cur), rt = dppShiftM<false, LATTICE>(cur);
-        e = 0;
-        if (cur.f & kActive) {       // excluded pixel: its residuals are not part of the cost (solver.t:583)
-            pair(cur, rt, T(-1), T(0)); pair(cur, lf, T(1), T(0)); pair(cur, dn, T(0), T(-1)); pair(cur, up, T(0), T(1));
-            if (cur.f & kFit) {
-                const T fx = A.w_fit * (cur.ox - ccCur.x), fy = A.w_fit * (cur.oy - ccCur.y);
-                e += fx * fx + fy * fy;
-            }
-        }
-        if (g.writer && live) acc += (double)(T(0.5) * e);
-        up = cur; cur = dn; ccCur = rdn.cc;
-    };
-    MRaw<T> rA = iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, g.yb + 1), rB;
-    for (int y = g.yb; y < g.ye; y += 2) {
-        if (IW_ROW_SYNC) __syncthreads();
-        rB = iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, y + 2);
-        row(y, rA, true);
-        rA = iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, y + 3);
-        row(y + 1, rB, y + 1 < g.ye);
-    }
-    const double t = blockReduceSum(acc, scratch);
-    if (threadIdx.x == 0) partials[blockIdx.x] = t;
-}
-
-// End of a Gauss-Newton linear solve in one pass over the unknowns: the deferred term of the paired delta update (if owed), the last PCGStep2's
-// delta += alpha p (solver.t:461-462) and PCGLinearUpdate X += delta (:552-557) -- X = X + ((delta [+ a2 p2]) + a1 p1), the reference's order of
-// additions.  delta itself is dead after the update and is not written back.  a1 = alphaNum / alphaDen of the last launch (guarded like PCGStep2's).
-template <class T>
-__global__ __launch_bounds__(kBlock) void iw_finishUpdate(T* __restrict__ XO, T* __restrict__ XA, const T* __restrict__ delta, const T* __restrict__ p1, const T* __restrict__ p2,
-                                                          const T* __restrict__ alpha2, long N, const double* __restrict__ aNumPartials, int nNum,
-                                                          const double* __restrict__ aDenPartials, int nDen) {
-    __shared__ double scratch[2 * (kBlock / kWave + 1)];
-    const double* const ps[2] = {aNumPartials, aDenPartials}; const int ns[2] = {nNum, nDen}; double o2[2];
-    sumPartialsN<2>(ps, ns, scratch, o2);
-    const T aNum = (T)o2[0], aDen = (T)o2[1];
-    const T a1 = (aDen > T(0)) ? aNum / aDen : T(0);
-    const T a2 = p2 ? alpha2[0] : T(0);
-    const V2<T>* dO = (const V2<T>*)delta; const T* dA = delta ? delta + 2 * N : nullptr;      // delta == nullptr: it stands for 0 (no launch of the loop has written it)
-    const V2<T>* qO = (const V2<T>*)p1; const T* qA = p1 + 2 * N;
-    const V2<T>* sO = (const V2<T>*)p2; const T* sA = p2 ? p2 + 2 * N : nullptr;
-    V2<T>* xO = (V2<T>*)XO;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
-        V2<T> d{0, 0}; T da = 0;
-        if (delta) { d = dO[i]; da = dA[i]; }
-        const V2<T> q = qO[i]; const T qa = qA[i];
-        const V2<T> x = xO[i]; const T xa = XA[i];
-        if (p2) { const V2<T> s = sO[i]; const T sa = sA[i]; d.x = d.x + a2 * s.x; d.y = d.y + a2 * s.y; da = da + a2 * sa; }
-        d.x = d.x + a1 * q.x; d.y = d.y + a1 * q.y; da = da + a1 * qa;
-        xO[i] = V2<T>{x.x + d.x, x.y + d.y}; XA[i] = xa + da;
-    }
-}
-
-// ---- one whole PCG iteration per launch (energy.h PcgIterArgs) --------------------------------------------------
-// Same marching / DPP / prefetch structure as iw_applyJTJ; per pixel it additionally applies the previous
-// iteration's PCGStep2 and PCGStep3 before the stencil, so the PCG loop is ONE kernel per iteration moving
-// r 12 + Ap 12 + p 12 + delta 12 + pre 12 (8 compact) + (cos,sin) 8 + U 8 (0 on a lattice) + flags 1 in and r, p, delta, Ap 48 out = 113-125 B/pixel
-// (three reference kernels: 180 B/pixel algorithmic).
-// The sums behind the expanded beta numerator  sum M (r - alpha Ap)^2 = [sum M r^2] - 2 alpha [sum M r Ap] + alpha^2 [sum M Ap^2]  must be CONSISTENT to far below
-// float precision: when the residual collapses in one iteration (stiff fit pixels: beta ~ 1e-8) the three terms cancel to eight digits, and products
-// rounded to float -- or a z = fl(M r) rounded before it enters two of the three sums -- leave an error of ~1e-9 sum M r^2, i.e. tens of per cent of
-// beta (round 3: profiles/r03_horizon_parity.md, adversarial family: 4.6e-2 of cost after 20 iterations against 4e-4 for the three-kernel loop).  So every
-// term is formed from the same M, r, Ap in double, where a product of two floats is exact: the expansion then equals the direct sum of the reference's
-// PCGStep2 up to the rounding of z and r themselves (1e-7 relative, no amplification).
-#ifndef IW_EXACT_SUMS
-#define IW_EXACT_SUMS 1      // 0: products in opt_float (round 2), A/B builds only (opt_amd/build.py build_variant)
-#endif
-template <class T> __device__ __forceinline__ double dprod3(T m, T a, T b) { return IW_EXACT_SUMS ? ((double)m * (double)a) * (double)b : (double)((m * a) * b); }
-
-template <class T>
-struct IterRaw {           // one pixel's loads, untouched (any ALU op here would force a wait before the loop back-edge)
-    V2<T> ro, ao, po, mo, cs, u, dO; T ra, aa, pa, ma, dA;   // r, Ap, p, pre (Offset part / Angle part), table, UrShape, delta
-    V2<T> co; T ca;                                          // CtC (Levenberg-Marquardt only)
-    int f, ok;
-};
-template <class T>
-struct IterPx {            // what the stencil needs (Px) + what the sums / stores need
-    Px<T> p;               // p_new, cos/sin, U, flags
-    T zx, zy, za;          // z = M r_new
-    T rx, ry, ra;          // r_new (the expansion sums use M, r, Ap themselves: dprod3)
-    T mx, my, ma;          // M
-};
-template <class T>
-struct IterK {             // kernel argument block
-    const T *rOld, *ApOld, *pOld; T *rNew, *ApNew, *pNew; T* delta; const T* pre; int first;
-    const T* mc;           // compact preconditioner {M_O, M_a} per pixel (M_O.x == M_O.y for this energy), or nullptr
-    int flip;              // 1: sweep bottom-up (the kernel works in mirrored row coordinates, see iw_pcgIter)
-    // iw_pcgIter2 only.  deltaMode 0: delta += alpha_{k-1} p_{k-1} in every launch.  Paired: 2 = this launch leaves delta alone,
-    // 1 = this launch applies the two pending terms alpha_{k-2} p_{k-2} + alpha_{k-1} p_{k-1}, reading p_{k-2} from the pNew buffer
-    // just before overwriting it (same thread, same address) -- 12 B/px extra every second launch instead of 24 B/px every launch.
-    int deltaMode; const T* alphaIn; T* alphaOut;   // alpha_{k-2} (written by the previous launch) / where this launch leaves alpha_{k-1}; [2] of either: the launch's beta
-    int reconP;            // deltaMode 1: rebuild p_{k-2} from the p_{k-1}, r_{k-1} this launch loads anyway instead of reading it (see the kernel)
-    // iw_pcgIter2, Gauss-Newton: r is not kept in memory at all.  p_{k-1} = M r_{k-1} + beta_{k-2} p_{k-2} determines r_{k-1} from the last two search
-    // directions, so the state of the loop is a ring of three p buffers: a launch reads p_{k-1} and p_{k-2} (through rOld), rebuilds r_{k-1}, and writes p_k
-    // only: 12 B/px less traffic per launch.  rfree = 0: r in memory (rOld / rNew);  1: rOld holds p_{k-2}, r rebuilt;  2: the first two launches of a
-    // linear solve -- rOld still holds the solver's true r_0, nothing to rebuild, but r is not written either.
-    int rfree;
-    // Levenberg-Marquardt variant of iw_pcgIter2 (energy.h PcgIterArgs): CtC, b, the Q partial sums, and the after-reset mode
-    const T* CtC; const T* b; double* q; unsigned qTag; int afterReset; const double* betaNum; int nBetaNum; const double* betaDen; int nBetaDen;
-    T* deltaOut;           // where the updated delta is written (== delta: in place)
-    T lmRadius, lmMin, lmMax;   // PRE == 3 with LM: CtC and the LM preconditioner are rebuilt from the flag byte (see the kernel)
-    const double *aNumPrev, *aDenPrev, *s2Prev, *s3Prev; int nNum, nDen, n2, n3;
-    double *aNum, *aDen, *s2, *s3;
-    // iw_pcgIter2 in slab mode: the launch may update r and p on some ghost rows too (A.yBegin / A.yEnd then include them) so that the
-    // neighbours' rows are needed only every few launches; the sums and delta stay on the owned rows [ownBegin, ownEnd) (image rows)
-    int ownBegin, ownEnd;
-    MailRefDev mail;       // slab mode, posted all-reduce: where the prologue polls the previous launch's four sums (words == nullptr: they are in aNumPrev .. s3Prev)
-    MailPostDev post;      // ... and where this launch's last workgroup posts its own four sums (world == 0: it does not)
-    int deltaZero;         // the delta buffer has not been written since PCGInit1 and stands for 0 (evalJTFInit skips the memset); honoured by the MODE 0 kernels only
-};
-
-// PRE: 0 = identity preconditioner, 1 = the solver's 3-channel one (12 B/px), 2 = compact {M_O, M_a} (8 B/px).  A template
-// parameter, not a test of K.mc / K.pre: a load inside a (even uniform) branch costs an s_waitcnt vmcnt(0) at the merge.
-template <class T, bool LATTICE, int PRE, bool ANGLE = false, bool LMV = false>
-__device__ __forceinline__ IterRaw<T> iw_iterLoad(const IWArgs<T>& A, const IterK<T>& K, long N, bool xok, int x, int y) {
-    IterRaw<T> r;
-    r.ok = xok && y >= 0 && y < A.H;
-    const int yc = min(max(y, 0), A.H - 1);
-    const long i = (long)(K.flip ? A.H - 1 - yc : yc) * A.W + min(max(x, 0), A.W - 1);
-    r.f = A.flags[i];
-    r.ro = ld2<kNTL>((const V2<T>*)K.rOld, i); r.ra = ld1<kNTL>(K.rOld + 2 * N, i);
-    r.ao = ld2<kNTL>((const V2<T>*)K.ApOld, i); r.aa = ld1<kNTL>(K.ApOld + 2 * N, i);
-    r.po = ld2<kNTL>((const V2<T>*)K.pOld, i); r.pa = ld1<kNTL>(K.pOld + 2 * N, i);
-    if (PRE == 3) { r.mo = V2<T>{0, 0}; r.ma = 0; }
-    else if (PRE == 2) { r.mo = V2<T>{0, 0}; r.ma = ld1<kNTL>(K.mc, i); }      // compact: M_a only (4 B/px); M_O from the flag byte
-    else if (PRE == 1) { r.mo = ld2<kNTL>((const V2<T>*)K.pre, i); r.ma = ld1<kNTL>(K.pre + 2 * N, i); }
-    else { r.mo = V2<T>{1, 1}; r.ma = 1; }
-    if (LMV) { r.co = ld2<kNTL>((const V2<T>*)K.CtC, i); r.ca = ld1<kNTL>(K.CtC + 2 * N, i); } else { r.co = V2<T>{0, 0}; r.ca = 0; }
-    if (ANGLE) { r.cs.x = ld1<kNTL>(A.Angle, i); r.cs.y = 0; }     // iw_pcgIter2: the 4 B/px angle instead of the 8 B/px (cos, sin) table
-    else r.cs = ld2<kNTL>((const V2<T>*)A.cs, i);
-    if (LATTICE) r.u = V2<T>{0, 0}; else r.u = ld2<kNTL>((const V2<T>*)A.UrShape, i);
-#ifndef IW_DELTA_NT
-#define IW_DELTA_NT 1
-#endif
-    // delta: read where it is written (IW_DELTA_LATE=1) rather than prefetched with the row -- measured equal or +3 % (interleaved
-    // A/B, 3 rounds, on a box where the prefetched form lost that much); the prefetched form is kept for comparison.
-#ifndef IW_DELTA_LATE
-#define IW_DELTA_LATE 1
-#endif
-    if (IW_DELTA_LATE) { r.dO = V2<T>{0, 0}; r.dA = 0; }
-    else { r.dO = ld2<IW_DELTA_NT != 0>((const V2<T>*)K.delta, i); r.dA = ld1<IW_DELTA_NT != 0>(K.delta + 2 * N, i); }     // prefetched with the row (was a load-wait-store inside the row)
-    return r;
-}
-// Row addressing of iw_pcgIter2 through buffer descriptors: element (row, x) of an array is  descriptor(base)  +  soffset = row * W * size (+ the offset of
-// the Angle part), one SALU product shared by all arrays of a row  +  voffset = x * size, a per-lane constant of the whole launch.  A load or store then
-// needs no address VALU at all, against a 64-bit multiply-add plus a 64-bit shift-add per array and row with pointers (20 of the kernel's 300 VALU
-// instructions per pixel-row -- and the kernel is VALU-bound on slabs and small images).  Byte offsets are 32-bit: the launcher takes this
-// form only while 3 * W * H * sizeof(V2<T>) / 2 < 2^32.
-#ifndef IW_BUFADDR
-#define IW_BUFADDR 1
-#endif
-#ifndef IW_REGCOPY
-#define IW_REGCOPY 1      // see regCopy
-#endif
-typedef unsigned int iw_u2 __attribute__((ext_vector_type(2)));
-typedef unsigned int iw_u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t iw_rsrc(const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1 /* 2^32 - 1 bytes */, 0x00020000); }
-__device__ __forceinline__ V2<float> bufLd2(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, const float*) { const iw_u2 w = __builtin_amdgcn_raw_buffer_load_b64(r, (int)v, (int)so, 0); return V2<float>{__uint_as_float(w.x), __uint_as_float(w.y)}; }
-__device__ __forceinline__ V2<double> bufLd2(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, const double*) { const iw_u4 w = __builtin_amdgcn_raw_buffer_load_b128(r, (int)v, (int)so, 0); V2<double> o; __builtin_memcpy(&o, &w, 16); return o; }
-__device__ __forceinline__ float bufLd1(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, const float*) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)v, (int)so, 0)); }
-__device__ __forceinline__ double bufLd1(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, const double*) { const iw_u2 w = __builtin_amdgcn_raw_buffer_load_b64(r, (int)v, (int)so, 0); double o; __builtin_memcpy(&o, &w, 8); return o; }
-__device__ __forceinline__ void bufSt2(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, float x, float y) { __builtin_amdgcn_raw_buffer_store_b64(iw_u2{__float_as_uint(x), __float_as_uint(y)}, r, (int)v, (int)so, 0); }
-__device__ __forceinline__ void bufSt2(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, double x, double y) { const V2<double> o{x, y}; iw_u4 w; __builtin_memcpy(&w, &o, 16); __builtin_amdgcn_raw_buffer_store_b128(w, r, (int)v, (int)so, 0); }
-__device__ __forceinline__ void bufSt1(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, float x) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, (int)v, (int)so, 0); }
-__device__ __forceinline__ void bufSt1(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, double x) { iw_u2 w; __builtin_memcpy(&w, &x, 8); __builtin_amdgcn_raw_buffer_store_b64(w, r, (int)v, (int)so, 0); }
-template <class T>
-struct IterBufs {          // descriptors of the arrays iw_pcgIter2 touches row by row, and the per-lane parts of the offsets
-    __amdgpu_buffer_rsrc_t rOld, pOld, pNew, rNew, delta, deltaOut, angle, flags, mc, pre, ctc, b, ur;
-    unsigned x2, x1, x0;   // x * sizeof(V2<T>), x * sizeof(T), x  (x clamped into the row)
-    unsigned aPart;        // 2 * N * sizeof(T): where the Angle part of a solver vector starts
-};
-// iw_iterLoad for iw_pcgIter2 (no A p, the 4 B angle) in that addressing
-template <class T, bool LATTICE, int PRE, bool LMV>
-__device__ __forceinline__ IterRaw<T> iw_iterLoadBuf(const IWArgs<T>& A, const IterK<T>& K, const IterBufs<T>& B, bool xok, int y) {
-    IterRaw<T> r;
-    r.ok = xok && y >= 0 && y < A.H;
-    const int yc = min(max(y, 0), A.H - 1);
-    const unsigned row = (unsigned)(K.flip ? A.H - 1 - yc : yc) * (unsigned)A.W;      // wave-uniform
-    const unsigned s2 = row * (unsigned)sizeof(V2<T>), s1 = row * (unsigned)sizeof(T), s1a = s1 + B.aPart;
-    const T* tag = nullptr;
-    r.f = __builtin_amdgcn_raw_buffer_load_b8(B.flags, (int)B.x0, (int)row, 0);
-    r.ro = bufLd2(B.rOld, B.x2, s2, tag); r.ra = bufLd1(B.rOld, B.x1, s1a, tag);
-    r.ao = V2<T>{0, 0}; r.aa = 0;
-    r.po = bufLd2(B.pOld, B.x2, s2, tag); r.pa = bufLd1(B.pOld, B.x1, s1a, tag);
-    if (PRE == 3) { r.mo = V2<T>{0, 0}; r.ma = 0; }
-    else if (PRE == 2) { r.mo = V2<T>{0, 0}; r.ma = bufLd1(B.mc, B.x1, s1, tag); }      // compact: M_a only (4 B/px); M_O from the flag byte
-    else if (PRE == 1) { r.mo = bufLd2(B.pre, B.x2, s2, tag); r.ma = bufLd1(B.pre, B.x1, s1a, tag); }
-    else { r.mo = V2<T>{1, 1}; r.ma = 1; }
-    if (LMV) { r.co = bufLd2(B.ctc, B.x2, s2, tag); r.ca = bufLd1(B.ctc, B.x1, s1a, tag); } else { r.co = V2<T>{0, 0}; r.ca = 0; }
-    r.cs.x = bufLd1(B.angle, B.x1, s1, tag); r.cs.y = 0;
-    if (LATTICE) r.u = V2<T>{0, 0}; else r.u = bufLd2(B.ur, B.x2, s2, tag);
-    r.dO = V2<T>{0, 0}; r.dA = 0;
-    return r;
-}
-
-#ifndef ITER_MIN_WAVES
-#define ITER_MIN_WAVES 1
-#endif
-// Workgroup size of the single-kernel iteration.  Measured at 4096^2 (interleaved A/B on one box, PCG it/s):
-// 256 threads 2090, 512 threads 2220-2370, 1024 threads 2200; a workgroup barrier every two rows (IW_ROW_SYNC=1:
-// keeps the strip's waves on the same rows, so the cache lines they share at the 62-pixel seams are fetched while
-// still hot) is worth +15 % over free-running waves, every row (=2) no better.
-#ifndef ITER_BLOCK
-#define ITER_BLOCK 512
-#endif
-constexpr int kIterBlock = ITER_BLOCK;
-constexpr int kIterStrip = (kIterBlock / kWave) * kSpan;
-// Sweep direction.  Successive launches alternate top-down / bottom-up (K.flip): the rows a launch finishes with -- inputs
-// it just read and r / p / Ap / delta it just wrote -- are the ones still resident in the 256 MB Infinity Cache (and L2)
-// when the next launch starts, so the next launch starts there.  A flipped launch runs the identical code in mirrored
-// row coordinates (logical row y <-> image row H-1-y; the slab bounds mirror too); only addresses go through phys().
-// The two vertical stencil terms are taken in image order in both directions, so Ap is bitwise independent of the sweep.
-template <class T, bool LATTICE, int PRE>
-__global__ __launch_bounds__(kIterBlock, ITER_MIN_WAVES) void iw_pcgIter(IWArgs<T> A, IterK<T> K, int rowsPerGroup, int gx, int gy) {
-    __shared__ double scratch[kIterBlock / kWave + 1];
-    const long N = (long)A.W * A.H;
-    // scalars of the previous iteration (solver.t:456-459, 544-547 guards), betaNumerator by expansion (energy.h)
-    T alpha = 0, beta = 0;
-    const bool first = K.first != 0;
-    if (!first) {
-        const double aNumD = sumPartials(K.aNumPrev, K.nNum, scratch), aDenD = sumPartials(K.aDenPrev, K.nDen, scratch);
-        const double s2 = sumPartials(K.s2Prev, K.n2, scratch), s3 = sumPartials(K.s3Prev, K.n3, scratch);
-        const T aNum = (T)aNumD, aDen = (T)aDenD;
-        alpha = (aDen > T(0)) ? aNum / aDen : T(0);
-        // betaNumerator = sum M r_k^2 by expansion (energy.h); the reference's direct sum cannot be negative, so cancellation
-        // noise below zero (residual dropping by >~1e3 in one iteration) is clamped away
-        const double bNumD = fmax(aNumD - 2.0 * (double)alpha * s2 + (double)alpha * (double)alpha * s3, 0.0);
-        beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
-    }
-    const int bx = blockIdx.x % gx, by = blockIdx.x / gx;
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    const int x = bx * kIterStrip + wave * kSpan + lane - 1;
-    const bool xok = x >= 0 && x < A.W;
-    const bool writer = xok && lane >= 1 && lane <= kSpan;
-    const bool flip = K.flip != 0;
-    const int lyBegin = flip ? A.H - A.yEnd : A.yBegin, lyEnd = flip ? A.H - A.yBegin : A.yEnd;     // owned rows, logical
-    auto phys = [&](int y) { return flip ? A.H - 1 - y : y; };
-    const int yb = lyBegin + by * rowsPerGroup;
-    const int ye = min(yb + rowsPerGroup, lyEnd);
-    const T w2 = A.w_reg * A.w_reg, wf2 = A.w_fit * A.w_fit;
-    double accDen = 0, accNum = 0, acc2 = 0, acc3 = 0;
-    V2<T>* rO = (V2<T>*)K.rNew; T* rA = K.rNew + 2 * N; V2<T>* pO = (V2<T>*)K.pNew; T* pA = K.pNew + 2 * N;
-    V2<T>* dO = (V2<T>*)K.delta; T* dA = K.delta + 2 * N; V2<T>* aO = (V2<T>*)K.ApNew; T* aA = K.ApNew + 2 * N;
-
-    // Step2 + Step3 of the previous iteration for one pixel; `own` rows also store r, p, delta and feed alphaNum
-    auto combine = [&](const IterRaw<T>& w, int y, bool own) {
-        IterPx<T> q;
-        const T rx = first ? w.ro.x : w.ro.x - alpha * w.ao.x, ry = first ? w.ro.y : w.ro.y - alpha * w.ao.y, ra = first ? w.ra : w.ra - alpha * w.aa;
-        static_assert(PRE != 2 && PRE != 3, "iw_pcgIter streams the full preconditioner vector (PRE 1) or none (PRE 0)");
-        q.mx = regCopy(w.mo.x); q.my = regCopy(w.mo.y); q.ma = regCopy(w.ma);
-        q.zx = q.mx * rx; q.zy = q.my * ry; q.za = q.ma * ra;
-        q.rx = rx; q.ry = ry; q.ra = ra;
-        q.p.ox = q.zx + beta * w.po.x; q.p.oy = q.zy + beta * w.po.y; q.p.a = q.za + beta * w.pa;
-        q.p.c = regCopy(w.cs.x); q.p.s = regCopy(w.cs.y); q.p.f = w.ok ? w.f : 0;
-        if (LATTICE) { q.p.ux = 0; q.p.uy = 0; } else { q.p.ux = regCopy(w.u.x); q.p.uy = regCopy(w.u.y); }
-        if (own && xok && y >= 0 && y < A.H) {
-            const long i = (long)phys(y) * A.W + x;
-            const bool ghost = y < lyBegin || y >= lyEnd;       // slab mode: ghost rows keep r / p current for the next launch
-            if (writer || (ghost && xok)) { st2<kNTS>(rO, i, rx, ry); st1<kNTS>(rA, i, ra); st2<kNTS>(pO, i, q.p.ox, q.p.oy); st1<kNTS>(pA, i, q.p.a); }
-            if (writer && !ghost) {
-                if (!first) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462); stores only inside the branch
-                    if (IW_DELTA_LATE) { const V2<T> d = dO[i]; const T da = dA[i]; st2<kNTS>(dO, i, d.x + alpha * w.po.x, d.y + alpha * w.po.y); st1<kNTS>(dA, i, da + alpha * w.pa); }
-                    else { st2<kNTS>(dO, i, w.dO.x + alpha * w.po.x, w.dO.y + alpha * w.po.y); st1<kNTS>(dA, i, w.dA + alpha * w.pa); }
-                }
-                accNum += dprod3(q.mx, rx, rx) + dprod3(q.my, ry, ry) + dprod3(q.ma, ra, ra);
-            }
-        }
-        return q;
-    };
-    IterPx<T> up = combine(iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, yb - 1), yb - 1, yb == lyBegin && yb - 1 >= 0);
-    IterPx<T> cur = combine(iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, yb), yb, yb < ye);
-    auto row = [&](int y, const IterRaw<T>& rdn, bool live) {
-        const IterPx<T> dn = combine(rdn, y + 1, live && y + 1 < A.H && (y + 1 < ye || y + 1 == lyEnd));
-        const long i = (long)phys(y) * A.W + x;
-        const Px<T> lf = dppShiftPx<true>(cur.p), rt = dppShiftPx<false>(cur.p);
-        const Px<T> below = flip ? up.p : dn.p, above = flip ? dn.p : up.p;     // image row y+1 / y-1 whichever way the sweep runs
-        T ax = 0, ay = 0, aa = 0;
-        if (LATTICE) {
-            iw_pairLattice<1, 0>(cur.p, rt, ax, ay, aa); iw_pairLattice<-1, 0>(cur.p, lf, ax, ay, aa);
-            iw_pairLattice<0, 1>(cur.p, below, ax, ay, aa); iw_pairLattice<0, -1>(cur.p, above, ax, ay, aa);
-        } else {
-            iw_pair(cur.p, rt, ax, ay, aa); iw_pair(cur.p, lf, ax, ay, aa); iw_pair(cur.p, below, ax, ay, aa); iw_pair(cur.p, above, ax, ay, aa);
-        }
-        T ox = w2 * ax, oy = w2 * ay, oa = w2 * aa;
-        const bool fit = (cur.p.f & kFit) != 0;
-        ox += fit ? wf2 * cur.p.ox : T(0); oy += fit ? wf2 * cur.p.oy : T(0);
-        const bool act = (cur.p.f & kActive) != 0;
-        ox = act ? ox : T(0); oy = act ? oy : T(0); oa = act ? oa : T(0);
-        if (writer && live) {
-            accDen += (double)(cur.p.ox * ox + cur.p.oy * oy + cur.p.a * oa);
-            acc2 += dprod3(cur.mx, cur.rx, ox) + dprod3(cur.my, cur.ry, oy) + dprod3(cur.ma, cur.ra, oa);
-            acc3 += dprod3(cur.mx, ox, ox) + dprod3(cur.my, oy, oy) + dprod3(cur.ma, oa, oa);
-            st2<kNTS>(aO, i, ox, oy); st1<kNTS>(aA, i, oa);
-        }
-        up = cur; cur = dn;
-    };
-    // two rows per trip, no branch around a load (see iw_applyJTJ); an odd last row runs as a predicated no-op
-    IterRaw<T> rA2 = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, yb + 1), rB2;
-    for (int y = yb; y < ye; y += 2) {
-        if (IW_ROW_SYNC) __syncthreads();
-        rB2 = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, y + 2);
-        row(y, rA2, true);
-        if (IW_ROW_SYNC == 2) __syncthreads();
-        rA2 = iw_iterLoad<T, LATTICE, PRE>(A, K, N, xok, x, y + 3);
-        row(y + 1, rB2, y + 1 < ye);
-    }
-    double t;
-    t = blockReduceSum(accDen, scratch); if (threadIdx.x == 0) K.aDen[blockIdx.x] = t;
-    t = blockReduceSum(accNum, scratch); if (threadIdx.x == 0) K.aNum[blockIdx.x] = t;
-    t = blockReduceSum(acc2, scratch); if (threadIdx.x == 0) K.s2[blockIdx.x] = t;
-    t = blockReduceSum(acc3, scratch); if (threadIdx.x == 0) K.s3[blockIdx.x] = t;
-}
-
-// ---- the same iteration without Ap in memory ------------------------------------------------------------------
-// iw_pcgIter stores Ap_k only so that the NEXT launch can form r_{k+1} = r_k - alpha_k Ap_k (12 B/px written + 12 B/px
-// read of 118).  Ap_k = J^T J p_k is a pure function of p_k, which the next launch reads anyway, so iw_pcgIter2 recomputes
-// it: launch k reads r_{k-1}, p_{k-1} on a 2-pixel ring, forms Ap_{k-1} on the 1-ring (second stencil evaluation, VALU is
-// idle 80 % of the time in this kernel), then r_k, z_k, p_k there, and Ap_k on its own pixels for the dot products --
-// never written.  In this first form the state in memory is r, p, delta: per pixel per iteration 24 + 24 + 24 + M 8 + (cos,sin) 8 +
-// flags 1 = 89 B against 118 B (and 180 B for the three reference kernels); with M from the flag byte, (cos, sin) from the angle, delta
-// paired over two launches and r rebuilt from p_{k-1}, p_{k-2} (IterK::rfree) it is 53 B.  The recomputed Ap_{k-1} is the same
-// instruction sequence on the same inputs as the Ap_{k-1} whose dot products the previous launch reduced.
-// A wave covers 64 consecutive pixels and produces the inner 60 (p_k needs one DPP ring, Ap_k a second).  Rows: a
-// sliding window of three rows of p_{k-1} and three of p_k in registers; trip y turns the freshly loaded row y+2 into
-// Ap_{k-1}(y+1), p_k(y+1) and then Ap_k(y).  With row slabs it needs two ghost rows per side (r and p of the neighbours'
-// edge rows, exchanged by the solver after every launch); with one ghost row the solver falls back to iw_pcgIter.
-// Workgroup shape (two stencil evaluations per pixel, 150-170 VGPRs): 768 threads = 3 waves per SIMD is the best,
-// 3400 PCG it/s against 3030 (512), 3190 (1024: fewer registers per wave), 2840 (256); interleaved A/B on one box.
-#ifndef ITER2_BLOCK
-#define ITER2_BLOCK 768
-#endif
-constexpr int kIterBlock2 = ITER2_BLOCK;
-// ... for the float unit-lattice kernel (136-142 VGPRs: three waves per SIMD).  The general-UrShape kernel carries U per pixel and the double
-// kernels twice the registers; under the 168-VGPR cap of a 768-thread workgroup they spilled to scratch (36-170 B per lane in float, 300-1000 B
-// in double; the general path ran at half the lattice rate).  Those variants run 512 / 256 threads per workgroup (256 / 512 VGPRs available).
-#ifndef ITER2_BLOCK_GENERAL
-#define ITER2_BLOCK_GENERAL 512
-#endif
-#ifndef ITER2_BLOCK_DOUBLE
-#define ITER2_BLOCK_DOUBLE 256
-#endif
-// Round 2, after the addresses moved to buffer descriptors and the launch state of the steady-state variants to compile time: the general-UrShape Gauss-Newton
-// kernel with the compact preconditioner (PRE == 2, the path of any non-lattice input) is down to 169-171 VGPRs and fits a 768-thread workgroup with 8-12 B of
-// scratch per lane (60 B in the two start-up launches of a solve): 4096^2 254 -> 234 us, 2048^2 79 -> 67 us per iteration.  Its other variants (full M vector,
-// LM: 200+ VGPRs) stay at 512.
-#ifndef ITER2_BLOCK_GENERAL_GN
-#define ITER2_BLOCK_GENERAL_GN 768
-#endif
-template <class T, bool LATTICE, int PRE = 3, bool LM = false> struct IterBlk {
-    static constexpr int value = sizeof(T) == 8 ? ITER2_BLOCK_DOUBLE : LATTICE ? kIterBlock2 : (PRE == 2 && !LM) ? ITER2_BLOCK_GENERAL_GN : ITER2_BLOCK_GENERAL;
-};
-constexpr int kSpan2 = kWave - 4;
-// VALU matters in this kernel (two stencil evaluations per pixel), so its inner loop avoids selects and moves:
-//  * activity is a 0/1 multiplier (`on`), the fit weight a 0/w_fit^2 multiplier (`fw`): an inactive or non-existent
-//    neighbour drops out of an FMA instead of a v_cndmask (its fields are finite: clamped loads, zero-filled DPP edges);
-//  * on a unit lattice the derivative columns R'(a)(U_c - U_n) are +-(sin, cos) picked at compile time per direction;
-//  * the sweep direction is a template parameter; the row windows are rotated by name over three trips per loop
-//    pass (three prefetch buffers), so no register copies are needed at the back-edge;
-//  * the shifted cos / sin / on of a row are kept from its first use (centre of Ap_{k-1}) for its second (centre of Ap_k).
-template <bool RIGHT, bool LATTICE, class T> __device__ __forceinline__ void dppShiftConst(const Q<T>& p, Q<T>& q) {   // the fields that do not change between p_{k-1} and p_k
-    q.c = dppShift<RIGHT>(p.c); q.s = dppShift<RIGHT>(p.s); q.on = dppShift<RIGHT>(p.on);
-    if (LATTICE) { q.ux = 0; q.uy = 0; } else { q.ux = dppShift<RIGHT>(p.ux); q.uy = dppShift<RIGHT>(p.uy); }
-    q.fw = 0;
-}
-template <bool RIGHT, class T> __device__ __forceinline__ void dppShiftVec(const Q<T>& p, Q<T>& q) {
-    q.ox = dppShift<RIGHT>(p.ox); q.oy = dppShift<RIGHT>(p.oy); q.a = dppShift<RIGHT>(p.a);
-}
-template <class T>
-struct OldRow {            // one row of iteration k-1: p_{k-1} and, while still needed, r_{k-1}, M and (LM) CtC
-    Q<T> q;
-    T rx, ry, ra, mx, my, ma;
-    T cx, cy, ca;
-    T p2x, p2y, p2a;       // r-free loop: p_{k-2} of this pixel as loaded (the deferred delta term of an even launch needs it exactly)
-};
-template <class T>
-struct NewRow {            // one row of iteration k: p_k, z_k, M, and the shifted constant fields of its neighbours
-    Q<T> q;
-    T rx, ry, ra, mx, my, ma;      // r_k and M (z_k = M r_k is consumed where it is formed; the sums use M, r, Ap themselves: dprod3)
-    T cx, cy, ca;          // CtC (LM)
-    Q<T> lf, rt;           // only c, s, (ux, uy,) on are kept here
-};
-// (cos a, sin a) recomputed per pixel per launch from the 4 B angle instead of read from the 8 B table: +4.7 % PCG it/s
-// (the kernel has VALU to spare; measured interleaved on one box, 3633 -> 3804).
-#ifndef IW_SINCOS_INLINE
-#define IW_SINCOS_INLINE 1
-#endif
-constexpr bool kSinCosInline = IW_SINCOS_INLINE != 0;
-#ifndef IW_OWN_CHECK
-#define IW_OWN_CHECK 1      // 0: compile the owned-row tests of the slab mode out (single-GPU A/B of their cost; slabs then need OPT_AMD_SLAB_PERIOD=1)
-#endif
-// LM = true: the Levenberg-Marquardt loop (A = J^T J + diag(CtC), Q sums, restart after a residual reset); see energy.h PcgIterArgs.
-// MODE: the launch-to-launch state as a compile-time constant for the steady state of the Gauss-Newton r-free loop, where it only takes two values --
-// 0: read it from K (first launches, LM, r in memory, slabs' A/B switches);  1: rfree == 1, odd launch (delta left alone);  2: rfree == 1, even launch
-// (the two pending delta terms, p_{k-2} from registers).  The kernel is instruction-issue bound (VALU + SALU): every wave-uniform
-// `if` on K.deltaMode / K.rfree / K.first costs scalar compares and a branch per row, and the steady state runs thousands of rows of them.
-template <class T, bool LATTICE, int PRE, bool FLIP, bool LM = false, int MODE = 0>
-__global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), ITER_MIN_WAVES) void iw_pcgIter2(IWArgs<T> A, IterK<T> K, int rowsPerGroup, int gx, int gy) {
-    static_assert(MODE == 0 || !LM, "steady-state specialisations are Gauss-Newton only");
-    // (Measured and dropped: modes that read (cos a, sin a) from the 8 B/px table instead of the 4 B/px angle + inline sincos -- 206 instead of 235 VALU
-    // instructions per row -- run at exactly the same rate up to 4096x1024 / 2048^2 and 6 % slower at 4096^2: the kernel follows its memory skeleton at
-    // every size, profiles/r02j_issue_bound.md.)
-    const int kDeltaMode = MODE == 1 ? 2 : MODE == 2 ? 1 : K.deltaMode, kRfree = MODE ? 1 : K.rfree, kReconP = MODE ? 1 : K.reconP;
-    constexpr int kBlk = IterBlk<T, LATTICE, PRE, LM>::value, kStripW = (kBlk / kWave) * kSpan2;
-    __shared__ double scratch[5 * (kBlk / kWave + 1)];
-    const long N = (long)A.W * A.H;
-    const int bx = blockIdx.x % gx, by = blockIdx.x / gx;
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    const int x = bx * kStripW + wave * kSpan2 + lane - 2;
-    const bool xok = x >= 0 && x < A.W;
-    const bool writer = xok && lane >= 2 && lane < 2 + kSpan2;
-    const int lyBegin = FLIP ? A.H - A.yEnd : A.yBegin, lyEnd = FLIP ? A.H - A.yBegin : A.yEnd;     // owned rows (a slab's ghost rows are plain halo here)
-    const int yb = lyBegin + by * rowsPerGroup, ye = min(yb + rowsPerGroup, lyEnd);
-    // The first five rows are requested before anything else: they do not depend on the scalars of the previous launch, so their latency
-    // overlaps the prologue's own memory round trip (the partial sums another kernel just wrote) instead of following it (-1.5 us per launch).
-    constexpr bool kBuf = IW_BUFADDR != 0 && kSinCosInline && !kNTL && !kNTS;
-    IterBufs<T> Bf;
-    if (kBuf) {
-        const unsigned xc = (unsigned)min(max(x, 0), A.W - 1);
-        Bf.x2 = xc * (unsigned)sizeof(V2<T>); Bf.x1 = xc * (unsigned)sizeof(T); Bf.x0 = xc; Bf.aPart = (unsigned)(2 * N * (long)sizeof(T));
-        Bf.rOld = iw_rsrc(K.rOld); Bf.pOld = iw_rsrc(K.pOld); Bf.pNew = iw_rsrc(K.pNew); Bf.rNew = iw_rsrc(K.rNew); Bf.delta = iw_rsrc(K.delta); Bf.deltaOut = iw_rsrc(K.deltaOut);
-        Bf.angle = iw_rsrc(A.Angle); Bf.flags = iw_rsrc(A.flags); Bf.mc = iw_rsrc(K.mc); Bf.pre = iw_rsrc(K.pre); Bf.ctc = iw_rsrc(K.CtC); Bf.b = iw_rsrc(K.b); Bf.ur = iw_rsrc(A.UrShape);
-    }
-    auto loadRow = [&](int y) {
-        if constexpr (kBuf) return iw_iterLoadBuf<T, LATTICE, PRE, LM && PRE != 3>(A, K, Bf, xok, y);
-        else return iw_iterLoad<T, LATTICE, PRE, kSinCosInline, LM && PRE != 3>(A, K, N, xok, x, y);
-    };
-    const IterRaw<T> raw0 = loadRow(yb - 2), raw1 = loadRow(yb - 1);
-    IterRaw<T> rwA = loadRow(yb), rwB = loadRow(yb + 1),
-               rwC = loadRow(yb + 2);
-    T alpha = 0, beta = 0;
-    const bool first = MODE ? false : K.first != 0;
-    const bool restart = LM && K.afterReset != 0;      // r and delta are already those of this iteration (split residual reset)
-    if (restart) {
-        const double* const ps[2] = {K.betaNum, K.betaDen}; const int ns[2] = {K.nBetaNum, K.nBetaDen}; double o2[2];
-        sumPartialsN<2>(ps, ns, scratch, o2);
-        const T bNum = (T)o2[0], bDen = (T)o2[1];
-        beta = (bDen > T(0)) ? bNum / bDen : T(0);     // solver.t:544-547
-    } else if (!first) {
-        const double* const ps[4] = {K.aNumPrev, K.aDenPrev, K.s2Prev, K.s3Prev}; const int ns[4] = {K.nNum, K.nDen, K.n2, K.n3}; double o4[4];
-        if (!LM && K.mail.words) {                     // slab mode: the sums were posted to this rank's mailbox by every rank and may still be in flight
-            __shared__ double mailScr[4 + 1 + 64];
-            pollMailSums<4>(K.mail, mailScr, o4);
-        } else sumPartialsN<4>(ps, ns, scratch, o4);   // the four sums of the previous launch, loads in flight together
-        const double aNumD = o4[0], aDenD = o4[1], s2 = o4[2], s3 = o4[3];
-        const T aNum = (T)aNumD, aDen = (T)aDenD;
-        alpha = (aDen > T(0)) ? aNum / aDen : T(0);
-        // betaNumerator = sum M r_k^2 by expansion (energy.h); the reference's direct sum cannot be negative, so cancellation
-        // noise below zero (residual dropping by >~1e3 in one iteration) is clamped away
-        const double bNumD = fmax(aNumD - 2.0 * (double)alpha * s2 + (double)alpha * (double)alpha * s3, 0.0);
-        beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
-    }
-    if (K.alphaOut && blockIdx.x == 0 && threadIdx.x == 0) { K.alphaOut[0] = alpha; K.alphaOut[2] = beta; }
-    const T alpha2 = (kDeltaMode == 1) ? K.alphaIn[0] : T(0);
-    // The deferred term alpha_{k-2} p_{k-2} of an even launch: p_{k-1} = z_{k-1} + beta_{k-2} p_{k-2} was formed by the previous launch from values this
-    // launch has in registers again (p_{k-1} as loaded, z_{k-1} = M r_{k-1}: the same product of the same operands), so
-    // p_{k-2} = (p_{k-1} - z_{k-1}) / beta_{k-2} costs three flops per scalar instead of a 12 B/px read of the p buffer about to be overwritten
-    // (93 -> 81 B/px on even launches).  The subtraction only undoes the one rounding of that fma, an error of the size of the update's own rounding.
-    // beta_{k-2} == 0 (the reference's guard, or an exactly converged solve) leaves nothing to divide by: that launch reads p_{k-2} from memory.
-    const bool reconR = !LM && kRfree == 1;
-    const T betaOlder = reconR ? K.alphaIn[2] : T(0);      // the beta of the previous launch: p_{k-1} = M r_{k-1} + betaOlder p_{k-2}
-    // (This rebuilt term is what runs with OPT_AMD_RFREE=0.  In the r-free loop p_{k-2} is an input of the launch anyway: the lattice kernel keeps it in three
-    // registers from its load, the general kernel -- no registers to spare -- reads it again; both exact.)
-    const T beta2 = (kDeltaMode == 1 && kReconP && (!kRfree || kReconP == 2)) ? K.alphaIn[2] : T(0);      // reconP == 2: A/B switch (OPT_AMD_RECON_P=2)
-    const bool recon = beta2 != T(0);
-    const T invBeta2 = recon ? T(1) / beta2 : T(0);
-    auto phys = [&](int y) { return FLIP ? A.H - 1 - y : y; };   // mirrored row coordinates, see iw_pcgIter (K.flip == FLIP)
-    const T w2 = A.w_reg * A.w_reg, wf2 = A.w_fit * A.w_fit;
-    double accDen = 0, accNum = 0, acc2 = 0, acc3 = 0, accQ = 0;
-    const bool keepR = first || restart;
-    V2<T>* rO = (V2<T>*)K.rNew; T* rA = K.rNew + 2 * N; V2<T>* pO = (V2<T>*)K.pNew; T* pA = K.pNew + 2 * N;
-    const V2<T>* dO = (const V2<T>*)K.delta; const T* dA = K.delta + 2 * N;
-    V2<T>* dOut = (V2<T>*)K.deltaOut; T* dAout = K.deltaOut + 2 * N;
-    // PRE == 3 (unit lattice): M = guardedInvert(diag J^T J) takes one of 10 (Offset) / 5 (Angle) values, indexed by the fit bit
-    // and the neighbour count of the flag byte.  The Offset entries repeat iw_evalJTF's accumulation order, so they are the
-    // values the solver's preconditioner vector holds, bit for bit; the Angle entries use |R'(a) n|^2 = 1 exactly where
-    // iw_evalJTF rounds cos^2 + sin^2.
-    __shared__ T mTab[16], cTab[16], iTab[16];      // iTab = 1 / M = (1 + sqrt(d))^2 directly (r-free mode)
-    // PRE == 2 (general UrShape): diag(J^T J) of the OFFSET part does not depend on UrShape at all (2 w^2 per active neighbour + w_fit^2), so M_O comes from the same
-    // table for any input and only M_a is streamed: 4 B/px instead of 8 (round 3; 69 -> 65 B/px)
-    if (PRE == 3 || PRE == 2) {
-        if (threadIdx.x < 15) {
-            const int t = threadIdx.x, cnt = t < 10 ? t % 5 : t - 10;
-            const T w = A.w_reg;
-            T d = 0;
-            if (t < 10) { for (int n = 0; n < cnt; ++n) d += w * w + w * w; if (t >= 5) d += A.w_fit * A.w_fit; }
-            else for (int n = 0; n < cnt; ++n) d += (w * T(1)) * (w * T(1));
-            const T sq = T(1) + sqrt(d);
-            const T gi = T(1) / (sq * sq);                   // solver.hip guardedInvert (solver.t:323-332)
-            if (LM) {   // k_finalizeDiagonal (solver.t:631-664) on the table: SSq is the first outer iteration's guardedInvert(diag), and diag does not change
-                const T radius = K.lmRadius, unclamped = d * (T(1) / radius), clampMul = (T(1) / gi) / radius;
-                const T c = fmin(fmax(unclamped, K.lmMin * clampMul), K.lmMax * clampMul);
-                cTab[t] = c; mTab[t] = T(1) / (c + radius * unclamped);
-            } else { mTab[t] = gi; iTab[t] = sq * sq; }
-        }
-        __syncthreads();
-    }
-
-    auto makeOld = [&](const IterRaw<T>& wRaw, OldRow<T>& o) {
-        // The fields that enter the row window unchanged go through a real register move (regCopy above: round 1 found this for cos/sin, U and M in the older
-        // kernels; in the r-free kernel it is p_{k-1}, p_{k-2} and the flag byte that pass through).  Otherwise the window field *is* the load's destination
-        // register, the next request for the buffer needs another one, and the compiler restores the names with copies at the back-edge -- copies of registers
-        // whose loads were issued a moment ago: `s_waitcnt vmcnt(0)` once per pass, the whole prefetch drained every third row.
-        IterRaw<T> w = wRaw;
-        if (IW_REGCOPY) {
-            w.po.x = regCopy(wRaw.po.x); w.po.y = regCopy(wRaw.po.y); w.pa = regCopy(wRaw.pa);
-            w.ro.x = regCopy(wRaw.ro.x); w.ro.y = regCopy(wRaw.ro.y); w.ra = regCopy(wRaw.ra);
-            w.f = regCopy(wRaw.f);
-        }
-        o.q.ox = w.po.x; o.q.oy = w.po.y; o.q.a = w.pa;
-        if (kSinCosInline) { T sn, cn; sincosT(w.cs.x, &sn, &cn); o.q.c = cn; o.q.s = sn; }      // the same sincos as iw_cossin: same values
-        else { o.q.c = w.cs.x; o.q.s = w.cs.y; }
-        if (LATTICE) { o.q.ux = 0; o.q.uy = 0; } else { o.q.ux = w.u.x; o.q.uy = w.u.y; }
-        o.q.on = (w.ok && (w.f & kActive)) ? T(1) : T(0);
-        o.q.fw = (w.f & kFit) ? wf2 : T(0);
-        o.rx = w.ro.x; o.ry = w.ro.y; o.ra = w.ra;
-        if (!(LM && PRE == 3)) { o.cx = w.co.x; o.cy = w.co.y; o.ca = w.ca; }
-        T ix = 1, iy = 1, ia = 1;
-        if (PRE == 3) {
-            const int cnt = (w.f >> kCountShift) & 7, io = cnt + ((w.f & kFit) ? 5 : 0);
-            o.mx = o.my = mTab[io]; o.ma = mTab[10 + cnt];
-            if (LM) { o.cx = o.cy = cTab[io]; o.ca = cTab[10 + cnt]; }
-            else if (reconR) { ix = iy = iTab[io]; ia = iTab[10 + cnt]; }
-        } else if (PRE == 2) {
-            const int cnt = (w.f >> kCountShift) & 7, io = cnt + ((w.f & kFit) ? 5 : 0);
-            o.mx = o.my = mTab[io]; o.ma = w.ma;
-            if (!LM && reconR) { ix = iy = iTab[io]; ia = T(1) / o.ma; }
-        } else {
-            o.mx = w.mo.x; o.my = w.mo.y; o.ma = w.ma;
-            if (!LM && PRE != 0 && reconR) { ix = T(1) / o.mx; iy = T(1) / o.my; ia = T(1) / o.ma; }
-        }
-        if (!LM && LATTICE && kRfree) { o.p2x = w.ro.x; o.p2y = w.ro.y; o.p2a = w.ra; }      // (the general-UrShape kernel has no registers to spare: it reads p_{k-2} again)
-        if (!LM && reconR) {      // r_{k-1} = (p_{k-1} - beta p_{k-2}) / M: w.ro / w.ra were loaded from the p_{k-2} buffer
-            o.rx = (o.q.ox - betaOlder * w.ro.x) * ix; o.ry = (o.q.oy - betaOlder * w.ro.y) * iy; o.ra = (o.q.a - betaOlder * w.ra) * ia;
-        }
-    };
-    // J^T J at centre c; prev / next are the rows before / after it in sweep order
-    // `vert`: in, what the previous trip's evaluation of this stream left for the pair (prev, c); out, the same for (c, next)
-    auto applyA = [&](const Q<T>& c, const Q<T>& lf, const Q<T>& rt, const Q<T>& prev, const Q<T>& next, PairOut<T>& vert, T& ox, T& oy, T& oa) {
-        T ax = 0, ay = 0, aa = 0;
-        if (IW_SHARE_PAIRS) {      // rt (formed), lf (lane x-1's rt pair), then image row y+1 and y-1: one of them formed, the other left by the previous trip
-            const PairOut<T> hr = iw_pairFull<1, 0, LATTICE>(c, rt, ax, ay, aa);
-            PairOut<T> hl; hl.dx = dppShift<true>(hr.dx); hl.dy = dppShift<true>(hr.dy); hl.tn = dppShift<true>(hr.tn);
-            iw_pairInherited(hl, lf.on, ax, ay, aa);
-            if (!FLIP) { const PairOut<T> vn = iw_pairFull<0, 1, LATTICE>(c, next, ax, ay, aa); iw_pairInherited(vert, prev.on, ax, ay, aa); vert = vn; }
-            else { iw_pairInherited(vert, prev.on, ax, ay, aa); vert = iw_pairFull<0, -1, LATTICE>(c, next, ax, ay, aa); }
-        } else {
-            const Q<T>& below = FLIP ? prev : next; const Q<T>& above = FLIP ? next : prev;     // image rows y+1 / y-1
-            iw_pairQ<1, 0, LATTICE>(c, rt, ax, ay, aa); iw_pairQ<-1, 0, LATTICE>(c, lf, ax, ay, aa);
-            iw_pairQ<0, 1, LATTICE>(c, below, ax, ay, aa); iw_pairQ<0, -1, LATTICE>(c, above, ax, ay, aa);
-        }
-        ox = c.on * (w2 * ax + c.fw * c.ox); oy = c.on * (w2 * ay + c.fw * c.oy); oa = c.on * (w2 * aa);
-    };
-    PairOut<T> vOld{0, 0, 0}, vNew{0, 0, 0};      // the vertical pairs the two stencil evaluations of a trip inherit (p_{k-1} rows / p_k rows)
-    // One trip: the freshly loaded row y+2 -> Ap_{k-1}(y+1), r_k, z_k, p_k (y+1) -> Ap_k(y).
-    // oA, oB = p_{k-1} rows y, y+1 (oC receives y+2);  nA, nB = p_k rows y-1, y (nC receives y+1)
-    // The delta of the row a trip updates (y + 1) is requested one trip ahead, before that trip's prefetch of a raw row: by the time it is used a whole trip
-    // has passed and the wait leaves the younger requests in flight, where a request at the point of use is the newest one and its wait (vmcnt(0)) drains
-    // the whole queue once per row.  Every launch of the LM loop and the even launches of the Gauss-Newton steady state (MODE 2) update delta in every
-    // trip and take this form (three named delta buffers rotating with the trips, like the raw rows); the others read it where they use it.
-    constexpr bool kDeltaEarly = kBuf && (MODE == 2 || LM);
-    struct DeltaPre { V2<T> o; T a; };
-    auto loadDelta = [&](int y1) {
-        DeltaPre d{V2<T>{0, 0}, 0};
-        if constexpr (kDeltaEarly) {
-            const int yc = min(max(y1, 0), A.H - 1);
-            const unsigned rowE = (unsigned)(FLIP ? A.H - 1 - yc : yc) * (unsigned)A.W;
-            const T* const tag = nullptr;
-            d.o = bufLd2(Bf.delta, Bf.x2, rowE * (unsigned)sizeof(V2<T>), tag); d.a = bufLd1(Bf.delta, Bf.x1, rowE * (unsigned)sizeof(T) + Bf.aPart, tag);
-            __builtin_amdgcn_sched_barrier(0);      // a side effect as far as code motion is concerned: the two requests stay here instead of being sunk into the branch that uses them
-        }
-        return d;
-    };
-    auto trip = [&](int y, const OldRow<T>& oA, const OldRow<T>& oB, const OldRow<T>& oC,
-                    const NewRow<T>& nA, const NewRow<T>& nB, NewRow<T>& nC, bool live, const DeltaPre& dPre) {
-        nC.q = oB.q;
-        if (IW_SHARE_PAIRS) { nC.lf = Q<T>{}; nC.lf.on = dppShift<true>(oB.q.on); }     // of the left neighbour only its activity is needed: its pair comes ready-made
-        else dppShiftConst<true, LATTICE>(oB.q, nC.lf);
-        dppShiftConst<false, LATTICE>(oB.q, nC.rt);
-        Q<T> lf = nC.lf, rt = nC.rt;
-        if (!IW_SHARE_PAIRS) dppShiftVec<true>(oB.q, lf);
-        dppShiftVec<false>(oB.q, rt);
-        T ax, ay, aa;
-        applyA(oB.q, lf, rt, oA.q, oC.q, vOld, ax, ay, aa);                             // Step1 of iteration k-1 again
-        if (LM) { ax += oB.cx * oB.q.ox; ay += oB.cy * oB.q.oy; aa += oB.ca * oB.q.a; }                                                       // + CtC p (o.t:2076-2082)
-        const T rx = keepR ? oB.rx : oB.rx - alpha * ax, ry = keepR ? oB.ry : oB.ry - alpha * ay, ra = keepR ? oB.ra : oB.ra - alpha * aa;   // Step2
-        nC.mx = oB.mx; nC.my = oB.my; nC.ma = oB.ma;
-        nC.cx = oB.cx; nC.cy = oB.cy; nC.ca = oB.ca;
-        nC.rx = rx; nC.ry = ry; nC.ra = ra;
-        const T zx = nC.mx * rx, zy = nC.my * ry, za = nC.ma * ra;
-        nC.q.ox = zx + beta * oB.q.ox; nC.q.oy = zy + beta * oB.q.oy; nC.q.a = za + beta * oB.q.a;                                        // Step3
-        if (live && writer && y + 1 >= yb && y + 1 < ye) {
-            const int yp = phys(y + 1);
-            const long i = (long)yp * A.W + x;
-            const unsigned rowE = (unsigned)yp * (unsigned)A.W, s2 = rowE * (unsigned)sizeof(V2<T>), s1a = rowE * (unsigned)sizeof(T) + Bf.aPart;      // kBuf: wave-uniform row offsets
-            const T* const tag = nullptr;
-            const bool own = !IW_OWN_CHECK || (yp >= K.ownBegin && yp < K.ownEnd);
-            if (own && !keepR && kDeltaMode != 2) {   // delta += alpha_{k-1} p_{k-1}  (solver.t:461-462), preceded by the deferred term of launch k-1
-                V2<T> d; T da;
-                if (kDeltaEarly) { d = dPre.o; da = dPre.a; }
-                else if (kBuf) { d = bufLd2(Bf.delta, Bf.x2, s2, tag); da = bufLd1(Bf.delta, Bf.x1, s1a, tag); } else { d = dO[i]; da = dA[i]; }
-                if (MODE == 0 && K.deltaZero) { d.x = 0; d.y = 0; da = 0; }      // first delta update of a linear solve whose PCGInit1 left the buffer untouched
-                if (kDeltaMode == 1) {
-                    if (!LM && LATTICE && kRfree == 1 && kReconP != 2) { d.x += alpha2 * oB.p2x; d.y += alpha2 * oB.p2y; da += alpha2 * oB.p2a; }      // p_{k-2} kept from the load: exact
-                    else if (recon) { d.x += alpha2 * ((oB.q.ox - oB.mx * oB.rx) * invBeta2); d.y += alpha2 * ((oB.q.oy - oB.my * oB.ry) * invBeta2); da += alpha2 * ((oB.q.a - oB.ma * oB.ra) * invBeta2); }
-                    else {      // p_{k-2} from memory: the p buffer about to be overwritten, or (r-free ring) the buffer read through rOld
-                        V2<T> q; T qa;
-                        if (kBuf) { const __amdgpu_buffer_rsrc_t qb = (!LM && kRfree) ? Bf.rOld : Bf.pNew; q = bufLd2(qb, Bf.x2, s2, tag); qa = bufLd1(qb, Bf.x1, s1a, tag); }
-                        else {
-                            const V2<T>* qO = (!LM && kRfree) ? (const V2<T>*)K.rOld : (const V2<T>*)pO; const T* qA = (!LM && kRfree) ? K.rOld + 2 * N : (const T*)pA;
-                            q = qO[i]; qa = qA[i];
-                        }
-                        d.x += alpha2 * q.x; d.y += alpha2 * q.y; da += alpha2 * qa;
-                    }
-                }
-                d.x += alpha * oB.q.ox; d.y += alpha * oB.q.oy; da += alpha * oB.q.a;
-                if (kBuf) { bufSt2(Bf.deltaOut, Bf.x2, s2, d.x, d.y); bufSt1(Bf.deltaOut, Bf.x1, s1a, da); } else { st2<kNTS>(dOut, i, d.x, d.y); st1<kNTS>(dAout, i, da); }
-                if (LM) {   // Q = 1/2 sum delta . (r + b) with the updated delta and r (solver.t:483-485)
-                    V2<T> bo; T ba;
-                    if (kBuf) { bo = bufLd2(Bf.b, Bf.x2, s2, tag); ba = bufLd1(Bf.b, Bf.x1, s1a, tag); } else { bo = ((const V2<T>*)K.b)[i]; ba = K.b[2 * N + i]; }
-                    accQ += (double)(T(0.5) * (d.x * (rx + bo.x))) + (double)(T(0.5) * (d.y * (ry + bo.y))) + (double)(T(0.5) * (da * (ra + ba)));
-                }
-            }
-            if (kBuf) {
-                if (LM || !kRfree) { bufSt2(Bf.rNew, Bf.x2, s2, rx, ry); bufSt1(Bf.rNew, Bf.x1, s1a, ra); }
-                bufSt2(Bf.pNew, Bf.x2, s2, nC.q.ox, nC.q.oy); bufSt1(Bf.pNew, Bf.x1, s1a, nC.q.a);
-            } else {
-                if (LM || !kRfree) { st2<kNTS>(rO, i, rx, ry); st1<kNTS>(rA, i, ra); }
-                st2<kNTS>(pO, i, nC.q.ox, nC.q.oy); st1<kNTS>(pA, i, nC.q.a);
-            }
-        }
-        Q<T> l2 = nB.lf, r2 = nB.rt;
-        if (!IW_SHARE_PAIRS) dppShiftVec<true>(nB.q, l2);
-        dppShiftVec<false>(nB.q, r2);
-        T ox, oy, oa;
-        applyA(nB.q, l2, r2, nA.q, nC.q, vNew, ox, oy, oa);                             // Step1 of iteration k
-        if (LM) { ox += nB.cx * nB.q.ox; oy += nB.cy * nB.q.oy; oa += nB.ca * nB.q.a; }
-        if (live && writer && y >= yb && (!IW_OWN_CHECK || (phys(y) >= K.ownBegin && phys(y) < K.ownEnd))) {
-            accDen += (double)(nB.q.ox * ox + nB.q.oy * oy + nB.q.a * oa);
-            // sum M r^2, sum M r Ap, sum M Ap^2 of this row from shared double factors (dprod3's arithmetic: ((double)M * (double)r) * (double)r etc.; sum M r^2 used to be
-            // taken where r_k is formed, one trip earlier -- the same rows in the same order, 8 conversions / products per row less)
-            {
-                const double mx = (double)nB.mx, my = (double)nB.my, ma = (double)nB.ma;
-                const double rx = (double)nB.rx, ry = (double)nB.ry, ra = (double)nB.ra, ax = (double)ox, ay = (double)oy, az = (double)oa;
-                const double mrx = mx * rx, mry = my * ry, mra = ma * ra;
-                accNum += mrx * rx + mry * ry + mra * ra;
-                acc2 += mrx * ax + mry * ay + mra * az;
-                acc3 += (mx * ax) * ax + (my * ay) * ay + (ma * az) * az;
-            }
-        }
-    };
-    OldRow<T> o0, o1, o2;
-    NewRow<T> n0{}, n1{}, n2{};
-    makeOld(raw0, o0);
-    makeOld(raw1, o1);
-    if (IW_SHARE_PAIRS) { T t0 = 0, t1 = 0, t2 = 0; vOld = iw_pairFull<0, FLIP ? -1 : 1, LATTICE>(o0.q, o1.q, t0, t1, t2); }      // the pair (row yb-2, row yb-1) the first trip inherits
-    DeltaPre dlA = loadDelta(yb - 1), dlB = dlA, dlC = dlA;      // (trip yb - 2 updates no row; its delta is a dummy)
-    // trips y = yb-2 .. ye-1 (the first two only build p_k(yb-1), p_k(yb)); three per pass, no branch around a load
-    for (int y = yb - 2; y < ye; y += 3) {
-        if (IW_ROW_SYNC) __syncthreads();
-        // a raw row is consumed into the row window before its buffer is requested again; the request still precedes the trip's arithmetic
-        { makeOld(rwA, o2); dlB = loadDelta(y + 2); rwA = loadRow(y + 5); trip(y, o0, o1, o2, n0, n1, n2, true, dlA); }
-        { makeOld(rwB, o0); dlC = loadDelta(y + 3); rwB = loadRow(y + 6); trip(y + 1, o1, o2, o0, n1, n2, n0, y + 1 < ye, dlB); }
-        { makeOld(rwC, o1); dlA = loadDelta(y + 4); rwC = loadRow(y + 7); trip(y + 2, o2, o0, o1, n2, n0, n1, y + 2 < ye, dlC); }
-    }
-    double v[5] = {accDen, accNum, acc2, acc3, accQ};
-    blockReduceSumN<5>(v, scratch);
-    if (threadIdx.x == 0) {
-        K.aDen[blockIdx.x] = v[0]; K.aNum[blockIdx.x] = v[1]; K.s2[blockIdx.x] = v[2]; K.s3[blockIdx.x] = v[3];
-        if (LM) { if (K.qTag) storeTaggedPartial(K.q, blockIdx.x, v[4], K.qTag); else K.q[blockIdx.x] = v[4]; }
-    }
-    if (!LM && K.post.world) {      // slab mode: the last workgroup to finish posts the four sums (order of the consumer's poll: aNum, aDen, s2, s3) to every rank's mailbox
-        double* const parts[4] = {K.aNum, K.aDen, K.s2, K.s3};
-        postMailSums<4>(K.post, parts, scratch);
-    }
-}
-
-// delta += alpha[0] * p over n scalars (the deferred term left over when the PCG loop ends on an odd launch)
-template <class T>
-__global__ __launch_bounds__(kBlock) void iw_axpyDeferred(T* __restrict__ delta, const T* __restrict__ p, const T* __restrict__ alpha, long n) {
-    const T a = alpha[0];
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) delta[i] = delta[i] + a * p[i];
-}
-
-// M_a per pixel from the solver's 3-channel preconditioner (the Angle part of the vector; only there so that `mc` has one meaning whoever fills it)
-template <class T>
-__global__ __launch_bounds__(kBlock) void iw_compactM(const T* __restrict__ pre, T* __restrict__ mc, long N) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) mc[i] = pre[2 * N + i];
-}
-// Is UrShape a unit lattice (U(x,y) - U(x+1,y) == (-1,0) and U(x,y) - U(x,y+1) == (0,-1) exactly)?  The reference
-// example always passes the pixel grid itself (examples/image_warping/src/CombinedSolver.h:161-172); any other input
-// clears the flag and the general kernel runs.  Checked at every bind because the caller may swap buffers.
-template <class T>
-__global__ __launch_bounds__(kBlock) void iw_checkLattice(IWArgs<T> A, int* __restrict__ notLattice) {
-    const long N = (long)A.W * A.H;
-    const V2<T>* U = (const V2<T>*)A.UrShape;
-    bool bad = false;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % A.W), y = (int)(i / A.W), gy = A.gy0 + y;
-        if (gy < 0 || gy >= A.Hg) continue;       // slab mode: ghost rows beyond the global image hold no data (their pixels are inactive, U there is never used)
-        const V2<T> u = U[i];
-        if (x + 1 < A.W) { const V2<T> n = U[i + 1]; bad |= !(u.x - n.x == T(-1) && u.y - n.y == T(0)); }
-        if (y + 1 < A.H && gy + 1 < A.Hg) { const V2<T> n = U[i + A.W]; bad |= !(u.x - n.x == T(0) && u.y - n.y == T(-1)); }
-    }
-    if (__any(bad) && (threadIdx.x & (kWave - 1)) == 0) atomicOr(notLattice, 1);
-}
-
-// ghost rows of `out` are zeroed so the flat streaming kernels see r = 0 / Ap = 0 there (energy.h contract)
-template <class T>
-__global__ __launch_bounds__(kBlock) void iw_zeroGhost(IWArgs<T> A, T* __restrict__ out) {
-    const long N = (long)A.W * A.H;
-    const int ghostRows[2] = {A.yBegin - 1, A.yEnd};
-    for (int g = 0; g < 2; ++g) {
-        const int y = ghostRows[g];
-        if (y < 0 || y >= A.H) continue;
-        for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < A.W; x += gridDim.x * blockDim.x) {
-            const long i = (long)y * A.W + x;
-            ((V2<T>*)out)[i] = V2<T>{0, 0}; out[2 * N + i] = 0;
-        }
-    }
-}
-
-// ---- modelcost (LM): 1/2 sum (F + J delta)^2 ------------------------------------------------------------------
-template <class T>
-__global__ __launch_bounds__(kBlock) void iw_modelCost(IWArgs<T> A, const T* __restrict__ delta, double* __restrict__ partials) {
-    __shared__ double scratch[kBlock / kWave + 1];
-    const long rows = A.yEnd - A.yBegin, NN = rows * A.W, N = (long)A.W * A.H;
-    const V2<T>* O = (const V2<T>*)A.Offset; const V2<T>* U = (const V2<T>*)A.UrShape; const V2<T>* C = (const V2<T>*)A.Constraints;
-    const V2<T>* CS = (const V2<T>*)A.cs; const V2<T>* dO = (const V2<T>*)delta; const T* da = delta + 2 * N;
-    double acc = 0;
-    for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < NN; j += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(j % A.W), y = A.yBegin + (int)(j / A.W);
-        const long i = (long)y * A.W + x;
-        const uint8_t f = A.flags[i];
-        if (!(f & kActive)) continue;
-        const V2<T> o = O[i], u = U[i], cs = CS[i], d = dO[i];
-        const T dang = da[i], w = A.w_reg;
-        T e = 0;
-        const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int nx = x + dx[n], ny = y + dy[n];
-            if (nx < 0 || nx >= A.W || ny < 0 || ny >= A.H) continue;
-            const long ni = (long)ny * A.W + nx;
-            if (!(A.flags[ni] & kActive)) continue;
-            const V2<T> on = O[ni], un = U[ni], dn = dO[ni];
-            const T ux = u.x - un.x, uy = u.y - un.y;
-            const T Dx = -cs.y * ux - cs.x * uy, Dy = cs.x * ux - cs.y * uy;
-            const T mx = w * ((o.x - on.x) - (cs.x * ux - cs.y * uy)) + (w * (d.x - dn.x) - (w * Dx) * dang);
-            const T my = w * ((o.y - on.y) - (cs.y * ux + cs.x * uy)) + (w * (d.y - dn.y) - (w * Dy) * dang);
-            e += mx * mx + my * my;
-        }
-        if (f & kFit) {
-            const V2<T> cc = C[i];
-            const T fx = A.w_fit * (o.x - cc.x) + A.w_fit * d.x, fy = A.w_fit * (o.y - cc.y) + A.w_fit * d.y;
-            e += fx * fx + fy * fy;
-        }
-        acc += (double)(T(0.5) * e);
-    }
-    double t = blockReduceSum(acc, scratch);
-    if (threadIdx.x == 0) partials[blockIdx.x] = t;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 template <class T>
 struct ImageWarpingOps : EnergyOps<T> {
     IWArgs<T> A{};
     int cus = 256;
+    // Switches (environment, read once per plan).  OPT_AMD_LATTICE=0: take the general-UrShape kernels whatever the input (bench.py's general_urshape leg, tests);
+    // OPT_AMD_ITER_ROWS=R: every row-marching workgroup takes R rows (tests run small images in the benchmark's regime); OPT_AMD_ITER_MAXWG=n: no row-marching
+    // launch uses more than n workgroups (ranks that SHARE one GPU: see maxWorkgroups); OPT_AMD_SLAB_PERIOD=1: exchange ghost rows after every launch;
+    // OPT_AMD_ONCHIP*: the on-chip linear solve (below).  The reference-ordered three-kernel loop is the solver's OPT_AMD_ONEKERNEL=0.
+    bool useLattice = true;
+    int forceRows = 0, maxWorkgroups = 1 << 30, maxExchangePeriod = 1 << 20;
     ImageWarpingOps(const unsigned* dims) {
         A.W = (int)dims[0]; A.H = (int)dims[1];
         this->usePreconditioner = true;                                           // image_warping.t:10
@@ -1351,21 +45,10 @@ struct ImageWarpingOps : EnergyOps<T> {
         HIP_CHECK(hipMalloc((void**)&A.cs, (size_t)A.W * A.H * 2 * sizeof(T)));
         int dev = 0; HIP_CHECK(hipGetDevice(&dev));
         HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        if (const char* e = getenv("OPT_AMD_XCD")) xcdMap = atoi(e) != 0;
-        if (const char* e = getenv("OPT_AMD_LATTICE")) useLattice = atoi(e) != 0;       // A/B switches
-        if (const char* e = getenv("OPT_AMD_COMPACT_M")) useCompactM = atoi(e) != 0;
-        if (const char* e = getenv("OPT_AMD_SWEEP")) alternateSweep = atoi(e) != 0;
-        if (const char* e = getenv("OPT_AMD_RECOMPUTE_AP")) recomputeAp = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_LATTICE")) useLattice = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_SLAB_PERIOD")) maxExchangePeriod = std::max(1, atoi(e));
-        if (const char* e = getenv("OPT_AMD_FLAG_M")) flagPreconditioner = atoi(e) != 0;
-        if (const char* e = getenv("OPT_AMD_PAIR_DELTA")) pairDelta = atoi(e) != 0;
-        if (const char* e = getenv("OPT_AMD_RECON_P")) reconstructP = atoi(e);
-        if (const char* e = getenv("OPT_AMD_RFREE")) rFree = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ITER_ROWS")) forceRows = std::max(0, atoi(e));
-        if (const char* e = getenv("OPT_AMD_ITER_STEADY")) steadyVariants = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ITER_MAXWG")) maxWorkgroups = std::max(1, atoi(e));
-        if (const char* e = getenv("OPT_AMD_MARCH_INIT")) marchKernels = atoi(e) != 0;
-        if (const char* e = getenv("OPT_AMD_FUSED_FINISH")) fusedFinish = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ONCHIP")) ocEnabled = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ONCHIP_ROWS")) ocForceRows = std::max(0, atoi(e));
         if (const char* e = getenv("OPT_AMD_ONCHIP_FLAT")) ocFlatMax = std::max(0, atoi(e));
@@ -1375,15 +58,23 @@ struct ImageWarpingOps : EnergyOps<T> {
         HIP_CHECK(hipHostMalloc((void**)&hNotLattice, 64)); *hNotLattice = 0;
         HIP_CHECK(hipEventCreateWithFlags(&bindEvent, hipEventDisableTiming));
     }
-    ~ImageWarpingOps() override { if (ocS.slots) { (void)hipFree(ocS.slots); (void)hipFree(ocS.groupSlots); (void)hipFree(ocS.inbox); (void)hipFree(ocS.bad); (void)hipHostFree(ocS.hostErr); } (void)hipHostFree(hNotLattice); (void)hipEventDestroy(bindEvent); for (T* b : ring) if (b) (void)hipFree(b); (void)hipFree(A.flags); (void)hipFree(A.cs); if (mc) (void)hipFree(mc); if (alphaSlots) (void)hipFree(alphaSlots); (void)hipFree(dNotLattice); }
+    ~ImageWarpingOps() override {
+        if (ocS.slots) { (void)hipFree(ocS.slots); (void)hipFree(ocS.groupSlots); (void)hipFree(ocS.inbox); (void)hipFree(ocS.bad); (void)hipHostFree(ocS.hostErr); }
+        (void)hipHostFree(hNotLattice); (void)hipEventDestroy(bindEvent);
+        for (T* b : ring) if (b) (void)hipFree(b);
+        (void)hipFree(A.flags); (void)hipFree(A.cs); if (mc) (void)hipFree(mc); if (alphaSlots) (void)hipFree(alphaSlots); (void)hipFree(dNotLattice);
+    }
     int flatGrid(long n) const { return (int)std::max<long>(1, std::min<long>((n + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
+
+    // ---- bind: flag bytes + is UrShape the unit lattice? (the reference example always passes the pixel grid, CombinedSolver.h:161-172) ---------------------
+    int* hNotLattice = nullptr; int* dNotLattice = nullptr; hipEvent_t bindEvent = nullptr; bool verdictPending = false, lattice = false;
     void bind(void** p, LaunchCtx& ctx) override {
         A.Offset = (const T*)p[0]; A.Angle = (const T*)p[1]; A.UrShape = (const T*)p[2]; A.Constraints = (const T*)p[3]; A.Mask = (const T*)p[4];
         A.w_fit = (T) * (const float*)p[5]; A.w_reg = (T) * (const float*)p[6];   // Param(..., float, ...) stays float in double mode (:7-8)
         const Slab& s = this->slab;
         if (s.active) { A.yBegin = s.yBegin; A.yEnd = s.yEnd; A.gy0 = s.gy0; A.Hg = s.Hg; }
         else { A.yBegin = 0; A.yEnd = A.H; A.gy0 = 0; A.Hg = A.H; }
-        if (!s.active && marchKernels) {
+        if (!s.active) {
             // one marching pass: flag bytes + the unit-lattice verdict, which lands in pinned memory and is read when it is first needed (resolveLattice) --
             // nothing blocks here.  Until then `lattice` keeps the previous bind's verdict as a hint (false before the first).
             ScopedKernel k(ctx, "bindFlags");
@@ -1397,6 +88,7 @@ struct ImageWarpingOps : EnergyOps<T> {
             if (!useLattice) lattice = false;
             return;
         }
+        // row slabs: the one-thread-per-pixel kernels (ghost rows beyond the global image count as non-existent), verdict read back at once
         { ScopedKernel k(ctx, "bindFlags"); iw_flags<T><<<flatGrid((long)A.W * A.H), kBlock, 0, ctx.stream>>>(A); }
         lattice = false; verdictPending = false;
         if (useLattice) {
@@ -1409,19 +101,6 @@ struct ImageWarpingOps : EnergyOps<T> {
             lattice = (h == 0);
         }
     }
-    T* unknownPtr(int img) const override { return const_cast<T*>(img == 0 ? A.Offset : A.Angle); }
-    // ---- marching once-per-step kernels (single GPU) -----------------------------------------------------------------------------
-    bool marchKernels = true, fusedFinish = true;      // OPT_AMD_MARCH_INIT=0 / OPT_AMD_FUSED_FINISH=0: the older one-thread-per-pixel passes (A/B switches)
-    int* hNotLattice = nullptr; hipEvent_t bindEvent = nullptr; bool verdictPending = false;
-    int occMarch = 0;
-    void marchGrid(int rows, int& gx, int& gy, int& rowsPerGroup) {
-        if (occMarch == 0) {      // 256-thread workgroups, ~60 VGPRs: the co-resident count of the widest of the marching kernels
-            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occMarch, (const void*)iw_jtfMarch<T, false>, kBlock, 0));
-            occMarch = std::max(1, std::min(occMarch, 8));
-        }
-        gx = divUp(A.W, kStrip);
-        splitRows(rows, gx, cus * occMarch, gy, rowsPerGroup);
-    }
     // The verdict of the last iw_bindMarch: waits for that kernel only (an event), not for what was enqueued behind it.
     bool resolveLattice() {
         if (verdictPending) {
@@ -1431,11 +110,34 @@ struct ImageWarpingOps : EnergyOps<T> {
         }
         return lattice;
     }
-    bool fastGN() const {      // the conditions under which pcgIteration runs the A p-free single-kernel loop with M from the flag byte or the compact {M_O, M_a}
-        return marchKernels && !this->slab.active && recomputeAp && useCompactM && flagPreconditioner &&
-               !(IW_BUFADDR && (unsigned long long)A.W * A.H * 3ull * sizeof(T) >= (1ull << 32));
+    T* unknownPtr(int img) const override { return const_cast<T*>(img == 0 ? A.Offset : A.Angle); }
+
+    // ---- grids: one co-resident wave of workgroups, rows split evenly ---------------------------------------------------------------------------------------
+    int occMarch = 0;
+    void marchGrid(int rows, int& gx, int& gy, int& rowsPerGroup) {
+        if (occMarch == 0) {      // 256-thread workgroups, ~60 VGPRs: the co-resident count of the widest of the marching kernels
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occMarch, (const void*)iw_jtfMarch<T, false>, kBlock, 0));
+            occMarch = std::max(1, std::min(occMarch, 8));
+        }
+        gx = divUp(A.W, kStrip);
+        splitRows(rows, gx, cus * occMarch, gy, rowsPerGroup);
     }
-    T *initR = nullptr, *initP = nullptr; Reduction* initRed = nullptr; bool initHint = false, mcFresh = false;
+    // maxWorkgroups: an iteration kernel that polls a posted all-reduce in its prologue must be co-resident with the peers' kernels it is waiting for, which holds
+    // on one GPU per rank and on a shared GPU only while all ranks' workgroups together fit the chip (bench.py --share-gpu, tests/test_peer_comm_gpu.py).
+    void splitRows(int rows, int gx, int target, int& gy, int& rowsPerGroup) const {
+        target = std::max(gx, std::min(target, maxWorkgroups));
+        gy = std::max(1, std::min(std::min(rows, target / gx), kMaxPartials / gx));
+        rowsPerGroup = divUp(rows, gy);
+        if (forceRows > 0) rowsPerGroup = std::max(divUp(rows, std::max(1, kMaxPartials / gx)), std::min(rows, forceRows));
+        gy = divUp(rows, rowsPerGroup);
+    }
+
+    // ---- once per Gauss-Newton step ----------------------------------------------------------------------------------------------------------------------------
+    bool fastGN() const {      // single GPU, vectors below 4 GiB (buffer-descriptor offsets are 32-bit): the marching PCGInit1 and the single-kernel / on-chip loops
+        return !this->slab.active && (unsigned long long)A.W * A.H * 3ull * sizeof(T) < (1ull << 32);
+    }
+    T *initR = nullptr, *initP = nullptr; Reduction* initRed = nullptr; bool initHint = false, mcFresh = false, initPending = false, deltaZero = false;
+    T* mc = nullptr;
     void launchJtf(bool lat, LaunchCtx& ctx) {
         ScopedKernel k(ctx, "PCGInit1");
         int gx, gy, rpg; marchGrid(A.yEnd - A.yBegin, gx, gy, rpg);
@@ -1445,23 +147,20 @@ struct ImageWarpingOps : EnergyOps<T> {
         initRed->n = gx * gy;
         mcFresh = !lat;
     }
-    // PCGInit1 + PCGInit1_Finish for the Gauss-Newton single-kernel loop: r = -J^T F, p = M r, delta = 0, partial sums of r.p -- one marching kernel and a
-    // memset instead of cos/sin table + gather kernel + flat pass (and no diag / preconditioner vectors: the loop takes M from the flag byte or from `mc`).
-    // The kernel variant follows the lattice verdict of the previous bind while this bind's is still in flight; pcgIteration checks it before its first launch.
-    bool evalJTFInit(T* r, T* p, T* delta, long nPad, Reduction& aNum0, LaunchCtx& ctx) override {
+    // PCGInit1 + PCGInit1_Finish for the Gauss-Newton loops: r = -J^T F, p = M r, partial sums of r.p -- one marching kernel (no cos/sin table, no diag /
+    // preconditioner vectors: the loops take M from the flag byte or from `mc`).  delta = 0 (solver.t:389) is not written: the first launch that updates delta takes
+    // it as 0 (IterK::deltaZero), finishUpdate / pcgFinish do the same if no launch did.  The kernel variant follows the lattice verdict of the previous bind
+    // while this bind's is still in flight; the loops check it before their first launch.
+    bool evalJTFInit(T* r, T* p, T* /*delta*/, long /*nPad*/, Reduction& aNum0, LaunchCtx& ctx) override {
         if (!fastGN()) return false;
         initR = r; initP = p; initRed = &aNum0; initHint = lattice;
         launchJtf(initHint, ctx);
-        // delta = 0 (PCGInit1, solver.t:389) is not written: the first launch of the loop that updates delta takes it as 0 (IterK::deltaZero), and
-        // finishUpdate / pcgFinish do the same if no launch did (lIterations <= 2) -- 12 B/px of memset less per Gauss-Newton step
-        (void)nPad; initDelta = delta; deltaZero = true;
-        initPending = true;
+        deltaZero = true; initPending = true;
         return true;
     }
-    bool initPending = false, deltaZero = false; T* initDelta = nullptr;
     void evalCost(Reduction& out, LaunchCtx& ctx) override {
         ScopedKernel k(ctx, "computeCost");
-        if (!this->slab.active && marchKernels) {
+        if (!this->slab.active) {
             const bool lat = resolveLattice();
             int gx, gy, rpg; marchGrid(A.yEnd - A.yBegin, gx, gy, rpg);
             if (lat) iw_costMarch<T, true><<<gx * gy, kBlock, 0, ctx.stream>>>(A, out.partials, rpg, gx, gy);
@@ -1473,27 +172,19 @@ struct ImageWarpingOps : EnergyOps<T> {
         iw_cost<T><<<g, kBlock, 0, ctx.stream>>>(A, out.partials);
         out.n = g;
     }
-    void evalJTF(T* r, T* diag, LaunchCtx& ctx) override {
+    void evalJTF(T* r, T* diag, LaunchCtx& ctx) override {      // the generic form: probes, LM, row slabs
         const int g = flatGrid((long)A.W * A.H);
         { ScopedKernel k(ctx, "cosSinTable"); iw_cossin<T><<<g, kBlock, 0, ctx.stream>>>(A); }
         { ScopedKernel k(ctx, "PCGInit1"); iw_evalJTF<T><<<g, kBlock, 0, ctx.stream>>>(A, r, diag); }
     }
-    int xcdMap = 0;                                    // OPT_AMD_XCD=0 disables the XCD-aware workgroup mapping (A/B switch)
-    // OPT_AMD_ITER_ROWS=R: every row-marching workgroup takes R rows (fewer if the image is shorter) instead of rows / (co-resident
-    // row groups).  The kernels have no inter-workgroup synchronisation, so any split is valid; the switch exists so that small test
-    // images run the marching loop in the regime of the benchmark (4096^2: 98 rows per workgroup) -- tests/test_steady_state_gpu.py.
-    int forceRows = 0;
-    // OPT_AMD_ITER_MAXWG=n: no row-marching launch uses more than n workgroups.  For ranks that SHARE one GPU (tests, bench.py --share-gpu): an iteration
-    // kernel that polls a posted all-reduce in its prologue must be co-resident with the peers' kernels it is waiting for, which holds on one GPU per rank
-    // and on a shared GPU only while all ranks' workgroups together fit the chip.
-    int maxWorkgroups = 1 << 30;
-    void splitRows(int rows, int gx, int target, int& gy, int& rowsPerGroup) const {
-        target = std::max(gx, std::min(target, maxWorkgroups));
-        gy = std::max(1, std::min(std::min(rows, target / gx), kMaxPartials / gx));
-        rowsPerGroup = divUp(rows, gy);
-        if (forceRows > 0) rowsPerGroup = std::max(divUp(rows, std::max(1, kMaxPartials / gx)), std::min(rows, forceRows));
-        gy = divUp(rows, rowsPerGroup);
+    void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {
+        ScopedKernel k(ctx, "computeModelCost");
+        const int g = flatGrid((long)A.W * (A.yEnd - A.yBegin));
+        iw_modelCost<T><<<g, kBlock, 0, ctx.stream>>>(A, delta, out.partials);
+        out.n = g;
     }
+
+    // ---- J^T J p as its own kernel (probes, the LM residual reset, the three-kernel loop) ------------------------------------------------------------------------
     int occ[2][2] = {{0, 0}, {0, 0}};
     int blocksPerCU(bool lmv, bool fused) {
         int& o = occ[lmv][fused];
@@ -1506,28 +197,22 @@ struct ImageWarpingOps : EnergyOps<T> {
         return o;
     }
     void launchApply(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx, const FuseArgs<T>* fuse) {
-        // co-resident grid: column strips x row groups sized from the kernel's real occupancy, rows split
-        // evenly, so every workgroup is resident at once and all finish together (see header comment)
         const int gx = divUp(A.W, kStrip);
-        const int rows = A.yEnd - A.yBegin;
-        const int target = cus * blocksPerCU(CtC != nullptr, fuse != nullptr);
         int gy, rowsPerGroup;
-        splitRows(rows, gx, target, gy, rowsPerGroup);
-        const int gyPad = xcdMap ? divUp(gy, 8) * 8 : gy;
-        const int nBlocks = gx * gyPad;
+        splitRows(A.yEnd - A.yBegin, gx, cus * blocksPerCU(CtC != nullptr, fuse != nullptr), gy, rowsPerGroup);
+        const int grid = gx * gy;
         {
             ScopedKernel k(ctx, fuse ? "PCGStep3+PCGStep1" : "PCGStep1");
-            const int grid = nBlocks;
             double* part = dot ? dot->partials : nullptr;
             FuseArgs<T> F = fuse ? *fuse : FuseArgs<T>{};
             if (fuse) {
-                if (CtC) iw_applyJTJ<T, true, true><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, CtC, part, rowsPerGroup, gx, gy, xcdMap, F);
-                else iw_applyJTJ<T, false, true><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, part, rowsPerGroup, gx, gy, xcdMap, F);
+                if (CtC) iw_applyJTJ<T, true, true><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, CtC, part, rowsPerGroup, gx, gy, F);
+                else iw_applyJTJ<T, false, true><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, part, rowsPerGroup, gx, gy, F);
             } else {
-                if (CtC) iw_applyJTJ<T, true, false><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, CtC, part, rowsPerGroup, gx, gy, xcdMap, F);
-                else iw_applyJTJ<T, false, false><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, part, rowsPerGroup, gx, gy, xcdMap, F);
+                if (CtC) iw_applyJTJ<T, true, false><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, CtC, part, rowsPerGroup, gx, gy, F);
+                else iw_applyJTJ<T, false, false><<<grid, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, part, rowsPerGroup, gx, gy, F);
             }
-            if (dot) dot->n = nBlocks;
+            if (dot) dot->n = grid;
         }
         if (this->slab.active) iw_zeroGhost<T><<<divUp(A.W, kBlock), kBlock, 0, ctx.stream>>>(A, out);
     }
@@ -1538,63 +223,42 @@ struct ImageWarpingOps : EnergyOps<T> {
         launchApply(pOld, out, CtC, dot, ctx, &F);
         return true;
     }
-    int occIter[15] = {0};
-    int iterFlip = 0; bool alternateSweep = true, recomputeAp = true;
-    int sinceExchange = 0, maxExchangePeriod = 1 << 20;      // OPT_AMD_SLAB_PERIOD=1: exchange after every launch whatever the ghost depth (A/B switch)
-    template <bool LAT, int PRE> static const void* iterFn(bool noAp, bool flip) {
-        if constexpr (PRE == 2) return flip ? (const void*)iw_pcgIter2<T, LAT, PRE, true> : (const void*)iw_pcgIter2<T, LAT, PRE, false>;      // (the compact M exists for the A p-free kernel only)
-        else return !noAp ? (const void*)iw_pcgIter<T, LAT, PRE> : flip ? (const void*)iw_pcgIter2<T, LAT, PRE, true> : (const void*)iw_pcgIter2<T, LAT, PRE, false>;
+
+    // ---- one launch per PCG iteration (iw_iter.h) ---------------------------------------------------------------------------------------------------------------------
+    static const void* iterKernel(bool lat, bool lmLoop, bool flip, int mode) {      // mode: 0 launch state from the arguments, 1 / 2 steady state of the Gauss-Newton loop (odd / even launch)
+#define IWK(LAT, PRE, LMV, MODE) (flip ? (const void*)iw_pcgIter2<T, LAT, PRE, true, LMV, MODE> : (const void*)iw_pcgIter2<T, LAT, PRE, false, LMV, MODE>)
+        if (lmLoop) return lat ? IWK(true, 3, true, 0) : IWK(false, 1, true, 0);
+        if (lat) return mode == 1 ? IWK(true, 3, false, 1) : mode == 2 ? IWK(true, 3, false, 2) : IWK(true, 3, false, 0);
+        return mode == 1 ? IWK(false, 2, false, 1) : mode == 2 ? IWK(false, 2, false, 2) : IWK(false, 2, false, 0);
+#undef IWK
     }
-    static const void* iterKernel(bool lat, int pre, bool noAp, bool flip) {
-        if (pre == 3) return flip ? (const void*)iw_pcgIter2<T, true, 3, true> : (const void*)iw_pcgIter2<T, true, 3, false>;      // (steady-state variants: steadyKernel)
-        return lat ? (pre == 2 ? iterFn<true, 2>(noAp, flip) : pre == 1 ? iterFn<true, 1>(noAp, flip) : iterFn<true, 0>(noAp, flip))
-                   : (pre == 2 ? iterFn<false, 2>(noAp, flip) : pre == 1 ? iterFn<false, 1>(noAp, flip) : iterFn<false, 0>(noAp, flip));
+    static int iterBlock(bool lat, bool lmLoop) { return sizeof(T) == 8 ? 256 : lat ? 768 : lmLoop ? 512 : 768; }      // IterBlk<T, LATTICE, PRE, LM>::value of iterKernel's choice
+    int occIter[4] = {0, 0, 0, 0};
+    int iterFlip = 0, sinceExchange = 0, iterIndex = 0;
+    bool deferredTerm = false, lastLoopRfree = false;
+    T* ring[3] = {nullptr, nullptr, nullptr}; const T* r0Ptr = nullptr; T* alphaSlots = nullptr;
+    // What the loops do before their first launch: this bind's lattice verdict (the marching bind does not block for it); a PCGInit1 that ran on the previous
+    // verdict and guessed "lattice" for an input that is none is redone.
+    void beginLoop(LaunchCtx& ctx) {
+        resolveLattice();
+        if (initPending) { if (initHint && !lattice) launchJtf(false, ctx); initHint = lattice; initPending = false; }
+        else mcFresh = false;      // r, M came from the generic PCGInit1: `mc` (if any) is stale
     }
-    // iw_pcgIter2<.., MODE>: the r-free steady state with the launch state compiled in (mode 1: odd launch, 2: even launch)
-    template <bool LAT, int PRE> static const void* steadyFn(bool flip, int mode) {
-        if (mode == 1) return flip ? (const void*)iw_pcgIter2<T, LAT, PRE, true, false, 1> : (const void*)iw_pcgIter2<T, LAT, PRE, false, false, 1>;
-        return flip ? (const void*)iw_pcgIter2<T, LAT, PRE, true, false, 2> : (const void*)iw_pcgIter2<T, LAT, PRE, false, false, 2>;
-    }
-    static const void* steadyKernel(bool lat, int pre, bool flip, int mode) {      // the two paths the benchmark line reports: unit lattice (flag-byte M) and general UrShape (compact M)
-        if (lat && pre == 3) return steadyFn<true, 3>(flip, mode);
-        if (!lat && pre == 2) return steadyFn<false, 2>(flip, mode);
-        return nullptr;
-    }
-    bool steadyVariants = true;      // OPT_AMD_ITER_STEADY=0: always the kernel that reads the launch state from its arguments (A/B switch)
-    static const void* lmKernel(bool lat, bool tables, bool flip) {
-        if (lat && tables) return flip ? (const void*)iw_pcgIter2<T, true, 3, true, true> : (const void*)iw_pcgIter2<T, true, 3, false, true>;
-        return lat ? (flip ? (const void*)iw_pcgIter2<T, true, 1, true, true> : (const void*)iw_pcgIter2<T, true, 1, false, true>)
-                   : (flip ? (const void*)iw_pcgIter2<T, false, 1, true, true> : (const void*)iw_pcgIter2<T, false, 1, false, true>);
-    }
-    bool flagPreconditioner = true, pairDelta = true, rFree = true;
-    // OPT_AMD_RECON_P=1 (r in memory only): rebuild the deferred p_{k-2} as (p_{k-1} - M r_{k-1}) / beta_{k-2} instead of reading it -- 12 B/px less, but a division by a beta that a
-    // collapsing residual makes ~1e-8 (round 3, adversarial family: 3.5e-11 in double where every other loop holds 1e-15); off by default, the r-free loop keeps p_{k-2} in registers.
-    int reconstructP = 0;
-    T* ring[3] = {nullptr, nullptr, nullptr}; const T* r0Ptr = nullptr; bool lastLoopRfree = false;
-    int iterIndex = 0; bool deferredTerm = false; T* alphaSlots = nullptr;
-    T* mc = nullptr; int* dNotLattice = nullptr; bool lattice = false, useLattice = true, useCompactM = true;
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
-        const bool noAp = recomputeAp && (!this->slab.active || this->slab.ghost >= 2);      // iw_pcgIter2: Ap recomputed instead of stored
-        // iw_pcgIter2 addresses its arrays through buffer descriptors with 32-bit byte offsets (IW_BUFADDR): a solver vector of 4 GiB or more (float: beyond
-        // 18900^2 pixels) takes the three-kernel loop instead
-        if (IW_BUFADDR && noAp && (unsigned long long)A.W * A.H * 3ull * sizeof(T) >= (1ull << 32)) return false;
+        // A p is recomputed, not stored, so a slab needs two ghost rows (one for each stencil evaluation); with one the solver runs the three-kernel loop.
+        if (!a.pre || (this->slab.active && this->slab.ghost < 2)) return false;
+        if ((unsigned long long)A.W * A.H * 3ull * sizeof(T) >= (1ull << 32)) return false;      // 32-bit buffer offsets
         const bool lmLoop = a.CtC != nullptr;
-        if (a.first) {
-            resolveLattice();                          // this bind's verdict (the marching bind does not block for it)
-            if (initPending) {                         // evalJTFInit ran on the previous verdict: a lattice variant on an input that is none has to be redone
-                if (initHint && !lattice) launchJtf(false, ctx);
-                initPending = false;
-            } else mcFresh = false;                    // r, M came from the generic PCGInit1: `mc` (if any) is stale
-        }
-        if (lmLoop && (!noAp || !a.pre || this->slab.active)) return false;      // LM: only the A p-free kernel has the variant (single GPU)
-        this->iterStateExchange = noAp;     // slab mode: r and p ghost rows come from the neighbours after a launch (iw_pcgIter: Ap before it)
-        this->iterTakesMail = noAp && !lmLoop;   // iw_pcgIter2's prologue can poll a posted all-reduce
-        // With g >= 2 ghost rows whose r and p are current to depth v, a launch can also update the ghost rows to depth v - 1 (their A p needs one
-        // more row on either side) and its sums need depth 2; so after an exchange at depth g the slab runs g - 1 launches before it needs the
-        // neighbours again, launch j = 1 .. g - 1 of the period updating g - j ghost rows (none in the last one: they are about to be overwritten).
+        if (lmLoop && this->slab.active) return false;      // the LM variant is single-GPU
+        if (a.first) beginLoop(ctx);
+        this->iterStateExchange = true;      // slab mode: the ghost rows of the loop state come from the neighbours after a launch
+        this->iterTakesMail = !lmLoop;       // the prologue can poll a posted all-reduce
+        // With g >= 2 ghost rows whose state is current to depth v, a launch can also update the ghost rows to depth v - 1 (their A p needs one more row on either
+        // side) and its sums need depth 2; so after an exchange at depth g the slab runs g - 1 launches before it needs the neighbours again, launch j = 1 .. g - 1
+        // of the period updating g - j ghost rows (none in the last one: they are about to be overwritten).
         int ext = 0;
         this->iterExchangeDue = true;
-        if (noAp && this->slab.active) {
+        if (this->slab.active) {
             if (a.first) sinceExchange = 0;
             const int period = std::max(1, std::min(this->slab.ghost - 1, maxExchangePeriod)), j = sinceExchange + 1;
             const bool due = j >= period;
@@ -1604,86 +268,83 @@ struct ImageWarpingOps : EnergyOps<T> {
         }
         IWArgs<T> Ax = A;                   // what the kernel sees: the rows it updates
         Ax.yBegin = std::max(0, A.yBegin - ext); Ax.yEnd = std::min(A.H, A.yEnd + ext);
-        const int pre = !a.pre ? 0 : (noAp && lattice && flagPreconditioner) ? 3 : lmLoop ? 1 : (useCompactM && noAp) ? 2 : 1;
-        const int L = lmLoop ? (lattice ? 14 : 13) : pre == 3 ? 12 : (noAp ? 6 : 0) + (lattice ? 3 : 0) + pre;
-        if (a.first) iterFlip = 0;      // every linear solve starts top-down, so a solve is reproducible whatever ran before it
-        const int blk = !noAp ? kIterBlock : sizeof(T) == 8 ? ITER2_BLOCK_DOUBLE : lattice ? kIterBlock2 : (pre == 2 && !lmLoop) ? ITER2_BLOCK_GENERAL_GN : ITER2_BLOCK_GENERAL;      // IterBlk<T, LATTICE, PRE, LM> of the kernel picked below
-        const void* fn = lmLoop ? lmKernel(lattice, pre == 3, iterFlip != 0) : iterKernel(lattice, pre, noAp, iterFlip != 0);
+        const int pre = lattice ? 3 : lmLoop ? 1 : 2;
+        if (a.first) { iterFlip = 0; iterIndex = 0; }      // every linear solve starts top-down, so a solve is reproducible whatever ran before it
+        const int blk = iterBlock(lattice, lmLoop), L = (lmLoop ? 2 : 0) + (lattice ? 1 : 0);
         if (occIter[L] == 0) {
-            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occIter[L], fn, blk, 0));
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occIter[L], iterKernel(lattice, lmLoop, false, 0), blk, 0));
             occIter[L] = std::max(1, std::min(occIter[L], 8));
         }
-        if (a.first && pre == 2 && !mcFresh) {
+        if (a.first && pre == 2 && !mcFresh) {      // general UrShape behind a generic PCGInit1: M_a out of the solver's 3-channel preconditioner
             if (!mc) HIP_CHECK(hipMalloc((void**)&mc, (size_t)A.W * A.H * sizeof(T)));
             ScopedKernel k(ctx, "compactPreconditioner");
             iw_compactM<T><<<flatGrid((long)A.W * A.H), kBlock, 0, ctx.stream>>>(a.pre, mc, (long)A.W * A.H);
         }
-        const int gx = divUp(A.W, noAp ? (blk / kWave) * kSpan2 : kIterStrip);
-        const int rows = Ax.yEnd - Ax.yBegin;
+        const int gx = divUp(A.W, (blk / kWave) * kSpan2);
         int gy, rowsPerGroup;
-        splitRows(rows, gx, cus * occIter[L], gy, rowsPerGroup);
-        if (a.first) iterIndex = 0;
-        const bool paired = noAp && pairDelta && !lmLoop;      // LM needs the current delta every iteration for Q
-        // r-free loop (IterK::rfree): Gauss-Newton with a preconditioner; slabs then exchange the ghost rows of the two newest p instead of r and p
-        const bool rfreeLoop = paired && rFree && pre != 0;
-        const T *rOldPtr = a.rOld, *pOldPtr = a.pOld; T* pNewPtr = a.pNew; int rfreeFlag = 0;
-        if (rfreeLoop) {
+        splitRows(Ax.yEnd - Ax.yBegin, gx, cus * occIter[L], gy, rowsPerGroup);
+        // Gauss-Newton: delta every second launch, and no residual vector -- the state is a ring of three p buffers (ring[j % 3] holds p_j; the first two
+        // launches read the solver's r_0).  LM keeps r in memory and updates delta in every launch (Q needs it).
+        const bool gn = !lmLoop;
+        const T *rOldPtr = a.rOld, *pOldPtr = a.pOld; T* pNewPtr = a.pNew; int rfreeFlag = 0, deltaMode = 0; const T* alphaIn = nullptr; T* alphaOut = nullptr;
+        if (gn) {
             const size_t bytes = ((size_t)A.W * A.H * 3 + 3) / 4 * 4 * sizeof(T);      // padded like the solver's vectors: its flat kernels read whole 16-byte packs of the last p
             for (int j = 0; j < 3; ++j) if (!ring[j]) { HIP_CHECK(hipMalloc((void**)&ring[j], bytes)); HIP_CHECK(hipMemsetAsync(ring[j], 0, bytes, ctx.stream)); }
             if (a.first) r0Ptr = a.rOld;                       // the solver swaps its r buffers after every launch; this one keeps r_0 until launch 1 has read it
             const int k = iterIndex;
-            pOldPtr = k == 0 ? a.pOld : ring[(k - 1) % 3];     // ring[j % 3] holds p_j
+            pOldPtr = k == 0 ? a.pOld : ring[(k - 1) % 3];
             rOldPtr = k <= 1 ? r0Ptr : ring[(k - 2) % 3];
             pNewPtr = ring[k % 3];
             rfreeFlag = k <= 1 ? 2 : 1;
-        }
-        lastLoopRfree = rfreeLoop;
-        int deltaMode = 0; const T* alphaIn = nullptr; T* alphaOut = nullptr;
-        if (paired) {
             if (!alphaSlots) { HIP_CHECK(hipMalloc((void**)&alphaSlots, 4 * sizeof(T))); HIP_CHECK(hipMemsetAsync(alphaSlots, 0, 4 * sizeof(T), ctx.stream)); }   // [0,1] alpha, [2,3] beta, ping-pong
-            deltaMode = (iterIndex >= 2 && iterIndex % 2 == 0) ? 1 : 2;           // launch 0 has nothing to apply; odd launches defer
-            alphaOut = alphaSlots + (iterIndex & 1); alphaIn = alphaSlots + ((iterIndex & 1) ^ 1);
+            deltaMode = (k >= 2 && k % 2 == 0) ? 1 : 2;           // launch 0 has nothing to apply; odd launches defer
+            alphaOut = alphaSlots + (k & 1); alphaIn = alphaSlots + ((k & 1) ^ 1);
         }
-        deferredTerm = paired && iterIndex >= 1 && iterIndex % 2 == 1;            // after an odd launch alpha_{k-1} p_{k-1} is still owed (pcgFinish)
-        IterK<T> K{rOldPtr, a.ApOld, pOldPtr, a.rNew, a.ApNew, pNewPtr, a.delta, a.pre, a.first, pre == 2 ? mc : nullptr, iterFlip, deltaMode, alphaIn, alphaOut, reconstructP,
-                   rfreeFlag, a.CtC, a.b, a.q ? a.q->partials : nullptr, a.qTag, a.afterReset, a.betaNum.partials, a.betaNum.n, a.betaDen.partials, a.betaDen.n,
-                   a.deltaOut ? a.deltaOut : a.delta, a.lmRadius, a.lmMinDiag, a.lmMaxDiag,
-                   a.aNumPrev.partials, a.aDenPrev.partials, a.s2Prev.partials, a.s3Prev.partials, a.aNumPrev.n, a.aDenPrev.n, a.s2Prev.n, a.s3Prev.n,
-                   a.aNum->partials, a.aDen->partials, a.s2->partials, a.s3->partials, A.yBegin, A.yEnd,
-                   MailRefDev{a.mail.words, a.mail.world, a.mail.stride, a.mail.tag, a.mail.timeoutTicks, a.mail.errFlag}, MailPostDev{}};
+        lastLoopRfree = gn;
+        deferredTerm = gn && iterIndex >= 1 && iterIndex % 2 == 1;            // after an odd launch alpha_{k-1} p_{k-1} is still owed (pcgFinish / finishUpdate)
+        IterK<T> K{};
+        K.rOld = rOldPtr; K.pOld = pOldPtr; K.rNew = a.rNew; K.pNew = pNewPtr; K.delta = a.delta; K.deltaOut = a.deltaOut ? a.deltaOut : a.delta;
+        K.pre = a.pre; K.mc = pre == 2 ? mc : nullptr; K.first = a.first; K.deltaMode = deltaMode; K.alphaIn = alphaIn; K.alphaOut = alphaOut; K.rfree = rfreeFlag;
+        K.CtC = a.CtC; K.b = a.b; K.q = a.q ? a.q->partials : nullptr; K.qTag = a.qTag; K.afterReset = a.afterReset;
+        K.betaNum = a.betaNum.partials; K.nBetaNum = a.betaNum.n; K.betaDen = a.betaDen.partials; K.nBetaDen = a.betaDen.n;
+        K.lmRadius = a.lmRadius; K.lmMin = a.lmMinDiag; K.lmMax = a.lmMaxDiag;
+        K.aNumPrev = a.aNumPrev.partials; K.aDenPrev = a.aDenPrev.partials; K.s2Prev = a.s2Prev.partials; K.s3Prev = a.s3Prev.partials;
+        K.nNum = a.aNumPrev.n; K.nDen = a.aDenPrev.n; K.n2 = a.s2Prev.n; K.n3 = a.s3Prev.n;
+        K.aNum = a.aNum->partials; K.aDen = a.aDen->partials; K.s2 = a.s2->partials; K.s3 = a.s3->partials;
+        K.ownBegin = A.yBegin; K.ownEnd = A.yEnd;
+        K.mail = MailRefDev{a.mail.words, a.mail.world, a.mail.stride, a.mail.tag, a.mail.timeoutTicks, a.mail.errFlag};
         for (int t = 0; t < 16; ++t) K.post.dst[t] = a.post.dst[t];
         K.post.world = a.post.world; K.post.tag = a.post.tag; K.post.ticket = a.post.ticket;
         K.deltaZero = 0;
-        if (deltaZero && !a.first && deltaMode != 2 && !lmLoop) { K.deltaZero = 1; deltaZero = false; }      // this launch writes every pixel's delta: from here on the buffer is real
+        if (deltaZero && !a.first && deltaMode != 2 && gn) { K.deltaZero = 1; deltaZero = false; }      // this launch writes every pixel's delta: from here on the buffer is real
         {
             ScopedKernel k(ctx, "PCGIteration");
             int rpg = rowsPerGroup, gxa = gx, gya = gy;
             void* kargs[] = {(void*)&Ax, (void*)&K, (void*)&rpg, (void*)&gxa, (void*)&gya};
-            const void* fnL = fn;      // same workgroup size and grid; the steady-state variants only drop the tests of the launch state
-            if (steadyVariants && !lmLoop && noAp && rfreeFlag == 1 && !a.first && reconstructP != 2 && (deltaMode == 1 || deltaMode == 2) && !K.deltaZero)
-                if (const void* f = steadyKernel(lattice, pre, iterFlip != 0, deltaMode == 2 ? 1 : 2)) fnL = f;
-            HIP_CHECK(hipLaunchKernel(fnL, dim3(gx * gy), dim3(blk), kargs, 0, ctx.stream));
+            // from the third launch of a Gauss-Newton solve on the launch state alternates between two values: compiled in
+            const int mode = (gn && rfreeFlag == 1 && !a.first && !K.deltaZero) ? (deltaMode == 2 ? 1 : 2) : 0;
+            HIP_CHECK(hipLaunchKernel(iterKernel(lattice, lmLoop, iterFlip != 0, mode), dim3(gx * gy), dim3(blk), kargs, 0, ctx.stream));
         }
-        if (alternateSweep) iterFlip ^= 1;
+        iterFlip ^= 1;      // successive launches sweep top-down / bottom-up: a launch starts on the rows the previous one left in the caches
         ++iterIndex;
         a.aNum->n = a.aDen->n = a.s2->n = a.s3->n = gx * gy;
         if (a.q) a.q->n = gx * gy;
-        if (this->slab.active && !noAp) iw_zeroGhost<T><<<divUp(A.W, kBlock), kBlock, 0, ctx.stream>>>(A, a.ApNew);
         return true;
     }
-    // After the last launch L-1 of a linear solve.  If it was an odd launch, the term alpha_{L-2} p_{L-2} was deferred: pPrev is the
-    // p buffer that launch read (p_{L-2}) and alpha_{L-2} sits in the slot that launch wrote.  The solver then adds alpha_{L-1} p_{L-1}.
-    int iterExchangeVectors(T** out) override {      // after launch iterIndex - 1
+    // Slab mode, after launch iterIndex - 1: the vectors whose ghost rows the neighbours must refresh -- the two newest search directions of the ring.
+    int iterExchangeVectors(T** out) override {
         if (!lastLoopRfree || iterIndex < 1) return 0;
         out[0] = ring[(iterIndex - 1) % 3];
         if (iterIndex < 2) return 1;                      // launch 1 reads the solver's r_0 (ghost rows exchanged before the loop) and p_0
         out[1] = ring[(iterIndex - 2) % 3];
         return 2;
     }
+    // After the last launch L-1 of a linear solve.  If it was an odd launch, the term alpha_{L-2} p_{L-2} was deferred: its alpha sits in the slot that launch
+    // wrote.  The solver then adds alpha_{L-1} p_{L-1}; returns where p_{L-1} lives.
     const T* pcgFinish(const T* pPrev, T* delta, LaunchCtx& ctx) override {
         if (deltaZero) { HIP_CHECK(hipMemsetAsync(delta, 0, ((size_t)A.W * A.H * 3 + 3) / 4 * 4 * sizeof(T), ctx.stream)); deltaZero = false; }      // the generic tail reads it
         const T* pLast = nullptr;
-        if (lastLoopRfree && iterIndex >= 1) {      // r-free ring: launch j left p_j in ring[j % 3]
+        if (lastLoopRfree && iterIndex >= 1) {
             pLast = ring[(iterIndex - 1) % 3];
             if (iterIndex >= 2) pPrev = ring[(iterIndex - 2) % 3];
         }
@@ -1694,10 +355,9 @@ struct ImageWarpingOps : EnergyOps<T> {
         deferredTerm = false;
         return pLast;
     }
-    // Last delta terms + X += delta in one pass (iw_finishUpdate).  pPrev / pLast: the solver's buffers of the last two search directions, used unless the
-    // r-free ring holds them.
+    // Last delta terms + X += delta in one pass (iw_finishUpdate), single GPU.
     bool finishUpdate(const T* pPrev, const T* pLast, const T* delta, const Reduction& aNum, const Reduction& aDen, LaunchCtx& ctx) override {
-        if (!fusedFinish || !marchKernels || this->slab.active) return false;
+        if (this->slab.active) return false;
         if (lastLoopRfree && iterIndex >= 1) {
             pLast = ring[(iterIndex - 1) % 3];
             if (iterIndex >= 2) pPrev = ring[(iterIndex - 2) % 3];
@@ -1709,6 +369,13 @@ struct ImageWarpingOps : EnergyOps<T> {
         deferredTerm = false; deltaZero = false;
         return true;
     }
+    bool iterPostsItself(bool lmLoop) const override {      // would pcgIteration accept the launch (and so carry out a planned post)?  Same conditions as its refusals above.
+        return !lmLoop && this->slab.active && this->slab.ghost >= 2 && (unsigned long long)A.W * A.H * 3ull * sizeof(T) < (1ull << 32);
+    }
+    bool slabIterationAvailable() const override { return this->slab.ghost >= 2 && (unsigned long long)A.W * A.H * 3ull * sizeof(T) < (1ull << 32); }
+    bool supportsSlab() const override { return true; }
+    long rowScalars(int img) const override { return (long)A.W * (img == 0 ? 2 : 1); }
+
     // ---- the whole linear solve on chip (iw_onchip.h): unit lattice, Gauss-Newton, single GPU, tiles <= CUs ------------------------------------------
     // OPT_AMD_ONCHIP=0 switches it off (the one A/B switch of the path); OPT_AMD_ONCHIP_ROWS=r forces the variant with r rows per lane (tests run every
     // variant on small images); OPT_AMD_ONCHIP_FLAT=n: grids of up to n workgroups sum flat instead of through the two-level tree (same bits either way).
@@ -1733,9 +400,9 @@ struct ImageWarpingOps : EnergyOps<T> {
         }
     }
     bool pcgSolveOnChip(const T* r0, const T* p0, T* delta, int L, double* traceDev, LaunchCtx& ctx) override {
-        if (!ocEnabled || ocFailed || this->slab.active || !marchKernels || L <= 0) return false;
+        if (!ocEnabled || ocFailed || !fastGN() || L <= 0) return false;
         resolveLattice();
-        if (initPending && initHint && !lattice) { launchJtf(false, ctx); initHint = false; }      // PCGInit1 ran on the previous bind's verdict (see pcgIteration)
+        if (initPending && initHint && !lattice) { launchJtf(false, ctx); initHint = false; }      // PCGInit1 ran on the previous bind's verdict (see beginLoop)
         if (!lattice) return false;
         ocInit();
         const int tX = divUp(A.W, kOcTileW);
@@ -1810,15 +477,6 @@ struct ImageWarpingOps : EnergyOps<T> {
         ocFailed = true;
         return true;
     }
-    void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {
-        ScopedKernel k(ctx, "computeModelCost");
-        const int g = flatGrid((long)A.W * (A.yEnd - A.yBegin));
-        iw_modelCost<T><<<g, kBlock, 0, ctx.stream>>>(A, delta, out.partials);
-        out.n = g;
-    }
-    bool iterPostsItself(bool lmLoop) const override { return !lmLoop && recomputeAp && this->slab.active && this->slab.ghost >= 2 && (sizeof(T) == 4 ? true : true); }
-    bool supportsSlab() const override { return true; }
-    long rowScalars(int img) const override { return (long)A.W * (img == 0 ? 2 : 1); }
 };
 
 template <class T> EnergyOps<T>* makeIW(const unsigned* dims) { return new ImageWarpingOps<T>(dims); }

@@ -79,5 +79,41 @@ __device__ __forceinline__ void iw_pairInherited(const PairOut<T>& o, T nOn, T& 
     ax -= nOn * o.dx; ay -= nOn * o.dy;
     aa -= nOn * o.tn;
 }
+template <class T>
+struct IWArgs {
+    int W, H;                 // local image (incl. ghost rows in slab mode)
+    int yBegin, yEnd;         // owned rows
+    int gy0, Hg;              // global row of local row 0, global height
+    const T* Offset; const T* Angle; const T* UrShape; const T* Constraints; const T* Mask;
+    T w_fit, w_reg;
+    uint8_t* flags;           // bit0: pixel exists and Mask == 0 ; bit1: fit constraint valid ; bits 2-4: number of active 4-neighbours
+    T* cs;                    // (cos a, sin a) per pixel
+};
+
+
+// A real register copy the compiler cannot fold.  The marching kernels pass some loaded fields (cos/sin, U, M) through
+// unchanged for three rows; left to itself the compiler keeps them in the registers the load wrote, has to rotate the
+// prefetch buffers with v_movs at the loop back-edge, and a v_mov of a register whose load is still in flight costs an
+// s_waitcnt there -- the prefetch drains every trip.  Copying once, where the data is consumed anyway, frees the raw
+// registers so the next prefetch lands in the same ones and the back-edge carries no waits.
+__device__ __forceinline__ float regCopy(float v) { float r; asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(v)); return r; }
+__device__ __forceinline__ int regCopy(int v) { int r; asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(v)); return r; }
+__device__ __forceinline__ double regCopy(double v) { return __hiloint2double(regCopy(__double2hiint(v)), regCopy(__double2loint(v))); }
+
+
+// Row addressing through buffer descriptors: element (row, x) of an array is  descriptor(base)  +  soffset = row * W * size (+ the offset of the Angle
+// part), one SALU product shared by all arrays of a row  +  voffset = x * size, a per-lane constant of the whole launch.  A load or store then needs no
+// address VALU at all.  Byte offsets are 32-bit: a kernel takes this form only while the solver vector stays below 4 GiB.
+typedef unsigned int iw_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned int iw_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t iw_rsrc(const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1 /* 2^32 - 1 bytes */, 0x00020000); }
+__device__ __forceinline__ V2<float> bufLd2(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, const float*) { const iw_u2 w = __builtin_amdgcn_raw_buffer_load_b64(r, (int)v, (int)so, 0); return V2<float>{__uint_as_float(w.x), __uint_as_float(w.y)}; }
+__device__ __forceinline__ V2<double> bufLd2(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, const double*) { const iw_u4 w = __builtin_amdgcn_raw_buffer_load_b128(r, (int)v, (int)so, 0); V2<double> o; __builtin_memcpy(&o, &w, 16); return o; }
+__device__ __forceinline__ float bufLd1(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, const float*) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)v, (int)so, 0)); }
+__device__ __forceinline__ double bufLd1(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, const double*) { const iw_u2 w = __builtin_amdgcn_raw_buffer_load_b64(r, (int)v, (int)so, 0); double o; __builtin_memcpy(&o, &w, 8); return o; }
+__device__ __forceinline__ void bufSt2(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, float x, float y) { __builtin_amdgcn_raw_buffer_store_b64(iw_u2{__float_as_uint(x), __float_as_uint(y)}, r, (int)v, (int)so, 0); }
+__device__ __forceinline__ void bufSt2(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, double x, double y) { const V2<double> o{x, y}; iw_u4 w; __builtin_memcpy(&w, &o, 16); __builtin_amdgcn_raw_buffer_store_b128(w, r, (int)v, (int)so, 0); }
+__device__ __forceinline__ void bufSt1(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, float x) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, (int)v, (int)so, 0); }
+__device__ __forceinline__ void bufSt1(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so, double x) { iw_u2 w; __builtin_memcpy(&w, &x, 8); __builtin_amdgcn_raw_buffer_store_b64(w, r, (int)v, (int)so, 0); }
 }  // namespace
 }  // namespace optamd

@@ -600,6 +600,7 @@ struct PcgSolver : SolverBase {
                 return true;
             }
         }
+        if (distributed && !E->slabIterationAvailable()) return false;      // (before anything is exchanged: the three-kernel loop needs r = 0 on ghost rows)
         Reduction prev[4] = {redC, Reduction{}, Reduction{}, Reduction{}};   // alphaNum_0 = sum r.p from PCGInit1
         if (distributed) {   // ghost rows of r_0, M and p_0 (written as 0 by evalJTF / PCGInit1_Finish) come from the slab neighbours once
             exchangeVector(r); exchangeVector(p); if (preArg) exchangeVector(preconditioner);

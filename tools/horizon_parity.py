@@ -6,8 +6,10 @@ Three HIP loops on identical inputs, one Gauss-Newton step each, lIterations in 
 
   ref-order : OPT_AMD_ONEKERNEL=0 -- the reference's sequence (PCGStep1, PCGStep2, PCGStep3 as separate passes, r and A p stored, beta numerator summed
               directly from z.r: solverGPUGaussNewton.t:421-550)
-  r-stored  : OPT_AMD_RFREE=0     -- one launch per iteration, A p recomputed, beta by expansion, r kept in memory
-  r-free    : default             -- additionally r rebuilt from the last two search directions (the benchmarked loop)
+  r-free    : OPT_AMD_ONCHIP=0    -- one launch per iteration (iw_pcgIter2: A p recomputed, beta by expansion, r rebuilt from the last two search directions): the
+              benchmarked loop at 4096^2
+  on-chip   : default             -- the whole linear solve as one persistent launch where the image fits the chip (iw_onchipPcg: 1024^2 does, 2048^2 does not and
+              takes the r-free loop again)
 
 against the frozen oracle costs of tests/golden/horizon_costs.json, with |oracle plain - oracle fma| (the same CPU restatement compiled with and without
 fused multiply-adds, horizon_costs_fma.json) beside them as the yardstick of what rounding alone does at that horizon.
@@ -25,7 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 GOLD = os.path.join(ROOT, "tests", "golden")
 HORIZONS = [20, 50, 100, 200, 400]
-LOOPS = {"ref-order": {"OPT_AMD_ONEKERNEL": "0"}, "r-stored": {"OPT_AMD_RFREE": "0"}, "r-free": {}}
+LOOPS = {"ref-order": {"OPT_AMD_ONEKERNEL": "0", "OPT_AMD_ONCHIP": "0"}, "r-free": {"OPT_AMD_ONCHIP": "0"}, "on-chip": {"OPT_AMD_ONCHIP": "1"}}
 ADVERSARIAL = dict(fit_fraction=0.002, w_fit_sqrt=100.0, w_reg_sqrt=0.01, random_state=5)      # = tests/golden/make_horizon_costs.py
 ADVERSARIAL_SIZE = 1024
 
@@ -95,19 +97,19 @@ def experiment(families=("horizon", "adversarial"), precisions=("float", "double
                     c = hip_cost(fam, dbl, L, env)[1]
                     row[name] = c
                     row[name + "_rel"] = abs(c - ref) / abs(ref)
-                row["rfree_vs_rstored"] = abs(row["r-free"] - row["r-stored"]) / abs(row["r-stored"])
+                row["onchip_vs_rfree"] = abs(row["on-chip"] - row["r-free"]) / abs(row["r-free"])
                 rows.append(row)
                 print(json.dumps(row), flush=True)
     return rows
 
 
 def markdown(rows):
-    out = ["| family | precision | PCG iterations | oracle cost | ref-order HIP | r-stored HIP | r-free HIP | r-free vs r-stored | oracle plain vs fma | oracle float vs double |",
+    out = ["| family | precision | PCG iterations | oracle cost | ref-order HIP | r-free HIP | on-chip HIP | on-chip vs r-free | oracle plain vs fma | oracle float vs double |",
            "|---|---|---|---|---|---|---|---|---|---|"]
     f = lambda v: "n/a" if v is None else f"{v:.2e}"
     for r in rows:
-        out.append(f"| {r['family']} {r['size']}² | {r['precision']} | {r['liters']} | {r['oracle']:.9g} | {f(r['ref-order_rel'])} | {f(r['r-stored_rel'])} | {f(r['r-free_rel'])} | "
-                   f"{f(r['rfree_vs_rstored'])} | {f(r.get('oracle_plain_vs_fma'))} | {f(r.get('oracle_float_vs_double'))} |")
+        out.append(f"| {r['family']} {r['size']}² | {r['precision']} | {r['liters']} | {r['oracle']:.9g} | {f(r['ref-order_rel'])} | {f(r['r-free_rel'])} | {f(r['on-chip_rel'])} | "
+                   f"{f(r['onchip_vs_rfree'])} | {f(r.get('oracle_plain_vs_fma'))} | {f(r.get('oracle_float_vs_double'))} |")
     return "\n".join(out)
 
 
