@@ -275,6 +275,7 @@ def main():
         local_rank = 0
         # all ranks on one GPU: their iteration kernels poll each other's posted sums, so together they must fit the chip (opt_amd/csrc/energy_image_warping.hip splitRows)
         os.environ.setdefault("OPT_AMD_ITER_MAXWG", str(max(1, 224 // max(1, world))))
+        os.environ.setdefault("OPT_AMD_PEER_POST", "1")      # (the communicator takes the posted all-reduce away when ranks share a GPU, unless told that the grids are capped)
     torch.cuda.set_device(local_rank)
     if distributed:
         if args.share_gpu:
@@ -290,12 +291,15 @@ def main():
     total_steps = args.warmup + args.steps
 
     comm_ranks = 1
+    preflight = None
     if distributed:
         from opt_amd import slab
         job = slab.SlabJob("image_warping", W, H, rank, world, comm=args.comm)     # every rank generates only its own slab (+ ghost rows)
         solver, dev, host0, unknown_slots = job.solver, job.params, job.local.params, job.local.unknown_slots
         comm_ranks = job.comm_ranks()
         args.comm = job.comm_kind              # "rccl" if the peer communicator was unavailable or failed its self-test on this machine
+        preflight = [None] * world             # per rank: which devices it can reach, IPC window / open / self-test, which communicator was chosen and why
+        dist.all_gather_object(preflight, job.preflight)
     else:
         P = wl.image_warping(W, H)
         dev = api.to_device(P)
@@ -319,8 +323,26 @@ def main():
         return float(t.item())
 
     def comm_error():
-        """Non-zero if the peer communicator raised its time-out flag: the sums of that run are garbage."""
-        return job.comm_error() if distributed else 0
+        """Non-zero if ANY rank's communicator is in its error state (a wait for a peer timed out, an oversize exchange, a HIP / RCCL error): the sums of that
+        run are garbage.  Collective, so that every rank takes the same exit."""
+        if not distributed:
+            return 0
+        t = torch.tensor([float(job.comm_error())], dtype=torch.float64, device="cpu" if args.share_gpu else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item())
+
+    def fail(code, where):
+        """One JSON error line on rank 0 and a non-zero exit code on every rank (the driver reads stdout; a library exit(1) used to leave nothing)."""
+        if rank == 0:
+            print(json.dumps({"error": "communicator failure", "where": where, "code": code, "codes": "peer: 1 all-reduce timed out, 2 halo acknowledgement, 3 halo rows, "
+                              "4 posted all-reduce polled by the iteration kernel, 5 oversize exchange, 6 too many values, 7 HIP error; rccl: ncclResult_t",
+                              "n_gpus": world, "comm": args.comm, "metric": f"PCG iters/s, GN solve of image_warping {W}^2", "value": None}), flush=True)
+        if distributed:
+            try:
+                dist.destroy_process_group()
+            except Exception:      # noqa
+                pass
+        os._exit(4)
 
     # ---- the timed region: K Opt_ProblemSteps ----------------------------------------------------------------------------------
     sync()                                   # ranks enter the first collective of the solve together
@@ -339,8 +361,9 @@ def main():
     dt = max_over_ranks(time.perf_counter() - t0)
     cost_final = solver.cost()
     value = args.steps * args.liters / dt
-    if comm_error():
-        sys.exit(f"bench.py: rank {rank}: the peer communicator timed out during the timed steps (code {comm_error()}); no result")
+    err = comm_error()
+    if err:
+        fail(err, "timed steps")
 
     gold, env = golden_cost(W, args.liters)
     parity = None
@@ -359,13 +382,25 @@ def main():
     # ---- roofline leg: the same plan goes on for two more steps with per-kernel hipEvents on the solver's stream -------------------
     roofline = None
     sha = kernel_src_sha16()
+    comm_us = None
     if extra_steps:
         solver.set_timing(True)
+        if distributed:
+            job.set_comm_timing(True)
         for _ in range(extra_steps):
             solver.step(dev)
         sync()
         kt = solver.kernel_timings()
         solver.set_timing(False)
+        if distributed:
+            ct = job.comm_timings()
+            job.set_comm_timing(False)
+            if ct:      # rank 0's hipEvents around the communicator's own kernels, per PCG iteration
+                its = extra_steps * args.liters
+                comm_us = {"allreduce_us_per_iteration": 1e3 * ct["allreduce"][1] / its, "allreduce_launches": ct["allreduce"][0],
+                           "halo_us_per_iteration": 1e3 * ct["halo"][1] / its, "halo_exchanges": ct["halo"][0],
+                           "note": "all-reduce = the one-workgroup kernel that sums this rank's partials and posts them to every mailbox (the wait for the peers' words "
+                                   "happens in the next iteration kernel's prologue), or the waiting all-reduce; halo = push + pull kernels, one exchange per ghost - 1 iterations"}
         if rank == 0 and "PCGIteration" in kt:
             cnt, tot = kt["PCGIteration"]
             avg_s = tot / cnt * 1e-3
@@ -387,7 +422,7 @@ def main():
                         "kernel_ms_per_step": per_step, "kernel_ms_per_step_sum": sum(v for k, v in per_step.items() if k != "overall"),
                         "kernel_avg_ms": {k: v[1] / v[0] for k, v in kt.items()}}
             if distributed:
-                roofline.update({"slab_rows": rows, "ghost_rows": job.layout.ghost, "per_iteration_ms": dt / args.steps / args.liters * 1e3,
+                roofline.update({"slab_rows": rows, "ghost_rows": job.layout.ghost, "per_iteration_ms": dt / args.steps / args.liters * 1e3, "comm_kernels": comm_us,
                                  "note": "rank 0's slab; per_iteration_ms - avg_kernel_ms = communicator kernels (all-reduce every iteration, halo exchange every ghost - 1 "
                                          "iterations; launched by libOptComm, not in the table) + launch gaps"})
 
@@ -468,6 +503,30 @@ def main():
     if rank == 0 and not distributed and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_size, args.cpu_liters)
 
+    # ---- the same slabs over RCCL (north_star names RCCL over xGMI): a short leg in the same job, so that RCCL demonstrably sees N ranks and both per-iteration
+    # times stand side by side.  Ranks that share one GPU cannot form an RCCL communicator.
+    rccl_leg = None
+    if distributed and args.comm == "peer" and not args.no_extras:
+        if args.share_gpu:
+            rccl_leg = {"skipped": "needs distinct devices (ranks share one GPU in this run)"}
+        else:
+            err = comm_error()
+            if err:
+                fail(err, "before the RCCL leg")
+            from opt_amd import slab
+            job2 = slab.SlabJob("image_warping", W, H, rank, world, comm="rccl")
+            job2.solver.set_parameter("nIterations", 3); job2.solver.set_parameter("lIterations", args.liters)
+            sync()
+            job2.solver.init(job2.params); job2.solver.step(job2.params)
+            sync()
+            t1 = time.perf_counter()
+            job2.solver.step(job2.params); job2.solver.step(job2.params)
+            sync()
+            rdt = max_over_ranks(time.perf_counter() - t1)
+            rccl_leg = {"comm": "rccl", "comm_ranks": job2.comm_ranks(), "steps": 2, "value": 2 * args.liters / rdt, "per_iteration_ms": rdt / 2 / args.liters * 1e3,
+                        "cost_after_3_steps": job2.solver.cost(), "comm_error": job2.comm_error()}
+            job2.close()
+
     if rank == 0:
         out = {"metric": f"PCG iters/s, GN solve of image_warping {W}^2", "value": value, "unit": "PCG iters/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -477,7 +536,8 @@ def main():
                           "parallelism": f"row-slabs x{world}, comm={args.comm}, ranks in the communicator: {comm_ranks}" if distributed else "single GPU",
                           "step": "one Opt_ProblemStep (1 GN iteration)"},
                "gn_solve": solve, "gn_solve_ms": solve["gn_solve_ms"] if solve else None,
-               "cost_initial": costs[0], "cost_final": cost_final, "parity": parity, "comm_ranks": comm_ranks,
+               "cost_initial": costs[0], "cost_final": cost_final, "parity": parity, "comm_ranks": comm_ranks, "preflight": preflight, "rccl_leg": rccl_leg,
+               "per_iteration_ms": dt / args.steps / args.liters * 1e3,
                "kernel_src_sha16": sha, "roofline": roofline, "general_urshape": general, "onchip": onchip, "reference_example_flows": flows, "cpu_baseline": cpu}
         print(json.dumps(out))
     if distributed:

@@ -42,7 +42,12 @@ unsigned long OptAmd_ProblemFileHash(const char* filename);
 long OptAmd_PlanNumUnknownScalars(Opt_Plan* plan);
 /* Device pointer of a solver vector owned by the plan: "delta","r","b","Adelta","z","p","Ap_X","CtC",
  * "preconditioner","SSq","prevX" (reference PlanData fields, solverGPUGaussNewton.t:173-185).
- * NULL for an unknown name. */
+ * NULL for an unknown name.
+ * What they hold after an Opt_ProblemStep is the reference's content only where the path that ran materialises the vector.  Gauss-Newton image_warping on
+ * one GPU keeps its loop state elsewhere: "delta" holds the step's update only when the linear solve ran on chip (iw_onchipPcg); with the streaming loop the
+ * last one or two alpha * p terms go straight into the unknowns and "delta" lacks them (it is never written when lIterations <= 2); "p" / "r" hold the
+ * PCGInit1 values, "preconditioner" / "CtC" / "Ap_X" are not written at all.  Every other energy, LM, row slabs and OPT_AMD_ONEKERNEL=0 fill them as
+ * the reference does. */
 void* OptAmd_PlanVector(Opt_Plan* plan, const char* name);
 
 /* Kernel-level entry points.  Each binds `problemparams` exactly like Opt_ProblemInit, launches the
@@ -136,6 +141,9 @@ typedef struct OptAmd_SlabCommExt {
      * contributions are still crossing the links, instead of behind a kernel that waited for them.  Returns 0 if unavailable.  n <= 8.  At most two
      * posted all-reduces may be outstanding (the mailbox has four slots). */
     int (*allReducePost)(void* ctx, const double* const* partials, const int* counts, int n, OptAmd_MailRef* ref, void* stream);
+    /* CO-RESIDENCY: every workgroup of the consuming kernel polls the mailbox, so the kernels of ALL ranks must be resident at the same time -- true with one GPU
+     * per rank, false for ranks that share a GPU with full-chip grids (a post kernel then queues behind a peer's launch that is waiting for it).  A communicator
+     * must leave this member (and allReducePlan) NULL when ranks share a device; libOptComm's peer communicator does (it compares PCI bus ids at connect time). */
     /* The same without any kernel of the communicator's: reserves the next all-reduce and describes it -- *post for the kernel that produces the n sums
      * (it posts them itself from its last workgroup, OptAmd_MailPost), *ref for the kernel that consumes them.  Between two PCG iteration kernels there is
      * then nothing at all.  Returns 0 if unavailable.  The reserved all-reduce MUST be carried out by a kernel enqueued before the next call of any entry point

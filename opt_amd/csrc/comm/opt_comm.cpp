@@ -20,7 +20,8 @@
 #include <vector>
 
 #define CK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "OptComm: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
-#define CK_NCCL(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { fprintf(stderr, "OptComm: RCCL error %s at %s:%d\n", ncclGetErrorString(r_), __FILE__, __LINE__); exit(1); } } while (0)
+// RCCL errors inside a callback are recorded on the context (sticky: later callbacks are skipped) and reported through OptComm_RcclError -- a library does not exit().
+#define CK_NCCL(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { fprintf(stderr, "OptComm(rccl) rank %d: %s at %s:%d\n", ctx_->rank, ncclGetErrorString(r_), __FILE__, __LINE__); ctx_->err = (int)r_; return; } } while (0)
 
 namespace {
 
@@ -28,10 +29,13 @@ namespace {
 struct RcclCtx {
     ncclComm_t comm;
     int rank, world;
+    int err = 0;
     OptAmd_SlabComm api;
 };
 void rcclHalo(void* c, int nb, const void* const* su, const void* const* sd, void* const* ru, void* const* rd, const long* bytes, void* stream) {
     auto* x = (RcclCtx*)c; hipStream_t s = (hipStream_t)stream;
+    RcclCtx* const ctx_ = x;
+    if (x->err) return;
     CK_NCCL(ncclGroupStart());
     for (int k = 0; k < nb; ++k) {
         if (x->rank > 0) { CK_NCCL(ncclSend(su[k], bytes[k], ncclChar, x->rank - 1, x->comm, s)); CK_NCCL(ncclRecv(ru[k], bytes[k], ncclChar, x->rank - 1, x->comm, s)); }
@@ -41,6 +45,8 @@ void rcclHalo(void* c, int nb, const void* const* su, const void* const* sd, voi
 }
 void rcclAllReduce(void* c, double* buf, int n, void* stream) {
     auto* x = (RcclCtx*)c;
+    RcclCtx* const ctx_ = x;
+    if (x->err) return;
     CK_NCCL(ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, x->comm, (hipStream_t)stream));
 }
 
@@ -100,12 +106,14 @@ int OptComm_GetUniqueId(char* out) { ncclUniqueId id; if (ncclGetUniqueId(&id) !
 void* OptComm_CreateRccl(const char* uniqueId, int rank, int world) {
     auto* x = new RcclCtx; x->rank = rank; x->world = world;
     ncclUniqueId id; memcpy(&id, uniqueId, sizeof(id));
-    CK_NCCL(ncclCommInitRank(&x->comm, world, id, rank));
+    const ncclResult_t r = ncclCommInitRank(&x->comm, world, id, rank);
+    if (r != ncclSuccess) { fprintf(stderr, "OptComm(rccl) rank %d: ncclCommInitRank failed: %s\n", rank, ncclGetErrorString(r)); delete x; return nullptr; }
     x->api = OptAmd_SlabComm{x, rank, world, rcclHalo, rcclAllReduce};
     return x;
 }
 const OptAmd_SlabComm* OptComm_RcclSlabComm(void* c) { return &((RcclCtx*)c)->api; }
 int OptComm_RcclCount(void* c) { int n = 0; if (ncclCommCount(((RcclCtx*)c)->comm, &n) != ncclSuccess) return -1; return n; }   // ranks RCCL itself sees
+int OptComm_RcclError(void* c) { return ((RcclCtx*)c)->err; }
 void OptComm_DestroyRccl(void* c) { auto* x = (RcclCtx*)c; ncclCommDestroy(x->comm); delete x; }
 
 void* OptComm_CreateThreadWorld(int world) { return new ThreadWorld(world); }

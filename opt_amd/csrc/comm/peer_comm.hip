@@ -21,8 +21,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
+#include <vector>
 
-#define CK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "OptComm(peer): HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+// Set-up and self-test: a HIP error there is reported and makes the entry point fail (the launcher falls back to RCCL); nothing in this library calls exit().
+#define CK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "OptComm(peer): HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 0; } } while (0)
+// Inside the communicator callbacks (which return nothing): record the error on the context; every later callback is then a no-op and the owner of the communicator
+// finds the code with OptComm_PeerError (bench.py prints a JSON error line and exits non-zero; opt_amd.slab.SlabJob.close raises).
+#define CK_HIP_CB(x, X) do { hipError_t e_ = (X); if (e_ != hipSuccess) { fprintf(stderr, "OptComm(peer) rank %d: HIP error %s at %s:%d\n", (x)->rank, hipGetErrorString(e_), __FILE__, __LINE__); fail((x), 7); return; } } while (0)
 
 namespace {
 
@@ -56,6 +62,10 @@ struct PeerCtx {
     volatile int* hostErr;         // pinned, device-visible
     long long timeoutTicks;        // wall_clock64 ticks (100 MHz)
     int memKind;                   // 3 uncached, 1 fine-grained, 0 plain hipMalloc
+    bool sharedDevice;             // some other rank's window lives on this rank's GPU (tests, bench.py --share-gpu)
+    char busId[32];                // PCI bus id of this rank's GPU, exchanged with the IPC handle
+    // optional hipEvent timing of the communicator's own kernels (OptComm_PeerSetTiming): {all-reduce, halo} x {count, pairs}
+    bool timing; std::vector<std::pair<hipEvent_t, hipEvent_t>> evAr, evHalo; double msAr, msHalo; long nAr, nHalo;
     OptAmd_SlabComm api;
     OptAmd_SlabCommExt ext;
 };
@@ -247,23 +257,37 @@ __global__ __launch_bounds__(256) void k_haloPull(HaloArgs H, Peers P, const cha
     }
 }
 
-void checkErr(PeerCtx* x, const char* where) {
+// Error codes (OptComm_PeerError): 1 all-reduce timed out, 2 halo acknowledgement, 3 halo rows, 4 a posted all-reduce polled by an iteration kernel,
+// 5 an exchange larger than the staging area, 6 more values / buffers than a call supports, 7 a HIP error inside a callback.  Sticky: once set, every
+// callback returns at once (the sums of that run are garbage either way) and the owner reports it -- the library never ends the process.
+void fail(PeerCtx* x, int code) { if (!*x->hostErr) *x->hostErr = code; }
+bool failed(PeerCtx* x, const char* where) {
     const int e = *x->hostErr;
-    if (e) {
-        fprintf(stderr, "OptComm(peer) rank %d: timeout waiting for a peer (%s; code %d: 1 = all-reduce, 2 = halo ack, 3 = halo rows, 4 = posted all-reduce polled by the iteration kernel) -- a rank died or fell out of step\n",
-                x->rank, where, e);
-        exit(3);
-    }
+    if (!e) return false;
+    static int said = 0;
+    if (!said++) fprintf(stderr, "OptComm(peer) rank %d: communicator in error state at %s (code %d: 1 = all-reduce timed out, 2 = halo ack, 3 = halo rows, 4 = posted all-reduce polled by the "
+                                  "iteration kernel, 5 = oversize exchange, 6 = too many values, 7 = HIP error) -- a rank died or fell out of step; further collectives are skipped\n", x->rank, where, e);
+    return true;
 }
+struct ScopedEv {      // brackets a callback's launches with an event pair when timing is on
+    PeerCtx* x; std::vector<std::pair<hipEvent_t, hipEvent_t>>* v; hipStream_t s; hipEvent_t b = nullptr;
+    ScopedEv(PeerCtx* x_, std::vector<std::pair<hipEvent_t, hipEvent_t>>* v_, hipStream_t s_) : x(x_), v(v_), s(s_) {
+        if (!x->timing) return;
+        hipEvent_t a; if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { b = nullptr; return; }
+        (void)hipEventRecord(a, s); v->push_back({a, b});
+    }
+    ~ScopedEv() { if (b) (void)hipEventRecord(b, s); }
+};
 Peers peersOf(PeerCtx* x) { Peers P; for (int r = 0; r < kMaxWorld; ++r) P.win[r] = x->win[r]; return P; }
 
 void peerAllReduceImpl(PeerCtx* x, double* buf, const PartialsIn* parts, int n, hipStream_t s) {
-    checkErr(x, "allReduce");
-    if (n > kMaxVals) { fprintf(stderr, "OptComm(peer): all-reduce of %d > %d doubles\n", n, kMaxVals); exit(1); }
+    if (failed(x, "allReduce")) return;
+    if (n > kMaxVals) { fprintf(stderr, "OptComm(peer): all-reduce of %d > %d doubles\n", n, kMaxVals); fail(x, 6); return; }
     PartialsIn pin{}; if (parts) pin = *parts;
     ++x->arSeq;
+    ScopedEv ev(x, &x->evAr, s);
     k_mailAllReduce<<<1, 256, 0, s>>>(buf, pin, parts ? 1 : 0, n, peersOf(x), x->rank, x->world, x->arSeq, x->timeoutTicks, x->hostErr);
-    CK_HIP(hipGetLastError());
+    CK_HIP_CB(x, hipGetLastError());
 }
 void peerAllReduce(void* c, double* buf, int n, void* stream) { peerAllReduceImpl((PeerCtx*)c, buf, nullptr, n, (hipStream_t)stream); }
 void peerAllReducePartials(void* c, const double* const* parts, const int* counts, int n, double* out, void* stream) {
@@ -273,20 +297,23 @@ void peerAllReducePartials(void* c, const double* const* parts, const int* count
 }
 int peerAllReducePost(void* c, const double* const* parts, const int* counts, int n, OptAmd_MailRef* ref, void* stream) {
     auto* x = (PeerCtx*)c;
-    checkErr(x, "allReducePost");
+    if (failed(x, "allReducePost")) return 0;
     if (n > kMaxVals || !ref) return 0;
     PartialsIn pin{};
     for (int i = 0; i < n; ++i) { pin.p[i] = parts[i]; pin.n[i] = counts[i]; }
     const u64 seq = ++x->arSeq;
-    k_mailPost<<<1, 256, 0, (hipStream_t)stream>>>(pin, n, peersOf(x), x->rank, x->world, seq);
-    CK_HIP(hipGetLastError());
+    {
+        ScopedEv ev(x, &x->evAr, (hipStream_t)stream);
+        k_mailPost<<<1, 256, 0, (hipStream_t)stream>>>(pin, n, peersOf(x), x->rank, x->world, seq);
+    }
+    if (hipGetLastError() != hipSuccess) { fail(x, 7); return 0; }
     ref->words = &x->win[x->rank]->ll[seq % kSlots][0][0];
     ref->world = x->world; ref->stride = 2 * kMaxVals; ref->tag = (unsigned)seq; ref->timeoutTicks = x->timeoutTicks; ref->errFlag = (int*)x->hostErr;
     return 1;
 }
 int peerAllReducePlan(void* c, int n, OptAmd_MailPost* post, OptAmd_MailRef* ref) {
     auto* x = (PeerCtx*)c;
-    checkErr(x, "allReducePlan");
+    if (failed(x, "allReducePlan")) return 0;
     if (n > kMaxVals || !post || !ref) return 0;
     const u64 seq = ++x->arSeq;
     const int slot = (int)(seq % kSlots);
@@ -298,16 +325,16 @@ int peerAllReducePlan(void* c, int n, OptAmd_MailPost* post, OptAmd_MailRef* ref
 }
 void peerHalo(void* c, int nb, const void* const* su, const void* const* sd, void* const* ru, void* const* rd, const long* bytes, void* stream) {
     auto* x = (PeerCtx*)c; hipStream_t s = (hipStream_t)stream;
-    checkErr(x, "haloExchange");
+    if (failed(x, "haloExchange")) return;
     if (x->world == 1) return;
-    if (nb > 8) { fprintf(stderr, "OptComm(peer): %d > 8 buffers in one exchange\n", nb); exit(1); }
+    if (nb > 8) { fprintf(stderr, "OptComm(peer): %d > 8 buffers in one exchange\n", nb); fail(x, 6); return; }
     HaloArgs H{}; H.nb = nb;
     long off = 0;
     for (int k = 0; k < nb; ++k) {
         H.sendUp[k] = (const char*)su[k]; H.sendDown[k] = (const char*)sd[k]; H.recvUp[k] = (char*)ru[k]; H.recvDown[k] = (char*)rd[k];
         H.bytes[k] = bytes[k]; H.offset[k] = off; off += (bytes[k] + 15) / 16 * 16;
     }
-    if ((size_t)off > x->stageBytes) { fprintf(stderr, "OptComm(peer): exchange of %ld bytes per side exceeds the staging capacity %zu (OptComm_PeerCreate)\n", off, x->stageBytes); exit(1); }
+    if ((size_t)off > x->stageBytes) { fprintf(stderr, "OptComm(peer): exchange of %ld bytes per side exceeds the staging capacity %zu (OptComm_PeerCreate)\n", off, x->stageBytes); fail(x, 5); return; }
     const u64 seq = ++x->haloSeq;
     const size_t blk = (size_t)(seq % kStageDepth) * x->stageBytes;
     // staging layout behind every window: [side 0 = rows coming from the rank above][side 1 = from the rank below], each kStageDepth blocks
@@ -316,16 +343,18 @@ void peerHalo(void* c, int nb, const void* const* su, const void* const* sd, voi
     const char* fromUp = x->stage[x->rank] + blk;
     const char* fromDown = x->stage[x->rank] + (size_t)kStageDepth * x->stageBytes + blk;
     const int grid = (int)std::max<long>(1, std::min<long>(64, off / (256 * 16) + 1));
+    ScopedEv ev(x, &x->evHalo, s);
     k_haloPush<<<grid, 256, 0, s>>>(H, peersOf(x), stageUp, stageDown, x->rank, x->world, seq, x->dCounter, x->timeoutTicks, x->hostErr);
     k_haloPull<<<grid, 256, 0, s>>>(H, peersOf(x), fromUp, fromDown, x->rank, x->world, seq, x->dCounter + 1, x->timeoutTicks, x->hostErr);
-    CK_HIP(hipGetLastError());
+    CK_HIP_CB(x, hipGetLastError());
 }
 
 }  // namespace
 
 extern "C" {
 
-int OptComm_PeerHandleBytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+// What the ranks all-gather: the IPC handle of the window followed by the PCI bus id of the GPU it lives on (so that a rank can tell that a peer SHARES its GPU).
+int OptComm_PeerHandleBytes(void) { return (int)sizeof(hipIpcMemHandle_t) + 32; }
 int OptComm_PeerMaxWorld(void) { return kMaxWorld; }
 
 // Phase 1 (every rank, its own GPU current): allocate the window + staging (stageBytes per side and depth), export its IPC handle.
@@ -351,6 +380,11 @@ void* OptComm_PeerCreate(int rank, int world, long stageBytes, double timeoutSec
         x->base = nullptr;
     }
     if (!x->base) { fprintf(stderr, "OptComm(peer): could not allocate an IPC-exportable window (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)\n"); delete x; return nullptr; }
+    {
+        int dev = 0; memset(x->busId, 0, sizeof x->busId);
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(x->busId, (int)sizeof x->busId - 1, dev) != hipSuccess) snprintf(x->busId, sizeof x->busId, "device-%d", dev);
+    }
+    x->sharedDevice = false; x->timing = false; x->msAr = x->msHalo = 0; x->nAr = x->nHalo = 0;
     CK_HIP(hipMemset(x->base, 0, total));
     CK_HIP(hipDeviceSynchronize());
     x->win[rank] = (Window*)x->base;
@@ -363,7 +397,10 @@ void* OptComm_PeerCreate(int rank, int world, long stageBytes, double timeoutSec
     x->api = OptAmd_SlabComm{x, rank, world, peerHalo, peerAllReduce};
     x->ext = OptAmd_SlabCommExt{};
     x->ext.size = sizeof(OptAmd_SlabCommExt); x->ext.allReducePartials = peerAllReducePartials;
-    if (const char* e = getenv("OPT_AMD_PEER_POST")) { if (atoi(e) != 0) x->ext.allReducePost = peerAllReducePost; }      // A/B switch; default below
+    // The posted all-reduce is polled by EVERY workgroup of the next iteration kernel, which is only safe while all ranks' kernels are co-resident: on one GPU per
+    // rank they are; ranks that share a GPU would wait for a post kernel queued behind a peer's full-chip launch.  OptComm_PeerConnect therefore takes it away when it
+    // finds a peer on this rank's GPU -- unless OPT_AMD_PEER_POST=1 insists (tests and bench.py --share-gpu, which cap the grids with OPT_AMD_ITER_MAXWG); =0: never.
+    if (const char* e = getenv("OPT_AMD_PEER_POST")) { if (atoi(e) != 0) x->ext.allReducePost = peerAllReducePost; }
     else x->ext.allReducePost = peerAllReducePost;
     // allReducePlan (the iteration kernel's last workgroup posts; no kernel of ours between two iterations) is OFF unless OPT_AMD_PEER_PLAN=1: measured on one GPU
     // (tools/slab_overhead.py, profiles/r03_slab_overhead_posted_allreduce.txt) the device-scope release / acquire around the ticket costs more than the
@@ -371,19 +408,43 @@ void* OptComm_PeerCreate(int rank, int world, long stageBytes, double timeoutSec
     if (const char* e = getenv("OPT_AMD_PEER_PLAN")) { if (atoi(e) != 0) x->ext.allReducePlan = peerAllReducePlan; }
     return x;
 }
-void OptComm_PeerHandle(void* c, char* out) { memcpy(out, &((PeerCtx*)c)->handle, sizeof(hipIpcMemHandle_t)); }
+void OptComm_PeerHandle(void* c, char* out) { auto* x = (PeerCtx*)c; memcpy(out, &x->handle, sizeof(hipIpcMemHandle_t)); memcpy(out + sizeof(hipIpcMemHandle_t), x->busId, 32); }
+int OptComm_PeerSharesDevice(void* c) { return ((PeerCtx*)c)->sharedDevice ? 1 : 0; }
+int OptComm_PeerPosts(void* c) { return ((PeerCtx*)c)->ext.allReducePost ? 1 : 0; }
+// hipEvent timing of the communicator's own kernels from now on (totals restart): what an iteration spends in the all-reduce / post kernel and in the halo copies.
+void OptComm_PeerSetTiming(void* c, int on) {
+    auto* x = (PeerCtx*)c;
+    for (auto* v : {&x->evAr, &x->evHalo}) { for (auto& p : *v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); } v->clear(); }
+    x->msAr = x->msHalo = 0; x->nAr = x->nHalo = 0; x->timing = on != 0;
+}
+// out[4] = {all-reduce launches, their total ms, halo exchanges, their total ms} since OptComm_PeerSetTiming; synchronises the recorded events.
+void OptComm_PeerTimings(void* c, double* out) {
+    auto* x = (PeerCtx*)c;
+    auto fold = [](std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, double& ms, long& n) {
+        for (auto& p : v) { float t = 0; if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) { ms += t; ++n; } (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+        v.clear();
+    };
+    fold(x->evAr, x->msAr, x->nAr); fold(x->evHalo, x->msHalo, x->nHalo);
+    out[0] = (double)x->nAr; out[1] = x->msAr; out[2] = (double)x->nHalo; out[3] = x->msHalo;
+}
 int OptComm_PeerMemKind(void* c) { return ((PeerCtx*)c)->memKind; }
 // Phase 2 (after the handles of all ranks were gathered, rank-major): map every peer's window.
 int OptComm_PeerConnect(void* c, const char* allHandles) {
     auto* x = (PeerCtx*)c;
+    const size_t rec = sizeof(hipIpcMemHandle_t) + 32;
     for (int r = 0; r < x->world; ++r) {
         if (r == x->rank) continue;
-        hipIpcMemHandle_t h; memcpy(&h, allHandles + (size_t)r * sizeof(h), sizeof(h));
+        if (strncmp(allHandles + (size_t)r * rec + sizeof(hipIpcMemHandle_t), x->busId, 32) == 0) x->sharedDevice = true;
+        hipIpcMemHandle_t h; memcpy(&h, allHandles + (size_t)r * rec, sizeof(h));
         void* p = nullptr;
         hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
         if (e != hipSuccess) { fprintf(stderr, "OptComm(peer) rank %d: hipIpcOpenMemHandle(rank %d) failed: %s\n", x->rank, r, hipGetErrorString(e)); return 0; }
         x->win[r] = (Window*)p;
         x->stage[r] = (char*)p + (sizeof(Window) + 255) / 256 * 256;
+    }
+    if (x->sharedDevice) {      // see OptComm_PeerCreate: co-residency of all ranks' kernels is not given on a shared GPU
+        const char* e = getenv("OPT_AMD_PEER_POST");
+        if (!(e && atoi(e) != 0)) { x->ext.allReducePost = nullptr; x->ext.allReducePlan = nullptr; }
     }
     return 1;
 }

@@ -96,6 +96,11 @@ def comm_lib():
         L.OptComm_RcclSlabComm.restype = ctypes.POINTER(api.OptAmd_SlabComm); L.OptComm_RcclSlabComm.argtypes = [vp]
         L.OptComm_DestroyRccl.argtypes = [vp]
         L.OptComm_RcclCount.restype = ci; L.OptComm_RcclCount.argtypes = [vp]
+        L.OptComm_RcclError.restype = ci; L.OptComm_RcclError.argtypes = [vp]
+        L.OptComm_PeerSharesDevice.restype = ci; L.OptComm_PeerSharesDevice.argtypes = [vp]
+        L.OptComm_PeerPosts.restype = ci; L.OptComm_PeerPosts.argtypes = [vp]
+        L.OptComm_PeerSetTiming.argtypes = [vp, ci]
+        L.OptComm_PeerTimings.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
         L.OptComm_PeerHandleBytes.restype = ci
         L.OptComm_PeerMaxWorld.restype = ci
         L.OptComm_PeerCreate.restype = vp; L.OptComm_PeerCreate.argtypes = [ci, ci, ctypes.c_long, ctypes.c_double]
@@ -137,6 +142,7 @@ class PeerComm:
         if timeout_s is None:
             timeout_s = float(os.environ.get("OPT_AMD_PEER_TIMEOUT", "60"))    # ranks may reach their first all-reduce seconds apart (page-in, module load)
         self.rank, self.world = rank, world
+        self.preflight = {"ipc_window": False, "ipc_open": False, "self_test": False, "self_test_ms": None}      # what happened on THIS rank, for bench.py's pre-flight block
 
         def agree(local_ok, what):             # failures are made collective: either every rank goes on or every rank raises (no rank left in a gather)
             oks = [None] * world
@@ -151,6 +157,7 @@ class PeerComm:
                 raise RuntimeError(f"{what} failed on rank(s) {[r for r, o in enumerate(oks) if not o]}")
 
         self._ctx = L.OptComm_PeerCreate(rank, world, int(stage_bytes), float(timeout_s))
+        self.preflight["ipc_window"] = bool(self._ctx)
         agree(self._ctx, "OptComm_PeerCreate (IPC-exportable device memory)")
         n = L.OptComm_PeerHandleBytes()
         buf = ctypes.create_string_buffer(n)
@@ -160,11 +167,17 @@ class PeerComm:
             dist.all_gather_object(handles, bytes(buf.raw))
         else:
             handles[0] = bytes(buf.raw)
-        agree(L.OptComm_PeerConnect(self._ctx, b"".join(handles)), "OptComm_PeerConnect (hipIpcOpenMemHandle)")
+        opened = bool(L.OptComm_PeerConnect(self._ctx, b"".join(handles)))
+        self.preflight["ipc_open"] = opened
+        agree(opened, "OptComm_PeerConnect (hipIpcOpenMemHandle)")
         if world > 1:
             dist.barrier()                     # every window is mapped everywhere before the first peer store
         # one all-reduce and one halo exchange with known answers; every rank must pass (collective verdict), else the caller falls back to RCCL
+        import time
+        t0 = time.perf_counter()
         ok = bool(L.OptComm_PeerSelfTest(self._ctx, float(os.environ.get("OPT_AMD_PEER_SELFTEST_TIMEOUT", "5"))))
+        self.preflight.update(self_test=ok, self_test_ms=1e3 * (time.perf_counter() - t0), shares_device=bool(L.OptComm_PeerSharesDevice(self._ctx)),
+                              posted_allreduce=bool(L.OptComm_PeerPosts(self._ctx)))
         if world > 1:
             verdicts = [None] * world
             dist.all_gather_object(verdicts, ok)
@@ -180,6 +193,16 @@ class PeerComm:
 
     def error(self):
         return comm_lib().OptComm_PeerError(self._ctx)
+
+    def set_timing(self, on):
+        """hipEvent timing of the communicator's own kernels (all-reduce / post, halo push + pull) from now on."""
+        comm_lib().OptComm_PeerSetTiming(self._ctx, 1 if on else 0)
+
+    def timings(self):
+        """{all-reduce: (launches, total ms), halo: (exchanges, total ms)} since set_timing(True)."""
+        out = (ctypes.c_double * 4)()
+        comm_lib().OptComm_PeerTimings(self._ctx, out)
+        return {"allreduce": (int(out[0]), out[1]), "halo": (int(out[2]), out[3])}
 
     def close(self):
         import torch.distributed as dist
@@ -211,6 +234,11 @@ class SlabJob:
         self.params = api.to_device(self.local)
         self.comm_kind, self.world = comm, world
         L = comm_lib()
+        self._peer = None
+        dev = torch.cuda.current_device()
+        self.preflight = {"rank": rank, "device": dev, "requested_comm": comm,
+                          "can_access_peer": [bool(torch.cuda.can_device_access_peer(dev, j)) if j != dev else True for j in range(torch.cuda.device_count())]}
+        why = "requested"
         if comm == "peer":
             # the largest exchange moves `ghost` rows of two solver vectors (r and p) per side; rows are W * (unknown scalars per pixel) wide
             scalars = sum(int(np.prod(np.asarray(self.local.params[i]).shape[2:])) or 1 for i in self.local.unknown_slots)
@@ -220,10 +248,14 @@ class SlabJob:
                 usable = self._peer.self_test_ok
             except RuntimeError as e:                      # no IPC-exportable window / mapping failed: same on every rank (collective calls inside)
                 self._peer, usable = None, False
+                why = f"peer communicator unavailable: {e}"
                 if rank == 0:
                     print(f"opt_amd.slab: peer communicator unavailable ({e}); falling back to RCCL", flush=True)
+            if self._peer is not None:
+                self.preflight["peer"] = dict(self._peer.preflight, mem_kind=self._peer.mem_kind)
             if not usable:
                 if self._peer is not None:
+                    why = "peer communicator failed its self-test on some rank"
                     if rank == 0:
                         print("opt_amd.slab: peer communicator failed its self-test; falling back to RCCL", flush=True)
                     self._peer.close()
@@ -242,9 +274,12 @@ class SlabJob:
                 dist.broadcast_object_list(ids, src=0)
             self._id = ids[0]
             self._ctx = L.OptComm_CreateRccl(self._id, rank, world)
+            if not self._ctx:
+                raise RuntimeError(f"rank {rank}: ncclCommInitRank failed (ranks that share one GPU cannot form an RCCL communicator)")
             slab_comm = L.OptComm_RcclSlabComm(self._ctx)
         else:
             raise ValueError(f"unknown comm {comm!r}")
+        self.preflight.update(comm=self.comm_kind, why=why)
         self.solver = api.Solver(api.energy_file(energy), kind, (W, self.layout.local_H), double=double)
         attach_slab(self.solver, self.layout, slab_comm, slab_ext)
 
@@ -255,8 +290,16 @@ class SlabJob:
         return self._peer.world
 
     def comm_error(self):
-        """Non-zero after a peer time-out (the collectives then returned NaN sums); always 0 for RCCL, which aborts by itself."""
-        return self._peer.error() if self.comm_kind == "peer" else 0
+        """Non-zero once the communicator is in its error state (peer: a wait timed out, an exchange was oversize, a HIP error -- codes in
+        csrc/comm/peer_comm.hip; RCCL: the ncclResult_t of the failed call).  The collectives after that point were skipped: the sums are garbage."""
+        return self._peer.error() if self.comm_kind == "peer" else comm_lib().OptComm_RcclError(self._ctx)
+
+    def set_comm_timing(self, on):
+        if self.comm_kind == "peer":
+            self._peer.set_timing(on)
+
+    def comm_timings(self):
+        return self._peer.timings() if self.comm_kind == "peer" else None
 
     def owned_unknowns(self):
         g = self.layout.ghost

@@ -32,7 +32,9 @@ def _rank_main(rank, world, port, case, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OPT_AMD_PEER_TIMEOUT="8")
     # ranks SHARING one GPU: the iteration kernel polls the posted all-reduce in its prologue, so all ranks' kernels must be co-resident (on one GPU per rank they
     # trivially are): cap every rank's grid so that together they fit the chip's 256 CUs
-    os.environ["OPT_AMD_ITER_MAXWG"] = str(max(1, 224 // world))
+    if not case.get("uncapped"):
+        os.environ["OPT_AMD_ITER_MAXWG"] = str(max(1, 224 // world))
+        os.environ["OPT_AMD_PEER_POST"] = "1"      # grids capped: keep the posted all-reduce although the ranks share a GPU (the communicator would take it away)
     os.environ.update(case.get("env", {}))
     if world == 1:
         os.environ["OPT_AMD_FORCE_COMM"] = "1"
@@ -88,6 +90,21 @@ def test_peer_mailbox_ranks_as_processes(world, ghost, double):
             assert rel_err(a, b[row0:row0 + rows]) < tol
     if world == 2:
         assert res[0][1] == res[1][1]                                           # rank-ordered sums: bitwise identical on every rank
+
+
+def test_ranks_sharing_a_gpu_run_uncapped_without_deadlock():
+    """the posted all-reduce is polled by every workgroup of the next iteration kernel, which needs all ranks' kernels co-resident; ranks that share a
+    GPU with full-chip grids are not.  The communicator sees its peers' PCI bus ids next to their IPC handles and, finding one on its own GPU, keeps the waiting
+    all-reduce (one workgroup): two ranks with NO grid cap and NO switch set run to the single-GPU result."""
+    case = dict(W=300, H=128, double=False, ghost=8, kind="gaussNewtonGPU", n=2, l=14, uncapped=True)
+    P = wl.image_warping(case["W"], case["H"], double=False, random_state=3, mask_fraction=0.06, perturb=0.3)
+    c1, x1 = _single(P, case["kind"], nIterations=case["n"], lIterations=case["l"])
+    res = _run(2, case)
+    for r in range(2):
+        _, costs, unk, row0, rows, mem_kind, err = res[r]
+        assert err == 0
+        np.testing.assert_allclose(costs, c1, rtol=2e-5)
+    assert res[0][1] == res[1][1]
 
 
 @pytest.mark.parametrize("world,ghost,double", [(3, 2, True), (4, 8, False), (4, 1, True), (8, 8, False)])
@@ -169,3 +186,29 @@ def test_peer_communicator_falls_back_to_rccl_when_unavailable():
     P = wl.image_warping(64, 40, random_state=3, perturb=0.3)
     c1, _ = _single(P, "gaussNewtonGPU", nIterations=2, lIterations=10)
     np.testing.assert_allclose(costs, c1, rtol=2e-5)
+
+
+def test_bench_two_ranks_is_self_describing():
+    """the first N > 1 run must explain itself.  `bench.py --gpus 2 --share-gpu` (functional on a 1-GPU box): the JSON line carries a
+    pre-flight block per rank (reachable devices, IPC window / open / self-test with its time, communicator chosen and why), rank 0's communicator kernel times
+    per PCG iteration next to the per-iteration wall time, and the RCCL leg -- here the marker that ranks sharing a GPU cannot form an RCCL communicator."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OPT_AMD_PEER_TIMEOUT="60")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--size", "1024", "--steps", "1", "--warmup", "0", "--liters", "14", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["comm_ranks"] == 2
+    pf = out["preflight"]
+    assert len(pf) == 2 and [p["rank"] for p in pf] == [0, 1]
+    for p in pf:
+        assert p["comm"] == "peer" and p["why"] == "requested" and p["can_access_peer"][p["device"]] is True
+        assert p["peer"]["ipc_window"] and p["peer"]["ipc_open"] and p["peer"]["self_test"] and p["peer"]["self_test_ms"] > 0
+        assert p["peer"]["shares_device"] is True and p["peer"]["posted_allreduce"] is True      # bench.py --share-gpu caps the grids and says so (OPT_AMD_PEER_POST=1)
+    ck = out["roofline"]["comm_kernels"]
+    assert ck["allreduce_launches"] > 0 and ck["allreduce_us_per_iteration"] > 0 and ck["halo_exchanges"] > 0
+    assert out["per_iteration_ms"] > 0 and out["roofline"]["per_iteration_ms"] > 0
+    assert "needs distinct devices" in out["rccl_leg"]["skipped"]
