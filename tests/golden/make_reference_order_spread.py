@@ -11,13 +11,16 @@ Every seed is one legal run of the reference's arithmetic (its atomics commit in
 spread of the cost at a horizon is what the reference's own trajectory contract can mean there; tests/test_horizon_gpu.py and bench.py read
 the frozen spreads from tests/golden/reference_order_costs.json.  Oracle outputs, generated offline (minutes to hours of host time).
 
-    python tests/golden/make_reference_order_spread.py [--seeds 1 2 3 4 5] [--families horizon adversarial solve8] [--threads 8] [--precisions float]
+    python tests/golden/make_reference_order_spread.py [--seeds 1 2 3 4 5] [--families horizon adversarial solve8] [--threads 8] [--precisions float] [--variant fma]
 """
 import argparse
 import json
 import os
 import sys
 import time
+
+if "--variant" in sys.argv and sys.argv[sys.argv.index("--variant") + 1] == "fma":
+    os.environ["OPT_ORACLE_VARIANT"] = "fma"      # read by oracle/binding.py at import: the same restatement compiled with fused multiply-adds allowed
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
@@ -52,7 +55,9 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--precisions", nargs="+", default=["float"])
     ap.add_argument("--size", type=int, default=2048)
+    ap.add_argument("--variant", default="plain", choices=["plain", "fma"], help="fma: keys get the suffix _fma")
     a = ap.parse_args()
+    sfx = "_fma" if a.variant == "fma" else ""
     res = json.load(open(OUT)) if os.path.exists(OUT) else {}
 
     def done(key, seed):
@@ -71,13 +76,13 @@ def main():
                 if fam in ("horizon", "adversarial"):
                     for L in HORIZONS:
                         size = a.size if fam == "horizon" else 1024
-                        key = f"{fam}_{size}_{prec}_{L}"
+                        key = f"{fam}_{size}_{prec}_{L}{sfx}"
                         if done(key, seed):
                             continue
                         P = wl.image_warping(size, size, double=dbl) if fam == "horizon" else wl.image_warping(size, size, double=dbl, **ADVERSARIAL)
                         put(key, seed, *run(P, dbl, 1, L, a.threads, seed))
                 else:
-                    key = f"solve8_{a.size}_{prec}"
+                    key = f"solve8_{a.size}_{prec}{sfx}"
                     if done(key, seed):
                         continue
                     put(key, seed, *run(wl.image_warping(a.size, a.size, double=dbl), dbl, 8, 400, a.threads, seed))
