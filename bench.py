@@ -401,6 +401,23 @@ def main():
                            "halo_us_per_iteration": 1e3 * ct["halo"][1] / its, "halo_exchanges": ct["halo"][0],
                            "note": "all-reduce = the one-workgroup kernel that sums this rank's partials and posts them to every mailbox (the wait for the peers' words "
                                    "happens in the next iteration kernel's prologue), or the waiting all-reduce; halo = push + pull kernels, one exchange per ghost - 1 iterations"}
+        if rank == 0 and "PCGIteration" not in kt and "PCGSolveOnChip" in kt:
+            # the slab fits the chip (8 x 4096x512): the whole linear solve is one persistent launch whose state never leaves registers / LDS -- HBM sees the loop's
+            # inputs and delta once per Gauss-Newton step, so the kernel is bound by its grid-wide waits and VALU, not by a roofline of bytes
+            cnt, tot = kt["PCGSolveOnChip"]
+            rows = job.layout.rows if distributed else H
+            per_step = {k: v[1] / extra_steps for k, v in kt.items()}
+            bytes_per_launch = (24 + 4 + 1 + 12) * W * rows
+            roofline = {"bound": "hbm", "kernel": "PCGSolveOnChip = iw_onchipPcg (the whole linear solve of a Gauss-Newton step in one persistent launch" + (", this rank's slab)" if distributed else ")"),
+                        "achieved": bytes_per_launch / (tot / cnt * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_per_launch / (tot / cnt * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "note": "state on chip: HBM is touched at entry (r_0, p_0, angle, flags) and exit (delta) only; the launch is bound by one grid-wide wait per PCG iteration "
+                                "plus VALU (DESIGN.md section 3.2), so the byte fraction is small by construction -- the figure of merit is us_per_iteration",
+                        "avg_kernel_ms": tot / cnt, "launches": cnt, "us_per_iteration": 1e3 * tot / cnt / args.liters,
+                        "streaming_equiv": {"bytes_per_pixel": MODEL_BYTES_PER_PIXEL["lattice"], "achieved": MODEL_BYTES_PER_PIXEL["lattice"] * W * rows * args.liters / (tot / cnt * 1e-3) / 1e9,
+                                            "note": "what the streaming kernel would have to sustain to match (its 53 B/px per iteration over this launch's time); not a physical fraction"},
+                        "kernel_ms_per_step": per_step, "kernel_avg_ms": {k: v[1] / v[0] for k, v in kt.items()}}
+            if distributed:
+                roofline.update({"slab_rows": rows, "ghost_rows": job.layout.ghost, "per_iteration_ms": dt / args.steps / args.liters * 1e3, "comm_kernels": comm_us})
         if rank == 0 and "PCGIteration" in kt:
             cnt, tot = kt["PCGIteration"]
             avg_s = tot / cnt * 1e-3

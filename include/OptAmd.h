@@ -128,6 +128,24 @@ typedef struct OptAmd_MailPost {
     unsigned* ticket;
 } OptAmd_MailPost;
 
+/* Links of the on-chip linear solve across ranks (OptAmd_SlabCommExt.onChipPlan): a persistent kernel on every rank runs `count` PCG iterations; in iteration k
+ * (0-based) its workgroup 0 stores the rank's n sums as tagged words -- value i as mailDst[t][slot * slotStride + 2 i], [.. + 2 i + 1] = (tag << 32) | payload half,
+ * slot = (seq0 + k) % slots, tag = seq0 + k -- into the mailbox of every rank t < world, and every workgroup polls mailMine[slot * slotStride + r * rankStride + w] for
+ * all r < world.  The edge tiles of neighbouring slabs hand each other rows of tagged words: this rank's top tiles store into edgeSendUp (the lower edge box of the
+ * rank above) and poll edgeRecvUp; likewise Down.  An edge box holds [parity 2][tile][wordsPerTile] words (parity = tag & 1); NULL where there is no neighbour.
+ * All stores / loads are relaxed, system-scope, 8 bytes.  Polls are bounded by timeoutTicks (100 MHz); on expiry the kernel stores a non-zero code to *errFlag. */
+typedef struct OptAmd_OnChipLinks {
+    unsigned long long* mailDst[16];
+    const unsigned long long* mailMine;
+    int world, rank, slots, slotStride, rankStride;
+    unsigned seq0;
+    unsigned long long* edgeSendUp; unsigned long long* edgeSendDown;
+    const unsigned long long* edgeRecvUp; const unsigned long long* edgeRecvDown;
+    long edgeParityStride;
+    long long timeoutTicks;
+    int* errFlag;
+} OptAmd_OnChipLinks;
+
 /* Optional accelerations of a communicator; any member may be NULL.  `size` must be sizeof(OptAmd_SlabCommExt) as the caller compiled it (a library
  * built against a longer struct reads no member beyond it), and the struct must be zero-initialised before the members are set. */
 typedef struct OptAmd_SlabCommExt {
@@ -149,6 +167,10 @@ typedef struct OptAmd_SlabCommExt {
      * then nothing at all.  Returns 0 if unavailable.  The reserved all-reduce MUST be carried out by a kernel enqueued before the next call of any entry point
      * of this communicator. */
     int (*allReducePlan)(void* ctx, int n, OptAmd_MailPost* post, OptAmd_MailRef* ref);
+    /* Reserve `count` consecutive all-reduces of n doubles and the edge boxes for tilesX tiles of wordsPerTile words per slab edge, for ONE persistent kernel per rank
+     * that carries all of them out itself (OptAmd_OnChipLinks).  Same co-residency requirement as allReducePost, over the whole launch.  Returns 0 if unavailable
+     * (too many tiles for the boxes, ranks sharing a device, ...): the caller then runs its streaming loop.  Every rank must make the same call. */
+    int (*onChipPlan)(void* ctx, int n, int count, int tilesX, long wordsPerTile, OptAmd_OnChipLinks* links);
 } OptAmd_SlabCommExt;
 /* Attach a slab description to a plan created with dims {W, rows + 2*g}: g >= 1 ghost rows above and below the `rows` owned
  * rows (g is inferred from the plan's height).  g = 1 is enough for every kernel set; with g >= 2 image_warping runs its

@@ -47,13 +47,17 @@ struct Window {
     u64 haloSeq[2];                            // [0]: last exchange pushed by the rank above, [1]: by the rank below
     u64 haloAck[2];                            // [0]: last exchange of MINE the rank above has consumed, [1]: the rank below
     u64 pad[4];
-    // followed by staging[2 sides][kStageDepth][stageBytes]
+    // followed by staging[2 sides][kStageDepth][stageBytes], then the edge boxes of the on-chip linear solve: [2 sides: 0 = written by the rank above, 1 = by the rank
+    // below][2 parities][kEdgeWords] tagged words
 };
+constexpr size_t kEdgeWords = 1 << 17;      // per (side, parity): 1 MiB -- 170 tiles of 768 words (float), 85 of 1536 (double)
+constexpr size_t kEdgeBytes = 2 * 2 * kEdgeWords * sizeof(u64);
 
 struct PeerCtx {
     int rank, world;
     Window* win[kMaxWorld];        // win[rank] = my own window, others IPC-mapped
     char* stage[kMaxWorld];        // staging area behind each window
+    u64* edge[kMaxWorld];          // edge boxes behind each staging area
     size_t stageBytes;             // per side and depth
     void* base;                    // my allocation
     hipIpcMemHandle_t handle;
@@ -323,6 +327,27 @@ int peerAllReducePlan(void* c, int n, OptAmd_MailPost* post, OptAmd_MailRef* ref
     ref->world = x->world; ref->stride = 2 * kMaxVals; ref->tag = (unsigned)seq; ref->timeoutTicks = x->timeoutTicks; ref->errFlag = (int*)x->hostErr;
     return 1;
 }
+// The on-chip linear solve across ranks: `count` all-reduces reserved at once (sequence numbers seq0 .. seq0 + count - 1; the kernel's workgroup 0 posts, every
+// workgroup polls -- the mailbox words of k_mailPost / pollMailSums) and the edge boxes behind the staging areas.
+int peerOnChipPlan(void* c, int n, int count, int tilesX, long wordsPerTile, OptAmd_OnChipLinks* L) {
+    auto* x = (PeerCtx*)c;
+    if (failed(x, "onChipPlan")) return 0;
+    if (n > kMaxVals || count < 1 || !L || (size_t)tilesX * (size_t)wordsPerTile > kEdgeWords) return 0;
+    const u64 seq0 = x->arSeq + 1;
+    x->arSeq += (u64)count;
+    for (int t = 0; t < 16; ++t) L->mailDst[t] = t < x->world ? &x->win[t]->ll[0][x->rank][0] : nullptr;
+    L->mailMine = &x->win[x->rank]->ll[0][0][0];
+    L->world = x->world; L->rank = x->rank; L->slots = kSlots; L->slotStride = kMaxWorld * 2 * kMaxVals; L->rankStride = 2 * kMaxVals;
+    L->seq0 = (unsigned)seq0;
+    // my top tiles write the LOWER box (side 1: "written by the rank below") of the rank above and read my own upper box (side 0); mirrored for the bottom tiles
+    L->edgeSendUp = x->rank > 0 ? x->edge[x->rank - 1] + 1 * 2 * kEdgeWords : nullptr;
+    L->edgeRecvUp = x->rank > 0 ? x->edge[x->rank] + 0 * 2 * kEdgeWords : nullptr;
+    L->edgeSendDown = x->rank < x->world - 1 ? x->edge[x->rank + 1] + 0 * 2 * kEdgeWords : nullptr;
+    L->edgeRecvDown = x->rank < x->world - 1 ? x->edge[x->rank] + 1 * 2 * kEdgeWords : nullptr;
+    L->edgeParityStride = (long)kEdgeWords;
+    L->timeoutTicks = x->timeoutTicks; L->errFlag = (int*)x->hostErr;
+    return 1;
+}
 void peerHalo(void* c, int nb, const void* const* su, const void* const* sd, void* const* ru, void* const* rd, const long* bytes, void* stream) {
     auto* x = (PeerCtx*)c; hipStream_t s = (hipStream_t)stream;
     if (failed(x, "haloExchange")) return;
@@ -362,7 +387,7 @@ void* OptComm_PeerCreate(int rank, int world, long stageBytes, double timeoutSec
     if (world > kMaxWorld || rank < 0 || rank >= world) { fprintf(stderr, "OptComm(peer): world %d > %d\n", world, kMaxWorld); return nullptr; }
     auto* x = new PeerCtx();
     x->rank = rank; x->world = world; x->stageBytes = (size_t)((stageBytes + 255) / 256 * 256);
-    const size_t total = (sizeof(Window) + 255) / 256 * 256 + 2 * (size_t)kStageDepth * x->stageBytes;
+    const size_t total = (sizeof(Window) + 255) / 256 * 256 + 2 * (size_t)kStageDepth * x->stageBytes + kEdgeBytes;
     // uncached device memory: peers' stores and our polling loads bypass the local caches (what RCCL uses for its own flags);
     // fall back to fine-grained, then plain device memory (loads/stores above are system-scope atomics either way)
     x->memKind = -1;
@@ -389,6 +414,7 @@ void* OptComm_PeerCreate(int rank, int world, long stageBytes, double timeoutSec
     CK_HIP(hipDeviceSynchronize());
     x->win[rank] = (Window*)x->base;
     x->stage[rank] = (char*)x->base + (sizeof(Window) + 255) / 256 * 256;
+    x->edge[rank] = (u64*)(x->stage[rank] + 2 * (size_t)kStageDepth * x->stageBytes);
     CK_HIP(hipMalloc((void**)&x->dCounter, 4 * sizeof(unsigned int)));      // [0], [1]: last-block counters of the halo kernels; [2]: ticket of in-kernel posts
     CK_HIP(hipMemset(x->dCounter, 0, 4 * sizeof(unsigned int)));
     CK_HIP(hipHostMalloc((void**)&x->hostErr, sizeof(int), hipHostMallocMapped));
@@ -406,6 +432,7 @@ void* OptComm_PeerCreate(int rank, int world, long stageBytes, double timeoutSec
     // (tools/slab_overhead.py, profiles/r03_slab_overhead_posted_allreduce.txt) the device-scope release / acquire around the ticket costs more than the
     // one-workgroup post kernel it removes -- 4096 x 512 slab: 36.6 us per iteration against 34.3 (k_mailPost) and 36.1 (round 2's waiting all-reduce); plain: 30.4
     if (const char* e = getenv("OPT_AMD_PEER_PLAN")) { if (atoi(e) != 0) x->ext.allReducePlan = peerAllReducePlan; }
+    x->ext.onChipPlan = peerOnChipPlan;      // (taken away like allReducePost when ranks share a device, unless OPT_AMD_PEER_POST=1 says the grids are capped)
     return x;
 }
 void OptComm_PeerHandle(void* c, char* out) { auto* x = (PeerCtx*)c; memcpy(out, &x->handle, sizeof(hipIpcMemHandle_t)); memcpy(out + sizeof(hipIpcMemHandle_t), x->busId, 32); }
@@ -441,10 +468,11 @@ int OptComm_PeerConnect(void* c, const char* allHandles) {
         if (e != hipSuccess) { fprintf(stderr, "OptComm(peer) rank %d: hipIpcOpenMemHandle(rank %d) failed: %s\n", x->rank, r, hipGetErrorString(e)); return 0; }
         x->win[r] = (Window*)p;
         x->stage[r] = (char*)p + (sizeof(Window) + 255) / 256 * 256;
+        x->edge[r] = (u64*)(x->stage[r] + 2 * (size_t)kStageDepth * x->stageBytes);
     }
     if (x->sharedDevice) {      // see OptComm_PeerCreate: co-residency of all ranks' kernels is not given on a shared GPU
         const char* e = getenv("OPT_AMD_PEER_POST");
-        if (!(e && atoi(e) != 0)) { x->ext.allReducePost = nullptr; x->ext.allReducePlan = nullptr; }
+        if (!(e && atoi(e) != 0)) { x->ext.allReducePost = nullptr; x->ext.allReducePlan = nullptr; x->ext.onChipPlan = nullptr; }
     }
     return 1;
 }

@@ -135,6 +135,11 @@ struct EnergyOps {
     // receives sum alpha_k p_k; traceDev (or nullptr) receives alphaNum, alphaDen, s2, s3 of every iteration (4 doubles each; beta numerator by expansion as
     // in PcgIterArgs).  false: the problem does not fit the chip or the kernel set has no such kernel -- nothing was touched.
     virtual bool pcgSolveOnChip(const T* /*r0*/, const T* /*p0*/, T* /*delta*/, int /*lIterations*/, double* /*traceDev*/, LaunchCtx&) { return false; }
+    // Row slabs: would pcgSolveOnChip run for this rank's slab right now (kernel variant fits, unit lattice, the communicator offers onChipPlan ...)?  The solver
+    // makes the decision collective (all ranks or none) before anyone launches.  onChipPlan / onChipCtx: the communicator's entry (OptAmd_SlabCommExt), set by the solver.
+    virtual bool slabOnChipAvailable(int /*lIterations*/) { return false; }
+    int (*onChipPlan)(void*, int, int, int, long, OptAmd_OnChipLinks*) = nullptr;
+    void* onChipCtx = nullptr;
     // After the stream has drained: did a wait inside the last on-chip solve time out (another tenant on the GPU kept its workgroups from being co-resident)?
     // Then the unknowns were left untouched, the kernel set has switched the path off for this plan, and the caller redoes the linear solve.
     virtual bool onChipFailed() { return false; }

@@ -399,24 +399,39 @@ struct ImageWarpingOps : EnergyOps<T> {
             v.occ = std::min(v.occ, 1);      // one workgroup per CU: the co-residency the in-kernel waits rely on does not depend on how the dispatcher packs CUs
         }
     }
+    // Which variant, if any: the smallest ROWS whose tiles fit one per CU.  A slab's owned rows must be whole tiles (its last tile row faces the next rank's first).
+    const OcVariant* ocSelect(int& tX, int& tY) {
+        ocInit();
+        tX = divUp(A.W, kOcTileW);
+        const int rowsOwned = A.yEnd - A.yBegin;
+        for (const auto& v : ocVariants) {
+            if (ocForceRows && v.rows != ocForceRows) continue;
+            const int th = kOcWavesY * v.rows;
+            if (this->slab.active && rowsOwned % th != 0) continue;
+            tY = divUp(rowsOwned, th);
+            if (v.occ >= 1 && (long)tX * tY <= std::min(std::min(cus * v.occ, kOcMaxTiles), maxWorkgroups)) return &v;
+        }
+        return nullptr;
+    }
+    bool slabOnChipAvailable(int L) override {      // (row slabs: the lattice verdict of this bind is already known, bind() read it back)
+        int tX, tY;
+        return ocEnabled && !ocFailed && L > 0 && this->slab.active && this->slab.ghost >= 2 && this->onChipPlan && lattice &&
+               (unsigned long long)A.W * A.H * 3ull * sizeof(T) < (1ull << 32) && ocSelect(tX, tY) != nullptr;
+    }
     bool pcgSolveOnChip(const T* r0, const T* p0, T* delta, int L, double* traceDev, LaunchCtx& ctx) override {
-        if (!ocEnabled || ocFailed || !fastGN() || L <= 0) return false;
+        const bool slabMode = this->slab.active;
+        if (!ocEnabled || ocFailed || L <= 0 || (unsigned long long)A.W * A.H * 3ull * sizeof(T) >= (1ull << 32)) return false;
+        if (slabMode && (traceDev || !slabOnChipAvailable(L))) return false;
         resolveLattice();
         if (initPending && initHint && !lattice) { launchJtf(false, ctx); initHint = false; }      // PCGInit1 ran on the previous bind's verdict (see beginLoop)
         if (!lattice) return false;
-        ocInit();
-        const int tX = divUp(A.W, kOcTileW);
-        const OcVariant* V = nullptr; int tY = 0;
-        for (const auto& v : ocVariants) {
-            if (ocForceRows && v.rows != ocForceRows) continue;
-            tY = divUp(A.H, kOcWavesY * v.rows);
-            if (v.occ >= 1 && (long)tX * tY <= std::min(cus * v.occ, kOcMaxTiles)) { V = &v; break; }
-        }
+        int tX = 0, tY = 0;
+        const OcVariant* V = ocSelect(tX, tY);
         if (!V) return false;
         const int G = tX * tY;
         if (!ocS.slots) {      // sized for this plan's image once (the dimensions of a plan are fixed); zero = no tag
             const int maxRows = ocVariants.front().rows;
-            const int gMax = std::min(kOcMaxTiles, tX * divUp(A.H, kOcWavesY * maxRows));
+            const int gMax = std::min(kOcMaxTiles, tX * divUp(A.yEnd - A.yBegin, kOcWavesY * maxRows));
             ocS.stride = 3L * kOcTileW * (long)(sizeof(T) / 4);
             ocSlotBytes = sizeof(oc_u64) * 2 * (size_t)gMax * 8; ocGroupBytes = sizeof(oc_u64) * 2 * (size_t)divUp(gMax, kOcGroup) * 8;
             ocInboxBytes = sizeof(oc_u64) * 2 * (size_t)gMax * 4 * (size_t)ocS.stride;
@@ -433,7 +448,17 @@ struct ImageWarpingOps : EnergyOps<T> {
             HIP_CHECK(hipMemsetAsync(ocS.inbox, 0, ocInboxBytes, ctx.stream));
             ocSeq = 2;
         }
-        OnchipArgs<T> K{A.W, A.H, tX, tY, G, r0, p0, A.Angle, A.flags, delta, A.w_fit, A.w_reg, L, ocSeq, G <= ocFlatMax ? 1 : 0, ocS, traceDev, ocTimeoutTicks, ocProf, ocFailAt};
+        OcLinks links{};
+        if (slabMode) {      // (every rank makes this call: the solver has made the decision to run on chip collective)
+            OptAmd_OnChipLinks Lk{};
+            if (!this->onChipPlan(this->onChipCtx, 4, L, tX, ocS.stride, &Lk)) return false;
+            for (int t = 0; t < 16; ++t) links.mailDst[t] = Lk.mailDst[t];
+            links.mailMine = Lk.mailMine; links.world = Lk.world; links.rank = Lk.rank; links.slots = Lk.slots; links.slotStride = Lk.slotStride; links.rankStride = Lk.rankStride;
+            links.seq0 = Lk.seq0; links.edgeSendUp = Lk.edgeSendUp; links.edgeSendDown = Lk.edgeSendDown; links.edgeRecvUp = Lk.edgeRecvUp; links.edgeRecvDown = Lk.edgeRecvDown;
+            links.edgeParityStride = Lk.edgeParityStride;
+        }
+        OnchipArgs<T> K{A.W, A.H, tX, tY, G, A.yBegin, A.yEnd, links, r0, p0, A.Angle, A.flags, delta, A.w_fit, A.w_reg, L, ocSeq, G <= ocFlatMax ? 1 : 0, ocS, traceDev,
+                        ocTimeoutTicks, ocProf, ocFailAt};
         ocSeq += (unsigned)L;
         {
             ScopedKernel k(ctx, "PCGSolveOnChip");

@@ -40,9 +40,17 @@ struct OnchipSync {
     int* hostErr;           // pinned host word, set by iw_applyDelta when `bad` is
     long stride;            // words per (tile, side): 3 * kOcTileW scalars
 };
+// Row slabs (one rank per GPU): the links of this rank's kernel to the other ranks' (include/OptAmd.h OptAmd_OnChipLinks; world <= 1: none).
+struct OcLinks {
+    oc_u64* mailDst[16]; const oc_u64* mailMine;
+    int world, rank, slots, slotStride, rankStride; unsigned seq0;
+    oc_u64 *edgeSendUp, *edgeSendDown; const oc_u64 *edgeRecvUp, *edgeRecvDown; long edgeParityStride;
+};
 template <class T>
 struct OnchipArgs {
-    int W, H, tilesX, tilesY, G;
+    int W, H, tilesX, tilesY, G;        // H: rows of the arrays (a slab's include its ghost rows)
+    int yBegin, yEnd;                   // the rows the tiles cover: [0, H) on one GPU, the slab's owned rows (a multiple of the tile height) otherwise
+    OcLinks links;
     const T* r0; const T* p0;           // solver layout: [O.x O.y] x N, then [a] x N
     const T* Angle; const uint8_t* flags;
     T* delta;                           // out: sum alpha_k p_k
@@ -56,18 +64,24 @@ struct OnchipArgs {
     int failAt;                         // test hook (OPT_AMD_ONCHIP_FAIL_AT): workgroup 0 raises `bad` in this iteration as a timed-out wait would; -1: never
 };
 
-__device__ __forceinline__ oc_u64 ocLoad(const oc_u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void ocStore(oc_u64* p, unsigned tag, unsigned half) { __hip_atomic_store(p, ((oc_u64)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// SYS: words that cross GPUs (the peer window: uncached memory, system scope); else agent scope
+template <bool SYS = false> __device__ __forceinline__ oc_u64 ocLoad(const oc_u64* p) {
+    return SYS ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool SYS = false> __device__ __forceinline__ void ocStore(oc_u64* p, unsigned tag, unsigned half) {
+    if (SYS) __hip_atomic_store(p, ((oc_u64)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else __hip_atomic_store(p, ((oc_u64)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // Waits until *src carries `tag`; returns the payload.  Bounded: after timeoutTicks of the 100 MHz wall clock -- or as soon as another waiter has given up --
 // the wait falls through with whatever is there (the caller's loop ends at its next sum).
-__device__ __forceinline__ unsigned ocAwait(const oc_u64* src, unsigned tag, int* bad, long long timeoutTicks) {
-    oc_u64 v = ocLoad(src);
+template <bool SYS = false> __device__ __forceinline__ unsigned ocAwait(const oc_u64* src, unsigned tag, int* bad, long long timeoutTicks) {
+    oc_u64 v = ocLoad<SYS>(src);
     if ((unsigned)(v >> 32) != tag) {
         const long long t0 = wall_clock64();
         unsigned spins = 0;
         for (;;) {
             __builtin_amdgcn_s_sleep(1);
-            v = ocLoad(src);
+            v = ocLoad<SYS>(src);
             if ((unsigned)(v >> 32) == tag) break;
             if ((++spins & 31u) == 0) {
                 if (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
@@ -78,10 +92,10 @@ __device__ __forceinline__ unsigned ocAwait(const oc_u64* src, unsigned tag, int
     return (unsigned)v;
 }
 // one scalar of the halo as tagged words: a float is one word, a double two
-__device__ __forceinline__ void ocSend(oc_u64* box, int idx, float v, unsigned tag) { ocStore(box + idx, tag, __float_as_uint(v)); }
-__device__ __forceinline__ void ocSend(oc_u64* box, int idx, double v, unsigned tag) {
+template <bool SYS = false> __device__ __forceinline__ void ocSend(oc_u64* box, int idx, float v, unsigned tag) { ocStore<SYS>(box + idx, tag, __float_as_uint(v)); }
+template <bool SYS = false> __device__ __forceinline__ void ocSend(oc_u64* box, int idx, double v, unsigned tag) {
     const oc_u64 b = (oc_u64)__double_as_longlong(v);
-    ocStore(box + 2 * idx, tag, (unsigned)b); ocStore(box + 2 * idx + 1, tag, (unsigned)(b >> 32));
+    ocStore<SYS>(box + 2 * idx, tag, (unsigned)b); ocStore<SYS>(box + 2 * idx + 1, tag, (unsigned)(b >> 32));
 }
 __device__ __forceinline__ void ocRecv(const oc_u64* box, int idx, unsigned tag, int* bad, long long to, float& v) { v = __uint_as_float(ocAwait(box + idx, tag, bad, to)); }
 __device__ __forceinline__ void ocRecv(const oc_u64* box, int idx, unsigned tag, int* bad, long long to, double& v) {
@@ -89,15 +103,15 @@ __device__ __forceinline__ void ocRecv(const oc_u64* box, int idx, unsigned tag,
     v = __longlong_as_double((long long)(((oc_u64)hi << 32) | lo));
 }
 // Three scalars of one halo pixel at once: all requests are in flight together (one fabric round trip when the words are already there, not three).
-__device__ __forceinline__ void ocRecv3(const oc_u64* box, int i0, int i1, int i2, unsigned tag, int* bad, long long to, float (&v)[3]) {
+template <bool SYS = false> __device__ __forceinline__ void ocRecv3(const oc_u64* box, int i0, int i1, int i2, unsigned tag, int* bad, long long to, float (&v)[3]) {
     const oc_u64 *p0 = box + i0, *p1 = box + i1, *p2 = box + i2;
-    oc_u64 a = ocLoad(p0), b = ocLoad(p1), c = ocLoad(p2);
+    oc_u64 a = ocLoad<SYS>(p0), b = ocLoad<SYS>(p1), c = ocLoad<SYS>(p2);
     if ((unsigned)(a >> 32) != tag || (unsigned)(b >> 32) != tag || (unsigned)(c >> 32) != tag) {
         const long long t0 = wall_clock64();
         unsigned spins = 0;
         for (;;) {
             __builtin_amdgcn_s_sleep(1);
-            a = ocLoad(p0); b = ocLoad(p1); c = ocLoad(p2);
+            a = ocLoad<SYS>(p0); b = ocLoad<SYS>(p1); c = ocLoad<SYS>(p2);
             if ((unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag && (unsigned)(c >> 32) == tag) break;
             if ((++spins & 31u) == 0) {
                 if (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
@@ -107,10 +121,10 @@ __device__ __forceinline__ void ocRecv3(const oc_u64* box, int i0, int i1, int i
     }
     v[0] = __uint_as_float((unsigned)a); v[1] = __uint_as_float((unsigned)b); v[2] = __uint_as_float((unsigned)c);
 }
-__device__ __forceinline__ void ocRecv3(const oc_u64* box, int i0, int i1, int i2, unsigned tag, int* bad, long long to, double (&v)[3]) {
+template <bool SYS = false> __device__ __forceinline__ void ocRecv3(const oc_u64* box, int i0, int i1, int i2, unsigned tag, int* bad, long long to, double (&v)[3]) {
     const oc_u64* q[6] = {box + 2 * i0, box + 2 * i0 + 1, box + 2 * i1, box + 2 * i1 + 1, box + 2 * i2, box + 2 * i2 + 1};
     oc_u64 w[6];
-    auto fetch = [&]() { bool ok = true; for (int i = 0; i < 6; ++i) w[i] = ocLoad(q[i]); for (int i = 0; i < 6; ++i) ok = ok && (unsigned)(w[i] >> 32) == tag; return ok; };
+    auto fetch = [&]() { bool ok = true; for (int i = 0; i < 6; ++i) w[i] = ocLoad<SYS>(q[i]); for (int i = 0; i < 6; ++i) ok = ok && (unsigned)(w[i] >> 32) == tag; return ok; };
     if (!fetch()) {
         const long long t0 = wall_clock64();
         unsigned spins = 0;
@@ -206,7 +220,7 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
 
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6, wx = wave & (kOcWavesX - 1), wy = wave / kOcWavesX;
     const int g = blockIdx.x, tx = g % K.tilesX, ty = g / K.tilesX;
-    const int x0 = tx * kOcTileW + wx * kWave, x = x0 + lane, yBase = (ty * kOcWavesY + wy) * ROWS;
+    const int x0 = tx * kOcTileW + wx * kWave, x = x0 + lane, yBase = K.yBegin + (ty * kOcWavesY + wy) * ROWS;
     const long N = (long)K.W * K.H;
     const bool xin = x < K.W;
     const T w2 = K.w_reg * K.w_reg, wf2 = K.w_fit * K.w_fit;
@@ -223,8 +237,10 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
         mTab[t] = T(1) / (sq * sq);
     }
     // p_0, r_0, cos, sin, activity and flag byte of a pixel that may lie outside the image (then: zeros, inactive)
-    auto loadPixel = [&](int xx, int yy, T (&pp)[3], T (&rr)[3], T& c, T& s, T& on, unsigned& f) {
-        const bool ok = xx >= 0 && xx < K.W && yy >= 0 && yy < K.H;
+    // (own pixels: the rows the tiles cover, [yBegin, yEnd); halo pixels: any row of the arrays -- a slab's ghost rows hold the neighbouring rank's pixels, and the
+    // flag byte of a ghost row beyond the global image says "does not exist")
+    auto loadPixel = [&](int xx, int yy, T (&pp)[3], T (&rr)[3], T& c, T& s, T& on, unsigned& f, bool own = false) {
+        const bool ok = xx >= 0 && xx < K.W && yy >= 0 && yy < (own ? K.yEnd : K.H);
         const long i = ok ? (long)yy * K.W + xx : 0;
         f = ok ? (unsigned)K.flags[i] : 0u;
         const V2<T> po = ((const V2<T>*)K.p0)[i], ro = ((const V2<T>*)K.r0)[i];
@@ -244,7 +260,7 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
         unsigned f; T on;
-        loadPixel(x, yBase + j, p[j], r[j], cs[j][0], cs[j][1], on, f);
+        loadPixel(x, yBase + j, p[j], r[j], cs[j][0], cs[j][1], on, f, true);
         fl[j >> 2] |= f << (8 * (j & 3));
         if (!DELTA_GLB) { dl[DELTA_GLB ? 0 : j][0] = 0; dl[DELTA_GLB ? 0 : j][1] = 0; dl[DELTA_GLB ? 0 : j][2] = 0; }
     }
@@ -297,7 +313,9 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
     OcH4<T>* const edgeDst = lane == 0 ? (wx > 0 ? sideA + ((wave - 1) * ROWS) * 2 + 1 : stageA + (wave * ROWS) * 2 + 0)
                                        : (wx + 1 < kOcWavesX ? sideA + ((wave + 1) * ROWS) * 2 + 0 : stageA + (wave * ROWS) * 2 + 1);
     const int nGroups = (K.G + kOcGroup - 1) / kOcGroup;
-    const bool hasUp = ty > 0, hasDown = ty + 1 < K.tilesY, hasLeft = tx > 0, hasRight = tx + 1 < K.tilesX;
+    // a tile's neighbours: tiles of this grid, or -- first / last tile row of a slab -- the edge tiles of the rank above / below (words in the peer window)
+    const bool upRemote = ty == 0 && K.links.edgeSendUp != nullptr, downRemote = ty + 1 == K.tilesY && K.links.edgeSendDown != nullptr;
+    const bool hasUp = ty > 0 || upRemote, hasDown = ty + 1 < K.tilesY || downRemote, hasLeft = tx > 0, hasRight = tx + 1 < K.tilesX;
     // the halo column this lane looks after: handed over inside the workgroup, by another tile, or by nobody (the image ends)
     const bool hIntra = haloLane && (hSide == 0 ? wx > 0 : wx + 1 < kOcWavesX);
     const bool hInter = haloLane && !hIntra && (hSide == 0 ? hasLeft : hasRight);
@@ -387,8 +405,10 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
             asm volatile("" : "+v"(ln));
             if (AP_LDS && wy == 0 && hasUp) { aFirst[0] = myAp[0]; aFirst[1] = myAp[kOcBlock]; aFirst[2] = myAp[2 * kOcBlock]; }      // (not held across the 16 rows)
             if (wy > 0) { if (!AP_LDS) { T* h = rowA + ((wave - kOcWavesX) * 2 + 1) * 3 * kWave; h[ln] = aFirst[0]; h[kWave + ln] = aFirst[1]; h[2 * kWave + ln] = aFirst[2]; } }
+            else if (upRemote) { oc_u64* d = K.links.edgeSendUp + par * K.links.edgeParityStride + (long)tx * K.S.stride; ocSend<true>(d, wx * kWave + ln, aFirst[0], tag); ocSend<true>(d, kOcTileW + wx * kWave + ln, aFirst[1], tag); ocSend<true>(d, 2 * kOcTileW + wx * kWave + ln, aFirst[2], tag); }
             else if (hasUp) { oc_u64* d = box(g - K.tilesX, 1); ocSend(d, wx * kWave + ln, aFirst[0], tag); ocSend(d, kOcTileW + wx * kWave + ln, aFirst[1], tag); ocSend(d, 2 * kOcTileW + wx * kWave + ln, aFirst[2], tag); }
             if (wy + 1 < kOcWavesY) { if (!AP_LDS) { T* h = rowA + ((wave + kOcWavesX) * 2 + 0) * 3 * kWave; h[ln] = aLast[0]; h[kWave + ln] = aLast[1]; h[2 * kWave + ln] = aLast[2]; } }
+            else if (downRemote) { oc_u64* d = K.links.edgeSendDown + par * K.links.edgeParityStride + (long)tx * K.S.stride; ocSend<true>(d, wx * kWave + ln, aLast[0], tag); ocSend<true>(d, kOcTileW + wx * kWave + ln, aLast[1], tag); ocSend<true>(d, 2 * kOcTileW + wx * kWave + ln, aLast[2], tag); }
             else if (hasDown) { oc_u64* d = box(g + K.tilesX, 0); ocSend(d, wx * kWave + ln, aLast[0], tag); ocSend(d, kOcTileW + wx * kWave + ln, aLast[1], tag); ocSend(d, 2 * kOcTileW + wx * kWave + ln, aLast[2], tag); }
             // a tile-edge wave's column leaves with one lane per pixel (the LDS operations of one wave execute in order: what lane 0 / 63 staged above is there)
             if (haloLane && ((hSide == 0 && wx == 0 && hasLeft) || (hSide == 1 && wx == kOcWavesX - 1 && hasRight))) {
@@ -434,8 +454,10 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
             // What other tiles handed over was posted before their sums and arrives before the totals can: it is collected FIRST, inside the wait for the sums
             // (a request costs a fabric round trip even when the words are there).  Only a group's first workgroup, on whose total 15 others wait, sums first.
             auto collectInbox = [&]() {
-                if (wy == 0 && hasUp) ocRecv3(box(g, 0), wx * kWave + ln, kOcTileW + wx * kWave + ln, 2 * kOcTileW + wx * kWave + ln, tag, bad, to, at);
-                if (wy == kOcWavesY - 1 && hasDown) ocRecv3(box(g, 1), wx * kWave + ln, kOcTileW + wx * kWave + ln, 2 * kOcTileW + wx * kWave + ln, tag, bad, to, ab);
+                if (wy == 0 && upRemote) ocRecv3<true>(K.links.edgeRecvUp + par * K.links.edgeParityStride + (long)tx * K.S.stride, wx * kWave + ln, kOcTileW + wx * kWave + ln, 2 * kOcTileW + wx * kWave + ln, tag, bad, to, at);
+                else if (wy == 0 && hasUp) ocRecv3(box(g, 0), wx * kWave + ln, kOcTileW + wx * kWave + ln, 2 * kOcTileW + wx * kWave + ln, tag, bad, to, at);
+                if (wy == kOcWavesY - 1 && downRemote) ocRecv3<true>(K.links.edgeRecvDown + par * K.links.edgeParityStride + (long)tx * K.S.stride, wx * kWave + ln, kOcTileW + wx * kWave + ln, 2 * kOcTileW + wx * kWave + ln, tag, bad, to, ab);
+                else if (wy == kOcWavesY - 1 && hasDown) ocRecv3(box(g, 1), wx * kWave + ln, kOcTileW + wx * kWave + ln, 2 * kOcTileW + wx * kWave + ln, tag, bad, to, ab);
                 if (hInter) { const int idx = (wy * ROWS + hRow) * 3; ocRecv3(box(g, hSide == 0 ? 2 : 3), idx, idx + 1, idx + 2, tag, bad, to, as); }
             };
             if (!leader) collectInbox();
@@ -495,6 +517,19 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
                 __syncthreads();
             }
             if (tq < 4) { double s = 0; for (int grp = 0; grp < nGroups; ++grp) s += GS[grp * 4 + tq]; TOT[tq] = s; }
+            if (K.links.world > 1) {      // row slabs: the rank hop -- workgroup 0 posts this rank's totals to every rank's mailbox, everybody adds the ranks' totals in rank order
+                __syncthreads();
+                const unsigned seq = K.links.seq0 + (unsigned)k;
+                const long slotOff = (long)(seq % (unsigned)K.links.slots) * K.links.slotStride;
+                if (g == 0 && tq < 8 * K.links.world) {
+                    const int t = tq >> 3, w = tq & 7;
+                    const oc_u64 b = (oc_u64)__double_as_longlong(TOT[w >> 1]);
+                    ocStore<true>(K.links.mailDst[t] + slotOff + w, seq, (w & 1) ? (unsigned)(b >> 32) : (unsigned)b);
+                }
+                if (tq < 8 * K.links.world) W2[tq] = ocAwait<true>(K.links.mailMine + slotOff + (long)(tq >> 3) * K.links.rankStride + (tq & 7), seq, bad, to);
+                __syncthreads();
+                if (tq < 4) { double s = 0; for (int rk = 0; rk < K.links.world; ++rk) s += ocJoin(W2[rk * 8 + 2 * tq], W2[rk * 8 + 2 * tq + 1]); TOT[tq] = s; }
+            }
             if (tq == 0) reinterpret_cast<int*>(TOT + 4)[0] = __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             OC_MARK(5);      // grid-wide sum
@@ -503,7 +538,7 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
         // the sums, and returns (lines this lane wrote one iteration ago, still in its XCD's L2) while the halo copies are updated.  (All 48 values requested
         // before the wait held 48 more registers over the sum, and every scratch reload in between waited for all of them: vmcnt counts in order.)
         constexpr int CH = ROWS < 4 ? ROWS : 4;
-        auto rowExists = [&](int j) { return xin && pix0 + j * K.W < (int)N; };      // (x < W: then y < H is the same as pixel index < N)
+        auto rowExists = [&](int j) { return xin && pix0 + j * K.W < K.yEnd * K.W; };      // (x < W: then y < yEnd is the same as pixel index < yEnd * W)
         auto rowIndex = [&](int j) { return rowExists(j) ? pix0 + j * K.W : 0; };     // 0: a valid address whose value is not used
         constexpr int NCH = (ROWS + CH - 1) / CH;
         T dN[DELTA_GLB ? NCH : 1][CH][3];      // (fully unrolled below: every chunk has its own registers, live from its request to its use -- two chunks at a time)
@@ -595,7 +630,7 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
             const int y = yBase + j;
-            if (xin && y < K.H) { const long i = (long)y * K.W + x; ((V2<T>*)K.delta)[i] = V2<T>{dl[DELTA_GLB ? 0 : j][0], dl[DELTA_GLB ? 0 : j][1]}; K.delta[2 * N + i] = dl[DELTA_GLB ? 0 : j][2]; }
+            if (xin && y < K.yEnd) { const long i = (long)y * K.W + x; ((V2<T>*)K.delta)[i] = V2<T>{dl[DELTA_GLB ? 0 : j][0], dl[DELTA_GLB ? 0 : j][1]}; K.delta[2 * N + i] = dl[DELTA_GLB ? 0 : j][2]; }
         }
     }
 }

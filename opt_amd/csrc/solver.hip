@@ -406,6 +406,15 @@ struct PcgSolver : SolverBase {
     }
 
     bool onChipOk = true, usedOnChip = false; double* onChipTrace = nullptr; int onChipTraceCap = 0;      // EnergyOps::pcgSolveOnChip
+    // true iff `mine` holds on every rank: one all-reduce of a count and one read-back (once per Gauss-Newton step in slab mode)
+    bool allRanksAgree(bool mine) {
+        hostBuf[0] = mine ? 0.0 : 1.0;
+        HIP_CHECK(hipMemcpyAsync(scal + 5, hostBuf, sizeof(double), hipMemcpyHostToDevice, stream));
+        comm.allReduceSum(comm.ctx, scal + 5, 1, (void*)stream);
+        HIP_CHECK(hipMemcpyAsync(hostBuf, scal + 5, sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        return hostBuf[0] == 0.0;
+    }
     // ---- reductions ---------------------------------------------------------------------------------
     // Host value of a reduction (blocking D2H like the reference's computeCost / fetchQ, solver.t:790-814)
     double hostSum(const Reduction& R) {
@@ -576,6 +585,17 @@ struct PcgSolver : SolverBase {
 
     // ---- PCG loop as one kernel per iteration (energy.h PcgIterArgs); returns false if the energy has no such kernel ----
     bool runSingleKernelLoop(const T* preArg) {
+        // Row slabs: the on-chip solve runs on ALL ranks or on none (their kernels wait for each other): every rank says whether it could, the communicator adds it up.
+        bool slabOnChip = false;
+        if (distributed) {
+            slabOnChip = allRanksAgree(onChipOk && preArg && sp.lIterations > 0 && !traceEnabled && E->slabOnChipAvailable(sp.lIterations));
+            if (!slabOnChip && !E->slabIterationAvailable()) return false;      // (before anything is exchanged: the three-kernel loop needs r = 0 on ghost rows)
+            if (slabOnChip) {      // the kernel reads r_0, p_0 of its halo rows from the ghost rows
+                exchangeVector(r); exchangeVector(p);
+                if (E->pcgSolveOnChip(r, p, delta, sp.lIterations, nullptr, ctx)) { usedOnChip = true; unknownsUpdated = true; return true; }
+                fprintf(stderr, "Opt(amd): the slab on-chip solve was agreed on but refused by this rank's kernel set\n"); exit(1);
+            }
+        }
         // The whole linear solve as one persistent launch with the loop state on chip, if the kernel set has one and the problem fits (iw_onchip.h);
         // it ends with PCGLinearUpdate.  A traced solve gets its per-iteration scalars from the kernel (beta numerator by expansion, as below).
         if (!distributed && preArg && onChipOk && sp.lIterations > 0) {
@@ -600,7 +620,6 @@ struct PcgSolver : SolverBase {
                 return true;
             }
         }
-        if (distributed && !E->slabIterationAvailable()) return false;      // (before anything is exchanged: the three-kernel loop needs r = 0 on ghost rows)
         Reduction prev[4] = {redC, Reduction{}, Reduction{}, Reduction{}};   // alphaNum_0 = sum r.p from PCGInit1
         if (distributed) {   // ghost rows of r_0, M and p_0 (written as 0 by evalJTF / PCGInit1_Finish) come from the slab neighbours once
             exchangeVector(r); exchangeVector(p); if (preArg) exchangeVector(preconditioner);
@@ -976,7 +995,9 @@ struct PcgSolver : SolverBase {
 
         if (usedOnChip) {      // (the stream has drained: the cost was read)
             usedOnChip = false;
-            if (E->onChipFailed()) {
+            bool ocFailedNow = E->onChipFailed();
+            if (distributed) ocFailedNow = !allRanksAgree(!ocFailedNow);      // a rank whose waits timed out applied nothing: then nobody keeps its update...
+            if (ocFailedNow) {
                 fprintf(stderr, "Opt(amd): a wait inside the on-chip PCG kernel timed out (its workgroups were not co-resident: is the GPU shared?); the unknowns were left untouched, "
                                 "this linear solve is redone with the streaming kernels and the plan stays on them\n");
                 onChipOk = false; unknownsUpdated = false;
@@ -1084,6 +1105,7 @@ struct PcgSolver : SolverBase {
         if (has(offsetof(OptAmd_SlabCommExt, allReducePartials), sizeof(e->allReducePartials))) commExt.allReducePartials = e->allReducePartials;
         if (has(offsetof(OptAmd_SlabCommExt, allReducePost), sizeof(e->allReducePost))) commExt.allReducePost = e->allReducePost;
         if (has(offsetof(OptAmd_SlabCommExt, allReducePlan), sizeof(e->allReducePlan))) commExt.allReducePlan = e->allReducePlan;
+        if (has(offsetof(OptAmd_SlabCommExt, onChipPlan), sizeof(e->onChipPlan))) { commExt.onChipPlan = e->onChipPlan; E->onChipPlan = e->onChipPlan; E->onChipCtx = comm.ctx; }
         commExt.size = sizeof(OptAmd_SlabCommExt);
         return 1;
     }

@@ -43,11 +43,15 @@ def _rank_main(rank, world, port, case, q):
     P = wl.image_warping(case["W"], case["H"], double=case["double"], random_state=3, mask_fraction=0.06, perturb=0.3)
     job = slab.SlabJob("image_warping", case["W"], case["H"], rank, world, kind=case["kind"], double=case["double"], problem=P, ghost=case["ghost"], comm="peer")
     job.solver.set_parameter("nIterations", case["n"]); job.solver.set_parameter("lIterations", case["l"])
+    if "expect_onchip" in case:
+        job.solver.set_timing(True)
     job.solver.init(job.params); costs = [job.solver.cost()]
     while job.solver.step(job.params):
         costs.append(job.solver.cost())
     torch.cuda.synchronize()
     assert job.comm_kind == "peer" and job._peer.self_test_ok      # the self-test passed: no silent fall-back to RCCL in this test
+    if "expect_onchip" in case:
+        assert ("PCGSolveOnChip" in job.solver.kernel_timings()) == case["expect_onchip"], job.solver.kernel_timings().keys()
     q.put((rank, costs, job.owned_unknowns(), job.layout.row0, job.layout.rows, job._peer.mem_kind, job._peer.error()))
     job.close()
     dist.destroy_process_group()
@@ -212,3 +216,35 @@ def test_bench_two_ranks_is_self_describing():
     assert ck["allreduce_launches"] > 0 and ck["allreduce_us_per_iteration"] > 0 and ck["halo_exchanges"] > 0
     assert out["per_iteration_ms"] > 0 and out["roofline"]["per_iteration_ms"] > 0
     assert "needs distinct devices" in out["rccl_leg"]["skipped"]
+
+
+@pytest.mark.parametrize("world,W,rows_per_rank,ghost,double,onchip_rows", [(2, 600, 64, 8, False, 4), (2, 300, 32, 2, True, 4), (4, 520, 32, 8, False, 8), (2, 260, 64, 4, False, 16), (3, 257, 24, 2, True, 4)])
+def test_onchip_linear_solve_across_ranks(world, W, rows_per_rank, ghost, double, onchip_rows):
+    """The slab form of the on-chip linear solve (iw_onchip.h, OptAmd_SlabCommExt.onChipPlan): every rank's persistent kernel runs the whole PCG loop on its slab;
+    the first / last tile rows of neighbouring ranks hand each other the A p of their edge rows through the edge boxes of the peer window, and the grid-wide sums
+    take a rank hop through the mailbox.  Ranks as processes sharing the box's one GPU (their kernels are co-resident: at most 112 / 56 tiles each); result against
+    the single-GPU solve, costs bitwise equal between the ranks.  ROWS = 4 / 8 / 16, float and double, middle ranks with a neighbour on both sides."""
+    H = world * rows_per_rank
+    case = dict(W=W, H=H, double=double, ghost=ghost, kind="gaussNewtonGPU", n=3, l=11, expect_onchip=True, env={"OPT_AMD_ONCHIP_ROWS": str(onchip_rows)})
+    P = wl.image_warping(W, H, double=double, random_state=3, mask_fraction=0.06, perturb=0.3)
+    c1, x1 = _single(P, case["kind"], nIterations=case["n"], lIterations=case["l"])
+    res = _run(world, case)
+    tol = 1e-10 if double else 2e-5
+    for r in range(world):
+        _, costs, unk, row0, rows, mem_kind, err = res[r]
+        assert err == 0
+        np.testing.assert_allclose(costs, c1, rtol=tol)
+        assert costs == res[0][1]
+        for a, b in zip(unk, x1):
+            assert rel_err(a, b[row0:row0 + rows]) < (1e-9 if double else 2e-5)
+
+
+def test_onchip_across_ranks_is_all_or_none():
+    """One rank's slab does not make whole tiles (33 + 32 rows): that rank cannot run on chip, so nobody does (the decision is an all-reduce) and the streaming slab
+    loop runs everywhere."""
+    case = dict(W=300, H=65, double=True, ghost=2, kind="gaussNewtonGPU", n=2, l=9, expect_onchip=False, env={"OPT_AMD_ONCHIP_ROWS": "4"})
+    P = wl.image_warping(300, 65, double=True, random_state=3, mask_fraction=0.06, perturb=0.3)
+    c1, x1 = _single(P, case["kind"], nIterations=case["n"], lIterations=case["l"])
+    res = _run(2, case)
+    for r in range(2):
+        np.testing.assert_allclose(res[r][1], c1, rtol=1e-10)
