@@ -517,7 +517,7 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
                 __syncthreads();
             }
             if (tq < 4) { double s = 0; for (int grp = 0; grp < nGroups; ++grp) s += GS[grp * 4 + tq]; TOT[tq] = s; }
-            if (K.links.world > 1) {      // row slabs: the rank hop -- workgroup 0 posts this rank's totals to every rank's mailbox, everybody adds the ranks' totals in rank order
+            if (K.links.mailMine) {      // row slabs: the rank hop (also with a single rank: a 1-rank slab job measures the hop without the xGMI flight) -- workgroup 0 posts this rank's totals to every rank's mailbox, everybody adds the ranks' totals in rank order
                 __syncthreads();
                 const unsigned seq = K.links.seq0 + (unsigned)k;
                 const long slotOff = (long)(seq % (unsigned)K.links.slots) * K.links.slotStride;

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Per-iteration overhead of the multi-GPU plumbing, measurable on ONE GPU: the same slab-sized image_warping problem solved (a) as a plain
 single-GPU problem, (b) as a 1-rank slab job with the peer-mailbox communicator forced on (every all-reduce / halo kernel runs, peers =
-self), (c) the same with RCCL.  The difference (a) -> (b)/(c) is what the communication path adds per PCG iteration before any xGMI latency."""
+self), (c) the same with RCCL.  The difference (a) -> (b)/(c) is what the communication path adds per PCG iteration before any xGMI latency.
+Modes: plain (on-chip where the image fits), onchip-slab (the on-chip solve as a 1-rank slab job: decision all-reduce, ghost-row exchange, the rank hop of the sums through
+the mailbox), plain-streaming / peer-post / peer-wait / rccl (one launch per PCG iteration, OPT_AMD_ONCHIP=0)."""
 import json
 import os
 import sys
@@ -15,7 +17,12 @@ def run(mode, W, H, liters, steps):
     import torch
     import torch.distributed as dist
     from opt_amd import api, slab, workloads as wl
-    if mode == "plain":
+    os.environ["OPT_AMD_ONCHIP"] = "0" if mode.endswith("-streaming") or mode in ("peer", "peer-post", "peer-wait", "rccl") else "1"
+    if mode == "onchip-slab":
+        os.environ["OPT_AMD_PEER_POST"] = "1"; os.environ["OPT_AMD_PEER_PLAN"] = "0"
+        job = slab.SlabJob("image_warping", W, H, 0, 1, comm="peer")
+        s, dev = job.solver, job.params
+    elif mode in ("plain", "plain-streaming"):
         P = wl.image_warping(W, H)
         dev = api.to_device(P)
         s = api.Solver(api.energy_file("image_warping"), "gaussNewtonGPU", (W, H))
@@ -50,10 +57,10 @@ def main():
     out = {}
     sizes = [(4096, 512), (4096, 1024), (4096, 2048), (8192, 1024)] if "--all" in sys.argv else [(4096, 512), (8192, 1024)]
     for (W, H) in sizes:
-        for mode in ("plain", "peer", "peer-post", "peer-wait", "rccl"):
+        for mode in ("plain", "onchip-slab", "plain-streaming", "peer-post", "peer-wait", "rccl"):
             us = run(mode, W, H, 400, 3)
             out[f"{W}x{H}_{mode}"] = us
-            print(f"{W}x{H:5d} {mode:5s}: {us:7.1f} us per PCG iteration", flush=True)
+            print(f"{W}x{H:5d} {mode:16s}: {us:7.1f} us per PCG iteration", flush=True)
     print(json.dumps(out))
     dist.destroy_process_group()
 
