@@ -10,10 +10,11 @@
 //                 J^T F (c) = 2 sum_n [(X_c - X_n) - (T_c - T_n)],  diag = 2 #n,  (J^T J p)(c) = 2 sum_n (p_c - p_n).
 //   laplacian: X float unknown, A float.  r = { 0.2 (X - A), X(0,0) - X(1,0), X(0,0) - X(0,1) }; a residual that
 //              leaves the image is 0 (o.t:1930-1933); no Exclude, no preconditioner.
-// Both are HBM-bound streaming stencils (poisson: 36 B/pixel algorithmic in applyJTJ).  Kernels are
-// one-thread-per-pixel with direct neighbour loads: rows are W*16 B (poisson) so the +-1 row re-reads come from
-// L2; these energies are not the headline workload and keep the simple shape.
+// Both are HBM-bound streaming stencils (poisson: 36 B/pixel algorithmic in applyJTJ).  The once-per-step kernels are
+// one-thread-per-pixel with direct neighbour loads (rows are W*16 B, so the +-1 row re-reads come from L2); the Gauss-Newton
+// PCG loop runs on the marching template of stencil_march.h (one launch per iteration, 65 B/pixel in float).
 #include "energy.h"
+#include "stencil_march.h"
 
 namespace optamd {
 namespace {
@@ -115,90 +116,42 @@ __global__ __launch_bounds__(kBlock) void poisson_applyJTJ(PArgs<T> A, const T* 
     if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
 }
 
-// ---- one whole Gauss-Newton PCG iteration per launch, A p never stored (energy.h PcgIterArgs; the scheme of iw_pcgIter2) -------------
-// Launch k: for the pixel and its 4 neighbours  Ap_{k-1} = J^T J p_{k-1} (p on a 13-point diamond),  r_k = r_{k-1} - alpha_{k-1} Ap_{k-1},
-// p_k = r_k + beta_{k-1} p_{k-1}  (this energy does not precondition: z = r);  then Ap_k at the pixel for the sums.  State in
-// memory is r, p, delta: 100 B/pixel per iteration instead of 212 in three launches.  One thread per pixel -- the 18 float4 loads
-// per pixel are L1 / L2 hits on what neighbouring threads fetch; with 4 independent channels per pixel there is no point in
-// marching rows through registers.  The reference's start-up quirk is kept: PCGInit leaves p_0 = 0.25 r_0 and
-// alphaNumerator_0 = r_0 . p_0 although later z = r (guardedInvert(1) = 1/4, solver.t:323-332, 384-392); launch 0 therefore takes
-// p_0 from memory, and launch 1 expands betaNumerator_0 = sum r_1^2 from 4 alphaNumerator_0 = sum r_0^2 (exact: a power of two).
+// ---- the operators of the marching PCG iteration (stencil_march.h) -------------------------------------------------------------------------
+// poisson: (J^T J p)(c) = 2 sum over in-bounds neighbours of (p_c - p_n), neighbour order (+1,0), (-1,0), (0,+1), (0,-1) as in poisson_applyJTJ
 template <class T>
-struct PIterK {
-    const T *rOld, *pOld; T *rNew, *pNew, *delta; int iter;
-    const double *aNumPrev, *aDenPrev, *s2Prev, *s3Prev; int nNum, nDen, n2, n3;
-    double *aNum, *aDen, *s2, *s3;
-};
-constexpr int kPTileW = 64, kPTileH = 4;     // 256 threads
-template <class T>
-__global__ __launch_bounds__(kBlock) void poisson_pcgIter(PArgs<T> A, PIterK<T> K) {
-    __shared__ double scratch[4 * (kBlock / kWave + 1)];
-    const bool first = K.iter == 0;
-    T alpha = 0, beta = 0;
-    if (!first) {
-        const double* const ps[4] = {K.aNumPrev, K.aDenPrev, K.s2Prev, K.s3Prev}; const int ns[4] = {K.nNum, K.nDen, K.n2, K.n3}; double o4[4];
-        sumPartialsN<4>(ps, ns, scratch, o4);
-        const double aNumD = o4[0], aDenD = o4[1], s2 = o4[2], s3 = o4[3];
-        const T aNum = (T)aNumD, aDen = (T)aDenD;
-        alpha = (aDen > T(0)) ? aNum / aDen : T(0);
-        const double rr = (K.iter == 1) ? 4.0 * aNumD : aNumD;                  // sum r_{k-1}^2 (see above)
-        const double bNumD = fmax(rr - 2.0 * (double)alpha * s2 + (double)alpha * (double)alpha * s3, 0.0);   // the direct sum is >= 0: clamp cancellation noise
-        beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
-    }
-    const V4<T>* R = (const V4<T>*)K.rOld; const V4<T>* P = (const V4<T>*)K.pOld;
-    const int tx = threadIdx.x % kPTileW, ty = threadIdx.x / kPTileW;
-    const int tilesX = (A.W + kPTileW - 1) / kPTileW, tilesY = (A.H + kPTileH - 1) / kPTileH;
-    double accDen = 0, accNum = 0, acc2 = 0, acc3 = 0;
-    const V4<T> zero{0, 0, 0, 0};
-    auto inb = [&](int x, int y) { return x >= 0 && x < A.W && y >= 0 && y < A.H; };
-    auto pAt = [&](int x, int y) { return inb(x, y) ? P[(long)y * A.W + x] : zero; };          // p is 0 on excluded pixels already
-    // J^T J p_{k-1} at (x, y): 2 sum over in-bounds neighbours of (p_c - p_n); the row of an excluded or non-existent pixel is 0
-    auto applyOld = [&](int x, int y, const V4<T>& pc) {
-        V4<T> o = zero;
-        const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};
+struct PoissonMarchOp {
+    static constexpr int C = 4; static constexpr bool kMasked = true;
+    using Vec = MVec<T, 4>;
+    __device__ __forceinline__ Vec apply(const Vec& pc, const Vec& pl, const Vec& pr, const Vec& pu, const Vec& pd, bool hasL, bool hasR, bool hasU, bool hasD) const {
+        Vec o;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) if (inb(x + dx[n], y + dy[n])) { const V4<T> d = pc - pAt(x + dx[n], y + dy[n]); o = o + (d + d); }
-        return o;
-    };
-    // r_k and p_k at (x, y); both 0 where the pixel is excluded or outside
-    auto update = [&](int x, int y, V4<T>& rk, V4<T>& pk, V4<T>& pold) {
-        rk = zero; pk = zero; pold = zero;
-        if (!inb(x, y)) return;
-        const long i = (long)y * A.W + x;
-        if (A.M[i] != T(0)) return;
-        pold = P[i];
-        const V4<T> r0 = R[i];
-        if (first) { rk = r0; pk = pold; return; }
-        const V4<T> ap = applyOld(x, y, pold);
-        rk = r0 - alpha * ap;
-        pk = rk + beta * pold;
-    };
-    for (int t = blockIdx.x; t < tilesX * tilesY; t += gridDim.x) {
-        const int x = (t % tilesX) * kPTileW + tx, y = (t / tilesX) * kPTileH + ty;
-        if (!inb(x, y)) continue;
-        const long i = (long)y * A.W + x;
-        V4<T> rk, pk, pold;
-        update(x, y, rk, pk, pold);
-        ((V4<T>*)K.rNew)[i] = rk; ((V4<T>*)K.pNew)[i] = pk;
-        if (A.M[i] != T(0)) continue;
-        if (!first) { V4<T>* D = (V4<T>*)K.delta; D[i] = D[i] + alpha * pold; }          // delta += alpha_{k-1} p_{k-1} (solver.t:461-462)
-        V4<T> o = zero;
-        const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            if (!inb(x + dx[n], y + dy[n])) continue;
-            V4<T> rn, pn, pon;
-            update(x + dx[n], y + dy[n], rn, pn, pon);
-            const V4<T> d = pk - pn;
-            o = o + (d + d);
+        for (int c = 0; c < 4; ++c) {
+            T a = 0;
+            if (hasR) { const T d = pc.v[c] - pr.v[c]; a = a + (d + d); }
+            if (hasL) { const T d = pc.v[c] - pl.v[c]; a = a + (d + d); }
+            if (hasD) { const T d = pc.v[c] - pd.v[c]; a = a + (d + d); }
+            if (hasU) { const T d = pc.v[c] - pu.v[c]; a = a + (d + d); }
+            o.v[c] = a;
         }
-        const V4<T> z = first ? pold : rk;                 // z_0 . r_0 is the reference's r_0 . p_0
-        accNum += (double)dot4(z, rk); accDen += (double)dot4(pk, o);
-        acc2 += (double)dot4(rk, o); acc3 += (double)dot4(o, o);
+        return o;
     }
-    double v[4] = {accDen, accNum, acc2, acc3};
-    blockReduceSumN<4>(v, scratch);
-    if (threadIdx.x == 0) { K.aDen[blockIdx.x] = v[0]; K.aNum[blockIdx.x] = v[1]; K.s2[blockIdx.x] = v[2]; K.s3[blockIdx.x] = v[3]; }
+};
+// laplacian: 0.2^2 p_c + sum over in-bounds neighbours of (p_c - p_n), order as in lap_applyJTJ
+struct LaplacianMarchOp {
+    static constexpr int C = 1; static constexpr bool kMasked = false;
+    using Vec = MVec<float, 1>;
+    __device__ __forceinline__ Vec apply(const Vec& pc, const Vec& pl, const Vec& pr, const Vec& pu, const Vec& pd, bool hasL, bool hasR, bool hasU, bool hasD) const {
+        float o = 0.2f * 0.2f * pc.v[0];
+        if (hasR) o += pc.v[0] - pr.v[0];
+        if (hasL) o += pc.v[0] - pl.v[0];
+        if (hasD) o += pc.v[0] - pd.v[0];
+        if (hasU) o += pc.v[0] - pu.v[0];
+        return Vec{{o}};
+    }
+};
+template <class T>
+__global__ __launch_bounds__(kBlock) void poisson_flags(const T* __restrict__ M, uint8_t* __restrict__ flags, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) flags[i] = M[i] == T(0) ? 1 : 0;
 }
 
 // ---- block-local "patch" PCG (the reference's LDS-resident comparator solver, examples/poisson_image_editing/src/
@@ -300,7 +253,8 @@ template <class T>
 struct PoissonOps : EnergyOps<T> {
     PArgs<T> A{};
     int cus = 256;
-    int iterIndex = 0; bool singleKernel = true;
+    bool singleKernel = true;
+    MarchLoop<T> march; uint8_t* flags = nullptr;      // bit 0: M == 0 (the pixel is an unknown), refreshed at every bind
     PoissonOps(const unsigned* dims) {
         A.W = (int)dims[0]; A.H = (int)dims[1];
         this->usePreconditioner = false;                       // poisson_image_editing.t:5
@@ -309,7 +263,14 @@ struct PoissonOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_POISSON_ONEKERNEL")) singleKernel = atoi(e) != 0;
     }
     int grid() const { return (int)std::max<long>(1, std::min<long>(((long)A.W * A.H + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
-    void bind(void** p, LaunchCtx&) override { A.X = (const T*)p[0]; A.Tg = (const T*)p[1]; A.M = (const T*)p[2]; }
+    void bind(void** p, LaunchCtx& ctx) override {
+        A.X = (const T*)p[0]; A.Tg = (const T*)p[1]; A.M = (const T*)p[2];
+        if (singleKernel) {
+            const long n = (long)A.W * A.H;
+            if (!flags) HIP_CHECK(hipMalloc((void**)&flags, (size_t)n));
+            poisson_flags<T><<<grid(), kBlock, 0, ctx.stream>>>(A.M, flags, n);
+        }
+    }
     T* unknownPtr(int) const override { return const_cast<T*>(A.X); }
     void evalCost(Reduction& out, LaunchCtx& ctx) override { ScopedKernel k(ctx, "computeCost"); poisson_cost<T, 0><<<grid(), kBlock, 0, ctx.stream>>>(A, nullptr, out.partials); out.n = grid(); }
     void evalJTF(T* r, T* diag, LaunchCtx& ctx) override { ScopedKernel k(ctx, "PCGInit1"); poisson_evalJTF<T><<<grid(), kBlock, 0, ctx.stream>>>(A, r, diag); }
@@ -324,21 +285,13 @@ struct PoissonOps : EnergyOps<T> {
     }
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
         if (!singleKernel || a.pre || a.CtC) return false;      // Gauss-Newton only: the Levenberg-Marquardt loop keeps the generic kernels
-        if (a.first) iterIndex = 0;
-        const int tiles = ((A.W + kPTileW - 1) / kPTileW) * ((A.H + kPTileH - 1) / kPTileH);
-        const int g = std::max(1, std::min(tiles, std::min(kMaxPartials, cus * 8)));
-        PIterK<T> K{a.rOld, a.pOld, a.rNew, a.pNew, a.delta, iterIndex,
-                    a.aNumPrev.partials, a.aDenPrev.partials, a.s2Prev.partials, a.s3Prev.partials, a.aNumPrev.n, a.aDenPrev.n, a.s2Prev.n, a.s3Prev.n,
-                    a.aNum->partials, a.aDen->partials, a.s2->partials, a.s3->partials};
-        { ScopedKernel k(ctx, "PCGIteration"); poisson_pcgIter<T><<<g, kBlock, 0, ctx.stream>>>(A, K); }
-        a.aNum->n = a.aDen->n = a.s2->n = a.s3->n = g;
-        ++iterIndex;
-        return true;
+        return march.launch(PoissonMarchOp<T>{}, A.W, A.H, flags, cus, a, ctx);
     }
+    const T* pcgFinish(const T*, T* delta, LaunchCtx& ctx) override { return march.finish(delta, 4L * A.W * A.H, cus, ctx); }
     // ---- patch solver: ping-pong between the caller's X and a scratch copy; patchFinish leaves the result in the caller's buffer
     T* scratchX = nullptr; bool inScratch = false;
     bool supportsPatch() const override { return true; }
-    ~PoissonOps() override { if (scratchX) (void)hipFree(scratchX); }
+    ~PoissonOps() override { if (scratchX) (void)hipFree(scratchX); if (flags) (void)hipFree(flags); }
     template <int PS> void launchPatch(const T* in, T* out, float fx, float fy, int nPatchIters, LaunchCtx& ctx) {
         const dim3 g((A.W + PS - 1) / PS + 1, (A.H + PS - 1) / PS + 1);     // one more block per axis for the shift
         poisson_patchSolve<T, PS><<<g, PS * PS, 0, ctx.stream>>>(A.W, A.H, in, out, A.Tg, A.M, (int)(fx * PS), (int)(fy * PS), nPatchIters);
@@ -435,6 +388,12 @@ struct LaplacianOps : EnergyOps<float> {
     void evalModelCost(const float* delta, Reduction& out, LaunchCtx& ctx) override {
         ScopedKernel k(ctx, "computeModelCost"); lap_cost<1><<<grid(), kBlock, 0, ctx.stream>>>(A, delta, out.partials); out.n = grid();
     }
+    MarchLoop<float> march;
+    bool pcgIteration(const PcgIterArgs<float>& a, LaunchCtx& ctx) override {
+        if (a.pre || a.CtC) return false;
+        return march.launch(LaplacianMarchOp{}, A.W, A.H, nullptr, cus, a, ctx);
+    }
+    const float* pcgFinish(const float*, float* delta, LaunchCtx& ctx) override { return march.finish(delta, (long)A.W * A.H, cus, ctx); }
 };
 
 template <class T> EnergyOps<T>* makePoisson(const unsigned* dims) { return new PoissonOps<T>(dims); }

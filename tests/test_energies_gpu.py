@@ -163,6 +163,7 @@ def test_minimal_laplacian_solve():
 def test_create_delete_cycle():
     """Reference tests/create_delete_cycle/main.cpp:22-31: repeated ProblemPlan / PlanFree must not leak or crash."""
     import torch
+    api.Solver(api.energy_file("laplacian"), "gaussNewtonGPU", (512, 512)).close()      # warm-up cycle: code objects, queues and the runtime's pools exist (as in the C++ caller)
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
     for _ in range(200):
@@ -182,8 +183,8 @@ def test_plan_failures_return_null():
 
 @pytest.mark.parametrize("double", [False, True])
 def test_poisson_single_kernel_iteration_matches_three_kernel_loop(double, monkeypatch):
-    """poisson_pcgIter (whole PCG iteration in one launch, A p recomputed, the p0 = r0 / 4 start-up quirk carried through the
-    beta-numerator expansion) against the Step1 / Step2 / Step3 loop over 150 iterations, odd and even image sizes."""
+    """march_pcgIter<PoissonMarchOp> (whole PCG iteration in one launch, A p recomputed, r rebuilt from the p ring, the p0 = r0 / 4 start-up quirk carried through
+    the beta-numerator expansion) against the Step1 / Step2 / Step3 loop over 150 iterations, odd and even image sizes."""
     P = wl.poisson_image_editing(333, 257, double=double, seed=9)
     res = {}
     for mode in ("1", "0"):
