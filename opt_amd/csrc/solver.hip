@@ -492,7 +492,7 @@ struct PcgSolver : SolverBase {
                     if (e != hipSuccess && e != hipErrorNotReady) HIP_CHECK(e);
                     if (e == hipSuccess) {      // idle stream, word not seen: one real synchronise and one more look before calling it an error
                         if (!synced) { HIP_CHECK(hipStreamSynchronize(stream)); synced = true; continue; }
-                        fprintf(stderr, "Opt(amd): Q partial %d of tag %u never arrived (the producing launch was not issued or faulted); Q is reported as NaN\n", i, tag);
+                        fprintf(stderr, "Opt(amd): Q partial %d of tag %u never arrived (the producing launch was not issued or faulted); this early-out test is skipped and the plan goes back to reading Q through the stream\n", i, tag);
                         return std::nan("");
                     }
                 }
@@ -708,7 +708,7 @@ struct PcgSolver : SolverBase {
             a.aNumPrev = prev[0]; a.aDenPrev = prev[1]; a.s2Prev = prev[2]; a.s3Prev = prev[3];
             a.aNum = &setS[cur][0]; a.aDen = &setS[cur][1]; a.s2 = &setS[cur][2]; a.s3 = &setS[cur][3];
             a.CtC = CtC; a.b = b; a.q = (k & 1) ? &redQ2 : &redQ; a.afterReset = restart ? 1 : 0; a.betaNum = bNumDirect; a.betaDen = bDenDirect;
-            if (taggedQ) { if (++launchTag == 0) ++launchTag; a.qTag = tagOf[k & 1] = launchTag; }
+            if (taggedQ) { if (++launchTag == 0) ++launchTag; a.qTag = tagOf[k & 1] = launchTag; } else tagOf[k & 1] = 0;      // (0: this launch writes plain partials)
             a.lmRadius = trust_region_radius; a.lmMinDiag = min_lm_diagonal; a.lmMaxDiag = max_lm_diagonal;
             issuedRestart = restart;
             return E->pcgIteration(a, ctx);
@@ -739,16 +739,21 @@ struct PcgSolver : SolverBase {
             };
             bool resetIssued = false;
             if (appliedStep2) {
-                if (!taggedQ) beginHostSum((lIter & 1) ? redQ2 : redQ);
+                const bool tagged = tagOf[lIter & 1] != 0;      // how THIS launch wrote its Q partials (taggedQ may have been switched off since it was issued)
+                if (!tagged) beginHostSum((lIter & 1) ? redQ2 : redQ);
                 // What follows is enqueued before Q is known.  The next launch writes only the alternate buffers, and the reset writes delta2, r (dead after
                 // an early-out) and scratch: if the test below ends the linear solve, their results are simply never adopted (the fetchQ of solver.t:1098
                 // no longer idles the GPU).
                 if (resetNow) { resetKernels(delta2); resetIssued = true; }
                 else if (lIter + 1 < sp.lIterations) { if (!issue(lIter + 1, false)) { fprintf(stderr, "pcgIteration refused mid-loop\n"); exit(1); } issued = true; }
-                const T Q1 = (T)(taggedQ ? pollTaggedSum((lIter & 1) ? redQ2 : redQ, tagOf[lIter & 1]) : endHostSum());
-                const T zeta = T(lIter) * (Q1 - Q0) / Q1;
-                if (zeta < q_tolerance) { if (verbosity > 0) printf("zeta=%.18g, breaking at iteration: %d\n", (double)zeta, lIter); return true; }
-                Q0 = Q1;
+                const T Q1 = (T)(tagged ? pollTaggedSum((lIter & 1) ? redQ2 : redQ, tagOf[lIter & 1]) : endHostSum());
+                if (Q1 != Q1) {      // a tagged Q partial never arrived (pollTaggedSum said why): this iteration's test is skipped, Q0 stays the last known value, and the
+                    taggedQ = false; //  plan reads Q through the stream (beginHostSum / endHostSum) from here on, so the later early-out tests are real again
+                } else {
+                    const T zeta = T(lIter) * (Q1 - Q0) / Q1;
+                    if (zeta < q_tolerance) { if (verbosity > 0) printf("zeta=%.18g, breaking at iteration: %d\n", (double)zeta, lIter); return true; }
+                    Q0 = Q1;
+                }
             }
             deltaOwed = true;                                          // iteration lIter: Step1 done, its Step2 still to come
             if (resetNow) {

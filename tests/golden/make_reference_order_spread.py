@@ -5,7 +5,8 @@ API/src/solverGPUGaussNewton.t:312-317 -- in a seeded random order) for several 
 
   horizon      : image_warping 2048^2 float, ONE Gauss-Newton step with lIterations in {20, 50, 100, 200, 400};
   adversarial  : 1024^2 with 0.2 % stiff fit pixels (w_fit = 1e4, w_reg = 1e-4), same horizons;
-  solve8       : the metric's solve at 2048^2, 8 Gauss-Newton steps x 400 PCG iterations from the initial guess.
+  solve8       : the metric's solve at 2048^2 (--size 4096: at the metric's own size), 8 Gauss-Newton steps x 400 PCG iterations from the initial guess;
+  bench        : what bench.py's timed region starts with, at --size (4096): 2 Gauss-Newton steps x 400 PCG iterations.
 
 Every seed is one legal run of the reference's arithmetic (its atomics commit in an order the hardware does not define).  The seed-to-seed
 spread of the cost at a horizon is what the reference's own trajectory contract can mean there; tests/test_horizon_gpu.py and bench.py read
@@ -55,10 +56,15 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--precisions", nargs="+", default=["float"])
     ap.add_argument("--size", type=int, default=2048)
+    ap.add_argument("--horizons", type=int, nargs="+", default=HORIZONS, help="horizon / adversarial families: which lIterations")
+    ap.add_argument("--tag", default="", help="key suffix for another legal variant of the run, e.g. `raster` with --threads 1: the single-threaded oracle scatters J^T J p in raster "
+                                               "order, the multi-threaded one in two colours of 4-row bands (oracle/solver.hpp forEachInstanceBanded) -- two accumulation orders of the same float additions")
+    ap.add_argument("--out", default=OUT, help="JSON file to extend (tools/reference_spread.py reads reference_order_costs*.json)")
     ap.add_argument("--variant", default="plain", choices=["plain", "fma"], help="fma: keys get the suffix _fma")
     a = ap.parse_args()
-    sfx = "_fma" if a.variant == "fma" else ""
-    res = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    sfx = ("_" + a.tag if a.tag else "") + ("_fma" if a.variant == "fma" else "")
+    out = a.out
+    res = json.load(open(out)) if os.path.exists(out) else {}
 
     def done(key, seed):
         return str(seed) in res.get(key, {}).get("costs_by_seed", {})
@@ -66,7 +72,8 @@ def main():
     def put(key, seed, costs, dt):
         e = res.setdefault(key, {"costs_by_seed": {}, "seconds_by_seed": {}, "reduction": "reference order (oracle reductionMode 1)"})
         e["costs_by_seed"][str(seed)] = costs; e["seconds_by_seed"][str(seed)] = dt
-        json.dump(res, open(OUT, "w"), indent=1, sort_keys=True)
+        json.dump(res, open(out + ".tmp", "w"), indent=1, sort_keys=True)
+        os.replace(out + ".tmp", out)
         print(key, "seed", seed, costs, f"{dt:.0f} s", flush=True)
 
     for fam in a.families:
@@ -74,13 +81,18 @@ def main():
             dbl = prec == "double"
             for seed in a.seeds:
                 if fam in ("horizon", "adversarial"):
-                    for L in HORIZONS:
+                    for L in a.horizons:
                         size = a.size if fam == "horizon" else 1024
                         key = f"{fam}_{size}_{prec}_{L}{sfx}"
                         if done(key, seed):
                             continue
                         P = wl.image_warping(size, size, double=dbl) if fam == "horizon" else wl.image_warping(size, size, double=dbl, **ADVERSARIAL)
                         put(key, seed, *run(P, dbl, 1, L, a.threads, seed))
+                elif fam == "bench":
+                    key = f"bench_{a.size}_{prec}_400x2{sfx}"
+                    if done(key, seed):
+                        continue
+                    put(key, seed, *run(wl.image_warping(a.size, a.size, double=dbl), dbl, 2, 400, a.threads, seed))
                 else:
                     key = f"solve8_{a.size}_{prec}{sfx}"
                     if done(key, seed):

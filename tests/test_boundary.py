@@ -184,7 +184,7 @@ def test_prototypes_equal_the_reference_header_and_a_reference_caller_links(opt_
 
 def test_bench_helpers_without_a_gpu():
     """bench.py's bookkeeping that needs no device: the kernel-source hash is stable and names real files, the frozen oracle values of the metric's solve load,
-    the re-rounding yardstick comes out of the committed horizon files, and a traffic file is only accepted for the kernel sources it was measured with."""
+    the reference-spread yardstick comes out of the committed golden files, and a traffic file is only accepted for the kernel sources it was measured with."""
     import importlib
     import sys
     sys.path.insert(0, ROOT)
@@ -195,8 +195,10 @@ def test_bench_helpers_without_a_gpu():
     assert len(sha) == 16 and sha == bench.kernel_src_sha16()
     fl, db = bench.golden_solve8(2048)
     assert fl is not None and len(fl) == 9 and fl[0] == 35515200.0 and fl[-1] < 1e-3 * fl[0]
-    y = bench.rerounding_yardstick()
-    assert 1e-4 < y < 1e-2            # 2.6e-3: the oracle against its own fma build over one 400-iteration float step
+    rs = bench.reference_spread()
+    y = rs.yardstick("horizon_2048_float_400", "float")
+    assert 1e-4 < y < 1e-2            # 2.3e-3: diameter of ten legal runs (reference-order sums under five seeds, exact-order sums, plain / fma build) after 400 float iterations
+    assert rs.n_reference_order_runs("horizon_2048_float_400") >= 5
     assert bench.measured_traffic("0" * 16) == (None, None)
     costs, env = bench.golden_cost(4096, 400)
     assert costs is not None and len(costs) == 3 and env is not None and env[0] == 0.0

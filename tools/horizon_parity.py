@@ -11,8 +11,10 @@ Three HIP loops on identical inputs, one Gauss-Newton step each, lIterations in 
   on-chip   : default             -- the whole linear solve as one persistent launch where the image fits the chip (iw_onchipPcg: 1024^2 does, 2048^2 does not and
               takes the r-free loop again)
 
-against the frozen oracle costs of tests/golden/horizon_costs.json, with |oracle plain - oracle fma| (the same CPU restatement compiled with and without
-fused multiply-adds, horizon_costs_fma.json) beside them as the yardstick of what rounding alone does at that horizon.
+against the frozen exact-order oracle costs of tests/golden/horizon_costs.json.  The yardstick beside them (tools/reference_spread.py) is the diameter of the
+frozen LEGAL runs of the reference's own arithmetic at that horizon: its per-warp float atomics commit in an undefined order, reproduced by the oracle's
+reference-order mode under several seeds (tests/golden/reference_order_costs.json), plus the exact-order sums and the fused-multiply-add build of the same
+restatement; never below the contract (1e-5 float, 1e-12 double).  A loop is `within_reference_spread` at 2 yardsticks or less.
 
     python tools/horizon_parity.py [--out gpurun_out/horizon] [--families horizon adversarial]
 
@@ -25,6 +27,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import reference_spread as rs      # noqa: E402
 GOLD = os.path.join(ROOT, "tests", "golden")
 HORIZONS = [20, 50, 100, 200, 400]
 LOOPS = {"ref-order": {"OPT_AMD_ONEKERNEL": "0", "OPT_AMD_ONCHIP": "0"}, "r-free": {"OPT_AMD_ONCHIP": "0"}, "on-chip": {"OPT_AMD_ONCHIP": "1"}}
@@ -98,18 +102,22 @@ def experiment(families=("horizon", "adversarial"), precisions=("float", "double
                     row[name] = c
                     row[name + "_rel"] = abs(c - ref) / abs(ref)
                 row["onchip_vs_rfree"] = abs(row["on-chip"] - row["r-free"]) / abs(row["r-free"])
+                row["yardstick"] = rs.yardstick(key, prec); row["reference_spread"] = rs.spread(key); row["seed_to_seed_spread"] = rs.seed_spread(key)
+                row["legal_runs"] = len(rs.legal_runs(key))
+                row["within_reference_spread"] = all(row[n + "_rel"] <= rs.FACTOR * row["yardstick"] for n in LOOPS)
                 rows.append(row)
                 print(json.dumps(row), flush=True)
     return rows
 
 
 def markdown(rows):
-    out = ["| family | precision | PCG iterations | oracle cost | ref-order HIP | r-free HIP | on-chip HIP | on-chip vs r-free | oracle plain vs fma | oracle float vs double |",
-           "|---|---|---|---|---|---|---|---|---|---|"]
+    out = ["| family | precision | PCG iterations | oracle cost | ref-order HIP | r-free HIP | on-chip HIP | legal runs | seed-to-seed | yardstick | worst loop / yardstick | within reference spread (<= 2) |",
+           "|---|---|---|---|---|---|---|---|---|---|---|---|"]
     f = lambda v: "n/a" if v is None else f"{v:.2e}"
     for r in rows:
+        worst = max(r[n + "_rel"] for n in LOOPS) / r["yardstick"]
         out.append(f"| {r['family']} {r['size']}² | {r['precision']} | {r['liters']} | {r['oracle']:.9g} | {f(r['ref-order_rel'])} | {f(r['r-free_rel'])} | {f(r['on-chip_rel'])} | "
-                   f"{f(r['onchip_vs_rfree'])} | {f(r.get('oracle_plain_vs_fma'))} | {f(r.get('oracle_float_vs_double'))} |")
+                   f"{r['legal_runs']} | {f(r.get('seed_to_seed_spread'))} | {f(r['yardstick'])} | {worst:.2f} | {'yes' if r['within_reference_spread'] else 'NO'} |")
     return "\n".join(out)
 
 
@@ -123,8 +131,8 @@ def main():
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(rows, open(args.out + ".json", "w"), indent=1)
     md = ("# |cost - oracle| / oracle after ONE Gauss-Newton step, by PCG horizon (image_warping, gaussNewtonGPU)\n\n"
-          "Columns 5-7: the three HIP loops against the frozen oracle of the same precision; column 9: the oracle against itself compiled with fused\n"
-          "multiply-adds (rounding alone); column 10: float oracle against double oracle.  tools/horizon_parity.py, tests/test_horizon_gpu.py.\n\n" + markdown(rows) + "\n")
+          "Columns 5-7: the three HIP loops against the frozen exact-order oracle of the same precision; yardstick = max(contract, diameter of the frozen legal runs\n"
+          "of the reference's arithmetic at that horizon) (tools/reference_spread.py, profiles/r04_reference_order_spread.md).  tests/test_horizon_gpu.py asserts the last column.\n\n" + markdown(rows) + "\n")
     open(args.out + ".md", "w").write(md)
     print(md)
 

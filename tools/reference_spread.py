@@ -1,0 +1,153 @@
+"""One yardstick for long-horizon parity: how far apart do LEGAL runs of the reference's arithmetic end?
+
+The reference sums its dot products with one opt_float atomicAdd per warp (API/src/util.t:612-623, API/src/solverGPUGaussNewton.t:312-317): the order in
+which the N/32 atomics commit is not defined, so two runs of the reference itself differ.  The oracle's reference-order mode (oracle/solver.hpp: per-element
+opt_float terms, the 32-lane shfl.down tree, the per-warp partials added in a seeded random order) reproduces that; every seed is one legal run.  The frozen
+runs are in tests/golden/:
+
+    horizon_costs.json / horizon_costs_fma.json       exact-order sums (long double), plain build / fused-multiply-add build of the oracle
+    reference_order_costs.json                        reference-order sums, seeds 1..5 (plain build) and 1..3 (fma build, keys *_fma)
+
+spread(key, step)  = the diameter of that set (largest pairwise relative distance of the cost after `step` Gauss-Newton steps);
+yardstick          = max(contract floor, spread)            contract floor: 1e-5 float, 1e-12 double (BASELINE.json north_star);
+a HIP loop is `within_reference_spread` if its cost is at most FACTOR (= 2) yardsticks from the exact-order plain oracle.
+
+No GPU, no oracle library: this module only reads the frozen numbers (tests/test_horizon_gpu.py, tools/horizon_parity.py, bench.py).
+"""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+FLOOR = {"float": 1e-5, "double": 1e-12}
+FACTOR = 2.0
+
+# key suffixes of the reference-order runs: build (plain / fused multiply-adds) x accumulation order of the J^T J p scatter (banded two-colour traversal of the
+# multi-threaded oracle / raster order of the single-threaded one) -- every combination is the same algorithm under another legal rounding
+VARIANTS = (("", "plain"), ("_fma", "fma"), ("_raster", "raster"), ("_raster_fma", "raster fma"))
+_cache = {}
+
+
+def _load(name):
+    if name not in _cache:
+        p = os.path.join(GOLD, name)
+        _cache[name] = json.load(open(p)) if os.path.exists(p) else {}
+    return _cache[name]
+
+
+def _reference_order():
+    """reference_order_costs.json merged with any reference_order_costs_*.json beside it (more seeds of some workloads, generated separately)."""
+    if "_ro" not in _cache:
+        import glob
+        R = {}
+        for p in sorted(glob.glob(os.path.join(GOLD, "reference_order_costs*.json"))):
+            for k, e in json.load(open(p)).items():
+                R.setdefault(k, {"costs_by_seed": {}})["costs_by_seed"].update(e.get("costs_by_seed", {}))
+        _cache["_ro"] = R
+    return _cache["_ro"]
+
+
+def _exact(key, name):
+    """The exact-order run of `key` in golden file `name`.  bench_<size>_<precision>_400x2 (bench.py's first two Gauss-Newton steps) is frozen in bench_costs.json."""
+    if key.startswith("bench_"):
+        if name != "horizon_costs.json":
+            return None
+        _, size, prec, _ = key.split("_")
+        return _load("bench_costs.json").get(f"image_warping_{size}x{size}_{prec}_gaussNewtonGPU_400")
+    return _load(name).get(key)
+
+
+def legal_runs(key, step=1):
+    """[(label, cost after `step` Gauss-Newton steps)] of every frozen run of workload `key` (e.g. "horizon_2048_float_400", "solve8_2048_float", "bench_4096_float_400x2")."""
+    runs = []
+    for label, name in (("exact-order plain", "horizon_costs.json"), ("exact-order fma", "horizon_costs_fma.json")):
+        e = _exact(key, name)
+        if e and len(e["costs"]) > step:
+            runs.append((label, e["costs"][step]))
+    R = _reference_order()
+    for sfx, tag in VARIANTS:
+        for seed, costs in sorted(R.get(key + sfx, {}).get("costs_by_seed", {}).items(), key=lambda kv: int(kv[0])):
+            if len(costs) > step:
+                runs.append((f"reference-order {tag} seed {seed}", costs[step]))
+    return runs
+
+
+def anchor(key, step=1):
+    e = _exact(key, "horizon_costs.json")
+    return e["costs"][step] if e and len(e["costs"]) > step else None
+
+
+def spread(key, step=1):
+    """Diameter of the legal runs relative to the anchor; None without at least two runs."""
+    runs = [c for _, c in legal_runs(key, step)]
+    a = anchor(key, step)
+    if len(runs) < 2 or a is None:
+        return None
+    return (max(runs) - min(runs)) / abs(a)
+
+
+def seed_spread(key, step=1):
+    """Seed-to-seed diameter of the reference-order runs of the plain build alone (what two runs of the reference differ by, nothing else varied)."""
+    R = _reference_order().get(key, {}).get("costs_by_seed", {})
+    v = [c[step] for c in R.values() if len(c) > step]
+    a = anchor(key, step)
+    return (max(v) - min(v)) / abs(a) if len(v) >= 2 and a else None
+
+
+def yardstick(key, precision, step=1):
+    s = spread(key, step)
+    return max(FLOOR[precision], s or 0.0)
+
+
+def n_reference_order_runs(key):
+    R = _reference_order()
+    return sum(len(R.get(key + sfx, {}).get("costs_by_seed", {})) for sfx, _ in VARIANTS)
+
+
+def verdict(key, precision, hip_cost, step=1):
+    """{'distance', 'spread', 'yardstick', 'factor', 'within_reference_spread', 'within_contract', 'runs'} for one HIP cost."""
+    a = anchor(key, step)
+    if a is None:
+        return None
+    d = abs(hip_cost - a) / abs(a)
+    y = yardstick(key, precision, step)
+    return {"distance_from_exact_order_oracle": d, "reference_spread": spread(key, step), "seed_to_seed_spread": seed_spread(key, step), "yardstick": y, "factor": FACTOR,
+            "within_reference_spread": d <= FACTOR * y, "within_contract": d <= FLOOR[precision], "legal_runs": len(legal_runs(key, step)),
+            "reference_order_runs": n_reference_order_runs(key)}
+
+
+def table(families=("horizon", "adversarial"), precisions=("float", "double"), horizons=(20, 50, 100, 200, 400)):
+    rows = []
+    for fam in families:
+        size = 2048 if fam == "horizon" else 1024
+        for prec in precisions:
+            for L in horizons:
+                key = f"{fam}_{size}_{prec}_{L}"
+                if anchor(key) is None:
+                    continue
+                rows.append({"key": key, "family": fam, "precision": prec, "liters": L, "anchor": anchor(key), "runs": legal_runs(key), "spread": spread(key),
+                             "seed_to_seed": seed_spread(key), "yardstick": yardstick(key, prec)})
+    return rows
+
+
+def markdown():
+    f = lambda v: "n/a" if v is None else f"{v:.2e}"
+    out = ["# Spread of the reference's own arithmetic (image_warping, one Gauss-Newton step, cost after L PCG iterations)", "",
+           "Frozen oracle runs (tests/golden/reference_order_costs.json, horizon_costs.json, horizon_costs_fma.json; generators beside them).  `seed-to-seed` = diameter of the",
+           "reference-order runs of the plain build (seeded random commit order of the per-warp float atomics, nothing else varied); `all legal runs` adds the exact-order",
+           "sums and the fused-multiply-add build of the same restatement (a compiler's choice the reference's Terra/LLVM build also makes).  yardstick = max(contract floor, all legal runs).", "",
+           "| workload | precision | L | exact-order oracle cost | runs | seed-to-seed | all legal runs | yardstick |", "|---|---|---|---|---|---|---|---|"]
+    for r in table():
+        out.append(f"| {r['family']} | {r['precision']} | {r['liters']} | {r['anchor']:.9g} | {len(r['runs'])} | {f(r['seed_to_seed'])} | {f(r['spread'])} | {f(r['yardstick'])} |")
+    out += ["", "## The metric's solve: 8 Gauss-Newton steps x 400 PCG iterations from the initial guess, final energy", "",
+            "| workload | precision | exact-order oracle | runs | seed-to-seed | all legal runs |", "|---|---|---|---|---|---|"]
+    for key, prec in (("solve8_2048_float", "float"), ("solve8_2048_double", "double"), ("solve8_4096_float", "float")):
+        a = anchor(key, 8)
+        if a is None:
+            continue
+        out.append(f"| {key} | {prec} | {a:.9g} | {len(legal_runs(key, 8))} | {f(seed_spread(key, 8))} | {f(spread(key, 8))} |")
+    return "\n".join(out) + "\n"
+
+
+if __name__ == "__main__":
+    print(markdown())
