@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_PIXEL = 48 + 96 + 36   # PCGStep1 + PCGStep2 + PCGStep3 of the reference formulation
 # what iw_pcgIter2 has to move per pixel per launch, float, Gauss-Newton: p_{k-1} 12 + p_{k-2} 12 in (r is rebuilt from them),
 # p_k 12 out, angle 4, flags 1 = 41; every second launch additionally delta 12 in / 12 out = 24 -> 12 on average; general UrShape: + U 8 + M_a 4
-MODEL_BYTES_PER_PIXEL = {"lattice": 41 + 12, "general": 41 + 12 + 8 + 4}      # general UrShape: + U 8 + M_a 4 (M_O from the flag byte, round 3)
+MODEL_BYTES_PER_PIXEL = {"lattice": 41 + 12, "general": 41 + 12 + 8}      # general UrShape: + U 8 (M_O from the flag byte; M_a rebuilt from the pairs the stencil evaluates, round 4)
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 KERNEL_SOURCES = ["opt_amd/csrc/energy_image_warping.hip", "opt_amd/csrc/iw_device.h", "opt_amd/csrc/iw_onchip.h", "opt_amd/csrc/solver.hip", "opt_amd/csrc/common.h", "opt_amd/csrc/energy.h", "opt_amd/build.py"]
 

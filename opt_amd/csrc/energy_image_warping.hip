@@ -62,7 +62,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (ocS.slots) { (void)hipFree(ocS.slots); (void)hipFree(ocS.groupSlots); (void)hipFree(ocS.inbox); (void)hipFree(ocS.bad); (void)hipHostFree(ocS.hostErr); }
         (void)hipHostFree(hNotLattice); (void)hipEventDestroy(bindEvent);
         for (T* b : ring) if (b) (void)hipFree(b);
-        (void)hipFree(A.flags); (void)hipFree(A.cs); if (mc) (void)hipFree(mc); if (alphaSlots) (void)hipFree(alphaSlots); (void)hipFree(dNotLattice);
+        (void)hipFree(A.flags); (void)hipFree(A.cs); if (alphaSlots) (void)hipFree(alphaSlots); (void)hipFree(dNotLattice);
     }
     int flatGrid(long n) const { return (int)std::max<long>(1, std::min<long>((n + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
 
@@ -136,19 +136,16 @@ struct ImageWarpingOps : EnergyOps<T> {
     bool fastGN() const {      // single GPU, vectors below 4 GiB (buffer-descriptor offsets are 32-bit): the marching PCGInit1 and the single-kernel / on-chip loops
         return !this->slab.active && (unsigned long long)A.W * A.H * 3ull * sizeof(T) < (1ull << 32);
     }
-    T *initR = nullptr, *initP = nullptr; Reduction* initRed = nullptr; bool initHint = false, mcFresh = false, initPending = false, deltaZero = false;
-    T* mc = nullptr;
+    T *initR = nullptr, *initP = nullptr; Reduction* initRed = nullptr; bool initHint = false, initPending = false, deltaZero = false;
     void launchJtf(bool lat, LaunchCtx& ctx) {
         ScopedKernel k(ctx, "PCGInit1");
         int gx, gy, rpg; marchGrid(A.yEnd - A.yBegin, gx, gy, rpg);
-        if (!lat && !mc) HIP_CHECK(hipMalloc((void**)&mc, (size_t)A.W * A.H * sizeof(T)));
-        if (lat) iw_jtfMarch<T, true><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, nullptr, initRed->partials, rpg, gx, gy);
-        else iw_jtfMarch<T, false><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, mc, initRed->partials, rpg, gx, gy);
+        if (lat) iw_jtfMarch<T, true><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, initRed->partials, rpg, gx, gy);
+        else iw_jtfMarch<T, false><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, initRed->partials, rpg, gx, gy);
         initRed->n = gx * gy;
-        mcFresh = !lat;
     }
     // PCGInit1 + PCGInit1_Finish for the Gauss-Newton loops: r = -J^T F, p = M r, partial sums of r.p -- one marching kernel (no cos/sin table, no diag /
-    // preconditioner vectors: the loops take M from the flag byte or from `mc`).  delta = 0 (solver.t:389) is not written: the first launch that updates delta takes
+    // preconditioner vectors: the loops take M from the flag byte and, for a general UrShape, from the pairs they evaluate).  delta = 0 (solver.t:389) is not written: the first launch that updates delta takes
     // it as 0 (IterK::deltaZero), finishUpdate / pcgFinish do the same if no launch did.  The kernel variant follows the lattice verdict of the previous bind
     // while this bind's is still in flight; the loops check it before their first launch.
     bool evalJTFInit(T* r, T* p, T* /*delta*/, long /*nPad*/, Reduction& aNum0, LaunchCtx& ctx) override {
@@ -242,7 +239,6 @@ struct ImageWarpingOps : EnergyOps<T> {
     void beginLoop(LaunchCtx& ctx) {
         resolveLattice();
         if (initPending) { if (initHint && !lattice) launchJtf(false, ctx); initHint = lattice; initPending = false; }
-        else mcFresh = false;      // r, M came from the generic PCGInit1: `mc` (if any) is stale
     }
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
         // A p is recomputed, not stored, so a slab needs two ghost rows (one for each stencil evaluation); with one the solver runs the three-kernel loop.
@@ -268,17 +264,11 @@ struct ImageWarpingOps : EnergyOps<T> {
         }
         IWArgs<T> Ax = A;                   // what the kernel sees: the rows it updates
         Ax.yBegin = std::max(0, A.yBegin - ext); Ax.yEnd = std::min(A.H, A.yEnd + ext);
-        const int pre = lattice ? 3 : lmLoop ? 1 : 2;
         if (a.first) { iterFlip = 0; iterIndex = 0; }      // every linear solve starts top-down, so a solve is reproducible whatever ran before it
         const int blk = iterBlock(lattice, lmLoop), L = (lmLoop ? 2 : 0) + (lattice ? 1 : 0);
         if (occIter[L] == 0) {
             HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occIter[L], iterKernel(lattice, lmLoop, false, 0), blk, 0));
             occIter[L] = std::max(1, std::min(occIter[L], 8));
-        }
-        if (a.first && pre == 2 && !mcFresh) {      // general UrShape behind a generic PCGInit1: M_a out of the solver's 3-channel preconditioner
-            if (!mc) HIP_CHECK(hipMalloc((void**)&mc, (size_t)A.W * A.H * sizeof(T)));
-            ScopedKernel k(ctx, "compactPreconditioner");
-            iw_compactM<T><<<flatGrid((long)A.W * A.H), kBlock, 0, ctx.stream>>>(a.pre, mc, (long)A.W * A.H);
         }
         const int gx = divUp(A.W, (blk / kWave) * kSpan2);
         int gy, rowsPerGroup;
@@ -304,7 +294,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         deferredTerm = gn && iterIndex >= 1 && iterIndex % 2 == 1;            // after an odd launch alpha_{k-1} p_{k-1} is still owed (pcgFinish / finishUpdate)
         IterK<T> K{};
         K.rOld = rOldPtr; K.pOld = pOldPtr; K.rNew = a.rNew; K.pNew = pNewPtr; K.delta = a.delta; K.deltaOut = a.deltaOut ? a.deltaOut : a.delta;
-        K.pre = a.pre; K.mc = pre == 2 ? mc : nullptr; K.first = a.first; K.deltaMode = deltaMode; K.alphaIn = alphaIn; K.alphaOut = alphaOut; K.rfree = rfreeFlag;
+        K.pre = a.pre; K.first = a.first; K.deltaMode = deltaMode; K.alphaIn = alphaIn; K.alphaOut = alphaOut; K.rfree = rfreeFlag;
         K.CtC = a.CtC; K.b = a.b; K.q = a.q ? a.q->partials : nullptr; K.qTag = a.qTag; K.afterReset = a.afterReset;
         K.betaNum = a.betaNum.partials; K.nBetaNum = a.betaNum.n; K.betaDen = a.betaDen.partials; K.nBetaDen = a.betaDen.n;
         K.lmRadius = a.lmRadius; K.lmMin = a.lmMinDiag; K.lmMax = a.lmMaxDiag;

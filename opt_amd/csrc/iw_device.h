@@ -52,8 +52,10 @@ __device__ __forceinline__ void iw_pairQ(const Q<T>& c, const Q<T>& n, T& ax, T&
 #define IW_SHARE_PAIRS 1
 #endif
 template <class T> struct PairOut { T dx, dy, tn; };      // (jc - jn).x, (jc - jn).y, Dn . jn
+// m2 (general UrShape only): receives this pair's term of diag(J^T J) of the Angle unknown -- (w D_x)^2 + (w D_y)^2, iw_evalJTF's `Pa` -- for the centre ([0]) and for
+// the neighbour ([1]); summed over a pixel's four pairs that is what its Jacobi preconditioner M_a inverts, so the iteration kernel needs no M_a from memory.
 template <int DX, int DY, bool LATTICE, class T>
-__device__ __forceinline__ PairOut<T> iw_pairFull(const Q<T>& c, const Q<T>& n, T& ax, T& ay, T& aa) {
+__device__ __forceinline__ PairOut<T> iw_pairFull(const Q<T>& c, const Q<T>& n, T& ax, T& ay, T& aa, T* m2 = nullptr, T w = T(0)) {
     T Dcx, Dcy, Dnx, Dny;
     if (LATTICE) {       // U_c - U_n = -(DX, DY)
         Dcx = DX ? T(DX) * c.s : T(DY) * c.c;   Dcy = DX ? T(-DX) * c.c : T(DY) * c.s;
@@ -62,6 +64,7 @@ __device__ __forceinline__ PairOut<T> iw_pairFull(const Q<T>& c, const Q<T>& n, 
         const T ux = c.ux - n.ux, uy = c.uy - n.uy;
         Dcx = -c.s * ux - c.c * uy; Dcy = c.c * ux - c.s * uy;
         Dnx = n.s * ux + n.c * uy;  Dny = -n.c * ux + n.s * uy;
+        if (m2) { m2[0] = (w * Dcx) * (w * Dcx) + (w * Dcy) * (w * Dcy); m2[1] = (w * Dnx) * (w * Dnx) + (w * Dny) * (w * Dny); }
     }
     const T dx = c.ox - n.ox, dy = c.oy - n.oy;
     const T jcx = dx - Dcx * c.a, jcy = dy - Dcy * c.a;

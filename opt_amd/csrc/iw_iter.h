@@ -8,7 +8,7 @@
 //   * Gauss-Newton keeps no residual vector either: p_{k-1} = M r_{k-1} + beta_{k-2} p_{k-2} determines r_{k-1}, so the state is a ring of three p buffers
 //     (IterK::rfree); the first two launches of a solve read the solver's true r_0;
 //   * Mask / Constraints are one flag byte, cos / sin come from the 4-byte angle, on a unit lattice U is folded into the arithmetic and the Jacobi
-//     preconditioner is a 15-entry table indexed by the flag byte (PRE == 3); any other UrShape streams U and M_a (PRE == 2);
+//     preconditioner is a 15-entry table indexed by the flag byte (PRE == 3); any other UrShape streams U and rebuilds M_a from the pairs it evaluates anyway (PRE == 2);
 //   * delta is touched every second launch (two terms at once; p_{k-2} is kept in registers from its load).
 // Structure: a workgroup owns a column strip and a contiguous range of rows; a lane keeps three rows of p_{k-1} and three of p_k of its column in registers
 // (trip y turns the freshly loaded row y+2 into Ap_{k-1}(y+1), r_k, p_k(y+1), then Ap_k(y)); horizontal neighbours are whole-wave DPP shifts (a wave covers
@@ -38,7 +38,6 @@ template <class T>
 struct IterK {             // kernel argument block
     const T *rOld, *pOld; T *rNew, *pNew; T* delta; T* deltaOut;      // deltaOut == delta: in place
     const T* pre;          // the solver's 3-channel Jacobi preconditioner (PRE == 1)
-    const T* mc;           // compact preconditioner: M_a per pixel (PRE == 2; M_O comes from the flag byte)
     int first;             // first launch of a linear solve: alpha = beta = 0, r as given
     // deltaMode 0: delta += alpha_{k-1} p_{k-1} in every launch (LM).  Paired (Gauss-Newton): 2 = this launch leaves delta alone, 1 = this launch applies the two
     // pending terms alpha_{k-2} p_{k-2} + alpha_{k-1} p_{k-1} in the reference's order -- 24 B/px every second launch instead of every launch.
@@ -55,7 +54,7 @@ struct IterK {             // kernel argument block
 };
 template <class T>
 struct IterBufs {          // descriptors of the arrays touched row by row, and the per-lane parts of the offsets
-    __amdgpu_buffer_rsrc_t rOld, pOld, pNew, rNew, delta, deltaOut, angle, flags, mc, pre, ctc, b, ur;
+    __amdgpu_buffer_rsrc_t rOld, pOld, pNew, rNew, delta, deltaOut, angle, flags, pre, ctc, b, ur;
     unsigned x2, x1, x0;   // x * sizeof(V2<T>), x * sizeof(T), x  (x clamped into the row)
     unsigned aPart;        // 2 * N * sizeof(T): where the Angle part of a solver vector starts
 };
@@ -70,8 +69,7 @@ __device__ __forceinline__ IterRaw<T> iw_iterLoad(const IWArgs<T>& A, const Iter
     r.f = __builtin_amdgcn_raw_buffer_load_b8(B.flags, (int)B.x0, (int)row, 0);
     r.ro = bufLd2(B.rOld, B.x2, s2, tag); r.ra = bufLd1(B.rOld, B.x1, s1a, tag);
     r.po = bufLd2(B.pOld, B.x2, s2, tag); r.pa = bufLd1(B.pOld, B.x1, s1a, tag);
-    if (PRE == 2) { r.mo = V2<T>{0, 0}; r.ma = bufLd1(B.mc, B.x1, s1, tag); }
-    else if (PRE == 1) { r.mo = bufLd2(B.pre, B.x2, s2, tag); r.ma = bufLd1(B.pre, B.x1, s1a, tag); }
+    if (PRE == 1) { r.mo = bufLd2(B.pre, B.x2, s2, tag); r.ma = bufLd1(B.pre, B.x1, s1a, tag); }
     else { r.mo = V2<T>{0, 0}; r.ma = 0; }
     if (LMV) { r.co = bufLd2(B.ctc, B.x2, s2, tag); r.ca = bufLd1(B.ctc, B.x1, s1a, tag); } else { r.co = V2<T>{0, 0}; r.ca = 0; }
     r.ang = bufLd1(B.angle, B.x1, s1, tag);
@@ -124,7 +122,7 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), 1) void iw_p
         const unsigned xc = (unsigned)min(max(x, 0), A.W - 1);
         Bf.x2 = xc * (unsigned)sizeof(V2<T>); Bf.x1 = xc * (unsigned)sizeof(T); Bf.x0 = xc; Bf.aPart = (unsigned)(2 * N * (long)sizeof(T));
         Bf.rOld = iw_rsrc(K.rOld); Bf.pOld = iw_rsrc(K.pOld); Bf.pNew = iw_rsrc(K.pNew); Bf.rNew = iw_rsrc(K.rNew); Bf.delta = iw_rsrc(K.delta); Bf.deltaOut = iw_rsrc(K.deltaOut);
-        Bf.angle = iw_rsrc(A.Angle); Bf.flags = iw_rsrc(A.flags); Bf.mc = iw_rsrc(K.mc); Bf.pre = iw_rsrc(K.pre); Bf.ctc = iw_rsrc(K.CtC); Bf.b = iw_rsrc(K.b); Bf.ur = iw_rsrc(A.UrShape);
+        Bf.angle = iw_rsrc(A.Angle); Bf.flags = iw_rsrc(A.flags); Bf.pre = iw_rsrc(K.pre); Bf.ctc = iw_rsrc(K.CtC); Bf.b = iw_rsrc(K.b); Bf.ur = iw_rsrc(A.UrShape);
     }
     auto loadRow = [&](int y) { return iw_iterLoad<T, LATTICE, PRE, LM && PRE != 3, FLIP>(A, Bf, xok, y); };
     const IterRaw<T> raw0 = loadRow(yb - 2), raw1 = loadRow(yb - 1);
@@ -202,9 +200,9 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), 1) void iw_p
             o.mx = o.my = mTab[io]; o.ma = mTab[10 + cnt];
             if (LM) { o.cx = o.cy = cTab[io]; o.ca = cTab[10 + cnt]; }
             else if (reconR) { ix = iy = iTab[io]; ia = iTab[10 + cnt]; }
-        } else if (PRE == 2) {
-            o.mx = o.my = mTab[io]; o.ma = w.ma;
-            if (!LM && reconR) { ix = iy = iTab[io]; ia = T(1) / o.ma; }
+        } else if (PRE == 2) {      // M_a follows from the pairs of the row's first stencil evaluation (trip): until then the Angle part of a rebuilt r stays unscaled
+            o.mx = o.my = mTab[io]; o.ma = 0;
+            if (!LM && reconR) { ix = iy = iTab[io]; ia = T(1); }
         } else {
             o.mx = w.mo.x; o.my = w.mo.y; o.ma = w.ma;
             if (!LM && reconR) { ix = T(1) / o.mx; iy = T(1) / o.my; ia = T(1) / o.ma; }
@@ -217,16 +215,26 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), 1) void iw_p
     // J^T J at centre c; prev / next are the rows before / after it in sweep order.  Each pair of residuals is formed ONCE (iw_device.h): the right-hand pair of
     // lane x is the left-hand pair of lane x + 1 (three DPP moves), the pair towards the next row of the march is the pair towards the previous row one trip later.
     // `vert`: in, what the previous trip's evaluation of this stream left for the pair (prev, c); out, the same for (c, next)
-    auto applyA = [&](const Q<T>& c, const Q<T>& lf, const Q<T>& rt, const Q<T>& prev, const Q<T>& next, PairOut<T>& vert, T& ox, T& oy, T& oa) {
+    // wantM (PRE == 2, the p_{k-1} stream): pa receives diag(J^T J) of the Angle unknown -- the four pairs' terms in iw_evalJTF's order (right, left, image row y+1, y-1), the
+    // left and the inherited vertical one taken from the neighbour's side of the pair (vertM: in, the previous trip's; out, this trip's)
+    auto applyA = [&](const Q<T>& c, const Q<T>& lf, const Q<T>& rt, const Q<T>& prev, const Q<T>& next, PairOut<T>& vert, T& ox, T& oy, T& oa, bool wantM, T& vertM, T& pa) {
         T ax = 0, ay = 0, aa = 0;
-        const PairOut<T> hr = iw_pairFull<1, 0, LATTICE>(c, rt, ax, ay, aa);
+        T mh[2] = {0, 0}, mv[2] = {0, 0};
+        const PairOut<T> hr = iw_pairFull<1, 0, LATTICE>(c, rt, ax, ay, aa, wantM ? mh : nullptr, A.w_reg);
         PairOut<T> hl; hl.dx = dppShift<true>(hr.dx); hl.dy = dppShift<true>(hr.dy); hl.tn = dppShift<true>(hr.tn);
+        const T mhl = wantM ? dppShift<true>(mh[1]) : T(0);
         iw_pairInherited(hl, lf.on, ax, ay, aa);
-        if (!FLIP) { const PairOut<T> vn = iw_pairFull<0, 1, LATTICE>(c, next, ax, ay, aa); iw_pairInherited(vert, prev.on, ax, ay, aa); vert = vn; }
-        else { iw_pairInherited(vert, prev.on, ax, ay, aa); vert = iw_pairFull<0, -1, LATTICE>(c, next, ax, ay, aa); }      // (image rows y+1, y-1 in that order in both directions)
+        if (!FLIP) {
+            const PairOut<T> vn = iw_pairFull<0, 1, LATTICE>(c, next, ax, ay, aa, wantM ? mv : nullptr, A.w_reg); iw_pairInherited(vert, prev.on, ax, ay, aa); vert = vn;
+            if (wantM) { T t = rt.on * mh[0]; t += lf.on * mhl; t += next.on * mv[0]; t += prev.on * vertM; pa = t; vertM = mv[1]; }
+        } else {      // (image rows y+1, y-1 in that order in both directions)
+            iw_pairInherited(vert, prev.on, ax, ay, aa); vert = iw_pairFull<0, -1, LATTICE>(c, next, ax, ay, aa, wantM ? mv : nullptr, A.w_reg);
+            if (wantM) { T t = rt.on * mh[0]; t += lf.on * mhl; t += prev.on * vertM; t += next.on * mv[0]; pa = t; vertM = mv[1]; }
+        }
         ox = c.on * (w2 * ax + c.fw * c.ox); oy = c.on * (w2 * ay + c.fw * c.oy); oa = c.on * (w2 * aa);
     };
     PairOut<T> vOld{0, 0, 0}, vNew{0, 0, 0};      // the vertical pairs the two stencil evaluations of a trip inherit (p_{k-1} rows / p_k rows)
+    T vOldM = 0, unusedM = 0;                     // ... and, for M_a, the neighbour-side term of the p_{k-1} stream's vertical pair
     // The delta of the row a trip updates (y + 1) is requested one trip ahead, before that trip's prefetch of a raw row: by the time it is used a whole trip
     // has passed and the wait leaves the younger requests in flight, where a request at the point of use is the newest one and its wait (vmcnt(0)) drains
     // the whole queue once per row.  Every launch of the LM loop and the even launches of the Gauss-Newton steady state (MODE 2) update delta in every
@@ -253,11 +261,17 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), 1) void iw_p
         dppShiftConst<false, LATTICE>(oB.q, nC.rt);
         Q<T> lf = nC.lf, rt = nC.rt;
         dppShiftVec<false>(oB.q, rt);
-        T ax, ay, aa;
-        applyA(oB.q, lf, rt, oA.q, oC.q, vOld, ax, ay, aa);                             // Step1 of iteration k-1 again
+        T ax, ay, aa, paB = 0;
+        applyA(oB.q, lf, rt, oA.q, oC.q, vOld, ax, ay, aa, PRE == 2, vOldM, paB);       // Step1 of iteration k-1 again
         if (LM) { ax += oB.cx * oB.q.ox; ay += oB.cy * oB.q.oy; aa += oB.ca * oB.q.a; }                                                       // + CtC p (o.t:2076-2082)
-        const T rx = keepR ? oB.rx : oB.rx - alpha * ax, ry = keepR ? oB.ry : oB.ry - alpha * ay, ra = keepR ? oB.ra : oB.ra - alpha * aa;   // Step2
-        nC.mx = oB.mx; nC.my = oB.my; nC.ma = oB.ma;
+        T maB = oB.ma, raB = oB.ra;
+        if (PRE == 2) {      // guardedInvert(diag J^T J) of the Angle unknown (solverGPUGaussNewton.t:323-332; iw_jtfMarch's mA)
+            const T sq = T(1) + sqrt(paB), ia = sq * sq;
+            maB = T(1) / ia;
+            if (!LM && reconR) raB = oB.ra * ia;      // the rebuilt residual's Angle part, scaled now that 1 / M_a is known
+        }
+        const T rx = keepR ? oB.rx : oB.rx - alpha * ax, ry = keepR ? oB.ry : oB.ry - alpha * ay, ra = keepR ? raB : raB - alpha * aa;   // Step2
+        nC.mx = oB.mx; nC.my = oB.my; nC.ma = maB;
         nC.cx = oB.cx; nC.cy = oB.cy; nC.ca = oB.ca;
         nC.rx = rx; nC.ry = ry; nC.ra = ra;
         const T zx = nC.mx * rx, zy = nC.my * ry, za = nC.ma * ra;
@@ -293,7 +307,7 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), 1) void iw_p
         Q<T> l2 = nB.lf, r2 = nB.rt;
         dppShiftVec<false>(nB.q, r2);
         T ox, oy, oa;
-        applyA(nB.q, l2, r2, nA.q, nC.q, vNew, ox, oy, oa);                             // Step1 of iteration k
+        applyA(nB.q, l2, r2, nA.q, nC.q, vNew, ox, oy, oa, false, unusedM, unusedM);     // Step1 of iteration k
         if (LM) { ox += nB.cx * nB.q.ox; oy += nB.cy * nB.q.oy; oa += nB.ca * nB.q.a; }
         if (live && writer && y >= yb && phys(y) >= K.ownBegin && phys(y) < K.ownEnd) {
             accDen += (double)(nB.q.ox * ox + nB.q.oy * oy + nB.q.a * oa);
@@ -311,7 +325,7 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), 1) void iw_p
     NewRow<T> n0{}, n1{}, n2{};
     makeOld(raw0, o0);
     makeOld(raw1, o1);
-    { T t0 = 0, t1 = 0, t2 = 0; vOld = iw_pairFull<0, FLIP ? -1 : 1, LATTICE>(o0.q, o1.q, t0, t1, t2); }      // the pair (row yb-2, row yb-1) the first trip inherits
+    { T t0 = 0, t1 = 0, t2 = 0, m0[2] = {0, 0}; vOld = iw_pairFull<0, FLIP ? -1 : 1, LATTICE>(o0.q, o1.q, t0, t1, t2, PRE == 2 ? m0 : nullptr, A.w_reg); vOldM = m0[1]; }      // the pair (row yb-2, row yb-1) the first trip inherits
     DeltaPre dlA = loadDelta(yb - 1), dlB = dlA, dlC = dlA;      // (trip yb - 2 updates no row; its delta is a dummy)
     // trips y = yb-2 .. ye-1 (the first two only build p_k(yb-1), p_k(yb)); three per pass, no branch around a load; the barrier keeps the strip's waves on the same rows
     for (int y = yb - 2; y < ye; y += 3) {

@@ -3,7 +3,7 @@
 //   one thread per pixel (row slabs, probes, LM):  iw_flags, iw_cossin, iw_cost, iw_evalJTF, iw_checkLattice, iw_modelCost, iw_zeroGhost
 //   row-marching (single GPU):                      iw_bindMarch (flags + unit-lattice verdict), iw_jtfMarch (PCGInit1 + PCGInit1_Finish), iw_costMarch
 //   row-marching stencil:                           iw_applyJTJ (PCGStep1, optionally with the previous PCGStep3 fused in)
-//   flat passes:                                    iw_finishUpdate (last delta terms + PCGLinearUpdate), iw_axpyDeferred, iw_compactM
+//   flat passes:                                    iw_finishUpdate (last delta terms + PCGLinearUpdate), iw_axpyDeferred
 #pragma once
 #include "iw_device.h"
 
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(kBlock) void iw_bindMarch(IWArgs<T> A, int* __restr
 
 // r = -J^T F, p = guardedInvert(diag J^T J) r, partial sums of r.p; LATTICE = false additionally writes the compact preconditioner {M_O, M_a}
 template <class T, bool LATTICE>
-__global__ __launch_bounds__(kBlock) void iw_jtfMarch(IWArgs<T> A, T* __restrict__ r, T* __restrict__ p, T* __restrict__ mc, double* __restrict__ partials,
+__global__ __launch_bounds__(kBlock) void iw_jtfMarch(IWArgs<T> A, T* __restrict__ r, T* __restrict__ p, double* __restrict__ partials,
                                                       int rowsPerGroup, int gx, int gy) {
     __shared__ double scratch[kBlock / kWave + 1];
     const MarchGeo g = marchGeo(A, rowsPerGroup, gx, gy);
@@ -441,7 +441,6 @@ __global__ __launch_bounds__(kBlock) void iw_jtfMarch(IWArgs<T> A, T* __restrict
             const T p0 = mO * r0, p1 = mO * r1, p2 = mA * r2;
             rO[i] = V2<T>{r0, r1}; ra[i] = r2;
             pO[i] = V2<T>{p0, p1}; pa[i] = p2;
-            if (!LATTICE) mc[i] = mA;      // the compact preconditioner of the general kernel: M_a only (M_O comes from the flag byte, see iw_pcgIter2)
             acc += (double)(r0 * p0) + (double)(r1 * p1) + (double)(r2 * p2);
         }
         up = cur; cur = dn; ccCur = rdn.cc;
@@ -537,11 +536,6 @@ __global__ __launch_bounds__(kBlock) void iw_axpyDeferred(T* __restrict__ delta,
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) delta[i] = delta[i] + a * p[i];
 }
 
-// M_a per pixel from the solver's 3-channel preconditioner (the Angle part of the vector; only there so that `mc` has one meaning whoever fills it)
-template <class T>
-__global__ __launch_bounds__(kBlock) void iw_compactM(const T* __restrict__ pre, T* __restrict__ mc, long N) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) mc[i] = pre[2 * N + i];
-}
 // Is UrShape a unit lattice (U(x,y) - U(x+1,y) == (-1,0) and U(x,y) - U(x,y+1) == (0,-1) exactly)?  The reference
 // example always passes the pixel grid itself (examples/image_warping/src/CombinedSolver.h:161-172); any other input
 // clears the flag and the general kernel runs.  Checked at every bind because the caller may swap buffers.

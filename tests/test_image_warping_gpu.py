@@ -259,6 +259,28 @@ def test_switches_keep_the_result(monkeypatch, jitter, liters):
         assert rel_err(got[1], ref[1]) < 1e-8, sw
 
 
+@pytest.mark.parametrize("double,liters", [(True, 1), (True, 2), (True, 3), (True, 9), (False, 8)])
+def test_half_lattice_image_takes_the_general_kernel(oracle_lib, double, liters):
+    """UrShape is the unit lattice on the upper half of the image and jittered below: the lattice verdict is per image, so the general kernel runs everywhere -- with
+    M_a rebuilt per pixel from the pairs its stencil evaluates (no preconditioner stream), on lattice and off-lattice rows alike, masks and sweep directions included."""
+    P = wl.image_warping(197, 120, double=double, random_state=31, mask_fraction=0.07, perturb=0.3)
+    rng = np.random.default_rng(5)
+    P.params[2][60:] += (0.2 * rng.standard_normal(P.params[2][60:].shape)).astype(P.params[2].dtype)
+    o = oracle_solver(oracle_lib, P, nIterations=2, lIterations=liters)
+    g = hip_solver(P, nIterations=2, lIterations=liters, timing=True)
+    Pref = P.clone(); dev = api.to_device(P)
+    o.init(Pref.params); g.init(dev)
+    while True:
+        a, b = o.step(Pref.params), g.step(dev)
+        assert a == b
+        assert abs(g.cost() - o.cost()) <= (1e-10 if double else 1e-5) * abs(o.cost())
+        if not a:
+            break
+    assert "PCGIteration" in g.kernel_timings()
+    assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < (1e-9 if double else 2e-5)
+    g.close(); o.close()
+
+
 def test_urshape_leaves_the_lattice_between_two_steps(oracle_lib):
     """The marching PCGInit1 of step n runs on the lattice verdict of step n - 1's bind while its own bind's verdict is in flight; a caller that moves UrShape off the
     unit lattice between two Opt_ProblemStep calls (in place, same buffers) makes that guess wrong: the lattice variant has to be redone as the general one before the first
