@@ -72,11 +72,10 @@ struct MarchK {            // kernel argument block
     double *aNum, *aDen, *s2, *s3;
 };
 
-template <class T, int C> constexpr int marchBlock() { return C * (int)sizeof(T) >= 32 ? 256 : 256; }
 
-template <class T, class Op, bool FLIP>
-__global__ __launch_bounds__((marchBlock<T, Op::C>())) void march_pcgIter(Op op, MarchK<T> K, int rowsPerGroup, int gx) {
-    constexpr int C = Op::C, kBlk = marchBlock<T, C>(), kStripW = (kBlk / kWave) * kMarchSpan;
+template <class T, class Op, bool FLIP, int kBlk>
+__global__ __launch_bounds__(kBlk) void march_pcgIter(Op op, MarchK<T> K, int rowsPerGroup, int gx) {
+    constexpr int C = Op::C, kStripW = (kBlk / kWave) * kMarchSpan;
     using Vec = MVec<T, C>;
     __shared__ double scratch[4 * (kBlk / kWave + 1)];
     const int bx = blockIdx.x % gx, by = blockIdx.x / gx;
@@ -206,19 +205,28 @@ __global__ __launch_bounds__(kBlock) void march_axpyDeferred(T* __restrict__ del
 template <class T>
 struct MarchLoop {
     T* ring[3] = {nullptr, nullptr, nullptr}; const T* r0Ptr = nullptr; T* alphaSlots = nullptr;
-    int iterIndex = 0, flip = 0, occ = 0, forceRows = 0; bool deferredTerm = false;
-    MarchLoop() { if (const char* e = getenv("OPT_AMD_ITER_ROWS")) forceRows = atoi(e); }
+    int iterIndex = 0, flip = 0, occ = 0, forceRows = 0, forceBlock = 0; bool deferredTerm = false;
+    MarchLoop() { if (const char* e = getenv("OPT_AMD_ITER_ROWS")) forceRows = atoi(e); if (const char* e = getenv("OPT_AMD_MARCH_BLOCK")) forceBlock = atoi(e); }
     ~MarchLoop() { for (T* b : ring) if (b) (void)hipFree(b); if (alphaSlots) (void)hipFree(alphaSlots); }
     template <class Op>
     bool launch(const Op& op, int W, int H, const uint8_t* flags, int cus, const PcgIterArgs<T>& a, LaunchCtx& ctx) {
-        constexpr int C = Op::C, blk = marchBlock<T, C>();
+        // 16-byte pixels leave room for 3 waves per SIMD in 768-thread workgroups (12 column strips side by side: fewer, fatter workgroups and a quarter of the partial
+        // sums the next prologue has to add); 32-byte pixels (double4: 206 VGPRs) run 256 threads
+        const int blk = forceBlock ? forceBlock : (Op::C * sizeof(T) <= 16 ? 768 : 256);
+        if (blk == 768) return launchB<Op, 768>(op, W, H, flags, cus, a, ctx);
+        if (blk == 512) return launchB<Op, 512>(op, W, H, flags, cus, a, ctx);
+        return launchB<Op, 256>(op, W, H, flags, cus, a, ctx);
+    }
+    template <class Op, int blk>
+    bool launchB(const Op& op, int W, int H, const uint8_t* flags, int cus, const PcgIterArgs<T>& a, LaunchCtx& ctx) {
+        constexpr int C = Op::C;
         if ((unsigned long long)W * H * C * sizeof(T) >= (1ull << 32)) return false;      // 32-bit buffer offsets
         const size_t bytes = ((size_t)W * H * C + 3) / 4 * 4 * sizeof(T);                 // padded like the solver's vectors: its flat kernels read whole 16-byte packs of the last p
         for (int j = 0; j < 3; ++j) if (!ring[j]) { HIP_CHECK(hipMalloc((void**)&ring[j], bytes)); HIP_CHECK(hipMemsetAsync(ring[j], 0, bytes, ctx.stream)); }
         if (!alphaSlots) { HIP_CHECK(hipMalloc((void**)&alphaSlots, 4 * sizeof(T))); HIP_CHECK(hipMemsetAsync(alphaSlots, 0, 4 * sizeof(T), ctx.stream)); }   // [0,1] alpha, [2,3] beta, ping-pong
         if (a.first) { iterIndex = 0; flip = 0; r0Ptr = a.rOld; }      // the solver swaps its r buffers after every launch; this one keeps r_0 until launch 1 has read it
         if (occ == 0) {
-            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, march_pcgIter<T, Op, false>, blk, 0));
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, march_pcgIter<T, Op, false, blk>, blk, 0));
             occ = std::max(1, std::min(occ, 8));
         }
         const int k = iterIndex;
@@ -242,8 +250,8 @@ struct MarchLoop {
         gy = divUp(H, rowsPerGroup);
         {
             ScopedKernel sk(ctx, "PCGIteration");
-            if (flip) march_pcgIter<T, Op, true><<<gx * gy, blk, 0, ctx.stream>>>(op, K, rowsPerGroup, gx);
-            else march_pcgIter<T, Op, false><<<gx * gy, blk, 0, ctx.stream>>>(op, K, rowsPerGroup, gx);
+            if (flip) march_pcgIter<T, Op, true, blk><<<gx * gy, blk, 0, ctx.stream>>>(op, K, rowsPerGroup, gx);
+            else march_pcgIter<T, Op, false, blk><<<gx * gy, blk, 0, ctx.stream>>>(op, K, rowsPerGroup, gx);
         }
         flip ^= 1;      // successive launches sweep top-down / bottom-up
         ++iterIndex;
