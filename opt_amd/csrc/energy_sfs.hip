@@ -32,6 +32,7 @@ struct SArgs {
     T w_p, w_s, w_g, f_x, f_y, u_x, u_y, L[9];
     const T* X; const T* D_i; const T* Im; const uint8_t* mR; const uint8_t* mC;
     T *B_I, *g0, *g1, *g2, *valid;     // ComputedArrays + gradient images
+    uint32_t* fl2;                     // fl | edgeMaskR << 8 | edgeMaskC << 16: one word per pixel for sfs_pcgMarch (one load, one register, one DPP move per neighbour)
     uint8_t* fl;                       // bit 0: D_i > 0 (the unknown is not excluded), bit 1: valid == 1 -- one byte for the marching iteration kernel instead of two doubles
     T* q;                              // 5 row values per pixel: [gh, gv, s0, s1, s2] planes
 };
@@ -87,7 +88,9 @@ __global__ __launch_bounds__(kBlock) void sfs_precompute(SArgs<T> A) {
             vl = v ? T(1) : T(0);
         }
         A.B_I[e] = bi; A.g0[e] = g0; A.g1[e] = g1; A.g2[e] = g2; A.valid[e] = vl;
-        A.fl[e] = (uint8_t)((Dself > T(0) ? 1 : 0) | (vl == T(1) ? 2 : 0));
+        const unsigned fl = (Dself > T(0) ? 1u : 0u) | (vl == T(1) ? 2u : 0u);
+        A.fl[e] = (uint8_t)fl;
+        A.fl2[e] = fl | ((unsigned)A.mR[e] << 8) | ((unsigned)A.mC[e] << 16);
     }
 }
 
@@ -467,20 +470,25 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
 // Trip Y stages row Y (PCGStep2 + PCGStep3 of the previous iteration: r_k, p_k, and for the rows the workgroup owns the stores of r_k, p_k, delta and the Q
 // sum), forms b(Y) = dB_I(., Y) . p_k, the five row values (J p_k)_r of the centres of row Y - 1, and the gather of row Y - 2 -- the expressions of
 // sfs_applyTiled in the same order, so the results are the tiled kernel's bit for bit.
-template <class T> struct SRaw { T r, p, ap, g0, g1, g2, ctc, dl, bb; int mr, mc, fl; };      // JTF mode: r = X, p = B_I, dl = D_i
+template <class T> struct SRaw { T r, p, ap, g0, g1, g2, ctc, dl, bb; int fb; };      // JTF mode: r = X, p = B_I, dl = D_i;  fb = SArgs::fl2 (flags and both edge masks in one word)
 template <class T> struct SRow {
     T v, rk;               // p_k (what J^T J is applied to), r_k        (JTF mode: X, B_I)
     T g0, g1, g2, ctc;     // dB_I / d{d0, d1, d2} (0 outside the image), CtC
-    int mr, mc;            // edge masks, 0 unless the pixel is an interior row centre
-    int ok, valid, ex;     // interior row centre; ... whose regularisation rows are on; D_i > 0 (the unknown is not excluded)
+    int bits;              // kEx: D_i > 0 (the unknown is not excluded); kValid: interior row centre whose regularisation rows are on; kOk: interior row centre;
+                           // bits 8-15 / 16-23: edge masks R / C, 0 unless the pixel is an interior row centre.  One register instead of five, one DPP move per neighbour.
 };
+constexpr int kSfsEx = 1, kSfsValid = 2, kSfsOk = 4;
+__device__ __forceinline__ int sfsMr(int b) { return (b >> 8) & 255; }
+__device__ __forceinline__ int sfsMc(int b) { return (b >> 16) & 255; }
 template <class T> struct SQ { T gh, gv, s0, s1, s2; };
 #ifndef SFS_MARCH_WAVES
 #define SFS_MARCH_WAVES 2
 #endif
 constexpr int kSfsMarchBlock = SFS_MARCH_WAVES * kWave, kSfsSpan = kWave - 4;
 #ifndef SFS_MARCH_MINWAVES
-#define SFS_MARCH_MINWAVES 1      // waves per SIMD the register allocation must leave room for (3: at most 168 VGPRs -- the double kernel then spills; A/B builds)
+#define SFS_MARCH_MINWAVES 1      // waves per SIMD the register allocation must leave room for.  Round 4 took the double LM kernel from 215 to 183 VGPRs (flags and both edge masks in one
+                                  // word, row coefficients in scalar registers, one accumulator for the two sums that never coexist); capped at 168 (3 waves per SIMD) it runs 45 us against 39:
+                                  // at 1024^2 the grid is sized by co-residency, more resident workgroups mean fewer rows each, and every workgroup stages 4 halo rows (see marchGrid)
 #endif
 // JTF = true turns the same march into PCGInit1 (sfs_rows<2> + sfs_gather<JTF> in one launch): the staged vector is X itself, b is the stored B_I instead of dB_I . v, the
 // row values are the residuals (in sfs_rows' association), the gather also sums the squared coefficients: out = -J^T F, diag = diag(J^T J).  No sums, no PCG state.
@@ -488,7 +496,7 @@ constexpr int kSfsMarchBlock = SFS_MARCH_WAVES * kWave, kSfsSpan = kWave - 4;
 // the clamped CtC, the LM preconditioner, b = r, p = M r and the partial sums of r . p -- the same expressions on the value the gather has just produced.
 template <class T> struct SFin { T *CtC, *SSq, *delta, *pre, *b, *p; T radius, minLm, maxLm; int saveSSq; double *dPart, *qPart; };
 template <class T, bool LM, bool JTF = false>
-__global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMarch(SArgs<T> A, T* __restrict__ out, const T* __restrict__ CtC, SIterK<T> K, int rowsPerGroup, int gx, int gy, int gyPerXcd,
+__global__ __launch_bounds__(kSfsMarchBlock, (JTF ? 1 : SFS_MARCH_MINWAVES)) void sfs_pcgMarch(SArgs<T> A, T* __restrict__ out, const T* __restrict__ CtC, SIterK<T> K, int rowsPerGroup, int gx, int gy, int gyPerXcd,
                                                                                    T* __restrict__ diag = nullptr, SFin<T> fin = SFin<T>{}) {
     __shared__ double scratch[6 * (kSfsMarchBlock / kWave + 1)];
     T alpha = 0, beta = 0;
@@ -519,15 +527,15 @@ __global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMar
     const bool writer = xin && lane >= 2 && lane < 2 + kSfsSpan;
     const int yb = idle ? A.H : by * rowsPerGroup, ye = idle ? A.H : min(yb + rowsPerGroup, A.H);
     const int xc = min(max(x, 0), A.W - 1);
-    const T cxc = coefK(A, 0, x, 0), cxl = coefK(A, 0, x - 1, 0), cxr = coefK(A, 0, x + 1, 0);      // P(u) coefficients of this column and its neighbours
-    double acc = 0, accNum = 0, acc2 = 0, acc3 = 0, accRR = 0, accQ = 0;
+    const T cxc = coefK(A, 0, x, 0);      // P(u) coefficient of this column; its neighbours' (the same expression at x - 1, x + 1) come from the neighbouring lanes where they are used
+    double acc = 0, accNum = 0, acc2 = 0, acc3 = 0, accX = 0;      // accX: sum r^2 in the first launch of a solve (which applies no Step2), the Q sum in the others
 
     // Clamped addresses, masked when staged.  What only the workgroup's own rows need -- CtC, delta, b -- is read from row 0 on the halo rows (the same few cache
     // lines every time: L1 / L2 hits, no branch around a load): a halo row (4 of 14-23 per workgroup) costs 51 B per pixel of memory traffic instead of 75.
     auto load = [&](int y) {
         SRaw<T> w;
         const long g = (long)min(max(y, 0), A.H - 1) * A.W + xc;
-        w.g0 = A.g0[g]; w.g1 = A.g1[g]; w.g2 = A.g2[g]; w.fl = A.fl[g]; w.mr = A.mR[g]; w.mc = A.mC[g];
+        w.g0 = A.g0[g]; w.g1 = A.g1[g]; w.g2 = A.g2[g]; w.fb = (int)A.fl2[g];
         const long go = (y >= yb && y < ye) ? g : (long)xc;
         if (JTF) { w.r = A.X[g]; w.p = A.B_I[g]; w.ap = 0; w.ctc = 0; w.dl = A.D_i[go]; w.bb = 0; return w; }
         w.r = K.rOld[g]; w.p = K.pOld[g]; w.ap = K.ApOld[g];
@@ -546,20 +554,24 @@ __global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMar
         n.v = pk; n.rk = rk;
         n.g0 = in ? w.g0 : T(0); n.g1 = in ? w.g1 : T(0); n.g2 = in ? w.g2 : T(0); if (!JTF) n.ctc = w.ctc;
         const bool ok = in && sfs_interior(A, x, y);
-        n.ok = ok; n.mr = ok ? w.mr : 0; n.mc = ok ? w.mc : 0; n.valid = ok && (w.fl & 2) != 0;
-        n.ex = in && (w.fl & 1) != 0;
+        n.bits = (in ? (w.fb & kSfsEx) : 0) | (ok ? ((w.fb & (kSfsValid | 0xffff00)) | kSfsOk) : 0);
         if (!JTF && writer && y >= yb && y < ye) {                                     // this workgroup's own rows
             const long g = (long)y * A.W + x;
             K.rNew[g] = rk; K.pNew[g] = pk;
             if (!keep) {                                                               // the rest of PCGStep2 of iteration k-1 for this pixel
                 const T dl = w.dl + alpha * w.p;                                       // solver.t:461-462
                 K.deltaOut[g] = dl;
-                if (LM) accQ += (double)(T(0.5) * (dl * (rk + w.bb)));                 // solver.t:483-485
+                if (LM) accX += (double)(T(0.5) * (dl * (rk + w.bb)));                 // solver.t:483-485
             }
         }
         return n;
     };
-    auto cyOf = [&](int y) { return coefK(A, 1, 0, y); };
+    // the row coefficient is wave-uniform: kept in scalar registers (three live values, six VGPRs less)
+    auto uni = [](T v) -> T {
+        if constexpr (sizeof(T) == 8) return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+        else return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+    };
+    auto cyOf = [&](int y) { return uni(coefK(A, 1, 0, y)); };
 
     // rows y+2, y+1, y, y-1 of the output row y; b = dB_I . v of rows y+2 / y+1; row values of rows y+1, y, y-1
     SRow<T> R1{}, R2{}, R3{};
@@ -576,13 +588,14 @@ __global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMar
         {
             const T right = dppShift<false>(b1);
             if (JTF) {      // sfs_rows<2>: w_g * ((B_I(c) - B_I(c + e)) * mask)
-                qn.gh = R1.ok ? A.w_g * ((b1 - right) * (T)R1.mr) : T(0);
-                qn.gv = R1.ok ? A.w_g * ((b1 - bY) * (T)R1.mc) : T(0);
+                qn.gh = (R1.bits & kSfsOk) ? A.w_g * ((b1 - right) * (T)sfsMr(R1.bits)) : T(0);
+                qn.gv = (R1.bits & kSfsOk) ? A.w_g * ((b1 - bY) * (T)sfsMc(R1.bits)) : T(0);
             } else {
-                qn.gh = R1.ok ? A.w_g * (T)R1.mr * (b1 - right) : T(0);
-                qn.gv = R1.ok ? A.w_g * (T)R1.mc * (b1 - bY) : T(0);
+                qn.gh = (R1.bits & kSfsOk) ? A.w_g * (T)sfsMr(R1.bits) * (b1 - right) : T(0);
+                qn.gv = (R1.bits & kSfsOk) ? A.w_g * (T)sfsMc(R1.bits) * (b1 - bY) : T(0);
             }
             const T v1l = dppShift<true>(R1.v), v1r = dppShift<false>(R1.v);
+            const T cxl = dppShift<true>(cxc), cxr = dppShift<false>(cxc);      // (lanes 0 / 63 read 0: they are halo lanes whose row values are never used)
             T js[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -590,10 +603,11 @@ __global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMar
                         cr = k == 0 ? cxr : k == 1 ? cy1 : T(1), cd = k == 0 ? cxc : k == 1 ? cyN : T(1);
                 T sj = 0;
                 sj += (T(4) * c0) * R1.v; sj += (T(-1) * cl) * v1l; sj += (T(-1) * cu) * R2.v; sj += (T(-1) * cr) * v1r; sj += (T(-1) * cd) * n.v;
-                js[k] = R1.valid ? A.w_s * sj : T(0);
+                js[k] = (R1.bits & kSfsValid) ? A.w_s * sj : T(0);
             }
             qn.s0 = js[0]; qn.s1 = js[1]; qn.s2 = js[2];
         }
+       
         // gather of row y = Y - 2 (centre row R2; row values qn at y + 1, q2 at y, q3 at y - 1)
         {
             const int y = Y - 2;
@@ -602,33 +616,34 @@ __global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMar
             auto add = [&](T coef, T q) { s += coef * q; if (JTF) dsum += coef * coef; };
             add(A.w_p, JTF ? A.w_p * (ve - R2.ctc) : A.w_p * ve);      // the fitting row: w_p (X - D_i) / w_p v
             const T g0r = dppShift<false>(R2.g0);
-            const int mrR = dppShift<false>(R2.mr), mrL = dppShift<true>(R2.mr), okR = dppShift<false>(R2.ok), okL = dppShift<true>(R2.ok);
-            const int mr1L = dppShift<true>(R1.mr), ok1L = dppShift<true>(R1.ok);
-            const int mcR = dppShift<false>(R2.mc), mc3R = dppShift<false>(R3.mc), ok3R = dppShift<false>(R3.ok);
-            { const T m = A.w_g * (T)R2.mr; T coef = m * (R2.g1 - g0r); coef = R2.ok ? coef : T(0); add(coef, q2.gh); }                       // gh, centre (x, y)
+            const int b2R = dppShift<false>(R2.bits), b2L = dppShift<true>(R2.bits), b1L = dppShift<true>(R1.bits), b3R = dppShift<false>(R3.bits);
+            const int mrR = sfsMr(b2R), mrL = sfsMr(b2L), okR = b2R & kSfsOk, okL = b2L & kSfsOk;
+            const int mr1L = sfsMr(b1L), ok1L = b1L & kSfsOk;
+            const int mcR = sfsMc(b2R), mc3R = sfsMc(b3R), ok3R = b3R & kSfsOk;
+            { const T m = A.w_g * (T)sfsMr(R2.bits); T coef = m * (R2.g1 - g0r); coef = (R2.bits & kSfsOk) ? coef : T(0); add(coef, q2.gh); }                       // gh, centre (x, y)
             { const T m = A.w_g * (T)mrR; T coef = m * g0r; coef = okR ? coef : T(0); add(coef, dppShift<false>(q2.gh)); }                     // (x+1, y)
-            { const T m = A.w_g * (T)R1.mr; T coef = m * R1.g2; coef = R1.ok ? coef : T(0); add(coef, qn.gh); }                                 // (x, y+1)
+            { const T m = A.w_g * (T)sfsMr(R1.bits); T coef = m * R1.g2; coef = (R1.bits & kSfsOk) ? coef : T(0); add(coef, qn.gh); }                                 // (x, y+1)
             { const T m = A.w_g * (T)mrL; T coef = -(m * R2.g1); coef = okL ? coef : T(0); add(coef, dppShift<true>(q2.gh)); }                  // (x-1, y)
             { const T m = A.w_g * (T)mr1L; T coef = -(m * R1.g2); coef = ok1L ? coef : T(0); add(coef, dppShift<true>(qn.gh)); }                // (x-1, y+1)
-            { const T m = A.w_g * (T)R2.mc; T coef = m * (R2.g1 - R1.g2); coef = R2.ok ? coef : T(0); add(coef, q2.gv); }                       // gv, centre (x, y)
+            { const T m = A.w_g * (T)sfsMc(R2.bits); T coef = m * (R2.g1 - R1.g2); coef = (R2.bits & kSfsOk) ? coef : T(0); add(coef, q2.gv); }                       // gv, centre (x, y)
             { const T m = A.w_g * (T)mcR; T coef = m * g0r; coef = okR ? coef : T(0); add(coef, dppShift<false>(q2.gv)); }                     // (x+1, y)
-            { const T m = A.w_g * (T)R1.mc; T coef = m * R1.g2; coef = R1.ok ? coef : T(0); add(coef, qn.gv); }                                 // (x, y+1)
-            { const T m = A.w_g * (T)R3.mc; T coef = -(m * R2.g1); coef = R3.ok ? coef : T(0); add(coef, q3.gv); }                              // (x, y-1)
+            { const T m = A.w_g * (T)sfsMc(R1.bits); T coef = m * R1.g2; coef = (R1.bits & kSfsOk) ? coef : T(0); add(coef, qn.gv); }                                 // (x, y+1)
+            { const T m = A.w_g * (T)sfsMc(R3.bits); T coef = -(m * R2.g1); coef = (R3.bits & kSfsOk) ? coef : T(0); add(coef, q3.gv); }                              // (x, y-1)
             { const T m = A.w_g * (T)mc3R; T coef = -(m * g0r); coef = ok3R ? coef : T(0); add(coef, dppShift<false>(q3.gv)); }                 // (x+1, y-1)
-            const int vR = dppShift<false>(R2.valid), vLft = dppShift<true>(R2.valid);
+            const int vR = b2R & kSfsValid, vLft = b2L & kSfsValid;
             auto reg = [&](int valid, T w4, T a0, T a1, T a2) {
                 const T wgt = valid ? A.w_s * w4 : T(0);
                 add(wgt * cxc, a0); add(wgt * cy2, a1); add(wgt * T(1), a2);
             };
-            reg(R2.valid, T(4), q2.s0, q2.s1, q2.s2);
+            reg(R2.bits & kSfsValid, T(4), q2.s0, q2.s1, q2.s2);
             reg(vR, T(-1), dppShift<false>(q2.s0), dppShift<false>(q2.s1), dppShift<false>(q2.s2));
             reg(vLft, T(-1), dppShift<true>(q2.s0), dppShift<true>(q2.s1), dppShift<true>(q2.s2));
-            reg(R1.valid, T(-1), qn.s0, qn.s1, qn.s2);
-            reg(R3.valid, T(-1), q3.s0, q3.s1, q3.s2);
+            reg(R1.bits & kSfsValid, T(-1), qn.s0, qn.s1, qn.s2);
+            reg(R3.bits & kSfsValid, T(-1), q3.s0, q3.s1, q3.s2);
             if (JTF) {
                 if (writer && y >= yb && y < ye) {
                     const long e = (long)y * A.W + x;
-                    const T r0 = R2.ex ? -s : -T(0), dg = R2.ex ? dsum : T(0);
+                    const T r0 = (R2.bits & kSfsEx) ? -s : -T(0), dg = (R2.bits & kSfsEx) ? dsum : T(0);
                     out[e] = r0;
                     if (fin.CtC) {      // k_finalizeDiagonal<T, true> with usePre = 0, graphMode = 0
                         const T s1 = T(1) + sqrt(T(1));
@@ -651,14 +666,14 @@ __global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMar
                 }
             } else {
             if (LM) s += R2.ctc * ve;
-            if (!R2.ex) s = 0;
+            if (!(R2.bits & kSfsEx)) s = 0;
             if (writer && y >= yb && y < ye) {
                 out[(long)y * A.W + x] = s;
                 acc += (double)(ve * s);
                 const T rk = R2.rk;
                 const T zk = K.first ? ve : rk;                                        // launch 0: alphaNumerator_0 = r_0 . p_0 (the reference's start)
                 accNum += (double)(zk * rk); acc2 += (double)(rk * s); acc3 += (double)(s * s);
-                if (K.first) accRR += (double)(rk * rk);
+                if (K.first) accX += (double)(rk * rk);
             }
             }
         }
@@ -691,7 +706,7 @@ __global__ __launch_bounds__(kSfsMarchBlock, SFS_MARCH_MINWAVES) void sfs_pcgMar
         }
         return;
     }
-    double vv[6] = {acc, accNum, acc2, acc3, accRR, accQ};
+    double vv[6] = {acc, accNum, acc2, acc3, K.first ? accX : 0.0, K.first ? 0.0 : accX};
     blockReduceSumN<6>(vv, scratch);
     if (threadIdx.x == 0) {
         K.aDen[blockIdx.x] = vv[0]; K.aNum[blockIdx.x] = vv[1]; K.s2[blockIdx.x] = vv[2]; K.s3[blockIdx.x] = vv[3];
@@ -790,6 +805,7 @@ struct SfsOps : EnergyOps<T> {
         for (auto pp : imgs) { HIP_CHECK(hipMalloc((void**)pp, n * sizeof(T))); HIP_CHECK(hipMemset(*pp, 0, n * sizeof(T))); owned.push_back(*pp); }
         HIP_CHECK(hipMalloc((void**)&A.q, 5 * n * sizeof(T))); owned.push_back(A.q);
         HIP_CHECK(hipMalloc((void**)&A.fl, n)); HIP_CHECK(hipMemset(A.fl, 0, n)); owned.push_back(A.fl);
+        HIP_CHECK(hipMalloc((void**)&A.fl2, 4 * n)); HIP_CHECK(hipMemset(A.fl2, 0, 4 * n)); owned.push_back(A.fl2);
         int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (const char* e = getenv("OPT_AMD_SFS_TILED")) tiledApply = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_SFS_ONEKERNEL")) oneKernel = atoi(e) != 0;
