@@ -2,6 +2,7 @@
 // volumetric_mesh_deformation -- SURVEY.md 8(f) rank 3.  Each functor restates the residuals of its reference .t once,
 // against a scalar type S that the engine instantiates as T or as a dual number.
 #include "stencil_engine.h"
+#include "stencil_march.h"
 #include "graph_common.h"      // makeVolumetricOnArap
 
 namespace optamd {
@@ -173,7 +174,55 @@ struct VolumetricE {
     }
 };
 
-template <class T> EnergyOps<T>* makeFlow(const unsigned* dims) { return new StencilOps<T, OpticalFlowE<T>>(dims, false); }
+// ---- optical_flow's Gauss-Newton PCG loop on the marching template (stencil_march.h) ----------------------------------------------------------------------------
+// J^T J of optical_flow.t is a 5-point stencil with one 2 x 2 block per pixel: the data residual w_fit (I - I_hat(x + X)) contributes w_fit^2 g (g . p) with
+// g = (I_hat_dx, I_hat_dy) sampled where the flow points (the partials SampledImage hands to the chain rule, o.t:582-589), every in-bounds smoothness edge appears in
+// both directions (2 w_reg^2 (p_c - p_n) per neighbour, like poisson).  g is formed once per Gauss-Newton step (flow_coef: the functor's own sample()) and streamed as the
+// operator's per-pixel coefficient; cost, J^T F and the LM loop stay on the functor engine.
+template <class T>
+struct FlowMarchOp {
+    static constexpr int C = 2, kCoef = 2; static constexpr bool kMasked = false;
+    using Vec = MVec<T, 2>;
+    T w_fit, w_reg;
+    __device__ __forceinline__ Vec apply(const Vec& pc, const Vec& pl, const Vec& pr, const Vec& pu, const Vec& pd, bool hasL, bool hasR, bool hasU, bool hasD, const MVec<T, 2>& g) const {
+        const T jp = -(w_fit * g.v[0]) * pc.v[0] + -(w_fit * g.v[1]) * pc.v[1];      // (J p) of the data residual: dr/dX = -w_fit g
+        Vec o;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            T a = -(w_fit * g.v[c]) * jp;
+            if (hasR) { const T t = w_reg * (w_reg * (pc.v[c] - pr.v[c])); a += t + t; }
+            if (hasL) { const T t = w_reg * (w_reg * (pc.v[c] - pl.v[c])); a += t + t; }
+            if (hasD) { const T t = w_reg * (w_reg * (pc.v[c] - pd.v[c])); a += t + t; }
+            if (hasU) { const T t = w_reg * (w_reg * (pc.v[c] - pu.v[c])); a += t + t; }
+            o.v[c] = a;
+        }
+        return o;
+    }
+};
+template <class T>
+__global__ __launch_bounds__(kBlock) void flow_coef(OpticalFlowE<T> e, T* __restrict__ g) {
+    const long n = (long)e.W * e.H;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % e.W), y = (int)(i / e.W);
+        const T px = T(x) + e.X[0][2 * i], py = T(y) + e.X[0][2 * i + 1];
+        g[2 * i] = e.sample(e.Idx, px, py); g[2 * i + 1] = e.sample(e.Idy, px, py);
+    }
+}
+template <class T>
+struct OpticalFlowOps : StencilOps<T, OpticalFlowE<T>> {
+    MarchLoop<T> march; T* coef = nullptr; bool useMarch = true;
+    OpticalFlowOps(const unsigned* dims) : StencilOps<T, OpticalFlowE<T>>(dims, false) { if (const char* e = getenv("OPT_AMD_FLOW_MARCH")) useMarch = atoi(e) != 0; }
+    ~OpticalFlowOps() override { if (coef) (void)hipFree(coef); }
+    bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
+        if (!useMarch || a.pre || a.CtC) return false;      // Gauss-Newton only
+        const long n = (long)this->e.W * this->e.H;
+        if (!coef) HIP_CHECK(hipMalloc((void**)&coef, (size_t)(2 * n) * sizeof(T)));
+        if (a.first) { ScopedKernel k(ctx, "operatorCoefficients"); flow_coef<T><<<this->grid(), kBlock, 0, ctx.stream>>>(this->e, coef); }
+        return march.launch(FlowMarchOp<T>{this->e.w_fit, this->e.w_reg}, this->e.W, this->e.H, nullptr, this->cus, a, ctx, coef);
+    }
+    const T* pcgFinish(const T*, T* delta, LaunchCtx& ctx) override { return march.finish(delta, 2L * this->e.W * this->e.H, this->cus, ctx); }
+};
+template <class T> EnergyOps<T>* makeFlow(const unsigned* dims) { return new OpticalFlowOps<T>(dims); }
 template <class T> EnergyOps<T>* makeIntrinsic(const unsigned* dims) { return new StencilOps<T, IntrinsicE<T>>(dims, false); }
 // OPT_AMD_VOLUMETRIC_ARAP=0: the functor engine; default: ARAP's kernel set on the lattice graph (graph_common.h makeVolumetricOnArap -- the same energy, 151 -> ... ms at 96^3)
 template <class T> EnergyOps<T>* makeVolumetric(const unsigned* dims) {

@@ -18,7 +18,8 @@
 //
 // The operator:
 //   struct Op { static constexpr int C;  static constexpr bool kMasked;      // channels; does a flag byte per pixel switch pixels off (Exclude, o.t:2452-2455)?
-//               __device__ MVec<T, C> apply(pc, pl, pr, pu, pd, hasL, hasR, hasU, hasD) const; }     // (J^T J p) at an active pixel; p of an inactive / absent pixel is 0
+//               static constexpr int kCoef;                                  // per-pixel coefficients of the operator (0: none), streamed from MarchK::coef once per row
+//               __device__ MVec<T, C> apply(pc, pl, pr, pu, pd, hasL, hasR, hasU, hasD, coef) const; }     // (J^T J p) at an active pixel; p of an inactive / absent pixel is 0
 #pragma once
 #include "iw_device.h"
 
@@ -64,6 +65,7 @@ struct MarchK {            // kernel argument block
     const T* qOld;         // rfree == 2: the solver's r_0;  rfree == 1: p_{k-2}
     const T* pOld; T* pNew; T* delta;
     const uint8_t* flags;  // bit 0: the pixel is an unknown (Op::kMasked)
+    const T* coef;         // Op::kCoef values per pixel (Op::kCoef > 0)
     int iter;              // k
     int deltaMode;         // 2: this launch leaves delta alone;  1: it applies alpha_{k-2} p_{k-2} + alpha_{k-1} p_{k-1}
     int rfree;
@@ -76,7 +78,8 @@ struct MarchK {            // kernel argument block
 template <class T, class Op, bool FLIP, int kBlk>
 __global__ __launch_bounds__(kBlk) void march_pcgIter(Op op, MarchK<T> K, int rowsPerGroup, int gx) {
     constexpr int C = Op::C, kStripW = (kBlk / kWave) * kMarchSpan;
-    using Vec = MVec<T, C>;
+    constexpr int kCoef = Op::kCoef, kCoefN = kCoef > 0 ? kCoef : 1;
+    using Vec = MVec<T, C>; using Coef = MVec<T, kCoefN>;
     __shared__ double scratch[4 * (kBlk / kWave + 1)];
     const int bx = blockIdx.x % gx, by = blockIdx.x / gx;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
@@ -85,11 +88,11 @@ __global__ __launch_bounds__(kBlk) void march_pcgIter(Op op, MarchK<T> K, int ro
     const bool writer = xok && lane >= 2 && lane < 2 + kMarchSpan;
     const bool hasL = x >= 1, hasR = x + 1 < K.W;
     const int yb = by * rowsPerGroup, ye = min(yb + rowsPerGroup, K.H);      // sweep coordinates
-    const __amdgpu_buffer_rsrc_t bQ = iw_rsrc(K.qOld), bP = iw_rsrc(K.pOld), bN = iw_rsrc(K.pNew), bD = iw_rsrc(K.delta), bF = iw_rsrc(K.flags);
-    const unsigned xc = (unsigned)min(max(x, 0), K.W - 1), xv = xc * (unsigned)(C * sizeof(T));
+    const __amdgpu_buffer_rsrc_t bQ = iw_rsrc(K.qOld), bP = iw_rsrc(K.pOld), bN = iw_rsrc(K.pNew), bD = iw_rsrc(K.delta), bF = iw_rsrc(K.flags), bC = iw_rsrc(K.coef);
+    const unsigned xc = (unsigned)min(max(x, 0), K.W - 1), xv = xc * (unsigned)(C * sizeof(T)), xcv = xc * (unsigned)(kCoefN * sizeof(T));
     const bool first = K.iter == 0;
     const bool paired = K.deltaMode == 1;
-    struct Raw { Vec p, q, d; int f; };      // one pixel's loads, untouched (any ALU op here would force a wait before the loop back-edge)
+    struct Raw { Vec p, q, d; Coef c; int f; };      // one pixel's loads, untouched (any ALU op here would force a wait before the loop back-edge)
     auto loadRow = [&](int y) {
         Raw r;
         const int yc = min(max(y, 0), K.H - 1);      // clamped: always a valid address; rows outside the image are switched off where they enter the window
@@ -98,6 +101,7 @@ __global__ __launch_bounds__(kBlk) void march_pcgIter(Op op, MarchK<T> K, int ro
         r.p = marchLoad<T, C>(bP, xv, so);
         r.q = marchLoad<T, C>(bQ, xv, so);
         if (paired) r.d = marchLoad<T, C>(bD, xv, so); else r.d = Vec{};
+        if constexpr (kCoef > 0) r.c = marchLoad<T, kCoefN>(bC, xcv, row * (unsigned)(kCoefN * sizeof(T))); else r.c = Coef{};
         return r;
     };
     // The first five rows are requested before anything else: they do not depend on the scalars of the previous launch, so their latency overlaps the prologue's
@@ -123,11 +127,15 @@ __global__ __launch_bounds__(kBlk) void march_pcgIter(Op op, MarchK<T> K, int ro
     const T betaOlder = reconR ? K.alphaIn[2] : T(0);      // the beta of the previous launch: p_{k-1} = r_{k-1} + betaOlder p_{k-2}
     double accDen = 0, accNum = 0, acc2 = 0, acc3 = 0;
 
-    struct Row { Vec p, r; bool on; };      // iteration k-1: p_{k-1}, r_{k-1};  iteration k: p_k, r_k
+    struct Row { Vec p, r; Coef c; bool on; };      // iteration k-1: p_{k-1}, r_{k-1} (and the pixel's operator coefficients);  iteration k: p_k, r_k
     // raw row y enters the window: the pixel is switched off outside the image and where the mask says so; r_{k-1} is rebuilt; the row's delta gets its two terms
     auto makeOld = [&](const Raw& w, int y, Row& o) {
         o.on = xok && y >= 0 && y < K.H && (regCopy(w.f) & 1);
         Vec pv, qv;      // real copies: the raw registers are free for the next request (iw_device.h regCopy)
+        if constexpr (kCoef > 0) {
+#pragma unroll
+            for (int c = 0; c < kCoefN; ++c) o.c.v[c] = regCopy(w.c.v[c]);
+        } else o.c = Coef{};
 #pragma unroll
         for (int c = 0; c < C; ++c) { pv.v[c] = regCopy(w.p.v[c]); qv.v[c] = regCopy(w.q.v[c]); }
 #pragma unroll
@@ -143,10 +151,10 @@ __global__ __launch_bounds__(kBlk) void march_pcgIter(Op op, MarchK<T> K, int ro
             marchStore<T, C>(bD, xv, row * (unsigned)(C * sizeof(T)), d);
         }
     };
-    auto applyAt = [&](const Row& c, const Row& prev, const Row& next, int y) {      // (J^T J p) of row y of a stream; prev / next in sweep order
+    auto applyAt = [&](const Row& c, const Row& prev, const Row& next, int y, const Coef& cf) {      // (J^T J p) of row y of a stream; prev / next in sweep order
         const Vec pl = marchShift<true>(c.p), pr = marchShift<false>(c.p);
         const bool hasPrev = y - 1 >= 0, hasNext = y + 1 < K.H;
-        Vec o = FLIP ? op.apply(c.p, pl, pr, next.p, prev.p, hasL, hasR, hasNext, hasPrev) : op.apply(c.p, pl, pr, prev.p, next.p, hasL, hasR, hasPrev, hasNext);
+        Vec o = FLIP ? op.apply(c.p, pl, pr, next.p, prev.p, hasL, hasR, hasNext, hasPrev, cf) : op.apply(c.p, pl, pr, prev.p, next.p, hasL, hasR, hasPrev, hasNext, cf);
 #pragma unroll
         for (int i = 0; i < C; ++i) o.v[i] = c.on ? o.v[i] : T(0);
         return o;
@@ -154,8 +162,8 @@ __global__ __launch_bounds__(kBlk) void march_pcgIter(Op op, MarchK<T> K, int ro
     // One trip: the freshly entered row y+2 -> A p_{k-1}(y+1), r_k, p_k (y+1) -> A p_k(y).
     // oA, oB, oC = p_{k-1} rows y, y+1, y+2;  nA, nB = p_k rows y-1, y (nC receives y+1)
     auto trip = [&](int y, const Row& oA, const Row& oB, const Row& oC, const Row& nA, const Row& nB, Row& nC, bool live) {
-        const Vec ap = applyAt(oB, oA, oC, y + 1);                                     // Step1 of iteration k-1 again
-        nC.on = oB.on;
+        const Vec ap = applyAt(oB, oA, oC, y + 1, oB.c);                               // Step1 of iteration k-1 again
+        nC.on = oB.on; nC.c = Coef{};
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const T r = first ? oB.r.v[c] : oB.r.v[c] - alpha * ap.v[c];                // Step2
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(kBlk) void march_pcgIter(Op op, MarchK<T> K, int ro
             const unsigned row = (unsigned)(FLIP ? K.H - 2 - y : y + 1) * (unsigned)K.W;
             marchStore<T, C>(bN, xv, row * (unsigned)(C * sizeof(T)), nC.p);
         }
-        const Vec o = applyAt(nB, nA, nC, y);                                           // Step1 of iteration k
+        const Vec o = applyAt(nB, nA, nC, y, oA.c);                                     // Step1 of iteration k (row y: the coefficients of oA's pixel)
         if (live && writer && y >= yb) {
             // every term from the same r, A p in double, where a product of two floats is exact: the expansion of the beta numerator cancels to as many digits as
             // the residual loses in one iteration
@@ -209,16 +217,16 @@ struct MarchLoop {
     MarchLoop() { if (const char* e = getenv("OPT_AMD_ITER_ROWS")) forceRows = atoi(e); if (const char* e = getenv("OPT_AMD_MARCH_BLOCK")) forceBlock = atoi(e); }
     ~MarchLoop() { for (T* b : ring) if (b) (void)hipFree(b); if (alphaSlots) (void)hipFree(alphaSlots); }
     template <class Op>
-    bool launch(const Op& op, int W, int H, const uint8_t* flags, int cus, const PcgIterArgs<T>& a, LaunchCtx& ctx) {
+    bool launch(const Op& op, int W, int H, const uint8_t* flags, int cus, const PcgIterArgs<T>& a, LaunchCtx& ctx, const T* coef = nullptr) {
         // 16-byte pixels leave room for 3 waves per SIMD in 768-thread workgroups (12 column strips side by side: fewer, fatter workgroups and a quarter of the partial
         // sums the next prologue has to add); 32-byte pixels (double4: 206 VGPRs) run 256 threads
         const int blk = forceBlock ? forceBlock : (Op::C * sizeof(T) <= 16 ? 768 : 256);
-        if (blk == 768) return launchB<Op, 768>(op, W, H, flags, cus, a, ctx);
-        if (blk == 512) return launchB<Op, 512>(op, W, H, flags, cus, a, ctx);
-        return launchB<Op, 256>(op, W, H, flags, cus, a, ctx);
+        if (blk == 768) return launchB<Op, 768>(op, W, H, flags, cus, a, ctx, coef);
+        if (blk == 512) return launchB<Op, 512>(op, W, H, flags, cus, a, ctx, coef);
+        return launchB<Op, 256>(op, W, H, flags, cus, a, ctx, coef);
     }
     template <class Op, int blk>
-    bool launchB(const Op& op, int W, int H, const uint8_t* flags, int cus, const PcgIterArgs<T>& a, LaunchCtx& ctx) {
+    bool launchB(const Op& op, int W, int H, const uint8_t* flags, int cus, const PcgIterArgs<T>& a, LaunchCtx& ctx, const T* coef) {
         constexpr int C = Op::C;
         if ((unsigned long long)W * H * C * sizeof(T) >= (1ull << 32)) return false;      // 32-bit buffer offsets
         const size_t bytes = ((size_t)W * H * C + 3) / 4 * 4 * sizeof(T);                 // padded like the solver's vectors: its flat kernels read whole 16-byte packs of the last p
@@ -231,7 +239,7 @@ struct MarchLoop {
         }
         const int k = iterIndex;
         MarchK<T> K{};
-        K.W = W; K.H = H; K.flags = flags; K.iter = k;
+        K.W = W; K.H = H; K.flags = flags; K.coef = coef; K.iter = k;
         K.pOld = k == 0 ? a.pOld : ring[(k - 1) % 3];
         K.qOld = k <= 1 ? r0Ptr : ring[(k - 2) % 3];
         K.pNew = ring[k % 3]; K.delta = a.delta;

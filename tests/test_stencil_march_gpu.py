@@ -1,5 +1,5 @@
-"""GPU parity tests (-m gpu) of the marching PCG iteration template (opt_amd/csrc/stencil_march.h) on its two instances: poisson_image_editing (float4 / double4,
-Exclude mask) and the tests/minimal laplacian (float, no mask).
+"""GPU parity tests (-m gpu) of the marching PCG iteration template (opt_amd/csrc/stencil_march.h) on its instances: poisson_image_editing (float4 / double4,
+Exclude mask), the tests/minimal laplacian (float, no mask) and optical_flow (float2 / double2 with a 2 x 2 block per pixel streamed as operator coefficients).
 
 One launch per PCG iteration (reference loop: solverGPUGaussNewton.t:1056-1092); no A p, no residual vector, delta every second launch -- so the cases walk the
 launch-to-launch state machine (1, 2, 3, 4, 5 iterations: first launch, the launch that reads r_0 again, the first rebuilt residual, the first paired delta update,
@@ -71,6 +71,31 @@ def test_poisson_float(oracle_lib, W, H, mask, liters):
 @pytest.mark.parametrize("W,H", SHAPES)
 def test_laplacian_float(oracle_lib, W, H, liters):
     _pair(oracle_lib, wl.laplacian(W, H, seed=W + H + liters), 2, _cap(W, H, liters, False), 1e-5, 2e-5)
+
+
+@pytest.mark.parametrize("liters", [1, 2, 3, 4, 5, 12])
+@pytest.mark.parametrize("double", [True, False])
+@pytest.mark.parametrize("W,H", [(7, 9), (61, 5), (240, 3), (241, 9), (300, 40), (64, 300), (517, 33)])
+def test_optical_flow(oracle_lib, W, H, double, liters):
+    """Off-lattice sample positions (seeded initial flow): the operator's per-pixel coefficients are the sampled derivative images at pixel + flow, rebuilt every
+    Gauss-Newton step (the second step runs from the first step's flow)."""
+    P = wl.optical_flow(W, H, double=double, seed=W + H + liters, init_flow=1.2)
+    _pair(oracle_lib, P, 2, liters, 1e-10 if double else 1e-5, 1e-9 if double else 2e-5)
+
+
+def test_optical_flow_march_matches_the_functor_engine_loop(monkeypatch):
+    res = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("OPT_AMD_FLOW_MARCH", on)
+        P = wl.optical_flow(333, 97, double=True, seed=4, init_flow=0.7)
+        g = hip_solver(P, "gaussNewtonGPU", timing=True, nIterations=3, lIterations=25)
+        dev = api.to_device(P)
+        g.solve(dev)
+        assert ("PCGIteration" in g.kernel_timings()) == (on == "1")
+        res.append((g.cost(), device_unknowns(P, dev)))
+        g.close()
+    assert abs(res[0][0] - res[1][0]) <= 1e-10 * abs(res[1][0])
+    assert rel_err(res[0][1], res[1][1]) < 1e-9
 
 
 @pytest.mark.parametrize("double", [False, True])
