@@ -285,93 +285,25 @@ __global__ __launch_bounds__(kBlock) void csr_checksum(const int* __restrict__ v
     if (threadIdx.x == 0) { unsigned long long t = 0; for (int w = 0; w < kBlock / kWave; ++w) t += part[w]; atomicAdd(out, t); }
 }
 
-template <class T>
-__global__ __launch_bounds__(kBlock) void arap_edgeJp(ArapArgs<T> A, const T* __restrict__ v, T* __restrict__ Jp, double* __restrict__ partials) {
-    __shared__ double scratch[kBlock / kWave + 1];
-    double acc = 0;
-    const long offA = 3 * A.N, nE = A.nE;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < nE; e += (long)gridDim.x * blockDim.x) {
-        const long a0 = A.v0[e], a1 = A.v1[e];
-        const V3<T> p0 = ld3(v, a0), p1 = ld3(v, a1), pa = ld3(v + offA, a0);
-        const T w = A.w_reg;
-        const T jx = w * (p0.x - p1.x) - w * (A.D[e] * pa.x + A.D[3 * nE + e] * pa.y + A.D[6 * nE + e] * pa.z);
-        const T jy = w * (p0.y - p1.y) - w * (A.D[nE + e] * pa.x + A.D[4 * nE + e] * pa.y + A.D[7 * nE + e] * pa.z);
-        const T jz = w * (p0.z - p1.z) - w * (A.D[2 * nE + e] * pa.x + A.D[5 * nE + e] * pa.y + A.D[8 * nE + e] * pa.z);
-        // {J p, D_k . J p}: everything the vertex pass needs from this half-edge, 24 contiguous bytes
-        T* o = Jp + 6 * e;
-        o[0] = jx; o[1] = jy; o[2] = jz;
-        o[3] = A.D[e] * jx + A.D[nE + e] * jy + A.D[2 * nE + e] * jz;
-        o[4] = A.D[3 * nE + e] * jx + A.D[4 * nE + e] * jy + A.D[5 * nE + e] * jz;
-        o[5] = A.D[6 * nE + e] * jx + A.D[7 * nE + e] * jy + A.D[8 * nE + e] * jz;
-        acc += (double)(jx * jx + jy * jy + jz * jz);   // sum_u p_u (J^T J p)_u of this edge = |J p|^2 (o.t:2117-2122)
-    }
-    double t = blockReduceSum(acc, scratch);
-    if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
-}
 // 8 lanes per vertex, each walking one slot of the out-list and one of the in-list (a mesh vertex has ~6 of each), so the
-// dependent index -> record gathers of one vertex are in flight together instead of in a 12-trip serial loop.  The kernel is
+// dependent index -> record gathers of one vertex are in flight together instead of in a 12-trip serial loop.  The gather kernels are
 // bound by how many such chains are in flight (time ~ 1 / resident workgroups), hence the full-occupancy grid.
 #ifndef ARAP_LANES
 #define ARAP_LANES 8
 #endif
 constexpr int kLanesPerVertex = ARAP_LANES;
-template <class T>
-__global__ __launch_bounds__(kBlock) void arap_vertexGather(ArapArgs<T> A, GraphCsr G, const T* __restrict__ v, const T* __restrict__ Jp, T* __restrict__ out, const T* __restrict__ CtC,
-                                                            double* __restrict__ partials) {
-    __shared__ double scratch[kBlock / kWave + 1];
-    double acc = 0;
-    const long offA = 3 * A.N;
-    const int sub = threadIdx.x % kLanesPerVertex, slot = sub;
-    const long nGroups = (A.N + (kBlock / kLanesPerVertex) - 1) / (kBlock / kLanesPerVertex);
-    for (long g = blockIdx.x; g < nGroups; g += gridDim.x) {       // uniform trip count: the shuffles below need whole waves
-        const long i = g * (kBlock / kLanesPerVertex) + threadIdx.x / kLanesPerVertex;
-        const bool ok = i < A.N;
-        const long iv = ok ? i : 0;
-        const T w = A.w_reg;
-        T s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
-        // each lane walks one slot of the out-list and one of the in-list: two independent index -> record chains in flight
-        const int bo = G.outOff[iv], eo = ok ? G.outOff[iv + 1] : bo, bi = G.inOff[iv], ei = ok ? G.inOff[iv + 1] : bi;
-        for (int k = 0; k < max(eo - bo, ei - bi); k += kLanesPerVertex) {
-            const int ko = bo + slot + k, ki = bi + slot + k;
-            const int eOut = ko < eo ? G.outIdx[ko] : -1, eIn = ki < ei ? G.inIdx[ki] : -1;
-            const T* o = Jp + 6 * (long)max(eOut, 0); const T* q = Jp + 6 * (long)max(eIn, 0);
-            const T wo = eOut >= 0 ? w : T(0), wi = eIn >= 0 ? w : T(0);
-            s0 += wo * o[0]; s1 += wo * o[1]; s2 += wo * o[2]; s3 -= wo * o[3]; s4 -= wo * o[4]; s5 -= wo * o[5];
-            s0 -= wi * q[0]; s1 -= wi * q[1]; s2 -= wi * q[2];
-        }
-#pragma unroll
-        for (int m = 1; m < kLanesPerVertex; m <<= 1) {
-            s0 += __shfl_xor(s0, m, kWave); s1 += __shfl_xor(s1, m, kWave); s2 += __shfl_xor(s2, m, kWave);
-            s3 += __shfl_xor(s3, m, kWave); s4 += __shfl_xor(s4, m, kWave); s5 += __shfl_xor(s5, m, kWave);
-        }
-        if (ok && sub == 0) {
-            // per-vertex ("centred") part: fitting term and, for LM, CtC p  -- what arap_vertices<3> computes
-            const bool valid = A.Constraints[3 * i] >= T(-999999.9);
-            const T wf = valid ? A.w_fit : T(0);
-            const V3<T> p = ld3(v, i), pa = ld3(v + offA, i);
-            V3<T> q{wf * wf * p.x, wf * wf * p.y, wf * wf * p.z}, qa{0, 0, 0};
-            if (CtC) { const V3<T> cO = ld3(CtC, i), cA = ld3(CtC + offA, i); q.x += cO.x * p.x; q.y += cO.y * p.y; q.z += cO.z * p.z; qa.x = cA.x * pa.x; qa.y = cA.y * pa.y; qa.z = cA.z * pa.z; }
-            acc += (double)(dot3(p, q) + dot3(pa, qa));
-            out[3 * i] = q.x + s0; out[3 * i + 1] = q.y + s1; out[3 * i + 2] = q.z + s2;
-            out[offA + 3 * i] = qa.x + s3; out[offA + 3 * i + 1] = qa.y + s4; out[offA + 3 * i + 2] = qa.z + s5;
-        }
-    }
-    double t = blockReduceSum(acc, scratch);
-    if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
-}
 
 // ---- edge pass and vertex gather in ONE launch (round 2) --------------------------------------------------------------------------
 // The two-pass form moves every half-edge's 24-byte record through memory twice more than needed: written by the edge pass, read back as
 // an out-record by its head vertex and as an in-record by its tail vertex (edge pass 240 MB + vertex pass 279 MB per J^T J p at 500 k
 // vertices / 3 M half-edges).  Here the lane that would read a record computes it instead: for its out-edge e = (v -> u) from p_u and the
-// edge's derivative columns D_e, for its in-edge e' = (u' -> v) from p_u', pa_u' and D_e' -- the same expressions as arap_edgeJp, summed in the
-// same lane / shuffle order as arap_vertexGather.  D is kept as 36-byte AoS rows (D9) for this kernel: a gathered in-edge costs one or two cache
+// edge's derivative columns D_e, for its in-edge e' = (u' -> v) from p_u', pa_u' and D_e' -- the per-edge expressions of arap_edges<3>, summed per vertex in a fixed lane / shuffle order.  D is kept as 36-byte AoS rows (D9) for this kernel: a gathered in-edge costs one or two cache
 // lines instead of nine plane accesses.  Neighbour p's are gathers that mostly hit L2 (a mesh neighbour is a memory neighbour).
 template <class T>
 __global__ __launch_bounds__(kBlock) void arap_packD(const T* __restrict__ D, T* __restrict__ D9, long nE) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < 9 * nE; i += (long)gridDim.x * blockDim.x) D9[i] = D[(i % 9) * nE + i / 9];
 }
-// S.r != nullptr (round 3): the launch is the Step1 half of a TWO-kernel PCG iteration (arap_flatStep + this one; EnergyOps::pcgIteration).  Besides p . A p it then sums, at the
+// S.r != nullptr (round 3): the launch is the Step1 half of a TWO-kernel PCG iteration (arap_flatStepRec + arap_applySym; EnergyOps::pcgIteration).  Besides p . A p it then sums, at the
 // lane that owns the vertex, what the expanded beta numerator of the next flat pass needs -- sum M r^2, sum M r . A p, sum M (A p)^2, every term from M, r, A p themselves in double
 // (exact products of floats; see energy_image_warping.hip dprod3) -- so that PCGStep2 and PCGStep3 become one flat pass without a reduction between them.
 template <class T> __device__ __forceinline__ double arap_dprod3(T m, T a, T b) { return ((double)m * (double)a) * (double)b; }
@@ -403,7 +335,7 @@ __global__ __launch_bounds__(kBlock) void arap_applyFused(ArapArgs<T> A, GraphCs
             const V3<T> pu = ld3(v, u), pq = ld3(v, uIn), paq = ld3(v + offA, uIn);
             const T* d = D9 + 9 * e; const T* h = D9 + 9 * f;
             const T wo = eOut >= 0 ? w : T(0), wi = eIn >= 0 ? w : T(0);
-            {   // out-edge (v -> u): J p and D_k . J p  (arap_edgeJp with v0 = v)
+            {   // out-edge (v -> u): J p and D_k . J p  (arap_edges<3> with v0 = v)
                 const T jx = w * (pv.x - pu.x) - w * (d[0] * pav.x + d[3] * pav.y + d[6] * pav.z);
                 const T jy = w * (pv.y - pu.y) - w * (d[1] * pav.x + d[4] * pav.y + d[7] * pav.z);
                 const T jz = w * (pv.z - pu.z) - w * (d[2] * pav.x + d[5] * pav.y + d[8] * pav.z);
@@ -452,34 +384,6 @@ __global__ __launch_bounds__(kBlock) void arap_applyFused(ArapArgs<T> A, GraphCs
 // PCGStep2 + PCGStep3 of iteration k-1 as ONE flat pass (solver.t:446-489, 537-550): alpha from the previous gather's sums, beta from their expansion
 //   sum M (r - alpha A p)^2 = aNum - 2 alpha s2 + alpha^2 s3   (all in double, clamped at 0 like the direct sum it replaces; energy.h PcgIterArgs),
 // then delta += alpha p, r -= alpha A p, z = M r, p = z + beta p -- no reduction in this kernel, none between Step2 and Step3.
-template <class T>
-__global__ __launch_bounds__(kBlock) void arap_flatStep(T* __restrict__ delta, const T* __restrict__ pOld, const T* __restrict__ rOld, const T* __restrict__ Ap, const T* __restrict__ M,
-                                                        T* __restrict__ rNew, T* __restrict__ pNew, long n4, const double* aNumP, int nNum, const double* aDenP, int nDen,
-                                                        const double* s2P, int n2, const double* s3P, int n3) {
-    __shared__ double scratch[4 * (kBlock / kWave + 1)];
-    const double* const ps[4] = {aNumP, aDenP, s2P, s3P}; const int ns[4] = {nNum, nDen, n2, n3}; double o4[4];
-    sumPartialsN<4>(ps, ns, scratch, o4);
-    const T aNum = (T)o4[0], aDen = (T)o4[1];
-    const T alpha = (aDen > T(0)) ? aNum / aDen : T(0);                                  // solver.t:456-459
-    const double bNumD = fmax(o4[0] - 2.0 * (double)alpha * o4[2] + (double)alpha * (double)alpha * o4[3], 0.0);
-    const T beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);                               // solver.t:544-547
-    constexpr int NP = 16 / sizeof(T);                                                   // scalars per 16-byte pack
-    typedef T VP __attribute__((ext_vector_type(NP)));
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        VP d = ((const VP*)delta)[i]; const VP p = ((const VP*)pOld)[i], r = ((const VP*)rOld)[i], a = ((const VP*)Ap)[i], m = ((const VP*)M)[i];
-        VP rn, pn;
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            d[k] = d[k] + alpha * p[k];
-            rn[k] = r[k] - alpha * a[k];
-            const T z = m[k] * rn[k];
-            pn[k] = z + beta * p[k];
-        }
-        ((VP*)delta)[i] = d; ((VP*)rNew)[i] = rn; ((VP*)pNew)[i] = pn;
-    }
-}
-
-
 // ---- round 3: J^T J p on a SYMMETRIC graph from one record per vertex ---------------------------------------------------------------------------
 // arap_applyFused is bound by the number of dependent index -> record chains in flight: per half-edge slot it follows outIdx / inIdx / outNbr / inNbr (16 B), two 36-byte
 // derivative rows and three 12-byte vectors of the neighbour, 3-5 cache lines.  A mesh carries every edge in both directions (examples/shared/OptGraph.h builds v0 -> v1 for
@@ -487,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void arap_flatStep(T* __restrict__ delta, c
 // lists are built (csr_symmetric), any other graph keeps arap_applyFused.  Then one walk of the out-list serves both directions, and everything the walk needs from a
 // neighbour u -- p_u, pa_u and the sines / cosines of its angles, from which its derivative columns D_k(u -> v) = dR3/da_k(a_u) (U_u - U_v) follow in ~60 flops instead of a
 // 36-byte row -- is ONE 64-byte record (one cache line); the slot itself is 16 contiguous bytes {U_v - U_u, u}.  Per half-edge pair: 80 B in two lines instead of ~190 B in
-// seven.  The expressions are arap_edgeJp's / arap_rot's (same association: J p = w (p_v0 - p_v1) - w (D_0 pa.x + D_1 pa.y + D_2 pa.z)), the in-edge terms are summed in
+// seven.  The expressions are arap_edges<3>'s / arap_rot's (same association: J p = w (p_v0 - p_v1) - w (D_0 pa.x + D_1 pa.y + D_2 pa.z)), the in-edge terms are summed in
 // out-list order.
 template <class T> struct alignas(16) ArapSlot { T ux, uy, uz; int nbr; };
 template <class T> struct alignas(16) ArapRec { T px, py, pz, ax, ay, az, sa, ca, sb, cb, sg, cg, pad0, pad1, pad2, pad3; };
@@ -583,9 +487,7 @@ __global__ __launch_bounds__(kBlock) void arap_step3Rec(const T* __restrict__ z,
 #ifndef ARAP_SYM_LANES
 #define ARAP_SYM_LANES 2
 #endif
-// PVEC (A/B): p and pa of a vertex are read from the solver's vector (two 12-byte pieces) instead of the record -- three cache lines per neighbour instead of one, but PCGStep3
-// stays the generic flat kernel and writes no records.
-template <class T, int LANES, bool PVEC, int BATCH>
+template <class T, int LANES, int BATCH>
 __global__ __launch_bounds__(kBlock) void arap_applySym(ArapArgs<T> A, const int* __restrict__ outOff, const ArapSlot<T>* __restrict__ slots, const ArapRec<T>* __restrict__ rec,
                                                         const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ CtC, double* __restrict__ partials, int xcd, ArapIterSums S) {
     __shared__ double scratch[4 * (kBlock / kWave + 1)];
@@ -606,7 +508,6 @@ __global__ __launch_bounds__(kBlock) void arap_applySym(ArapArgs<T> A, const int
         const long iv = ok ? i : 0;
         const T w = A.w_reg;
         ArapRec<T> me = rec[iv];
-        if (PVEC) { const V3<T> a = ld3(v, iv), b = ld3(v + offA, iv); me.px = a.x; me.py = a.y; me.pz = a.z; me.ax = b.x; me.ay = b.y; me.az = b.z; }
         const int bo = outOff[iv], eo = ok ? outOff[iv + 1] : bo;
         V3<T> rO{0, 0, 0}, rA{0, 0, 0}, mO{0, 0, 0}, mA{0, 0, 0};
         if (rv && sub == 0) { rO = ld3(rv, iv); rA = ld3(rv + offA, iv); mO = ld3(Mv, iv); mA = ld3(Mv + offA, iv); }      // requested before the walk: known from the vertex index alone
@@ -622,7 +523,6 @@ __global__ __launch_bounds__(kBlock) void arap_applySym(ArapArgs<T> A, const int
 #pragma unroll
             for (int j = 0; j < BATCH; ++j) {
                 nbs[j] = rec[sl[j].nbr];
-                if (PVEC) { const V3<T> a = ld3(v, (long)sl[j].nbr), b = ld3(v + offA, (long)sl[j].nbr); nbs[j].px = a.x; nbs[j].py = a.y; nbs[j].pz = a.z; nbs[j].ax = b.x; nbs[j].ay = b.y; nbs[j].az = b.z; }
             }
 #pragma unroll
             for (int j = 0; j < BATCH; ++j) {
@@ -631,7 +531,7 @@ __global__ __launch_bounds__(kBlock) void arap_applySym(ArapArgs<T> A, const int
                 const V3<T> u{sl[j].ux, sl[j].uy, sl[j].uz}, un{-sl[j].ux, -sl[j].uy, -sl[j].uz};
                 V3<T> D0, D1, D2;
                 arap_cols(cv, u, D0, D1, D2);
-                {   // out-edge (v -> u): J p and D_k . J p  (arap_edgeJp with v0 = v)
+                {   // out-edge (v -> u): J p and D_k . J p  (arap_edges<3> with v0 = v)
                     const T jx = w * (pv.x - nb.px) - w * (D0.x * pav.x + D1.x * pav.y + D2.x * pav.z);
                     const T jy = w * (pv.y - nb.py) - w * (D0.y * pav.x + D1.y * pav.y + D2.y * pav.z);
                     const T jz = w * (pv.z - nb.pz) - w * (D0.z * pav.x + D1.z * pav.y + D2.z * pav.z);
@@ -682,7 +582,7 @@ __global__ __launch_bounds__(kBlock) void arap_applySym(ArapArgs<T> A, const int
     if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
 }
 
-// PCGStep2 + PCGStep3 (arap_flatStep) for the record path: a workgroup takes 256 consecutive vertices = 3 * 256 / NP 16-byte packs of the Offset half and as many of the Angle
+// PCGStep2 + PCGStep3 in one flat pass for the record path: a workgroup takes 256 consecutive vertices = 3 * 256 / NP 16-byte packs of the Offset half and as many of the Angle
 // half (N a multiple of 4: both halves start on a pack boundary), updates delta, r, p pack by pack, and passes the new p through LDS to the thread that owns the vertex's record.
 template <class T>
 __global__ __launch_bounds__(kBlock) void arap_flatStepRec(T* __restrict__ delta, const T* __restrict__ pOld, const T* __restrict__ rOld, const T* __restrict__ Ap, const T* __restrict__ M,
@@ -797,12 +697,11 @@ struct ArapOps : EnergyOps<T> {
     void* scanTemp = nullptr; size_t scanTempBytes = 0; unsigned long long* dChecksum = nullptr;
     const int *csrV0 = nullptr, *csrV1 = nullptr; int csrNE = -1; unsigned long long csrSum = 0; bool csrValid = false;
     bool useGather = true;   // OPT_AMD_ARAP_GATHER=0: scatter with wave-aggregated atomics instead
-    bool useFused = true;    // OPT_AMD_ARAP_FUSED=0: edge pass + vertex gather as two launches through the record buffer
     T* D9 = nullptr; long d9Capacity = 0; int* nbr = nullptr;
     // symmetric-graph path (arap_applySym): out-list slots {U_v - U_u, u}, one record per vertex; OPT_AMD_ARAP_SYM=0 keeps arap_applyFused
     bool useSym = true, symGraph = false;
     ArapSlot<T>* slots = nullptr; ArapRec<T>* rec = nullptr; int* dNotSym = nullptr;
-    bool symPath() const { return useGather && useFused && useSym && symGraph; }
+    bool symPath() const { return useGather && useSym && symGraph; }
     ~ArapOps() override {
         if (D9) (void)hipFree(D9);
         if (nbr) (void)hipFree(nbr);
@@ -841,7 +740,7 @@ struct ArapOps : EnergyOps<T> {
         csr_neighbours<<<ge, kBlock, 0, st>>>(A.v0, A.v1, A.nE, outIdx, inIdx, nbr, nbr + std::max(1, A.nE));
         // does every edge come with its reverse (per vertex: out-neighbours == in-neighbours as multisets)?  Then J^T J p walks the out-lists only (arap_applySym)
         symGraph = false;
-        if (useSym && useFused) {
+        if (useSym) {
             if (!dNotSym) HIP_CHECK(hipMalloc((void**)&dNotSym, 4));
             HIP_CHECK(hipMemsetAsync(dNotSym, 0, 4, st));
             csr_symmetric<<<vgrid(), kBlock, 0, st>>>(A.N, outOff, nbr, inOff, nbr + std::max(1, A.nE), dNotSym);
@@ -864,12 +763,8 @@ struct ArapOps : EnergyOps<T> {
         this->addUnknown(2, A.N, 3); this->addUnknown(3, A.N, 3);                // Offset, Angle (:4-5)
         int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (const char* e = getenv("OPT_AMD_ARAP_GATHER")) useGather = atoi(e) != 0;
-        if (const char* e = getenv("OPT_AMD_ARAP_FUSED")) useFused = atoi(e) != 0;
-        if (const char* e = getenv("OPT_AMD_ARAP_ITER")) { fusedIter = atoi(e) != 0; fusedIterEnv = atoi(e) != 0; }
+        if (const char* e = getenv("OPT_AMD_ARAP_ITER")) fusedIterEnv = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ARAP_SYM")) useSym = atoi(e) != 0;
-        if (const char* e = getenv("OPT_AMD_ARAP_SYM_LANES")) symLanes = atoi(e);
-        if (const char* e = getenv("OPT_AMD_ARAP_SYM_PVEC")) symPvec = atoi(e) != 0;
-        if (const char* e = getenv("OPT_AMD_ARAP_SYM_BATCH")) symBatch = symBatchIter = atoi(e);
         if (const char* e = getenv("OPT_AMD_ARAP_SYM_XCD")) symXcd = atoi(e);
         if (const char* e = getenv("OPT_AMD_ARAP_VGRID")) symGridCap = atoi(e);
     }
@@ -907,7 +802,7 @@ struct ArapOps : EnergyOps<T> {
                 ScopedKernel k(ctx, "vertexRecords");
                 arap_buildRecTrig<T><<<vgrid(), kBlock, 0, ctx.stream>>>(A, rec);
             }
-            if (useFused && (!symPath() || fusedIter)) {     // the derivative columns of this Gauss-Newton iteration as 36-byte rows for arap_applyFused
+            if (!symPath()) {     // the derivative columns of this Gauss-Newton iteration as 36-byte rows for arap_applyFused
                 if (A.nE > d9Capacity) { if (D9) HIP_CHECK(hipFree(D9)); d9Capacity = A.nE; HIP_CHECK(hipMalloc((void**)&D9, (size_t)9 * std::max<long>(1, d9Capacity) * sizeof(T))); }
                 ScopedKernel k(ctx, "packDerivativeRows");
                 arap_packD<T><<<edgeGrid(A.nE, cus), kBlock, 0, ctx.stream>>>(A.D, D9, (long)A.nE);
@@ -917,80 +812,55 @@ struct ArapOps : EnergyOps<T> {
     void applyJTJ(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) override {
         const int gv = vgrid(), ge = edgeGrid(A.nE, cus);
         if (symPath()) {
-            if (!symPvec) { ScopedKernel k(ctx, "packVertexRecords"); arap_packRec<T><<<gv, kBlock, 0, ctx.stream>>>(v, rec, A.N); }
+            { ScopedKernel k(ctx, "packVertexRecords"); arap_packRec<T><<<gv, kBlock, 0, ctx.stream>>>(v, rec, A.N); }
             ScopedKernel k(ctx, "PCGStep1");
             launchSym(v, out, CtC, dot, ctx);
             return;
         }
-        if (useGather && useFused) {
+        if (useGather) {
             GraphCsr G{outOff, outIdx, inOff, inIdx, nbr, nbr + std::max(1, A.nE)};
             ScopedKernel k(ctx, "PCGStep1");
             arap_applyFused<T><<<gv, kBlock, 0, ctx.stream>>>(A, G, D9, v, out, CtC, dot ? dot->partials : nullptr);
             if (dot) dot->n = gv;
             return;
         }
-        if (useGather) {
-            GraphCsr G{outOff, outIdx, inOff, inIdx};
-            { ScopedKernel k(ctx, "PCGStep1_Graph"); arap_edgeJp<T><<<ge, kBlock, 0, ctx.stream>>>(A, v, Jp, dot ? dot->partials + gv : nullptr); }
-            { ScopedKernel k(ctx, "PCGStep1"); arap_vertexGather<T><<<gv, kBlock, 0, ctx.stream>>>(A, G, v, Jp, out, CtC, dot ? dot->partials : nullptr); }   // gv <= kMaxPartials/2 workgroups, grid-stride over 16-vertex groups
-        } else {
+        {
             { ScopedKernel k(ctx, "PCGStep1"); arap_vertices<T, 3><<<gv, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, CtC, dot ? dot->partials : nullptr); }
             { ScopedKernel k(ctx, "PCGStep1_Graph"); arap_edges<T, 3><<<ge, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, dot ? dot->partials + gv : nullptr); }
         }
         if (dot) dot->n = gv + ge;
     }
-    int symLanes = ARAP_SYM_LANES;      // OPT_AMD_ARAP_SYM_LANES=1|2|4|8 (A/B switch)
-    bool symPvec = false;               // OPT_AMD_ARAP_SYM_PVEC=1 (A/B switch, see arap_applySym)
     int symGrid() const {               // all workgroups resident at once (4 per CU): a second, partial round of workgroups costs more than the longer grid-stride loops
         const int cap = symGridCap;
-        const long groups = (A.N + kBlock / symLanes - 1) / (kBlock / symLanes);
+        const long groups = (A.N + kBlock / ARAP_SYM_LANES - 1) / (kBlock / ARAP_SYM_LANES);
         return (int)std::max<long>(1, std::min<long>(groups, cap > 0 ? cap : std::min<long>(4L * cus, kMaxPartials / 2)));
     }
     int symGridCap = 0;                 // OPT_AMD_ARAP_VGRID (read per plan)
     int symXcd = 1;                     // OPT_AMD_ARAP_SYM_XCD=0: consecutive vertex groups on consecutive workgroups (A/B switch, see arap_applySym)
-    int symBatch = 4;                   // OPT_AMD_ARAP_SYM_BATCH=1|2|3|4: slots a lane requests together (a mesh vertex has ~6 neighbours: 3 per lane at two lanes per vertex); measured 31.0 / 34.9 / 32.6 / 29.3 us
-    template <bool PVEC, int BATCH> void launchSymPB(const T* v, T* out, const T* CtC, double* part, int g, LaunchCtx& ctx, const ArapIterSums& S) {
-        switch (symLanes) {
-            case 1: arap_applySym<T, 1, PVEC, BATCH><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part, symXcd && g % 8 == 0, S); break;
-            case 4: arap_applySym<T, 4, PVEC, BATCH><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part, symXcd && g % 8 == 0, S); break;
-            case 8: arap_applySym<T, 8, PVEC, BATCH><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part, symXcd && g % 8 == 0, S); break;
-            default: arap_applySym<T, 2, PVEC, BATCH><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part, symXcd && g % 8 == 0, S); break;
-        }
-    }
-    int symBatchIter = 1;               // ... and with the expansion sums of the two-kernel iteration in the same kernel (more live registers): 30.5 against 34.7 us with batches of 4
-    template <bool PVEC> void launchSymP(const T* v, T* out, const T* CtC, double* part, int g, LaunchCtx& ctx, const ArapIterSums& S) {
-        switch (S.r ? symBatchIter : symBatch) {
-            case 1: launchSymPB<PVEC, 1>(v, out, CtC, part, g, ctx, S); break;
-            case 2: launchSymPB<PVEC, 2>(v, out, CtC, part, g, ctx, S); break;
-            case 3: launchSymPB<PVEC, 3>(v, out, CtC, part, g, ctx, S); break;
-            default: launchSymPB<PVEC, 4>(v, out, CtC, part, g, ctx, S); break;
-        }
-    }
+    // slots a lane requests together: 4 for the plain J^T J p (a mesh vertex has ~6 neighbours, 3 per lane at two lanes per vertex: measured 31.0 / 34.9 / 32.6 / 29.3 us for 1 .. 4),
+    // 1 with the expansion sums of the two-kernel iteration in the same kernel (more live registers: 30.5 against 34.7 us)
     int launchSym(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx, const ArapIterSums& S = ArapIterSums{nullptr, nullptr, nullptr, nullptr, nullptr}) {
         const int g = symGrid();
         double* part = dot ? dot->partials : nullptr;
-        if (symPvec) launchSymP<true>(v, out, CtC, part, g, ctx, S); else launchSymP<false>(v, out, CtC, part, g, ctx, S);
+        if (S.r) arap_applySym<T, ARAP_SYM_LANES, 1><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part, symXcd && g % 8 == 0, S);
+        else arap_applySym<T, ARAP_SYM_LANES, 4><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part, symXcd && g % 8 == 0, S);
         if (dot) dot->n = g;
         return g;
     }
     // PCGStep3 of the previous iteration + PCGStep1 (symmetric-graph path): the flat pass that forms p = z + beta p also writes it into the vertex records the gather reads
     bool applyJTJFused(const T* pOld, const T* z, T* pNew, T* out, const T* CtC, Reduction* dot, const Reduction& bNum, const double* aNumOld, double* aNumNext, LaunchCtx& ctx) override {
-        if (!symPath() || symPvec) return false;
+        if (!symPath()) return false;
         { ScopedKernel k(ctx, "PCGStep3"); arap_step3Rec<T><<<vgrid(), kBlock, 0, ctx.stream>>>(z, pOld, pNew, rec, A.N, bNum.partials, bNum.n, aNumOld, aNumNext); }
         ScopedKernel k(ctx, "PCGStep1");
         launchSym(pNew, out, CtC, dot, ctx);
         return true;
     }
-    // ---- two kernels per Gauss-Newton PCG iteration instead of three (round 3): [PCGStep2 + PCGStep3 of iteration k-1 as one flat pass] + [PCGStep1 of iteration k with the sums of the
-    // expanded beta numerator].  Correct (all ARAP parity tests pass with it, final cost of config 4 equal to 8e-8) and MEASURED SLOWER, for the third time in three formulations:
-    // the flat part drops from 35.5 to 27.6 us per iteration, but the gather -- bound by how many dependent offset -> index -> record chains are in flight -- pays 13 us for
-    // the owner lane's r and M (requested before the edge walk) and its three extra sums (74 -> 87 us): config 4 217 -> 234 ms.  Off unless OPT_AMD_ARAP_ITER=1.
-    // On the symmetric-graph path (round 3, later) the balance is the other way round: arap_applySym is bound by HBM traffic, not by chains, the owner lane's r and M are 24 MB
-    // on top of 170, and the flat pass (arap_flatStepRec: delta, r, p and the records in one go) replaces 22 + 21 us of PCGStep2 and PCGStep3 -- there it is the default
-    // (OPT_AMD_ARAP_ITER=0 switches it off).
-    bool fusedIter = false; int fusedIterEnv = -1;
+    // ---- two kernels per Gauss-Newton PCG iteration instead of three on the symmetric-graph path: [PCGStep2 + PCGStep3 of iteration k-1 as one flat pass that also rewrites the
+    // records: arap_flatStepRec] + [PCGStep1 of iteration k with the sums of the expanded beta numerator: arap_applySym].  OPT_AMD_ARAP_ITER=0 keeps the reference's three
+    // kernels per iteration (the parity control).  On the edge-list gather of asymmetric graphs the same fusion lost in three formulations (profiles/NOTES.md) and is not offered.
+    int fusedIterEnv = -1;
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
-        if (symPath() && !symPvec && fusedIterEnv != 0 && !a.CtC && a.pre && !this->slab.active && A.N % 4 == 0 &&
+        if (symPath() && fusedIterEnv != 0 && !a.CtC && a.pre && !this->slab.active && A.N % 4 == 0 &&
             ((uintptr_t)a.delta | (uintptr_t)a.pOld | (uintptr_t)a.rOld | (uintptr_t)a.ApOld | (uintptr_t)a.pre | (uintptr_t)a.rNew | (uintptr_t)a.pNew) % 16 == 0) {
             const long n = 6 * A.N, nPad = (n + 3) / 4 * 4;
             if (a.first) {      // the solver adopts rNew / pNew after every launch: the start state moves there unchanged
@@ -1008,25 +878,7 @@ struct ArapOps : EnergyOps<T> {
             a.aNum->n = a.aDen->n = a.s2->n = a.s3->n = g;
             return true;
         }
-        if (!fusedIter || !useGather || !useFused || a.CtC || !a.pre || this->slab.active) return false;
-        const long n = 6 * A.N, nPad = (n + 3) / 4 * 4, nPacks = nPad * (long)sizeof(T) / 16;
-        if (a.first) {      // the solver adopts rNew / pNew after every launch: the start state moves there unchanged
-            HIP_CHECK(hipMemcpyAsync(a.rNew, a.rOld, nPad * sizeof(T), hipMemcpyDeviceToDevice, ctx.stream));
-            HIP_CHECK(hipMemcpyAsync(a.pNew, a.pOld, nPad * sizeof(T), hipMemcpyDeviceToDevice, ctx.stream));
-        } else {
-            ScopedKernel k(ctx, "PCGStep2+PCGStep3");
-            const int g = (int)std::max<long>(1, std::min<long>((nPacks + kBlock - 1) / kBlock, (long)cus * 8));
-            arap_flatStep<T><<<g, kBlock, 0, ctx.stream>>>(a.delta, a.pOld, a.rOld, a.ApOld, a.pre, a.rNew, a.pNew, nPacks, a.aNumPrev.partials, a.aNumPrev.n, a.aDenPrev.partials, a.aDenPrev.n,
-                                                          a.s2Prev.partials, a.s2Prev.n, a.s3Prev.partials, a.s3Prev.n);
-        }
-        {
-            const int gv = vgrid();
-            GraphCsr G{outOff, outIdx, inOff, inIdx, nbr, nbr + std::max(1, A.nE)};
-            ScopedKernel k(ctx, "PCGStep1");
-            arap_applyFused<T><<<gv, kBlock, 0, ctx.stream>>>(A, G, D9, a.pNew, a.ApNew, nullptr, a.aDen->partials, ArapIterSums{a.rNew, a.pre, a.aNum->partials, a.s2->partials, a.s3->partials});
-            a.aNum->n = a.aDen->n = a.s2->n = a.s3->n = gv;
-        }
-        return true;
+        return false;
     }
     void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {
         const int gv = vgrid(), ge = edgeGrid(A.nE, cus);

@@ -13,13 +13,11 @@
 // read them through those stored gradients (o.t:913-925).  The same structure is kept here: sfs_precompute
 // writes B_I, dB_I/d{d0,d1,d2} and valid; everything else is linear algebra on those images.
 //
-// Kernel structure.  The shading rows couple a pixel with a 2-pixel neighbourhood (5 unknowns per row, 15
-// rows touching each unknown), so J^T J p is evaluated as two stencil passes instead of one wide gather:
-//   sfs_rows   : for every pixel, the 5 coupled residual rows -> q_r = r (for J^T F) or (J v)_r (for J^T J v),
-//                or directly the reduced cost / model cost;
-//   sfs_gather : out(c) = sum over the <= 16 rows that touch X_c of dr/dX_c * q_r  (+ diag, + CtC v).
-// Both are radius-1 stencils over W*H doubles; at the 1024^2 config every array involved sits in the 256 MB
-// Infinity Cache, so they are cache-bandwidth bound and kept simple.
+// Kernel structure.  The shading rows couple a pixel with a 2-pixel neighbourhood (5 unknowns per row, 15 rows touching each unknown), so J^T J p is evaluated
+// as row values (J v)_r of the five coupled residual rows of every pixel followed by a gather  out(c) = sum over the <= 16 rows that touch X_c of dr/dX_c * q_r:
+//   sfs_pcgMarch  : one whole PCG iteration per launch as a row march (registers + DPP); with JTF = true the same march is PCGInit1 (+ PCGFinalizeDiagonal for LM);
+//   sfs_costMarch : cost / model cost on the same layout;   sfs_applyTiled : plain J^T J v through LDS tiles for probes and the LM residual reset.
+// At the 1024^2 config every array involved sits in the 256 MB Infinity Cache: the kernels are bound by cache bandwidth and by their seams, not by HBM.
 #include "energy.h"
 #include <cstdint>
 
@@ -34,7 +32,6 @@ struct SArgs {
     T *B_I, *g0, *g1, *g2, *valid;     // ComputedArrays + gradient images
     uint32_t* fl2;                     // fl | edgeMaskR << 8 | edgeMaskC << 16: one word per pixel for sfs_pcgMarch (one load, one register, one DPP move per neighbour)
     uint8_t* fl;                       // bit 0: D_i > 0 (the unknown is not excluded), bit 1: valid == 1 -- one byte for the marching iteration kernel instead of two doubles
-    T* q;                              // 5 row values per pixel: [gh, gv, s0, s1, s2] planes
 };
 
 // 3-partial forward-mode scalar for the precompute kernel (the chain rule through the normalised normal)
@@ -98,144 +95,21 @@ template <class T> __device__ __forceinline__ T coefK(const SArgs<T>& A, int k, 
     return k == 0 ? ((T)x - A.u_x) / A.f_x : k == 1 ? ((T)y - A.u_y) / A.f_y : T(1);
 }
 
-// MODE 0: cost partials; 1: model-cost partials (v = delta); 2: q = residual values; 3: q = J v
-template <class T, int MODE>
-__global__ __launch_bounds__(kBlock) void sfs_rows(SArgs<T> A, const T* __restrict__ v, double* __restrict__ partials) {
-    __shared__ double scratch[kBlock / kWave + 1];
-    const long N = (long)A.W * A.H;
-    double acc = 0;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < N; e += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(e % A.W), y = (int)(e / A.W);
-        const bool in1 = sfs_interior(A, x, y);
-        const bool dvalid = A.D_i[e] > T(0);
-        T rp = 0, rgh = 0, rgv = 0, rs[3] = {0, 0, 0};       // residual values
-        T jp = 0, jgh = 0, jgv = 0, js[3] = {0, 0, 0};       // (J v) per row
-        const bool needR = MODE != 3, needJ = MODE == 1 || MODE == 3;
-        if (dvalid) { if (needR) rp = A.w_p * (A.X[e] - A.D_i[e]); if (needJ) jp = A.w_p * v[e]; }
-        {   // branch-free: a border pixel reads the addresses of the interior pixel (1,1) and masks the results, so the loads
-            // are not queued up behind `if (interior)` / `if (valid)`
-            const long c = in1 ? e : (long)A.W + 1;
-            const long er = c + 1, ed = c + A.W;
-            const T mr = (T)A.mR[c], mc = (T)A.mC[c];
-            if (needR) { rgh = A.w_g * ((A.B_I[c] - A.B_I[er]) * mr); rgv = A.w_g * ((A.B_I[c] - A.B_I[ed]) * mc); }
-            if (needJ) {
-                const T base = A.g1[c] * v[c] + A.g0[c] * v[c - 1] + A.g2[c] * v[c - A.W];          // d B_I(c) . v
-                const T right = A.g1[er] * v[er] + A.g0[er] * v[c] + A.g2[er] * v[er - A.W];         // d B_I(c+ex) . v
-                const T down = A.g1[ed] * v[ed] + A.g0[ed] * v[ed - 1] + A.g2[ed] * v[c];            // d B_I(c+ey) . v
-                jgh = A.w_g * mr * (base - right); jgv = A.w_g * mc * (base - down);
-            }
-            const bool vok = in1 && A.valid[c] == T(1);
-            {
-                const long nb[5] = {c, c - 1, c - A.W, c + 1, c + A.W};
-                const int ox[5] = {0, -1, 0, 1, 0}, oy[5] = {0, 0, -1, 0, 1};
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    T sr = 0, sj = 0;
-#pragma unroll
-                    for (int u = 0; u < 5; ++u) {
-                        const T cf = (u == 0 ? T(4) : T(-1)) * coefK(A, k, x + ox[u], y + oy[u]);
-                        if (needR) sr += cf * A.X[nb[u]];
-                        if (needJ) sj += cf * v[nb[u]];
-                    }
-                    rs[k] = vok ? A.w_s * sr : T(0); js[k] = vok ? A.w_s * sj : T(0);
-                }
-            }
-            if (!in1) { rgh = 0; rgv = 0; jgh = 0; jgv = 0; }
-        }
-        if (MODE == 0 || MODE == 1) {
-            if (dvalid) {   // rows centred on excluded pixels are not part of the cost (solver.t:583, 669)
-                const T a = rp + jp, b = rgh + jgh, c = rgv + jgv, d0 = rs[0] + js[0], d1 = rs[1] + js[1], d2 = rs[2] + js[2];
-                acc += (double)(T(0.5) * (a * a + b * b + c * c + d0 * d0 + d1 * d1 + d2 * d2));
-            }
-        } else {
-            const bool J = MODE == 3;
-            A.q[e] = J ? jgh : rgh; A.q[N + e] = J ? jgv : rgv;
-            A.q[2 * N + e] = J ? js[0] : rs[0]; A.q[3 * N + e] = J ? js[1] : rs[1]; A.q[4 * N + e] = J ? js[2] : rs[2];
-        }
-    }
-    if (MODE == 0 || MODE == 1) {
-        double t = blockReduceSum(acc, scratch);
-        if (threadIdx.x == 0) partials[blockIdx.x] = t;
-    }
-}
-
-// out(c) = sum_rows dr/dX_c * q_r.  JTF: out = -(...) and diag = sum (dr/dX_c)^2;  JTJ: out = ... (+ CtC v), dot partials.
-template <class T, bool JTF, bool LM>
-__global__ __launch_bounds__(kBlock) void sfs_gather(SArgs<T> A, const T* __restrict__ v, T* __restrict__ out, T* __restrict__ diag, const T* __restrict__ CtC,
-                                                     double* __restrict__ partials) {
-    __shared__ double scratch[kBlock / kWave + 1];
-    const long N = (long)A.W * A.H;
-    const T* qgh = A.q; const T* qgv = A.q + N; const T* qs = A.q + 2 * N;
-    double acc = 0;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < N; e += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(e % A.W), y = (int)(e / A.W);
-        T s = 0, d = 0;
-        if (A.D_i[e] > T(0)) {
-            auto add = [&](T coef, T q) { s += coef * q; if (JTF) d += coef * coef; };
-            // fitting row at c (its q is recomputed: one multiply)
-            { const T q = JTF ? A.w_p * (A.X[e] - A.D_i[e]) : A.w_p * v[e]; add(A.w_p, q); }
-            // shading rows: which (row centre c', slot) pairs contain X_c -- see the header comment of sfs_rows.  Branch-free: a row
-            // centre outside the interior reads this pixel's (valid) addresses and gets coefficient 0, so every load of the pixel
-            // can be in flight at once instead of one behind each `if`.
-            auto centre = [&](int cx, int cy, bool& ok) { ok = sfs_interior(A, cx, cy); return ok ? (long)cy * A.W + cx : (x >= 1 && x <= A.W - 2 && y >= 1 && y <= A.H - 2 ? e : (long)A.W + 1); };
-            auto gh = [&](int cx, int cy, int slot) {
-                bool ok; const long c = centre(cx, cy, ok), cr = c + 1;
-                const T m = A.w_g * (T)A.mR[c];
-                T coef = slot == 0 ? m * (A.g1[c] - A.g0[cr]) : slot == 1 ? m * A.g0[c] : slot == 2 ? m * A.g2[c] : slot == 3 ? -(m * A.g1[cr]) : -(m * A.g2[cr]);
-                coef = ok ? coef : T(0);
-                add(coef, qgh[c]);
-            };
-            auto gv = [&](int cx, int cy, int slot) {
-                bool ok; const long c = centre(cx, cy, ok), cd = c + A.W;
-                const T m = A.w_g * (T)A.mC[c];
-                T coef = slot == 0 ? m * (A.g1[c] - A.g2[cd]) : slot == 1 ? m * A.g0[c] : slot == 2 ? m * A.g2[c] : slot == 3 ? -(m * A.g1[cd]) : -(m * A.g0[cd]);
-                coef = ok ? coef : T(0);
-                add(coef, qgv[c]);
-            };
-            gh(x, y, 0); gh(x + 1, y, 1); gh(x, y + 1, 2); gh(x - 1, y, 3); gh(x - 1, y + 1, 4);
-            gv(x, y, 0); gv(x + 1, y, 1); gv(x, y + 1, 2); gv(x, y - 1, 3); gv(x + 1, y - 1, 4);
-            // regularisation rows centred at c and its 4 neighbours
-            const int ox[5] = {0, 1, -1, 0, 0}, oy[5] = {0, 0, 0, 1, -1};
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                bool ok; const long c = centre(x + ox[u], y + oy[u], ok);
-                ok = ok && A.valid[c] == T(1);
-                const T wgt = ok ? A.w_s * (u == 0 ? T(4) : T(-1)) : T(0);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) add(wgt * coefK(A, k, x, y), qs[(long)k * N + c]);
-            }
-        }
-        if (JTF) { out[e] = -s; diag[e] = d; }
-        else {
-            if (LM) s += CtC[e] * v[e];
-            if (!(A.D_i[e] > T(0))) s = 0;
-            out[e] = s;
-            acc += (double)(v[e] * s);
-        }
-    }
-    if (!JTF) {
-        double t = blockReduceSum(acc, scratch);
-        if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
-    }
-}
-
 // J^T J v in one launch through LDS: a workgroup owns a 32 x 8 tile of pixels, stages v and the gradient / mask images of the tile
-// plus a 2-pixel apron once, forms the five row values (J v)_r of every row centre in the tile + 1-pixel ring in LDS (what sfs_rows<3>
-// writes to the q planes), and gathers from there (what sfs_gather<false> reads back).  Same expressions in the same order as the
-// two passes; HBM traffic ~90 B/px instead of ~290 B/px, one launch instead of two.
+// plus a 2-pixel apron once, forms the five row values (J v)_r of every row centre in the tile + 1-pixel ring in LDS, and gathers from there
+// (out(c) = sum over the <= 16 rows that touch X_c of dr/dX_c * (J v)_r, + CtC v): ~90 B/px of HBM traffic.
 #ifndef SFS_TW
 #define SFS_TW 32
 #define SFS_TH 8
 #endif
 constexpr int kSfsTW = SFS_TW, kSfsTH = SFS_TH;
-// ITER = true turns the same kernel into ONE WHOLE PCG ITERATION (energy.h PcgIterArgs; the scheme of iw_pcgIter with A p kept in memory,
-// because recomputing it would need a 4-pixel apron here): while staging the tile + apron a workgroup first applies PCGStep2 and PCGStep3 of
-// the previous iteration to every pixel it stages -- r_k = r - alpha Ap_{k-1}, z_k = r_k (this energy does not precondition: pre = 1 after
-// the start, solver.t:467-472), p_k = r_k + beta p_{k-1} -- writes r_k, p_k, delta += alpha p_{k-1} (and the Q partial sums for LM) for its
-// own tile, and then applies J^T J (+ CtC) to the staged p_k.  betaNumerator = sum r_k^2 comes from the previous launch's sums by expansion:
-// rr - 2 alpha s2 + alpha^2 s3 with rr = sum r_{k-1}^2, s2 = r.Ap, s3 = Ap.Ap.  The start is the reference's: p_0 comes from memory
-// (PCGInit1: r_0 / 4; LM: the Jacobi-preconditioned r_0 of PCGFinalizeDiagonal, solver.t:650-656) and alphaNumerator_0 = r_0 . p_0, so launch 0
-// also sums rr_0 = r_0 . r_0 for launch 1's expansion.  Per PCG iteration: one launch instead of three (PCGStep1, PCGStep2, PCGStep3).
+// It serves probes and the LM residual reset (computeAdelta); the PCG loop runs on sfs_pcgMarch below.
+// Arguments of the one-launch-per-iteration kernel (energy.h PcgIterArgs; A p is kept in memory: recomputing it would need a 4-pixel ring).  Launch k first applies
+// PCGStep2 and PCGStep3 of the previous iteration to every pixel it stages -- r_k = r - alpha Ap_{k-1}, z_k = r_k (this energy does not precondition: pre = 1 after
+// the start, solver.t:467-472), p_k = r_k + beta p_{k-1} -- writes r_k, p_k, delta += alpha p_{k-1} (and the Q partial sums for LM) for its own rows, then applies
+// J^T J (+ CtC) to p_k.  betaNumerator = sum r_k^2 comes from the previous launch's sums by expansion: rr - 2 alpha s2 + alpha^2 s3 with rr = sum r_{k-1}^2,
+// s2 = r.Ap, s3 = Ap.Ap.  The start is the reference's: p_0 comes from memory (PCGInit1: r_0 / 4; LM: the Jacobi-preconditioned r_0 of PCGFinalizeDiagonal,
+// solver.t:650-656) and alphaNumerator_0 = r_0 . p_0, so launch 0 also sums rr_0 = r_0 . r_0 for launch 1's expansion.
 template <class T>
 struct SIterK {
     const T *rOld, *ApOld, *pOld; T *rNew, *pNew; const T* delta; T* deltaOut; const T* b; double* q; unsigned qTag;
@@ -244,34 +118,12 @@ struct SIterK {
     const double *betaNum, *betaDen; int nBetaNum, nBetaDen;
     double *aNum, *aDen, *s2, *s3, *rr;
 };
-template <class T, bool LM, bool ITER = false>
-__global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ CtC, double* __restrict__ partials,
-                                                         SIterK<T> K = SIterK<T>{}) {
+template <class T, bool LM>
+__global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ CtC, double* __restrict__ partials) {
     constexpr int TW = kSfsTW, TH = kSfsTH, VW = TW + 4, VH = TH + 4, QW = TW + 2, QH = TH + 2;
     static_assert(TW * TH == kBlock, "one thread per tile pixel");
-    __shared__ double scratch[6 * (kBlock / kWave + 1)];
+    __shared__ double scratch[kBlock / kWave + 1];
     __shared__ T sv[VH][VW], s0[VH][VW], s1[VH][VW], s2[VH][VW];      // v, g0, g1, g2 on the tile + 2 apron (index [y+2][x+2])
-    __shared__ T sr[ITER ? VH : 1][ITER ? VW : 1];                    // ITER: r_k on the same footprint
-    __shared__ T sp[ITER ? VH : 1][ITER ? VW : 1];                    // ITER: p_{k-1} (the own pixel's delta update needs it)
-    T alpha = 0, beta = 0;
-    const bool keep = ITER && (K.first != 0 || K.restart != 0);       // r (and, at the start, p) are already those of this iteration
-    if (ITER) {
-        if (K.restart) {
-            const double* const ps[2] = {K.betaNum, K.betaDen}; const int ns[2] = {K.nBetaNum, K.nBetaDen}; double o2[2];
-            sumPartialsN<2>(ps, ns, scratch, o2);
-            const T bNum = (T)o2[0], bDen = (T)o2[1];
-            beta = (bDen > T(0)) ? bNum / bDen : T(0);                // solver.t:544-547
-        } else if (!K.first) {
-            const double* const ps[5] = {K.aNumPrev, K.aDenPrev, K.s2Prev, K.s3Prev, K.rrPrev}; const int ns[5] = {K.nNum, K.nDen, K.n2, K.n3, K.rrFromPrivate ? K.nRR : 0}; double o5[5];
-            sumPartialsN<5>(ps, ns, scratch, o5);
-            const T aNum = (T)o5[0], aDen = (T)o5[1];
-            alpha = (aDen > T(0)) ? aNum / aDen : T(0);               // solver.t:456-459
-            const double rr = K.rrFromPrivate ? o5[4] : o5[0];        // sum r_{k-1}^2: the previous launch's alphaNumerator, except right after the start
-            const double bNumD = fmax(rr - 2.0 * (double)alpha * o5[2] + (double)alpha * (double)alpha * o5[3], 0.0);
-            beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
-        }
-    }
-    double accNum = 0, acc2 = 0, acc3 = 0, accRR = 0, accQ = 0;
     __shared__ T sq[5][QH][QW];                                       // gh, gv, s0..s2 row values on the tile + 1 ring (index [y+1][x+1])
     __shared__ uint8_t smr[QH][QW], smc[QH][QW], sok[QH][QW], svalid[QH][QW];
     // P(u) coefficients (i_u - u_x) / f_x and (j_u - u_y) / f_y of the tile's columns / rows: one division per column and row of the footprint instead of
@@ -283,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
     // flight while tile t goes through its three LDS phases, so a workgroup pays the global latency once instead of twice per tile (the
     // own-pixel inputs of the gather phase -- D_i, CtC, delta, b -- used to be a second dependent round trip at the end of every tile).
     constexpr int NV = (VW * VH + kBlock - 1) / kBlock, NQ = (QW * QH + kBlock - 1) / kBlock;      // staged pixels per thread: 2 and 2
-    struct Pre { T a[NV], b[NV], c[NV], g0[NV], g1[NV], g2[NV]; T vl[NQ]; uint8_t mr[NQ], mc[NQ]; T Di, ctc, dl, bb; };
+    struct Pre { T a[NV], g0[NV], g1[NV], g2[NV]; T vl[NQ]; uint8_t mr[NQ], mc[NQ]; T Di, ctc; };
     auto fetch = [&](int t) {
         Pre P;
         const int x0 = (t % tilesX) * TW, y0 = (t / tilesX) * TH;
@@ -292,8 +144,7 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
             const int i = min((int)threadIdx.x + j * kBlock, VW * VH - 1);
             const int lx = i % VW, ly = i / VW, gx = x0 + lx - 2, gy = y0 + ly - 2;
             const long g = (long)min(max(gy, 0), A.H - 1) * A.W + min(max(gx, 0), A.W - 1);      // clamped: no branch around a load; masked when staged
-            if (ITER) { P.a[j] = K.rOld[g]; P.b[j] = K.pOld[g]; P.c[j] = (K.first || K.restart) ? T(0) : K.ApOld[g]; }
-            else { P.a[j] = v[g]; P.b[j] = 0; P.c[j] = 0; }
+            P.a[j] = v[g];
             P.g0[j] = A.g0[g]; P.g1[j] = A.g1[g]; P.g2[j] = A.g2[g];
         }
 #pragma unroll
@@ -309,10 +160,8 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
 #ifndef SFS_LATE_OWN
 #define SFS_LATE_OWN 1      // 1: the own-pixel inputs of the gather phase are loaded there instead of with the tile (8 fewer live registers; config 3: 42.1 against 42.9 ms); 0 with SFS_PREFETCH
 #endif
-            if (!SFS_LATE_OWN) {
-                P.Di = A.D_i[e]; P.ctc = LM ? CtC[e] : T(0);
-                P.dl = (ITER && !(K.first || K.restart)) ? K.delta[e] : T(0); P.bb = (ITER && LM && !(K.first || K.restart)) ? K.b[e] : T(0);
-            } else { P.Di = 0; P.ctc = 0; P.dl = 0; P.bb = 0; }
+            if (!SFS_LATE_OWN) { P.Di = A.D_i[e]; P.ctc = LM ? CtC[e] : T(0); }
+            else { P.Di = 0; P.ctc = 0; }
         }
         return P;
     };
@@ -334,17 +183,7 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
             if (i < VW * VH) {
                 const int lx = i % VW, ly = i / VW, gx = x0 + lx - 2, gy = y0 + ly - 2;
                 const bool in = gx >= 0 && gx < A.W && gy >= 0 && gy < A.H;
-                if (ITER) {
-                    T rk = 0, pk = 0;
-                    if (in) {
-                        const long g = (long)gy * A.W + gx;
-                        const T ro = cur.a[j], po = cur.b[j];
-                        rk = keep ? ro : ro - alpha * cur.c[j];                                     // PCGStep2 (solver.t:464)
-                        pk = K.first ? po : rk + beta * po;                                         // PCGStep3 with z = r (solver.t:549)
-                        if (lx >= 2 && lx < TW + 2 && ly >= 2 && ly < TH + 2) { K.rNew[g] = rk; K.pNew[g] = pk; }     // this workgroup's own tile
-                    }
-                    sr[ly][lx] = rk; sv[ly][lx] = pk; sp[ly][lx] = cur.b[j];
-                } else sv[ly][lx] = in ? cur.a[j] : T(0);
+                sv[ly][lx] = in ? cur.a[j] : T(0);
                 s0[ly][lx] = in ? cur.g0[j] : T(0); s1[ly][lx] = in ? cur.g1[j] : T(0); s2[ly][lx] = in ? cur.g2[j] : T(0);
             }
         }
@@ -393,10 +232,7 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
         if (x < A.W && y < A.H) {
             const long e = (long)y * A.W + x;
             const T ve = sv[ty + 2][tx + 2];
-            if (SFS_LATE_OWN) {
-                cur.Di = A.D_i[e]; cur.ctc = LM ? CtC[e] : T(0);
-                cur.dl = (ITER && !(K.first || K.restart)) ? K.delta[e] : T(0); cur.bb = (ITER && LM && !(K.first || K.restart)) ? K.b[e] : T(0);
-            }
+            if (SFS_LATE_OWN) { cur.Di = A.D_i[e]; cur.ctc = LM ? CtC[e] : T(0); }
             T s = 0;
             {   // (branch-free like the row values above; an excluded pixel's sum is discarded by the select below)
                 auto add = [&](T coef, T q) { s += coef * q; };
@@ -431,45 +267,24 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
             if (!(cur.Di > T(0))) s = 0;
             out[e] = s;
             acc += (double)(ve * s);
-            if (ITER) {
-                const T rk = sr[ty + 2][tx + 2];
-                const T zk = K.first ? ve : rk;                                                 // launch 0: alphaNumerator_0 = r_0 . p_0 (the reference's start)
-                accNum += (double)(zk * rk); acc2 += (double)(rk * s); acc3 += (double)(s * s);
-                if (K.first) accRR += (double)(rk * rk);
-                if (!keep) {                                                                    // the rest of PCGStep2 of iteration k-1 for this pixel
-                    const T dl = cur.dl + alpha * sp[ty + 2][tx + 2];                           // solver.t:461-462
-                    K.deltaOut[e] = dl;
-                    if (LM) accQ += (double)(T(0.5) * (dl * (rk + cur.bb)));                    // solver.t:483-485
-                }
-            }
         }
 #if SFS_PREFETCH
         cur = nxt;
 #endif
     }
-    if (ITER) {
-        double vv[6] = {acc, accNum, acc2, acc3, accRR, accQ};
-        blockReduceSumN<6>(vv, scratch);
-        if (threadIdx.x == 0) {
-            K.aDen[blockIdx.x] = vv[0]; K.aNum[blockIdx.x] = vv[1]; K.s2[blockIdx.x] = vv[2]; K.s3[blockIdx.x] = vv[3];
-            if (K.first) K.rr[blockIdx.x] = vv[4];
-            if (LM && K.q) { if (K.qTag) storeTaggedPartial(K.q, blockIdx.x, vv[5], K.qTag); else K.q[blockIdx.x] = vv[5]; }
-        }
-    } else {
-        double t = blockReduceSum(acc, scratch);
-        if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
-    }
+    double t = blockReduceSum(acc, scratch);
+    if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
 }
 
-// ---- the same PCG iteration as a ROW-MARCHING kernel (round 3) ---------------------------------------------------------------------------------
-// sfs_applyTiled<.., ITER> is latency-bound: three barrier-separated LDS phases per 32 x 8 tile, a 36 x 12 footprint staged for 256 outputs (1.7 x), 0.49 of
-// the HBM peak on a problem that sits in the Infinity Cache.  sfs_pcgMarch does the same work in the layout of image_warping's iteration
+// ---- the PCG iteration as a ROW-MARCHING kernel ---------------------------------------------------------------------------------------------------------
+// (An LDS-tiled form -- three barrier-separated phases per 32 x 8 tile, a 36 x 12 footprint staged for 256 outputs -- was latency-bound at 0.49 of the HBM peak and
+// is gone since round 4.)  sfs_pcgMarch works in the layout of image_warping's iteration
 // kernel: a wave owns 64 consecutive columns (the inner 60 are outputs; two halo lanes per side, because a pixel's gather reads row values on its 1-ring and
 // those read p_k on their 1-ring) and marches down a range of rows, a lane keeping four staged rows of its column, two rows of dB.v and three rows of the five
 // row values in registers.  Vertical neighbours cost nothing, horizontal ones are DPP wave shifts; there is no LDS staging and no barrier in the loop.
 // Trip Y stages row Y (PCGStep2 + PCGStep3 of the previous iteration: r_k, p_k, and for the rows the workgroup owns the stores of r_k, p_k, delta and the Q
 // sum), forms b(Y) = dB_I(., Y) . p_k, the five row values (J p_k)_r of the centres of row Y - 1, and the gather of row Y - 2 -- the expressions of
-// sfs_applyTiled in the same order, so the results are the tiled kernel's bit for bit.
+// sfs_applyTiled in the same order.
 template <class T> struct SRaw { T r, p, ap, g0, g1, g2, ctc, dl, bb; int fb; };      // JTF mode: r = X, p = B_I, dl = D_i;  fb = SArgs::fl2 (flags and both edge masks in one word)
 template <class T> struct SRow {
     T v, rk;               // p_k (what J^T J is applied to), r_k        (JTF mode: X, B_I)
@@ -803,18 +618,12 @@ struct SfsOps : EnergyOps<T> {
         const size_t n = (size_t)A.W * A.H;
         T** imgs[5] = {&A.B_I, &A.g0, &A.g1, &A.g2, &A.valid};
         for (auto pp : imgs) { HIP_CHECK(hipMalloc((void**)pp, n * sizeof(T))); HIP_CHECK(hipMemset(*pp, 0, n * sizeof(T))); owned.push_back(*pp); }
-        HIP_CHECK(hipMalloc((void**)&A.q, 5 * n * sizeof(T))); owned.push_back(A.q);
         HIP_CHECK(hipMalloc((void**)&A.fl, n)); HIP_CHECK(hipMemset(A.fl, 0, n)); owned.push_back(A.fl);
         HIP_CHECK(hipMalloc((void**)&A.fl2, 4 * n)); HIP_CHECK(hipMemset(A.fl2, 0, 4 * n)); owned.push_back(A.fl2);
         int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        if (const char* e = getenv("OPT_AMD_SFS_TILED")) tiledApply = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_SFS_ONEKERNEL")) oneKernel = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_SFS_GRID")) gridOverride = atoi(e);
-        if (const char* e = getenv("OPT_AMD_SFS_MARCH")) marchIter = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_SFS_MARCH_GRID")) marchGridOverride = atoi(e);
-        if (const char* e = getenv("OPT_AMD_SFS_MARCH_JTF")) marchJtf = atoi(e) != 0;
-        if (const char* e = getenv("OPT_AMD_SFS_MARCH_COST")) marchCost = atoi(e) != 0;
-        if (const char* e = getenv("OPT_AMD_SFS_MARCH_FIN")) marchFin = atoi(e) != 0;
     }
     ~SfsOps() override { for (void* p : owned) (void)hipFree(p); }
     int grid() const { return (int)std::max<long>(1, std::min<long>(((long)A.W * A.H + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
@@ -829,25 +638,16 @@ struct SfsOps : EnergyOps<T> {
     void precompute(LaunchCtx& ctx) override { ScopedKernel k(ctx, "precompute"); sfs_precompute<T><<<grid(), kBlock, 0, ctx.stream>>>(A); }
     void evalCost(Reduction& out, LaunchCtx& ctx) override {
         ScopedKernel k(ctx, "computeCost");
-        if (marchIter && marchCost) {
-            int gx, gy, rows, per; marchGrid(false, gx, gy, rows, per);
-            sfs_costMarch<T, false><<<8 * per * gx, kSfsMarchBlock, 0, ctx.stream>>>(A, nullptr, out.partials, rows, gx, gy, per); out.n = 8 * per * gx;
-            return;
-        }
-        sfs_rows<T, 0><<<grid(), kBlock, 0, ctx.stream>>>(A, nullptr, out.partials); out.n = grid();
+        int gx, gy, rows, per; marchGrid(false, gx, gy, rows, per);
+        sfs_costMarch<T, false><<<8 * per * gx, kSfsMarchBlock, 0, ctx.stream>>>(A, nullptr, out.partials, rows, gx, gy, per); out.n = 8 * per * gx;
     }
     void evalJTF(T* r, T* diag, LaunchCtx& ctx) override {
-        if (marchIter && marchJtf) {      // rows + gather in one marching launch (round 3)
-            ScopedKernel k(ctx, "PCGInit1");
-            int gx, gy, rows, per; marchGrid(false, gx, gy, rows, per);
-            sfs_pcgMarch<T, false, true><<<8 * per * gx, kSfsMarchBlock, 0, ctx.stream>>>(A, r, nullptr, SIterK<T>{}, rows, gx, gy, per, diag);
-            return;
-        }
-        { ScopedKernel k(ctx, "PCGInit1_rows"); sfs_rows<T, 2><<<grid(), kBlock, 0, ctx.stream>>>(A, nullptr, nullptr); }
-        { ScopedKernel k(ctx, "PCGInit1"); sfs_gather<T, true, false><<<grid(), kBlock, 0, ctx.stream>>>(A, nullptr, r, diag, nullptr, nullptr); }
+        ScopedKernel k(ctx, "PCGInit1");      // row values + gather in one marching launch
+        int gx, gy, rows, per; marchGrid(false, gx, gy, rows, per);
+        sfs_pcgMarch<T, false, true><<<8 * per * gx, kSfsMarchBlock, 0, ctx.stream>>>(A, r, nullptr, SIterK<T>{}, rows, gx, gy, per, diag);
     }
     bool evalJTFInitLM(const LmInitArgs<T>& a, LaunchCtx& ctx) override {
-        if (!(marchIter && marchJtf && marchFin) || this->slab.active) return false;
+        if (this->slab.active) return false;
         ScopedKernel k(ctx, "PCGInit1");
         int gx, gy, rows, per; marchGrid(false, gx, gy, rows, per);
         const int g = 8 * per * gx;
@@ -856,17 +656,14 @@ struct SfsOps : EnergyOps<T> {
         a.rDotP->n = g; a.q->n = g;
         return true;
     }
-    bool marchFin = true;       // OPT_AMD_SFS_MARCH_FIN=0: PCGFinalizeDiagonal as the solver's flat pass
-    bool tiledApply = true;     // OPT_AMD_SFS_TILED=0: rows pass + gather pass through the q planes
     // Grid of the tiled kernels: every workgroup loops over tiles, so the grid is capped at what is co-resident (LDS-limited: 4-5 workgroups per CU);
     // with more, the last round of workgroups runs on a partly empty chip (2048 workgroups on 1280 slots: 1.6 rounds).  OPT_AMD_SFS_GRID overrides (A/B).
-    int occTiled[2][2] = {{0, 0}, {0, 0}}; int gridOverride = 0;
-    int tileGrid(bool lmv = false, bool iter = false) {
+    int occTiled[2] = {0, 0}; int gridOverride = 0;
+    int tileGrid(bool lmv) {
         const long t = (long)((A.W + kSfsTW - 1) / kSfsTW) * ((A.H + kSfsTH - 1) / kSfsTH);
-        int& o = occTiled[lmv][iter];
+        int& o = occTiled[lmv];
         if (o == 0) {
-            const void* fn = lmv ? (iter ? (const void*)sfs_applyTiled<T, true, true> : (const void*)sfs_applyTiled<T, true, false>)
-                                 : (iter ? (const void*)sfs_applyTiled<T, false, true> : (const void*)sfs_applyTiled<T, false, false>);
+            const void* fn = lmv ? (const void*)sfs_applyTiled<T, true> : (const void*)sfs_applyTiled<T, false>;
             HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, fn, kBlock, 0));
             o = std::max(1, std::min(o, 8));
         }
@@ -874,34 +671,19 @@ struct SfsOps : EnergyOps<T> {
         return (int)std::max<long>(1, std::min<long>(t, std::min<long>(kMaxPartials / 2, cap)));
     }
     void applyJTJ(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) override {
-        if (tiledApply) {
-            ScopedKernel k(ctx, "PCGStep1");
-            const int g = tileGrid(CtC != nullptr, false);
-            if (CtC) sfs_applyTiled<T, true><<<g, kBlock, 0, ctx.stream>>>(A, v, out, CtC, dot ? dot->partials : nullptr);
-            else sfs_applyTiled<T, false><<<g, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, dot ? dot->partials : nullptr);
-            if (dot) dot->n = g;
-            return;
-        }
-        { ScopedKernel k(ctx, "PCGStep1_rows"); sfs_rows<T, 3><<<grid(), kBlock, 0, ctx.stream>>>(A, v, nullptr); }
-        { ScopedKernel k(ctx, "PCGStep1");
-          if (CtC) sfs_gather<T, false, true><<<grid(), kBlock, 0, ctx.stream>>>(A, v, out, nullptr, CtC, dot ? dot->partials : nullptr);
-          else sfs_gather<T, false, false><<<grid(), kBlock, 0, ctx.stream>>>(A, v, out, nullptr, nullptr, dot ? dot->partials : nullptr); }
-        if (dot) dot->n = grid();
+        ScopedKernel k(ctx, "PCGStep1");
+        const int g = tileGrid(CtC != nullptr);
+        if (CtC) sfs_applyTiled<T, true><<<g, kBlock, 0, ctx.stream>>>(A, v, out, CtC, dot ? dot->partials : nullptr);
+        else sfs_applyTiled<T, false><<<g, kBlock, 0, ctx.stream>>>(A, v, out, nullptr, dot ? dot->partials : nullptr);
+        if (dot) dot->n = g;
     }
     void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {
         ScopedKernel k(ctx, "computeModelCost");
-        if (marchIter && marchCost) {
-            int gx, gy, rows, per; marchGrid(false, gx, gy, rows, per);
-            sfs_costMarch<T, true><<<8 * per * gx, kSfsMarchBlock, 0, ctx.stream>>>(A, delta, out.partials, rows, gx, gy, per); out.n = 8 * per * gx;
-            return;
-        }
-        sfs_rows<T, 1><<<grid(), kBlock, 0, ctx.stream>>>(A, delta, out.partials); out.n = grid();
+        int gx, gy, rows, per; marchGrid(false, gx, gy, rows, per);
+        sfs_costMarch<T, true><<<8 * per * gx, kSfsMarchBlock, 0, ctx.stream>>>(A, delta, out.partials, rows, gx, gy, per); out.n = 8 * per * gx;
     }
-    // ---- one kernel per PCG iteration (sfs_applyTiled<.., ITER>) ----
-    bool oneKernel = true;              // OPT_AMD_SFS_ONEKERNEL=0: three kernels per iteration (A/B switch)
-    bool marchIter = true;              // OPT_AMD_SFS_MARCH=0: the LDS-tiled iteration kernel of round 2 (A/B switch)
-    bool marchJtf = true;               // OPT_AMD_SFS_MARCH_JTF=0: PCGInit1 as rows pass + gather pass
-    bool marchCost = true;              // OPT_AMD_SFS_MARCH_COST=0: computeCost / computeModelCost as the flat rows pass
+    // ---- one kernel per PCG iteration (sfs_pcgMarch) ----
+    bool oneKernel = true;              // OPT_AMD_SFS_ONEKERNEL=0: the reference-ordered three kernels per iteration (the parity control)
     int occMarch[2] = {0, 0}, marchGridOverride = 0;
     // grid of the marching kernels: column strips of kSfsSpan columns per wave x row groups, 8 XCD-contiguous ranges of row groups
     void marchGrid(bool lmLoop, int& mgx, int& mgy, int& mRows, int& mPer) {
@@ -921,14 +703,14 @@ struct SfsOps : EnergyOps<T> {
     }
     double* rrPartials = nullptr; int nRR = 0; bool prevWasFirst = false;
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
-        if (!oneKernel || !tiledApply || a.pre || this->slab.active) return false;       // this energy does not precondition (pre == nullptr)
+        if (!oneKernel || a.pre || this->slab.active) return false;       // this energy does not precondition (pre == nullptr)
         if (a.ApNew == a.ApOld || a.rNew == a.rOld || a.pNew == a.pOld) return false;     // neighbouring tiles read the old apron while this one writes
         if (!rrPartials) { HIP_CHECK(hipMalloc((void**)&rrPartials, kMaxPartials * sizeof(double))); owned.push_back(rrPartials); }
         const bool lmLoop = a.CtC != nullptr;
-        int g = tileGrid(lmLoop, true);
         // the marching kernel's grid: column strips of kSfsSpan columns per wave x row groups sized to be co-resident, 8 XCD-contiguous ranges of row groups
         int mgx = 0, mgy = 0, mRows = 0, mPer = 0;
-        if (marchIter) { marchGrid(lmLoop, mgx, mgy, mRows, mPer); g = 8 * mPer * mgx; }
+        marchGrid(lmLoop, mgx, mgy, mRows, mPer);
+        const int g = 8 * mPer * mgx;
         SIterK<T> K{};
         K.rOld = a.rOld; K.ApOld = a.ApOld; K.pOld = a.pOld; K.rNew = a.rNew; K.pNew = a.pNew; K.delta = a.delta; K.deltaOut = a.deltaOut ? a.deltaOut : a.delta;
         K.b = a.b; K.q = a.q ? a.q->partials : nullptr; K.qTag = a.qTag; K.first = a.first; K.restart = a.afterReset;
@@ -939,12 +721,8 @@ struct SfsOps : EnergyOps<T> {
         K.aNum = a.aNum->partials; K.aDen = a.aDen->partials; K.s2 = a.s2->partials; K.s3 = a.s3->partials; K.rr = rrPartials;
         {
             ScopedKernel k(ctx, "PCGIteration");
-            if (marchIter) {
-                if (lmLoop) sfs_pcgMarch<T, true><<<g, kSfsMarchBlock, 0, ctx.stream>>>(A, a.ApNew, a.CtC, K, mRows, mgx, mgy, mPer);
-                else sfs_pcgMarch<T, false><<<g, kSfsMarchBlock, 0, ctx.stream>>>(A, a.ApNew, nullptr, K, mRows, mgx, mgy, mPer);
-            }
-            else if (lmLoop) sfs_applyTiled<T, true, true><<<g, kBlock, 0, ctx.stream>>>(A, nullptr, a.ApNew, a.CtC, nullptr, K);
-            else sfs_applyTiled<T, false, true><<<g, kBlock, 0, ctx.stream>>>(A, nullptr, a.ApNew, nullptr, nullptr, K);
+            if (lmLoop) sfs_pcgMarch<T, true><<<g, kSfsMarchBlock, 0, ctx.stream>>>(A, a.ApNew, a.CtC, K, mRows, mgx, mgy, mPer);
+            else sfs_pcgMarch<T, false><<<g, kSfsMarchBlock, 0, ctx.stream>>>(A, a.ApNew, nullptr, K, mRows, mgx, mgy, mPer);
         }
         if (a.first) nRR = g;
         prevWasFirst = a.first != 0;
