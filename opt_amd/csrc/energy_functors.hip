@@ -181,7 +181,7 @@ struct VolumetricE {
 // operator's per-pixel coefficient; cost, J^T F and the LM loop stay on the functor engine.
 template <class T>
 struct FlowMarchOp {
-    static constexpr int C = 2, kCoef = 2; static constexpr bool kMasked = false;
+    static constexpr int C = 2, kCoef = 2; static constexpr bool kMasked = false, kSplit31 = false;
     using Vec = MVec<T, 2>;
     T w_fit, w_reg;
     __device__ __forceinline__ Vec apply(const Vec& pc, const Vec& pl, const Vec& pr, const Vec& pu, const Vec& pd, bool hasL, bool hasR, bool hasU, bool hasD, const MVec<T, 2>& g) const {
@@ -223,7 +223,51 @@ struct OpticalFlowOps : StencilOps<T, OpticalFlowE<T>> {
     const T* pcgFinish(const T*, T* delta, LaunchCtx& ctx) override { return march.finish(delta, 2L * this->e.W * this->e.H, this->cus, ctx); }
 };
 template <class T> EnergyOps<T>* makeFlow(const unsigned* dims) { return new OpticalFlowOps<T>(dims); }
-template <class T> EnergyOps<T>* makeIntrinsic(const unsigned* dims) { return new StencilOps<T, IntrinsicE<T>>(dims, false); }
+// ---- intrinsic_image_decomposition's Gauss-Newton PCG loop on the marching template ------------------------------------------------------------------------------
+// Per pixel four unknowns (log-albedo r, three channels, and log-shading s: two images in the solver's vectors, Op::kSplit31) and four operator coefficients: the
+// L_p weights sqrtC of the four stencil directions (IntrinsicE::computeAux, refreshed by precompute after every update).  The residual of edge (c, n) appears centred
+// at c and centred at n with the same weight bit for bit (|r_c - r_n| is symmetric), so an in-bounds edge contributes 2 (w_A sqrtC)^2 (p_c - p_n) per albedo channel and
+// 2 w_S^2 (p_c - p_n) to the shading; the fit rows w_fit (r_k + s - i_k) couple the four unknowns of a pixel.
+template <class T>
+struct IntrinsicMarchOp {
+    static constexpr int C = 4, kCoef = 4; static constexpr bool kMasked = false, kSplit31 = true;
+    using Vec = MVec<T, 4>;
+    T w_fit, w_regA, w_regS;
+    __device__ __forceinline__ Vec apply(const Vec& pc, const Vec& pl, const Vec& pr, const Vec& pu, const Vec& pd, bool hasL, bool hasR, bool hasU, bool hasD, const MVec<T, 4>& w) const {
+        Vec o{{0, 0, 0, 0}};
+        auto edge = [&](bool has, const Vec& pn, T sqrtC) {      // stencil direction order of the .t: (+1,0), (-1,0), (0,+1), (0,-1)
+            if (!has) return;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const T e = w_regA * (sqrtC * (pc.v[c] - pn.v[c])); const T t = (w_regA * sqrtC) * e; o.v[c] += t + t; }
+            const T es = w_regS * (pc.v[3] - pn.v[3]); const T ts = w_regS * es; o.v[3] += ts + ts;
+        };
+        edge(hasR, pr, w.v[0]); edge(hasL, pl, w.v[1]); edge(hasD, pd, w.v[2]); edge(hasU, pu, w.v[3]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const T f = w_fit * (pc.v[c] + pc.v[3]); const T t = w_fit * f; o.v[c] += t; o.v[3] += t; }
+        return o;
+    }
+};
+template <class T>
+__global__ __launch_bounds__(kBlock) void intrinsic_coef(const T* __restrict__ aux, T* __restrict__ coef, long n) {      // four planes -> four values per pixel
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        coef[4 * i] = aux[i]; coef[4 * i + 1] = aux[n + i]; coef[4 * i + 2] = aux[2 * n + i]; coef[4 * i + 3] = aux[3 * n + i];
+    }
+}
+template <class T>
+struct IntrinsicOps : StencilOps<T, IntrinsicE<T>> {
+    MarchLoop<T> march; T* coef = nullptr; bool useMarch = true;
+    IntrinsicOps(const unsigned* dims) : StencilOps<T, IntrinsicE<T>>(dims, false) { if (const char* e = getenv("OPT_AMD_INTRINSIC_MARCH")) useMarch = atoi(e) != 0; }
+    ~IntrinsicOps() override { if (coef) (void)hipFree(coef); }
+    bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
+        if (!useMarch || a.pre || a.CtC) return false;      // Gauss-Newton only
+        const long n = (long)this->e.W * this->e.H;
+        if (!coef) HIP_CHECK(hipMalloc((void**)&coef, (size_t)(4 * n) * sizeof(T)));
+        if (a.first) { ScopedKernel k(ctx, "operatorCoefficients"); intrinsic_coef<T><<<this->grid(), kBlock, 0, ctx.stream>>>(this->e.aux, coef, n); }
+        return march.launch(IntrinsicMarchOp<T>{this->e.w_fit, this->e.w_regA, this->e.w_regS}, this->e.W, this->e.H, nullptr, this->cus, a, ctx, coef);
+    }
+    const T* pcgFinish(const T*, T* delta, LaunchCtx& ctx) override { return march.finish(delta, 4L * this->e.W * this->e.H, this->cus, ctx); }
+};
+template <class T> EnergyOps<T>* makeIntrinsic(const unsigned* dims) { return new IntrinsicOps<T>(dims); }
 // OPT_AMD_VOLUMETRIC_ARAP=0: the functor engine; default: ARAP's kernel set on the lattice graph (graph_common.h makeVolumetricOnArap -- the same energy, 151 -> ... ms at 96^3)
 template <class T> EnergyOps<T>* makeVolumetric(const unsigned* dims) {
     const char* e = getenv("OPT_AMD_VOLUMETRIC_ARAP");

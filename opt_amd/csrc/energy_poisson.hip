@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kBlock) void poisson_applyJTJ(PArgs<T> A, const T* 
 // poisson: (J^T J p)(c) = 2 sum over in-bounds neighbours of (p_c - p_n), neighbour order (+1,0), (-1,0), (0,+1), (0,-1) as in poisson_applyJTJ
 template <class T>
 struct PoissonMarchOp {
-    static constexpr int C = 4, kCoef = 0; static constexpr bool kMasked = true;
+    static constexpr int C = 4, kCoef = 0; static constexpr bool kMasked = true, kSplit31 = false;
     using Vec = MVec<T, 4>;
     __device__ __forceinline__ Vec apply(const Vec& pc, const Vec& pl, const Vec& pr, const Vec& pu, const Vec& pd, bool hasL, bool hasR, bool hasU, bool hasD, const MVec<T, 1>&) const {
         Vec o;
@@ -138,7 +138,7 @@ struct PoissonMarchOp {
 };
 // laplacian: 0.2^2 p_c + sum over in-bounds neighbours of (p_c - p_n), order as in lap_applyJTJ
 struct LaplacianMarchOp {
-    static constexpr int C = 1, kCoef = 0; static constexpr bool kMasked = false;
+    static constexpr int C = 1, kCoef = 0; static constexpr bool kMasked = false, kSplit31 = false;
     using Vec = MVec<float, 1>;
     __device__ __forceinline__ Vec apply(const Vec& pc, const Vec& pl, const Vec& pr, const Vec& pu, const Vec& pd, bool hasL, bool hasR, bool hasU, bool hasD, const MVec<float, 1>&) const {
         float o = 0.2f * 0.2f * pc.v[0];

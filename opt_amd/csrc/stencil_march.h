@@ -19,6 +19,7 @@
 // The operator:
 //   struct Op { static constexpr int C;  static constexpr bool kMasked;      // channels; does a flag byte per pixel switch pixels off (Exclude, o.t:2452-2455)?
 //               static constexpr int kCoef;                                  // per-pixel coefficients of the operator (0: none), streamed from MarchK::coef once per row
+//               static constexpr bool kSplit31;                              // the unknown vector is a 3-channel image followed by a 1-channel image (C = 4), see marchLoadSplit
 //               __device__ MVec<T, C> apply(pc, pl, pr, pu, pd, hasL, hasR, hasU, hasD, coef) const; }     // (J^T J p) at an active pixel; p of an inactive / absent pixel is 0
 #pragma once
 #include "iw_device.h"
@@ -50,6 +51,31 @@ template <class T, int C> __device__ __forceinline__ void marchStore(__amdgpu_bu
     else {
         iw_u4 w0, w1; __builtin_memcpy(&w0, &o, 16); __builtin_memcpy(&w1, reinterpret_cast<const char*>(&o) + 16, 16);
         __builtin_amdgcn_raw_buffer_store_b128(w0, r, (int)v, (int)so, 0); __builtin_amdgcn_raw_buffer_store_b128(w1, r, (int)v, (int)(so + 16u), 0);
+    }
+}
+// A solver vector of two unknown images -- three channels per pixel followed, after all pixels, by one channel per pixel (intrinsic_image_decomposition: r then s; the
+// solver's layout, energy.h) -- seen as four channels per pixel: x3 = x * 3 * sizeof(T), x1 = x * sizeof(T), so3 / so1 the row offsets of the two parts
+typedef unsigned int march_u3 __attribute__((ext_vector_type(3)));
+template <class T> __device__ __forceinline__ MVec<T, 4> marchLoadSplit(__amdgpu_buffer_rsrc_t r, unsigned x3, unsigned so3, unsigned x1, unsigned so1) {
+    MVec<T, 4> o;
+    if constexpr (sizeof(T) == 4) {
+        const march_u3 a = __builtin_amdgcn_raw_buffer_load_b96(r, (int)x3, (int)so3, 0); const unsigned b = __builtin_amdgcn_raw_buffer_load_b32(r, (int)x1, (int)so1, 0);
+        __builtin_memcpy(&o, &a, 12); __builtin_memcpy(reinterpret_cast<char*>(&o) + 12, &b, 4);
+    } else {
+        const iw_u4 a = __builtin_amdgcn_raw_buffer_load_b128(r, (int)x3, (int)so3, 0); const iw_u2 a2 = __builtin_amdgcn_raw_buffer_load_b64(r, (int)x3, (int)(so3 + 16u), 0);
+        const iw_u2 b = __builtin_amdgcn_raw_buffer_load_b64(r, (int)x1, (int)so1, 0);
+        __builtin_memcpy(&o, &a, 16); __builtin_memcpy(reinterpret_cast<char*>(&o) + 16, &a2, 8); __builtin_memcpy(reinterpret_cast<char*>(&o) + 24, &b, 8);
+    }
+    return o;
+}
+template <class T> __device__ __forceinline__ void marchStoreSplit(__amdgpu_buffer_rsrc_t r, unsigned x3, unsigned so3, unsigned x1, unsigned so1, const MVec<T, 4>& o) {
+    if constexpr (sizeof(T) == 4) {
+        march_u3 a; unsigned b; __builtin_memcpy(&a, &o, 12); __builtin_memcpy(&b, reinterpret_cast<const char*>(&o) + 12, 4);
+        __builtin_amdgcn_raw_buffer_store_b96(a, r, (int)x3, (int)so3, 0); __builtin_amdgcn_raw_buffer_store_b32(b, r, (int)x1, (int)so1, 0);
+    } else {
+        iw_u4 a; iw_u2 a2, b; __builtin_memcpy(&a, &o, 16); __builtin_memcpy(&a2, reinterpret_cast<const char*>(&o) + 16, 8); __builtin_memcpy(&b, reinterpret_cast<const char*>(&o) + 24, 8);
+        __builtin_amdgcn_raw_buffer_store_b128(a, r, (int)x3, (int)so3, 0); __builtin_amdgcn_raw_buffer_store_b64(a2, r, (int)x3, (int)(so3 + 16u), 0);
+        __builtin_amdgcn_raw_buffer_store_b64(b, r, (int)x1, (int)so1, 0);
     }
 }
 template <bool RIGHT, class T, int C> __device__ __forceinline__ MVec<T, C> marchShift(const MVec<T, C>& a) {
@@ -92,15 +118,24 @@ __global__ __launch_bounds__(kBlk) void march_pcgIter(Op op, MarchK<T> K, int ro
     const unsigned xc = (unsigned)min(max(x, 0), K.W - 1), xv = xc * (unsigned)(C * sizeof(T)), xcv = xc * (unsigned)(kCoefN * sizeof(T));
     const bool first = K.iter == 0;
     const bool paired = K.deltaMode == 1;
+    const unsigned x3 = xc * (unsigned)(3 * sizeof(T)), x1 = xc * (unsigned)sizeof(T), part1 = (unsigned)(3ull * (unsigned)K.W * (unsigned)K.H * sizeof(T));      // (kSplit31)
+    auto vload = [&](__amdgpu_buffer_rsrc_t b, unsigned row) -> Vec {
+        if constexpr (Op::kSplit31) return marchLoadSplit<T>(b, x3, row * (unsigned)(3 * sizeof(T)), x1, part1 + row * (unsigned)sizeof(T));
+        else return marchLoad<T, C>(b, xv, row * (unsigned)(C * sizeof(T)));
+    };
+    auto vstore = [&](__amdgpu_buffer_rsrc_t b, unsigned row, const Vec& v) {
+        if constexpr (Op::kSplit31) marchStoreSplit<T>(b, x3, row * (unsigned)(3 * sizeof(T)), x1, part1 + row * (unsigned)sizeof(T), v);
+        else marchStore<T, C>(b, xv, row * (unsigned)(C * sizeof(T)), v);
+    };
     struct Raw { Vec p, q, d; Coef c; int f; };      // one pixel's loads, untouched (any ALU op here would force a wait before the loop back-edge)
     auto loadRow = [&](int y) {
         Raw r;
         const int yc = min(max(y, 0), K.H - 1);      // clamped: always a valid address; rows outside the image are switched off where they enter the window
-        const unsigned row = (unsigned)(FLIP ? K.H - 1 - yc : yc) * (unsigned)K.W, so = row * (unsigned)(C * sizeof(T));      // wave-uniform
+        const unsigned row = (unsigned)(FLIP ? K.H - 1 - yc : yc) * (unsigned)K.W;      // wave-uniform
         r.f = Op::kMasked ? (int)__builtin_amdgcn_raw_buffer_load_b8(bF, (int)xc, (int)row, 0) : 1;
-        r.p = marchLoad<T, C>(bP, xv, so);
-        r.q = marchLoad<T, C>(bQ, xv, so);
-        if (paired) r.d = marchLoad<T, C>(bD, xv, so); else r.d = Vec{};
+        r.p = vload(bP, row);
+        r.q = vload(bQ, row);
+        if (paired) r.d = vload(bD, row); else r.d = Vec{};
         if constexpr (kCoef > 0) r.c = marchLoad<T, kCoefN>(bC, xcv, row * (unsigned)(kCoefN * sizeof(T))); else r.c = Coef{};
         return r;
     };
@@ -148,7 +183,7 @@ __global__ __launch_bounds__(kBlk) void march_pcgIter(Op op, MarchK<T> K, int ro
 #pragma unroll
             for (int c = 0; c < C; ++c) { T t = regCopy(w.d.v[c]); t += alpha2 * qv.v[c]; t += alpha * pv.v[c]; d.v[c] = t; }
             const unsigned row = (unsigned)(FLIP ? K.H - 1 - y : y) * (unsigned)K.W;
-            marchStore<T, C>(bD, xv, row * (unsigned)(C * sizeof(T)), d);
+            vstore(bD, row, d);
         }
     };
     auto applyAt = [&](const Row& c, const Row& prev, const Row& next, int y, const Coef& cf) {      // (J^T J p) of row y of a stream; prev / next in sweep order
@@ -172,7 +207,7 @@ __global__ __launch_bounds__(kBlk) void march_pcgIter(Op op, MarchK<T> K, int ro
         }
         if (live && writer && y + 1 >= yb && y + 1 < ye) {
             const unsigned row = (unsigned)(FLIP ? K.H - 2 - y : y + 1) * (unsigned)K.W;
-            marchStore<T, C>(bN, xv, row * (unsigned)(C * sizeof(T)), nC.p);
+            vstore(bN, row, nC.p);
         }
         const Vec o = applyAt(nB, nA, nC, y, oA.c);                                     // Step1 of iteration k (row y: the coefficients of oA's pixel)
         if (live && writer && y >= yb) {

@@ -83,6 +83,31 @@ def test_optical_flow(oracle_lib, W, H, double, liters):
     _pair(oracle_lib, P, 2, liters, 1e-10 if double else 1e-5, 1e-9 if double else 2e-5)
 
 
+@pytest.mark.parametrize("liters", [1, 2, 3, 4, 5, 12])
+@pytest.mark.parametrize("W,H", [(7, 9), (61, 5), (240, 3), (241, 9), (300, 40), (64, 300), (517, 33)])
+def test_intrinsic_double(oracle_lib, W, H, liters):
+    """intrinsic_image_decomposition: two unknown images (3 + 1 channels per pixel, the template's split layout) and four L_p weights per pixel as operator coefficients.
+    The system is ill-conditioned (weights 500 / 1000 / 10000 on differences of ~0.02, unpreconditioned): a 1-ulp difference between libm pow and the device pow is
+    amplified ~1e7-fold in a Gauss-Newton step, which is why the double bars are 1e-8 / 1e-7 here as in tests/test_energies_gpu.py; float runs are smoke level there."""
+    P = wl.intrinsic_image_decomposition(W, H, double=True, seed=W + H + liters)
+    _pair(oracle_lib, P, 2, liters, 1e-8, 1e-7)
+
+
+def test_intrinsic_march_matches_the_functor_engine_loop(monkeypatch):
+    res = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("OPT_AMD_INTRINSIC_MARCH", on)
+        P = wl.intrinsic_image_decomposition(333, 97, double=True, seed=4)
+        g = hip_solver(P, "gaussNewtonGPU", timing=True, nIterations=3, lIterations=10)
+        dev = api.to_device(P)
+        g.solve(dev)
+        assert ("PCGIteration" in g.kernel_timings()) == (on == "1")
+        res.append((g.cost(), device_unknowns(P, dev)))
+        g.close()
+    assert abs(res[0][0] - res[1][0]) <= 1e-8 * abs(res[1][0])
+    assert rel_err(res[0][1], res[1][1]) < 1e-7
+
+
 def test_optical_flow_march_matches_the_functor_engine_loop(monkeypatch):
     res = []
     for on in ("1", "0"):
