@@ -130,22 +130,37 @@ def table(families=("horizon", "adversarial"), precisions=("float", "double"), h
     return rows
 
 
+def _tail_note():
+    key = "horizon_2048_float_50"; a = anchor(key)
+    d = sorted(abs(c - a) / a for _, c in legal_runs(key))
+    near = sum(1 for v in d if v <= 1e-5); far = [v for v in d if v > 1e-4]
+    return (f"The outcomes are heavy-tailed: after 50 float iterations {near} of {len(d)} runs agree to 1e-5 and {len(far)} sit " + ", ".join(f"{v:.1e}" for v in far) +
+            " away -- a handful of runs does not measure the spread.")
+
+
 def markdown():
     f = lambda v: "n/a" if v is None else f"{v:.2e}"
     out = ["# Spread of the reference's own arithmetic (image_warping, one Gauss-Newton step, cost after L PCG iterations)", "",
-           "Frozen oracle runs (tests/golden/reference_order_costs.json, horizon_costs.json, horizon_costs_fma.json; generators beside them).  `seed-to-seed` = diameter of the",
-           "reference-order runs of the plain build (seeded random commit order of the per-warp float atomics, nothing else varied); `all legal runs` adds the exact-order",
-           "sums and the fused-multiply-add build of the same restatement (a compiler's choice the reference's Terra/LLVM build also makes).  yardstick = max(contract floor, all legal runs).", "",
+           "Frozen oracle runs (tests/golden/reference_order_costs*.json, horizon_costs.json, horizon_costs_fma.json; generators beside them).  A *legal run* is the same",
+           "algorithm under another rounding the reference itself may take: `reference-order` = its own sums (one float term per pixel, the 32-lane shfl.down tree of",
+           "util.t:612-623, one float atomicAdd per warp -- solverGPUGaussNewton.t:312-317 -- committed in a seeded random order); `fma` = the restatement compiled with fused",
+           "multiply-adds (what an NVPTX / AMDGPU back end does to the generated code); `raster` = J^T J p scattered in raster order instead of the banded order of the",
+           "multi-threaded oracle; `exact-order` = sums accumulated in long double.  `seed-to-seed` = diameter of the reference-order runs of the plain build alone (nothing varied",
+           "but the commit order of the atomics); `all legal runs` = diameter of everything; yardstick = max(contract floor 1e-5 / 1e-12, all legal runs).  " + _tail_note(), "",
            "| workload | precision | L | exact-order oracle cost | runs | seed-to-seed | all legal runs | yardstick |", "|---|---|---|---|---|---|---|---|"]
     for r in table():
         out.append(f"| {r['family']} | {r['precision']} | {r['liters']} | {r['anchor']:.9g} | {len(r['runs'])} | {f(r['seed_to_seed'])} | {f(r['spread'])} | {f(r['yardstick'])} |")
-    out += ["", "## The metric's solve: 8 Gauss-Newton steps x 400 PCG iterations from the initial guess, final energy", "",
-            "| workload | precision | exact-order oracle | runs | seed-to-seed | all legal runs |", "|---|---|---|---|---|---|"]
-    for key, prec in (("solve8_2048_float", "float"), ("solve8_2048_double", "double"), ("solve8_4096_float", "float")):
-        a = anchor(key, 8)
-        if a is None:
+    out += ["", "## Multi-step solves: cost after every Gauss-Newton step (400 PCG iterations each), relative diameter of the legal runs", "",
+            "| workload | precision | runs | " + " | ".join(f"step {i}" for i in range(1, 9)) + " |", "|---|---|---|" + "---|" * 8]
+    for key, prec, steps in (("bench_4096_float_400x2", "float", 2), ("solve8_2048_float", "float", 8), ("solve8_2048_double", "double", 8), ("solve8_4096_float", "float", 8)):
+        if anchor(key, 1) is None:
             continue
-        out.append(f"| {key} | {prec} | {a:.9g} | {len(legal_runs(key, 8))} | {f(seed_spread(key, 8))} | {f(spread(key, 8))} |")
+        cells = [f(spread(key, i)) if i <= steps else "" for i in range(1, 9)]
+        out.append(f"| {key} | {prec} | {len(legal_runs(key, steps))} | " + " | ".join(cells) + " |")
+    out += ["", "Individual runs at the short horizons (relative distance from the exact-order plain oracle):", ""]
+    for L in (20, 50, 100):
+        key = f"horizon_2048_float_{L}"; a = anchor(key)
+        out.append(f"* L = {L}: " + ", ".join(f"{(c - a) / a:+.1e}" for _, c in legal_runs(key)))
     return "\n".join(out) + "\n"
 
 
