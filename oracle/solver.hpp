@@ -31,6 +31,9 @@
 //       on a zeroed scalar (solverGPUGaussNewton.t:312-317, 580-592) in an order the hardware does not define -- modelled as a seeded random
 //       permutation of the warps.  Two seeds are two legal runs of the reference; how far apart they land after N PCG iterations is the
 //       reproducibility of the reference against ITSELF (tests/golden/make_reference_order_spread.py, profiles/r04_reference_order_spread.md).
+//       Graph energies: the reference's graph kernels scatter J^T F and J^T J p with one opt_float atomicAdd per (vertex, channel) of every hyperedge
+//       (o.t:2092-2126, 2228-2253; util.t:528-597) -- again in no defined order; in this mode the hyperedges are visited in a seeded random permutation (a new
+//       one for every pass), the global sums stay exact.
 //
 // PARITY STATUS: the reference path is Terra/Lua JIT-compiled to PTX and cannot be built or run in this
 // environment, and the reference ships no golden vectors.  This restatement is pinned by (i) the
@@ -193,10 +196,23 @@ struct Solver {
             f(buf, k);
         }
         long ne = E->nEdges();
+        if (reductionMode == 1 && E->usesGraph && ne > 1) {      // the scatter order of the reference's per-edge atomics is undefined: a seeded permutation per pass
+            edgeOrder(ne);
+            for (long j = 0; j < ne; ++j) { int k = E->evalEdge(edgePerm[(size_t)j], buf); f(buf, k); }
+            return;
+        }
         for (long e = 0; e < ne; ++e) {
             int k = E->evalEdge(e, buf);
             f(buf, k);
         }
+    }
+    mutable std::vector<long> edgePerm;
+    void edgeOrder(long ne) const {
+        edgePerm.resize((size_t)ne);
+        for (long e = 0; e < ne; ++e) edgePerm[(size_t)e] = e;
+        unsigned long long st = 0x9E3779B97F4A7C15ull * (reductionSeed + 1) + 0xD1B54A32D192ED03ull * (++reductionCount);
+        auto next = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (unsigned long long)(st >> 33); };
+        for (size_t i = edgePerm.size(); i > 1; --i) { const size_t j = (size_t)(next() % i); std::swap(edgePerm[i - 1], edgePerm[j]); }
     }
 
     // Row-banded traversal of the centred instances for the multi-threaded baseline.  Every residual's support lies
@@ -228,7 +244,10 @@ struct Solver {
         }
         Inst<T> buf[MAXR];
         long double s = 0;
-        for (long e = 0; e < E->nEdges(); ++e) { int k = E->evalEdge(e, buf); f(buf, k, bandSums ? &s : nullptr); }
+        const long ne = E->nEdges();
+        const bool perm = reductionMode == 1 && E->usesGraph && ne > 1;
+        if (perm) edgeOrder(ne);
+        for (long j = 0; j < ne; ++j) { int k = E->evalEdge(perm ? edgePerm[(size_t)j] : j, buf); f(buf, k, bandSums ? &s : nullptr); }
         if (bandSums) (*bandSums)[nb] = s;
     }
     static long double sumBands(const std::vector<long double>& v) { long double s = 0; for (auto x : v) s += x; return s; }

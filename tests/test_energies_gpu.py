@@ -1,6 +1,8 @@
 """GPU parity tests (-m gpu) for every registered energy other than the headline one: each stage of the HIP
 path against the CPU oracle through the C ABI, then GN and LM trajectories.  Same bar as
 test_image_warping_gpu.py: 1e-5 relative in float, 1e-12 on double costs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -57,6 +59,21 @@ CASES = {
 }
 
 
+def _envelopes():
+    """{case_kind: (largest relative diameter of the frozen legal oracle runs' cost over the trajectory, relative spread of their final unknowns)}"""
+    import json
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "float_envelopes.json")
+    out = {}
+    for k, e in json.load(open(p)).items():
+        runs = list(e["runs"].values()); a = e["runs"]["exact-order plain"]; s = max(abs(a[0]), 1e-300)
+        n = min(len(c) for c in runs)
+        out[k] = (max((max(c[i] for c in runs) - min(c[i] for c in runs)) / max(abs(a[i]), 1e-7 * s) for i in range(n)), e["x_spread"])
+    return out
+
+
+ENVELOPES = _envelopes()
+
+
 def _cases():
     out = []
     for name in sorted(CASES):
@@ -103,22 +120,17 @@ def test_trajectory(oracle_lib, name, double, kind):
     o.init(Pref.params); g.init(dev)
     ctol = 1e-10 if P.double else 1e-5
     xtol = 1e-9 if P.double else 2e-5
-    if name == "curveFitting" and not P.double:
-        # cos(b x) with b x ~ 600 rad loses ~4 digits in float, so libm and the device sincosf legitimately differ;
-        # the reference runs this energy in double (tests/minimal_graph_only/main.cpp:11).  Float is a smoke check.
-        ctol, xtol = 5e-3, 1e-3
-    if name in ("cotangent", "embedded", "embedded_rest", "robust") and not P.double:
-        # float sums over a vertex's hyperedges in a different order than the oracle's (records gathered in (slot, edge) order; the
-        # scatter mode of the engine, like the reference's graph kernels, has no fixed order at all); the double runs hold 1e-10
-        ctol, xtol = 5e-5, 1e-4
-        if name == "cotangent":     # normalize / cot / sqrt chains differentiated in float: 8e-5 after four Gauss-Newton steps
-            ctol, xtol = 3e-4, 1e-3
-    if name == "intrinsic":
-        # weights of 500 / 1000 / 10000 on differences of ~0.02 plus the (|dr| + 1e-7)^(-0.6) re-weighting make the system
-        # ill-conditioned (unpreconditioned, 12 PCG iterations, far from converged): a 1-ulp difference between libm pow and the
-        # device pow is amplified ~1e7-fold in the Gauss-Newton step -- 1.3e-9 in double, 1e-3 in float; the LM runs (damped)
-        # and the per-stage checks of cost / J^T F / J^T J p above hold the usual bars on the same inputs.
-        ctol, xtol = (1e-8, 1e-7) if P.double else (3e-2, 1e-1)     # float: smoke level, like curveFitting
+    if name == "intrinsic" and P.double:
+        # weights of 500 / 1000 / 10000 on differences of ~0.02 plus the (|dr| + 1e-7)^(-0.6) re-weighting make the system ill-conditioned (unpreconditioned, 12 PCG
+        # iterations, far from converged): a 1-ulp difference between libm pow and the device pow is amplified ~1e7-fold in the Gauss-Newton step -- 1.3e-9 in double
+        ctol, xtol = 1e-8, 1e-7
+    if not P.double:
+        # Float: where legal runs of the reference's own arithmetic (reference-order sums / scatter order under several seeds, plain and fma build of the oracle; frozen
+        # in tests/golden/float_envelopes.json by make_float_envelopes.py) end further apart than the contract, twice their diameter is the bar -- a measured yardstick
+        # per case: 1e-5 for most, 2.6e-4 for curveFitting LM (cos / sin of ~600 rad), 2e-4 for cotangent GN (float atomics in no defined order), 3e-2 for intrinsic GN.
+        env = ENVELOPES.get(f"{name}_{kind}")
+        if env is not None:
+            ctol, xtol = max(ctol, 2.0 * env[0]), max(xtol, 2.0 * env[1])
     scale = max(abs(o.cost()), 1e-300)
     assert abs(g.cost() - o.cost()) <= ctol * scale
     while True:
@@ -345,5 +357,6 @@ def test_graph_functor_engine_is_deterministic_and_scatter_mode_agrees(oracle_li
     assert a[0] == b[0] and np.array_equal(a[1], b[1])
     monkeypatch.setenv("OPT_AMD_GRAPH_GATHER", "0")
     c = run()
-    assert abs(c[0] - a[0]) <= 3e-4 * abs(a[0])
-    assert rel_err(c[1], a[1]) < 1e-3
+    env = ENVELOPES[f"{name}_gaussNewtonGPU"]      # two scatter orders are two legal runs: the measured spread of such runs (tests/golden/float_envelopes.json), never below the contract
+    assert abs(c[0] - a[0]) <= max(1e-5, 2.0 * env[0]) * abs(a[0])
+    assert rel_err(c[1], a[1]) < max(2e-5, 2.0 * env[1])
