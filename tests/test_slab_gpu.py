@@ -98,8 +98,7 @@ def test_rccl_comm_single_rank():
 
 
 def test_deep_ghost_slabs_general_ur_shape_and_period_switch(monkeypatch):
-    """5 ghost rows (period 4) with a jittered UrShape (compact preconditioner from the solver's vector, valid on all ghost rows after the
-    one exchange per step), and the same slabs with OPT_AMD_SLAB_PERIOD=1 (exchange after every launch): identical results."""
+    """5 ghost rows (period 4) with a jittered UrShape (the general kernel, which rebuilds M_a from the pairs it evaluates -- also on the ghost rows it updates), and the same slabs with OPT_AMD_SLAB_PERIOD=1 (exchange after every launch): identical results."""
     P = wl.image_warping(66, 47, double=True, random_state=13, mask_fraction=0.05, perturb=0.3, jitter_urshape=0.2)
     kw = dict(nIterations=2, lIterations=11)
     c1, x1 = _single(P.clone(), "gaussNewtonGPU", **kw)
@@ -114,8 +113,8 @@ def test_deep_ghost_slabs_general_ur_shape_and_period_switch(monkeypatch):
 
 
 def test_gn_slabs_lattice_and_general_ur_shape():
-    """Ap-free iteration on slabs for both preconditioner sources: unit-lattice UrShape (M from the flag byte) and a
-    jittered UrShape (compact M exchanged once), odd row counts so the slabs differ in height."""
+    """Ap-free iteration on slabs for both kernels: unit-lattice UrShape (M from the flag byte) and a
+    jittered UrShape (M_O from the flag byte, M_a rebuilt from the pairs), odd row counts so the slabs differ in height."""
     for jitter in (0.0, 0.2):
         P = wl.image_warping(66, 47, random_state=11, mask_fraction=0.05, perturb=0.3, jitter_urshape=jitter)
         kw = dict(nIterations=2, lIterations=25)
