@@ -111,6 +111,20 @@ def test_the_reference_does_not_meet_its_contract_against_itself_at_long_horizon
     assert rs.seed_spread("horizon_2048_float_20") > 1e-5
 
 
+def test_bench_keys_reuse_the_first_steps_of_the_frozen_solves():
+    """bench_<size>_<precision>_400x2 = the first two Gauss-Newton steps of bench.py's workload: anchored on tests/golden/bench_costs.json, its legal runs include the
+    first two steps of the frozen 8 x 400 solves of the same size (same workload, same initial guess), and at 4096^2 its own reference-order runs."""
+    for key, prec, nref in (("bench_4096_float_400x2", "float", 5), ("bench_2048_float_400x2", "float", 3), ("bench_2048_double_400x2", "double", 3)):
+        assert rs.n_reference_order_runs(key) >= nref, key
+        for step in (1, 2):
+            a = rs.anchor(key, step)
+            assert a is not None and a == rs.anchor(key.replace("bench_", "solve8_").replace("_400x2", ""), step)      # the same exact-order oracle run, frozen twice
+            assert rs.spread(key, step) > rs.FLOOR[prec]
+            assert rs.verdict(key, prec, a, step)["within_reference_spread"]
+    # what the yardstick says about the metric's own size: after the first 400 float iterations the reference's legal runs are ~1e-2 apart
+    assert 1e-3 < rs.spread("bench_4096_float_400x2", 1) < 5e-2
+
+
 def test_verdict_logic():
     key = "horizon_2048_float_400"
     a, y = rs.anchor(key), rs.yardstick(key, "float")
