@@ -316,21 +316,25 @@ __global__ __launch_bounds__(kSfsMarchBlock, (JTF ? 1 : SFS_MARCH_MINWAVES)) voi
     __shared__ double scratch[6 * (kSfsMarchBlock / kWave + 1)];
     T alpha = 0, beta = 0;
     const bool keep = JTF || K.first != 0 || K.restart != 0;       // r (and, at the start, p) are already those of this iteration
-    if (JTF) {
-    } else if (K.restart) {
-        const double* const ps[2] = {K.betaNum, K.betaDen}; const int ns[2] = {K.nBetaNum, K.nBetaDen}; double o2[2];
-        sumPartialsN<2>(ps, ns, scratch, o2);
-        const T bNum = (T)o2[0], bDen = (T)o2[1];
-        beta = (bDen > T(0)) ? bNum / bDen : T(0);                 // solver.t:544-547
-    } else if (!K.first) {
-        const double* const ps[5] = {K.aNumPrev, K.aDenPrev, K.s2Prev, K.s3Prev, K.rrPrev}; const int ns[5] = {K.nNum, K.nDen, K.n2, K.n3, K.rrFromPrivate ? K.nRR : 0}; double o5[5];
-        sumPartialsN<5>(ps, ns, scratch, o5);
-        const T aNum = (T)o5[0], aDen = (T)o5[1];
-        alpha = (aDen > T(0)) ? aNum / aDen : T(0);                // solver.t:456-459
-        const double rr = K.rrFromPrivate ? o5[4] : o5[0];
-        const double bNumD = fmax(rr - 2.0 * (double)alpha * o5[2] + (double)alpha * (double)alpha * o5[3], 0.0);
-        beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
-    }
+    // alpha, beta of this launch from the previous launch's partial sums -- called AFTER the first rows have been requested: their latency then overlaps this
+    // memory round trip (partials another kernel just wrote) instead of following it
+    auto prologue = [&]() {
+        if (JTF) {
+        } else if (K.restart) {
+            const double* const ps[2] = {K.betaNum, K.betaDen}; const int ns[2] = {K.nBetaNum, K.nBetaDen}; double o2[2];
+            sumPartialsN<2>(ps, ns, scratch, o2);
+            const T bNum = (T)o2[0], bDen = (T)o2[1];
+            beta = (bDen > T(0)) ? bNum / bDen : T(0);                 // solver.t:544-547
+        } else if (!K.first) {
+            const double* const ps[5] = {K.aNumPrev, K.aDenPrev, K.s2Prev, K.s3Prev, K.rrPrev}; const int ns[5] = {K.nNum, K.nDen, K.n2, K.n3, K.rrFromPrivate ? K.nRR : 0}; double o5[5];
+            sumPartialsN<5>(ps, ns, scratch, o5);
+            const T aNum = (T)o5[0], aDen = (T)o5[1];
+            alpha = (aDen > T(0)) ? aNum / aDen : T(0);                // solver.t:456-459
+            const double rr = K.rrFromPrivate ? o5[4] : o5[0];
+            const double bNumD = fmax(rr - 2.0 * (double)alpha * o5[2] + (double)alpha * (double)alpha * o5[3], 0.0);
+            beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
+        }
+    };
     // workgroup -> (column strip, row group); the 8 XCDs take contiguous ranges of row groups, so that the halo rows two vertically adjacent workgroups both
     // stage are served by one L2
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -502,6 +506,7 @@ __global__ __launch_bounds__(kSfsMarchBlock, (JTF ? 1 : SFS_MARCH_MINWAVES)) voi
 #endif
     if (SFS_MARCH_DEPTH == 2) {
         SRaw<T> rA = load(yb - 2), rB = load(yb - 1), rC;
+        prologue();
         for (int Y = yb - 2; Y < ye + 2; Y += 3) {
             rC = load(Y + 2); trip(Y, rA);
             rA = load(Y + 3); trip(Y + 1, rB);
@@ -509,6 +514,7 @@ __global__ __launch_bounds__(kSfsMarchBlock, (JTF ? 1 : SFS_MARCH_MINWAVES)) voi
         }
     } else {
         SRaw<T> rA = load(yb - 2), rB;
+        prologue();
         for (int Y = yb - 2; Y < ye + 2; Y += 2) {
             rB = load(Y + 1); trip(Y, rA);
             rA = load(Y + 2); trip(Y + 1, rB);
