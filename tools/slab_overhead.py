@@ -57,7 +57,7 @@ def main():
     out = {}
     sizes = [(4096, 512), (4096, 1024), (4096, 2048), (8192, 1024)] if "--all" in sys.argv else [(4096, 512), (8192, 1024)]
     for (W, H) in sizes:
-        for mode in ("plain", "onchip-slab", "plain-streaming", "peer-post", "peer-wait", "rccl"):
+        for mode in (("plain-streaming", "peer", "peer-post") if "--plan" in sys.argv else ("plain", "onchip-slab", "plain-streaming", "peer-post", "peer-wait", "rccl")):
             us = run(mode, W, H, 400, 3)
             out[f"{W}x{H}_{mode}"] = us
             print(f"{W}x{H:5d} {mode:16s}: {us:7.1f} us per PCG iteration", flush=True)
