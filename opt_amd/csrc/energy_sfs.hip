@@ -649,13 +649,13 @@ struct SfsOps : EnergyOps<T> {
     }
     void evalJTF(T* r, T* diag, LaunchCtx& ctx) override {
         ScopedKernel k(ctx, "PCGInit1");      // row values + gather in one marching launch
-        int gx, gy, rows, per; marchGrid(false, gx, gy, rows, per);
+        int gx, gy, rows, per; marchGrid(false, gx, gy, rows, per, true);
         sfs_pcgMarch<T, false, true><<<8 * per * gx, kSfsMarchBlock, 0, ctx.stream>>>(A, r, nullptr, SIterK<T>{}, rows, gx, gy, per, diag);
     }
     bool evalJTFInitLM(const LmInitArgs<T>& a, LaunchCtx& ctx) override {
         if (this->slab.active) return false;
         ScopedKernel k(ctx, "PCGInit1");
-        int gx, gy, rows, per; marchGrid(false, gx, gy, rows, per);
+        int gx, gy, rows, per; marchGrid(false, gx, gy, rows, per, true);
         const int g = 8 * per * gx;
         SFin<T> fin{a.CtC, a.SSq, a.delta, a.pre, a.b, a.p, a.radius, a.minLm, a.maxLm, a.saveSSq, a.rDotP->partials, a.q->partials};
         sfs_pcgMarch<T, false, true><<<g, kSfsMarchBlock, 0, ctx.stream>>>(A, a.r, nullptr, SIterK<T>{}, rows, gx, gy, per, nullptr, fin);
@@ -692,7 +692,7 @@ struct SfsOps : EnergyOps<T> {
     bool oneKernel = true;              // OPT_AMD_SFS_ONEKERNEL=0: the reference-ordered three kernels per iteration (the parity control)
     int occMarch[2] = {0, 0}, marchGridOverride = 0;
     // grid of the marching kernels: column strips of kSfsSpan columns per wave x row groups, 8 XCD-contiguous ranges of row groups
-    void marchGrid(bool lmLoop, int& mgx, int& mgy, int& mRows, int& mPer) {
+    void marchGrid(bool lmLoop, int& mgx, int& mgy, int& mRows, int& mPer, bool full = false) {
         int& o = occMarch[lmLoop];
         if (o == 0) {
             const void* fn = lmLoop ? (const void*)sfs_pcgMarch<T, true> : (const void*)sfs_pcgMarch<T, false>;
@@ -702,7 +702,8 @@ struct SfsOps : EnergyOps<T> {
         mgx = divUp(A.W, (kSfsMarchBlock / kWave) * kSfsSpan);
         // Rows per workgroup against workgroups in flight: every workgroup stages 4 halo rows on top of its own (measured at 1024^2 double LM, us per iteration:
         // 1024 workgroups of 10 rows 44.0, 768 x 13 rows 41.6, 512 x 19 rows 42.1, 256 x 37 rows 59.3): the default takes three quarters of the co-resident count.
-        const int target = marchGridOverride > 0 ? marchGridOverride : std::max(1, cus * o * 3 / 4);
+        // (PCGInit1 -- no prologue, more arithmetic per row -- prefers every co-resident slot: 30.5 us with 1024 workgroups against 33.8 with 768)
+        const int target = marchGridOverride > 0 ? marchGridOverride : std::max(1, full ? cus * o : cus * o * 3 / 4);
         mgy = std::max(1, std::min(std::min(A.H, target / mgx), (kMaxPartials / 2 - 8 * mgx) / mgx));
         mRows = divUp(A.H, mgy); mgy = divUp(A.H, mRows);
         mPer = divUp(mgy, 8);
