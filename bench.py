@@ -476,7 +476,7 @@ def main():
         solve["reference_default_10x10"] = {"solve_ms": ddt * 1e3, "ms_per_gn_step": ddt * 1e2, "pcg_iters_per_s": 100 / ddt, "final_energy": solver.cost()}
         solver.set_parameter("lIterations", args.liters)
 
-    # ---- the general kernel (arbitrary UrShape: + U and a compact preconditioner, 69 B/pixel) on the same input -----------------------
+    # ---- the general kernel (arbitrary UrShape: + U, 61 B/pixel; M_a rebuilt from the pairs the stencil evaluates) on the same input ------
     general = None
     if not distributed and not args.no_extras:
         solver.close()
