@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
         if ((int)threadIdx.x < VW) cxTab[threadIdx.x] = coefK(A, 0, x0 + (int)threadIdx.x - 2, 0);
         else if ((int)threadIdx.x < VW + VH) cyTab[threadIdx.x - VW] = coefK(A, 1, 0, y0 + (int)threadIdx.x - VW - 2);
         __syncthreads();
-        // row values at every centre of the tile + ring (sfs_rows<3>): centre (qx, qy) in q coordinates = (qx + 1, qy + 1) in v coordinates
+        // row values at every centre of the tile + ring: centre (qx, qy) in q coordinates = (qx + 1, qy + 1) in v coordinates
         for (int i = threadIdx.x; i < QW * QH; i += kBlock) {
             const int qx = i % QW, qy = i / QW, vx = qx + 1, vy = qy + 1;
             // Branch-free: every LDS read below is inside the staged footprint for every (qx, qy); the masks (interior / valid) are applied as
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void sfs_applyTiled(SArgs<T> A, const T* __
             sq[0][qy][qx] = jgh; sq[1][qy][qx] = jgv; sq[2][qy][qx] = js[0]; sq[3][qy][qx] = js[1]; sq[4][qy][qx] = js[2];
         }
         __syncthreads();
-        // gather (sfs_gather<false>): this thread's pixel is (tx, ty) in the tile = (tx + 1, ty + 1) in q coordinates
+        // gather: this thread's pixel is (tx, ty) in the tile = (tx + 1, ty + 1) in q coordinates
         const int tx = threadIdx.x % TW, ty = threadIdx.x / TW, x = x0 + tx, y = y0 + ty;
         if (x < A.W && y < A.H) {
             const long e = (long)y * A.W + x;
@@ -305,8 +305,8 @@ constexpr int kSfsMarchBlock = SFS_MARCH_WAVES * kWave, kSfsSpan = kWave - 4;
                                   // word, row coefficients in scalar registers, one accumulator for the two sums that never coexist); capped at 168 (3 waves per SIMD) it runs 45 us against 39:
                                   // at 1024^2 the grid is sized by co-residency, more resident workgroups mean fewer rows each, and every workgroup stages 4 halo rows (see marchGrid)
 #endif
-// JTF = true turns the same march into PCGInit1 (sfs_rows<2> + sfs_gather<JTF> in one launch): the staged vector is X itself, b is the stored B_I instead of dB_I . v, the
-// row values are the residuals (in sfs_rows' association), the gather also sums the squared coefficients: out = -J^T F, diag = diag(J^T J).  No sums, no PCG state.
+// JTF = true turns the same march into PCGInit1 (residual rows + gather in one launch): the staged vector is X itself, b is the stored B_I instead of dB_I . v, the
+// row values are the residuals, the gather also sums the squared coefficients: out = -J^T F, diag = diag(J^T J).  No sums, no PCG state.
 // With `fin.CtC` set the JTF march also does what k_finalizeDiagonal<T, true> does after PCGInit1 in an LM step (this energy: no preconditioner, no graph): SSq, delta = 0,
 // the clamped CtC, the LM preconditioner, b = r, p = M r and the partial sums of r . p -- the same expressions on the value the gather has just produced.
 template <class T> struct SFin { T *CtC, *SSq, *delta, *pre, *b, *p; T radius, minLm, maxLm; int saveSSq; double *dPart, *qPart; };
@@ -399,14 +399,14 @@ __global__ __launch_bounds__(kSfsMarchBlock, (JTF ? 1 : SFS_MARCH_MINWAVES)) voi
     auto trip = [&](int Y, const SRaw<T>& cur) {
         const SRow<T> n = stage(cur, Y);
         const T cyN = cyOf(Y);
-        // b(., Y) = g1 v + g0 v(x-1) + g2 v(y-1)                                      (sfs_rows<3>'s `base`)
+        // b(., Y) = g1 v + g0 v(x-1) + g2 v(y-1)                                      (d B_I(c) . v)
         const T vL = dppShift<true>(n.v);
         const T bY = JTF ? n.rk : n.g1 * n.v + n.g0 * vL + n.g2 * R1.v;
         // row values at the centres of row Y - 1 (R1)
         SQ<T> qn;
         {
             const T right = dppShift<false>(b1);
-            if (JTF) {      // sfs_rows<2>: w_g * ((B_I(c) - B_I(c + e)) * mask)
+            if (JTF) {      // residual values: w_g * ((B_I(c) - B_I(c + e)) * mask)
                 qn.gh = (R1.bits & kSfsOk) ? A.w_g * ((b1 - right) * (T)sfsMr(R1.bits)) : T(0);
                 qn.gv = (R1.bits & kSfsOk) ? A.w_g * ((b1 - bY) * (T)sfsMc(R1.bits)) : T(0);
             } else {
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(kSfsMarchBlock, (JTF ? 1 : SFS_MARCH_MINWAVES)) voi
     }
 }
 
-// ---- computeCost / computeModelCost as a march (round 3): sfs_rows<0 / 1>'s expressions, centre row Y - 1 from the rows Y - 2 .. Y of X (and of delta) held in registers ---------
+// ---- computeCost / computeModelCost as a march (round 3): the residual-row expressions of the energy (header), centre row Y - 1 from the rows Y - 2 .. Y of X (and of delta) held in registers ---------
 template <class T, bool MODEL>
 __global__ __launch_bounds__(kSfsMarchBlock) void sfs_costMarch(SArgs<T> A, const T* __restrict__ dl, double* __restrict__ partials, int rowsPerGroup, int gx, int gy, int gyPerXcd) {
     __shared__ double scratch[kSfsMarchBlock / kWave + 1];
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(kSfsMarchBlock) void sfs_costMarch(SArgs<T> A, cons
         n.ok = ok; n.mr = ok ? w.mr : 0; n.mc = ok ? w.mc : 0; n.valid = ok && (w.fl & 2) != 0; n.ex = in && (w.fl & 1) != 0;
         const T cyN = coefK(A, 1, 0, Y);
         n.db = 0;
-        if (MODEL) { const T dL = dppShift<true>(n.d); n.db = (in ? w.g1 : T(0)) * n.d + (in ? w.g0 : T(0)) * dL + (in ? w.g2 : T(0)) * R1.d; }      // sfs_rows' `base`
+        if (MODEL) { const T dL = dppShift<true>(n.d); n.db = (in ? w.g1 : T(0)) * n.d + (in ? w.g0 : T(0)) * dL + (in ? w.g2 : T(0)) * R1.d; }      // d B_I(c) . delta
         // centre row Y - 1 (R1); rows Y - 2 (R2) and Y (n) around it
         {
             const int y = Y - 1;

@@ -394,7 +394,7 @@ __global__ __launch_bounds__(kBlock) void iw_bindMarch(IWArgs<T> A, int* __restr
     if (CHECK && __any(bad) && (threadIdx.x & (kWave - 1)) == 0) __hip_atomic_store(notLattice, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// r = -J^T F, p = guardedInvert(diag J^T J) r, partial sums of r.p; LATTICE = false additionally writes the compact preconditioner {M_O, M_a}
+// r = -J^T F, p = guardedInvert(diag J^T J) r, partial sums of r.p (the iteration kernels rebuild M themselves: no preconditioner vector is written)
 template <class T, bool LATTICE>
 __global__ __launch_bounds__(kBlock) void iw_jtfMarch(IWArgs<T> A, T* __restrict__ r, T* __restrict__ p, double* __restrict__ partials,
                                                       int rowsPerGroup, int gx, int gy) {

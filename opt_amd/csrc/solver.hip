@@ -672,7 +672,7 @@ struct PcgSolver : SolverBase {
                 const double aNum = hostSumLocal(prev[0]), aDen = hostSumLocal(prev[1]), s2 = hostSumLocal(prev[2]), s3 = hostSumLocal(prev[3]);
                 const T al = ((T)aDen > T(0)) ? (T)aNum / (T)aDen : T(0);
                 // an energy that does not precondition starts from p_0 = r_0 / 4 (guardedInvert(1)) but continues with z = r, so the
-                // first alphaNumerator is a quarter of sum r_0^2 -- which is what the expansion needs (see poisson_pcgIter)
+                // first alphaNumerator is a quarter of sum r_0^2 -- which is what the expansion needs (see march_pcgIter, stencil_march.h)
                 const double rr = (lIter == 0 && !preArg && !E->usesGraph) ? 4.0 * aNum : aNum;
                 const double bNum = std::fmax(rr - 2.0 * (double)al * s2 + (double)al * (double)al * s3, 0.0);
                 trace.insert(trace.end(), {(double)sp.nIter, (double)lIter, aNum, aDen, bNum, 0.0});
