@@ -98,8 +98,12 @@ __device__ __forceinline__ void sumPartialsN(const double* const (&partials)[K],
     const int tid = threadIdx.x + threadIdx.y * blockDim.x, nt = blockDim.x * blockDim.y;
     const int lane = tid & (kWave - 1), wave = tid >> 6, nw = (nt + kWave - 1) / kWave;
     double t[K];
+    // every array's first element is requested before anything is added: written as K loops the compiler waits for each array's load before it requests the next one --
+    // K dependent memory round trips in the prologue of every iteration kernel (ISA of iw_pcgIter2, round 4) -- although a workgroup rarely needs a second pass
 #pragma unroll
-    for (int k = 0; k < K; ++k) { t[k] = 0; for (int i = tid; i < n[k]; i += nt) t[k] += partials[k][i]; }
+    for (int k = 0; k < K; ++k) t[k] = tid < n[k] ? partials[k][tid] : 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) for (int i = tid + nt; i < n[k]; i += nt) t[k] += partials[k][i];
 #pragma unroll
     for (int k = 0; k < K; ++k) { t[k] = waveReduceSum(t[k]); if (lane == 0) scratch[k * (nw + 1) + wave] = t[k]; }
     __syncthreads();
