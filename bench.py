@@ -46,7 +46,7 @@ ALGO_BYTES_PER_PIXEL = 48 + 96 + 36   # PCGStep1 + PCGStep2 + PCGStep3 of the re
 # p_k 12 out, angle 4, flags 1 = 41; every second launch additionally delta 12 in / 12 out = 24 -> 12 on average; general UrShape: + U 8 + M_a 4
 MODEL_BYTES_PER_PIXEL = {"lattice": 41 + 12, "general": 41 + 12 + 8}      # general UrShape: + U 8 (M_O from the flag byte; M_a rebuilt from the pairs the stencil evaluates, round 4)
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-KERNEL_SOURCES = ["opt_amd/csrc/energy_image_warping.hip", "opt_amd/csrc/iw_device.h", "opt_amd/csrc/iw_onchip.h", "opt_amd/csrc/solver.hip", "opt_amd/csrc/common.h", "opt_amd/csrc/energy.h", "opt_amd/build.py"]
+KERNEL_SOURCES = ["opt_amd/csrc/energy_image_warping.hip", "opt_amd/csrc/iw_device.h", "opt_amd/csrc/iw_iter.h", "opt_amd/csrc/iw_step.h", "opt_amd/csrc/iw_onchip.h", "opt_amd/csrc/solver.hip", "opt_amd/csrc/common.h", "opt_amd/csrc/energy.h", "opt_amd/build.py"]
 
 
 def kernel_src_sha16():
