@@ -297,7 +297,7 @@ __device__ __forceinline__ int sfsMr(int b) { return (b >> 8) & 255; }
 __device__ __forceinline__ int sfsMc(int b) { return (b >> 16) & 255; }
 template <class T> struct SQ { T gh, gv, s0, s1, s2; };
 #ifndef SFS_MARCH_WAVES
-#define SFS_MARCH_WAVES 2
+#define SFS_MARCH_WAVES 4      // waves per workgroup (column strips side by side).  1024^2 double LM, us per iteration on one box: 1 wave 52.3, 2 36.3, 3 34.8, 4 33.9, 5 40.7 (1500 lanes for 1024 columns), 6 34.2, 8 34.0
 #endif
 constexpr int kSfsMarchBlock = SFS_MARCH_WAVES * kWave, kSfsSpan = kWave - 4;
 #ifndef SFS_MARCH_MINWAVES
