@@ -254,8 +254,10 @@ struct MarchLoop {
     template <class Op>
     bool launch(const Op& op, int W, int H, const uint8_t* flags, int cus, const PcgIterArgs<T>& a, LaunchCtx& ctx, const T* coef = nullptr) {
         // 16-byte pixels leave room for 3 waves per SIMD in 768-thread workgroups (12 column strips side by side: fewer, fatter workgroups and a quarter of the partial
-        // sums the next prologue has to add); 32-byte pixels (double4: 206 VGPRs) run 256 threads
-        const int blk = forceBlock ? forceBlock : (Op::C * sizeof(T) <= 16 ? 768 : 256);
+        // sums the next prologue has to add): best at 2048^2 (poisson 55.8 us against 58.6 with 512 threads, 60.8 with 256); narrower images do better with 512
+        // (1024^2: optical_flow 21.4 / 21.8 / 25.2 us for 512 / 768 / 256, intrinsic 28.2 / 32.5 / 30.9; poisson 256^2 11.9 / 13.6 / 13.0); 32-byte pixels
+        // (double4: 206 VGPRs) run 256 threads
+        const int blk = forceBlock ? forceBlock : (Op::C * sizeof(T) <= 16 ? (W >= 1536 ? 768 : 512) : 256);
         if (blk == 768) return launchB<Op, 768>(op, W, H, flags, cus, a, ctx, coef);
         if (blk == 512) return launchB<Op, 512>(op, W, H, flags, cus, a, ctx, coef);
         return launchB<Op, 256>(op, W, H, flags, cus, a, ctx, coef);
