@@ -703,7 +703,8 @@ struct SfsOps : EnergyOps<T> {
         // Rows per workgroup against workgroups in flight: every workgroup stages 4 halo rows on top of its own (measured at 1024^2 double LM, us per iteration:
         // 1024 workgroups of 10 rows 44.0, 768 x 13 rows 41.6, 512 x 19 rows 42.1, 256 x 37 rows 59.3): the default takes three quarters of the co-resident count.
         // (PCGInit1 -- no prologue, more arithmetic per row -- prefers every co-resident slot: 30.5 us with 1024 workgroups against 33.8 with 768)
-        const int target = marchGridOverride > 0 ? marchGridOverride : std::max(1, full ? cus * o : cus * o * 3 / 4);
+        // (4-wave workgroups, round 4: 256 / 320 / 384 / 448 / 512 / 576 workgroups 42.1 / 35.2 / 33.8 / 31.3-32.2 / 31.7-32.9 / 43.3 us, config 3 wall time best at 448: seven eighths)
+        const int target = marchGridOverride > 0 ? marchGridOverride : std::max(1, full ? cus * o : cus * o * 7 / 8);
         mgy = std::max(1, std::min(std::min(A.H, target / mgx), (kMaxPartials / 2 - 8 * mgx) / mgx));
         mRows = divUp(A.H, mgy); mgy = divUp(A.H, mRows);
         mPer = divUp(mgy, 8);
