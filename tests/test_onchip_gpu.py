@@ -4,7 +4,7 @@ The whole PCG loop of a Gauss-Newton step (reference: solverGPUGaussNewton.t:105
 launch that keeps p, r, A p and delta in registers / LDS and synchronises the grid through tagged 8-byte words.  It is selected by the
 solver itself when the image fits (tiles of 256 x 2 ROWS pixels <= CUs); these tests put it against the CPU oracle, the same way the
 streaming kernels are tested (tests/test_steady_state_gpu.py):
-  * every kernel variant (ROWS = 4 / 8 / 16 float, 4 double; A p in registers or LDS, delta in registers or memory) on small and
+  * every kernel variant (ROWS = 2 / 4 / 8 / 16 float, 2 / 4 double; A p in registers or LDS, delta in registers or memory) on small and
     ragged images (one tile, several tiles across and down, partial tiles, a single column / row of tiles), with masks;
   * flat and two-level-tree grid sums (bitwise the same result), several groups of 16 workgroups;
   * odd / even / tiny iteration counts (1, 2, 3, 7, 8, 20), two Gauss-Newton steps (the tag counter runs on between launches);
@@ -55,7 +55,7 @@ SHAPES = [(96, 64), (300, 40), (517, 33), (64, 300), (260, 131), (1, 70), (700, 
 
 
 @pytest.mark.parametrize("liters", [1, 2, 3, 7, 8])
-@pytest.mark.parametrize("rows", [4])
+@pytest.mark.parametrize("rows", [2, 4])
 @pytest.mark.parametrize("W,H", SHAPES)
 def test_variants_double(oracle_lib, monkeypatch, W, H, rows, liters):
     monkeypatch.setenv("OPT_AMD_ONCHIP_ROWS", str(rows))
@@ -64,7 +64,7 @@ def test_variants_double(oracle_lib, monkeypatch, W, H, rows, liters):
 
 
 @pytest.mark.parametrize("liters", [3, 8, 20])
-@pytest.mark.parametrize("rows", [4, 8, 16])
+@pytest.mark.parametrize("rows", [2, 4, 8, 16])
 @pytest.mark.parametrize("W,H", SHAPES)
 def test_variants_float(oracle_lib, monkeypatch, W, H, rows, liters):
     monkeypatch.setenv("OPT_AMD_ONCHIP_ROWS", str(rows))
