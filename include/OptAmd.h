@@ -72,6 +72,14 @@ void OptAmd_PlanGetTrace(Opt_Plan* plan, double* rows6);
 /* Current LM trust-region radius (reference pd.parameters.trust_region_radius). */
 double OptAmd_PlanTrustRegionRadius(Opt_Plan* plan);
 
+/* Which linear-solve path the plan's last step took and whether the plan has given the on-chip path up:
+ *   0  launch-per-iteration kernels (the problem does not fit the chip, the kernel set has no on-chip solve, or it is switched off);
+ *   1  the whole linear solve of the last step ran as one persistent on-chip launch;
+ *   2  a wait inside an on-chip launch timed out at some step (workgroups not co-resident: a shared GPU); that step was redone by the streaming kernels and
+ *      the plan stays on them for the rest of its life (also reported once on stderr).  The two paths round differently: a caller that compares runs should
+ *      check this. */
+int OptAmd_PlanOnChipStatus(Opt_Plan* plan);
+
 /* hipEvent timing of one kernel name since the last Opt_ProblemInit (requires
  * collectPerKernelTimingInfo).  Returns 0 if the name was never launched. */
 int OptAmd_PlanKernelTiming(Opt_Plan* plan, const char* kernel, long* count, double* total_ms);
@@ -132,7 +140,8 @@ typedef struct OptAmd_MailPost {
  * (0-based) its workgroup 0 stores the rank's n sums as tagged words -- value i as mailDst[t][slot * slotStride + 2 i], [.. + 2 i + 1] = (tag << 32) | payload half,
  * slot = (seq0 + k) % slots, tag = seq0 + k -- into the mailbox of every rank t < world, and every workgroup polls mailMine[slot * slotStride + r * rankStride + w] for
  * all r < world.  The edge tiles of neighbouring slabs hand each other rows of tagged words: this rank's top tiles store into edgeSendUp (the lower edge box of the
- * rank above) and poll edgeRecvUp; likewise Down.  An edge box holds [parity 2][tile][wordsPerTile] words (parity = tag & 1); NULL where there is no neighbour.
+ * rank above) and poll edgeRecvUp; likewise Down.  An edge box holds [parity 2][tile][wordsPerTile] words, tagged like the mailbox words with tag = seq0 + k
+ * (parity = tag & 1: a communicator-wide sequence number, so no word left by an earlier plan can match); NULL where there is no neighbour.
  * All stores / loads are relaxed, system-scope, 8 bytes.  Polls are bounded by timeoutTicks (100 MHz); on expiry the kernel stores a non-zero code to *errFlag. */
 typedef struct OptAmd_OnChipLinks {
     unsigned long long* mailDst[16];
@@ -169,7 +178,8 @@ typedef struct OptAmd_SlabCommExt {
     int (*allReducePlan)(void* ctx, int n, OptAmd_MailPost* post, OptAmd_MailRef* ref);
     /* Reserve `count` consecutive all-reduces of n doubles and the edge boxes for tilesX tiles of wordsPerTile words per slab edge, for ONE persistent kernel per rank
      * that carries all of them out itself (OptAmd_OnChipLinks).  Same co-residency requirement as allReducePost, over the whole launch.  Returns 0 if unavailable
-     * (too many tiles for the boxes, ranks sharing a device, ...): the caller then runs its streaming loop.  Every rank must make the same call. */
+     * (too many tiles for the boxes, ranks sharing a device, ...): the caller then runs its streaming loop.  Every rank must make the same call.
+     * count == 0 (links may be NULL) is a dry query: 1 if such a plan could be made right now, nothing reserved -- a rank asks it before it votes for running on chip. */
     int (*onChipPlan)(void* ctx, int n, int count, int tilesX, long wordsPerTile, OptAmd_OnChipLinks* links);
 } OptAmd_SlabCommExt;
 /* Attach a slab description to a plan created with dims {W, rows + 2*g}: g >= 1 ghost rows above and below the `rows` owned

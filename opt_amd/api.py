@@ -23,7 +23,7 @@ OPT_SYMBOLS = ["Opt_NewState", "Opt_ProblemDefine", "Opt_ProblemDelete", "Opt_Pr
 OPTAMD_SYMBOLS = ["OptAmd_Version", "OptAmd_EnergyCount", "OptAmd_EnergyName", "OptAmd_PlanNumUnknownScalars", "OptAmd_PlanVector",
                   "OptAmd_EvalJTF", "OptAmd_ApplyJTJ", "OptAmd_EvalCost", "OptAmd_PlanEnableTrace", "OptAmd_PlanTraceRows",
                   "OptAmd_PlanGetTrace", "OptAmd_PlanTrustRegionRadius", "OptAmd_PlanKernelTiming", "OptAmd_PlanSetTiming", "OptAmd_PlanKernelCount",
-                  "OptAmd_PlanKernelName", "OptAmd_PlanSetSlab", "OptAmd_PlanSetSlabExt", "OptAmd_CheckProblemFile", "OptAmd_ProblemFileHash"]
+                  "OptAmd_PlanKernelName", "OptAmd_PlanOnChipStatus", "OptAmd_PlanSetSlab", "OptAmd_PlanSetSlabExt", "OptAmd_CheckProblemFile", "OptAmd_ProblemFileHash"]
 
 
 class Opt_InitializationParameters(ctypes.Structure):
@@ -79,6 +79,7 @@ def lib():
     L.OptAmd_PlanTraceRows.restype = cl; L.OptAmd_PlanTraceRows.argtypes = [vp]
     L.OptAmd_PlanGetTrace.restype = None; L.OptAmd_PlanGetTrace.argtypes = [vp, vp]
     L.OptAmd_PlanTrustRegionRadius.restype = cd; L.OptAmd_PlanTrustRegionRadius.argtypes = [vp]
+    L.OptAmd_PlanOnChipStatus.restype = ci; L.OptAmd_PlanOnChipStatus.argtypes = [vp]
     L.OptAmd_PlanSetTiming.restype = None; L.OptAmd_PlanSetTiming.argtypes = [vp, ci]
     L.OptAmd_PlanKernelTiming.restype = ci; L.OptAmd_PlanKernelTiming.argtypes = [vp, cp, ctypes.POINTER(cl), ctypes.POINTER(cd)]
     L.OptAmd_PlanKernelCount.restype = ci; L.OptAmd_PlanKernelCount.argtypes = [vp]
@@ -229,6 +230,10 @@ class Solver:
 
     def trust_region_radius(self):
         return lib().OptAmd_PlanTrustRegionRadius(self.plan)
+
+    def on_chip_status(self):
+        """0: launch-per-iteration kernels; 1: the last step's linear solve ran as one on-chip launch; 2: an on-chip wait timed out, the plan fell back for good."""
+        return lib().OptAmd_PlanOnChipStatus(self.plan)
 
     def set_timing(self, on):
         """Per-kernel hipEvent timing on / off from the next launch on (totals restart)."""

@@ -332,7 +332,9 @@ int peerAllReducePlan(void* c, int n, OptAmd_MailPost* post, OptAmd_MailRef* ref
 int peerOnChipPlan(void* c, int n, int count, int tilesX, long wordsPerTile, OptAmd_OnChipLinks* L) {
     auto* x = (PeerCtx*)c;
     if (failed(x, "onChipPlan")) return 0;
-    if (n > kMaxVals || count < 1 || !L || (size_t)tilesX * (size_t)wordsPerTile > kEdgeWords) return 0;
+    if (n > kMaxVals || (size_t)tilesX * (size_t)wordsPerTile > kEdgeWords) return 0;
+    if (count == 0) return 1;      // dry query: could a plan be made? (part of the ranks' vote on running on chip; nothing is reserved)
+    if (count < 1 || !L) return 0;
     const u64 seq0 = x->arSeq + 1;
     x->arSeq += (u64)count;
     for (int t = 0; t < 16; ++t) L->mailDst[t] = t < x->world ? &x->win[t]->ll[0][x->rank][0] : nullptr;

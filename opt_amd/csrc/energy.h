@@ -74,6 +74,10 @@ struct LmInitArgs {
     Reduction *rDotP, *q;           // partial sums of r . p (the first alphaNumerator) and of Q_0 (exactly 0)
 };
 
+// Levenberg-Marquardt controls of EnergyOps::pcgSolveOnChip: the scalars of PCGFinalizeDiagonal (solver.t:631-664), q_tolerance and residual_reset_period (:1077-1102).
+template <class T>
+struct OnChipLm { T radius, minLm, maxLm, qTolerance; int resetPeriod; };
+
 // Everything the solver needs from an energy.  T = opt_float (float or double).
 // Contract shared by all implementations:
 //  * solver vectors are laid out like the unknown vector: unknown images in declaration order, AoS,
@@ -130,16 +134,22 @@ struct EnergyOps {
     virtual bool finishUpdate(const T* /*pPrev*/, const T* /*pLast*/, const T* /*delta*/, const Reduction& /*aNum*/, const Reduction& /*aDen*/, LaunchCtx&) { return false; }
     // Optional: one WHOLE Gauss-Newton PCG iteration as a single kernel (see PcgIterArgs and solver.hip).
     virtual bool pcgIteration(const PcgIterArgs<T>& /*args*/, LaunchCtx&) { return false; }
-    // Optional (Gauss-Newton, single GPU): the WHOLE linear solve -- lIterations PCG iterations (solverGPUGaussNewton.t:1056-1092) from r = r_0, p = M r_0 as PCGInit1
+    // Optional (single GPU; Gauss-Newton also on row slabs): the WHOLE linear solve -- lIterations PCG iterations (solverGPUGaussNewton.t:1056-1092) from r = r_0, p = M r_0 as PCGInit1
     // left them, then PCGLinearUpdate X += delta -- as one persistent launch that keeps the loop state on chip (iw_onchip.h).  r0 and p0 are only read; delta
     // receives sum alpha_k p_k; traceDev (or nullptr) receives alphaNum, alphaDen, s2, s3 of every iteration (4 doubles each; beta numerator by expansion as
     // in PcgIterArgs).  false: the problem does not fit the chip or the kernel set has no such kernel -- nothing was touched.
-    virtual bool pcgSolveOnChip(const T* /*r0*/, const T* /*p0*/, T* /*delta*/, int /*lIterations*/, double* /*traceDev*/, LaunchCtx&) { return false; }
+    // lm != nullptr: the Levenberg-Marquardt loop instead (A = J^T J + diag(CtC), the q early-out decided on chip, the split residual reset as a second stencil pass;
+    // r0 = b and p0 as PCGFinalizeDiagonal left them).  Then the kernel only produces delta: the solver applies savePreviousUnknowns + PCGLinearUpdate itself.
+    virtual bool pcgSolveOnChip(const T* /*r0*/, const T* /*p0*/, T* /*delta*/, int /*lIterations*/, double* /*traceDev*/, const OnChipLm<T>* /*lm*/, LaunchCtx&) { return false; }
     // Row slabs: would pcgSolveOnChip run for this rank's slab right now (kernel variant fits, unit lattice, the communicator offers onChipPlan ...)?  The solver
     // makes the decision collective (all ranks or none) before anyone launches.  onChipPlan / onChipCtx: the communicator's entry (OptAmd_SlabCommExt), set by the solver.
     virtual bool slabOnChipAvailable(int /*lIterations*/) { return false; }
     int (*onChipPlan)(void*, int, int, int, long, OptAmd_OnChipLinks*) = nullptr;
     void* onChipCtx = nullptr;
+    // Row slabs, behind a pcgSolveOnChip launch (which then applies nothing itself): onChipVerdict leaves this rank's verdict (0 fine / 1 failed) in a device scalar, the
+    // solver all-reduces it, onChipApply applies X += delta iff the sum is 0 -- every rank keeps its update or none does -- and tells the host (onChipFailed).
+    virtual void onChipVerdict(double* /*out*/, bool /*refused*/, LaunchCtx&) {}
+    virtual void onChipApply(const T* /*delta*/, const double* /*verdict*/, bool /*refused*/, LaunchCtx&) {}
     // After the stream has drained: did a wait inside the last on-chip solve time out (another tenant on the GPU kept its workgroups from being co-resident)?
     // Then the unknowns were left untouched, the kernel set has switched the path off for this plan, and the caller redoes the linear solve.
     virtual bool onChipFailed() { return false; }

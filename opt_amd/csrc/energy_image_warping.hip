@@ -59,7 +59,8 @@ struct ImageWarpingOps : EnergyOps<T> {
         HIP_CHECK(hipEventCreateWithFlags(&bindEvent, hipEventDisableTiming));
     }
     ~ImageWarpingOps() override {
-        if (ocS.slots) { (void)hipFree(ocS.slots); (void)hipFree(ocS.groupSlots); (void)hipFree(ocS.inbox); (void)hipFree(ocS.bad); (void)hipHostFree(ocS.hostErr); }
+        if (ocS.slots) { (void)hipFree(ocS.slots); (void)hipFree(ocS.groupSlots); (void)hipFree(ocS.inbox); }
+        if (ocS.bad) { (void)hipFree(ocS.bad); (void)hipHostFree(ocS.hostErr); }
         (void)hipHostFree(hNotLattice); (void)hipEventDestroy(bindEvent);
         for (T* b : ring) if (b) (void)hipFree(b);
         (void)hipFree(A.flags); (void)hipFree(A.cs); if (alphaSlots) (void)hipFree(alphaSlots); (void)hipFree(dNotLattice);
@@ -366,11 +367,11 @@ struct ImageWarpingOps : EnergyOps<T> {
     bool supportsSlab() const override { return true; }
     long rowScalars(int img) const override { return (long)A.W * (img == 0 ? 2 : 1); }
 
-    // ---- the whole linear solve on chip (iw_onchip.h): unit lattice, Gauss-Newton, single GPU, tiles <= CUs ------------------------------------------
+    // ---- the whole linear solve on chip (iw_onchip.h): unit lattice, Gauss-Newton (also on row slabs) or Levenberg-Marquardt, tiles <= CUs ------------------------------------------
     // OPT_AMD_ONCHIP=0 switches it off (the one A/B switch of the path); OPT_AMD_ONCHIP_ROWS=r forces the variant with r rows per lane (tests run every
     // variant on small images); OPT_AMD_ONCHIP_FLAT=n: grids of up to n workgroups sum flat instead of through the two-level tree (same bits either way).
     struct OcVariant { int rows; bool apLds, deltaGlb; const void* fn; size_t lds; int occ; };
-    std::vector<OcVariant> ocVariants;
+    std::vector<OcVariant> ocVariants, ocVariantsLM;
     bool ocEnabled = true, ocFailed = false, ocLaunched = false;
     int ocForceRows = 0, ocFlatMax = 256, ocFailAt = -1; long long* ocProf = nullptr; long long ocTimeoutTicks = 2000LL * 100000;      // 2 s of the 100 MHz wall clock
     OnchipSync ocS{}; unsigned ocSeq = 1; size_t ocInboxBytes = 0, ocSlotBytes = 0, ocGroupBytes = 0;
@@ -381,22 +382,28 @@ struct ImageWarpingOps : EnergyOps<T> {
             ocVariants.push_back({4, false, false, (const void*)iw_onchipPcg<T, 4, false, false>, OcLds<T>::total(4, false), 0});
             ocVariants.push_back({8, false, false, (const void*)iw_onchipPcg<T, 8, false, false>, OcLds<T>::total(8, false), 0});
             ocVariants.push_back({16, true, true, (const void*)iw_onchipPcg<T, 16, true, true>, OcLds<T>::total(16, true), 0});
+            // Levenberg-Marquardt: A p and delta in registers, b in LDS (up to 4096 pixels per CU: 1 M pixels)
+            ocVariantsLM.push_back({2, false, false, (const void*)iw_onchipPcg<T, 2, false, false, true>, OcLds<T>::total(2, false, true), 0});
+            ocVariantsLM.push_back({4, false, false, (const void*)iw_onchipPcg<T, 4, false, false, true>, OcLds<T>::total(4, false, true), 0});
+            ocVariantsLM.push_back({8, false, false, (const void*)iw_onchipPcg<T, 8, false, false, true>, OcLds<T>::total(8, false, true), 0});
         } else {
             ocVariants.push_back({2, false, false, (const void*)iw_onchipPcg<T, 2, false, false>, OcLds<T>::total(2, false), 0});
             ocVariants.push_back({4, false, false, (const void*)iw_onchipPcg<T, 4, false, false>, OcLds<T>::total(4, false), 0});      // (double: up to 2048 pixels per CU)
+            ocVariantsLM.push_back({2, false, false, (const void*)iw_onchipPcg<T, 2, false, false, true>, OcLds<T>::total(2, false, true), 0});      // (double LM: b and the halo copies of delta do not fit the LDS at ROWS = 4)
         }
-        for (auto& v : ocVariants) {
-            HIP_CHECK(hipFuncSetAttribute(v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v.occ, v.fn, kOcBlock, v.lds) != hipSuccess) v.occ = 0;
-            v.occ = std::min(v.occ, 1);      // one workgroup per CU: the co-residency the in-kernel waits rely on does not depend on how the dispatcher packs CUs
-        }
+        for (auto* vs : {&ocVariants, &ocVariantsLM})
+            for (auto& v : *vs) {
+                if (hipFuncSetAttribute(v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds) != hipSuccess) { (void)hipGetLastError(); v.occ = 0; continue; }      // (a variant the device cannot hold is simply not offered)
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v.occ, v.fn, kOcBlock, v.lds) != hipSuccess) { (void)hipGetLastError(); v.occ = 0; }
+                v.occ = std::min(v.occ, 1);      // one workgroup per CU: the co-residency the in-kernel waits rely on does not depend on how the dispatcher packs CUs
+            }
     }
     // Which variant, if any: the smallest ROWS whose tiles fit one per CU.  A slab's owned rows must be whole tiles (its last tile row faces the next rank's first).
-    const OcVariant* ocSelect(int& tX, int& tY) {
+    const OcVariant* ocSelect(int& tX, int& tY, bool lmv = false) {
         ocInit();
         tX = divUp(A.W, kOcTileW);
         const int rowsOwned = A.yEnd - A.yBegin;
-        for (const auto& v : ocVariants) {
+        for (const auto& v : lmv ? ocVariantsLM : ocVariants) {
             if (ocForceRows && v.rows != ocForceRows) continue;
             const int th = kOcWavesY * v.rows;
             if (this->slab.active && rowsOwned % th != 0) continue;
@@ -407,35 +414,39 @@ struct ImageWarpingOps : EnergyOps<T> {
     }
     bool slabOnChipAvailable(int L) override {      // (row slabs: the lattice verdict of this bind is already known, bind() read it back)
         int tX, tY;
-        return ocEnabled && !ocFailed && L > 0 && this->slab.active && this->slab.ghost >= 2 && this->onChipPlan && lattice &&
-               (unsigned long long)A.W * A.H * 3ull * sizeof(T) < (1ull << 32) && ocSelect(tX, tY) != nullptr;
+        if (!(ocEnabled && !ocFailed && L > 0 && this->slab.active && this->slab.ghost >= 2 && this->onChipPlan && lattice &&
+              (unsigned long long)A.W * A.H * 3ull * sizeof(T) < (1ull << 32) && ocSelect(tX, tY) != nullptr)) return false;
+        // ... and the communicator could plan it (count = 0: a dry query -- its sticky error state and the capacity of its edge boxes -- so that a "no" is part of the vote)
+        return this->onChipPlan(this->onChipCtx, 4, 0, tX, 3L * kOcTileW * (long)(sizeof(T) / 4), nullptr) != 0;
     }
-    bool pcgSolveOnChip(const T* r0, const T* p0, T* delta, int L, double* traceDev, LaunchCtx& ctx) override {
+    bool pcgSolveOnChip(const T* r0, const T* p0, T* delta, int L, double* traceDev, const OnChipLm<T>* lmArgs, LaunchCtx& ctx) override {
         const bool slabMode = this->slab.active;
+        if (lmArgs && (slabMode || traceDev || lmArgs->resetPeriod < 1)) return false;      // the LM variants are single-GPU
         if (!ocEnabled || ocFailed || L <= 0 || (unsigned long long)A.W * A.H * 3ull * sizeof(T) >= (1ull << 32)) return false;
         if (slabMode && (traceDev || !slabOnChipAvailable(L))) return false;
         resolveLattice();
         if (initPending && initHint && !lattice) { launchJtf(false, ctx); initHint = false; }      // PCGInit1 ran on the previous bind's verdict (see beginLoop)
         if (!lattice) return false;
         int tX = 0, tY = 0;
-        const OcVariant* V = ocSelect(tX, tY);
+        const OcVariant* V = ocSelect(tX, tY, lmArgs != nullptr);
         if (!V) return false;
         const int G = tX * tY;
+        if (lmArgs && G > ocFlatMax) return false;      // (the LM variants sum flat)
         if (!ocS.slots) {      // sized for this plan's image once (the dimensions of a plan are fixed); zero = no tag
             const int maxRows = ocVariants.front().rows;
             const int gMax = std::min(kOcMaxTiles, tX * divUp(A.yEnd - A.yBegin, kOcWavesY * maxRows));
             ocS.stride = 3L * kOcTileW * (long)(sizeof(T) / 4);
-            ocSlotBytes = sizeof(oc_u64) * 2 * (size_t)gMax * 8; ocGroupBytes = sizeof(oc_u64) * 2 * (size_t)divUp(gMax, kOcGroup) * 8;
+            ocSlotBytes = sizeof(oc_u64) * 2 * (size_t)gMax * 2 * kOcSumsMax; ocGroupBytes = sizeof(oc_u64) * 2 * (size_t)divUp(gMax, kOcGroup) * 8;
             ocInboxBytes = sizeof(oc_u64) * 2 * (size_t)gMax * 4 * (size_t)ocS.stride;
             HIP_CHECK(hipMalloc((void**)&ocS.slots, ocSlotBytes)); HIP_CHECK(hipMalloc((void**)&ocS.groupSlots, ocGroupBytes)); HIP_CHECK(hipMalloc((void**)&ocS.inbox, ocInboxBytes));
-            HIP_CHECK(hipMalloc((void**)&ocS.bad, sizeof(int))); HIP_CHECK(hipHostMalloc((void**)&ocS.hostErr, 64)); *ocS.hostErr = 0;
-            HIP_CHECK(hipMemsetAsync(ocS.bad, 0, sizeof(int), ctx.stream));
+            if (!ocS.bad) { HIP_CHECK(hipMalloc((void**)&ocS.bad, sizeof(int))); HIP_CHECK(hipHostMalloc((void**)&ocS.hostErr, 64)); *ocS.hostErr = 0; HIP_CHECK(hipMemsetAsync(ocS.bad, 0, sizeof(int), ctx.stream)); }
             ocSeq = 0xE0000001u;      // forces the clearing below
 #if OC_PROFILE
             if (getenv("OPT_AMD_ONCHIP_PROFILE")) { HIP_CHECK(hipMalloc((void**)&ocProf, sizeof(long long) * kOcWaves * 16 * kOcMaxTiles)); }
 #endif
         }
-        if (ocSeq > 0xE0000000u || ocSeq + (unsigned)L > 0xE0000000u) {      // tags never repeat: start over on cleared buffers long before the counter wraps
+        const unsigned nTags = lmArgs ? 2u * (unsigned)L : (unsigned)L;      // (an LM iteration that ends with the split residual reset has two phases)
+        if (ocSeq > 0xE0000000u || ocSeq + nTags > 0xE0000000u) {      // tags never repeat: start over on cleared buffers long before the counter wraps
             HIP_CHECK(hipMemsetAsync(ocS.slots, 0, ocSlotBytes, ctx.stream)); HIP_CHECK(hipMemsetAsync(ocS.groupSlots, 0, ocGroupBytes, ctx.stream));
             HIP_CHECK(hipMemsetAsync(ocS.inbox, 0, ocInboxBytes, ctx.stream));
             ocSeq = 2;
@@ -450,19 +461,16 @@ struct ImageWarpingOps : EnergyOps<T> {
             links.edgeParityStride = Lk.edgeParityStride;
         }
         OnchipArgs<T> K{A.W, A.H, tX, tY, G, A.yBegin, A.yEnd, links, r0, p0, A.Angle, A.flags, delta, A.w_fit, A.w_reg, L, ocSeq, G <= ocFlatMax ? 1 : 0, ocS, traceDev,
-                        ocTimeoutTicks, ocProf, ocFailAt};
-        ocSeq += (unsigned)L;
+                        ocTimeoutTicks, ocProf, ocFailAt, T(0), T(0), T(0), T(0), 1};
+        if (lmArgs) { K.lmRadius = lmArgs->radius; K.lmMin = lmArgs->minLm; K.lmMax = lmArgs->maxLm; K.qTolerance = lmArgs->qTolerance; K.resetPeriod = lmArgs->resetPeriod; }
+        ocSeq += nTags;
         {
             ScopedKernel k(ctx, "PCGSolveOnChip");
             void* kargs[] = {(void*)&K};
             HIP_CHECK(hipLaunchKernel(V->fn, dim3(G), dim3(kOcBlock), kargs, V->lds, ctx.stream));
         }
-        {
-            ScopedKernel k(ctx, "PCGLinearUpdate");
-            const long N = (long)A.W * A.H;
-            iw_applyDelta<T><<<flatGrid(N), kBlock, 0, ctx.stream>>>(const_cast<T*>(A.Offset), const_cast<T*>(A.Angle), delta, N, ocS.bad, ocS.hostErr);
-        }
-        ocLaunched = true;
+        if (lmArgs) { iw_relayBad<<<1, kWave, 0, ctx.stream>>>(ocS.bad, ocS.hostErr); ocLaunched = true; }      // (the solver applies the update itself)
+        else if (!slabMode) onChipApply(delta, nullptr, false, ctx);      // (row slabs: the solver all-reduces the ranks' verdicts first, then calls onChipApply)
 #if OC_PROFILE
         if (ocProf) {      // development builds: where an iteration's time goes, per wave of a workgroup, mean over the workgroups
             std::vector<long long> h((size_t)G * kOcWaves * 16);
@@ -486,6 +494,18 @@ struct ImageWarpingOps : EnergyOps<T> {
         }
 #endif
         return true;
+    }
+    // PCGLinearUpdate behind the on-chip Gauss-Newton solve.  verdict (row slabs): device scalar, the number of ranks whose kernel failed -- all ranks apply or none.
+    // refused: this rank launched no kernel at all (its peers will time out): its contribution to the verdict is "failed".
+    void onChipVerdict(double* out, bool refused, LaunchCtx& ctx) override {
+        if (!ocS.bad) { HIP_CHECK(hipMalloc((void**)&ocS.bad, sizeof(int))); HIP_CHECK(hipHostMalloc((void**)&ocS.hostErr, 64)); *ocS.hostErr = 0; HIP_CHECK(hipMemsetAsync(ocS.bad, 0, sizeof(int), ctx.stream)); }
+        iw_badToScalar<<<1, kWave, 0, ctx.stream>>>(ocS.bad, refused ? 1 : 0, out);
+    }
+    void onChipApply(const T* delta, const double* verdict, bool /*refused*/, LaunchCtx& ctx) override {
+        ScopedKernel k(ctx, "PCGLinearUpdate");
+        const long N = (long)A.W * A.H;
+        iw_applyDelta<T><<<flatGrid(N), kBlock, 0, ctx.stream>>>(const_cast<T*>(A.Offset), const_cast<T*>(A.Angle), delta, N, ocS.bad, verdict, ocS.hostErr);
+        ocLaunched = true;
     }
     bool onChipFailed() override {
         if (!ocLaunched) return false;

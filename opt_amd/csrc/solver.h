@@ -40,6 +40,7 @@ struct SolverBase {
     virtual double applyJTJ(void** params, const void* v, void* out) = 0;
     virtual double evalCost(void** params) = 0;
     virtual double trustRegionRadius() const = 0;
+    virtual int onChipStatus() const { return 0; }             // OptAmd_PlanOnChipStatus
     virtual int setSlab(long row0, long rows, long globalHeight, const OptAmd_SlabComm* comm) = 0;
     virtual int setSlabExt(const OptAmd_SlabCommExt* ext) = 0;
     virtual void setTiming(bool on) = 0;                        // OptAmd_PlanSetTiming

@@ -405,7 +405,7 @@ struct PcgSolver : SolverBase {
         (void)hipStreamDestroy(stream);
     }
 
-    bool onChipOk = true, usedOnChip = false; double* onChipTrace = nullptr; int onChipTraceCap = 0;      // EnergyOps::pcgSolveOnChip
+    bool onChipOk = true, usedOnChip = false, onChipFellBack = false, lastStepOnChip = false; double* onChipTrace = nullptr; int onChipTraceCap = 0;      // EnergyOps::pcgSolveOnChip
     // true iff `mine` holds on every rank: one all-reduce of a count and one read-back (once per Gauss-Newton step in slab mode)
     bool allRanksAgree(bool mine) {
         hostBuf[0] = mine ? 0.0 : 1.0;
@@ -592,8 +592,15 @@ struct PcgSolver : SolverBase {
             if (!slabOnChip && !E->slabIterationAvailable()) return false;      // (before anything is exchanged: the three-kernel loop needs r = 0 on ghost rows)
             if (slabOnChip) {      // the kernel reads r_0, p_0 of its halo rows from the ghost rows
                 exchangeVector(r); exchangeVector(p);
-                if (E->pcgSolveOnChip(r, p, delta, sp.lIterations, nullptr, ctx)) { usedOnChip = true; unknownsUpdated = true; return true; }
-                fprintf(stderr, "Opt(amd): the slab on-chip solve was agreed on but refused by this rank's kernel set\n"); exit(1);
+                // A rank whose kernel set refuses after the vote (it should not: the vote covers the communicator's capacity and error state) launches nothing; its
+                // peers' waits then time out, and the verdict below makes every rank redo the step with the streaming loop -- a library does not exit().
+                const bool refused = !E->pcgSolveOnChip(r, p, delta, sp.lIterations, nullptr, nullptr, ctx);
+                if (refused) fprintf(stderr, "Opt(amd): the slab on-chip solve was agreed on but refused by this rank's kernel set; the step will be redone by the streaming loop\n");
+                // all ranks keep their update or none does: the ranks' verdicts (0 fine / 1 a wait timed out) are all-reduced on the device, PCGLinearUpdate checks the sum
+                E->onChipVerdict(scal + 5, refused, ctx);
+                comm.allReduceSum(comm.ctx, scal + 5, 1, (void*)stream);
+                E->onChipApply(delta, scal + 5, refused, ctx);
+                usedOnChip = true; unknownsUpdated = true; return true;
             }
         }
         // The whole linear solve as one persistent launch with the loop state on chip, if the kernel set has one and the problem fits (iw_onchip.h);
@@ -604,7 +611,7 @@ struct PcgSolver : SolverBase {
                 if (onChipTraceCap < sp.lIterations) { if (onChipTrace) HIP_CHECK(hipFree(onChipTrace)); onChipTraceCap = sp.lIterations; HIP_CHECK(hipMalloc((void**)&onChipTrace, sizeof(double) * 4 * onChipTraceCap)); }
                 tr = onChipTrace;
             }
-            if (E->pcgSolveOnChip(r, p, delta, sp.lIterations, tr, ctx)) {
+            if (E->pcgSolveOnChip(r, p, delta, sp.lIterations, tr, nullptr, ctx)) {
                 usedOnChip = true; unknownsUpdated = true;
                 if (traceEnabled) {
                     std::vector<double> h(4 * (size_t)sp.lIterations);
@@ -695,6 +702,12 @@ struct PcgSolver : SolverBase {
     // restarts from that r with beta given directly.  Returns false (nothing touched) if the energy has no such kernel.
     bool runSingleKernelLoopLM(const T* preArg, T Q0, T q_tolerance) {
         if (distributed || traceEnabled || keepReferenceP) return false;
+        // The whole LM linear solve as one persistent launch (iw_onchip.h, LMV): CtC, the q early-out and the split residual reset happen on chip, the host
+        // sees only delta.  (A listening caller -- verbosity > 0 -- wants the "breaking at iteration" message: the launch-per-iteration loop prints it.)
+        if (onChipOk && preArg && sp.lIterations > 0 && verbosity == 0 && Q0 == T(0)) {
+            const OnChipLm<T> la{trust_region_radius, min_lm_diagonal, max_lm_diagonal, q_tolerance, sp.residual_reset_period};
+            if (E->pcgSolveOnChip(r, p, delta, sp.lIterations, nullptr, &la, ctx)) { usedOnChip = true; return true; }
+        }
         if (!delta2) delta2 = allocVec();                       // zero-filled like delta; every launch that updates delta rewrites all of it
         Reduction prev[4] = {redC, Reduction{}, Reduction{}, Reduction{}};
         int cur = 0;
@@ -967,49 +980,59 @@ struct PcgSolver : SolverBase {
         }
 
         T model_cost_change = 0;
-        if (lm) {   // solver.t:1108-1113, 819-827
-            exchangeVector(delta);
-            E->evalModelCost(delta, distributed ? redA : redMH, ctx);   // (its own partials buffer: the value is read together with the new cost below)
-            imageOp(3);   // savePreviousUnknowns + PCGLinearUpdate
-        } else if (!unknownsUpdated) imageOp(0);   // PCGLinearUpdate
-        exchangeUnknowns();
-        E->precompute(ctx);
-        // The reference reads the model cost, then updates, then reads the new cost (two blocking copies, solver.t:1108-1117).  Neither value steers
-        // anything before both are known, so all of it is enqueued and the stream is drained once.
-        T newCost;
-        if (lm && !distributed) {
-            E->evalCost(redCH, ctx);                   // both sets of partials are written straight to pinned memory: one drain, no copy kernels
-            drain();
-            double sm = 0, sc = 0;
-            for (int i = 0; i < redMH.n; ++i) sm += redMH.partials[i];
-            for (int i = 0; i < redCH.n; ++i) sc += redCH.partials[i];
-            newCost = (T)sc;
-            const T model_cost = (T)sm;
-            if (verbosity > 0) printf(" cost=%f \n model_cost=%f \n", (double)prevCost, (double)model_cost);
-            model_cost_change = prevCost - model_cost;
-            if (verbosity > 0) printf(" model_cost_change=%f \n", (double)model_cost_change);
-        } else {
-            if (lm) {
-                T model_cost = (T)hostSum(redA);
+        T newCost = 0;
+        // What follows the linear solve (solver.t:1108-1117): model cost, savePreviousUnknowns + PCGLinearUpdate, precompute, the new cost.  The reference reads the
+        // model cost, then updates, then reads the new cost (two blocking copies); neither value steers anything before both are known, so all of it is enqueued
+        // and the stream is drained once.
+        auto afterLinearSolve = [&]() {
+            if (lm) {   // solver.t:1108-1113, 819-827
+                exchangeVector(delta);
+                E->evalModelCost(delta, distributed ? redA : redMH, ctx);   // (its own partials buffer: the value is read together with the new cost below)
+                imageOp(3);   // savePreviousUnknowns + PCGLinearUpdate
+            } else if (!unknownsUpdated) imageOp(0);   // PCGLinearUpdate
+            exchangeUnknowns();
+            E->precompute(ctx);
+            if (lm && !distributed) {
+                E->evalCost(redCH, ctx);                   // both sets of partials are written straight to pinned memory: one drain, no copy kernels
+                drain();
+                double sm = 0, sc = 0;
+                for (int i = 0; i < redMH.n; ++i) sm += redMH.partials[i];
+                for (int i = 0; i < redCH.n; ++i) sc += redCH.partials[i];
+                newCost = (T)sc;
+                const T model_cost = (T)sm;
                 if (verbosity > 0) printf(" cost=%f \n model_cost=%f \n", (double)prevCost, (double)model_cost);
                 model_cost_change = prevCost - model_cost;
                 if (verbosity > 0) printf(" model_cost_change=%f \n", (double)model_cost_change);
+            } else {
+                if (lm) {
+                    T model_cost = (T)hostSum(redA);
+                    if (verbosity > 0) printf(" cost=%f \n model_cost=%f \n", (double)prevCost, (double)model_cost);
+                    model_cost_change = prevCost - model_cost;
+                    if (verbosity > 0) printf(" model_cost_change=%f \n", (double)model_cost_change);
+                }
+                newCost = computeCost();
             }
-            newCost = computeCost();
-        }
+        };
+        afterLinearSolve();
 
+        lastStepOnChip = usedOnChip;
         if (usedOnChip) {      // (the stream has drained: the cost was read)
             usedOnChip = false;
             bool ocFailedNow = E->onChipFailed();
-            if (distributed) ocFailedNow = !allRanksAgree(!ocFailedNow);      // a rank whose waits timed out applied nothing: then nobody keeps its update...
             if (ocFailedNow) {
-                fprintf(stderr, "Opt(amd): a wait inside the on-chip PCG kernel timed out (its workgroups were not co-resident: is the GPU shared?); the unknowns were left untouched, "
+                fprintf(stderr, "Opt(amd): a wait inside the on-chip PCG kernel timed out (its workgroups were not co-resident: is the GPU shared?); "
                                 "this linear solve is redone with the streaming kernels and the plan stays on them\n");
-                onChipOk = false; unknownsUpdated = false;
-                if (!runSingleKernelLoop(preArg)) { fprintf(stderr, "Opt(amd): the streaming loop refused the redo\n"); exit(1); }
-                if (!unknownsUpdated) imageOp(0);
-                E->precompute(ctx);
-                newCost = computeCost();
+                onChipOk = false; onChipFellBack = true; lastStepOnChip = false; unknownsUpdated = false;
+                if (lm) {      // the kernel produced no delta: the update above added nothing meaningful -- back to the saved unknowns, then the launch-per-iteration loop
+                    imageOp(2);
+                    if (!runSingleKernelLoopLM(preArg, T(0), q_tolerance)) { fprintf(stderr, "Opt(amd): the streaming LM loop refused the redo\n"); exit(1); }
+                } else {
+                    // Gauss-Newton: nothing was applied (iw_applyDelta checks the flag -- in slab mode the all-reduced verdict, so no rank kept its update).  Row slabs
+                    // start the redone loop from delta = 0 as PCGInit1 left it: the ROWS = 16 variant accumulates delta in memory while it runs.
+                    if (distributed) HIP_CHECK(hipMemsetAsync(delta, 0, nPad * sizeof(T), stream));
+                    if (!runSingleKernelLoop(preArg)) { fprintf(stderr, "Opt(amd): the streaming loop refused the redo\n"); exit(1); }
+                }
+                afterLinearSolve();
             }
         }
         if (lm) {   // solver.t:1119-1157
@@ -1058,6 +1081,7 @@ struct PcgSolver : SolverBase {
     }
     long numUnknownScalars() const override { return n; }
     double trustRegionRadius() const override { return (double)trust_region_radius; }
+    int onChipStatus() const override { return onChipFellBack ? 2 : lastStepOnChip ? 1 : 0; }
     void* vector(const std::string& nm) override {
         if (nm == "delta") return delta; if (nm == "r") return r; if (nm == "b") return b; if (nm == "Adelta") return Adelta;
         if (nm == "z") return z; if (nm == "p") return p; if (nm == "Ap_X") return Ap_X; if (nm == "CtC") return CtC;

@@ -102,4 +102,5 @@ def test_verbose_run_takes_the_listening_path(oracle_lib, capfd):
         costs.append(g.cost())
     costs.append(g.cost())
     g.close()
-    assert costs[:3] == [c[1] for c in silent][:3]
+    # (the silent run takes the on-chip LM solve since round 5, the verbose one the launch-per-iteration loop: the same iterates, sums in another order)
+    assert np.allclose(costs[:3], [c[1] for c in silent][:3], rtol=1e-12, atol=0)

@@ -36,6 +36,7 @@ def _rank_main(rank, world, port, case, q):
         os.environ["OPT_AMD_ITER_MAXWG"] = str(max(1, 224 // world))
         os.environ["OPT_AMD_PEER_POST"] = "1"      # grids capped: keep the posted all-reduce although the ranks share a GPU (the communicator would take it away)
     os.environ.update(case.get("env", {}))
+    os.environ.update(case.get("env_by_rank", {}).get(rank, {}))
     if world == 1:
         os.environ["OPT_AMD_FORCE_COMM"] = "1"
     torch.cuda.set_device(0)                                   # all ranks share the box's one GPU
@@ -52,6 +53,9 @@ def _rank_main(rank, world, port, case, q):
     assert job.comm_kind == "peer" and job._peer.self_test_ok      # the self-test passed: no silent fall-back to RCCL in this test
     if "expect_onchip" in case:
         assert ("PCGSolveOnChip" in job.solver.kernel_timings()) == case["expect_onchip"], job.solver.kernel_timings().keys()
+    if case.get("expect_fallback"):
+        t = job.solver.kernel_timings()
+        assert t["PCGSolveOnChip"][0] == 1 and "PCGIteration" in t and job.solver.on_chip_status() == 2, (t.keys(), job.solver.on_chip_status())
     q.put((rank, costs, job.owned_unknowns(), job.layout.row0, job.layout.rows, job._peer.mem_kind, job._peer.error()))
     job.close()
     dist.destroy_process_group()
@@ -233,6 +237,26 @@ def test_onchip_linear_solve_across_ranks(world, W, rows_per_rank, ghost, double
     for r in range(world):
         _, costs, unk, row0, rows, mem_kind, err = res[r]
         assert err == 0
+        np.testing.assert_allclose(costs, c1, rtol=tol)
+        assert costs == res[0][1]
+        for a, b in zip(unk, x1):
+            assert rel_err(a, b[row0:row0 + rows]) < (1e-9 if double else 2e-5)
+
+
+@pytest.mark.parametrize("world,W,rows_per_rank,ghost,double,onchip_rows,fail_rank", [(2, 260, 64, 4, False, 16, 1), (2, 300, 32, 2, True, 4, 0), (3, 257, 24, 2, True, 4, 1)])
+def test_onchip_across_ranks_one_rank_times_out(world, W, rows_per_rank, ghost, double, onchip_rows, fail_rank):
+    """ONE rank's kernel gives up (test hook OPT_AMD_ONCHIP_FAIL_AT on that rank only), the others finish their loops or time out waiting for it.
+    The ranks' verdicts are all-reduced on the device before anyone applies its delta, so no rank keeps an update; every rank then redoes the step with the streaming
+    slab loop from delta = 0 -- the ROWS = 16 variant accumulates delta in memory while it runs -- and the job ends at the single-GPU result."""
+    H = world * rows_per_rank
+    case = dict(W=W, H=H, double=double, ghost=ghost, kind="gaussNewtonGPU", n=3, l=11, expect_onchip=True, expect_fallback=True,
+                env={"OPT_AMD_ONCHIP_ROWS": str(onchip_rows), "OPT_AMD_ONCHIP_TIMEOUT_MS": "300"}, env_by_rank={fail_rank: {"OPT_AMD_ONCHIP_FAIL_AT": "3"}})
+    P = wl.image_warping(W, H, double=double, random_state=3, mask_fraction=0.06, perturb=0.3)
+    c1, x1 = _single(P, case["kind"], nIterations=case["n"], lIterations=case["l"])
+    res = _run(world, case)
+    tol = 1e-10 if double else 2e-5
+    for r in range(world):
+        _, costs, unk, row0, rows, mem_kind, err = res[r]
         np.testing.assert_allclose(costs, c1, rtol=tol)
         assert costs == res[0][1]
         for a, b in zip(unk, x1):
