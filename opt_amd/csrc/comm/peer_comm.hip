@@ -1,8 +1,8 @@
 // "peer" implementation of OptAmd_SlabComm: peer-mapped mailboxes over xGMI instead of RCCL collectives.
 //
 // Why: the PCG loop's inter-GPU traffic is one sum of four doubles per iteration plus a few hundred KiB of edge rows every
-// 7th iteration.  At 8 slabs of 4096^2 the iteration kernel takes ~35 us, so the loop is bound by the
-// latency of whatever sits between two launches; an ncclAllReduce of 32 bytes costs a kernel launch plus a multi-hop
+// 7th iteration.  At 8 slabs of 4096^2 the streaming iteration kernel takes ~29 us (and the on-chip solve ~15 us per iteration
+// with no launch at all between iterations: peerOnChipPlan), so the loop is bound by the latency of whatever sits between two launches; an ncclAllReduce of 32 bytes costs a kernel launch plus a multi-hop
 // protocol.  Here every rank maps every other rank's window (hipIpc handles, one process per GPU) and
 //   * all-reduce = ONE small kernel: sum this rank's per-workgroup partials, store the totals into every peer's mailbox slot
 //     (direct peer stores over the pair's own xGMI link) as 8-byte words that each carry 4 bytes of payload and the all-reduce's
@@ -430,10 +430,13 @@ void* OptComm_PeerCreate(int rank, int world, long stageBytes, double timeoutSec
     // finds a peer on this rank's GPU -- unless OPT_AMD_PEER_POST=1 insists (tests and bench.py --share-gpu, which cap the grids with OPT_AMD_ITER_MAXWG); =0: never.
     if (const char* e = getenv("OPT_AMD_PEER_POST")) { if (atoi(e) != 0) x->ext.allReducePost = peerAllReducePost; }
     else x->ext.allReducePost = peerAllReducePost;
-    // allReducePlan (the iteration kernel's last workgroup posts; no kernel of ours between two iterations) is OFF unless OPT_AMD_PEER_PLAN=1: measured on one GPU
+    // allReducePlan (the iteration kernel's last workgroup posts; no kernel of ours between two iterations) is not offered: measured on one GPU
     // (tools/slab_overhead.py, profiles/r03_slab_overhead_posted_allreduce.txt) the device-scope release / acquire around the ticket costs more than the
-    // one-workgroup post kernel it removes -- 4096 x 512 slab: 36.6 us per iteration against 34.3 (k_mailPost) and 36.1 (round 2's waiting all-reduce); plain: 30.4
+    // one-workgroup post kernel it removes -- 4096 x 512 slab: 36.6 us per iteration against 34.3 (k_mailPost) and 36.1 (round 2's waiting all-reduce); plain: 30.4.
+    // (Development builds, -DOPT_AMD_DEV_SWITCHES: OPT_AMD_PEER_PLAN=1 offers it.)
+#ifdef OPT_AMD_DEV_SWITCHES
     if (const char* e = getenv("OPT_AMD_PEER_PLAN")) { if (atoi(e) != 0) x->ext.allReducePlan = peerAllReducePlan; }
+#endif
     x->ext.onChipPlan = peerOnChipPlan;      // (taken away like allReducePost when ranks share a device, unless OPT_AMD_PEER_POST=1 says the grids are capped)
     return x;
 }

@@ -15,6 +15,16 @@
 #include <string>
 #include <vector>
 
+// A/B switches of questions that are settled (DESIGN.md section 3 says how): a product build does not read them -- the default is compiled in, the other arm is
+// reachable only in a development build (-DOPT_AMD_DEV_SWITCHES: opt_amd/build.py build_variant("dev", ["OPT_AMD_DEV_SWITCHES"])).
+inline int devSwitch(const char* name, int dflt) {
+#ifdef OPT_AMD_DEV_SWITCHES
+    if (const char* e = getenv(name)) return atoi(e);
+#endif
+    (void)name;
+    return dflt;
+}
+
 #define HIP_CHECK(call)                                                                                   \
     do {                                                                                                  \
         hipError_t e_ = (call);                                                                           \

@@ -6,11 +6,15 @@
 // vector with one atomic per (vertex, channel); the per-vertex ("centred") kernel runs first and OVERWRITES,
 // the edge kernel then accumulates on top (solver.t:1032-1036, 1062-1065).
 //
-// MI355X design: the scatter is done with wave-aggregated atomics.  Edges arrive grouped by head vertex
-// (examples/shared/OptGraph.h:64-76), so inside a wave64 the lanes that target the same head form contiguous
-// runs; a 6-step segmented shuffle reduction folds each run into its first lane, which issues ONE hardware
-// f32/f64 atomic (gfx950 has both natively -- no CAS loop as in util.t:574-597).  Runs need not be sorted for
-// correctness, only for the aggregation to pay off.  Tail-vertex targets are irregular and use plain atomics.
+// MI355X design: no atomics.  The edge lists are turned into per-vertex out- / in-lists once per graph (ensureCsr), and J^T J p is a GATHER:
+//   * symmetric graphs (every mesh: OptGraph.h:64-76 emits both directions of every edge; checked per vertex by csr_symmetric): one walk of a vertex's out-list serves
+//     both edge directions, a neighbour is ONE 64-byte record {p, p_a, sin / cos of its angles}, the slot of a half-edge 16 bytes {U_v - U_u, u} (arap_applySym), and a
+//     Gauss-Newton PCG iteration is two kernels -- the flat PCGStep2 + PCGStep3 pass that also rewrites the records (arap_flatStepRec) and the gather with the
+//     sums of the expanded beta numerator; vertices are dealt to the XCDs in contiguous eighths so that a record's readers share one L2;
+//   * any other graph: the edge-list gather arap_applyFused (36-byte derivative rows per half-edge) in the reference's three-kernel loop.
+// The same inputs give the same bits (fixed summation order per vertex).  The scatter with wave-aggregated atomics (arap_vertices<3> + arap_edges<3>: runs of lanes
+// that target the same head vertex folded by a segmented shuffle reduction into one hardware f32 / f64 atomic) is what cost, model cost and curveFitting still use,
+// and the J^T J p alternative of development builds (-DOPT_AMD_DEV_SWITCHES, OPT_AMD_ARAP_GATHER=0).
 #include "energy.h"
 #include "graph_common.h"
 #include <hipcub/hipcub.hpp>
@@ -696,7 +700,7 @@ struct ArapOps : EnergyOps<T> {
     int *outOff = nullptr, *outIdx = nullptr, *inOff = nullptr, *inIdx = nullptr, *cursors = nullptr; T* Jp = nullptr;
     void* scanTemp = nullptr; size_t scanTempBytes = 0; unsigned long long* dChecksum = nullptr;
     const int *csrV0 = nullptr, *csrV1 = nullptr; int csrNE = -1; unsigned long long csrSum = 0; bool csrValid = false;
-    bool useGather = true;   // OPT_AMD_ARAP_GATHER=0: scatter with wave-aggregated atomics instead
+    bool useGather = true;   // (development builds: OPT_AMD_ARAP_GATHER=0 scatters with wave-aggregated atomics instead)
     T* D9 = nullptr; long d9Capacity = 0; int* nbr = nullptr;
     // symmetric-graph path (arap_applySym): out-list slots {U_v - U_u, u}, one record per vertex; OPT_AMD_ARAP_SYM=0 keeps arap_applyFused
     bool useSym = true, symGraph = false;
@@ -762,8 +766,8 @@ struct ArapOps : EnergyOps<T> {
         this->usePreconditioner = true; this->usesGraph = true;                  // arap_mesh_deformation.t:9
         this->addUnknown(2, A.N, 3); this->addUnknown(3, A.N, 3);                // Offset, Angle (:4-5)
         int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        if (const char* e = getenv("OPT_AMD_ARAP_GATHER")) useGather = atoi(e) != 0;
-        if (const char* e = getenv("OPT_AMD_ARAP_ITER")) fusedIterEnv = atoi(e) != 0;
+        useGather = devSwitch("OPT_AMD_ARAP_GATHER", 1) != 0;
+        fusedIterEnv = devSwitch("OPT_AMD_ARAP_ITER", -1);
         if (const char* e = getenv("OPT_AMD_ARAP_SYM")) useSym = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ARAP_SYM_XCD")) symXcd = atoi(e);
         if (const char* e = getenv("OPT_AMD_ARAP_VGRID")) symGridCap = atoi(e);
@@ -856,8 +860,8 @@ struct ArapOps : EnergyOps<T> {
         return true;
     }
     // ---- two kernels per Gauss-Newton PCG iteration instead of three on the symmetric-graph path: [PCGStep2 + PCGStep3 of iteration k-1 as one flat pass that also rewrites the
-    // records: arap_flatStepRec] + [PCGStep1 of iteration k with the sums of the expanded beta numerator: arap_applySym].  OPT_AMD_ARAP_ITER=0 keeps the reference's three
-    // kernels per iteration (the parity control).  On the edge-list gather of asymmetric graphs the same fusion lost in three formulations (profiles/NOTES.md) and is not offered.
+    // records: arap_flatStepRec] + [PCGStep1 of iteration k with the sums of the expanded beta numerator: arap_applySym].  (Development builds: OPT_AMD_ARAP_ITER=0 keeps the reference's three
+    // kernels per iteration.)  On the edge-list gather of asymmetric graphs the same fusion lost in three formulations (profiles/NOTES.md) and is not offered.
     int fusedIterEnv = -1;
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
         if (symPath() && fusedIterEnv != 0 && !a.CtC && a.pre && !this->slab.active && A.N % 4 == 0 &&

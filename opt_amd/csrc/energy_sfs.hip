@@ -628,7 +628,7 @@ struct SfsOps : EnergyOps<T> {
         HIP_CHECK(hipMalloc((void**)&A.fl2, 4 * n)); HIP_CHECK(hipMemset(A.fl2, 0, 4 * n)); owned.push_back(A.fl2);
         int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (const char* e = getenv("OPT_AMD_SFS_ONEKERNEL")) oneKernel = atoi(e) != 0;
-        if (const char* e = getenv("OPT_AMD_SFS_GRID")) gridOverride = atoi(e);
+        gridOverride = devSwitch("OPT_AMD_SFS_GRID", gridOverride);
         if (const char* e = getenv("OPT_AMD_SFS_MARCH_GRID")) marchGridOverride = atoi(e);
     }
     ~SfsOps() override { for (void* p : owned) (void)hipFree(p); }
@@ -663,7 +663,7 @@ struct SfsOps : EnergyOps<T> {
         return true;
     }
     // Grid of the tiled kernels: every workgroup loops over tiles, so the grid is capped at what is co-resident (LDS-limited: 4-5 workgroups per CU);
-    // with more, the last round of workgroups runs on a partly empty chip (2048 workgroups on 1280 slots: 1.6 rounds).  OPT_AMD_SFS_GRID overrides (A/B).
+    // with more, the last round of workgroups runs on a partly empty chip (2048 workgroups on 1280 slots: 1.6 rounds).  (Development builds: OPT_AMD_SFS_GRID overrides.)
     int occTiled[2] = {0, 0}; int gridOverride = 0;
     int tileGrid(bool lmv) {
         const long t = (long)((A.W + kSfsTW - 1) / kSfsTW) * ((A.H + kSfsTH - 1) / kSfsTH);

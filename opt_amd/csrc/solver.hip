@@ -64,19 +64,6 @@ template <class T> __device__ __forceinline__ T guardedInvert(T x) {   // solver
     return T(1) / (s * s);
 }
 
-// Write-through (sc1) 16-byte store through a buffer descriptor: the line leaves the XCD's L2 immediately instead of
-// lingering dirty until the end-of-kernel write-back (MI355X_MICROARCH.md, "stores of each flavour").  Measured
-// with tools/microbench_boundary.hip on the PCGStep2 shape at 4096^2: plain 294 us, nt 291 us, sc1 285 us per launch.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-template <class T> __device__ __forceinline__ void stwt(__amdgpu_buffer_rsrc_t rsrc, long i, const Pack<T>& p) {
-    u32x4 v;
-    __builtin_memcpy(&v, &p, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)(i * 16), 0, /*aux: sc1*/ 16);
-}
-template <class T> __device__ __forceinline__ __amdgpu_buffer_rsrc_t makeRsrc(T* base, long nPacks) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(nPacks * 16), 0x00020000);
-}
-
 // PCGInit1 (non-graph tail) / PCGInit1_Finish (graph): solver.t:384-392, 399-419.  r already holds -J^T F.
 template <class T>
 __global__ __launch_bounds__(kBlock) void k_initFinish(const T* __restrict__ r, const T* __restrict__ diag, T* __restrict__ pre,
@@ -119,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void k_finalizeSum4(Partials4 in, double* _
 }
 
 // PCGStep2: solver.t:446-489
-template <class T, bool LM, int WT>
+template <class T, bool LM>
 __global__ __launch_bounds__(kBlock) void k_step2(T* __restrict__ delta, const T* __restrict__ p, T* __restrict__ r, const T* __restrict__ Ap,
                                                   const T* __restrict__ pre /*nullptr -> 1*/, const T* __restrict__ b, T* __restrict__ z, long nPacks,
                                                   const double* __restrict__ aNumTotal, const double* __restrict__ aDenPartials, int nDen,
@@ -131,8 +118,6 @@ __global__ __launch_bounds__(kBlock) void k_step2(T* __restrict__ delta, const T
     const T alpha = (aDen > T(0)) ? aNum / aDen : T(0);   // guardDivisionByZero, solver.t:456-459
     double accB = 0, accQ = 0;
     const long stride = (long)gridDim.x * blockDim.x;
-    __amdgpu_buffer_rsrc_t rsDelta, rsR, rsZ;
-    if (WT) { rsDelta = makeRsrc(delta, nPacks); rsR = makeRsrc(r, nPacks); rsZ = makeRsrc(z, nPacks); }
     for (long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x; i0 < nPacks; i0 += 2 * stride) {
         // two packs per lane in flight: issue all loads of both before the first use
         Pack<T> D[2], P[2], R[2], A[2], M[2], B[2], Z;
@@ -159,12 +144,7 @@ __global__ __launch_bounds__(kBlock) void k_step2(T* __restrict__ delta, const T
                     accB += (double)(zz * rr);
                     if (LM) accQ += (double)(T(0.5) * (dl * (rr + B[u].v[k])));
                 }
-                // WT: 0 = all non-temporal; 1 = all write-through; 2 = delta, r write-through + z plain; 3 = delta, r write-through + z nt; 4 = all plain
-                if (WT == 1) { stwt(rsDelta, i, D[u]); stwt(rsR, i, R[u]); stwt(rsZ, i, Z); }
-                else if (WT == 2) { stwt(rsDelta, i, D[u]); stwt(rsR, i, R[u]); ((Pack<T>*)z)[i] = Z; }
-                else if (WT == 3) { stwt(rsDelta, i, D[u]); stwt(rsR, i, R[u]); stnt(z, i, Z); }
-                else if (WT == 4) { ((Pack<T>*)delta)[i] = D[u]; ((Pack<T>*)r)[i] = R[u]; ((Pack<T>*)z)[i] = Z; }
-                else { stnt(delta, i, D[u]); stnt(r, i, R[u]); stnt(z, i, Z); }
+                stnt(delta, i, D[u]); stnt(r, i, R[u]); stnt(z, i, Z);      // non-temporal: nothing of this pass is read again before the next one has streamed past it
             }
         }
     }
@@ -322,23 +302,21 @@ struct PcgSolver : SolverBase {
     T *delta = nullptr, *r = nullptr, *b = nullptr, *Adelta = nullptr, *z = nullptr, *p = nullptr, *Ap_X = nullptr, *CtC = nullptr, *preconditioner = nullptr,
       *SSq = nullptr, *prevX = nullptr;
     T* p2 = nullptr;                    // second search-direction buffer for the fused PCGStep3+PCGStep1 kernel
-    bool fuseStep3 = true;              // OPT_AMD_FUSE=0 disables (A/B switch)
     T *r2 = nullptr, *Ap2 = nullptr;    // second r / Ap buffers for the single-kernel PCG iteration (z doubles as nothing there)
     T* delta2 = nullptr;                // second delta buffer of the LM single-kernel loop (allocated on first use)
     bool oneKernel = true;              // OPT_AMD_ONEKERNEL=0: use the Step1(+3)/Step2 pair instead of one kernel per PCG iteration
     bool oneKernelLM = true;            // OPT_AMD_ONEKERNEL_LM=0: the same switch for the Levenberg-Marquardt loop only
     Reduction setS[2][4];               // ping-pong {alphaNum, alphaDen, s2, s3} of the single-kernel iteration
-    int storeMode = 0;                  // OPT_AMD_SC1=0..4: store flavours of PCGStep2 (see k_step2), A/B switch
     bool unknownsUpdated = false;       // this step's PCGLinearUpdate was folded into the end of the PCG loop (EnergyOps::finishUpdate)
     bool keepReferenceP = false;        // run the (dead) last PCGStep3 so that `p` matches the reference after a step
     std::vector<void*> allocs;
     Reduction redA, redB, redQ, redC;   // alpha denominator, beta numerator, q, cost / init numerator
     Reduction redQ2;                    // second Q buffer: the LM single-kernel loop enqueues launch k + 1 (which writes Q_k) before the host has read Q_{k-1}
     Reduction redQR;                    // pinned: Q of the split residual reset (its own buffer: the reset is enqueued while the host may still poll redQ / redQ2)
-    unsigned long long* stampFlag = nullptr; unsigned long long stampSeq = 0; bool pollSync = true;   // drain(): OPT_AMD_POLL_SYNC=0 -> hipStreamSynchronize
+    unsigned long long* stampFlag = nullptr; unsigned long long stampSeq = 0; bool pollSync = true;   // drain(): false (only after a stamp failed to arrive) -> hipStreamSynchronize
     Reduction redMH, redCH;             // pinned: model cost / cost partials that only the host sums (no copy kernel between the producer and the read)
     unsigned launchTag = 0;             // tags of the Q partials the single-kernel LM launches deliver as self-validating words (common.h storeTaggedPartial)
-    bool taggedQ = true;                // OPT_AMD_TAGGED_Q=0: plain partials + an event in the stream (A/B switch)
+    bool taggedQ = true;                // Q of the single-kernel LM launches as tagged words the host polls; false (only after a tag failed to arrive): plain partials + an event in the stream
     double* scal = nullptr;             // device: [0],[1] alphaNumerator ping-pong, [2..5] slab totals
     double* scal4[2] = {nullptr, nullptr};   // device: all-reduced {alphaNum, alphaDen, s2, s3} of the single-kernel iteration (slab mode), ping-pong
     int aSlot = 0;
@@ -371,19 +349,15 @@ struct PcgSolver : SolverBase {
         delta = allocVec(); r = allocVec(); z = allocVec(); p = allocVec(); Ap_X = allocVec(); CtC = allocVec(); preconditioner = allocVec();
         if (lm) { b = allocVec(); Adelta = allocVec(); SSq = allocVec(); prevX = allocVec(); }
         p2 = allocVec();
-        if (const char* e = getenv("OPT_AMD_FUSE")) fuseStep3 = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ONEKERNEL")) oneKernel = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ONEKERNEL_LM")) oneKernelLM = atoi(e) != 0;
         r2 = allocVec(); Ap2 = allocVec();                // second r / A p buffers of the single-kernel iterations (kernels that keep A p in memory read the old one on a halo)
         for (auto& st : setS) for (auto& R : st) R = allocRed();
-        if (const char* e = getenv("OPT_AMD_SC1")) storeMode = atoi(e);
         redA = allocRed(); redB = allocRed(); redC = allocRed();
         // Q (solver.t:483-485, 1093-1102) is read by the host once per LM iteration and by no kernel: its partials go straight to pinned host memory
         // (<= 16 KB of posted writes per launch) instead of through a device buffer and a copy kernel per iteration (830 copyBuffer launches, 7 % of config 3's GPU time)
         // With the single-kernel loop each partial is two tagged words (2 x kMaxPartials slots), which the host polls: no event packet in the stream either.
         for (Reduction* R : {&redQ, &redQ2, &redQR, &redMH, &redCH}) { HIP_CHECK(hipHostMalloc((void**)&R->partials, 2 * kMaxPartials * sizeof(double))); memset(R->partials, 0, 2 * kMaxPartials * sizeof(double)); R->hostVisible = true; }
-        if (const char* e = getenv("OPT_AMD_TAGGED_Q")) taggedQ = atoi(e) != 0;
-        if (const char* e = getenv("OPT_AMD_POLL_SYNC")) pollSync = atoi(e) != 0;
         HIP_CHECK(hipHostMalloc((void**)&stampFlag, 64)); *stampFlag = 0;
         HIP_CHECK(hipMalloc((void**)&scal, 16 * sizeof(double))); HIP_CHECK(hipMemset(scal, 0, 16 * sizeof(double))); allocs.push_back(scal);
         scal4[0] = scal + 8; scal4[1] = scal + 12;
@@ -881,9 +855,8 @@ struct PcgSolver : SolverBase {
             }
             preArg = E->usePreconditioner ? preconditioner : nullptr;
             // fetchQ, solver.t:1050: Q_0 = 1/2 sum delta . (r + b) with the delta PCGInit1 has just zeroed -- exactly 0 for every finite r, so the
-            // blocking read (one full drain of the stream per outer iteration) is skipped; OPT_AMD_FETCH_Q0=1 performs it
-            static const bool fetchQ0 = [] { const char* e = getenv("OPT_AMD_FETCH_Q0"); return e && atoi(e) != 0; }();
-            Q0 = fetchQ0 ? (T)hostSum(redQ) : T(0);
+            // blocking read (one full drain of the stream per outer iteration) is not performed
+            Q0 = T(0);
         }
 
         // Loop structure: the reference runs Step1, Step2, Step3 per iteration (:1056-1103).  Here Step3 of
@@ -902,11 +875,9 @@ struct PcgSolver : SolverBase {
         auto stepThreeAndOne = [&]() {
             bool applied = false;
             if (pendingStep3) {
-                if (fuseStep3) {
-                    exchangeVector(z);
-                    applied = E->applyJTJFused(p, z, p2, Ap_X, lm ? CtC : nullptr, &redA, bNum, scal + aSlot, scal + (aSlot ^ 1), ctx);
-                    if (applied) std::swap(p, p2);
-                }
+                exchangeVector(z);      // (an energy without the fused kernel refuses: the generic PCGStep3 below)
+                applied = E->applyJTJFused(p, z, p2, Ap_X, lm ? CtC : nullptr, &redA, bNum, scal + aSlot, scal + (aSlot ^ 1), ctx);
+                if (applied) std::swap(p, p2);
                 if (!applied) {
                     ScopedKernel k(ctx, "PCGStep3");
                     k_step3<T><<<streamGrid, kBlock, 0, stream>>>(z, p, nPacks, bNum.partials, bNum.n, scal + aSlot, scal + (aSlot ^ 1));
@@ -920,8 +891,7 @@ struct PcgSolver : SolverBase {
             }
             aDen = forConsumers(redA, 0);
         };
-        static const bool overlapQ = [] { const char* e = getenv("OPT_AMD_OVERLAP_Q"); return !e || atoi(e) != 0; }();   // A/B switch
-        const bool speculate = !traceEnabled && overlapQ;
+        const bool speculate = !traceEnabled;
         if (!single && sp.lIterations > 0) stepThreeAndOne();     // Step1 of iteration 0
         for (int lIter = 0; !single && lIter < sp.lIterations; ++lIter) {
             const bool reset = lm && ((lIter + 1) % sp.residual_reset_period) == 0;
@@ -942,13 +912,8 @@ struct PcgSolver : SolverBase {
                 redB.n = streamGrid; redQ.n = streamGrid;
             } else {
                 ScopedKernel k(ctx, "PCGStep2");
-                const int wt = (nPad * (long)sizeof(T) < (1L << 31)) ? storeMode : 0;   // 32-bit buffer offsets
-#define OPTAMD_STEP2(LMV, WTV, BV, QV) k_step2<T, LMV, WTV><<<streamGrid, kBlock, 0, stream>>>(delta, p, r, Ap_X, preArg, BV, z, nPacks, scal + aSlot, aDen.partials, aDen.n, redB.partials, QV)
-                if (lm) { switch (wt) { case 1: OPTAMD_STEP2(true, 1, b, redQ.partials); break; case 2: OPTAMD_STEP2(true, 2, b, redQ.partials); break; case 3: OPTAMD_STEP2(true, 3, b, redQ.partials); break;
-                                        case 4: OPTAMD_STEP2(true, 4, b, redQ.partials); break; default: OPTAMD_STEP2(true, 0, b, redQ.partials); } }
-                else { switch (wt) { case 1: OPTAMD_STEP2(false, 1, nullptr, nullptr); break; case 2: OPTAMD_STEP2(false, 2, nullptr, nullptr); break; case 3: OPTAMD_STEP2(false, 3, nullptr, nullptr); break;
-                                     case 4: OPTAMD_STEP2(false, 4, nullptr, nullptr); break; default: OPTAMD_STEP2(false, 0, nullptr, nullptr); } }
-#undef OPTAMD_STEP2
+                if (lm) k_step2<T, true><<<streamGrid, kBlock, 0, stream>>>(delta, p, r, Ap_X, preArg, b, z, nPacks, scal + aSlot, aDen.partials, aDen.n, redB.partials, redQ.partials);
+                else k_step2<T, false><<<streamGrid, kBlock, 0, stream>>>(delta, p, r, Ap_X, preArg, nullptr, z, nPacks, scal + aSlot, aDen.partials, aDen.n, redB.partials, nullptr);
                 redB.n = streamGrid; redQ.n = streamGrid;
             }
             bNum = forConsumers(redB, 1);

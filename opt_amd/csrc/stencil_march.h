@@ -249,7 +249,7 @@ template <class T>
 struct MarchLoop {
     T* ring[3] = {nullptr, nullptr, nullptr}; const T* r0Ptr = nullptr; T* alphaSlots = nullptr;
     int iterIndex = 0, flip = 0, occ = 0, forceRows = 0, forceBlock = 0; bool deferredTerm = false;
-    MarchLoop() { if (const char* e = getenv("OPT_AMD_ITER_ROWS")) forceRows = atoi(e); if (const char* e = getenv("OPT_AMD_MARCH_BLOCK")) forceBlock = atoi(e); }
+    MarchLoop() { if (const char* e = getenv("OPT_AMD_ITER_ROWS")) forceRows = atoi(e); forceBlock = devSwitch("OPT_AMD_MARCH_BLOCK", forceBlock); }
     ~MarchLoop() { for (T* b : ring) if (b) (void)hipFree(b); if (alphaSlots) (void)hipFree(alphaSlots); }
     template <class Op>
     bool launch(const Op& op, int W, int H, const uint8_t* flags, int cus, const PcgIterArgs<T>& a, LaunchCtx& ctx, const T* coef = nullptr) {

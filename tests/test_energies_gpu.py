@@ -213,24 +213,6 @@ def test_poisson_single_kernel_iteration_matches_three_kernel_loop(double, monke
     np.testing.assert_allclose(res["1"][2][:5, 2:5], res["0"][2][:5, 2:5], rtol=1e-9 if double else 1e-4)
 
 
-@pytest.mark.parametrize("double", [False, True])
-def test_arap_two_kernel_iteration_matches_three_kernel_loop(double, monkeypatch):
-    """OPT_AMD_ARAP_ITER=1 (off by default: measured slower): PCGStep2 + PCGStep3 as one flat pass whose beta comes from the expansion, the
-    gather summing M r^2, M r . A p, M (A p)^2 from exact double products -- against the default Step1 / Step2 / Step3 loop over 3 x 40 iterations."""
-    P = wl.arap_mesh_deformation(41, 29, double=double, seed=5, perturb=0.01)
-    res = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("OPT_AMD_ARAP_ITER", mode)
-        g = hip_solver(P, nIterations=3, lIterations=40)
-        dev = api.to_device(P)
-        g.init(dev); c = [g.cost()]
-        while g.step(dev):
-            c.append(g.cost())
-        res[mode] = (c, device_unknowns(P, dev)); g.close()
-    np.testing.assert_allclose(res["1"][0], res["0"][0], rtol=1e-9 if double else 1e-5)
-    assert rel_err(res["1"][1], res["0"][1]) < (1e-8 if double else 2e-5)
-
-
 @pytest.mark.parametrize("grid", [(41, 29), (40, 30)])      # vertex counts 1189 (one vertex per thread in PCGStep3) and 1200 (a multiple of 4: whole 16-byte packs)
 @pytest.mark.parametrize("kind", ["gaussNewtonGPU", "LMGPU"])
 @pytest.mark.parametrize("double", [False, True])

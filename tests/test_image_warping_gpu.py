@@ -229,7 +229,7 @@ def test_iteration_kernel_on_ragged_sizes(oracle_lib, W, H, liters):
     g.close(); o.close()
 
 
-SWITCHES = [{"OPT_AMD_ONEKERNEL": "0"}, {"OPT_AMD_ONEKERNEL": "0", "OPT_AMD_FUSE": "0"}, {"OPT_AMD_LATTICE": "0"}, {"OPT_AMD_ITER_ROWS": "5"}]
+SWITCHES = [{"OPT_AMD_ONEKERNEL": "0"}, {"OPT_AMD_LATTICE": "0"}, {"OPT_AMD_ITER_ROWS": "5"}]
 
 
 @pytest.mark.parametrize("jitter", [0.0, 0.04])

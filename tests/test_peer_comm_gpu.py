@@ -135,20 +135,18 @@ def test_peer_mailbox_middle_ranks(world, ghost, double):
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_posted_allreduce_equals_the_waited_one(world):
-    """Round 3: the per-iteration all-reduce is POSTED and the next iteration kernel's prologue polls this rank's mailbox (common.h pollMailSums) instead of a
-    kernel waiting between two launches -- either by a one-workgroup kernel of the communicator's (k_mailPost, OptAmd_SlabCommExt.allReducePost) or, the default,
-    by the iteration kernel's own last workgroup (a device-scope ticket; allReducePlan, common.h postMailSums: nothing at all between two iteration launches).
-    Same contributions, same order of the additions: the cost trajectory must be bitwise the one of the waited all-reduce, on every rank."""
+    """Round 3: the per-iteration all-reduce is POSTED by a one-workgroup kernel of the communicator's (k_mailPost, OptAmd_SlabCommExt.allReducePost) and the next
+    iteration kernel's prologue polls this rank's mailbox (common.h pollMailSums) instead of a kernel waiting between two launches.  Same contributions, same order
+    of the additions: the cost trajectory must be bitwise the one of the waited all-reduce, on every rank."""
     out = {}
-    modes = {"planned": {"OPT_AMD_PEER_POST": "1", "OPT_AMD_PEER_PLAN": "1"}, "posted": {"OPT_AMD_PEER_POST": "1", "OPT_AMD_PEER_PLAN": "0"},
-             "waited": {"OPT_AMD_PEER_POST": "0", "OPT_AMD_PEER_PLAN": "0"}}
+    modes = {"posted": {"OPT_AMD_PEER_POST": "1"}, "waited": {"OPT_AMD_PEER_POST": "0"}}
     for name, env in modes.items():
         case = dict(W=70, H=96, double=False, ghost=8, kind="gaussNewtonGPU", n=2, l=30, env=env)
         res = _run(world, case)
         assert all(res[r][6] == 0 for r in range(world))
         assert all(res[r][1] == res[0][1] for r in range(world))
         out[name] = res[0][1]
-    assert out["planned"] == out["waited"] and out["posted"] == out["waited"], out
+    assert out["posted"] == out["waited"], out
 
 
 def test_peer_mailbox_lm_two_processes():

@@ -47,17 +47,6 @@ def test_lm_slabs_match_single():
     assert rel_err(flat_unknowns(Q), x1) < 1e-8
 
 
-def test_unfused_path_slabs(monkeypatch):
-    monkeypatch.setenv("OPT_AMD_FUSE", "0")
-    P = wl.image_warping(40, 33, double=True, random_state=9, perturb=0.2)
-    kw = dict(nIterations=2, lIterations=9)
-    c1, x1 = _single(P.clone(), "gaussNewtonGPU", **kw)
-    Q = P.clone()
-    cN = slab.run_threads(Q, 3, "gaussNewtonGPU", kw)
-    np.testing.assert_allclose(cN, c1, rtol=1e-11)
-    assert rel_err(flat_unknowns(Q), x1) < 1e-11
-
-
 def _rccl_world1(q):
     import os
     import torch
