@@ -38,6 +38,16 @@ struct DeviceBuffer {   // owning device array, uploaded from / downloaded to a 
     std::vector<T> download() const { std::vector<T> h(n); EX_HIP(hipMemcpy(h.data(), ptr, n * sizeof(T), hipMemcpyDeviceToHost)); return h; }
 };
 
+// OPT_EXAMPLE_DUMP=<directory>: the example writes the host arrays it hands to the solver as raw little-endian files <directory>/<name>.bin, so that a test can
+// run the CPU oracle on exactly the caller's inputs (tests/test_cpp_callers_gpu.py) instead of re-deriving them.
+template <class T>
+inline void dumpInput(const std::string& name, const std::vector<T>& v) {
+    const char* dir = getenv("OPT_EXAMPLE_DUMP");
+    if (!dir) return;
+    std::ofstream f(std::string(dir) + "/" + name + ".bin", std::ios::binary);
+    f.write(reinterpret_cast<const char*>(v.data()), (std::streamsize)(v.size() * sizeof(T)));
+}
+
 struct SolverIteration { double cost; double timeInMS; };
 
 // Init + Step loop with a (cost, ms) record per outer iteration (what OptUtils.h's launchProfiledSolve collects).

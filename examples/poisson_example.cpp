@@ -19,6 +19,7 @@ int main(int argc, char** argv) {
         ins[4 * i + 3] = 255;
         if (x >= W / 4 && x < W / 4 + W / 2 && y >= H / 4 && y < H / 4 + H / 2) mask[i] = 0.f;   // pasted region
     }
+    dumpInput("poisson_base", base); dumpInput("poisson_inserted", ins); dumpInput("poisson_mask", mask);
     DeviceBuffer<float> dT(ins), dM(mask), dX(base.size());
     Opt_InitializationParameters ip = {};
     Opt_State* state = Opt_NewState(ip);

@@ -71,6 +71,8 @@ int main(int argc, char** argv) {
         Im = shade(detail, W, H, fx, fy, ux, uy, L);
         edgeR.assign((size_t)W * H, 1); edgeC.assign((size_t)W * H, 1);
     }
+    dumpInput("sfs_X", X); dumpInput("sfs_D", D); dumpInput("sfs_Im", Im); dumpInput("sfs_edgeR", edgeR); dumpInput("sfs_edgeC", edgeC);
+    dumpInput("sfs_scalars", std::vector<float>{wts[0], wts[1], wts[2], fx, fy, ux, uy, L[0], L[1], L[2], L[3], L[4], L[5], L[6], L[7], L[8]});
     DeviceBuffer<double> dX(X), dD(D), dIm(Im);
     DeviceBuffer<unsigned char> dR(edgeR), dC(edgeC);
     Opt_InitializationParameters ip = {};

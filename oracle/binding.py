@@ -47,6 +47,7 @@ def lib():
         L.OptOracle_CurrentCost.argtypes = [vp]
         L.OptOracle_SetThreads.argtypes = [vp, ci]
         L.OptOracle_SetReduction.argtypes = [vp, ci, ctypes.c_uint]
+        L.OptOracle_SetTrigVariant.argtypes = [ctypes.c_uint]
         L.OptOracle_NumUnknownScalars.restype = cl
         L.OptOracle_NumUnknownScalars.argtypes = [vp]
         L.OptOracle_GetVector.restype = ci
@@ -66,6 +67,12 @@ def lib():
         L.OptOracle_PoissonPatchSolve.argtypes = [ci, ci, ci, vp, vp, vp, ci, ci, ci, ci, vp]
         _lib = L
     return _lib
+
+
+def set_trig_variant(seed):
+    """Process-wide: 0 = float sin / cos of the host libm (default); n > 0 = a seeded stand-in for another implementation within 1 ulp (oracle/dual.hpp:
+    the reference calls libdevice's, the HIP product ocml's -- legal elementwise variants of the same algorithm)."""
+    lib().OptOracle_SetTrigVariant(int(seed))
 
 
 _INT_PARAMS = {"nIterations", "lIterations", "residual_reset_period", "nIter"}

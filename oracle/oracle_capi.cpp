@@ -80,6 +80,8 @@ void OptOracle_SetReduction(void* hv, int mode, unsigned seed) {
     if (h->dbl) { h->sd->reductionMode = mode; h->sd->reductionSeed = seed; h->sd->reductionCount = 0; }
     else { h->sf->reductionMode = mode; h->sf->reductionSeed = seed; h->sf->reductionCount = 0; }
 }
+// Process-wide: which float sin / cos the restatement evaluates (dual.hpp trigSeed: 0 = the host libm; n > 0 = a seeded implementation within 1 ulp)
+void OptOracle_SetTrigVariant(unsigned seed) { oracle::trigSeed() = seed; }
 void OptOracle_SetThreads(void* hv, int n) { auto* h = (Handle*)hv; if (h->dbl) h->sd->threads = n; else h->sf->threads = n; }
 long OptOracle_NumUnknownScalars(void* hv) { auto* h = (Handle*)hv; return h->dbl ? h->ed->nScalars : h->ef->nScalars; }
 

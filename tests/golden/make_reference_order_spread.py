@@ -12,7 +12,7 @@ Every seed is one legal run of the reference's arithmetic (its atomics commit in
 spread of the cost at a horizon is what the reference's own trajectory contract can mean there; tests/test_horizon_gpu.py and bench.py read
 the frozen spreads from tests/golden/reference_order_costs.json.  Oracle outputs, generated offline (minutes to hours of host time).
 
-    python tests/golden/make_reference_order_spread.py [--seeds 1 2 3 4 5] [--families horizon adversarial solve8] [--threads 8] [--precisions float] [--variant fma]
+    python tests/golden/make_reference_order_spread.py [--seeds 1 2 3 4 5] [--families horizon adversarial solve8] [--threads 8] [--precisions float] [--variant fma] [--trig --tag trig]
 """
 import argparse
 import json
@@ -61,6 +61,8 @@ def main():
                                                "order, the multi-threaded one in two colours of 4-row bands (oracle/solver.hpp forEachInstanceBanded) -- two accumulation orders of the same float additions")
     ap.add_argument("--out", default=OUT, help="JSON file to extend (tools/reference_spread.py reads reference_order_costs*.json)")
     ap.add_argument("--variant", default="plain", choices=["plain", "fma"], help="fma: keys get the suffix _fma")
+    ap.add_argument("--trig", action="store_true", help="also vary the float sin / cos: seed n runs with oracle trig variant n (oracle/dual.hpp: a seeded implementation within 1 ulp of the "
+                                                       "correctly rounded value -- the reference calls libdevice's __nv_sinf / __nv_cosf, util.t:162-171, this restatement the host libm); use with --tag trig")
     a = ap.parse_args()
     sfx = ("_" + a.tag if a.tag else "") + ("_fma" if a.variant == "fma" else "")
     out = a.out
@@ -80,6 +82,9 @@ def main():
         for prec in a.precisions:
             dbl = prec == "double"
             for seed in a.seeds:
+                if a.trig:
+                    from oracle import binding
+                    binding.set_trig_variant(seed)
                 if fam in ("horizon", "adversarial"):
                     for L in a.horizons:
                         size = a.size if fam == "horizon" else 1024

@@ -12,12 +12,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(name, *args, timeout=300):
+def _run(name, *args, timeout=300, env=None):
     exe = os.path.join(ROOT, "examples", "bin", name)
     if not os.path.exists(exe):
         from opt_amd import build
         build.build_examples()
-    return subprocess.run([exe, *map(str, args)], cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([exe, *map(str, args)], cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=e)
+
+
+def _dumped(tmp_path, name, dtype, shape=None):
+    """An input array the example wrote under OPT_EXAMPLE_DUMP (examples/common.h dumpInput): exactly what the C++ caller handed to the solver."""
+    import numpy as np
+    a = np.fromfile(os.path.join(str(tmp_path), name + ".bin"), dtype=dtype)
+    return a.reshape(shape) if shape is not None else a
 
 
 def _final_costs(stdout):
@@ -90,11 +99,23 @@ def test_image_warping_example_flow(oracle_lib):
     os.remove(os.path.join(ROOT, "results_float.csv"))
 
 
-def test_poisson_example_flow():
-    r = _run("poisson_example", 256, 192, 60)
+def test_poisson_example_flow(oracle_lib, tmp_path):
+    """The caller's final costs (GN and LM, 1 x 60 on a 256 x 192 image) against the oracle run on the caller's own arrays (dumped by the example)."""
+    import numpy as np
+    from opt_amd import workloads as wl
+    from helpers import oracle_solver
+    W, H, L = 256, 192, 60
+    r = _run("poisson_example", W, H, L, env={"OPT_EXAMPLE_DUMP": str(tmp_path)})
     assert r.returncode == 0, r.stdout + r.stderr
     gn, lm = _final_costs(r.stdout)
     assert "===Poisson Image Editing===" in r.stdout and gn > 0 and lm > 0
+    base, ins, mask = _dumped(tmp_path, "poisson_base", np.float32, (H, W, 4)), _dumped(tmp_path, "poisson_inserted", np.float32, (H, W, 4)), _dumped(tmp_path, "poisson_mask", np.float32, (H, W))
+    for kind, got in (("gaussNewtonGPU", gn), ("LMGPU", lm)):
+        P = wl.Problem("poisson_image_editing", (W, H), [base.copy(), ins, mask], (0,), False)
+        o = oracle_solver(oracle_lib, P, kind, nIterations=1, lIterations=L)
+        o.solve(P.params)
+        assert abs(got - o.cost()) <= 1e-5 * o.cost(), (kind, got, o.cost())
+        o.close()
     os.remove(os.path.join(ROOT, "results_float.csv"))
 
 
@@ -105,16 +126,65 @@ def test_poisson_example_with_patch_solver():
     os.remove(os.path.join(ROOT, "results_float.csv"))
 
 
-def test_arap_example_flow():
-    r = _run("arap_example", 60, 50, 3, 6, 40)
+def _oracle_arap_ramp(oracle_lib, tmp_path, nx, ny, passes, n_it, l_it, double):
+    """The ARAP example's flow (examples/arap_example.cpp = the reference's arap_mesh_deformation/src/main.cpp:75-104) on the CPU oracle, fed with the arrays the
+    caller dumped: rest pose, half-edge lists and the constraint array of every pass of the handle ramp; the unknowns carry over from pass to pass."""
+    import numpy as np
+    from opt_amd import workloads as wl
+    from helpers import oracle_solver
+    ft = np.float64 if double else np.float32
+    N = nx * ny
+    rest = _dumped(tmp_path, "arap_rest", ft, (N, 3))
+    head, tail = _dumped(tmp_path, "arap_head", np.int32), _dumped(tmp_path, "arap_tail", np.int32)
+    w_fit = np.array(np.sqrt(np.float32(4.0)), dtype=np.float32); w_reg = np.array(np.sqrt(np.float32(1.0)), dtype=np.float32)
+    P = wl.Problem("arap_mesh_deformation", (N,), [w_fit, w_reg, rest.copy(), np.zeros((N, 3), dtype=ft), rest, np.zeros((N, 3), dtype=ft), np.array(len(head), dtype=np.int32), head, tail],
+                   (2, 3), double, {"n_edges": int(len(head))})
+    o = oracle_solver(oracle_lib, P, "gaussNewtonGPU", nIterations=n_it, lIterations=l_it)
+    for i in range(passes):
+        P.params[5][...] = _dumped(tmp_path, f"arap_constraints_{i}", ft, (N, 3))
+        o.solve(P.params)
+    c = o.cost()
+    o.close()
+    return c
+
+
+def test_arap_example_flow(oracle_lib, tmp_path):
+    """The 10-pass handle ramp of the reference's ARAP example (main.cpp:75-79: 10 passes x 20 x 100 there; 10 x 4 x 25 on a 40 x 30 mesh here) in double: the
+    caller's final cost must be the oracle's on the same inputs (1e-8: 1000 undamped PCG iterations); a short float flow at the float contract."""
+    energy = os.path.join("opt_amd", "energies", "arap_mesh_deformation.t")
+    r = _run("arap_example", 40, 30, 10, 4, 25, energy, 1, env={"OPT_EXAMPLE_DUMP": str(tmp_path)})
     assert r.returncode == 0, r.stdout + r.stderr
     assert "===Mesh Deformation ARAP===" in r.stdout and "half-edges" in r.stdout
+    gn, _ = _final_costs(r.stdout)
+    ref = _oracle_arap_ramp(oracle_lib, tmp_path, 40, 30, 10, 4, 25, True)
+    assert abs(gn - ref) <= 1e-8 * ref, (gn, ref)
+    os.remove(os.path.join(ROOT, "results_double.csv"))
+    r = _run("arap_example", 60, 50, 3, 2, 10, energy, 0, env={"OPT_EXAMPLE_DUMP": str(tmp_path)})
+    assert r.returncode == 0, r.stdout + r.stderr
+    gnf, _ = _final_costs(r.stdout)
+    reff = _oracle_arap_ramp(oracle_lib, tmp_path, 60, 50, 3, 2, 10, False)
+    assert abs(gnf - reff) <= 1e-5 * reff, (gnf, reff)
     os.remove(os.path.join(ROOT, "results_float.csv"))
 
 
-def test_sfs_example_flow_double_lm():
-    r = _run("sfs_example", "-", 192)
+def test_sfs_example_flow_double_lm(oracle_lib, tmp_path):
+    """The SFS example (main.cpp:27-38: LM 60 x 10, double) on a 128^2 procedural surface: final cost against the oracle on the caller's own arrays."""
+    import numpy as np
+    from opt_amd import workloads as wl
+    from helpers import oracle_solver
+    W = H = 128
+    r = _run("sfs_example", "-", W, env={"OPT_EXAMPLE_DUMP": str(tmp_path)})
     assert r.returncode == 0, r.stdout + r.stderr
     gn, lm = _final_costs(r.stdout)
     assert "===Shape From Shading===" in r.stdout and gn is None and lm > 0
+    sc = _dumped(tmp_path, "sfs_scalars", np.float32)
+    params = [np.array(v, dtype=np.float32) for v in sc]
+    params += [_dumped(tmp_path, "sfs_X", np.float64, (H, W)), _dumped(tmp_path, "sfs_D", np.float64, (H, W)), _dumped(tmp_path, "sfs_Im", np.float64, (H, W)),
+               _dumped(tmp_path, "sfs_edgeR", np.uint8, (H, W)), _dumped(tmp_path, "sfs_edgeC", np.uint8, (H, W))]
+    P = wl.Problem("shape_from_shading", (W, H), params, (16,), True)
+    o = oracle_solver(oracle_lib, P, "LMGPU", nIterations=60, lIterations=10)
+    o.set_threads(8)
+    o.solve(P.params)
+    assert abs(lm - o.cost()) <= 1e-9 * o.cost(), (lm, o.cost())
+    o.close()
     os.remove(os.path.join(ROOT, "results_double.csv"))

@@ -23,8 +23,9 @@ FLOOR = {"float": 1e-5, "double": 1e-12}
 FACTOR = 2.0
 
 # key suffixes of the reference-order runs: build (plain / fused multiply-adds) x accumulation order of the J^T J p scatter (banded two-colour traversal of the
-# multi-threaded oracle / raster order of the single-threaded one) -- every combination is the same algorithm under another legal rounding
-VARIANTS = (("", "plain"), ("_fma", "fma"), ("_raster", "raster"), ("_raster_fma", "raster fma"))
+# multi-threaded oracle / raster order of the single-threaded one) x float sin / cos (the host libm / `trig`: a seeded implementation within 1 ulp, oracle/dual.hpp --
+# the reference calls libdevice's) -- every combination is the same algorithm under another legal rounding
+VARIANTS = (("", "plain"), ("_fma", "fma"), ("_raster", "raster"), ("_raster_fma", "raster fma"), ("_trig", "trig"), ("_trig_fma", "trig fma"))
 _cache = {}
 
 
