@@ -23,11 +23,11 @@
 // checks tiles <= CUs x occupancy.
 #pragma once
 #include "iw_device.h"
+#include "onchip_sync.h"
 
 namespace optamd {
 namespace {
 
-typedef unsigned long long oc_u64;
 constexpr int kOcBlock = 512, kOcWavesX = 4, kOcWavesY = 2, kOcWaves = kOcBlock / kWave, kOcTileW = kOcWavesX * kWave;
 constexpr int kOcGroup = 16;                  // workgroups per first-level group of the grid-wide sum
 constexpr int kOcMaxTiles = 256;              // 16 groups of 16
@@ -66,33 +66,6 @@ struct OnchipArgs {
     T lmRadius, lmMin, lmMax, qTolerance; int resetPeriod;
 };
 
-// SYS: words that cross GPUs (the peer window: uncached memory, system scope); else agent scope
-template <bool SYS = false> __device__ __forceinline__ oc_u64 ocLoad(const oc_u64* p) {
-    return SYS ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <bool SYS = false> __device__ __forceinline__ void ocStore(oc_u64* p, unsigned tag, unsigned half) {
-    if (SYS) __hip_atomic_store(p, ((oc_u64)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    else __hip_atomic_store(p, ((oc_u64)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// Waits until *src carries `tag`; returns the payload.  Bounded: after timeoutTicks of the 100 MHz wall clock -- or as soon as another waiter has given up --
-// the wait falls through with whatever is there (the caller's loop ends at its next sum).
-template <bool SYS = false> __device__ __forceinline__ unsigned ocAwait(const oc_u64* src, unsigned tag, int* bad, long long timeoutTicks) {
-    oc_u64 v = ocLoad<SYS>(src);
-    if ((unsigned)(v >> 32) != tag) {
-        const long long t0 = wall_clock64();
-        unsigned spins = 0;
-        for (;;) {
-            __builtin_amdgcn_s_sleep(1);
-            v = ocLoad<SYS>(src);
-            if ((unsigned)(v >> 32) == tag) break;
-            if ((++spins & 31u) == 0) {
-                if (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                if (wall_clock64() - t0 > timeoutTicks) { __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-        }
-    }
-    return (unsigned)v;
-}
 // one scalar of the halo as tagged words: a float is one word, a double two
 template <bool SYS = false> __device__ __forceinline__ void ocSend(oc_u64* box, int idx, float v, unsigned tag) { ocStore<SYS>(box + idx, tag, __float_as_uint(v)); }
 template <bool SYS = false> __device__ __forceinline__ void ocSend(oc_u64* box, int idx, double v, unsigned tag) {
@@ -141,7 +114,6 @@ template <bool SYS = false> __device__ __forceinline__ void ocRecv3(const oc_u64
     }
     for (int i = 0; i < 3; ++i) v[i] = __longlong_as_double((long long)((w[2 * i + 1] << 32) | (w[2 * i] & 0xffffffffull)));
 }
-__device__ __forceinline__ double ocJoin(unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((oc_u64)hi << 32) | lo)); }
 
 // Whole-wave shifts that KEEP `old` in the lane whose source lies outside the wave (bound_ctrl off): lane 0 of fromLeft / lane 63 of fromRight receive the
 // halo value the caller put there, every other lane its neighbour's register -- the wave-edge column costs no extra instruction.
@@ -160,19 +132,6 @@ template <class T> struct __attribute__((aligned(16))) OcH4 { T v[4]; };      //
 
 __device__ __forceinline__ float ocFma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double ocFma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-
-// Sum over the wave, valid in lane 63: prefix sums inside the rows of 16 lanes (row_shr 1, 2, 4, 8), then row 0 -> 1 and 2 -> 3 (row_bcast:15), then rows 0-1 -> 2-3
-// (row_bcast:31).  13 DPP moves + 6 adds per double on the VALU, against six ds_bpermute round trips for the __shfl_down tree (1.2 us per iteration for four sums).
-template <int CTRL, int ROWMASK> __device__ __forceinline__ double ocDppAdd(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, true), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, true);
-    return v + __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double ocWaveSum63(double v) {
-    v = ocDppAdd<0x111, 0xf>(v); v = ocDppAdd<0x112, 0xf>(v); v = ocDppAdd<0x114, 0xf>(v); v = ocDppAdd<0x118, 0xf>(v);      // lane 15 of every row: the row's sum
-    v = ocDppAdd<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
-    v = ocDppAdd<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
-    return v;
-}
 
 // LDS carve-up (bytes), shared by the kernel and the launcher
 constexpr int kOcSumsMax = 6;                 // capacity of the per-phase sums (Gauss-Newton 4, Levenberg-Marquardt 5)

@@ -992,9 +992,9 @@ struct PcgSolver : SolverBase {
                     imageOp(2);
                     if (!runSingleKernelLoopLM(preArg, T(0), q_tolerance)) { fprintf(stderr, "Opt(amd): the streaming LM loop refused the redo\n"); exit(1); }
                 } else {
-                    // Gauss-Newton: nothing was applied (iw_applyDelta checks the flag -- in slab mode the all-reduced verdict, so no rank kept its update).  Row slabs
-                    // start the redone loop from delta = 0 as PCGInit1 left it: the ROWS = 16 variant accumulates delta in memory while it runs.
-                    if (distributed) HIP_CHECK(hipMemsetAsync(delta, 0, nPad * sizeof(T), stream));
+                    // Gauss-Newton: nothing was applied (iw_applyDelta checks the flag -- in slab mode the all-reduced verdict, so no rank kept its update).
+                    // The redone loop starts from delta = 0 as PCGInit1 left it: the ROWS = 16 variant accumulates delta in memory while it runs.
+                    HIP_CHECK(hipMemsetAsync(delta, 0, nPad * sizeof(T), stream));
                     if (!runSingleKernelLoop(preArg)) { fprintf(stderr, "Opt(amd): the streaming loop refused the redo\n"); exit(1); }
                 }
                 afterLinearSolve();

@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--precisions", nargs="+", default=["float", "double"])
     ap.add_argument("--redo", action="store_true")
+    ap.add_argument("--horizons", type=int, nargs="+", default=HORIZONS, help="horizon / adversarial families: which lIterations (round 5: 26, 37, 48 = quiet\n"
+                    "iterations of the horizon family's ~5.5-iteration amplification cycle, profiles/r05_l50_bisect.md)")
     ap.add_argument("--variant", default="plain", choices=["plain", "fma"])
     args = ap.parse_args()
     res = json.load(open(OUT)) if os.path.exists(OUT) else {}
@@ -72,7 +74,7 @@ def main():
         for prec in args.precisions:
             dbl = prec == "double"
             if fam in ("horizon", "adversarial"):
-                for L in HORIZONS:
+                for L in args.horizons:
                     key = f"{fam}_{2048 if fam == 'horizon' else ADVERSARIAL_SIZE}_{prec}_{L}"
                     if key in res and not args.redo:
                         continue
