@@ -25,6 +25,8 @@ The same JSON line carries
                  every iteration, halo exchange every 7th) plus launch gaps -- on a real multi-GPU box that is the xGMI cost per iteration.
   cpu_baseline : the CPU oracle (a port, not the reference) timed on a bounded sample on the host cores (rank 0, N = 1 only).
   parity       : cost after the first step next to the frozen oracle value for this workload (tests/golden/bench_costs.json).
+  box          : what the line ran on -- power cap, clocks and power sampled under load, the box's own measured copy bandwidth (boxes of the pool differ by ~10 %).
+  --dry        : set-up only; prints what every rank WOULD do (on chip or streaming, communicator, ghost depth, bytes per exchange) and exits.
 """
 import argparse
 import hashlib
@@ -70,6 +72,8 @@ def parse():
     ap.add_argument("--cpu-liters", type=int, default=24)      # ~12 s of host work on the 128-thread box (the contract asks for 10-30 s)
     ap.add_argument("--comm", default=os.environ.get("OPT_AMD_COMM", "peer"), choices=["peer", "rccl"])
     ap.add_argument("--cpu-smoke", action="store_true", help="launcher check without GPUs: ranks rendezvous over gloo and report the world size")
+    ap.add_argument("--dry", action="store_true", help="set everything up (slabs, communicator, plan) and print, per rank, what the solve WOULD do -- on chip or one launch per "
+                                                       "iteration, communicator and its fast paths, ghost depth, bytes per exchange (OptAmd_PlanDescribe) -- without running a step")
     ap.add_argument("--share-gpu", action="store_true", help="functional check of the N-rank path on a 1-GPU box: all ranks use device 0, set-up over gloo (timings meaningless)")
     return ap.parse_args()
 
@@ -223,6 +227,82 @@ def reference_example_flows():
     return out
 
 
+def box_info(torch):
+    """Which box is this?  Boxes of the pool differ by ~10 % on the same binary (sclk / power behaviour): the line says what it ran on.  Static facts from rocm-smi
+    (power cap, mclk, performance level), and -- because an idle GPU reports its sleep clocks -- a one-second copy loop during which sclk / mclk / power are sampled,
+    whose own GB/s is the box's measured-copy ceiling (MI355X_MICROARCH.md quotes 6.29 TB/s)."""
+    import re
+    import threading
+    info = {}
+
+    def smi(*opts):
+        try:
+            return subprocess.run(["rocm-smi", *opts], capture_output=True, text=True, timeout=20).stdout
+        except Exception as e:      # noqa
+            return f"rocm-smi failed: {e}"
+
+    def grab(txt, pat):
+        m = re.search(pat, txt)
+        return float(m.group(1)) if m else None
+
+    static = smi("--showmaxpower", "--showperflevel")
+    info["power_cap_w"] = grab(static, r"Max Graphics Package Power \(W\): ([0-9.]+)")
+    m = re.search(r"Performance Level: (\w+)", static)
+    info["perf_level"] = m.group(1) if m else None
+    n = 1 << 28      # 1 GiB of floats in, 1 GiB out
+    a = torch.empty(n, dtype=torch.float32, device="cuda"); b = torch.empty_like(a)
+    b.copy_(a); torch.cuda.synchronize()
+    sample = {}
+    th = threading.Thread(target=lambda: sample.update(txt=smi("--showclocks", "--showpower")))
+    t0 = time.perf_counter()
+    th.start()
+    reps = 0
+    while time.perf_counter() - t0 < 1.0:
+        for _ in range(8):
+            b.copy_(a)
+        torch.cuda.synchronize()
+        reps += 8
+    dt = time.perf_counter() - t0
+    th.join()
+    info["copy_gbs"] = 2.0 * n * 4 * reps / dt / 1e9
+    txt = sample.get("txt", "")
+    info["sclk_mhz_under_load"] = grab(txt, r"sclk clock level: \S+ \(([0-9.]+)Mhz\)")
+    info["mclk_mhz_under_load"] = grab(txt, r"mclk clock level: \S+ \(([0-9.]+)Mhz\)")
+    info["power_w_under_load"] = grab(txt, r"Current Socket Graphics Package Power \(W\): ([0-9.]+)")
+    info["device"] = torch.cuda.get_device_name(0)
+    info["kind"] = f"copy {info['copy_gbs'] / 1e3:.2f} TB/s, sclk {info['sclk_mhz_under_load']} MHz under load, cap {info['power_cap_w']} W"
+    del a, b
+    return info
+
+
+def flow_parity(flows):
+    """The example flow's final costs (both HIP paths) next to the frozen oracle runs of the SAME flow (tests/golden/reference_flow_costs.json: exact-order sums and
+    reference-order seeds, tests/golden/make_reference_flow.py): where do the HIP paths land relative to the runs of the reference's own arithmetic?"""
+    try:
+        G = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_flow_costs.json")))
+    except OSError:
+        return None
+    out = {}
+    for kind, field in (("gaussNewtonGPU", "final_cost_gn"), ("LMGPU", "final_cost_lm")):
+        e = G.get(f"image_warping_512_float_{kind}_19x8x400")
+        if not e:
+            continue
+        runs = {seed: c[-1] for seed, c in e["costs_by_seed"].items()}
+        vals = sorted(runs.values())
+        med = vals[len(vals) // 2] if len(vals) % 2 else 0.5 * (vals[len(vals) // 2 - 1] + vals[len(vals) // 2])
+        row = {"frozen_runs": runs, "frozen_median": med, "frozen_min": vals[0], "frozen_max": vals[-1], "frozen_diameter_rel": (vals[-1] - vals[0]) / med}
+        for name in ("onchip", "streaming"):
+            f = (flows or {}).get("image_warping_512_19x8x400_" + name)
+            if f and f.get(field) is not None:
+                c = f[field]
+                row["hip_" + name] = {"final_cost": c, "rel_to_median": (c - med) / med, "inside_frozen_range": vals[0] <= c <= vals[-1],
+                                      "within_contract_1e-5_of_some_run": any(abs(c - v) <= 1e-5 * abs(v) for v in vals)}
+        out[kind] = row
+    out["note"] = ("seed 0 = exact-order sums, seeds >= 1 = the reference's own sums (float atomics in a seeded order): every frozen run is a legal run of the reference; "
+                   "their diameter is what the reference's 1e-5 contract can mean over 19 x 8 x 400 float iterations")
+    return out
+
+
 def main():
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
@@ -290,6 +370,23 @@ def main():
     extra_steps = 0 if args.no_extras else 2      # the roofline leg runs on the SAME plan, after the timed steps (per-kernel hipEvents switched on by OptAmd_PlanSetTiming)
     solver.set_parameter("nIterations", total_steps + extra_steps)
     solver.set_parameter("lIterations", args.liters)
+
+    if args.dry:      # what WOULD this run do?  One line, every rank's answer in it; no step is taken
+        mine = {"rank": rank, "device": torch.cuda.current_device(), "plan": solver.describe(), "comm": args.comm if distributed else None,
+                "slab": {"row0": job.layout.row0, "rows": job.layout.rows, "ghost": job.layout.ghost} if distributed else None}
+        allr = [None] * world
+        if distributed:
+            dist.all_gather_object(allr, mine)
+        else:
+            allr = [mine]
+        if rank == 0:
+            print(json.dumps({"dry": True, "n_gpus": world, "workload": f"image_warping {W}x{H} float, gaussNewtonGPU, {args.liters} PCG iterations per GN step", "ranks": allr, "preflight": preflight}))
+        if distributed:
+            job.close()
+            dist.destroy_process_group()
+        else:
+            solver.close()
+        return
 
     def sync():
         torch.cuda.synchronize()
@@ -371,7 +468,9 @@ def main():
     sha = kernel_src_sha16()
     comm_us = None
     if extra_steps:
-        solver.set_timing(True)
+        # single GPU: one event pair per RUN of launches of one name -- the 400 PCGIteration launches of a step cost two event records, not 800.  Row slabs: a pair per
+        # launch (the communicator's kernels run between two iteration launches and must stay outside the brackets)
+        solver.set_timing(1 if distributed else 2)
         if distributed:
             job.set_comm_timing(True)
         sync()
@@ -425,10 +524,11 @@ def main():
                         "algorithmic_equiv": {"bytes_per_pixel": ALGO_BYTES_PER_PIXEL, "bytes_per_launch": ALGO_BYTES_PER_PIXEL * W * rows,
                                               "achieved": algo, "ratio_to_peak": algo / HBM_PEAK_GBS,
                                               "note": "reference formulation (3 kernels, SURVEY 8d) over this kernel's time; not a physical fraction"},
-                        "timed_on": "the benchmarked plan itself: the two Opt_ProblemSteps after the timed ones, per-kernel hipEvents switched on (OptAmd_PlanSetTiming)",
+                        "timed_on": "the benchmarked plan itself: the two Opt_ProblemSteps after the timed ones, hipEvents switched on (OptAmd_PlanSetTiming mode 2: one event pair around each "
+                                    "run of launches of one name -- the 400 PCGIteration launches of a step are bracketed ONCE, avg_kernel_ms = that interval / 400, launch gaps included)",
                         "kernel_ms_per_step": per_step, "kernel_ms_per_step_sum": sum(v for k, v in per_step.items() if k != "overall"),
                         "timed_leg_ms_per_step": leg_ms_per_step,
-                        "timed_leg_note": "kernel_ms_per_step_sum <= timed_leg_ms_per_step (this leg's wall clock, event records included); ms_per_step of the line is the leg without events",
+                        "timed_leg_note": "kernel_ms_per_step_sum <= timed_leg_ms_per_step (this leg's wall clock); with one event pair per run the leg costs what a timed step costs",
                         "kernel_avg_ms": {k: v[1] / v[0] for k, v in kt.items()}}
             if distributed:
                 roofline.update({"slab_rows": rows, "ghost_rows": job.layout.ghost, "per_iteration_ms": dt / args.steps / args.liters * 1e3, "comm_kernels": comm_us,
@@ -505,6 +605,9 @@ def main():
     if not distributed and not args.no_extras:
         onchip = onchip_table(api, wl, torch, args.liters)
         flows = reference_example_flows()
+        if flows is not None:
+            flows["parity_vs_frozen_reference_runs"] = flow_parity(flows)
+    box = box_info(torch) if (rank == 0 and not args.share_gpu) else None
 
     # ---- CPU leg last: the GPU work sits at the front of the run in one block ------------------------------------------------------------
     cpu = None
@@ -546,7 +649,7 @@ def main():
                "gn_solve": solve, "gn_solve_ms": solve["gn_solve_ms"] if solve else None,
                "cost_initial": costs[0], "cost_final": cost_final, "parity": parity, "comm_ranks": comm_ranks, "preflight": preflight, "rccl_leg": rccl_leg,
                "per_iteration_ms": dt / args.steps / args.liters * 1e3,
-               "kernel_src_sha16": sha, "roofline": roofline, "general_urshape": general, "onchip": onchip, "reference_example_flows": flows, "cpu_baseline": cpu}
+               "kernel_src_sha16": sha, "box": box, "roofline": roofline, "general_urshape": general, "onchip": onchip, "reference_example_flows": flows, "cpu_baseline": cpu}
         print(json.dumps(out))
     if distributed:
         job.close()

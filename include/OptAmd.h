@@ -79,6 +79,10 @@ double OptAmd_PlanTrustRegionRadius(Opt_Plan* plan);
  *      the plan stays on them for the rest of its life (also reported once on stderr).  The two paths round differently: a caller that compares runs should
  *      check this. */
 int OptAmd_PlanOnChipStatus(Opt_Plan* plan);
+/* What the plan WOULD do at its next step, as "key=value; ..." text (truncated to outLen - 1 characters; returns the full length): the linear-solve path of its kernel
+ * set for the plan's dimensions and slab (on chip or one launch per iteration, and why), tiles, LDS, ghost depth, bytes that cross ranks per PCG iteration, the
+ * communicator's fast paths.  Uses the solver parameters set so far (lIterations).  `bench.py --gpus N --dry` prints it per rank without running a step. */
+int OptAmd_PlanDescribe(Opt_Plan* plan, char* out, int outLen);
 
 /* hipEvent timing of one kernel name since the last Opt_ProblemInit (requires
  * collectPerKernelTimingInfo).  Returns 0 if the name was never launched. */
@@ -86,7 +90,8 @@ int OptAmd_PlanKernelTiming(Opt_Plan* plan, const char* kernel, long* count, dou
 /* Switch the per-kernel hipEvent timing of a plan on or off between steps (what
  * Opt_InitializationParameters.collectPerKernelTimingInfo fixes at plan time; the reference has no such call).
  * The totals restart from zero.  bench.py times its steps without the events and then turns them on for the
- * roofline leg of the same multi-GPU job. */
+ * roofline leg of the same job.  enable = 2: one event pair per RUN of consecutive launches under the same name (the start of the first, the
+ * end of the last) instead of one per launch: a loop of 400 PCGIteration launches costs two event records and its time is the loop's own. */
 void OptAmd_PlanSetTiming(Opt_Plan* plan, int enable);
 /* Number of distinct kernel names timed, and the i-th name. */
 int OptAmd_PlanKernelCount(Opt_Plan* plan);

@@ -23,7 +23,7 @@ OPT_SYMBOLS = ["Opt_NewState", "Opt_ProblemDefine", "Opt_ProblemDelete", "Opt_Pr
 OPTAMD_SYMBOLS = ["OptAmd_Version", "OptAmd_EnergyCount", "OptAmd_EnergyName", "OptAmd_PlanNumUnknownScalars", "OptAmd_PlanVector",
                   "OptAmd_EvalJTF", "OptAmd_ApplyJTJ", "OptAmd_EvalCost", "OptAmd_PlanEnableTrace", "OptAmd_PlanTraceRows",
                   "OptAmd_PlanGetTrace", "OptAmd_PlanTrustRegionRadius", "OptAmd_PlanKernelTiming", "OptAmd_PlanSetTiming", "OptAmd_PlanKernelCount",
-                  "OptAmd_PlanKernelName", "OptAmd_PlanOnChipStatus", "OptAmd_PlanSetSlab", "OptAmd_PlanSetSlabExt", "OptAmd_CheckProblemFile", "OptAmd_ProblemFileHash"]
+                  "OptAmd_PlanKernelName", "OptAmd_PlanOnChipStatus", "OptAmd_PlanDescribe", "OptAmd_PlanSetSlab", "OptAmd_PlanSetSlabExt", "OptAmd_CheckProblemFile", "OptAmd_ProblemFileHash"]
 
 
 class Opt_InitializationParameters(ctypes.Structure):
@@ -80,6 +80,7 @@ def lib():
     L.OptAmd_PlanGetTrace.restype = None; L.OptAmd_PlanGetTrace.argtypes = [vp, vp]
     L.OptAmd_PlanTrustRegionRadius.restype = cd; L.OptAmd_PlanTrustRegionRadius.argtypes = [vp]
     L.OptAmd_PlanOnChipStatus.restype = ci; L.OptAmd_PlanOnChipStatus.argtypes = [vp]
+    L.OptAmd_PlanDescribe.restype = ci; L.OptAmd_PlanDescribe.argtypes = [vp, ctypes.c_char_p, ci]
     L.OptAmd_PlanSetTiming.restype = None; L.OptAmd_PlanSetTiming.argtypes = [vp, ci]
     L.OptAmd_PlanKernelTiming.restype = ci; L.OptAmd_PlanKernelTiming.argtypes = [vp, cp, ctypes.POINTER(cl), ctypes.POINTER(cd)]
     L.OptAmd_PlanKernelCount.restype = ci; L.OptAmd_PlanKernelCount.argtypes = [vp]
@@ -231,13 +232,19 @@ class Solver:
     def trust_region_radius(self):
         return lib().OptAmd_PlanTrustRegionRadius(self.plan)
 
+    def describe(self):
+        """What the plan would do at its next step (OptAmd_PlanDescribe), as a dict of the kernel set's key=value pairs."""
+        buf = ctypes.create_string_buffer(2048)
+        lib().OptAmd_PlanDescribe(self.plan, buf, 2048)
+        return dict(kv.strip().split("=", 1) for kv in buf.value.decode().split(";") if "=" in kv)
+
     def on_chip_status(self):
         """0: launch-per-iteration kernels; 1: the last step's linear solve ran as one on-chip launch; 2: an on-chip wait timed out, the plan fell back for good."""
         return lib().OptAmd_PlanOnChipStatus(self.plan)
 
     def set_timing(self, on):
-        """Per-kernel hipEvent timing on / off from the next launch on (totals restart)."""
-        lib().OptAmd_PlanSetTiming(self.plan, 1 if on else 0)
+        """Per-kernel hipEvent timing on / off from the next launch on (totals restart).  on = 2: one event pair per run of consecutive launches of one name."""
+        lib().OptAmd_PlanSetTiming(self.plan, int(on))
 
     def kernel_timings(self):
         """{kernel name: (count, total_ms)} since the last init (needs timing=True)."""

@@ -232,7 +232,11 @@ __device__ __forceinline__ void postMailSums(const MailPostDev& P, double* const
 // ---- per-kernel hipEvent timing (reference util.t:404-511) ---------------------------------------------
 struct KernelTimer {
     bool enabled = false;
-    struct Rec { std::string name; hipEvent_t a, b; };
+    // coarse: consecutive launches under the same name share ONE event pair -- the start of the first, the end of the last (recorded when another name begins or the
+    // table is evaluated: in stream order that is right behind the last launch).  A loop of 400 PCGIteration launches then costs two event records instead of 800,
+    // and its time is the loop's own (bench.py's roofline leg: the events of the per-launch mode cost ~1 % of a step).  OptAmd_PlanSetTiming(plan, 2).
+    bool coarse = false;
+    struct Rec { std::string name; hipEvent_t a, b; long count = 1; bool open = false; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
     std::map<std::string, std::pair<long, double>> totals;   // name -> (count, ms), filled by evaluate()
@@ -242,27 +246,36 @@ struct KernelTimer {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
         hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return e;
     }
+    void closeRun(hipStream_t s) { if (!recs.empty() && recs.back().open) { HIP_CHECK(hipEventRecord(recs.back().b, s)); recs.back().open = false; } }
     void begin(const char* name, hipStream_t s) {
         if (!enabled) return;
+        if (coarse) {
+            if (!recs.empty() && recs.back().open && recs.back().name == name) { ++recs.back().count; return; }
+            closeRun(s);
+        }
         Rec r{name, get(), get()};
+        r.open = coarse;
         HIP_CHECK(hipEventRecord(r.a, s));
         recs.push_back(r);
+        lastStream = s;
     }
     void end(hipStream_t s) {
-        if (!enabled) return;
+        if (!enabled || coarse) return;
         HIP_CHECK(hipEventRecord(recs.back().b, s));
     }
+    hipStream_t lastStream = nullptr;
     void reset() {
         for (auto& r : recs) { pool.push_back(r.a); pool.push_back(r.b); }
         recs.clear(); totals.clear(); order.clear();
     }
     void evaluate() {   // synchronises every pending event pair and folds it into `totals`
+        closeRun(lastStream);
         for (auto& r : recs) {
             HIP_CHECK(hipEventSynchronize(r.b));
             float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
             auto it = totals.find(r.name);
-            if (it == totals.end()) { totals[r.name] = {1, (double)ms}; order.push_back(r.name); }
-            else { it->second.first += 1; it->second.second += ms; }
+            if (it == totals.end()) { totals[r.name] = {r.count, (double)ms}; order.push_back(r.name); }
+            else { it->second.first += r.count; it->second.second += ms; }
             pool.push_back(r.a); pool.push_back(r.b);
         }
         recs.clear();

@@ -6,6 +6,7 @@
 // kernels so it can pick its own tiling, LDS staging and reduction shape.
 #pragma once
 #include "common.h"
+#include <string>
 #include "../../include/OptAmd.h"
 
 namespace optamd {
@@ -150,6 +151,9 @@ struct EnergyOps {
     // solver all-reduces it, onChipApply applies X += delta iff the sum is 0 -- every rank keeps its update or none does -- and tells the host (onChipFailed).
     virtual void onChipVerdict(double* /*out*/, bool /*refused*/, LaunchCtx&) {}
     virtual void onChipApply(const T* /*delta*/, const double* /*verdict*/, bool /*refused*/, LaunchCtx&) {}
+    // OptAmd_PlanDescribe: which linear-solve path the kernel set would take for the plan as it stands (dims, slab), as "key=value; ..." -- bench.py --dry prints it per
+    // rank so that a multi-GPU run can be read before it is started.
+    virtual std::string describe(int /*lIterations*/, bool /*lm*/) { return "path=launch-per-iteration"; }
     // After the stream has drained: did a wait inside the last on-chip solve time out (another tenant on the GPU kept its workgroups from being co-resident)?
     // Then the unknowns were left untouched, the kernel set has switched the path off for this plan, and the caller redoes the linear solve.
     virtual bool onChipFailed() { return false; }

@@ -507,6 +507,29 @@ struct ImageWarpingOps : EnergyOps<T> {
         iw_applyDelta<T><<<flatGrid(N), kBlock, 0, ctx.stream>>>(const_cast<T*>(A.Offset), const_cast<T*>(A.Angle), delta, N, ocS.bad, verdict, ocS.hostErr);
         ocLaunched = true;
     }
+    std::string describe(int L, bool lmv) override {
+        const Slab& sl = this->slab;
+        const int rowsOwned = (sl.active ? sl.yEnd - sl.yBegin : A.H);
+        char buf[640];
+        if (sl.active) { A.yBegin = sl.yBegin; A.yEnd = sl.yEnd; } else { A.yBegin = 0; A.yEnd = A.H; }      // (what bind() will set: ocSelect reads them)
+        int tX = 0, tY = 0;
+        const OcVariant* V = (ocEnabled && !ocFailed && L > 0 && !(lmv && sl.active)) ? ocSelect(tX, tY, lmv) : nullptr;
+        const bool ghostOk = !sl.active || sl.ghost >= 2;
+        const long rowBytes = (long)A.W * 3 * (long)sizeof(T);
+        if (V && ghostOk)
+            snprintf(buf, sizeof buf, "path=on-chip (if UrShape is the unit lattice%s); onchip_rows_per_lane=%d; tiles=%dx%d of %d CUs; lds_bytes=%zu; slab_rows=%d; ghost_rows=%d; "
+                     "per_iteration_cross_rank=%s; fallback=one launch per PCG iteration (iw_pcgIter2)",
+                     sl.active ? " and every rank and the communicator agree" : "", V->rows, tX, tY, cus, V->lds, rowsOwned, sl.active ? sl.ghost : 0,
+                     sl.active ? "edge rows of A p as tagged words (2 x W x 3 scalars x 8 B per neighbour) + one rank hop of 4 doubles, inside the persistent launch" : "none");
+        else
+            snprintf(buf, sizeof buf, "path=one launch per PCG iteration (iw_pcgIter2%s); why_not_on_chip=%s; slab_rows=%d; ghost_rows=%d; "
+                     "per_iteration_cross_rank=%s",
+                     lmv ? ", LM" : "", !ocEnabled ? "switched off" : ocFailed ? "a wait timed out earlier" : (lmv && sl.active) ? "the LM variants are single-GPU" : !ghostOk ? "needs >= 2 ghost rows" :
+                     "the tiles do not fit one per CU (or the slab is no whole number of tiles)", rowsOwned, sl.active ? sl.ghost : 0,
+                     sl.active ? (std::string("one all-reduce of 4 doubles; every ") + std::to_string(std::max(1, sl.ghost - 1)) + " iterations " + std::to_string(2L * sl.ghost * rowBytes) +
+                                  " B of edge rows (the two newest search directions) per neighbour").c_str() : "none");
+        return buf;
+    }
     bool onChipFailed() override {
         if (!ocLaunched) return false;
         ocLaunched = false;

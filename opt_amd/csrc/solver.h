@@ -41,9 +41,10 @@ struct SolverBase {
     virtual double evalCost(void** params) = 0;
     virtual double trustRegionRadius() const = 0;
     virtual int onChipStatus() const { return 0; }             // OptAmd_PlanOnChipStatus
+    virtual std::string describe() { return ""; }              // OptAmd_PlanDescribe
     virtual int setSlab(long row0, long rows, long globalHeight, const OptAmd_SlabComm* comm) = 0;
     virtual int setSlabExt(const OptAmd_SlabCommExt* ext) = 0;
-    virtual void setTiming(bool on) = 0;                        // OptAmd_PlanSetTiming
+    virtual void setTiming(int mode) = 0;                       // OptAmd_PlanSetTiming: 0 off, 1 an event pair per launch, 2 an event pair per run of launches of one name
     bool setParameter(const char* name, const void* value);   // solver.t:1205-1221
 };
 

@@ -789,7 +789,7 @@ struct PcgSolver : SolverBase {
     void cleanup() {   // solver.t:1009-1014
         if (verbosity > 0) printf("final cost=%f\n", (double)prevCost);
         if (timer.enabled) {
-            if (overallOpen) { KernelTimer::Rec rec{"overall", overallStart, timer.get()}; HIP_CHECK(hipEventRecord(rec.b, stream)); timer.recs.push_back(rec); overallOpen = false; }
+            if (overallOpen) { timer.closeRun(stream); KernelTimer::Rec rec{"overall", overallStart, timer.get()}; HIP_CHECK(hipEventRecord(rec.b, stream)); timer.recs.push_back(rec); overallOpen = false; }
             timer.evaluate();
             if (verbosity > 0) timer.print();
         }
@@ -1039,14 +1039,21 @@ struct PcgSolver : SolverBase {
     }
 
     double cost() const override { return (double)prevCost; }   // solver.t:1179-1182
-    void setTiming(bool on) override {      // per-kernel hipEvents from the next launch on (what collectPerKernelTimingInfo sets at plan time)
+    void setTiming(int mode) override {      // per-kernel hipEvents from the next launch on (what collectPerKernelTimingInfo sets at plan time); 2: one pair per run of equal names
         HIP_CHECK(hipStreamSynchronize(stream));
         if (overallOpen) { timer.pool.push_back(overallStart); overallOpen = false; }
-        timer.reset(); timer.enabled = on; ctx.timer = on ? &timer : nullptr;
+        const bool on = mode != 0;
+        timer.reset(); timer.enabled = on; timer.coarse = mode == 2; ctx.timer = on ? &timer : nullptr;
     }
     long numUnknownScalars() const override { return n; }
     double trustRegionRadius() const override { return (double)trust_region_radius; }
     int onChipStatus() const override { return onChipFellBack ? 2 : lastStepOnChip ? 1 : 0; }
+    std::string describe() override {
+        std::string d = E->describe(sp.lIterations, lm);
+        d += std::string("; solver=") + (lm ? "LM" : "GN") + "; distributed=" + (distributed ? "yes" : "no") + "; comm_world=" + std::to_string(distributed ? comm.world : 1) +
+             "; comm_ext=" + (commExt.onChipPlan ? "onChipPlan " : "") + (commExt.allReducePost ? "allReducePost " : "") + (commExt.allReducePartials ? "allReducePartials" : "");
+        return d;
+    }
     void* vector(const std::string& nm) override {
         if (nm == "delta") return delta; if (nm == "r") return r; if (nm == "b") return b; if (nm == "Adelta") return Adelta;
         if (nm == "z") return z; if (nm == "p") return p; if (nm == "Ap_X") return Ap_X; if (nm == "CtC") return CtC;

@@ -35,12 +35,13 @@ template <class T, int N> Dual<T,N> operator/(T a, const Dual<T,N>& b) { return 
 
 // ---- which float sin / cos?  The reference calls libdevice's __nv_sinf / __nv_cosf (util.t:162-171), documented to 2 ulp; this restatement calls the host's
 // libm, the HIP product ocml's -- three implementations that agree to an ulp or two and are not bitwise equal.  trigSeed() != 0 emulates "another
-// implementation within 1 ulp": the correctly rounded value (computed in double), nudged by one ulp up or down for a seeded quarter of the arguments (a hash of
-// the argument's bits, so the same angle gives the same value throughout a run).  Every seed is a legal elementwise variant of the reference, the way every
+// implementation within 1 ulp": the correctly rounded value (computed in double), nudged by one ulp up or down for a seeded quarter of the arguments whose result is
+// not exact (a hash of the argument's bits, so the same angle gives the same value throughout a run).  Every seed is a legal elementwise variant of the reference, the way every
 // seed of reductionMode 1 is a legal order of its atomics (tests/golden/make_trig_variants.py).  Double precision is left alone.
 inline unsigned& trigSeed() { static unsigned s = 0; return s; }
 inline float trigVariant(float x, double exact) {
     float r = (float)exact;
+    if ((double)r == exact) return r;      // an exact result (sin 0 = 0, cos 0 = 1: every angle of the example's initial guess) is exact in every implementation
     unsigned b; __builtin_memcpy(&b, &x, 4);
     unsigned h = (b ^ (trigSeed() * 0x9E3779B9u)) * 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     if ((h & 3u) == 0u) r = std::nextafter(r, (h & 4u) ? 2.0f : -2.0f);
