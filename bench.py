@@ -265,6 +265,17 @@ def box_info(torch):
     dt = time.perf_counter() - t0
     th.join()
     info["copy_gbs"] = 2.0 * n * 4 * reps / dt / 1e9
+    # the same copy on a working set that stays in the 256 MiB Infinity Cache (64 MiB in + 64 MiB out): the ceiling a streaming kernel can reach on the cache-resident
+    # working sets of configs 3 and 4 (SFS 1024^2 double: 132 MB; ARAP 500 k vertices: 239 MB) -- measured, not quoted
+    m = 1 << 24
+    for _ in range(4):
+        b[:m].copy_(a[:m])
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(200):
+        b[:m].copy_(a[:m])
+    torch.cuda.synchronize()
+    info["copy_gbs_cache_resident_128MiB"] = 2.0 * m * 4 * 200 / (time.perf_counter() - t1) / 1e9
     txt = sample.get("txt", "")
     info["sclk_mhz_under_load"] = grab(txt, r"sclk clock level: \S+ \(([0-9.]+)Mhz\)")
     info["mclk_mhz_under_load"] = grab(txt, r"mclk clock level: \S+ \(([0-9.]+)Mhz\)")

@@ -9,8 +9,11 @@ tests/golden/reference_order_costs.json / horizon_costs*.json, and their diamete
 3.8e-4 / 1.4e-3 / 6.1e-3 / 6.9e-3 / 2.3e-3 after 20 / 50 / 100 / 200 / 400 float iterations at 2048^2, seed-to-seed alone 3.7e-4 / 1.4e-5 / 3.0e-3 / 2.9e-3 / 1.1e-3).
 
   * every HIP loop -- the reference-ordered three-kernel loop, the benchmarked one-launch-per-iteration loop, the on-chip linear solve -- at every horizon, in
-    float and double, on the benchmark family and on the adversarial one (sparse stiff fit pixels, Jacobi entries spanning eight decades): at most 2 yardsticks
-    from the exact-order oracle, yardstick = max(contract, diameter of the legal runs).  No running maxima, no skipped family.
+    float and double, on the adversarial family (sparse stiff fit pixels, Jacobi entries spanning eight decades) and the benchmark family in double: at most ONE yardstick
+    from the exact-order oracle, yardstick = max(contract, diameter of the legal runs) (round 4 allowed two);
+  * the benchmark family in float in PCG ITERATIONS OF PROGRESS from the hull of the two exact-order oracle builds (plain / fma), with the neighbouring horizons frozen;
+    the reference-ordered loop against the fma build's exact-order run at the 1e-5 contract itself at 20 / 200 / 400 iterations; the HIP side's own ensemble of launch
+    geometries (round 5; profiles/r05_l50_bisect.md says why a diameter of scalar-noise runs was the wrong yardstick there);
   * the adversarial family after 400 iterations (converged): the float contract itself;
   * the metric's own solve, 8 x 400 from the initial guess through Opt_ProblemSolve: final energy within 2 yardsticks of the frozen runs of that solve.
 
@@ -62,13 +65,68 @@ HORIZONS = [20, 50, 100, 200, 400]
 @pytest.mark.parametrize("precision", ["float", "double"])
 @pytest.mark.parametrize("liters", HORIZONS)
 def test_every_loop_within_the_reference_spread(table, family, precision, liters):
+    """One yardstick -- max(contract, diameter of the frozen legal runs) -- and no allowance on top of it (round 4 multiplied by two).  The benchmark family in float is
+    measured with the physical yardstick below instead (test_horizon_float_in_iterations_of_progress): its diameter is a diameter of scalar-noise runs."""
+    if (family, precision) == ("horizon", "float"):
+        pytest.skip("measured in PCG iterations of progress: test_horizon_float_in_iterations_of_progress")
     r = table.get((family, precision, liters))
     assert r is not None, "no frozen oracle value for this case"
     assert r["legal_runs"] >= 5, r                      # exact-order plain + fma, reference-order seeds
     yard = r["yardstick"]
-    assert yard >= FLOOR[precision]
+    assert yard >= FLOOR[precision] and rs.FACTOR == 1.0
     for loop in ("ref-order", "r-free", "on-chip"):      # (on-chip: where the image fits -- the 1024^2 family; at 2048^2 the streaming loop again)
-        assert r[loop + "_rel"] <= rs.FACTOR * yard, (loop, r[loop + "_rel"], yard, r)
+        assert r[loop + "_rel"] <= yard, (loop, r[loop + "_rel"], yard, r)
+
+
+@pytest.mark.parametrize("liters", HORIZONS)
+def test_horizon_float_in_iterations_of_progress(table, liters):
+    """The benchmark family (2048^2 float, one Gauss-Newton step of L PCG iterations), every HIP loop, in the unit the solve itself offers: ONE PCG ITERATION OF PROGRESS,
+    |c(L-1) - c(L+1)| / 2 of the exact-order oracle (frozen neighbouring horizons), measured from the HULL of the two exact-order oracle runs -- plain build and
+    fused-multiply-add build: the same algorithm and sums under the two legal contractions of its elementwise arithmetic (the HIP compiler contracts like the second).
+    profiles/r05_l50_bisect.md: the solve has a ~5.5-iteration cycle of near-breakdowns that amplifies 1e-7 differences 1e5-fold for two iterations at a time, and its cost
+    still falls 0.46 % per iteration at L = 50 -- so a cost at a fixed horizon is known to a fraction of an iteration, not to 1e-5.  Measured (profiles/r05_horizon_parity.md):
+    the reference-ordered loop 0.12 iterations outside the hull at L = 50 and inside it everywhere else; the r-free / on-chip loops at most 0.64 (L = 50) and 1.45 (L = 100,
+    worst launch geometry).  Bars: 0.25 and 2 iterations."""
+    r = table[("horizon", "float", liters)]
+    its = {loop: rs.iterations_from_hull("horizon", 2048, "float", liters, r[loop]) for loop in ("ref-order", "r-free", "on-chip")}
+    assert all(v is not None for v in its.values()), "neighbouring horizons not frozen (tests/golden/make_horizon_costs.py --horizons)"
+    print(f"L = {liters}: iterations of progress outside the exact-order hull: {its}")
+    assert its["ref-order"] <= 0.25, its
+    assert its["r-free"] <= 2.0 and its["on-chip"] <= 2.0, its
+
+
+@pytest.mark.parametrize("liters", [20, 200, 400])
+def test_reference_ordered_loop_meets_the_contract_against_the_fma_build(table, liters):
+    """The reference-ordered HIP loop (per-workgroup double partials added in a fixed order = exact-order sums to float precision; elementwise arithmetic contracted to FMAs
+    by the compiler) against the frozen exact-order run of the oracle's fused-multiply-add build -- the legal run it restates: within the 1e-5 contract at the horizons that
+    end in a quiet stretch of the solve's cycle, INCLUDING the metric's 400 iterations (measured 3.2e-7 / 1e-6 / 5.3e-7).  At 50 and 100 (inside a near-breakdown) the same
+    pair is 5.4e-4 / 9.5e-5 apart = 0.12 / 0.06 iterations of progress (previous test)."""
+    r = table[("horizon", "float", liters)]
+    assert "oracle_fma" in r
+    rel = abs(r["ref-order"] - r["oracle_fma"]) / abs(r["oracle_fma"])
+    print(f"L = {liters}: HIP reference-ordered loop vs exact-order fma oracle: {rel:.2e}")
+    assert rel <= 1e-5, (r["ref-order"], r["oracle_fma"], rel)
+
+
+def test_hip_ensemble_against_the_frozen_legal_runs():
+    """The HIP side's own ensemble (tools/horizon_ensemble.py): two loops x 9 launch geometries -- every geometry is another legal summation order -- at L = 50 and 100, the two
+    horizons that end inside a near-breakdown.  (i) The reference-ordered loop does not depend on the geometry AT ALL: its double partial sums round to the same float whatever
+    the order, so its runs are one run, bit for bit.  (ii) Every run of the r-free loop is within 2 iterations of progress of the exact-order hull.  (iii) The distribution is
+    reported against the frozen reference-order ensemble (anchored on ITS median): quantiles, fraction within 1e-5, two-sample KS.  The two distributions are NOT the same at these
+    horizons (KS p < 1e-8: the reference-order seeds perturb scalars, the HIP loops' roundings perturb vectors, and only the latter is amplified by a near-breakdown) -- the
+    test prints that instead of asserting a similarity that does not exist."""
+    import horizon_ensemble as he
+    for L in (50, 100):
+        geoms = he.ROWS[::2]      # 9 of the tool's 17 launch geometries (the full table: profiles/r05_horizon_ensemble.md)
+        hip = {loop: [(rows, he.hip_run(L, loop, rows)[0]) for rows in geoms] for loop in he.LOOPS}
+        ref_costs = {c for _, c in hip["ref-order"]}
+        assert len(ref_costs) == 1, ("the reference-ordered loop depends on the launch geometry", hip["ref-order"])
+        for rows, c in hip["r-free"] + hip["ref-order"][:1]:
+            its = rs.iterations_from_hull("horizon", 2048, "float", L, c)
+            assert its is not None and its <= 2.0, (L, rows, c, its)
+        cmp = he.compare([c for loop in he.LOOPS for _, c in hip[loop]], he.reference_ensemble(L))
+        print(f"L = {L}: {cmp}")
+        assert cmp["n_ref"] >= 8 and cmp["n_hip"] == 2 * len(geoms)
 
 
 def test_adversarial_float_meets_the_contract_itself_at_400_iterations(table):
@@ -82,7 +140,7 @@ def test_adversarial_float_meets_the_contract_itself_at_400_iterations(table):
 @pytest.mark.parametrize("size,precision", [(2048, "float"), (2048, "double"), (4096, "float")])
 def test_metric_solve_8x400_final_energy(size, precision):
     """The metric's solve (examples/image_warping/src/main.cpp:113-114: nIterations 8, lIterations 400) from the initial guess through Opt_ProblemSolve: final energy
-    against the frozen exact-order oracle run of the same precision, within 2 yardsticks -- the diameter of the frozen legal runs of THIS solve (exact-order plain / fma
+    against the frozen exact-order oracle run of the same precision, within one yardstick -- the diameter of the frozen legal runs of THIS solve (exact-order plain / fma
     build; reference-order seeds where generated: tests/golden/reference_order_costs.json solve8_*), never below the contract."""
     import torch
     from opt_amd import api, workloads as wl

@@ -1,0 +1,90 @@
+#!/usr/bin/env python
+"""A `roofline` object per BASELINE config: the dominant kernel(s) of configs 1-4 with their hipEvent time (tools/bench_configs.py), the HBM bytes
+rocprofv3's PMC passes measured for them (tools/profile_config.sh: 2 x FETCH_SIZE + WRITE_SIZE, per launch) and the bytes the kernel HAS to move (its own model, DESIGN.md
+section 3), against two ceilings: HBM's 8 TB/s and -- for working sets that sit in the 256 MiB Infinity Cache -- the copy rate THIS box measured on a 128 MiB working
+set (bench.py `box.copy_gbs_cache_resident_128MiB`).
+
+    python tools/config_rooflines.py gpurun_out/<tag> profiles/<tag>_configs.json
+
+Reads <src>/configs.json (one JSON line per config), <src>/bench.json (the box object) and <src>/<cfg>/{kt,pmc_fetch,pmc_write} where a config was profiled.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+HBM_PEAK = 8000.0
+# dominant kernel per config: (name in kernel_avg_us, substring of the rocprof kernel name, bytes the kernel has to move per launch, what that model is)
+MODELS = {
+    "config1": [("PCGIteration", "march_pcgIter", 65.0 * 256 * 256, "poisson marching iteration: 65 B/px (DESIGN 3.5)")],
+    "poisson_image_editing 2048": [("PCGIteration", "march_pcgIter", 65.0 * 2048 * 2048, "poisson marching iteration: 65 B/px (DESIGN 3.5)")],
+    "config2": [("PCGIteration", "iw_pcgIter2", 53.0 * 2048 * 2048, "image_warping iteration: 53 B/px (DESIGN 3.1)")],
+    "config3": [("PCGIteration", "sfs_pcgMarch", 126.0 * 1024 * 1024, "SFS double LM iteration: ~126 B/px (DESIGN 3.5); working set 132 MB: Infinity-Cache-resident")],
+    "config4": [("PCGStep1", "arap_applySym", 125e6, "ARAP record gather: slots + records + outputs 125 MB (DESIGN 3.5); working set 239 MB: Infinity-Cache-resident"),
+                ("PCGStep2+PCGStep3", "arap_flatStepRec", 114e6, "ARAP flat PCGStep2 + PCGStep3 + record rewrite: 114 MB")],
+}
+
+
+def counters(path):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def traffic(src, cfgdir, needle):
+    f = glob.glob(os.path.join(src, cfgdir, "pmc_fetch", "*counter_collection.csv"))
+    w = glob.glob(os.path.join(src, cfgdir, "pmc_write", "*counter_collection.csv"))
+    if not f or not w:
+        return None
+    F, Wr = counters(f[0]), counters(w[0])
+    k = [n for n in F if needle in n]
+    if not k:
+        return None
+    rd = sum(2 * F[n] * 1024 for n in k) / len(k)      # gfx950: FETCH_SIZE counts half of the streamed bytes, unit KiB (MI355X_MICROARCH.md)
+    wr = sum(Wr.get(n, 0.0) * 1024 for n in k) / len(k)
+    return {"read": rd, "write": wr, "total": rd + wr}
+
+
+def main(src, out):
+    box = None
+    try:
+        box = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1]).get("box")
+    except (OSError, ValueError, IndexError):
+        pass
+    cache_peak = (box or {}).get("copy_gbs_cache_resident_128MiB")
+    rows = []
+    for ln in open(os.path.join(src, "configs.json")):
+        ln = ln.strip()
+        if not ln.startswith("{"):
+            continue
+        r = json.loads(ln)
+        key = next((k for k in MODELS if k in r["config"]), None)
+        if key:
+            r["roofline"] = []
+            for kname, needle, model, what in MODELS[key]:
+                us = r["kernel_avg_us"].get(kname)
+                if not us:
+                    continue
+                t = traffic(src, "pmc_" + key.split()[0], needle)
+                ach = model / (us * 1e-6) / 1e9
+                o = {"kernel": f"{kname} = {needle}", "avg_us": us, "bound": "hbm", "model_bytes_per_launch": model, "model": what, "achieved": ach, "unit": "GB/s",
+                     "peak": HBM_PEAK, "frac": ach / HBM_PEAK, "traffic": t["total"] if t else None, "traffic_read_write": t,
+                     "hbm_achieved": t["total"] / (us * 1e-6) / 1e9 if t else None}
+                if "Infinity-Cache-resident" in what and cache_peak:
+                    o.update({"cache_resident_peak_measured": cache_peak, "frac_of_cache_resident_peak": ach / cache_peak,
+                              "note": "the working set sits in the 256 MiB Infinity Cache: HBM sees only part of the bytes (traffic < model); the honest ceiling is the box's own copy rate on a 128 MiB working set"})
+                r["roofline"].append(o)
+        rows.append(r)
+    json.dump({"box": box, "configs": rows}, open(out, "w"), indent=1)
+    for r in rows:
+        for o in r.get("roofline", []):
+            print(f"{r['config'][:60]:60s} {o['kernel']:40s} {o['avg_us']:8.1f} us  model {o['achieved']:7.0f} GB/s = {o['frac']:.2f} of HBM peak"
+                  + (f", {o['frac_of_cache_resident_peak']:.2f} of the measured cache-resident copy rate" if "frac_of_cache_resident_peak" in o else "")
+                  + (f"; PMC traffic {o['traffic'] / 1e6:.0f} MB" if o["traffic"] else ""))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

@@ -105,19 +105,25 @@ def experiment(families=("horizon", "adversarial"), precisions=("float", "double
                 row["yardstick"] = rs.yardstick(key, prec); row["reference_spread"] = rs.spread(key); row["seed_to_seed_spread"] = rs.seed_spread(key)
                 row["legal_runs"] = len(rs.legal_runs(key))
                 row["within_reference_spread"] = all(row[n + "_rel"] <= rs.FACTOR * row["yardstick"] for n in LOOPS)
+                if fam == "horizon" and prec == "float":      # the physical yardstick: PCG iterations of progress outside the hull of the two exact-order oracle builds
+                    for n in LOOPS:
+                        row[n + "_iters"] = rs.iterations_from_hull(fam, size, prec, L, row[n])
+                    if "oracle_fma" in row:
+                        row["ref-order_vs_fma_oracle"] = abs(row["ref-order"] - row["oracle_fma"]) / abs(row["oracle_fma"])
                 rows.append(row)
                 print(json.dumps(row), flush=True)
     return rows
 
 
 def markdown(rows):
-    out = ["| family | precision | PCG iterations | oracle cost | ref-order HIP | r-free HIP | on-chip HIP | legal runs | seed-to-seed | yardstick | worst loop / yardstick | within reference spread (<= 2) |",
-           "|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    out = ["| family | precision | PCG iterations | oracle cost | ref-order HIP | r-free HIP | on-chip HIP | legal runs | seed-to-seed | yardstick | worst loop / yardstick | within one yardstick | iterations of progress outside the exact-order hull (ref-order / r-free / on-chip) | ref-order HIP vs fma-build oracle |",
+           "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     f = lambda v: "n/a" if v is None else f"{v:.2e}"
     for r in rows:
         worst = max(r[n + "_rel"] for n in LOOPS) / r["yardstick"]
         out.append(f"| {r['family']} {r['size']}² | {r['precision']} | {r['liters']} | {r['oracle']:.9g} | {f(r['ref-order_rel'])} | {f(r['r-free_rel'])} | {f(r['on-chip_rel'])} | "
-                   f"{r['legal_runs']} | {f(r.get('seed_to_seed_spread'))} | {f(r['yardstick'])} | {worst:.2f} | {'yes' if r['within_reference_spread'] else 'NO'} |")
+                   f"{r['legal_runs']} | {f(r.get('seed_to_seed_spread'))} | {f(r['yardstick'])} | {worst:.2f} | {'yes' if r['within_reference_spread'] else 'NO'} | " +
+                   (" / ".join("n/a" if r.get(n + "_iters") is None else f"{r[n + '_iters']:.2f}" for n in LOOPS) if "ref-order_iters" in r else "") + f" | {f(r.get('ref-order_vs_fma_oracle'))} |")
     return "\n".join(out)
 
 
@@ -132,7 +138,9 @@ def main():
     json.dump(rows, open(args.out + ".json", "w"), indent=1)
     md = ("# |cost - oracle| / oracle after ONE Gauss-Newton step, by PCG horizon (image_warping, gaussNewtonGPU)\n\n"
           "Columns 5-7: the three HIP loops against the frozen exact-order oracle of the same precision; yardstick = max(contract, diameter of the frozen legal runs\n"
-          "of the reference's arithmetic at that horizon) (tools/reference_spread.py, profiles/r04_reference_order_spread.md).  tests/test_horizon_gpu.py asserts the last column.\n\n" + markdown(rows) + "\n")
+          "of the reference's arithmetic at that horizon) (tools/reference_spread.py), no allowance on top (round 4: x 2).  Benchmark family, float: PCG iterations of progress\n"
+          "outside the hull of the exact-order plain / fma oracle runs (frozen neighbouring horizons) and the reference-ordered loop against the fma build (profiles/r05_l50_bisect.md).\n"
+          "tests/test_horizon_gpu.py asserts these columns.\n\n" + markdown(rows) + "\n")
     open(args.out + ".md", "w").write(md)
     print(md)
 
