@@ -507,27 +507,34 @@ struct ImageWarpingOps : EnergyOps<T> {
         iw_applyDelta<T><<<flatGrid(N), kBlock, 0, ctx.stream>>>(const_cast<T*>(A.Offset), const_cast<T*>(A.Angle), delta, N, ocS.bad, verdict, ocS.hostErr);
         ocLaunched = true;
     }
-    std::string describe(int L, bool lmv) override {
+    std::string describe(int L, bool lmv) override {      // ("key=value; ..." -- no ';' inside a value)
         const Slab& sl = this->slab;
         const int rowsOwned = (sl.active ? sl.yEnd - sl.yBegin : A.H);
-        char buf[640];
+        char buf[900];
         if (sl.active) { A.yBegin = sl.yBegin; A.yEnd = sl.yEnd; } else { A.yBegin = 0; A.yEnd = A.H; }      // (what bind() will set: ocSelect reads them)
         int tX = 0, tY = 0;
-        const OcVariant* V = (ocEnabled && !ocFailed && L > 0 && !(lmv && sl.active)) ? ocSelect(tX, tY, lmv) : nullptr;
+        const bool eligible = ocEnabled && !ocFailed && L > 0 && !(lmv && sl.active);
+        const OcVariant* V = eligible ? ocSelect(tX, tY, lmv) : nullptr;
+        // the same question without the workgroup cap of ranks that SHARE a GPU (OPT_AMD_ITER_MAXWG): what one GPU per rank would answer
+        int uX = 0, uY = 0; const OcVariant* U = nullptr;
+        if (eligible && !V && maxWorkgroups < (1 << 30)) { const int keep = maxWorkgroups; maxWorkgroups = 1 << 30; U = ocSelect(uX, uY, lmv); maxWorkgroups = keep; }
         const bool ghostOk = !sl.active || sl.ghost >= 2;
         const long rowBytes = (long)A.W * 3 * (long)sizeof(T);
+        const std::string cap = maxWorkgroups < (1 << 30) ? std::to_string(maxWorkgroups) + " (OPT_AMD_ITER_MAXWG: ranks share a GPU)" : std::string("none");
         if (V && ghostOk)
-            snprintf(buf, sizeof buf, "path=on-chip (if UrShape is the unit lattice%s); onchip_rows_per_lane=%d; tiles=%dx%d of %d CUs; lds_bytes=%zu; slab_rows=%d; ghost_rows=%d; "
+            snprintf(buf, sizeof buf, "path=on-chip (if UrShape is the unit lattice%s); onchip_rows_per_lane=%d; tiles=%dx%d of %d CUs; lds_bytes=%zu; slab_rows=%d; ghost_rows=%d; workgroup_cap=%s; "
                      "per_iteration_cross_rank=%s; fallback=one launch per PCG iteration (iw_pcgIter2)",
-                     sl.active ? " and every rank and the communicator agree" : "", V->rows, tX, tY, cus, V->lds, rowsOwned, sl.active ? sl.ghost : 0,
+                     sl.active ? " and every rank and the communicator agree" : "", V->rows, tX, tY, cus, V->lds, rowsOwned, sl.active ? sl.ghost : 0, cap.c_str(),
                      sl.active ? "edge rows of A p as tagged words (2 x W x 3 scalars x 8 B per neighbour) + one rank hop of 4 doubles, inside the persistent launch" : "none");
-        else
-            snprintf(buf, sizeof buf, "path=one launch per PCG iteration (iw_pcgIter2%s); why_not_on_chip=%s; slab_rows=%d; ghost_rows=%d; "
-                     "per_iteration_cross_rank=%s",
-                     lmv ? ", LM" : "", !ocEnabled ? "switched off" : ocFailed ? "a wait timed out earlier" : (lmv && sl.active) ? "the LM variants are single-GPU" : !ghostOk ? "needs >= 2 ghost rows" :
-                     "the tiles do not fit one per CU (or the slab is no whole number of tiles)", rowsOwned, sl.active ? sl.ghost : 0,
-                     sl.active ? (std::string("one all-reduce of 4 doubles; every ") + std::to_string(std::max(1, sl.ghost - 1)) + " iterations " + std::to_string(2L * sl.ghost * rowBytes) +
-                                  " B of edge rows (the two newest search directions) per neighbour").c_str() : "none");
+        else {
+            const std::string why = !ocEnabled ? "switched off" : ocFailed ? "a wait timed out earlier" : (lmv && sl.active) ? "the LM variants are single-GPU" : !ghostOk ? "needs >= 2 ghost rows" :
+                                    U ? "the workgroup cap -- without it: on-chip, " + std::to_string(U->rows) + " rows per lane, " + std::to_string(uX) + "x" + std::to_string(uY) + " tiles" :
+                                    "the tiles do not fit one per CU (or the slab is no whole number of tiles)";
+            const std::string cross = sl.active ? "one all-reduce of 4 doubles, and every " + std::to_string(std::max(1, sl.ghost - 1)) + " iterations " + std::to_string(2L * sl.ghost * rowBytes) +
+                                                  " B of edge rows (the two newest search directions) per neighbour" : std::string("none");
+            snprintf(buf, sizeof buf, "path=one launch per PCG iteration (iw_pcgIter2%s); why_not_on_chip=%s; slab_rows=%d; ghost_rows=%d; workgroup_cap=%s; per_iteration_cross_rank=%s",
+                     lmv ? ", LM" : "", why.c_str(), rowsOwned, sl.active ? sl.ghost : 0, cap.c_str(), cross.c_str());
+        }
         return buf;
     }
     bool onChipFailed() override {

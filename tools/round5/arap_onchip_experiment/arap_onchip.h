@@ -20,13 +20,13 @@
 // The arithmetic per half-edge pair is arap_applySym's, term for term (same association), with one lane per vertex walking its whole out-list.  Every wait is bounded by
 // the wall clock; a time-out raises `bad`, every workgroup leaves at its next sum, nothing is applied and the host redoes the step with the two-kernel loop.
 #pragma once
-#include "onchip_sync.h"
+#include "../../../opt_amd/csrc/onchip_sync.h"
 
 namespace optamd {
 namespace {
 
 constexpr int kAoBlock = 512, kAoWaves = kAoBlock / kWave, kAoMaxGrid = 256;
-constexpr int kAoHaloCap = 3072, kAoHaloPerThread = kAoHaloCap / kAoBlock;      // remote vertices a workgroup may depend on (a 708-wide mesh row-major: ~1420)
+constexpr int kAoHaloCap = 1024, kAoHaloPerThread = kAoHaloCap / kAoBlock;      // remote vertices a workgroup may depend on (chunks of 2048 vertices in Morton order of the rest positions: a few hundred on a mesh)
 typedef unsigned int ao_u4 __attribute__((ext_vector_type(4)));
 
 struct ArapOnchipSync { oc_u64* slots; int* bad; int* hostErr; };      // slots: [2][G][8]
@@ -36,7 +36,9 @@ struct ArapOnchipArgs {
     const int* outOff; const ArapSlot<T>* slots; const ArapRec<T>* rec;      // rec: only the sines / cosines (floats 6 .. 11 of a record) are read
     const void* aoSlots;                                                      // AoSlot<T> per half-edge slot (ao_buildSlots)
     const int* haloList; const int* haloCount; const unsigned char* boundary; // [chunks][kAoHaloCap] remote vertices a chunk reads; their number; per vertex: some other chunk reads it
-    const T* r0; const T* p0; const T* M;                                     // solver layout: [O.xyz] x N, then [a.xyz] x N
+    const int* perm;                                                          // position -> vertex: the vertices in Morton order of their rest positions (a chunk = kAoBlock * VPT consecutive positions)
+    const T* r0; const T* p0; const T* diag;                                  // solver layout: [O.xyz] x N, then [a.xyz] x N; diag = raw diag(J^T J): M = guardedInvert(diag) (k_initFinish)
+    long long* prof;                                                          // [G][8] ticks per phase (development), or nullptr
     T* delta;                                                                 // in: 0 (PCGInit1); out: sum alpha_k p_k
     T* XO; T* XA;                                                             // the unknowns: X += delta at the end (PCGLinearUpdate, solver.t:552-557)
     ao_u4* gran;                                                              // [2][N][3]: a boundary vertex's published search direction, {p.x, tag, p.y, tag} {p.z, tag, pa.x, tag} {pa.y, tag, pa.z, tag}
@@ -46,6 +48,7 @@ struct ArapOnchipArgs {
     long long timeoutTicks; int failAt;
 };
 
+template <class T> __device__ __forceinline__ T aoGi(T x) { const T sq = T(1) + sqrt(x); return T(1) / (sq * sq); }      // guardedInvert (solver.t:323-332)
 __device__ __forceinline__ ao_u4 aoLoad(__amdgpu_buffer_rsrc_t rs, unsigned byteOff) { return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byteOff, 0, /*aux: sc1*/ 16); }
 __device__ __forceinline__ void aoStore(__amdgpu_buffer_rsrc_t rs, unsigned byteOff, float a, float b, unsigned tag) {
     __builtin_amdgcn_raw_buffer_store_b128(ao_u4{__float_as_uint(a), tag, __float_as_uint(b), tag}, rs, (int)byteOff, 0, /*aux: sc1*/ 16);
@@ -53,22 +56,51 @@ __device__ __forceinline__ void aoStore(__amdgpu_buffer_rsrc_t rs, unsigned byte
 // which chunk of NV consecutive vertices workgroup g owns: workgroup g runs on XCD g % 8 and takes the (g / 8)-th chunk of that XCD's contiguous eighth of the chunks
 __host__ __device__ inline long aoChunkOf(int g, int G) { return (long)(g % 8) * (G / 8) + g / 8; }
 
+// ---- once per graph: the vertices in Morton order of their rest positions, so that a chunk of consecutive positions is a compact patch of the mesh (a chunk of a mesh
+// in its file's vertex order is a strip of whole rows: 70 % of its vertices then have a neighbour in another chunk, and the exchange costs 18-28 us per iteration) ----
+__device__ __forceinline__ unsigned aoOrdered(float x) { const unsigned f = __float_as_uint(x); return f ^ ((f >> 31) ? 0xffffffffu : 0x80000000u); }
+__device__ __forceinline__ float aoUnordered(unsigned o) { return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xffffffffu)); }
+template <class T>
+__global__ __launch_bounds__(kBlock) void ao_bbox(long N, const T* __restrict__ U, unsigned* __restrict__ mm) {      // mm[0..2] = min, mm[3..5] = max (ordered encoding)
+    unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0, 0, 0};
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x)
+        for (int c = 0; c < 3; ++c) { const unsigned o = aoOrdered((float)U[3 * i + c]); lo[c] = min(lo[c], o); hi[c] = max(hi[c], o); }
+    for (int c = 0; c < 3; ++c) { atomicMin(mm + c, lo[c]); atomicMax(mm + 3 + c, hi[c]); }
+}
+__device__ __forceinline__ unsigned aoSpread10(unsigned v) { v &= 1023u; v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u; return v; }
+template <class T>
+__global__ __launch_bounds__(kBlock) void ao_mortonKeys(long N, const T* __restrict__ U, const unsigned* __restrict__ mm, unsigned* __restrict__ keys, int* __restrict__ ids) {
+    float lo[3], sc[3];
+    float ext = 0.f;      // ONE scale for the three axes (the largest extent): a nearly flat mesh must not spend Morton bits on its thickness
+    for (int c = 0; c < 3; ++c) { lo[c] = aoUnordered(mm[c]); ext = fmaxf(ext, aoUnordered(mm[3 + c]) - lo[c]); }
+    for (int c = 0; c < 3; ++c) sc[c] = ext > 0.f ? 1023.f / ext : 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+        unsigned q[3];
+        for (int c = 0; c < 3; ++c) q[c] = (unsigned)fminf(1023.f, fmaxf(0.f, ((float)U[3 * i + c] - lo[c]) * sc[c]));
+        keys[i] = aoSpread10(q[0]) | (aoSpread10(q[1]) << 1) | (aoSpread10(q[2]) << 2);
+        ids[i] = (int)i;
+    }
+}
+__global__ __launch_bounds__(kBlock) void ao_invert(long N, const int* __restrict__ perm, int* __restrict__ inv) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) inv[perm[i]] = (int)i;
+}
+
 // ---- once per graph: who reads whom across chunks ---------------------------------------------------------------------------------------------------------------
 // Pass 1, per vertex u: for every chunk other than its own that holds a neighbour of u, u joins that chunk's halo list (once); posIn[k] = u's position in the halo
 // list of the chunk of slot k's neighbour (or -1 if that neighbour is in u's own chunk).  The order inside a list is whatever the atomics give: it only decides where a
 // value sits in LDS.
 template <class T>
-__global__ __launch_bounds__(kBlock) void ao_buildHalo(long N, int NV, const int* __restrict__ outOff, const ArapSlot<T>* __restrict__ slots, int* __restrict__ haloCount,
+__global__ __launch_bounds__(kBlock) void ao_buildHalo(long N, int NV, const int* __restrict__ inv, const int* __restrict__ outOff, const ArapSlot<T>* __restrict__ slots, int* __restrict__ haloCount,
                                                        int* __restrict__ haloList, int* __restrict__ posIn, unsigned char* __restrict__ boundary) {
     for (long u = blockIdx.x * (long)blockDim.x + threadIdx.x; u < N; u += (long)gridDim.x * blockDim.x) {
-        const int cu = (int)(u / NV), bo = outOff[u], eo = outOff[u + 1];
+        const int cu = inv[u] / NV, bo = outOff[u], eo = outOff[u + 1];
         bool any = false;
         for (int k = bo; k < eo; ++k) {
-            const int cv = slots[k].nbr / NV;
+            const int cv = inv[slots[k].nbr] / NV;
             int pos = -1;
             if (cv != cu) {
                 any = true;
-                for (int k2 = bo; k2 < k && pos < 0; ++k2) if (slots[k2].nbr / NV == cv) pos = posIn[k2];      // (this thread wrote it a moment ago)
+                for (int k2 = bo; k2 < k && pos < 0; ++k2) if (inv[slots[k2].nbr] / NV == cv) pos = posIn[k2];      // (this thread wrote it a moment ago)
                 if (pos < 0) { pos = atomicAdd(haloCount + cv, 1); if (pos < kAoHaloCap) haloList[(long)cv * kAoHaloCap + pos] = (int)u; }
             }
             posIn[k] = pos;
@@ -79,13 +111,13 @@ __global__ __launch_bounds__(kBlock) void ao_buildHalo(long N, int NV, const int
 // Pass 2, per slot (v -> u): the LDS index of u's search direction in v's workgroup: u - first vertex of the chunk, or NV + u's position in the chunk's halo list
 // (found through the reverse slot (u -> v): the graph is symmetric).
 template <class T>
-__global__ __launch_bounds__(kBlock) void ao_buildIndex(long N, int NV, const int* __restrict__ outOff, const ArapSlot<T>* __restrict__ slots, const int* __restrict__ posIn, int* __restrict__ sidx) {
+__global__ __launch_bounds__(kBlock) void ao_buildIndex(long N, int NV, const int* __restrict__ inv, const int* __restrict__ outOff, const ArapSlot<T>* __restrict__ slots, const int* __restrict__ posIn, int* __restrict__ sidx) {
     for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < N; v += (long)gridDim.x * blockDim.x) {
-        const int cv = (int)(v / NV);
+        const int cv = inv[v] / NV;
         for (int k = outOff[v]; k < outOff[v + 1]; ++k) {
             const int u = slots[k].nbr;
             int idx;
-            if (u / NV == cv) idx = u - cv * NV;
+            if (inv[u] / NV == cv) idx = inv[u] - cv * NV;
             else {
                 idx = -1;
                 for (int k2 = outOff[u]; k2 < outOff[u + 1] && idx < 0; ++k2) if (slots[k2].nbr == (int)v) idx = NV + posIn[k2];
@@ -132,11 +164,13 @@ __global__ __launch_bounds__(kAoBlock, 2) void arap_onchipPcg(ArapOnchipArgs<T> 
 
     T p[VPT][6], r[VPT][6], ap[VPT][6], wf2[VPT];
     bool ok[VPT], pub[VPT];
+    int vid[VPT];      // the vertices this thread owns (positions base + j * 512 + tid of the Morton order)
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
-        const long i = base + (long)j * kAoBlock + tid;
-        ok[j] = i < N;
-        const long iv = ok[j] ? i : 0;
+        const long pos = base + (long)j * kAoBlock + tid;
+        ok[j] = pos < N;
+        vid[j] = ok[j] ? K.perm[pos] : 0;
+        const long iv = vid[j];
         const V3<T> po = ld3(K.p0, iv), pa = ld3(K.p0 + offA, iv), ro = ld3(K.r0, iv), ra = ld3(K.r0 + offA, iv);
         p[j][0] = po.x; p[j][1] = po.y; p[j][2] = po.z; p[j][3] = pa.x; p[j][4] = pa.y; p[j][5] = pa.z;
         r[j][0] = ro.x; r[j][1] = ro.y; r[j][2] = ro.z; r[j][3] = ra.x; r[j][4] = ra.y; r[j][5] = ra.z;
@@ -158,7 +192,7 @@ __global__ __launch_bounds__(kAoBlock, 2) void arap_onchipPcg(ArapOnchipArgs<T> 
 #pragma unroll
             for (int c = 0; c < 6; ++c) pL[c * NL + lj] = p[j][c];
             if (pub[j]) {
-                const long i = base + lj;
+                const long i = vid[j];
                 const unsigned off = (unsigned)((((long)(tag & 1u) * N + i) * 3) * 16);
                 aoStore(gr, off, p[j][0], p[j][1], tag); aoStore(gr, off + 16, p[j][2], p[j][3], tag); aoStore(gr, off + 32, p[j][4], p[j][5], tag);
             }
@@ -204,6 +238,8 @@ __global__ __launch_bounds__(kAoBlock, 2) void arap_onchipPcg(ArapOnchipArgs<T> 
     __syncthreads();
 
     bool failed = false;
+    long long tPh[6] = {0, 0, 0, 0, 0, 0}, tPrev = wall_clock64();
+#define AO_MARK(i) do { if (K.prof && tid == 0) { const long long t_ = wall_clock64(); tPh[i] += t_ - tPrev; tPrev = t_; } } while (0)
     for (int k = 0; k < K.L; ++k) {
         const unsigned tag = K.tag0 + (unsigned)k;
         if (k == K.failAt && g == 0 && tid == 0) __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -211,8 +247,8 @@ __global__ __launch_bounds__(kAoBlock, 2) void arap_onchipPcg(ArapOnchipArgs<T> 
         double accDen = 0, accNum = 0, acc2 = 0, acc3 = 0;
 #pragma unroll
         for (int j = 0; j < VPT; ++j) {
-            const long i = base + (long)j * kAoBlock + tid;
-            const long iv = ok[j] ? i : 0;
+            const long i = vid[j];
+            const long iv = i;
             const ao_u4* const mine = reinterpret_cast<const ao_u4*>(K.rec + iv);
             const ao_u4 t1 = mine[1], t2 = mine[2];      // {ay, az, sa, ca} {sb, cb, sg, cg}
             const ArapCoef<T> cv = arap_coef(__uint_as_float(t1.z), __uint_as_float(t1.w), __uint_as_float(t2.x), __uint_as_float(t2.y), __uint_as_float(t2.z), __uint_as_float(t2.w));
@@ -256,8 +292,8 @@ __global__ __launch_bounds__(kAoBlock, 2) void arap_onchipPcg(ArapOnchipArgs<T> 
                 accDen += (double)(dot3(pv, q) + T(0));
                 const V3<T> oO{q.x + s0, q.y + s1, q.z + s2}, oA{T(0) + s3, T(0) + s4, T(0) + s5};
                 ap[j][0] = oO.x; ap[j][1] = oO.y; ap[j][2] = oO.z; ap[j][3] = oA.x; ap[j][4] = oA.y; ap[j][5] = oA.z;
-                const V3<T> mO = ld3(K.M, i), mA = ld3(K.M + offA, i);
-                const T m[6] = {mO.x, mO.y, mO.z, mA.x, mA.y, mA.z};
+                const V3<T> dgO = ld3(K.diag, i), dgA = ld3(K.diag + offA, i);
+                const T m[6] = {aoGi(dgO.x), aoGi(dgO.y), aoGi(dgO.z), aoGi(dgA.x), aoGi(dgA.y), aoGi(dgA.z)};
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {      // the expansion sums of arap_applySym: exact double products of M, r, A p
                     accNum += arap_dprod3(m[c], r[j][c], r[j][c]);
@@ -269,6 +305,7 @@ __global__ __launch_bounds__(kAoBlock, 2) void arap_onchipPcg(ArapOnchipArgs<T> 
                 for (int c = 0; c < 6; ++c) ap[j][c] = 0;
             }
         }
+        AO_MARK(0);      // gather
         // ---- the grid-wide sums: every workgroup posts, every workgroup reads all and adds in workgroup order -------------------------------------------------
         {
             double v4[4] = {accNum, accDen, acc2, acc3};
@@ -312,6 +349,7 @@ __global__ __launch_bounds__(kAoBlock, 2) void arap_onchipPcg(ArapOnchipArgs<T> 
             if (tid == 0) badL = __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
         }
+        AO_MARK(1);      // sums (incl. waiting for the slowest workgroup's gather)
         const double aNumD = GS[0], aDenD = GS[1], sum2 = GS[2], sum3 = GS[3];
         if (badL) { failed = true; break; }
         if (K.trace && g == 0 && tid == 0) { K.trace[4 * k] = aNumD; K.trace[4 * k + 1] = aDenD; K.trace[4 * k + 2] = sum2; K.trace[4 * k + 3] = sum3; }
@@ -324,7 +362,7 @@ __global__ __launch_bounds__(kAoBlock, 2) void arap_onchipPcg(ArapOnchipArgs<T> 
 #pragma unroll
         for (int j = 0; j < VPT; ++j) {
             if (!ok[j]) continue;
-            const long i = base + (long)j * kAoBlock + tid;
+            const long i = vid[j];
             V3<T> dO = ld3(K.delta, i), dA = ld3(K.delta + offA, i);
             dO.x = dO.x + alpha * p[j][0]; dO.y = dO.y + alpha * p[j][1]; dO.z = dO.z + alpha * p[j][2];
             dA.x = dA.x + alpha * p[j][3]; dA.y = dA.y + alpha * p[j][4]; dA.z = dA.z + alpha * p[j][5];
@@ -335,8 +373,8 @@ __global__ __launch_bounds__(kAoBlock, 2) void arap_onchipPcg(ArapOnchipArgs<T> 
                 K.XA[3 * i] += dA.x; K.XA[3 * i + 1] += dA.y; K.XA[3 * i + 2] += dA.z;
                 continue;
             }
-            const V3<T> mO = ld3(K.M, i), mA = ld3(K.M + offA, i);
-            const T m[6] = {mO.x, mO.y, mO.z, mA.x, mA.y, mA.z};
+            const V3<T> dgO = ld3(K.diag, i), dgA = ld3(K.diag + offA, i);
+            const T m[6] = {aoGi(dgO.x), aoGi(dgO.y), aoGi(dgO.z), aoGi(dgA.x), aoGi(dgA.y), aoGi(dgA.z)};
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 const T rn = r[j][c] - alpha * ap[j][c];
@@ -345,13 +383,18 @@ __global__ __launch_bounds__(kAoBlock, 2) void arap_onchipPcg(ArapOnchipArgs<T> 
                 p[j][c] = z + beta * p[j][c];
             }
         }
+        AO_MARK(2);      // update
         if (!last) {      // (every wave of the workgroup is past its gather: the sums' barriers lie in between)
             shareAndPublish(tag + 1u);
+            AO_MARK(3);      // share + publish
             fetchHalo(tag + 1u);
+            AO_MARK(4);      // halo fetch
             __syncthreads();
+            AO_MARK(5);      // barrier
         }
     }
     (void)failed;
+    if (K.prof && tid == 0) for (int q = 0; q < 6; ++q) K.prof[(long)g * 8 + q] = tPh[q];
 }
 
 // Behind the persistent launch: tell the host if a wait timed out (then nothing was applied: every workgroup left before its last iteration).
