@@ -586,6 +586,25 @@ def main():
         ddt = max_over_ranks(time.perf_counter() - t1)
         solve["reference_default_10x10"] = {"solve_ms": ddt * 1e3, "ms_per_gn_step": ddt * 1e2, "pcg_iters_per_s": 100 / ddt, "final_energy": solver.cost()}
         solver.set_parameter("lIterations", args.liters)
+        if not distributed:      # the same default shape at the reference's own image size (512^2: the linear solve runs on chip, the once-per-step launches weigh as much as it does)
+            P5 = wl.image_warping(512, 512)
+            d5 = api.to_device(P5)
+            for kind in ("gaussNewtonGPU", "LMGPU"):
+                s5 = api.Solver(api.energy_file("image_warping"), kind, (512, 512))
+                s5.set_parameter("nIterations", 10); s5.set_parameter("lIterations", 10)
+                for slot in P5.unknown_slots:
+                    d5[slot].copy_(torch.from_numpy(P5.params[slot]))
+                s5.solve(d5)      # warm-up (allocations, occupancy queries)
+                for slot in P5.unknown_slots:
+                    d5[slot].copy_(torch.from_numpy(P5.params[slot]))
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                s5.solve(d5)
+                torch.cuda.synchronize()
+                t5 = time.perf_counter() - t1
+                solve["reference_default_10x10_512_" + ("gn" if kind == "gaussNewtonGPU" else "lm")] = {"solve_ms": t5 * 1e3, "ms_per_outer_step": t5 * 1e2, "final_energy": s5.cost(), "on_chip_status": s5.on_chip_status()}
+                s5.close()
+            del d5
 
     # ---- the general kernel (arbitrary UrShape: + U, 61 B/pixel; M_a rebuilt from the pairs the stencil evaluates) on the same input ------
     general = None

@@ -99,6 +99,28 @@ def test_image_warping_example_flow(oracle_lib):
     os.remove(os.path.join(ROOT, "results_float.csv"))
 
 
+@pytest.mark.parametrize("path", ["onchip", "streaming"])
+def test_image_warping_reference_flow_against_frozen_runs(path):
+    """The reference's FULL default flow -- 512^2, 19 constraint passes x 8 x 400, Gauss-Newton and Levenberg-Marquardt in float (examples/image_warping/src/main.cpp:110-134) --
+    through the C++ caller, on both HIP paths (the on-chip linear solve and the launch-per-iteration kernels), against the frozen oracle runs of the same flow
+    (tests/golden/reference_flow_costs.json: exact-order sums + reference-order seeds, each a legal run of the reference's arithmetic; make_reference_flow.py, ~20 min of host
+    time per run).  60 800 float PCG iterations: the frozen runs themselves end 0.8 % (GN) and 3 % (LM) apart, so the bar is their range widened by one diameter on either side
+    -- with n frozen runs a further legal run falls outside their range with probability 2 / (n + 1), and one diameter is the scale of that excursion."""
+    import json
+    G = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_flow_costs.json")))
+    r = _run("image_warping_example", 512, 19, 8, 400, timeout=600, env={} if path == "onchip" else {"OPT_AMD_ONCHIP": "0"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    gn, lm = _final_costs(r.stdout)
+    for kind, got in (("gaussNewtonGPU", gn), ("LMGPU", lm)):
+        runs = sorted(c[-1] for c in G[f"image_warping_512_float_{kind}_19x8x400"]["costs_by_seed"].values())
+        assert len(runs) >= 2, "freeze at least two runs (tests/golden/make_reference_flow.py)"
+        lo, hi = runs[0], runs[-1]
+        d = hi - lo
+        print(f"{path} {kind}: hip {got:.4f}, {len(runs)} frozen runs in [{lo:.4f}, {hi:.4f}] (diameter {d / lo:.2e})")
+        assert lo - d <= got <= hi + d, (path, kind, got, runs)
+    os.remove(os.path.join(ROOT, "results_float.csv"))
+
+
 def test_poisson_example_flow(oracle_lib, tmp_path):
     """The caller's final costs (GN and LM, 1 x 60 on a 256 x 192 image) against the oracle run on the caller's own arrays (dumped by the example)."""
     import numpy as np
