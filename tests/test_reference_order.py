@@ -129,7 +129,8 @@ def test_verdict_logic():
     key = "horizon_2048_float_400"
     a, y = rs.anchor(key), rs.yardstick(key, "float")
     assert rs.verdict(key, "float", a)["within_reference_spread"] and rs.verdict(key, "float", a)["within_contract"]
-    v = rs.verdict(key, "float", a * (1 + 1.9 * y))
+    v = rs.verdict(key, "float", a * (1 + 0.95 * rs.FACTOR * y))
     assert v["within_reference_spread"] and not v["within_contract"]
-    assert not rs.verdict(key, "float", a * (1 + 2.1 * y))["within_reference_spread"]
+    assert not rs.verdict(key, "float", a * (1 + 1.05 * rs.FACTOR * y))["within_reference_spread"]
+    assert rs.FACTOR == 1.0      # round 5: no allowance on top of the diameter of the legal runs (round 4: 2)
     assert rs.verdict("no_such_key", "float", 1.0) is None
