@@ -77,7 +77,7 @@ struct LmInitArgs {
 
 // Levenberg-Marquardt controls of EnergyOps::pcgSolveOnChip: the scalars of PCGFinalizeDiagonal (solver.t:631-664), q_tolerance and residual_reset_period (:1077-1102).
 template <class T>
-struct OnChipLm { T radius, minLm, maxLm, qTolerance; int resetPeriod; };
+struct OnChipLm { T radius, minLm, maxLm, qTolerance; int resetPeriod; const T* CtC = nullptr; };      // CtC: the clamped diagonal PCGFinalizeDiagonal has just written (energies whose kernel does not rebuild it from a table)
 
 // Everything the solver needs from an energy.  T = opt_float (float or double).
 // Contract shared by all implementations:
@@ -142,6 +142,8 @@ struct EnergyOps {
     // lm != nullptr: the Levenberg-Marquardt loop instead (A = J^T J + diag(CtC), the q early-out decided on chip, the split residual reset as a second stencil pass;
     // r0 = b and p0 as PCGFinalizeDiagonal left them).  Then the kernel only produces delta: the solver applies savePreviousUnknowns + PCGLinearUpdate itself.
     virtual bool pcgSolveOnChip(const T* /*r0*/, const T* /*p0*/, T* /*delta*/, int /*lIterations*/, double* /*traceDev*/, const OnChipLm<T>* /*lm*/, LaunchCtx&) { return false; }
+    // an energy that does not precondition (UsePreconditioner(false): no preconditioner vector exists) but offers pcgSolveOnChip all the same
+    virtual bool onChipWithoutPreconditioner() const { return false; }
     // Row slabs: would pcgSolveOnChip run for this rank's slab right now (kernel variant fits, unit lattice, the communicator offers onChipPlan ...)?  The solver
     // makes the decision collective (all ranks or none) before anyone launches.  onChipPlan / onChipCtx: the communicator's entry (OptAmd_SlabCommExt), set by the solver.
     virtual bool slabOnChipAvailable(int /*lIterations*/) { return false; }

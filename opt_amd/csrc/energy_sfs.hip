@@ -612,6 +612,12 @@ __global__ __launch_bounds__(kSfsMarchBlock) void sfs_costMarch(SArgs<T> A, cons
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
+}  // namespace
+}  // namespace optamd
+#include "sfs_onchip.h"
+namespace optamd {
+namespace {
+
 template <class T>
 struct SfsOps : EnergyOps<T> {
     SArgs<T> A{};
@@ -630,8 +636,12 @@ struct SfsOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_SFS_ONEKERNEL")) oneKernel = atoi(e) != 0;
         gridOverride = devSwitch("OPT_AMD_SFS_GRID", gridOverride);
         if (const char* e = getenv("OPT_AMD_SFS_MARCH_GRID")) marchGridOverride = atoi(e);
+        if (const char* e = getenv("OPT_AMD_ONCHIP")) soEnabled = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_ONCHIP_ROWS")) soForceRows = std::max(0, atoi(e));
+        if (const char* e = getenv("OPT_AMD_ONCHIP_FAIL_AT")) soFailAt = atoi(e);      // test hook: see SfsOcArgs::failAt
+        if (const char* e = getenv("OPT_AMD_ONCHIP_TIMEOUT_MS")) soTimeoutTicks = std::max(1, atoi(e)) * 100000LL;
     }
-    ~SfsOps() override { for (void* p : owned) (void)hipFree(p); }
+    ~SfsOps() override { for (void* p : owned) (void)hipFree(p); if (soHostErr) (void)hipHostFree(soHostErr); }
     int grid() const { return (int)std::max<long>(1, std::min<long>(((long)A.W * A.H + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
     void bind(void** p, LaunchCtx&) override {
         // sqrt(Param(...)) is evaluated in opt_float on the float parameter (shape_from_shading.t:4-6)
@@ -737,6 +747,88 @@ struct SfsOps : EnergyOps<T> {
         a.aNum->n = a.aDen->n = a.s2->n = a.s3->n = g;
         if (a.q) a.q->n = g;
         return true;
+    }
+
+    // ---- the whole linear solve on chip (sfs_onchip.h): Gauss-Newton or Levenberg-Marquardt, one GPU, workgroups <= CUs ---------------------------------------------
+    // OPT_AMD_ONCHIP=0 switches it off (the one A/B switch of the path); OPT_AMD_ONCHIP_ROWS=r forces the variant that owns r rows per wave (tests run every variant
+    // on small images); OPT_AMD_ONCHIP_FAIL_AT / _TIMEOUT_MS: the time-out path's test hooks.
+    struct SoVariant { int rows; const void* gn; const void* lm; };
+    bool soEnabled = true, soFailed = false, soLaunched = false;
+    int soForceRows = 0, soFailAt = -1; long long soTimeoutTicks = 2000LL * 100000;      // 2 s of the 100 MHz wall clock
+    oc_u64 *soSlots = nullptr, *soBox = nullptr; int *soBad = nullptr, *soHostErr = nullptr; unsigned soSeq = 0; size_t soSlotBytes = 0, soBoxBytes = 0;
+    static const std::vector<SoVariant>& soVariants() {
+        static const std::vector<SoVariant> v = [] {
+            std::vector<SoVariant> o;
+#define SO_VARIANT(R) o.push_back({R, (const void*)sfs_onchipPcg<T, R, false>, (const void*)sfs_onchipPcg<T, R, true>})
+            SO_VARIANT(4); SO_VARIANT(6); SO_VARIANT(8); SO_VARIANT(10);
+#undef SO_VARIANT
+            return o;
+        }();
+        return v;
+    }
+    // Which variant, if any: the fewest rows per wave whose workgroups fit one per CU (fewer rows: less serial work per wave, more of it redundant ring work).
+    const SoVariant* soSelect(int& stripsX, int& tilesY, int& G) const {
+        stripsX = divUp(A.W, kSoSpan);
+        for (const auto& v : soVariants()) {
+            if (soForceRows && v.rows != soForceRows) continue;
+            tilesY = divUp(A.H, v.rows);
+            G = divUp(stripsX * tilesY, kSoWaves);
+            if (G <= std::min(cus, kSoMaxG)) return &v;
+        }
+        return nullptr;
+    }
+    bool onChipWithoutPreconditioner() const override { return true; }
+    bool pcgSolveOnChip(const T* r0, const T* p0, T* delta, int L, double* traceDev, const OnChipLm<T>* lmArgs, LaunchCtx& ctx) override {
+        if (!soEnabled || soFailed || this->slab.active || traceDev || L <= 0 || (unsigned long long)A.W * A.H * sizeof(T) >= (1ull << 30)) return false;
+        if (lmArgs && (!lmArgs->CtC || lmArgs->resetPeriod < L)) return false;      // a split residual reset before the last iteration: the marching loop's business
+        int stripsX = 0, tilesY = 0, G = 0;
+        const SoVariant* V = soSelect(stripsX, tilesY, G);
+        if (!V) return false;
+        if (!soSlots) {      // sized for this plan's image once (the dimensions of a plan are fixed); zero = no tag
+            soSlotBytes = sizeof(oc_u64) * 2 * (size_t)kSoMaxG * kSoNW; soBoxBytes = sizeof(oc_u64) * 2 * (size_t)A.W * A.H * (sizeof(T) / 4);
+            HIP_CHECK(hipMalloc((void**)&soSlots, soSlotBytes)); owned.push_back(soSlots);
+            HIP_CHECK(hipMalloc((void**)&soBox, soBoxBytes)); owned.push_back(soBox);
+            HIP_CHECK(hipMalloc((void**)&soBad, sizeof(int))); owned.push_back(soBad);
+            HIP_CHECK(hipHostMalloc((void**)&soHostErr, 64)); *soHostErr = 0;
+            HIP_CHECK(hipMemsetAsync(soBad, 0, sizeof(int), ctx.stream));
+            soSeq = 0xE0000001u;      // forces the clearing below
+        }
+        if (soSeq > 0xE0000000u || soSeq + (unsigned)L > 0xE0000000u) {      // tags never repeat: start over on cleared buffers long before the counter wraps
+            HIP_CHECK(hipMemsetAsync(soSlots, 0, soSlotBytes, ctx.stream)); HIP_CHECK(hipMemsetAsync(soBox, 0, soBoxBytes, ctx.stream));
+            soSeq = 2;
+        }
+        SfsOcArgs<T> K{A, r0, p0, lmArgs ? lmArgs->CtC : nullptr, delta, stripsX, tilesY, G, L, soSeq, soSlots, soBox, soBad, soTimeoutTicks, soFailAt, lmArgs ? lmArgs->qTolerance : T(0)};
+        soSeq += (unsigned)L;
+        {
+            ScopedKernel k(ctx, "PCGSolveOnChip");
+            void* kargs[] = {(void*)&K};
+            HIP_CHECK(hipLaunchKernel(lmArgs ? V->lm : V->gn, dim3(G), dim3(kSoBlock), kargs, 0, ctx.stream));
+        }
+        if (lmArgs) sfs_relayBad<<<1, kWave, 0, ctx.stream>>>(soBad, soHostErr);      // (the solver applies the update itself)
+        else {
+            ScopedKernel k(ctx, "PCGLinearUpdate");
+            const long N = (long)A.W * A.H;
+            sfs_applyDelta<T><<<grid(), kBlock, 0, ctx.stream>>>(const_cast<T*>(A.X), delta, N, soBad, soHostErr);
+        }
+        soLaunched = true;
+        return true;
+    }
+    bool onChipFailed() override {
+        if (!soLaunched) return false;
+        soLaunched = false;
+        if (__atomic_load_n(soHostErr, __ATOMIC_ACQUIRE) == 0) return false;
+        soFailed = true;
+        return true;
+    }
+    std::string describe(int L, bool lmv) override {      // ("key=value; ..." -- no ';' inside a value)
+        int stripsX = 0, tilesY = 0, G = 0;
+        const SoVariant* V = (soEnabled && !soFailed && !this->slab.active && L > 0) ? soSelect(stripsX, tilesY, G) : nullptr;
+        char buf[600];
+        if (V) snprintf(buf, sizeof buf, "path=on-chip (sfs_onchipPcg%s%s); onchip_rows_per_wave=%d; wave_tiles=%dx%d of 60 x %d pixels; workgroups=%d of %d CUs; fallback=one launch per PCG iteration (sfs_pcgMarch)",
+                        lmv ? ", LM" : "", lmv ? " while lIterations <= residual_reset_period" : "", V->rows, stripsX, tilesY, V->rows, G, cus);
+        else snprintf(buf, sizeof buf, "path=one launch per PCG iteration (sfs_pcgMarch%s); why_not_on_chip=%s", lmv ? ", LM" : "",
+                      !soEnabled ? "switched off" : soFailed ? "a wait timed out earlier" : this->slab.active ? "row slabs" : "the wave tiles do not fit 8 per CU");
+        return buf;
     }
 };
 

@@ -1,0 +1,363 @@
+// shape_from_shading: the WHOLE PCG linear solve of one Gauss-Newton / Levenberg-Marquardt step as one persistent launch whose loop state never leaves the chip.
+//
+// Included by energy_sfs.hip behind the marching kernels (host side: SfsOps::pcgSolveOnChip).  What it replaces: the reference's loop
+// `for lIter = 0, lIterations do PCGStep1; PCGStep2; PCGStep3 end` (solverGPUGaussNewton.t:1056-1103) -- three launches and two same-address-atomic sums per
+// iteration there, one marching launch per iteration in sfs_pcgMarch -- for images whose loop state fits the register files (the reference's own input is
+// 640 x 480, examples/shape_from_shading/src/main.cpp:27-38; BASELINE config 3 is 1024^2).  Same protocol as iw_onchip.h, re-cut for a 5 x 5 coupling:
+//   tile    a WAVE holds 64 columns x (R + 4) rows of p and r in registers and owns the 60 x R pixels in the middle: the two-pixel ring around them is held as well
+//           and updated by the holder with the same alpha, beta and the same fused operations as by its owner, so the new search direction never travels;
+//   march   A p of the owned pixels is one pass over the R + 4 held rows with the expressions of sfs_pcgMarch (row values of the centres of row Y - 1, gather of
+//           row Y - 2; DPP shifts for the neighbouring columns); what is constant over the solve (dB_I / d{d0, d1, d2}, the flag word, CtC, b) is re-read per
+//           iteration through the caches (read-only, never written while the kernel runs);
+//   ring    the A p of a tile's two outermost rows / columns goes to a tagged image (one 8-byte {payload, tag} word per float, two per double; relaxed agent-scope
+//           stores, no fence), double-buffered by the parity of the iteration; the ring holders pick their pixels' words up INSIDE the wait for the sums;
+//   sums    five per iteration (alphaNum, alphaDen, s2, s3 and -- iteration 0 -- sum r^2 / -- later -- Q of the iteration before): every workgroup posts its
+//           partial sums as tagged words and adds ALL workgroups' words in workgroup order: the same bits everywhere, so alpha, beta and the q early-out
+//           (solver.t:1093-1102) agree on the whole grid without a broadcast.  One grid-wide wait per iteration.
+// Levenberg-Marquardt: + CtC p (o.t:2076-2082); Q_k = 1/2 sum delta . (r + b) (:483-485) is formed where iteration k is applied and travels with the sums of
+// iteration k + 1 -- exactly the hand-over of the launch-per-iteration loop (solver.hip runSingleKernelLoopLM), so an early-out leaves the reference's delta.
+// A split residual reset in the MIDDLE of a linear solve (lIterations > residual_reset_period) is not offered: the host keeps such solves on sfs_pcgMarch.
+// Every wait is bounded by the device's wall clock; a time-out raises `bad`, every workgroup leaves the loop at its next sum, nothing is written to delta and the
+// host redoes the linear solve with the marching kernels.  The grid must be co-resident (one workgroup per CU): the launcher checks workgroups <= CUs.
+#pragma once
+#include "onchip_sync.h"
+
+namespace optamd {
+namespace {
+
+constexpr int kSoBlock = 512, kSoWaves = kSoBlock / kWave, kSoSpan = kWave - 4;
+constexpr int kSoMaxG = 256;                  // workgroups (one per CU)
+constexpr int kSoNS = 5, kSoNW = 2 * kSoNS;   // sums per iteration; tagged words per workgroup
+
+template <class T>
+struct SfsOcArgs {
+    SArgs<T> A;
+    const T* r0; const T* p0;           // b = r_0 (solver.t:657)
+    const T* CtC;                       // LM
+    T* delta;                           // out: sum alpha_k p_k (untouched if a wait timed out)
+    int stripsX, tilesY, G, L;
+    unsigned tag0;                      // tag of iteration 0 (tags never repeat over the life of the buffers)
+    oc_u64* slots;                      // [2][G][10]
+    oc_u64* apBox;                      // [2][W * H * sizeof(T) / 4]
+    int* bad; long long timeoutTicks; int failAt;
+    T qTolerance;
+};
+
+template <class T> struct SoRowC { T g0, g1, g2, ctc; int fb; };
+
+__device__ __forceinline__ float soFma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double soFma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+template <class T, int R, bool LM>
+__global__ __launch_bounds__(kSoBlock) void sfs_onchipPcg(SfsOcArgs<T> K) {
+    constexpr int HR = R + 4;                          // held rows: two above and two below the R owned ones
+    constexpr int WPS = (int)sizeof(T) / 4;            // tagged words per scalar
+    static_assert(R >= 2, "the ring must come from the adjacent tiles only");
+    __shared__ double red[kSoNS * kSoWaves];
+    __shared__ double TOT[kSoNS + 1];
+    __shared__ unsigned W1[kSoMaxG * kSoNW];
+    const SArgs<T>& A = K.A;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = blockIdx.x;      // (wave: uniform, kept in a scalar register)
+    const int tile = g * kSoWaves + wave;
+    const int sx = tile % K.stripsX, ty = tile / K.stripsX;
+    const bool idle = ty >= K.tilesY;                  // (wave-uniform) a wave without a tile: contributes zeros to the sums
+    const int x = sx * kSoSpan + lane - 2;
+    int yBase = ty * R;                                // first owned row; held row h is image row yBase - 2 + h
+    const bool xin = !idle && x >= 0 && x < A.W;
+    const bool writer = xin && lane >= 2 && lane < 2 + kSoSpan;
+    int xc = min(max(x, 0), A.W - 1);
+    const int N = A.W * A.H;
+    int* const bad = K.bad;
+    const long long to = K.timeoutTicks;
+    const T cxc = coefK(A, 0, x, 0);
+
+    auto rowIn = [&](int h) { const int y = yBase - 2 + h; return xin && y >= 0 && y < A.H; };
+    auto rowIdx = [&](int h) { const int y = yBase - 2 + h; return (y >= 0 && y < A.H && !idle) ? y * A.W + xc : xc; };      // a valid address either way
+    auto uni = [](T v) -> T {
+        if constexpr (sizeof(T) == 8) return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+        else return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+    };
+
+    // ---- p_0, r_0 of the held pixels (zeros outside the image); delta = 0 ------------------------------------------------------------------------------------
+    T p[HR], r[HR], dl[R], apOwn[R];
+#pragma unroll
+    for (int h = 0; h < HR; ++h) {
+        const int i = rowIdx(h);
+        const T pv = K.p0[i], rv = K.r0[i];
+        const bool in = rowIn(h);
+        p[h] = in ? pv : T(0); r[h] = in ? rv : T(0);
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) { dl[i] = 0; apOwn[i] = 0; }
+
+    int pixBase = (yBase - 2) * A.W + xc;      // (opaque per iteration below: addresses are recomputed, not kept)
+    bool failed = false;
+    double accQ = 0;
+    T Q0 = 0;                                  // fetchQ before the loop (solver.t:1050): delta = 0, so exactly 0
+    const size_t boxStride = (size_t)N * WPS;
+
+    for (int k = 0; k < K.L; ++k) {
+        // What is derived from the tile's position (row addresses of six arrays, bounds predicates) is invariant over the solve; hoisted out of this loop it would occupy
+        // a hundred registers.  The empty asm makes the sources opaque per iteration, so each use recomputes its two or three instructions.
+        asm volatile("" : "+v"(pixBase), "+v"(xc), "+s"(yBase));
+        const unsigned tag = K.tag0 + (unsigned)k;
+        const int par = (int)(tag & 1u);
+        oc_u64* const box = K.apBox + (size_t)par * boxStride;
+        oc_u64* const slotPar = K.slots + (size_t)par * K.G * kSoNW;
+        if (k == K.failAt && g == 0 && tid == 0) __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool first = k == 0;
+
+        // ---- PCGStep1: A p_k on the owned pixels, with the sums (the expressions of sfs_pcgMarch, in its order) ------------------------------------------------
+        double acc = 0, accNum = 0, acc2 = 0, acc3 = 0, accX = 0;
+        if (!idle) {
+            auto loadRow = [&](int h) {
+                SoRowC<T> c;
+                const int i = rowIdx(h);
+                c.g0 = A.g0[i]; c.g1 = A.g1[i]; c.g2 = A.g2[i]; c.fb = (int)A.fl2[i];
+                c.ctc = (LM && h >= 2 && h < R + 2) ? K.CtC[i] : T(0);
+                return c;
+            };
+            SRow<T> R1{}, R2{}, R3{};
+            SQ<T> q2{}, q3{};
+            T b1 = 0, cy1 = 0, cy2 = 0;
+            SoRowC<T> cN = loadRow(0);
+#pragma unroll
+            for (int h = 0; h < HR; ++h) {
+                const SoRowC<T> c = cN;
+                if (h + 1 < HR) cN = loadRow(h + 1 < HR ? h + 1 : h);
+                const int Y = yBase - 2 + h;
+                SRow<T> n;
+                {
+                    const bool in = rowIn(h);
+                    n.v = p[h]; n.rk = r[h];
+                    n.g0 = in ? c.g0 : T(0); n.g1 = in ? c.g1 : T(0); n.g2 = in ? c.g2 : T(0); n.ctc = c.ctc;
+                    const bool ok = in && sfs_interior(A, x, Y);
+                    n.bits = (in ? (c.fb & kSfsEx) : 0) | (ok ? ((c.fb & (kSfsValid | 0xffff00)) | kSfsOk) : 0);
+                }
+                const T cyN = uni(coefK(A, 1, 0, Y));
+                // b(., Y) = g1 v + g0 v(x-1) + g2 v(y-1)                                      (d B_I(c) . v)
+                const T vL = dppShift<true>(n.v);
+                const T bY = n.g1 * n.v + n.g0 * vL + n.g2 * R1.v;
+                // row values at the centres of row Y - 1 (R1)
+                SQ<T> qn;
+                {
+                    const T right = dppShift<false>(b1);
+                    qn.gh = (R1.bits & kSfsOk) ? A.w_g * (T)sfsMr(R1.bits) * (b1 - right) : T(0);
+                    qn.gv = (R1.bits & kSfsOk) ? A.w_g * (T)sfsMc(R1.bits) * (b1 - bY) : T(0);
+                    const T v1l = dppShift<true>(R1.v), v1r = dppShift<false>(R1.v);
+                    const T cxl = dppShift<true>(cxc), cxr = dppShift<false>(cxc);
+                    T js[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const T c0 = q == 0 ? cxc : q == 1 ? cy1 : T(1), cl = q == 0 ? cxl : q == 1 ? cy1 : T(1), cu = q == 0 ? cxc : q == 1 ? cy2 : T(1),
+                                cr = q == 0 ? cxr : q == 1 ? cy1 : T(1), cd = q == 0 ? cxc : q == 1 ? cyN : T(1);
+                        T sj = 0;
+                        sj += (T(4) * c0) * R1.v; sj += (T(-1) * cl) * v1l; sj += (T(-1) * cu) * R2.v; sj += (T(-1) * cr) * v1r; sj += (T(-1) * cd) * n.v;
+                        js[q] = (R1.bits & kSfsValid) ? A.w_s * sj : T(0);
+                    }
+                    qn.s0 = js[0]; qn.s1 = js[1]; qn.s2 = js[2];
+                }
+                // gather of row y = Y - 2 (centre row R2; row values qn at y + 1, q2 at y, q3 at y - 1): held row h - 2, owned row h - 4
+                if (h >= 4) {
+                    const T ve = R2.v;
+                    T s = 0;
+                    auto add = [&](T coef, T q) { s += coef * q; };
+                    add(A.w_p, A.w_p * ve);      // the fitting row
+                    const T g0r = dppShift<false>(R2.g0);
+                    const int b2R = dppShift<false>(R2.bits), b2L = dppShift<true>(R2.bits), b1L = dppShift<true>(R1.bits), b3R = dppShift<false>(R3.bits);
+                    const int mrR = sfsMr(b2R), mrL = sfsMr(b2L), okR = b2R & kSfsOk, okL = b2L & kSfsOk;
+                    const int mr1L = sfsMr(b1L), ok1L = b1L & kSfsOk;
+                    const int mcR = sfsMc(b2R), mc3R = sfsMc(b3R), ok3R = b3R & kSfsOk;
+                    { const T m = A.w_g * (T)sfsMr(R2.bits); T coef = m * (R2.g1 - g0r); coef = (R2.bits & kSfsOk) ? coef : T(0); add(coef, q2.gh); }
+                    { const T m = A.w_g * (T)mrR; T coef = m * g0r; coef = okR ? coef : T(0); add(coef, dppShift<false>(q2.gh)); }
+                    { const T m = A.w_g * (T)sfsMr(R1.bits); T coef = m * R1.g2; coef = (R1.bits & kSfsOk) ? coef : T(0); add(coef, qn.gh); }
+                    { const T m = A.w_g * (T)mrL; T coef = -(m * R2.g1); coef = okL ? coef : T(0); add(coef, dppShift<true>(q2.gh)); }
+                    { const T m = A.w_g * (T)mr1L; T coef = -(m * R1.g2); coef = ok1L ? coef : T(0); add(coef, dppShift<true>(qn.gh)); }
+                    { const T m = A.w_g * (T)sfsMc(R2.bits); T coef = m * (R2.g1 - R1.g2); coef = (R2.bits & kSfsOk) ? coef : T(0); add(coef, q2.gv); }
+                    { const T m = A.w_g * (T)mcR; T coef = m * g0r; coef = okR ? coef : T(0); add(coef, dppShift<false>(q2.gv)); }
+                    { const T m = A.w_g * (T)sfsMc(R1.bits); T coef = m * R1.g2; coef = (R1.bits & kSfsOk) ? coef : T(0); add(coef, qn.gv); }
+                    { const T m = A.w_g * (T)sfsMc(R3.bits); T coef = -(m * R2.g1); coef = (R3.bits & kSfsOk) ? coef : T(0); add(coef, q3.gv); }
+                    { const T m = A.w_g * (T)mc3R; T coef = -(m * g0r); coef = ok3R ? coef : T(0); add(coef, dppShift<false>(q3.gv)); }
+                    const int vR = b2R & kSfsValid, vLft = b2L & kSfsValid;
+                    auto reg = [&](int valid, T w4, T a0, T a1, T a2) {
+                        const T wgt = valid ? A.w_s * w4 : T(0);
+                        add(wgt * cxc, a0); add(wgt * cy2, a1); add(wgt * T(1), a2);
+                    };
+                    reg(R2.bits & kSfsValid, T(4), q2.s0, q2.s1, q2.s2);
+                    reg(vR, T(-1), dppShift<false>(q2.s0), dppShift<false>(q2.s1), dppShift<false>(q2.s2));
+                    reg(vLft, T(-1), dppShift<true>(q2.s0), dppShift<true>(q2.s1), dppShift<true>(q2.s2));
+                    reg(R1.bits & kSfsValid, T(-1), qn.s0, qn.s1, qn.s2);
+                    reg(R3.bits & kSfsValid, T(-1), q3.s0, q3.s1, q3.s2);
+                    if (LM) s += R2.ctc * ve;
+                    if (!(R2.bits & kSfsEx)) s = 0;
+                    apOwn[h >= 4 ? h - 4 : 0] = s;
+                    if (writer && Y - 2 < A.H) {
+                        acc += (double)(ve * s);
+                        const T rk = R2.rk;
+                        const T zk = first ? ve : rk;                                          // iteration 0: alphaNumerator_0 = r_0 . p_0 (the reference's start)
+                        accNum += (double)(zk * rk); acc2 += (double)(rk * s); acc3 += (double)(s * s);
+                        if (first) accX += (double)(rk * rk);
+                        // the tile's two outermost rows / columns: to the tagged image, for whoever holds them as ring
+                        if (h - 4 < 2 || h - 4 >= R - 2 || lane < 4 || lane >= kWave - 4) {
+                            const int i = pixBase + (h - 2) * A.W;
+                            if constexpr (WPS == 1) ocStore(box + i, tag, __float_as_uint((float)s));
+                            else { const oc_u64 b = (oc_u64)__double_as_longlong((double)s); ocStore(box + 2 * (size_t)i, tag, (unsigned)b); ocStore(box + 2 * (size_t)i + 1, tag, (unsigned)(b >> 32)); }
+                        }
+                    }
+                }
+                R3 = R2; R2 = R1; R1 = n; q3 = q2; q2 = qn; b1 = bY; cy2 = cy1; cy1 = cyN;
+                __builtin_amdgcn_sched_barrier(0);      // one row per scheduling region: left to itself the scheduler interleaves the unrolled rows until their temporaries fill the register budget
+            }
+        }
+        if (!first) accX = accQ;      // Q of the iteration before (LM; 0 otherwise)
+
+        // ---- the grid-wide sums; the ring's A p is collected inside the wait ------------------------------------------------------------------------------------
+        {
+            double v5[kSoNS] = {accNum, acc, acc2, acc3, accX};
+#pragma unroll
+            for (int q = 0; q < kSoNS; ++q) { v5[q] = ocWaveSum63(v5[q]); if (lane == kWave - 1) red[q * kSoWaves + wave] = v5[q]; }
+        }
+        __syncthreads();
+        if (tid < kSoNW) {
+            double s = 0;
+            for (int w = 0; w < kSoWaves; ++w) s += red[(tid >> 1) * kSoWaves + w];
+            const oc_u64 b = (oc_u64)__double_as_longlong(s);
+            ocStore(slotPar + (size_t)g * kSoNW + tid, tag, (tid & 1) ? (unsigned)(b >> 32) : (unsigned)b);
+        }
+        // b of the owned pixels (LM: for Q), requested before the wait
+        T bb[LM ? R : 1];
+        if (LM) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) bb[LM ? i : 0] = K.r0[rowIdx(i + 2)];
+        }
+        // ring: held pixels inside the image that this wave does not own
+        T ring[HR];
+        if (!idle) {
+            auto need = [&](int h) { return rowIn(h) && !(writer && h >= 2 && h < R + 2); };
+            auto fetch = [&]() {
+                bool ok = true;
+#pragma unroll
+                for (int h = 0; h < HR; ++h) {
+                    T v = 0;
+                    if (need(h)) {
+                        const int i = pixBase + h * A.W;
+                        if constexpr (WPS == 1) {
+                            const oc_u64 w = ocLoad(box + i);
+                            ok = ok && (unsigned)(w >> 32) == tag; v = __uint_as_float((unsigned)w);
+                        } else {
+                            const oc_u64 w0 = ocLoad(box + 2 * (size_t)i), w1 = ocLoad(box + 2 * (size_t)i + 1);
+                            ok = ok && (unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag;
+                            v = __longlong_as_double((long long)((w1 << 32) | (w0 & 0xffffffffull)));
+                        }
+                    }
+                    ring[h] = v;
+                }
+                return ok;
+            };
+            if (!fetch()) {
+                const long long t0 = wall_clock64();
+                unsigned spins = 0;
+                for (;;) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (fetch()) break;
+                    if ((++spins & 31u) == 0) {
+                        if (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                        if (wall_clock64() - t0 > to) { __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < HR; ++h) ring[h] = 0;
+        }
+        {      // every workgroup reads every workgroup's words and adds them in workgroup order
+            constexpr int kPer = (kSoMaxG * kSoNW + kSoBlock - 1) / kSoBlock;
+            oc_u64 w[kPer];
+            const int nW = K.G * kSoNW;
+            auto fetchSums = [&]() {
+                bool ok = true;
+#pragma unroll
+                for (int u = 0; u < kPer; ++u) { const int i = tid + u * kSoBlock; w[u] = ocLoad(slotPar + (i < nW ? i : tid % nW)); }
+#pragma unroll
+                for (int u = 0; u < kPer; ++u) { const int i = tid + u * kSoBlock; ok = ok && (i >= nW || (unsigned)(w[u] >> 32) == tag); }
+                return ok;
+            };
+            if (!fetchSums()) {
+                const long long t0 = wall_clock64();
+                unsigned spins = 0;
+                for (;;) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (fetchSums()) break;
+                    if ((++spins & 31u) == 0) {
+                        if (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                        if (wall_clock64() - t0 > to) { __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) { const int i = tid + u * kSoBlock; if (i < nW) W1[i] = (unsigned)w[u]; }
+            __syncthreads();
+            if (tid < kSoNS) {
+                double s = 0;
+                for (int m = 0; m < K.G; ++m) s += ocJoin(W1[m * kSoNW + 2 * tid], W1[m * kSoNW + 2 * tid + 1]);
+                TOT[tid] = s;
+            }
+            if (tid == 0) reinterpret_cast<int*>(TOT + kSoNS)[0] = __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+        }
+        const double aNumD = TOT[0], aDenD = TOT[1], s2 = TOT[2], s3 = TOT[3], xD = TOT[4];
+        if (reinterpret_cast<const int*>(TOT + kSoNS)[0]) { failed = true; break; }      // uniform over the workgroup: a wait timed out somewhere
+        if (LM && !first) {      // the q early-out of iteration k - 1 (solver.t:1093-1102): nothing of iteration k has been applied yet
+            const T Q1 = (T)xD;
+            const T zeta = T(k) * (Q1 - Q0) / Q1;
+            if (zeta < K.qTolerance) break;
+            Q0 = Q1;
+        }
+        // the scalars of sfs_pcgMarch's prologue (solver.t:456-459, 544-547 guards; beta numerator by expansion, clamped like the direct sum it replaces)
+        const T aNum = (T)aNumD, aDen = (T)aDenD;
+        const T alpha = (aDen > T(0)) ? aNum / aDen : T(0);
+        const double rr = first ? xD : aNumD;
+        const double bNumD = fmax(rr - 2.0 * (double)alpha * s2 + (double)alpha * (double)alpha * s3, 0.0);
+        const T beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
+        const bool last = k + 1 == K.L;
+
+        // ---- PCGStep2 + PCGStep3 (z = r: this energy does not precondition after the start): delta += alpha p;  r -= alpha A p;  p = r + beta p -- on the owned
+        // pixels and, with the same fused operations, on the ring (after the last iteration only delta survives)
+        accQ = 0;
+#pragma unroll
+        for (int h = 0; h < HR; ++h) {
+            const bool ownRow = h >= 2 && h < R + 2;
+            const T apv = ownRow ? (writer ? apOwn[ownRow ? h - 2 : 0] : ring[h]) : ring[h];
+            if (ownRow) dl[ownRow ? h - 2 : 0] = soFma(alpha, p[h], dl[ownRow ? h - 2 : 0]);
+            if (!last) {
+                r[h] = soFma(-alpha, apv, r[h]);
+                if (LM && ownRow && writer && yBase + (h - 2) < A.H) accQ += (double)(T(0.5) * (dl[ownRow ? h - 2 : 0] * (r[h] + bb[LM && ownRow ? h - 2 : 0])));      // solver.t:483-485
+                p[h] = soFma(beta, p[h], r[h]);
+            }
+        }
+    }
+    if (!failed && writer) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int y = yBase + i;
+            if (y < A.H) K.delta[y * A.W + x] = dl[i];
+        }
+    }
+}
+
+// behind an on-chip solve whose update the solver applies itself (Levenberg-Marquardt): tell the host if a wait timed out
+__global__ void sfs_relayBad(const int* __restrict__ bad, int* hostErr) {
+    if (threadIdx.x == 0 && __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) __hip_atomic_store(hostErr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// PCGLinearUpdate X += delta (solver.t:552-557) behind the on-chip Gauss-Newton solve -- unless a wait timed out: then the unknowns stay untouched and the host is told
+template <class T>
+__global__ __launch_bounds__(kBlock) void sfs_applyDelta(T* __restrict__ X, const T* __restrict__ delta, long N, const int* __restrict__ bad, int* hostErr) {
+    if (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(hostErr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) X[i] = X[i] + delta[i];
+}
+
+}  // namespace
+}  // namespace optamd

@@ -579,7 +579,7 @@ struct PcgSolver : SolverBase {
         }
         // The whole linear solve as one persistent launch with the loop state on chip, if the kernel set has one and the problem fits (iw_onchip.h);
         // it ends with PCGLinearUpdate.  A traced solve gets its per-iteration scalars from the kernel (beta numerator by expansion, as below).
-        if (!distributed && preArg && onChipOk && sp.lIterations > 0) {
+        if (!distributed && (preArg || E->onChipWithoutPreconditioner()) && onChipOk && sp.lIterations > 0) {
             double* tr = nullptr;
             if (traceEnabled) {
                 if (onChipTraceCap < sp.lIterations) { if (onChipTrace) HIP_CHECK(hipFree(onChipTrace)); onChipTraceCap = sp.lIterations; HIP_CHECK(hipMalloc((void**)&onChipTrace, sizeof(double) * 4 * onChipTraceCap)); }
@@ -678,8 +678,8 @@ struct PcgSolver : SolverBase {
         if (distributed || traceEnabled || keepReferenceP) return false;
         // The whole LM linear solve as one persistent launch (iw_onchip.h, LMV): CtC, the q early-out and the split residual reset happen on chip, the host
         // sees only delta.  (A listening caller -- verbosity > 0 -- wants the "breaking at iteration" message: the launch-per-iteration loop prints it.)
-        if (onChipOk && preArg && sp.lIterations > 0 && verbosity == 0 && Q0 == T(0)) {
-            const OnChipLm<T> la{trust_region_radius, min_lm_diagonal, max_lm_diagonal, q_tolerance, sp.residual_reset_period};
+        if (onChipOk && (preArg || E->onChipWithoutPreconditioner()) && sp.lIterations > 0 && verbosity == 0 && Q0 == T(0)) {
+            const OnChipLm<T> la{trust_region_radius, min_lm_diagonal, max_lm_diagonal, q_tolerance, sp.residual_reset_period, CtC};
             if (E->pcgSolveOnChip(r, p, delta, sp.lIterations, nullptr, &la, ctx)) { usedOnChip = true; return true; }
         }
         if (!delta2) delta2 = allocVec();                       // zero-filled like delta; every launch that updates delta rewrites all of it
