@@ -638,6 +638,7 @@ struct SfsOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_SFS_MARCH_GRID")) marchGridOverride = atoi(e);
         if (const char* e = getenv("OPT_AMD_ONCHIP")) soEnabled = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ONCHIP_ROWS")) soForceRows = std::max(0, atoi(e));
+        if (const char* e = getenv("OPT_AMD_ONCHIP_WAVES")) soForceWaves = std::max(0, atoi(e));
         if (const char* e = getenv("OPT_AMD_ONCHIP_FAIL_AT")) soFailAt = atoi(e);      // test hook: see SfsOcArgs::failAt
         if (const char* e = getenv("OPT_AMD_ONCHIP_TIMEOUT_MS")) soTimeoutTicks = std::max(1, atoi(e)) * 100000LL;
     }
@@ -750,32 +751,37 @@ struct SfsOps : EnergyOps<T> {
     }
 
     // ---- the whole linear solve on chip (sfs_onchip.h): Gauss-Newton or Levenberg-Marquardt, one GPU, workgroups <= CUs ---------------------------------------------
-    // OPT_AMD_ONCHIP=0 switches it off (the one A/B switch of the path); OPT_AMD_ONCHIP_ROWS=r forces the variant that owns r rows per wave (tests run every variant
-    // on small images); OPT_AMD_ONCHIP_FAIL_AT / _TIMEOUT_MS: the time-out path's test hooks.
-    struct SoVariant { int rows; const void* gn; const void* lm; };
+    // OPT_AMD_ONCHIP=0 switches it off (the one A/B switch of the path); OPT_AMD_ONCHIP_ROWS=r / OPT_AMD_ONCHIP_WAVES=w force the variant that owns r rows per wave / has w waves per workgroup (tests run
+    // every variant on small images); OPT_AMD_ONCHIP_FAIL_AT / _TIMEOUT_MS: the time-out path's test hooks.
+    struct SoVariant { int rows, waves; const void* gn; const void* lm; };
     bool soEnabled = true, soFailed = false, soLaunched = false;
-    int soForceRows = 0, soFailAt = -1; long long soTimeoutTicks = 2000LL * 100000;      // 2 s of the 100 MHz wall clock
+    int soForceRows = 0, soForceWaves = 0, soFailAt = -1; long long soTimeoutTicks = 2000LL * 100000;      // 2 s of the 100 MHz wall clock
     oc_u64 *soSlots = nullptr, *soBox = nullptr; int *soBad = nullptr, *soHostErr = nullptr; unsigned soSeq = 0; size_t soSlotBytes = 0, soBoxBytes = 0;
     static const std::vector<SoVariant>& soVariants() {
         static const std::vector<SoVariant> v = [] {
             std::vector<SoVariant> o;
-#define SO_VARIANT(R) o.push_back({R, (const void*)sfs_onchipPcg<T, R, false>, (const void*)sfs_onchipPcg<T, R, true>})
-            SO_VARIANT(4); SO_VARIANT(6); SO_VARIANT(8); SO_VARIANT(10);
+#define SO_VARIANT(R, WV) o.push_back({R, WV, (const void*)sfs_onchipPcg<T, R, false, WV>, (const void*)sfs_onchipPcg<T, R, true, WV>})
+            SO_VARIANT(4, 4); SO_VARIANT(6, 4); SO_VARIANT(8, 4); SO_VARIANT(10, 4);
+            SO_VARIANT(4, 8); SO_VARIANT(6, 8); SO_VARIANT(8, 8); SO_VARIANT(10, 8);
 #undef SO_VARIANT
             return o;
         }();
         return v;
     }
-    // Which variant, if any: the fewest rows per wave whose workgroups fit one per CU (fewer rows: less serial work per wave, more of it redundant ring work).
+    // Which variant, if any: among those whose workgroups fit one per CU, the one with the fewest marching trips per SIMD and iteration -- (waves per SIMD) x (rows
+    // held per wave); ties go to the fewer rows (less work behind the wait).
     const SoVariant* soSelect(int& stripsX, int& tilesY, int& G) const {
         stripsX = divUp(A.W, kSoSpan);
+        const SoVariant* best = nullptr; int bestCost = 1 << 30;
         for (const auto& v : soVariants()) {
             if (soForceRows && v.rows != soForceRows) continue;
-            tilesY = divUp(A.H, v.rows);
-            G = divUp(stripsX * tilesY, kSoWaves);
-            if (G <= std::min(cus, kSoMaxG)) return &v;
+            if (soForceWaves && v.waves != soForceWaves) continue;
+            const int ty = divUp(A.H, v.rows), g = divUp(stripsX * ty, v.waves);
+            if (g > std::min(cus, kSoMaxG)) continue;
+            const int cost = (v.waves / 4) * (v.rows + 4);
+            if (cost < bestCost) { best = &v; bestCost = cost; tilesY = ty; G = g; }
         }
-        return nullptr;
+        return best;
     }
     bool onChipWithoutPreconditioner() const override { return true; }
     bool pcgSolveOnChip(const T* r0, const T* p0, T* delta, int L, double* traceDev, const OnChipLm<T>* lmArgs, LaunchCtx& ctx) override {
@@ -802,7 +808,7 @@ struct SfsOps : EnergyOps<T> {
         {
             ScopedKernel k(ctx, "PCGSolveOnChip");
             void* kargs[] = {(void*)&K};
-            HIP_CHECK(hipLaunchKernel(lmArgs ? V->lm : V->gn, dim3(G), dim3(kSoBlock), kargs, 0, ctx.stream));
+            HIP_CHECK(hipLaunchKernel(lmArgs ? V->lm : V->gn, dim3(G), dim3(V->waves * kWave), kargs, 0, ctx.stream));
         }
         if (lmArgs) sfs_relayBad<<<1, kWave, 0, ctx.stream>>>(soBad, soHostErr);      // (the solver applies the update itself)
         else {
@@ -824,10 +830,10 @@ struct SfsOps : EnergyOps<T> {
         int stripsX = 0, tilesY = 0, G = 0;
         const SoVariant* V = (soEnabled && !soFailed && !this->slab.active && L > 0) ? soSelect(stripsX, tilesY, G) : nullptr;
         char buf[600];
-        if (V) snprintf(buf, sizeof buf, "path=on-chip (sfs_onchipPcg%s%s); onchip_rows_per_wave=%d; wave_tiles=%dx%d of 60 x %d pixels; workgroups=%d of %d CUs; fallback=one launch per PCG iteration (sfs_pcgMarch)",
-                        lmv ? ", LM" : "", lmv ? " while lIterations <= residual_reset_period" : "", V->rows, stripsX, tilesY, V->rows, G, cus);
+        if (V) snprintf(buf, sizeof buf, "path=on-chip (sfs_onchipPcg%s%s); onchip_rows_per_wave=%d; waves_per_workgroup=%d; wave_tiles=%dx%d of 60 x %d pixels; workgroups=%d of %d CUs; fallback=one launch per PCG iteration (sfs_pcgMarch)",
+                        lmv ? ", LM" : "", lmv ? " while lIterations <= residual_reset_period" : "", V->rows, V->waves, stripsX, tilesY, V->rows, G, cus);
         else snprintf(buf, sizeof buf, "path=one launch per PCG iteration (sfs_pcgMarch%s); why_not_on_chip=%s", lmv ? ", LM" : "",
-                      !soEnabled ? "switched off" : soFailed ? "a wait timed out earlier" : this->slab.active ? "row slabs" : "the wave tiles do not fit 8 per CU");
+                      !soEnabled ? "switched off" : soFailed ? "a wait timed out earlier" : this->slab.active ? "row slabs" : "the wave tiles do not fit the CUs");
         return buf;
     }
 };

@@ -25,9 +25,11 @@
 namespace optamd {
 namespace {
 
-constexpr int kSoBlock = 512, kSoWaves = kSoBlock / kWave, kSoSpan = kWave - 4;
+constexpr int kSoSpan = kWave - 4;
 constexpr int kSoMaxG = 256;                  // workgroups (one per CU)
 constexpr int kSoNS = 5, kSoNW = 2 * kSoNS;   // sums per iteration; tagged words per workgroup
+constexpr int kSoChunk = 16;                  // workgroups per first-level partial of the sum over workgroups (in LDS; fixed, so the bits do not depend on who adds)
+constexpr int kSoDepth = 2;                   // rows of constants in flight ahead of the row being worked on
 
 template <class T>
 struct SfsOcArgs {
@@ -48,14 +50,24 @@ template <class T> struct SoRowC { T g0, g1, g2, ctc; int fb; };
 __device__ __forceinline__ float soFma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double soFma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-template <class T, int R, bool LM>
-__global__ __launch_bounds__(kSoBlock) void sfs_onchipPcg(SfsOcArgs<T> K) {
+// WAVES: waves per workgroup = per CU (4: one per SIMD, 8: two).  A marching trip is ~350 instructions whatever the row holds, so an iteration costs
+// (waves per SIMD) x (R + 4) trips: the launcher picks the (R, WAVES) that minimises it among those whose workgroups fit one per CU.
+template <class T, int R, bool LM, int WAVES>
+__global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
+    constexpr int kSoWaves = WAVES, kSoBlock = WAVES * kWave;
     constexpr int HR = R + 4;                          // held rows: two above and two below the R owned ones
     constexpr int WPS = (int)sizeof(T) / 4;            // tagged words per scalar
     static_assert(R >= 2, "the ring must come from the adjacent tiles only");
+    static_assert(HR % kSoDepth == 0, "the rows requested behind the last trip are the first rows of the next iteration");
     __shared__ double red[kSoNS * kSoWaves];
     __shared__ double TOT[kSoNS + 1];
+    __shared__ double GS[(kSoMaxG / kSoChunk) * kSoNS];
     __shared__ unsigned W1[kSoMaxG * kSoNW];
+    // b = r_0 of the owned pixels (LM: for Q) and -- where the registers are short: double, R >= 8 -- the A p of the owned pixels between the march and the update:
+    // [row][thread], conflict-free
+    constexpr bool AP_LDS = sizeof(T) * R >= 64;
+    __shared__ T bL[(LM ? R : 1) * kSoBlock];
+    __shared__ T apL[(AP_LDS ? R : 1) * kSoBlock];
     const SArgs<T>& A = K.A;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = blockIdx.x;      // (wave: uniform, kept in a scalar register)
     const int tile = g * kSoWaves + wave;
@@ -79,7 +91,7 @@ __global__ __launch_bounds__(kSoBlock) void sfs_onchipPcg(SfsOcArgs<T> K) {
     };
 
     // ---- p_0, r_0 of the held pixels (zeros outside the image); delta = 0 ------------------------------------------------------------------------------------
-    T p[HR], r[HR], dl[R], apOwn[R];
+    T p[HR], r[HR], dl[R], apOwn[AP_LDS ? 1 : R];
 #pragma unroll
     for (int h = 0; h < HR; ++h) {
         const int i = rowIdx(h);
@@ -88,9 +100,21 @@ __global__ __launch_bounds__(kSoBlock) void sfs_onchipPcg(SfsOcArgs<T> K) {
         p[h] = in ? pv : T(0); r[h] = in ? rv : T(0);
     }
 #pragma unroll
-    for (int i = 0; i < R; ++i) { dl[i] = 0; apOwn[i] = 0; }
+    for (int i = 0; i < R; ++i) { dl[i] = 0; if (!AP_LDS) apOwn[AP_LDS ? 0 : i] = 0; else apL[(AP_LDS ? i : 0) * kSoBlock + tid] = 0; if (LM) bL[(LM ? i : 0) * kSoBlock + tid] = r[i + 2]; }      // b = r_0 (solver.t:657)
 
     int pixBase = (yBase - 2) * A.W + xc;      // (opaque per iteration below: addresses are recomputed, not kept)
+    // the constants of a held row (read-only while the kernel runs: plain cached loads); the first kSoDepth rows of an iteration are requested BEFORE the wait of
+    // the iteration before, the others kSoDepth trips ahead of their use
+    auto loadRow = [&](int h) {
+        SoRowC<T> c;
+        const int i = rowIdx(h);
+        c.g0 = A.g0[i]; c.g1 = A.g1[i]; c.g2 = A.g2[i]; c.fb = (int)A.fl2[i];
+        c.ctc = (LM && h >= 2 && h < R + 2) ? K.CtC[i] : T(0);
+        return c;
+    };
+    SoRowC<T> cq[kSoDepth];
+#pragma unroll
+    for (int d = 0; d < kSoDepth; ++d) cq[d] = loadRow(d);
     bool failed = false;
     double accQ = 0;
     T Q0 = 0;                                  // fetchQ before the loop (solver.t:1050): delta = 0, so exactly 0
@@ -110,21 +134,13 @@ __global__ __launch_bounds__(kSoBlock) void sfs_onchipPcg(SfsOcArgs<T> K) {
         // ---- PCGStep1: A p_k on the owned pixels, with the sums (the expressions of sfs_pcgMarch, in its order) ------------------------------------------------
         double acc = 0, accNum = 0, acc2 = 0, acc3 = 0, accX = 0;
         if (!idle) {
-            auto loadRow = [&](int h) {
-                SoRowC<T> c;
-                const int i = rowIdx(h);
-                c.g0 = A.g0[i]; c.g1 = A.g1[i]; c.g2 = A.g2[i]; c.fb = (int)A.fl2[i];
-                c.ctc = (LM && h >= 2 && h < R + 2) ? K.CtC[i] : T(0);
-                return c;
-            };
             SRow<T> R1{}, R2{}, R3{};
             SQ<T> q2{}, q3{};
             T b1 = 0, cy1 = 0, cy2 = 0;
-            SoRowC<T> cN = loadRow(0);
 #pragma unroll
             for (int h = 0; h < HR; ++h) {
-                const SoRowC<T> c = cN;
-                if (h + 1 < HR) cN = loadRow(h + 1 < HR ? h + 1 : h);
+                const SoRowC<T> c = cq[h % kSoDepth];
+                cq[h % kSoDepth] = loadRow((h + kSoDepth) % HR);      // (behind the last rows: rows 0 .. kSoDepth - 1 of the next iteration)
                 const int Y = yBase - 2 + h;
                 SRow<T> n;
                 {
@@ -190,7 +206,7 @@ __global__ __launch_bounds__(kSoBlock) void sfs_onchipPcg(SfsOcArgs<T> K) {
                     reg(R3.bits & kSfsValid, T(-1), q3.s0, q3.s1, q3.s2);
                     if (LM) s += R2.ctc * ve;
                     if (!(R2.bits & kSfsEx)) s = 0;
-                    apOwn[h >= 4 ? h - 4 : 0] = s;
+                    if (AP_LDS) apL[(AP_LDS && h >= 4 ? h - 4 : 0) * kSoBlock + tid] = s; else apOwn[!AP_LDS && h >= 4 ? h - 4 : 0] = s;
                     if (writer && Y - 2 < A.H) {
                         acc += (double)(ve * s);
                         const T rk = R2.rk;
@@ -224,33 +240,38 @@ __global__ __launch_bounds__(kSoBlock) void sfs_onchipPcg(SfsOcArgs<T> K) {
             const oc_u64 b = (oc_u64)__double_as_longlong(s);
             ocStore(slotPar + (size_t)g * kSoNW + tid, tag, (tid & 1) ? (unsigned)(b >> 32) : (unsigned)b);
         }
-        // b of the owned pixels (LM: for Q), requested before the wait
-        T bb[LM ? R : 1];
-        if (LM) {
-#pragma unroll
-            for (int i = 0; i < R; ++i) bb[LM ? i : 0] = K.r0[rowIdx(i + 2)];
-        }
-        // ring: held pixels inside the image that this wave does not own
+        // ---- ONE wait: the ring's A p (held pixels inside the image that this wave does not own; posted before their owners' sums) and every workgroup's sums are
+        // requested together, re-requested until all carry this iteration's tag
         T ring[HR];
-        if (!idle) {
-            auto need = [&](int h) { return rowIn(h) && !(writer && h >= 2 && h < R + 2); };
+        {
+            constexpr int kPer = (kSoMaxG * kSoNW + kSoBlock - 1) / kSoBlock;
+            oc_u64 w[kPer];
+            const int nW = K.G * kSoNW;
+            const bool lastIt = k + 1 == K.L;      // (after the last iteration only delta survives: nobody needs the ring)
+            auto need = [&](int h) { return !lastIt && rowIn(h) && !(writer && h >= 2 && h < R + 2); };
             auto fetch = [&]() {
                 bool ok = true;
+                oc_u64 rw[HR][WPS];
+#pragma unroll
+                for (int u = 0; u < kPer; ++u) { const int i = tid + u * kSoBlock; w[u] = ocLoad(slotPar + (i < nW ? i : tid % nW)); }
 #pragma unroll
                 for (int h = 0; h < HR; ++h) {
-                    T v = 0;
+#pragma unroll
+                    for (int q = 0; q < WPS; ++q) rw[h][q] = (oc_u64)tag << 32;
                     if (need(h)) {
-                        const int i = pixBase + h * A.W;
-                        if constexpr (WPS == 1) {
-                            const oc_u64 w = ocLoad(box + i);
-                            ok = ok && (unsigned)(w >> 32) == tag; v = __uint_as_float((unsigned)w);
-                        } else {
-                            const oc_u64 w0 = ocLoad(box + 2 * (size_t)i), w1 = ocLoad(box + 2 * (size_t)i + 1);
-                            ok = ok && (unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag;
-                            v = __longlong_as_double((long long)((w1 << 32) | (w0 & 0xffffffffull)));
-                        }
+                        const size_t i = (size_t)(pixBase + h * A.W) * WPS;
+#pragma unroll
+                        for (int q = 0; q < WPS; ++q) rw[h][q] = ocLoad(box + i + q);
                     }
-                    ring[h] = v;
+                }
+#pragma unroll
+                for (int u = 0; u < kPer; ++u) { const int i = tid + u * kSoBlock; ok = ok && (i >= nW || (unsigned)(w[u] >> 32) == tag); }
+#pragma unroll
+                for (int h = 0; h < HR; ++h) {
+#pragma unroll
+                    for (int q = 0; q < WPS; ++q) ok = ok && (unsigned)(rw[h][q] >> 32) == tag;
+                    if constexpr (WPS == 1) ring[h] = __uint_as_float((unsigned)rw[h][0]);
+                    else ring[h] = __longlong_as_double((long long)((rw[h][WPS - 1] << 32) | (rw[h][0] & 0xffffffffull)));
                 }
                 return ok;
             };
@@ -266,42 +287,19 @@ __global__ __launch_bounds__(kSoBlock) void sfs_onchipPcg(SfsOcArgs<T> K) {
                     }
                 }
             }
-        } else {
-#pragma unroll
-            for (int h = 0; h < HR; ++h) ring[h] = 0;
-        }
-        {      // every workgroup reads every workgroup's words and adds them in workgroup order
-            constexpr int kPer = (kSoMaxG * kSoNW + kSoBlock - 1) / kSoBlock;
-            oc_u64 w[kPer];
-            const int nW = K.G * kSoNW;
-            auto fetchSums = [&]() {
-                bool ok = true;
-#pragma unroll
-                for (int u = 0; u < kPer; ++u) { const int i = tid + u * kSoBlock; w[u] = ocLoad(slotPar + (i < nW ? i : tid % nW)); }
-#pragma unroll
-                for (int u = 0; u < kPer; ++u) { const int i = tid + u * kSoBlock; ok = ok && (i >= nW || (unsigned)(w[u] >> 32) == tag); }
-                return ok;
-            };
-            if (!fetchSums()) {
-                const long long t0 = wall_clock64();
-                unsigned spins = 0;
-                for (;;) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (fetchSums()) break;
-                    if ((++spins & 31u) == 0) {
-                        if (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                        if (wall_clock64() - t0 > to) { __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                    }
-                }
-            }
 #pragma unroll
             for (int u = 0; u < kPer; ++u) { const int i = tid + u * kSoBlock; if (i < nW) W1[i] = (unsigned)w[u]; }
             __syncthreads();
-            if (tid < kSoNS) {
+            // every workgroup adds all workgroups' words in the same order: chunks of 16 workgroups, then the chunks
+            const int nChunks = (K.G + kSoChunk - 1) / kSoChunk;
+            if (tid < nChunks * kSoNS) {
+                const int q = tid % kSoNS, ch = tid / kSoNS, n = min(kSoChunk, K.G - ch * kSoChunk);
                 double s = 0;
-                for (int m = 0; m < K.G; ++m) s += ocJoin(W1[m * kSoNW + 2 * tid], W1[m * kSoNW + 2 * tid + 1]);
-                TOT[tid] = s;
+                for (int m = 0; m < n; ++m) s += ocJoin(W1[(ch * kSoChunk + m) * kSoNW + 2 * q], W1[(ch * kSoChunk + m) * kSoNW + 2 * q + 1]);
+                GS[ch * kSoNS + q] = s;
             }
+            __syncthreads();
+            if (tid < kSoNS) { double s = 0; for (int ch = 0; ch < nChunks; ++ch) s += GS[ch * kSoNS + tid]; TOT[tid] = s; }
             if (tid == 0) reinterpret_cast<int*>(TOT + kSoNS)[0] = __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
         }
@@ -327,11 +325,11 @@ __global__ __launch_bounds__(kSoBlock) void sfs_onchipPcg(SfsOcArgs<T> K) {
 #pragma unroll
         for (int h = 0; h < HR; ++h) {
             const bool ownRow = h >= 2 && h < R + 2;
-            const T apv = ownRow ? (writer ? apOwn[ownRow ? h - 2 : 0] : ring[h]) : ring[h];
+            const T apv = ownRow ? (writer ? (AP_LDS ? apL[(AP_LDS && ownRow ? h - 2 : 0) * kSoBlock + tid] : apOwn[!AP_LDS && ownRow ? h - 2 : 0]) : ring[h]) : ring[h];
             if (ownRow) dl[ownRow ? h - 2 : 0] = soFma(alpha, p[h], dl[ownRow ? h - 2 : 0]);
             if (!last) {
                 r[h] = soFma(-alpha, apv, r[h]);
-                if (LM && ownRow && writer && yBase + (h - 2) < A.H) accQ += (double)(T(0.5) * (dl[ownRow ? h - 2 : 0] * (r[h] + bb[LM && ownRow ? h - 2 : 0])));      // solver.t:483-485
+                if (LM && ownRow && writer && yBase + (h - 2) < A.H) accQ += (double)(T(0.5) * (dl[ownRow ? h - 2 : 0] * (r[h] + bL[(LM && ownRow ? h - 2 : 0) * kSoBlock + tid])));      // solver.t:483-485
                 p[h] = soFma(beta, p[h], r[h]);
             }
         }

