@@ -808,7 +808,11 @@ struct SfsOps : EnergyOps<T> {
         {
             ScopedKernel k(ctx, "PCGSolveOnChip");
             void* kargs[] = {(void*)&K};
-            HIP_CHECK(hipLaunchKernel(lmArgs ? V->lm : V->gn, dim3(G), dim3(V->waves * kWave), kargs, 0, ctx.stream));
+            if (hipLaunchKernel(lmArgs ? V->lm : V->gn, dim3(G), dim3(V->waves * kWave), kargs, 0, ctx.stream) != hipSuccess) {      // (a device that cannot hold the variant's LDS: not offered again)
+                (void)hipGetLastError(); soEnabled = false; soSeq -= (unsigned)L;
+                fprintf(stderr, "Opt(amd): the on-chip shape_from_shading kernel (%d rows, %d waves) could not be launched; the plan stays on the marching kernels\n", V->rows, V->waves);
+                return false;
+            }
         }
         if (lmArgs) sfs_relayBad<<<1, kWave, 0, ctx.stream>>>(soBad, soHostErr);      // (the solver applies the update itself)
         else {

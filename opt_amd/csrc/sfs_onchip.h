@@ -45,7 +45,8 @@ struct SfsOcArgs {
     T qTolerance;
 };
 
-template <class T> struct SoRowC { T g0, g1, g2, ctc; int fb; };
+template <class T> struct SoRowC { T g0, g1, g2; int fb; };
+template <class T> struct SoRow { T v, rk, g0, g1, g2, wr, wc, ws; int ex; };      // a staged row: p, r, dB_I / d{d0, d1, d2}, the three mask multipliers (see the march), `not excluded`
 
 __device__ __forceinline__ float soFma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double soFma(double a, double b, double c) { return __builtin_fma(a, b, c); }
@@ -68,6 +69,8 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
     constexpr bool AP_LDS = sizeof(T) * R >= 64;
     __shared__ T bL[(LM ? R : 1) * kSoBlock];
     __shared__ T apL[(AP_LDS ? R : 1) * kSoBlock];
+    constexpr bool DL_LDS = sizeof(T) * R >= 80 && WAVES == 8;      // ... and delta itself in the tightest variant (double, R = 10, two waves per SIMD: 1024^2)
+    __shared__ T dlL[(DL_LDS ? R : 1) * kSoBlock];
     const SArgs<T>& A = K.A;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = blockIdx.x;      // (wave: uniform, kept in a scalar register)
     const int tile = g * kSoWaves + wave;
@@ -82,6 +85,7 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
     int* const bad = K.bad;
     const long long to = K.timeoutTicks;
     const T cxc = coefK(A, 0, x, 0);
+    const T cxl = dppShift<true>(cxc), cxr = dppShift<false>(cxc);      // (lanes 0 / 63 read 0: they are ring lanes whose row values are never used)
 
     auto rowIn = [&](int h) { const int y = yBase - 2 + h; return xin && y >= 0 && y < A.H; };
     auto rowIdx = [&](int h) { const int y = yBase - 2 + h; return (y >= 0 && y < A.H && !idle) ? y * A.W + xc : xc; };      // a valid address either way
@@ -90,8 +94,15 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
         else return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
     };
 
+    // the P(u) coefficient of held row h, wave-uniform: lane h computes it once, a trip reads it from there into scalar registers
+    const T cyLane = coefK(A, 1, 0, yBase - 2 + lane);
+    auto uniLane = [](T v, int l) -> T {
+        if constexpr (sizeof(T) == 8) return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+        else return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+    };
+
     // ---- p_0, r_0 of the held pixels (zeros outside the image); delta = 0 ------------------------------------------------------------------------------------
-    T p[HR], r[HR], dl[R], apOwn[AP_LDS ? 1 : R];
+    T p[HR], r[HR], dl[DL_LDS ? 1 : R], apOwn[AP_LDS ? 1 : R];
 #pragma unroll
     for (int h = 0; h < HR; ++h) {
         const int i = rowIdx(h);
@@ -100,7 +111,7 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
         p[h] = in ? pv : T(0); r[h] = in ? rv : T(0);
     }
 #pragma unroll
-    for (int i = 0; i < R; ++i) { dl[i] = 0; if (!AP_LDS) apOwn[AP_LDS ? 0 : i] = 0; else apL[(AP_LDS ? i : 0) * kSoBlock + tid] = 0; if (LM) bL[(LM ? i : 0) * kSoBlock + tid] = r[i + 2]; }      // b = r_0 (solver.t:657)
+    for (int i = 0; i < R; ++i) { if (DL_LDS) dlL[(DL_LDS ? i : 0) * kSoBlock + tid] = 0; else dl[DL_LDS ? 0 : i] = 0; if (!AP_LDS) apOwn[AP_LDS ? 0 : i] = 0; else apL[(AP_LDS ? i : 0) * kSoBlock + tid] = 0; if (LM) bL[(LM ? i : 0) * kSoBlock + tid] = r[i + 2]; }      // b = r_0 (solver.t:657)
 
     int pixBase = (yBase - 2) * A.W + xc;      // (opaque per iteration below: addresses are recomputed, not kept)
     // the constants of a held row (read-only while the kernel runs: plain cached loads); the first kSoDepth rows of an iteration are requested BEFORE the wait of
@@ -109,7 +120,6 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
         SoRowC<T> c;
         const int i = rowIdx(h);
         c.g0 = A.g0[i]; c.g1 = A.g1[i]; c.g2 = A.g2[i]; c.fb = (int)A.fl2[i];
-        c.ctc = (LM && h >= 2 && h < R + 2) ? K.CtC[i] : T(0);
         return c;
     };
     SoRowC<T> cq[kSoDepth];
@@ -134,34 +144,41 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
         // ---- PCGStep1: A p_k on the owned pixels, with the sums (the expressions of sfs_pcgMarch, in its order) ------------------------------------------------
         double acc = 0, accNum = 0, acc2 = 0, acc3 = 0, accX = 0;
         if (!idle) {
-            SRow<T> R1{}, R2{}, R3{};
+            SoRow<T> R1{}, R2{}, R3{};
             SQ<T> q2{}, q3{};
             T b1 = 0, cy1 = 0, cy2 = 0;
+            T ctcQ[2] = {0, 0};      // CtC of the owned rows: requested when the row is staged, used two trips later by its gather
 #pragma unroll
             for (int h = 0; h < HR; ++h) {
                 const SoRowC<T> c = cq[h % kSoDepth];
+                const T ctcNow = ctcQ[h % 2];
+                if (LM && h >= 2 && h < R + 2) ctcQ[h % 2] = K.CtC[rowIdx(h)];
                 cq[h % kSoDepth] = loadRow((h + kSoDepth) % HR);      // (behind the last rows: rows 0 .. kSoDepth - 1 of the next iteration)
                 const int Y = yBase - 2 + h;
-                SRow<T> n;
+                // The staged row.  The masks of sfs_pcgMarch -- `interior row centre ? w_g * edge mask : 0`, `regularisation rows on ? w_s : 0` -- are formed ONCE per
+                // pixel as multipliers in the solver's precision and travel to the neighbouring columns as such: where the march selects `ok ? m * g : 0` per use, this
+                // kernel multiplies by a multiplier that is exactly 0 -- the same products in the same order where the row counts, +-0 where it does not.
+                SoRow<T> n;
                 {
                     const bool in = rowIn(h);
                     n.v = p[h]; n.rk = r[h];
-                    n.g0 = in ? c.g0 : T(0); n.g1 = in ? c.g1 : T(0); n.g2 = in ? c.g2 : T(0); n.ctc = c.ctc;
+                    n.g0 = in ? c.g0 : T(0); n.g1 = in ? c.g1 : T(0); n.g2 = in ? c.g2 : T(0);
                     const bool ok = in && sfs_interior(A, x, Y);
-                    n.bits = (in ? (c.fb & kSfsEx) : 0) | (ok ? ((c.fb & (kSfsValid | 0xffff00)) | kSfsOk) : 0);
+                    n.wr = ok ? A.w_g * (T)sfsMr(c.fb) : T(0); n.wc = ok ? A.w_g * (T)sfsMc(c.fb) : T(0);
+                    n.ws = (ok && (c.fb & kSfsValid)) ? A.w_s : T(0);
+                    n.ex = in ? (c.fb & kSfsEx) : 0;
                 }
-                const T cyN = uni(coefK(A, 1, 0, Y));
+                const T cyN = uniLane(cyLane, h);
                 // b(., Y) = g1 v + g0 v(x-1) + g2 v(y-1)                                      (d B_I(c) . v)
                 const T vL = dppShift<true>(n.v);
                 const T bY = n.g1 * n.v + n.g0 * vL + n.g2 * R1.v;
-                // row values at the centres of row Y - 1 (R1)
-                SQ<T> qn;
-                {
+                // row values at the centres of row Y - 1 (R1); those of the held rows 0 and 1 feed no owned pixel
+                SQ<T> qn{};
+                if (h >= 2) {
                     const T right = dppShift<false>(b1);
-                    qn.gh = (R1.bits & kSfsOk) ? A.w_g * (T)sfsMr(R1.bits) * (b1 - right) : T(0);
-                    qn.gv = (R1.bits & kSfsOk) ? A.w_g * (T)sfsMc(R1.bits) * (b1 - bY) : T(0);
+                    qn.gh = R1.wr * (b1 - right);
+                    qn.gv = R1.wc * (b1 - bY);
                     const T v1l = dppShift<true>(R1.v), v1r = dppShift<false>(R1.v);
-                    const T cxl = dppShift<true>(cxc), cxr = dppShift<false>(cxc);
                     T js[3];
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
@@ -169,7 +186,7 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
                                 cr = q == 0 ? cxr : q == 1 ? cy1 : T(1), cd = q == 0 ? cxc : q == 1 ? cyN : T(1);
                         T sj = 0;
                         sj += (T(4) * c0) * R1.v; sj += (T(-1) * cl) * v1l; sj += (T(-1) * cu) * R2.v; sj += (T(-1) * cr) * v1r; sj += (T(-1) * cd) * n.v;
-                        js[q] = (R1.bits & kSfsValid) ? A.w_s * sj : T(0);
+                        js[q] = R1.ws * sj;
                     }
                     qn.s0 = js[0]; qn.s1 = js[1]; qn.s2 = js[2];
                 }
@@ -180,32 +197,29 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
                     auto add = [&](T coef, T q) { s += coef * q; };
                     add(A.w_p, A.w_p * ve);      // the fitting row
                     const T g0r = dppShift<false>(R2.g0);
-                    const int b2R = dppShift<false>(R2.bits), b2L = dppShift<true>(R2.bits), b1L = dppShift<true>(R1.bits), b3R = dppShift<false>(R3.bits);
-                    const int mrR = sfsMr(b2R), mrL = sfsMr(b2L), okR = b2R & kSfsOk, okL = b2L & kSfsOk;
-                    const int mr1L = sfsMr(b1L), ok1L = b1L & kSfsOk;
-                    const int mcR = sfsMc(b2R), mc3R = sfsMc(b3R), ok3R = b3R & kSfsOk;
-                    { const T m = A.w_g * (T)sfsMr(R2.bits); T coef = m * (R2.g1 - g0r); coef = (R2.bits & kSfsOk) ? coef : T(0); add(coef, q2.gh); }
-                    { const T m = A.w_g * (T)mrR; T coef = m * g0r; coef = okR ? coef : T(0); add(coef, dppShift<false>(q2.gh)); }
-                    { const T m = A.w_g * (T)sfsMr(R1.bits); T coef = m * R1.g2; coef = (R1.bits & kSfsOk) ? coef : T(0); add(coef, qn.gh); }
-                    { const T m = A.w_g * (T)mrL; T coef = -(m * R2.g1); coef = okL ? coef : T(0); add(coef, dppShift<true>(q2.gh)); }
-                    { const T m = A.w_g * (T)mr1L; T coef = -(m * R1.g2); coef = ok1L ? coef : T(0); add(coef, dppShift<true>(qn.gh)); }
-                    { const T m = A.w_g * (T)sfsMc(R2.bits); T coef = m * (R2.g1 - R1.g2); coef = (R2.bits & kSfsOk) ? coef : T(0); add(coef, q2.gv); }
-                    { const T m = A.w_g * (T)mcR; T coef = m * g0r; coef = okR ? coef : T(0); add(coef, dppShift<false>(q2.gv)); }
-                    { const T m = A.w_g * (T)sfsMc(R1.bits); T coef = m * R1.g2; coef = (R1.bits & kSfsOk) ? coef : T(0); add(coef, qn.gv); }
-                    { const T m = A.w_g * (T)sfsMc(R3.bits); T coef = -(m * R2.g1); coef = (R3.bits & kSfsOk) ? coef : T(0); add(coef, q3.gv); }
-                    { const T m = A.w_g * (T)mc3R; T coef = -(m * g0r); coef = ok3R ? coef : T(0); add(coef, dppShift<false>(q3.gv)); }
-                    const int vR = b2R & kSfsValid, vLft = b2L & kSfsValid;
-                    auto reg = [&](int valid, T w4, T a0, T a1, T a2) {
-                        const T wgt = valid ? A.w_s * w4 : T(0);
+                    const T wrR = dppShift<false>(R2.wr), wrL = dppShift<true>(R2.wr), wr1L = dppShift<true>(R1.wr);
+                    const T wcR = dppShift<false>(R2.wc), wc3R = dppShift<false>(R3.wc);
+                    add(R2.wr * (R2.g1 - g0r), q2.gh);                     // gh, centre (x, y)
+                    add(wrR * g0r, dppShift<false>(q2.gh));                // (x+1, y)
+                    add(R1.wr * R1.g2, qn.gh);                             // (x, y+1)
+                    add(-(wrL * R2.g1), dppShift<true>(q2.gh));            // (x-1, y)
+                    add(-(wr1L * R1.g2), dppShift<true>(qn.gh));           // (x-1, y+1)
+                    add(R2.wc * (R2.g1 - R1.g2), q2.gv);                   // gv, centre (x, y)
+                    add(wcR * g0r, dppShift<false>(q2.gv));                // (x+1, y)
+                    add(R1.wc * R1.g2, qn.gv);                             // (x, y+1)
+                    add(-(R3.wc * R2.g1), q3.gv);                          // (x, y-1)
+                    add(-(wc3R * g0r), dppShift<false>(q3.gv));            // (x+1, y-1)
+                    auto reg = [&](T ws, T w4, T a0, T a1, T a2) {
+                        const T wgt = ws * w4;
                         add(wgt * cxc, a0); add(wgt * cy2, a1); add(wgt * T(1), a2);
                     };
-                    reg(R2.bits & kSfsValid, T(4), q2.s0, q2.s1, q2.s2);
-                    reg(vR, T(-1), dppShift<false>(q2.s0), dppShift<false>(q2.s1), dppShift<false>(q2.s2));
-                    reg(vLft, T(-1), dppShift<true>(q2.s0), dppShift<true>(q2.s1), dppShift<true>(q2.s2));
-                    reg(R1.bits & kSfsValid, T(-1), qn.s0, qn.s1, qn.s2);
-                    reg(R3.bits & kSfsValid, T(-1), q3.s0, q3.s1, q3.s2);
-                    if (LM) s += R2.ctc * ve;
-                    if (!(R2.bits & kSfsEx)) s = 0;
+                    reg(R2.ws, T(4), q2.s0, q2.s1, q2.s2);
+                    reg(dppShift<false>(R2.ws), T(-1), dppShift<false>(q2.s0), dppShift<false>(q2.s1), dppShift<false>(q2.s2));
+                    reg(dppShift<true>(R2.ws), T(-1), dppShift<true>(q2.s0), dppShift<true>(q2.s1), dppShift<true>(q2.s2));
+                    reg(R1.ws, T(-1), qn.s0, qn.s1, qn.s2);
+                    reg(R3.ws, T(-1), q3.s0, q3.s1, q3.s2);
+                    if (LM) s += ctcNow * ve;
+                    if (!R2.ex) s = 0;
                     if (AP_LDS) apL[(AP_LDS && h >= 4 ? h - 4 : 0) * kSoBlock + tid] = s; else apOwn[!AP_LDS && h >= 4 ? h - 4 : 0] = s;
                     if (writer && Y - 2 < A.H) {
                         acc += (double)(ve * s);
@@ -226,6 +240,7 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
             }
         }
         if (!first) accX = accQ;      // Q of the iteration before (LM; 0 otherwise)
+        asm volatile("" : "+v"(pixBase), "+v"(xc), "+s"(yBase));      // (the row predicates of the march are not kept for the wait: recomputed there)
 
         // ---- the grid-wide sums; the ring's A p is collected inside the wait ------------------------------------------------------------------------------------
         {
@@ -326,10 +341,14 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
         for (int h = 0; h < HR; ++h) {
             const bool ownRow = h >= 2 && h < R + 2;
             const T apv = ownRow ? (writer ? (AP_LDS ? apL[(AP_LDS && ownRow ? h - 2 : 0) * kSoBlock + tid] : apOwn[!AP_LDS && ownRow ? h - 2 : 0]) : ring[h]) : ring[h];
-            if (ownRow) dl[ownRow ? h - 2 : 0] = soFma(alpha, p[h], dl[ownRow ? h - 2 : 0]);
+            T dNew = 0;
+            if (ownRow) {
+                dNew = soFma(alpha, p[h], DL_LDS ? dlL[(DL_LDS && ownRow ? h - 2 : 0) * kSoBlock + tid] : dl[!DL_LDS && ownRow ? h - 2 : 0]);
+                if (DL_LDS) dlL[(DL_LDS && ownRow ? h - 2 : 0) * kSoBlock + tid] = dNew; else dl[!DL_LDS && ownRow ? h - 2 : 0] = dNew;
+            }
             if (!last) {
                 r[h] = soFma(-alpha, apv, r[h]);
-                if (LM && ownRow && writer && yBase + (h - 2) < A.H) accQ += (double)(T(0.5) * (dl[ownRow ? h - 2 : 0] * (r[h] + bL[(LM && ownRow ? h - 2 : 0) * kSoBlock + tid])));      // solver.t:483-485
+                if (LM && ownRow && writer && yBase + (h - 2) < A.H) accQ += (double)(T(0.5) * (dNew * (r[h] + bL[(LM && ownRow ? h - 2 : 0) * kSoBlock + tid])));      // solver.t:483-485
                 p[h] = soFma(beta, p[h], r[h]);
             }
         }
@@ -338,7 +357,7 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const int y = yBase + i;
-            if (y < A.H) K.delta[y * A.W + x] = dl[i];
+            if (y < A.H) K.delta[y * A.W + x] = DL_LDS ? dlL[(DL_LDS ? i : 0) * kSoBlock + tid] : dl[DL_LDS ? 0 : i];
         }
     }
 }
