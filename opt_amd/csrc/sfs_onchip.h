@@ -162,7 +162,9 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
                 {
                     const bool in = rowIn(h);
                     n.v = p[h]; n.rk = r[h];
-                    n.g0 = in ? c.g0 : T(0); n.g1 = in ? c.g1 : T(0); n.g2 = in ? c.g2 : T(0);
+                    // (the gradient images of a pixel outside the image are whatever the clamped address holds -- finite numbers: they only ever meet a p or a multiplier
+                    //  that is exactly 0 there, or end in an output that the `excluded` test below zeroes)
+                    n.g0 = c.g0; n.g1 = c.g1; n.g2 = c.g2;
                     const bool ok = in && sfs_interior(A, x, Y);
                     n.wr = ok ? A.w_g * (T)sfsMr(c.fb) : T(0); n.wc = ok ? A.w_g * (T)sfsMc(c.fb) : T(0);
                     n.ws = (ok && (c.fb & kSfsValid)) ? A.w_s : T(0);
