@@ -52,9 +52,14 @@ def run(P, kind, nit, lit, timing):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kt = s.kernel_timings() if timing else None
+    global LAST_PLAN
+    LAST_PLAN = {"describe": s.describe(), "on_chip_status": s.on_chip_status()}      # which linear-solve path the plan took (OptAmd_PlanDescribe / OptAmd_PlanOnChipStatus)
     out = (dt, c0, s.cost(), steps, kt)
     s.close()
     return out
+
+
+LAST_PLAN = {}
 
 
 def cpu_port(P, kind, lit):
@@ -89,7 +94,7 @@ def main():
         pcg = sum(v[0] for k, v in kt.items() if k in ("PCGStep2", "PCGStep2_2ndHalf", "PCGIteration")) if kt else 0
         row = {"config": name, "solver": kind, "double": P.double, "wall_s": dt, "outer_steps": steps, "cost_initial": c0, "cost_final": c1,
                "pcg_iters_per_s_nominal": steps * lit / dt, "kernel_avg_us": {k: round(v[1] / v[0] * 1e3, 2) for k, v in (kt or {}).items()},
-               "pcg_iterations_in_timed_solve": pcg}
+               "pcg_iterations_in_timed_solve": pcg, "linear_solve_launches_in_timed_solve": (kt or {}).get("PCGSolveOnChip", (0, 0))[0], "plan": LAST_PLAN}
         if with_cpu and not kind.startswith("patch"):
             row["cpu_port"] = cpu_port(make(), kind, min(lit, 10))
             row["gpu_over_cpu_port"] = row["pcg_iters_per_s_nominal"] / row["cpu_port"]["pcg_iters_per_s"]

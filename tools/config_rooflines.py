@@ -27,6 +27,28 @@ MODELS = {
 }
 
 
+# The on-chip shape_from_shading solve (sfs_onchip.h) moves almost nothing through HBM: it is bound by VALU issue.  Instructions of one marching trip (a wave, one held
+# row) from the ISA of the shipped variants (tools/round5: (instr(R = 10) - instr(R = 6)) / 4): 448 in all, 279 of them VALU; a wave64 VALU instruction occupies its SIMD for
+# 4 cycles.  Per PCG iteration a SIMD issues (waves per SIMD) x (R + 4) trips.
+SFS_TRIP_VALU, SFS_TRIP_ALL, CLOCK_HZ = 279.0, 448.0, 2.4e9
+
+
+def sfs_onchip_roofline(r):
+    us = r["kernel_avg_us"].get("PCGSolveOnChip")
+    d = (r.get("plan") or {}).get("describe") or {}
+    if not us or "onchip_rows_per_wave" not in d:
+        return None
+    R, waves = int(d["onchip_rows_per_wave"]), int(d["waves_per_workgroup"])
+    L = 10      # lIterations of the config (an LM early-out can end a launch sooner: the bound below is then pessimistic for the kernel)
+    trips = (waves // 4) * (R + 4)
+    valu_us = L * trips * SFS_TRIP_VALU * 4 / CLOCK_HZ * 1e6
+    return {"kernel": "PCGSolveOnChip = sfs_onchipPcg (one launch per linear solve of up to 10 PCG iterations)", "avg_us": us, "us_per_pcg_iteration": us / L, "bound": "valu-issue",
+            "model": f"{waves // 4} wave(s) per SIMD x {R + 4} marching trips per iteration x {SFS_TRIP_VALU:.0f} VALU instructions per trip x 4 cycles at {CLOCK_HZ / 1e9:.1f} GHz",
+            "valu_issue_us_per_launch": valu_us, "frac": valu_us / us, "unit": "fraction of the launch during which the SIMDs issue the marching trips' VALU instructions",
+            "note": "HBM sees only the constants' re-reads (cache hits) and the ring words; all " + f"{SFS_TRIP_ALL:.0f}" + " instructions of a trip (scalar ones included) at 4 cycles would be "
+                    f"{L * trips * SFS_TRIP_ALL * 4 / CLOCK_HZ * 1e6:.0f} us", "variant": {"rows_per_wave": R, "waves_per_workgroup": waves}}
+
+
 def counters(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
@@ -64,6 +86,12 @@ def main(src, out):
         key = next((k for k in MODELS if k in r["config"]), None)
         if key:
             r["roofline"] = []
+            if key == "config3":
+                o = sfs_onchip_roofline(r)
+                if o:
+                    t = traffic(src, "pmc_config3", "sfs_onchipPcg")
+                    o.update({"traffic": t["total"] if t else None, "traffic_read_write": t})      # HBM bytes per LAUNCH (a whole linear solve)
+                    r["roofline"].append(o)
             for kname, needle, model, what in MODELS[key]:
                 us = r["kernel_avg_us"].get(kname)
                 if not us:
@@ -81,6 +109,9 @@ def main(src, out):
     json.dump({"box": box, "configs": rows}, open(out, "w"), indent=1)
     for r in rows:
         for o in r.get("roofline", []):
+            if o.get("bound") == "valu-issue":
+                print(f"{r['config'][:60]:60s} {o['kernel'][:40]:40s} {o['avg_us']:8.1f} us  VALU issue {o['valu_issue_us_per_launch']:.0f} us = {o['frac']:.2f} of the launch")
+                continue
             print(f"{r['config'][:60]:60s} {o['kernel']:40s} {o['avg_us']:8.1f} us  model {o['achieved']:7.0f} GB/s = {o['frac']:.2f} of HBM peak"
                   + (f", {o['frac_of_cache_resident_peak']:.2f} of the measured cache-resident copy rate" if "frac_of_cache_resident_peak" in o else "")
                   + (f"; PMC traffic {o['traffic'] / 1e6:.0f} MB" if o["traffic"] else ""))
