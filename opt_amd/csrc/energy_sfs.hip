@@ -756,6 +756,7 @@ struct SfsOps : EnergyOps<T> {
     struct SoVariant { int rows, waves; const void* gn; const void* lm; };
     bool soEnabled = true, soFailed = false, soLaunched = false;
     int soForceRows = 0, soForceWaves = 0, soFailAt = -1; long long soTimeoutTicks = 2000LL * 100000;      // 2 s of the 100 MHz wall clock
+    long long* soProf = nullptr;
     oc_u64 *soSlots = nullptr, *soBox = nullptr; int *soBad = nullptr, *soHostErr = nullptr; unsigned soSeq = 0; size_t soSlotBytes = 0, soBoxBytes = 0;
     static const std::vector<SoVariant>& soVariants() {
         static const std::vector<SoVariant> v = [] {
@@ -798,12 +799,15 @@ struct SfsOps : EnergyOps<T> {
             HIP_CHECK(hipHostMalloc((void**)&soHostErr, 64)); *soHostErr = 0;
             HIP_CHECK(hipMemsetAsync(soBad, 0, sizeof(int), ctx.stream));
             soSeq = 0xE0000001u;      // forces the clearing below
+#if SO_PROFILE
+            if (getenv("OPT_AMD_ONCHIP_PROFILE")) { HIP_CHECK(hipMalloc((void**)&soProf, sizeof(long long) * 8 * kSoMaxG)); owned.push_back(soProf); }
+#endif
         }
         if (soSeq > 0xE0000000u || soSeq + (unsigned)L > 0xE0000000u) {      // tags never repeat: start over on cleared buffers long before the counter wraps
             HIP_CHECK(hipMemsetAsync(soSlots, 0, soSlotBytes, ctx.stream)); HIP_CHECK(hipMemsetAsync(soBox, 0, soBoxBytes, ctx.stream));
             soSeq = 2;
         }
-        SfsOcArgs<T> K{A, r0, p0, lmArgs ? lmArgs->CtC : nullptr, delta, stripsX, tilesY, G, L, soSeq, soSlots, soBox, soBad, soTimeoutTicks, soFailAt, lmArgs ? lmArgs->qTolerance : T(0)};
+        SfsOcArgs<T> K{A, r0, p0, lmArgs ? lmArgs->CtC : nullptr, delta, stripsX, tilesY, G, L, soSeq, soSlots, soBox, soBad, soTimeoutTicks, soFailAt, lmArgs ? lmArgs->qTolerance : T(0), soProf};
         soSeq += (unsigned)L;
         {
             ScopedKernel k(ctx, "PCGSolveOnChip");
@@ -814,6 +818,21 @@ struct SfsOps : EnergyOps<T> {
                 return false;
             }
         }
+#if SO_PROFILE
+        if (soProf) {      // development builds: where an iteration's time goes (thread 0 of every workgroup; mean and max over the workgroups)
+            std::vector<long long> h((size_t)G * 8);
+            HIP_CHECK(hipStreamSynchronize(ctx.stream));
+            HIP_CHECK(hipMemcpy(h.data(), soProf, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            const char* names[6] = {"march", "wave-sums", "barrier", "wait", "grid-sum", "update"};
+            fprintf(stderr, "sfs on-chip profile %dx%d rows=%d waves=%d G=%d L=%d (us per iteration: mean / max over workgroups):", A.W, A.H, V->rows, V->waves, G, L);
+            for (int ph = 0; ph < 6; ++ph) {
+                double mean = 0, mx = 0;
+                for (int b = 0; b < G; ++b) { const double v = h[(size_t)b * 8 + ph] * 0.01 / L; mean += v / G; mx = std::max(mx, v); }
+                fprintf(stderr, "  %s %.2f / %.2f", names[ph], mean, mx);
+            }
+            fprintf(stderr, "\n");
+        }
+#endif
         if (lmArgs) sfs_relayBad<<<1, kWave, 0, ctx.stream>>>(soBad, soHostErr);      // (the solver applies the update itself)
         else {
             ScopedKernel k(ctx, "PCGLinearUpdate");

@@ -28,7 +28,6 @@ namespace {
 constexpr int kSoSpan = kWave - 4;
 constexpr int kSoMaxG = 256;                  // workgroups (one per CU)
 constexpr int kSoNS = 5, kSoNW = 2 * kSoNS;   // sums per iteration; tagged words per workgroup
-constexpr int kSoChunk = 16;                  // workgroups per first-level partial of the sum over workgroups (in LDS; fixed, so the bits do not depend on who adds)
 constexpr int kSoDepth = 2;                   // rows of constants in flight ahead of the row being worked on
 
 template <class T>
@@ -43,7 +42,19 @@ struct SfsOcArgs {
     oc_u64* apBox;                      // [2][W * H * sizeof(T) / 4]
     int* bad; long long timeoutTicks; int failAt;
     T qTolerance;
+    long long* prof;                    // SO_PROFILE builds: [G][8] ticks per phase (wave 0 of every workgroup), else nullptr
 };
+
+// Development builds (opt_amd/build.py build_variant with SO_PROFILE=1; OPT_AMD_ONCHIP_PROFILE=1): thread 0 of every workgroup accumulates the wall-clock ticks
+// (100 MHz) it spends in each phase of an iteration and leaves them in K.prof[workgroup][8].
+#ifndef SO_PROFILE
+#define SO_PROFILE 0
+#endif
+#if SO_PROFILE
+#define SO_MARK(i) do { if (tid == 0) { const long long t_ = wall_clock64(); soProf[i] += t_ - soPrev; soPrev = t_; } } while (0)
+#else
+#define SO_MARK(i) do { } while (0)
+#endif
 
 template <class T> struct SoRowC { T g0, g1, g2; int fb; };
 template <class T> struct SoRow { T v, rk, g0, g1, g2, wr, wc, ws; int ex; };      // a staged row: p, r, dB_I / d{d0, d1, d2}, the three mask multipliers (see the march), `not excluded`
@@ -58,11 +69,11 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
     constexpr int kSoWaves = WAVES, kSoBlock = WAVES * kWave;
     constexpr int HR = R + 4;                          // held rows: two above and two below the R owned ones
     constexpr int WPS = (int)sizeof(T) / 4;            // tagged words per scalar
+    constexpr bool VREG_ARGS = true;
     static_assert(R >= 2, "the ring must come from the adjacent tiles only");
     static_assert(HR % kSoDepth == 0, "the rows requested behind the last trip are the first rows of the next iteration");
     __shared__ double red[kSoNS * kSoWaves];
     __shared__ double TOT[kSoNS + 1];
-    __shared__ double GS[(kSoMaxG / kSoChunk) * kSoNS];
     __shared__ unsigned W1[kSoMaxG * kSoNW];
     // b = r_0 of the owned pixels (LM: for Q) and -- where the registers are short: double, R >= 8 -- the A p of the owned pixels between the march and the update:
     // [row][thread], conflict-free
@@ -89,10 +100,6 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
 
     auto rowIn = [&](int h) { const int y = yBase - 2 + h; return xin && y >= 0 && y < A.H; };
     auto rowIdx = [&](int h) { const int y = yBase - 2 + h; return (y >= 0 && y < A.H && !idle) ? y * A.W + xc : xc; };      // a valid address either way
-    auto uni = [](T v) -> T {
-        if constexpr (sizeof(T) == 8) return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-        else return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
-    };
 
     // the P(u) coefficient of held row h, wave-uniform: lane h computes it once, a trip reads it from there into scalar registers
     const T cyLane = coefK(A, 1, 0, yBase - 2 + lane);
@@ -114,12 +121,17 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
     for (int i = 0; i < R; ++i) { if (DL_LDS) dlL[(DL_LDS ? i : 0) * kSoBlock + tid] = 0; else dl[DL_LDS ? 0 : i] = 0; if (!AP_LDS) apOwn[AP_LDS ? 0 : i] = 0; else apL[(AP_LDS ? i : 0) * kSoBlock + tid] = 0; if (LM) bL[(LM ? i : 0) * kSoBlock + tid] = r[i + 2]; }      // b = r_0 (solver.t:657)
 
     int pixBase = (yBase - 2) * A.W + xc;      // (opaque per iteration below: addresses are recomputed, not kept)
+    // The array bases and the three weights are uniform, and the scalar registers are short (lane masks of every predicate live there): kept there, they are spilled to
+    // vector lanes and read back -- 32 v_readlane per trip.  As (opaque) vector registers they cost nothing per use.
+    const T *g0p = A.g0, *g1p = A.g1, *g2p = A.g2, *ctcp = K.CtC; const uint32_t* flp = A.fl2;
+    T wG = A.w_g, wS = A.w_s, wP = A.w_p;
+    if (VREG_ARGS) asm volatile("" : "+v"(g0p), "+v"(g1p), "+v"(g2p), "+v"(ctcp), "+v"(flp), "+v"(wG), "+v"(wS), "+v"(wP));
     // the constants of a held row (read-only while the kernel runs: plain cached loads); the first kSoDepth rows of an iteration are requested BEFORE the wait of
     // the iteration before, the others kSoDepth trips ahead of their use
     auto loadRow = [&](int h) {
         SoRowC<T> c;
         const int i = rowIdx(h);
-        c.g0 = A.g0[i]; c.g1 = A.g1[i]; c.g2 = A.g2[i]; c.fb = (int)A.fl2[i];
+        c.g0 = g0p[i]; c.g1 = g1p[i]; c.g2 = g2p[i]; c.fb = (int)flp[i];
         return c;
     };
     SoRowC<T> cq[kSoDepth];
@@ -130,6 +142,9 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
     T Q0 = 0;                                  // fetchQ before the loop (solver.t:1050): delta = 0, so exactly 0
     const size_t boxStride = (size_t)N * WPS;
 
+#if SO_PROFILE
+    long long soProf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, soPrev = wall_clock64();
+#endif
     for (int k = 0; k < K.L; ++k) {
         // What is derived from the tile's position (row addresses of six arrays, bounds predicates) is invariant over the solve; hoisted out of this loop it would occupy
         // a hundred registers.  The empty asm makes the sources opaque per iteration, so each use recomputes its two or three instructions.
@@ -150,9 +165,10 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
             T ctcQ[2] = {0, 0};      // CtC of the owned rows: requested when the row is staged, used two trips later by its gather
 #pragma unroll
             for (int h = 0; h < HR; ++h) {
+                asm volatile("" : "+s"(yBase), "+v"(xc));      // (per trip: the row predicates and addresses of all trips are otherwise formed at the top of the iteration and kept -- in scalar registers the kernel does not have)
                 const SoRowC<T> c = cq[h % kSoDepth];
                 const T ctcNow = ctcQ[h % 2];
-                if (LM && h >= 2 && h < R + 2) ctcQ[h % 2] = K.CtC[rowIdx(h)];
+                if (LM && h >= 2 && h < R + 2) ctcQ[h % 2] = ctcp[rowIdx(h)];
                 cq[h % kSoDepth] = loadRow((h + kSoDepth) % HR);      // (behind the last rows: rows 0 .. kSoDepth - 1 of the next iteration)
                 const int Y = yBase - 2 + h;
                 // The staged row.  The masks of sfs_pcgMarch -- `interior row centre ? w_g * edge mask : 0`, `regularisation rows on ? w_s : 0` -- are formed ONCE per
@@ -166,8 +182,8 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
                     //  that is exactly 0 there, or end in an output that the `excluded` test below zeroes)
                     n.g0 = c.g0; n.g1 = c.g1; n.g2 = c.g2;
                     const bool ok = in && sfs_interior(A, x, Y);
-                    n.wr = ok ? A.w_g * (T)sfsMr(c.fb) : T(0); n.wc = ok ? A.w_g * (T)sfsMc(c.fb) : T(0);
-                    n.ws = (ok && (c.fb & kSfsValid)) ? A.w_s : T(0);
+                    n.wr = ok ? wG * (T)sfsMr(c.fb) : T(0); n.wc = ok ? wG * (T)sfsMc(c.fb) : T(0);
+                    n.ws = (ok && (c.fb & kSfsValid)) ? wS : T(0);
                     n.ex = in ? (c.fb & kSfsEx) : 0;
                 }
                 const T cyN = uniLane(cyLane, h);
@@ -197,7 +213,7 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
                     const T ve = R2.v;
                     T s = 0;
                     auto add = [&](T coef, T q) { s += coef * q; };
-                    add(A.w_p, A.w_p * ve);      // the fitting row
+                    add(wP, wP * ve);      // the fitting row
                     const T g0r = dppShift<false>(R2.g0);
                     const T wrR = dppShift<false>(R2.wr), wrL = dppShift<true>(R2.wr), wr1L = dppShift<true>(R1.wr);
                     const T wcR = dppShift<false>(R2.wc), wc3R = dppShift<false>(R3.wc);
@@ -241,6 +257,7 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
                 __builtin_amdgcn_sched_barrier(0);      // one row per scheduling region: left to itself the scheduler interleaves the unrolled rows until their temporaries fill the register budget
             }
         }
+        SO_MARK(0);      // march
         if (!first) accX = accQ;      // Q of the iteration before (LM; 0 otherwise)
         asm volatile("" : "+v"(pixBase), "+v"(xc), "+s"(yBase));      // (the row predicates of the march are not kept for the wait: recomputed there)
 
@@ -250,7 +267,9 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
 #pragma unroll
             for (int q = 0; q < kSoNS; ++q) { v5[q] = ocWaveSum63(v5[q]); if (lane == kWave - 1) red[q * kSoWaves + wave] = v5[q]; }
         }
+        SO_MARK(1);      // wave sums
         __syncthreads();
+        SO_MARK(2);      // barrier: the slowest wave's march
         if (tid < kSoNW) {
             double s = 0;
             for (int w = 0; w < kSoWaves; ++w) s += red[(tid >> 1) * kSoWaves + w];
@@ -261,16 +280,22 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
         // requested together, re-requested until all carry this iteration's tag
         T ring[HR];
         {
+            // (measured: a word-major layout that lets every wave request "its" sum directly -- no staging -- makes eight workgroups post into one 64-byte line: the wait
+            //  grows from 3.5 to 5.6 us.  Workgroup-major words, thread i requests word i, the words are regrouped through LDS.)
             constexpr int kPer = (kSoMaxG * kSoNW + kSoBlock - 1) / kSoBlock;
             oc_u64 w[kPer];
             const int nW = K.G * kSoNW;
             const bool lastIt = k + 1 == K.L;      // (after the last iteration only delta survives: nobody needs the ring)
             auto need = [&](int h) { return !lastIt && rowIn(h) && !(writer && h >= 2 && h < R + 2); };
-            auto fetch = [&]() {
-                bool ok = true;
-                oc_u64 rw[HR][WPS];
+            oc_u64 rw[HR][WPS];
+            bool sumsOk = false, ringOk = false;
+            // requests and checks apart: the first round asks for everything at once; a later round asks again only for what has not arrived (the ring words are
+            // posted before their owners' sums and are normally there by then: the re-requests are the ten words of the sums)
+            auto askSums = [&]() {
 #pragma unroll
                 for (int u = 0; u < kPer; ++u) { const int i = tid + u * kSoBlock; w[u] = ocLoad(slotPar + (i < nW ? i : tid % nW)); }
+            };
+            auto askRing = [&]() {
 #pragma unroll
                 for (int h = 0; h < HR; ++h) {
 #pragma unroll
@@ -281,23 +306,34 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
                         for (int q = 0; q < WPS; ++q) rw[h][q] = ocLoad(box + i + q);
                     }
                 }
-#pragma unroll
-                for (int u = 0; u < kPer; ++u) { const int i = tid + u * kSoBlock; ok = ok && (i >= nW || (unsigned)(w[u] >> 32) == tag); }
-#pragma unroll
-                for (int h = 0; h < HR; ++h) {
-#pragma unroll
-                    for (int q = 0; q < WPS; ++q) ok = ok && (unsigned)(rw[h][q] >> 32) == tag;
-                    if constexpr (WPS == 1) ring[h] = __uint_as_float((unsigned)rw[h][0]);
-                    else ring[h] = __longlong_as_double((long long)((rw[h][WPS - 1] << 32) | (rw[h][0] & 0xffffffffull)));
-                }
-                return ok;
             };
-            if (!fetch()) {
+            auto check = [&]() {
+                if (!sumsOk) {
+                    bool ok = true;
+#pragma unroll
+                    for (int u = 0; u < kPer; ++u) { const int i = tid + u * kSoBlock; ok = ok && (i >= nW || (unsigned)(w[u] >> 32) == tag); }
+                    sumsOk = ok;
+                }
+                if (!ringOk) {
+                    bool ok = true;
+#pragma unroll
+                    for (int h = 0; h < HR; ++h) {
+#pragma unroll
+                        for (int q = 0; q < WPS; ++q) ok = ok && (unsigned)(rw[h][q] >> 32) == tag;
+                    }
+                    ringOk = ok;
+                }
+                return sumsOk && ringOk;
+            };
+            askSums(); askRing();
+            if (!check()) {
                 const long long t0 = wall_clock64();
                 unsigned spins = 0;
                 for (;;) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (fetch()) break;
+                    if (!sumsOk) askSums();
+                    if (!ringOk) askRing();
+                    if (check()) break;
                     if ((++spins & 31u) == 0) {
                         if (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                         if (wall_clock64() - t0 > to) { __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
@@ -305,21 +341,35 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
                 }
             }
 #pragma unroll
+            for (int h = 0; h < HR; ++h) {
+                if constexpr (WPS == 1) ring[h] = __uint_as_float((unsigned)rw[h][0]);
+                else ring[h] = __longlong_as_double((long long)((rw[h][WPS - 1] << 32) | (rw[h][0] & 0xffffffffull)));
+            }
+            SO_MARK(3);      // the wait: ring + sums words
+#pragma unroll
             for (int u = 0; u < kPer; ++u) { const int i = tid + u * kSoBlock; if (i < nW) W1[i] = (unsigned)w[u]; }
             __syncthreads();
-            // every workgroup adds all workgroups' words in the same order: chunks of 16 workgroups, then the chunks
-            const int nChunks = (K.G + kSoChunk - 1) / kSoChunk;
-            if (tid < nChunks * kSoNS) {
-                const int q = tid % kSoNS, ch = tid / kSoNS, n = min(kSoChunk, K.G - ch * kSoChunk);
-                double s = 0;
-                for (int m = 0; m < n; ++m) s += ocJoin(W1[(ch * kSoChunk + m) * kSoNW + 2 * q], W1[(ch * kSoChunk + m) * kSoNW + 2 * q + 1]);
-                GS[ch * kSoNS + q] = s;
+            // Every workgroup adds all workgroups' words in the same order: wave q (the fifth sum: wave 0 again) takes sum q, a lane the workgroups lane, lane + 64,
+            // lane + 128, lane + 192 in that order, then the wave's DPP tree -- the same association everywhere, so the same bits.
+#pragma unroll
+            for (int pass = 0; pass < (kSoNS + kSoWaves - 1) / kSoWaves; ++pass) {
+                const int q = wave + pass * kSoWaves;
+                if (q < kSoNS) {
+                    double sacc = 0;
+#pragma unroll
+                    for (int c = 0; c < kSoMaxG / kWave; ++c) {
+                        const int m = lane + c * kWave;
+                        const double v = m < K.G ? ocJoin(W1[m * kSoNW + 2 * q], W1[m * kSoNW + 2 * q + 1]) : 0.0;
+                        sacc += v;
+                    }
+                    sacc = ocWaveSum63(sacc);
+                    if (lane == kWave - 1) TOT[q] = sacc;
+                }
             }
-            __syncthreads();
-            if (tid < kSoNS) { double s = 0; for (int ch = 0; ch < nChunks; ++ch) s += GS[ch * kSoNS + tid]; TOT[tid] = s; }
             if (tid == 0) reinterpret_cast<int*>(TOT + kSoNS)[0] = __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
         }
+        SO_MARK(4);      // sum over workgroups
         const double aNumD = TOT[0], aDenD = TOT[1], s2 = TOT[2], s3 = TOT[3], xD = TOT[4];
         if (reinterpret_cast<const int*>(TOT + kSoNS)[0]) { failed = true; break; }      // uniform over the workgroup: a wait timed out somewhere
         if (LM && !first) {      // the q early-out of iteration k - 1 (solver.t:1093-1102): nothing of iteration k has been applied yet
@@ -354,7 +404,11 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
                 p[h] = soFma(beta, p[h], r[h]);
             }
         }
+        SO_MARK(5);      // update
     }
+#if SO_PROFILE
+    if (tid == 0 && K.prof) { for (int i = 0; i < 8; ++i) K.prof[(long)g * 8 + i] = soProf[i]; }
+#endif
     if (!failed && writer) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
