@@ -28,9 +28,9 @@ MODELS = {
 
 
 # The on-chip shape_from_shading solve (sfs_onchip.h) moves almost nothing through HBM: it is bound by VALU issue.  Instructions of one marching trip (a wave, one held
-# row) from the ISA of the shipped variants (tools/round5: (instr(R = 10) - instr(R = 6)) / 4): 448 in all, 279 of them VALU; a wave64 VALU instruction occupies its SIMD for
+# row) from the ISA of the shipped variants ((instr(R = 10) - instr(R = 6)) / 4, double LM): 343 in all, 199 of them VALU; a wave64 VALU instruction occupies its SIMD for
 # 4 cycles.  Per PCG iteration a SIMD issues (waves per SIMD) x (R + 4) trips.
-SFS_TRIP_VALU, SFS_TRIP_ALL, CLOCK_HZ = 279.0, 448.0, 2.4e9
+SFS_TRIP_VALU, SFS_TRIP_ALL, CLOCK_HZ = 199.0, 343.0, 2.4e9
 
 
 def sfs_onchip_roofline(r):
