@@ -807,7 +807,7 @@ struct SfsOps : EnergyOps<T> {
             HIP_CHECK(hipMemsetAsync(soSlots, 0, soSlotBytes, ctx.stream)); HIP_CHECK(hipMemsetAsync(soBox, 0, soBoxBytes, ctx.stream));
             soSeq = 2;
         }
-        SfsOcArgs<T> K{A, r0, p0, lmArgs ? lmArgs->CtC : nullptr, delta, stripsX, tilesY, G, L, soSeq, soSlots, soBox, soBad, soTimeoutTicks, soFailAt, lmArgs ? lmArgs->qTolerance : T(0), soProf};
+        SfsOcArgs<T> K{A, r0, p0, lmArgs ? lmArgs->CtC : nullptr, delta, stripsX, tilesY, G, L, soSeq, soSlots, soBox, soBad, soTimeoutTicks, soFailAt, lmArgs ? lmArgs->qTolerance : T(0), lmArgs ? soHostErr : nullptr, soProf};
         soSeq += (unsigned)L;
         {
             ScopedKernel k(ctx, "PCGSolveOnChip");
@@ -833,8 +833,7 @@ struct SfsOps : EnergyOps<T> {
             fprintf(stderr, "\n");
         }
 #endif
-        if (lmArgs) sfs_relayBad<<<1, kWave, 0, ctx.stream>>>(soBad, soHostErr);      // (the solver applies the update itself)
-        else {
+        if (!lmArgs) {      // (LM: the solver applies the update itself; a workgroup that gave up has told the host on its way out)
             ScopedKernel k(ctx, "PCGLinearUpdate");
             const long N = (long)A.W * A.H;
             sfs_applyDelta<T><<<grid(), kBlock, 0, ctx.stream>>>(const_cast<T*>(A.X), delta, N, soBad, soHostErr);

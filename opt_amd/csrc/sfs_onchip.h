@@ -42,6 +42,7 @@ struct SfsOcArgs {
     oc_u64* apBox;                      // [2][W * H * sizeof(T) / 4]
     int* bad; long long timeoutTicks; int failAt;
     T qTolerance;
+    int* hostErr;                       // LM (the solver applies the update itself): pinned host word a workgroup that gave up raises on its way out; GN: nullptr (sfs_applyDelta tells the host)
     long long* prof;                    // SO_PROFILE builds: [G][8] ticks per phase (wave 0 of every workgroup), else nullptr
 };
 
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
 #if SO_PROFILE
     if (tid == 0 && K.prof) { for (int i = 0; i < 8; ++i) K.prof[(long)g * 8 + i] = soProf[i]; }
 #endif
+    if (failed && tid == 0 && K.hostErr) __hip_atomic_store(K.hostErr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (!failed && writer) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -428,10 +430,6 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
     }
 }
 
-// behind an on-chip solve whose update the solver applies itself (Levenberg-Marquardt): tell the host if a wait timed out
-__global__ void sfs_relayBad(const int* __restrict__ bad, int* hostErr) {
-    if (threadIdx.x == 0 && __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) __hip_atomic_store(hostErr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 // PCGLinearUpdate X += delta (solver.t:552-557) behind the on-chip Gauss-Newton solve -- unless a wait timed out: then the unknowns stay untouched and the host is told
 template <class T>
 __global__ __launch_bounds__(kBlock) void sfs_applyDelta(T* __restrict__ X, const T* __restrict__ delta, long N, const int* __restrict__ bad, int* hostErr) {

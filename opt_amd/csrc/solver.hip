@@ -990,6 +990,7 @@ struct PcgSolver : SolverBase {
                 onChipOk = false; onChipFellBack = true; lastStepOnChip = false; unknownsUpdated = false;
                 if (lm) {      // the kernel produced no delta: the update above added nothing meaningful -- back to the saved unknowns, then the launch-per-iteration loop
                     imageOp(2);
+                    HIP_CHECK(hipMemsetAsync(delta, 0, nPad * sizeof(T), stream));      // (workgroups that had finished before the others gave up may have written theirs)
                     if (!runSingleKernelLoopLM(preArg, T(0), q_tolerance)) { fprintf(stderr, "Opt(amd): the streaming LM loop refused the redo\n"); exit(1); }
                 } else {
                     // Gauss-Newton: nothing was applied (iw_applyDelta checks the flag -- in slab mode the all-reduced verdict, so no rank kept its update).
