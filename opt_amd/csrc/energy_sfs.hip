@@ -830,6 +830,7 @@ struct SfsOps : EnergyOps<T> {
                 for (int b = 0; b < G; ++b) { const double v = h[(size_t)b * 8 + ph] * 0.01 / L; mean += v / G; mx = std::max(mx, v); }
                 fprintf(stderr, "  %s %.2f / %.2f", names[ph], mean, mx);
             }
+            { double r6 = 0, r7 = 0; for (int b = 0; b < G; ++b) { r6 += (double)h[(size_t)b * 8 + 6] / L / G; r7 += h[(size_t)b * 8 + 7] * 0.01 / L / G; } fprintf(stderr, "  [thread 0: first round %.2f us, %.2f further rounds per iteration]", r7, r6); }
             fprintf(stderr, "\n");
         }
 #endif

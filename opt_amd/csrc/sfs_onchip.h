@@ -337,13 +337,22 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
                 return sumsOk && ringOk;
             };
             askSums(); askRing();
+#if SO_PROFILE
+            const bool firstOk = check();
+            if (tid == 0) { const long long t_ = wall_clock64(); soProf[7] += t_ - soPrev; }      // (slot 7: the first round alone; slot 6: rounds after it, counted by thread 0)
+            if (!firstOk) {
+#else
             if (!check()) {
+#endif
                 const long long t0 = wall_clock64();
                 unsigned spins = 0;
                 for (;;) {
                     __builtin_amdgcn_s_sleep(1);
                     if (!sumsOk) askSums();
                     if (!ringOk) askRing();
+#if SO_PROFILE
+                    if (tid == 0) soProf[6] += 1;
+#endif
                     if (check()) break;
                     if ((++spins & 31u) == 0) {
                         if (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
