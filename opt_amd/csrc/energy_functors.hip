@@ -3,6 +3,7 @@
 // against a scalar type S that the engine instantiates as T or as a dual number.
 #include "stencil_engine.h"
 #include "stencil_march.h"
+#include "stencil_onchip.h"
 #include "graph_common.h"      // makeVolumetricOnArap
 
 namespace optamd {
@@ -221,6 +222,20 @@ struct OpticalFlowOps : StencilOps<T, OpticalFlowE<T>> {
         return march.launch(FlowMarchOp<T>{this->e.w_fit, this->e.w_reg}, this->e.W, this->e.H, nullptr, this->cus, a, ctx, coef);
     }
     const T* pcgFinish(const T*, T* delta, LaunchCtx& ctx) override { return march.finish(delta, 2L * this->e.W * this->e.H, this->cus, ctx); }
+    // ---- the whole Gauss-Newton linear solve on chip (stencil_onchip.h); the operator's per-pixel coefficient is formed first, as for the marching loop ----
+    OnchipMarch<T> oc;
+    bool onChipWithoutPreconditioner() const override { return true; }
+    bool pcgSolveOnChip(const T* r0, const T* p0, T* delta, int L, double* traceDev, const OnChipLm<T>* lm, LaunchCtx& ctx) override {
+        if (!useMarch || lm || traceDev || this->slab.active) return false;
+        int sx, ty, G;
+        if (!oc.enabled || oc.failed || !oc.template select<FlowMarchOp<T>>(this->e.W, this->e.H, this->cus, sx, ty, G)) return false;      // (before the coefficient pass is spent)
+        const long n = (long)this->e.W * this->e.H;
+        if (!coef) HIP_CHECK(hipMalloc((void**)&coef, (size_t)(2 * n) * sizeof(T)));
+        { ScopedKernel k(ctx, "operatorCoefficients"); flow_coef<T><<<this->grid(), kBlock, 0, ctx.stream>>>(this->e, coef); }
+        return oc.solve(FlowMarchOp<T>{this->e.w_fit, this->e.w_reg}, this->e.W, this->e.H, nullptr, coef, r0, p0, delta, const_cast<T*>(this->e.X[0]), L, this->cus, ctx);
+    }
+    bool onChipFailed() override { return oc.failedNow(); }
+    std::string describe(int L, bool lmv) override { return oc.template describe<FlowMarchOp<T>>(this->e.W, this->e.H, this->cus, useMarch ? L : 0, lmv, "march_pcgIter"); }
 };
 template <class T> EnergyOps<T>* makeFlow(const unsigned* dims) { return new OpticalFlowOps<T>(dims); }
 // ---- intrinsic_image_decomposition's Gauss-Newton PCG loop on the marching template ------------------------------------------------------------------------------

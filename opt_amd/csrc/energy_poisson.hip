@@ -15,6 +15,7 @@
 // PCG loop runs on the marching template of stencil_march.h (one launch per iteration, 65 B/pixel in float).
 #include "energy.h"
 #include "stencil_march.h"
+#include "stencil_onchip.h"
 
 namespace optamd {
 namespace {
@@ -288,6 +289,15 @@ struct PoissonOps : EnergyOps<T> {
         return march.launch(PoissonMarchOp<T>{}, A.W, A.H, flags, cus, a, ctx);
     }
     const T* pcgFinish(const T*, T* delta, LaunchCtx& ctx) override { return march.finish(delta, 4L * A.W * A.H, cus, ctx); }
+    // ---- the whole Gauss-Newton linear solve on chip (stencil_onchip.h) ----
+    OnchipMarch<T> oc;
+    bool onChipWithoutPreconditioner() const override { return true; }
+    bool pcgSolveOnChip(const T* r0, const T* p0, T* delta, int L, double* traceDev, const OnChipLm<T>* lm, LaunchCtx& ctx) override {
+        if (!singleKernel || lm || traceDev || this->slab.active) return false;
+        return oc.solve(PoissonMarchOp<T>{}, A.W, A.H, flags, nullptr, r0, p0, delta, const_cast<T*>(A.X), L, cus, ctx);
+    }
+    bool onChipFailed() override { return oc.failedNow(); }
+    std::string describe(int L, bool lmv) override { return oc.template describe<PoissonMarchOp<T>>(A.W, A.H, cus, singleKernel ? L : 0, lmv, "march_pcgIter"); }
     // ---- patch solver: ping-pong between the caller's X and a scratch copy; patchFinish leaves the result in the caller's buffer
     T* scratchX = nullptr; bool inScratch = false;
     bool supportsPatch() const override { return true; }
@@ -394,6 +404,14 @@ struct LaplacianOps : EnergyOps<float> {
         return march.launch(LaplacianMarchOp{}, A.W, A.H, nullptr, cus, a, ctx);
     }
     const float* pcgFinish(const float*, float* delta, LaunchCtx& ctx) override { return march.finish(delta, (long)A.W * A.H, cus, ctx); }
+    OnchipMarch<float> oc;      // the whole Gauss-Newton linear solve on chip (stencil_onchip.h)
+    bool onChipWithoutPreconditioner() const override { return true; }
+    bool pcgSolveOnChip(const float* r0, const float* p0, float* delta, int L, double* traceDev, const OnChipLm<float>* lm, LaunchCtx& ctx) override {
+        if (lm || traceDev || this->slab.active) return false;
+        return oc.solve(LaplacianMarchOp{}, A.W, A.H, nullptr, nullptr, r0, p0, delta, const_cast<float*>(A.X), L, cus, ctx);
+    }
+    bool onChipFailed() override { return oc.failedNow(); }
+    std::string describe(int L, bool lmv) override { return oc.describe<LaplacianMarchOp>(A.W, A.H, cus, L, lmv, "march_pcgIter"); }
 };
 
 template <class T> EnergyOps<T>* makePoisson(const unsigned* dims) { return new PoissonOps<T>(dims); }

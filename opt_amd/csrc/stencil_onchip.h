@@ -1,0 +1,378 @@
+// 5-point stencils with C channels per pixel (the operators of stencil_march.h: poisson_image_editing, the minimal laplacian, optical_flow): the WHOLE PCG linear solve
+// of a Gauss-Newton step as one persistent launch whose loop state never leaves the chip.
+//
+// What it replaces: the reference's loop `for lIter = 0, lIterations do PCGStep1; PCGStep2; PCGStep3 end` (solverGPUGaussNewton.t:1056-1092) -- one marching launch per
+// iteration in march_pcgIter, 11-16 us each on images that are all launch latency (BASELINE config 1: poisson 256^2).  The protocol is sfs_onchip.h's with a one-pixel ring:
+//   tile    a WAVE holds 64 columns x (R + 2) rows of p and r in registers and owns the 62 x R pixels in the middle; the ring is updated by the holder with the owner's
+//           alpha, beta and the same fused operations, so the search direction never travels;
+//   A p     Op::apply on the owned rows (neighbouring columns: whole-wave DPP shifts; rows above / below: the lane's own registers); flag bit and operator coefficients
+//           of the held pixels stay in registers for the whole solve;
+//   ring    the A p of a tile's outermost rows / columns goes to a tagged image (8-byte {payload, tag} words, relaxed agent-scope stores, parity-double-buffered) and is
+//           picked up by the ring holders inside the ONE wait per iteration that also carries the four sums (alphaNum, alphaDen, s2, s3; beta by expansion as in
+//           march_pcgIter, including the reference's start: p_0 = r_0 / 4, alphaNumerator_0 = r_0 . p_0, so sum r_0^2 = 4 alphaNumerator_0 exactly);
+//   sums    every workgroup posts its partial sums as tagged words and adds ALL workgroups' words in the same order: the same bits everywhere.
+// Every wait is bounded by the device's wall clock; a time-out raises `bad`, nothing is written to delta, the unknowns stay untouched (march_applyDelta checks the flag) and
+// the host redoes the linear solve with the marching kernels.  The grid must be co-resident (one workgroup per CU): the launcher checks workgroups <= CUs.
+// Gauss-Newton only (as the marching loop: the Levenberg-Marquardt loop of these energies keeps the generic kernels); not for Op::kSplit31 (intrinsic_image_decomposition).
+#pragma once
+#include "stencil_march.h"
+#include "onchip_sync.h"
+
+namespace optamd {
+namespace {
+
+constexpr int kMoSpan = kWave - 2;            // pixels a wave owns per row (one DPP ring)
+constexpr int kMoMaxG = 256;                  // workgroups (one per CU)
+constexpr int kMoNS = 4, kMoNW = 2 * kMoNS;   // sums per iteration; tagged words per workgroup
+
+template <class T>
+struct MoArgs {
+    int W, H;
+    const T* r0; const T* p0; T* delta;     // solver vectors: C channels per pixel, interleaved
+    const uint8_t* flags; const T* coef;    // Op::kMasked / Op::kCoef
+    int stripsX, tilesY, G, L;
+    unsigned tag0;                          // tag of iteration 0 (tags never repeat over the life of the buffers)
+    oc_u64* slots;                          // [2][G][8]
+    oc_u64* apBox;                          // [2][W * H * C * sizeof(T) / 4]
+    int* bad; long long timeoutTicks; int failAt;
+};
+
+__device__ __forceinline__ float moFma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double moFma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+template <class T, class Op, int R, int WAVES>
+__global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T> K) {
+    static_assert(!Op::kSplit31, "one image of C channels per pixel");
+    constexpr int C = Op::C, HR = R + 2, kBlk = WAVES * kWave, WPS = (int)sizeof(T) / 4;
+    constexpr int kCoefN = Op::kCoef > 0 ? Op::kCoef : 1;
+    using Vec = MVec<T, C>; using Coef = MVec<T, kCoefN>;
+    __shared__ double red[kMoNS * WAVES];
+    __shared__ double TOT[kMoNS + 1];
+    __shared__ unsigned W1[kMoMaxG * kMoNW];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = blockIdx.x;
+    const int tile = g * WAVES + wave;
+    const int sx = tile % K.stripsX, ty = tile / K.stripsX;
+    const bool idle = ty >= K.tilesY;                  // (wave-uniform) a wave without a tile: contributes zeros to the sums
+    const int x = sx * kMoSpan + lane - 1;
+    const int yBase = ty * R;                          // first owned row; held row h is image row yBase - 1 + h
+    const bool xin = !idle && x >= 0 && x < K.W;
+    const bool writer = xin && lane >= 1 && lane <= kMoSpan;
+    const bool hasL = x >= 1, hasR = x + 1 < K.W;
+    const int xc = min(max(x, 0), K.W - 1);
+    const int N = K.W * K.H;
+    int* const bad = K.bad;
+    const long long to = K.timeoutTicks;
+
+    // ---- p_0, r_0, the flag bit and the operator coefficients of the held pixels (a pixel outside the image or switched off: zeros, off); delta = 0 ----------------
+    Vec p[HR], r[HR], dl[R], ap[R];
+    Coef cf[HR];
+    unsigned onBits = 0;
+#pragma unroll
+    for (int h = 0; h < HR; ++h) {
+        const int y = yBase - 1 + h;
+        const bool in = xin && y >= 0 && y < K.H;
+        const long i = in ? (long)y * K.W + xc : (long)xc;      // a valid address either way
+        bool on = in;
+        if (Op::kMasked) on = on && (K.flags[i] & 1);
+#pragma unroll
+        for (int c = 0; c < C; ++c) { const T pv = K.p0[i * C + c], rv = K.r0[i * C + c]; p[h].v[c] = on ? pv : T(0); r[h].v[c] = on ? rv : T(0); }
+#pragma unroll
+        for (int c = 0; c < kCoefN; ++c) cf[h].v[c] = Op::kCoef > 0 ? K.coef[i * kCoefN + c] : T(0);
+        onBits |= on ? (1u << h) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int c = 0; c < C; ++c) { dl[i].v[c] = 0; ap[i].v[c] = 0; }
+
+    const int pixBase = (yBase - 1) * K.W + xc;      // index of held row 0 of this lane's column (used only where the row exists)
+    auto rowIn = [&](int h) { const int y = yBase - 1 + h; return xin && y >= 0 && y < K.H; };
+    bool failed = false;
+    const size_t boxStride = (size_t)N * C * WPS;
+
+    for (int k = 0; k < K.L; ++k) {
+        const unsigned tag = K.tag0 + (unsigned)k;
+        const int par = (int)(tag & 1u);
+        oc_u64* const box = K.apBox + (size_t)par * boxStride;
+        oc_u64* const slotPar = K.slots + (size_t)par * K.G * kMoNW;
+        if (k == K.failAt && g == 0 && tid == 0) __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool first = k == 0;
+
+        // ---- PCGStep1: A p_k on the owned pixels, with the four sums (march_pcgIter's expressions) --------------------------------------------------------------
+        double accDen = 0, accNum = 0, acc2 = 0, acc3 = 0;
+        if (!idle) {
+#pragma unroll
+            for (int h = 1; h <= R; ++h) {
+                const int y = yBase - 1 + h;
+                const Vec pl = marchShift<true>(p[h]), pr = marchShift<false>(p[h]);
+                Vec o = op.apply(p[h], pl, pr, p[h - 1], p[h + 1], hasL, hasR, y - 1 >= 0, y + 1 < K.H, cf[h]);
+                const bool on = (onBits >> h) & 1u;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { o.v[c] = on ? o.v[c] : T(0); ap[h - 1].v[c] = o.v[c]; }
+                if (writer && y < K.H) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const double rr = (double)r[h].v[c], a = (double)o.v[c], pp = (double)p[h].v[c];
+                        accNum += (first ? pp : rr) * rr;      // z_0 . r_0 is the reference's r_0 . p_0
+                        accDen += pp * a; acc2 += rr * a; acc3 += a * a;
+                    }
+                    // the tile's outermost rows / columns: to the tagged image, for whoever holds them as ring
+                    if (h == 1 || h == R || lane == 1 || lane == kMoSpan) {
+                        const size_t i = (size_t)(pixBase + h * K.W) * C * WPS;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            if constexpr (WPS == 1) ocStore(box + i + c, tag, __float_as_uint((float)o.v[c]));
+                            else { const oc_u64 b = (oc_u64)__double_as_longlong((double)o.v[c]); ocStore(box + i + 2 * c, tag, (unsigned)b); ocStore(box + i + 2 * c + 1, tag, (unsigned)(b >> 32)); }
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        // ---- the grid-wide sums; the ring's A p is collected inside the wait ------------------------------------------------------------------------------------
+        {
+            double v4[kMoNS] = {accNum, accDen, acc2, acc3};
+#pragma unroll
+            for (int q = 0; q < kMoNS; ++q) { v4[q] = ocWaveSum63(v4[q]); if (lane == kWave - 1) red[q * WAVES + wave] = v4[q]; }
+        }
+        __syncthreads();
+        if (tid < kMoNW) {
+            double s = 0;
+            for (int w = 0; w < WAVES; ++w) s += red[(tid >> 1) * WAVES + w];
+            const oc_u64 b = (oc_u64)__double_as_longlong(s);
+            ocStore(slotPar + (size_t)g * kMoNW + tid, tag, (tid & 1) ? (unsigned)(b >> 32) : (unsigned)b);
+        }
+        Vec ring[HR];
+        {
+            constexpr int kPer = (kMoMaxG * kMoNW + kBlk - 1) / kBlk;
+            oc_u64 w[kPer];
+            const int nW = K.G * kMoNW;
+            const bool lastIt = k + 1 == K.L;      // (after the last iteration only delta survives: nobody needs the ring)
+            auto need = [&](int h) { return !lastIt && rowIn(h) && !(writer && h >= 1 && h <= R); };
+            oc_u64 rw[HR][C * WPS];
+            bool sumsOk = false, ringOk = false;
+            auto askSums = [&]() {
+#pragma unroll
+                for (int u = 0; u < kPer; ++u) { const int i = tid + u * kBlk; w[u] = ocLoad(slotPar + (i < nW ? i : tid % nW)); }
+            };
+            auto askRing = [&]() {
+#pragma unroll
+                for (int h = 0; h < HR; ++h) {
+#pragma unroll
+                    for (int q = 0; q < C * WPS; ++q) rw[h][q] = (oc_u64)tag << 32;
+                    if (need(h)) {
+                        const size_t i = (size_t)(pixBase + h * K.W) * C * WPS;
+#pragma unroll
+                        for (int q = 0; q < C * WPS; ++q) rw[h][q] = ocLoad(box + i + q);
+                    }
+                }
+            };
+            auto check = [&]() {
+                if (!sumsOk) {
+                    bool ok = true;
+#pragma unroll
+                    for (int u = 0; u < kPer; ++u) { const int i = tid + u * kBlk; ok = ok && (i >= nW || (unsigned)(w[u] >> 32) == tag); }
+                    sumsOk = ok;
+                }
+                if (!ringOk) {
+                    bool ok = true;
+#pragma unroll
+                    for (int h = 0; h < HR; ++h)
+#pragma unroll
+                        for (int q = 0; q < C * WPS; ++q) ok = ok && (unsigned)(rw[h][q] >> 32) == tag;
+                    ringOk = ok;
+                }
+                return sumsOk && ringOk;
+            };
+            askSums(); askRing();
+            if (!check()) {
+                const long long t0 = wall_clock64();
+                unsigned spins = 0;
+                for (;;) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (!sumsOk) askSums();
+                    if (!ringOk) askRing();
+                    if (check()) break;
+                    if ((++spins & 31u) == 0) {
+                        if (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                        if (wall_clock64() - t0 > to) { __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < HR; ++h)
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    if constexpr (WPS == 1) ring[h].v[c] = __uint_as_float((unsigned)rw[h][c]);
+                    else ring[h].v[c] = __longlong_as_double((long long)((rw[h][2 * c + 1] << 32) | (rw[h][2 * c] & 0xffffffffull)));
+                }
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) { const int i = tid + u * kBlk; if (i < nW) W1[i] = (unsigned)w[u]; }
+            __syncthreads();
+            // every workgroup adds all workgroups' words in the same order: wave q takes sum q, a lane the workgroups lane, lane + 64, lane + 128, lane + 192 in that
+            // order, then the wave's DPP tree -- the same association everywhere, so the same bits
+            if (wave < kMoNS) {
+                const int q = wave;
+                double sacc = 0;
+#pragma unroll
+                for (int c = 0; c < kMoMaxG / kWave; ++c) {
+                    const int m = lane + c * kWave;
+                    const double v = m < K.G ? ocJoin(W1[m * kMoNW + 2 * q], W1[m * kMoNW + 2 * q + 1]) : 0.0;
+                    sacc += v;
+                }
+                sacc = ocWaveSum63(sacc);
+                if (lane == kWave - 1) TOT[q] = sacc;
+            }
+            if (tid == 0) reinterpret_cast<int*>(TOT + kMoNS)[0] = __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+        }
+        const double aNumD = TOT[0], aDenD = TOT[1], s2 = TOT[2], s3 = TOT[3];
+        if (reinterpret_cast<const int*>(TOT + kMoNS)[0]) { failed = true; break; }      // uniform over the workgroup: a wait timed out somewhere
+        // the scalars of march_pcgIter's prologue (solver.t:456-459, 544-547 guards; beta numerator by expansion, clamped like the direct sum it replaces; the start-up
+        // quirk: sum r_0^2 = 4 alphaNumerator_0, exact)
+        const T aNum = (T)aNumD, aDen = (T)aDenD;
+        const T alpha = (aDen > T(0)) ? aNum / aDen : T(0);
+        const double rr = first ? 4.0 * aNumD : aNumD;
+        const double bNumD = fmax(rr - 2.0 * (double)alpha * s2 + (double)alpha * (double)alpha * s3, 0.0);
+        const T beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
+        const bool last = k + 1 == K.L;
+
+        // ---- PCGStep2 + PCGStep3 (z = r): delta += alpha p;  r -= alpha A p;  p = r + beta p -- on the owned pixels and, with the same fused operations, on the ring
+#pragma unroll
+        for (int h = 0; h < HR; ++h) {
+            const bool ownRow = h >= 1 && h <= R;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const T apv = ownRow ? (writer ? ap[ownRow ? h - 1 : 0].v[c] : ring[h].v[c]) : ring[h].v[c];
+                if (ownRow) dl[ownRow ? h - 1 : 0].v[c] = moFma(alpha, p[h].v[c], dl[ownRow ? h - 1 : 0].v[c]);
+                if (!last) {
+                    r[h].v[c] = moFma(-alpha, apv, r[h].v[c]);
+                    p[h].v[c] = moFma(beta, p[h].v[c], r[h].v[c]);
+                }
+            }
+        }
+    }
+    if (!failed && writer) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int y = yBase + i;
+            if (y < K.H) {
+                const long e = ((long)y * K.W + x) * C;
+#pragma unroll
+                for (int c = 0; c < C; ++c) K.delta[e + c] = dl[i].v[c];
+            }
+        }
+    }
+}
+
+// PCGLinearUpdate X += delta (solver.t:552-557) behind the on-chip solve -- unless a wait timed out: then the unknowns stay untouched and the host is told
+template <class T>
+__global__ __launch_bounds__(kBlock) void march_applyDelta(T* __restrict__ X, const T* __restrict__ delta, long n, const int* __restrict__ bad, int* hostErr) {
+    if (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(hostErr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) X[i] = X[i] + delta[i];
+}
+
+// Host side: buffers, variant choice, launch, the time-out verdict.  OPT_AMD_ONCHIP=0 switches the path off (the one A/B switch); OPT_AMD_ONCHIP_ROWS / _WAVES force a
+// variant (tests run every variant on small images); OPT_AMD_ONCHIP_FAIL_AT / _TIMEOUT_MS: the time-out path's test hooks.
+template <class T>
+struct OnchipMarch {
+    bool enabled = true, failed = false, launched = false;
+    int forceRows = 0, forceWaves = 0, failAt = -1; long long timeoutTicks = 2000LL * 100000;      // 2 s of the 100 MHz wall clock
+    oc_u64 *slots = nullptr, *box = nullptr; int *bad = nullptr, *hostErr = nullptr; unsigned seq = 0; size_t slotBytes = 0, boxBytes = 0;
+    int lastRows = 0, lastWaves = 0, lastG = 0;
+    OnchipMarch() {
+        if (const char* e = getenv("OPT_AMD_ONCHIP")) enabled = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_ONCHIP_ROWS")) forceRows = std::max(0, atoi(e));
+        if (const char* e = getenv("OPT_AMD_ONCHIP_WAVES")) forceWaves = std::max(0, atoi(e));
+        if (const char* e = getenv("OPT_AMD_ONCHIP_FAIL_AT")) failAt = atoi(e);
+        if (const char* e = getenv("OPT_AMD_ONCHIP_TIMEOUT_MS")) timeoutTicks = std::max(1, atoi(e)) * 100000LL;
+    }
+    ~OnchipMarch() { if (slots) (void)hipFree(slots); if (box) (void)hipFree(box); if (bad) (void)hipFree(bad); if (hostErr) (void)hipHostFree(hostErr); }
+    struct Variant { int rows, waves; const void* fn; };
+    template <class Op> static const std::vector<Variant>& variants() {
+        static const std::vector<Variant> v = [] {
+            std::vector<Variant> o;
+#define MO_VARIANT(R, WV) o.push_back({R, WV, (const void*)march_onchipPcg<T, Op, R, WV>})
+            MO_VARIANT(2, 4); MO_VARIANT(4, 4); MO_VARIANT(8, 4); MO_VARIANT(2, 8); MO_VARIANT(4, 8); MO_VARIANT(8, 8);
+#undef MO_VARIANT
+            // a variant whose registers do not hold its loop state (16- and 32-byte pixels at 8 rows) is not offered: no scratch in a kernel that is all latency
+            std::vector<Variant> ok;
+            for (const auto& v : o) { hipFuncAttributes fa{}; if (hipFuncGetAttributes(&fa, v.fn) == hipSuccess && fa.localSizeBytes == 0) ok.push_back(v); else (void)hipGetLastError(); }
+            return ok;
+        }();
+        return v;
+    }
+    // among the variants whose workgroups fit one per CU: the fewest rows marched per SIMD and iteration, (waves per SIMD) x (rows held per wave)
+    template <class Op> const Variant* select(int W, int H, int cus, int& stripsX, int& tilesY, int& G) const {
+        stripsX = divUp(W, kMoSpan);
+        const Variant* best = nullptr; int bestCost = 1 << 30;
+        for (const auto& v : variants<Op>()) {
+            if (forceRows && v.rows != forceRows) continue;
+            if (forceWaves && v.waves != forceWaves) continue;
+            const int ty = divUp(H, v.rows), g = divUp(stripsX * ty, v.waves);
+            if (g > std::min(cus, kMoMaxG)) continue;
+            const int cost = (v.waves / 4) * (v.rows + 2);
+            if (cost < bestCost) { best = &v; bestCost = cost; tilesY = ty; G = g; }
+        }
+        return best;
+    }
+    // the whole linear solve + X += delta; false (nothing touched): not offered for this plan
+    template <class Op> bool solve(const Op& op, int W, int H, const uint8_t* flags, const T* coef, const T* r0, const T* p0, T* delta, T* X, int L, int cus, LaunchCtx& ctx) {
+        constexpr int C = Op::C;
+        if (!enabled || failed || L <= 0 || (unsigned long long)W * H * C * sizeof(T) >= (1ull << 30)) return false;
+        int stripsX = 0, tilesY = 0, G = 0;
+        const Variant* V = select<Op>(W, H, cus, stripsX, tilesY, G);
+        if (!V) return false;
+        if (!slots) {      // sized for this plan's image once (the dimensions of a plan are fixed); zero = no tag
+            slotBytes = sizeof(oc_u64) * 2 * (size_t)kMoMaxG * kMoNW; boxBytes = sizeof(oc_u64) * 2 * (size_t)W * H * C * (sizeof(T) / 4);
+            HIP_CHECK(hipMalloc((void**)&slots, slotBytes)); HIP_CHECK(hipMalloc((void**)&box, boxBytes));
+            HIP_CHECK(hipMalloc((void**)&bad, sizeof(int))); HIP_CHECK(hipHostMalloc((void**)&hostErr, 64)); *hostErr = 0;
+            HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), ctx.stream));
+            seq = 0xE0000001u;      // forces the clearing below
+        }
+        if (seq > 0xE0000000u || seq + (unsigned)L > 0xE0000000u) {      // tags never repeat: start over on cleared buffers long before the counter wraps
+            HIP_CHECK(hipMemsetAsync(slots, 0, slotBytes, ctx.stream)); HIP_CHECK(hipMemsetAsync(box, 0, boxBytes, ctx.stream));
+            seq = 2;
+        }
+        MoArgs<T> K{W, H, r0, p0, delta, flags, coef, stripsX, tilesY, G, L, seq, slots, box, bad, timeoutTicks, failAt};
+        {
+            ScopedKernel k(ctx, "PCGSolveOnChip");
+            Op opc = op;
+            void* kargs[] = {(void*)&opc, (void*)&K};
+            if (hipLaunchKernel(V->fn, dim3(G), dim3(V->waves * kWave), kargs, 0, ctx.stream) != hipSuccess) { (void)hipGetLastError(); enabled = false; return false; }
+        }
+        seq += (unsigned)L;
+        {
+            ScopedKernel k(ctx, "PCGLinearUpdate");
+            const long n = (long)W * H * C;
+            const int grid = (int)std::max<long>(1, std::min<long>((n + kBlock - 1) / kBlock, (long)cus * 8));
+            march_applyDelta<T><<<grid, kBlock, 0, ctx.stream>>>(X, delta, n, bad, hostErr);
+        }
+        launched = true; lastRows = V->rows; lastWaves = V->waves; lastG = G;
+        return true;
+    }
+    bool failedNow() {
+        if (!launched) return false;
+        launched = false;
+        if (__atomic_load_n(hostErr, __ATOMIC_ACQUIRE) == 0) return false;
+        failed = true;
+        return true;
+    }
+    template <class Op> std::string describe(int W, int H, int cus, int L, bool lmv, const char* marchName) const {
+        int stripsX = 0, tilesY = 0, G = 0;
+        const Variant* V = (enabled && !failed && !lmv && L > 0) ? select<Op>(W, H, cus, stripsX, tilesY, G) : nullptr;
+        char buf[500];
+        if (V) snprintf(buf, sizeof buf, "path=on-chip (march_onchipPcg); onchip_rows_per_wave=%d; waves_per_workgroup=%d; wave_tiles=%dx%d of 62 x %d pixels; workgroups=%d of %d CUs; fallback=one launch per PCG iteration (%s)",
+                        V->rows, V->waves, stripsX, tilesY, V->rows, G, cus, marchName);
+        else snprintf(buf, sizeof buf, "path=one launch per PCG iteration (%s); why_not_on_chip=%s", lmv ? "generic kernels, LM" : marchName,
+                      !enabled ? "switched off" : failed ? "a wait timed out earlier" : lmv ? "Gauss-Newton only" : "the wave tiles do not fit the CUs");
+        return buf;
+    }
+};
+
+}  // namespace
+}  // namespace optamd
