@@ -49,6 +49,8 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
     __shared__ double red[kMoNS * WAVES];
     __shared__ double TOT[kMoNS + 1];
     __shared__ unsigned W1[kMoMaxG * kMoNW];
+    constexpr bool AP_LDS = C * sizeof(T) * R >= 128;      // where the registers are short, A p of the owned pixels waits in LDS between the stencil and the update: [row][channel][thread]
+    __shared__ T apL[AP_LDS ? R * C * kBlk : 1];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = blockIdx.x;
     const int tile = g * WAVES + wave;
     const int sx = tile % K.stripsX, ty = tile / K.stripsX;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
     const long long to = K.timeoutTicks;
 
     // ---- p_0, r_0, the flag bit and the operator coefficients of the held pixels (a pixel outside the image or switched off: zeros, off); delta = 0 ----------------
-    Vec p[HR], r[HR], dl[R], ap[R];
+    Vec p[HR], r[HR], dl[R], ap[AP_LDS ? 1 : R];
     Coef cf[HR];
     unsigned onBits = 0;
 #pragma unroll
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
 #pragma unroll
     for (int i = 0; i < R; ++i)
 #pragma unroll
-        for (int c = 0; c < C; ++c) { dl[i].v[c] = 0; ap[i].v[c] = 0; }
+        for (int c = 0; c < C; ++c) { dl[i].v[c] = 0; if (AP_LDS) apL[((AP_LDS ? i : 0) * C + c) * kBlk + tid] = 0; else ap[AP_LDS ? 0 : i].v[c] = 0; }
 
     const int pixBase = (yBase - 1) * K.W + xc;      // index of held row 0 of this lane's column (used only where the row exists)
     auto rowIn = [&](int h) { const int y = yBase - 1 + h; return xin && y >= 0 && y < K.H; };
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
                 Vec o = op.apply(p[h], pl, pr, p[h - 1], p[h + 1], hasL, hasR, y - 1 >= 0, y + 1 < K.H, cf[h]);
                 const bool on = (onBits >> h) & 1u;
 #pragma unroll
-                for (int c = 0; c < C; ++c) { o.v[c] = on ? o.v[c] : T(0); ap[h - 1].v[c] = o.v[c]; }
+                for (int c = 0; c < C; ++c) { o.v[c] = on ? o.v[c] : T(0); if (AP_LDS) apL[((AP_LDS ? h - 1 : 0) * C + c) * kBlk + tid] = o.v[c]; else ap[AP_LDS ? 0 : h - 1].v[c] = o.v[c]; }
                 if (writer && y < K.H) {
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
@@ -149,8 +151,15 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
             oc_u64 w[kPer];
             const int nW = K.G * kMoNW;
             const bool lastIt = k + 1 == K.L;      // (after the last iteration only delta survives: nobody needs the ring)
-            auto need = [&](int h) { return !lastIt && rowIn(h) && !(writer && h >= 1 && h <= R); };
-            oc_u64 rw[HR][C * WPS];
+            // Ring requests: every lane asks for its column's pixel of the rows above and below the tile; the two side columns are asked for by ONE lane per pixel
+            // (lane h: the left neighbour of row h, lane 32 + h: the right one) and handed to lanes 0 / 63 through scalar registers afterwards -- a lane holds three
+            // pixels' words during the wait instead of R + 2 (the difference is what lets 16 rows per wave fit).
+            static_assert(R + 1 < 32, "one lane per side pixel");
+            const int sRow = lane & 31, sX = (lane < 32) ? sx * kMoSpan - 1 : sx * kMoSpan + kMoSpan, sY = yBase - 1 + sRow;
+            const bool needTop = !lastIt && rowIn(0), needBot = !lastIt && rowIn(HR - 1);
+            const bool needSide = !lastIt && !idle && sRow >= 1 && sRow <= R && sX >= 0 && sX < K.W && sY < K.H;
+            const size_t iTop = (size_t)pixBase * C * WPS, iBot = (size_t)(pixBase + (HR - 1) * K.W) * C * WPS, iSide = needSide ? ((size_t)sY * K.W + sX) * C * WPS : 0;
+            oc_u64 rw[3][C * WPS];      // top, bottom, side
             bool sumsOk = false, ringOk = false;
             auto askSums = [&]() {
 #pragma unroll
@@ -158,13 +167,14 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
             };
             auto askRing = [&]() {
 #pragma unroll
-                for (int h = 0; h < HR; ++h) {
+                for (int j = 0; j < 3; ++j) {
+                    const bool nd = j == 0 ? needTop : j == 1 ? needBot : needSide;
+                    const size_t i = j == 0 ? iTop : j == 1 ? iBot : iSide;
 #pragma unroll
-                    for (int q = 0; q < C * WPS; ++q) rw[h][q] = (oc_u64)tag << 32;
-                    if (need(h)) {
-                        const size_t i = (size_t)(pixBase + h * K.W) * C * WPS;
+                    for (int q = 0; q < C * WPS; ++q) rw[j][q] = (oc_u64)tag << 32;
+                    if (nd) {
 #pragma unroll
-                        for (int q = 0; q < C * WPS; ++q) rw[h][q] = ocLoad(box + i + q);
+                        for (int q = 0; q < C * WPS; ++q) rw[j][q] = ocLoad(box + i + q);
                     }
                 }
             };
@@ -178,9 +188,9 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
                 if (!ringOk) {
                     bool ok = true;
 #pragma unroll
-                    for (int h = 0; h < HR; ++h)
+                    for (int j = 0; j < 3; ++j)
 #pragma unroll
-                        for (int q = 0; q < C * WPS; ++q) ok = ok && (unsigned)(rw[h][q] >> 32) == tag;
+                        for (int q = 0; q < C * WPS; ++q) ok = ok && (unsigned)(rw[j][q] >> 32) == tag;
                     ringOk = ok;
                 }
                 return sumsOk && ringOk;
@@ -200,13 +210,21 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
                     }
                 }
             }
+            auto decode = [&](const oc_u64 (&q)[C * WPS], int c) -> T {
+                if constexpr (WPS == 1) return __uint_as_float((unsigned)q[c]);
+                else return __longlong_as_double((long long)((q[2 * c + 1] << 32) | (q[2 * c] & 0xffffffffull)));
+            };
+            auto laneOf = [](T v, int l) -> T {
+                if constexpr (sizeof(T) == 8) return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+                else return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+            };
 #pragma unroll
-            for (int h = 0; h < HR; ++h)
+            for (int c = 0; c < C; ++c) {
+                ring[0].v[c] = decode(rw[0], c); ring[HR - 1].v[c] = decode(rw[1], c);
+                const T sv = decode(rw[2], c);
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    if constexpr (WPS == 1) ring[h].v[c] = __uint_as_float((unsigned)rw[h][c]);
-                    else ring[h].v[c] = __longlong_as_double((long long)((rw[h][2 * c + 1] << 32) | (rw[h][2 * c] & 0xffffffffull)));
-                }
+                for (int h = 1; h <= R; ++h) { const T lft = laneOf(sv, h), rgt = laneOf(sv, 32 + h); ring[h].v[c] = lane == 0 ? lft : rgt; }      // (only lanes 0 and 63 use them)
+            }
 #pragma unroll
             for (int u = 0; u < kPer; ++u) { const int i = tid + u * kBlk; if (i < nW) W1[i] = (unsigned)w[u]; }
             __syncthreads();
@@ -244,7 +262,7 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
             const bool ownRow = h >= 1 && h <= R;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const T apv = ownRow ? (writer ? ap[ownRow ? h - 1 : 0].v[c] : ring[h].v[c]) : ring[h].v[c];
+                const T apv = ownRow ? (writer ? (AP_LDS ? apL[((AP_LDS && ownRow ? h - 1 : 0) * C + c) * kBlk + tid] : ap[!AP_LDS && ownRow ? h - 1 : 0].v[c]) : ring[h].v[c]) : ring[h].v[c];
                 if (ownRow) dl[ownRow ? h - 1 : 0].v[c] = moFma(alpha, p[h].v[c], dl[ownRow ? h - 1 : 0].v[c]);
                 if (!last) {
                     r[h].v[c] = moFma(-alpha, apv, r[h].v[c]);
@@ -298,6 +316,7 @@ struct OnchipMarch {
             std::vector<Variant> o;
 #define MO_VARIANT(R, WV) o.push_back({R, WV, (const void*)march_onchipPcg<T, Op, R, WV>})
             MO_VARIANT(2, 4); MO_VARIANT(4, 4); MO_VARIANT(8, 4); MO_VARIANT(2, 8); MO_VARIANT(4, 8); MO_VARIANT(8, 8);
+            if constexpr (Op::C * sizeof(T) <= 8) { MO_VARIANT(16, 4); MO_VARIANT(16, 8); }
 #undef MO_VARIANT
             // a variant whose registers do not hold its loop state (16- and 32-byte pixels at 8 rows) is not offered: no scratch in a kernel that is all latency
             std::vector<Variant> ok;
@@ -306,7 +325,7 @@ struct OnchipMarch {
         }();
         return v;
     }
-    // among the variants whose workgroups fit one per CU: the fewest rows marched per SIMD and iteration, (waves per SIMD) x (rows held per wave)
+    // among the variants whose workgroups fit one per CU: the least marching time per SIMD and iteration
     template <class Op> const Variant* select(int W, int H, int cus, int& stripsX, int& tilesY, int& G) const {
         stripsX = divUp(W, kMoSpan);
         const Variant* best = nullptr; int bestCost = 1 << 30;
@@ -315,7 +334,7 @@ struct OnchipMarch {
             if (forceWaves && v.waves != forceWaves) continue;
             const int ty = divUp(H, v.rows), g = divUp(stripsX * ty, v.waves);
             if (g > std::min(cus, kMoMaxG)) continue;
-            const int cost = (v.waves / 4) * (v.rows + 2);
+            const int cost = (v.waves == 4 ? 100 : 136) * (v.rows + 2);      // (measured: two waves per SIMD march a row pair in 1.36 of the time one wave marches a row)
             if (cost < bestCost) { best = &v; bestCost = cost; tilesY = ty; G = g; }
         }
         return best;

@@ -4,7 +4,7 @@ poisson_image_editing (float4 / double4, Exclude mask), the tests/minimal laplac
 The reference's loop (solverGPUGaussNewton.t:1056-1092) runs as ONE persistent launch per Gauss-Newton step: a wave holds 64 x (R + 2) pixels of p and r in registers and
 owns the 62 x R in the middle, the A p of the one-pixel ring travels through a tagged image, four sums per iteration are added by every workgroup in the same order; the
 start is the reference's (p_0 = r_0 / 4, alphaNumerator_0 = r_0 . p_0).  Side by side with the CPU oracle:
-  * every kernel variant that keeps its state in registers (R = 2 / 4 / 8 rows per wave x 4 / 8 waves per workgroup) on images narrower than a wave, exactly one strip, one
+  * every kernel variant that keeps its state in registers (R = 2 / 4 / 8 -- pixels of up to 8 bytes: 16 -- rows per wave x 4 / 8 waves per workgroup) on images narrower than a wave, exactly one strip, one
     pixel more, lower than a tile, with random masks that reach the border and with none;
   * 1, 2, 3, 5, 12 PCG iterations, two Gauss-Newton steps on one plan (the tags run on; optical_flow's coefficients are rebuilt);
   * the time-out path (nothing applied, the step redone by the marching kernels, on_chip_status 2) and on-chip against marching kernels on the same input.
@@ -59,15 +59,8 @@ def _pair(oracle_lib, P, nsteps, liters, cost_tol, x_tol, status=1):
     g.close(); o.close()
 
 
-def _variant(monkeypatch, rows, waves, double, channels):
-    """variants whose loop state does not fit the registers are not offered (16- and 32-byte pixels at 8 rows): the forced choice then finds nothing and the test is void"""
-    if channels * (8 if double else 4) * rows >= 128 and not (channels * (8 if double else 4) * rows == 128 and waves == 4):
-        pytest.skip("variant not offered for this pixel size")
-    monkeypatch.setenv("OPT_AMD_ONCHIP_ROWS", str(rows)); monkeypatch.setenv("OPT_AMD_ONCHIP_WAVES", str(waves))
-
-
 @pytest.mark.parametrize("liters", [1, 2, 5, 12])
-@pytest.mark.parametrize("rows,waves", [(2, 4), (4, 4), (2, 8)])
+@pytest.mark.parametrize("rows,waves", [(2, 4), (4, 4), (8, 4), (2, 8), (4, 8)])      # (8 rows x 8 waves of 32-byte pixels does not fit the registers: not offered)
 @pytest.mark.parametrize("mask", ["random", "none"])
 @pytest.mark.parametrize("W,H", SHAPES)
 def test_poisson_double(oracle_lib, monkeypatch, W, H, mask, rows, waves, liters):
@@ -76,7 +69,7 @@ def test_poisson_double(oracle_lib, monkeypatch, W, H, mask, rows, waves, liters
 
 
 @pytest.mark.parametrize("liters", [2, 12])
-@pytest.mark.parametrize("rows,waves", [(2, 4), (4, 4), (8, 4), (2, 8), (4, 8)])
+@pytest.mark.parametrize("rows,waves", VARIANTS)
 @pytest.mark.parametrize("mask", ["random", "box"])
 @pytest.mark.parametrize("W,H", SHAPES)
 def test_poisson_float(oracle_lib, monkeypatch, W, H, mask, rows, waves, liters):
@@ -85,7 +78,7 @@ def test_poisson_float(oracle_lib, monkeypatch, W, H, mask, rows, waves, liters)
 
 
 @pytest.mark.parametrize("liters", [1, 3, 12])
-@pytest.mark.parametrize("rows,waves", VARIANTS)
+@pytest.mark.parametrize("rows,waves", VARIANTS + [(16, 4), (16, 8)])
 @pytest.mark.parametrize("W,H", SHAPES)
 def test_laplacian_float(oracle_lib, monkeypatch, W, H, rows, waves, liters):
     monkeypatch.setenv("OPT_AMD_ONCHIP_ROWS", str(rows)); monkeypatch.setenv("OPT_AMD_ONCHIP_WAVES", str(waves))
@@ -93,11 +86,13 @@ def test_laplacian_float(oracle_lib, monkeypatch, W, H, rows, waves, liters):
 
 
 @pytest.mark.parametrize("liters", [1, 3, 12])
-@pytest.mark.parametrize("rows,waves", [(2, 4), (4, 4), (8, 4), (2, 8), (4, 8)])
+@pytest.mark.parametrize("rows,waves", VARIANTS + [(16, 4), (16, 8)])
 @pytest.mark.parametrize("double", [True, False])
 @pytest.mark.parametrize("W,H", [(7, 9), (61, 5), (62, 3), (63, 9), (300, 40), (64, 300), (517, 33)])
 def test_optical_flow(oracle_lib, monkeypatch, W, H, double, rows, waves, liters):
     """off-lattice sample positions (seeded initial flow): the per-pixel coefficients are rebuilt every Gauss-Newton step"""
+    if double and rows == 16:
+        pytest.skip("16 rows per wave are offered for pixels of up to 8 bytes")
     monkeypatch.setenv("OPT_AMD_ONCHIP_ROWS", str(rows)); monkeypatch.setenv("OPT_AMD_ONCHIP_WAVES", str(waves))
     P = wl.optical_flow(W, H, double=double, seed=W + H + liters, init_flow=1.2)
     _pair(oracle_lib, P, 2, liters, 1e-10 if double else 1e-5, 1e-9 if double else 2e-5)
