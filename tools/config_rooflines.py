@@ -86,6 +86,11 @@ def main(src, out):
         key = next((k for k in MODELS if k in r["config"]), None)
         if key:
             r["roofline"] = []
+            if key == "config1" and r["kernel_avg_us"].get("PCGSolveOnChip"):      # 256^2: the whole linear solve is one persistent launch (stencil_onchip.h); nothing streams
+                us = r["kernel_avg_us"]["PCGSolveOnChip"]
+                r["roofline"].append({"kernel": "PCGSolveOnChip = march_onchipPcg (one launch per linear solve of 10 PCG iterations)", "avg_us": us, "us_per_pcg_iteration": us / 10,
+                                      "bound": "latency", "model": "one grid-wide wait per iteration (tagged words through the memory side: ~3.5 us) + the stencil on 2 rows per wave; 65 k pixels x 65 B = 4 MB of state, all of it in registers",
+                                      "note": "no bandwidth or issue ceiling applies at this size: the launch-per-iteration kernel it replaces took 11.4 us per iteration, all launch latency", "plan": (r.get("plan") or {}).get("describe")})
             if key == "config3":
                 o = sfs_onchip_roofline(r)
                 if o:
@@ -109,6 +114,9 @@ def main(src, out):
     json.dump({"box": box, "configs": rows}, open(out, "w"), indent=1)
     for r in rows:
         for o in r.get("roofline", []):
+            if o.get("bound") == "latency":
+                print(f"{r['config'][:60]:60s} {o['kernel'][:40]:40s} {o['avg_us']:8.1f} us  = {o['us_per_pcg_iteration']:.1f} us per PCG iteration (latency-bound)")
+                continue
             if o.get("bound") == "valu-issue":
                 print(f"{r['config'][:60]:60s} {o['kernel'][:40]:40s} {o['avg_us']:8.1f} us  VALU issue {o['valu_issue_us_per_launch']:.0f} us = {o['frac']:.2f} of the launch")
                 continue
