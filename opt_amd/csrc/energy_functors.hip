@@ -226,13 +226,14 @@ struct OpticalFlowOps : StencilOps<T, OpticalFlowE<T>> {
     OnchipMarch<T> oc;
     bool onChipWithoutPreconditioner() const override { return true; }
     bool pcgSolveOnChip(const T* r0, const T* p0, T* delta, int L, double* traceDev, const OnChipLm<T>* lm, LaunchCtx& ctx) override {
-        if (!useMarch || lm || traceDev || this->slab.active) return false;
+        if (!useMarch || traceDev || this->slab.active) return false;
         int sx, ty, G;
-        if (!oc.enabled || oc.failed || !oc.template select<FlowMarchOp<T>>(this->e.W, this->e.H, this->cus, sx, ty, G)) return false;      // (before the coefficient pass is spent)
+        if (!oc.enabled || oc.failed || (lm && (!lm->CtC || lm->resetPeriod < L)) ||
+            !(lm ? oc.template select<FlowMarchOp<T>, true>(this->e.W, this->e.H, this->cus, sx, ty, G) : oc.template select<FlowMarchOp<T>, false>(this->e.W, this->e.H, this->cus, sx, ty, G))) return false;      // (before the coefficient pass is spent)
         const long n = (long)this->e.W * this->e.H;
         if (!coef) HIP_CHECK(hipMalloc((void**)&coef, (size_t)(2 * n) * sizeof(T)));
         { ScopedKernel k(ctx, "operatorCoefficients"); flow_coef<T><<<this->grid(), kBlock, 0, ctx.stream>>>(this->e, coef); }
-        return oc.solve(FlowMarchOp<T>{this->e.w_fit, this->e.w_reg}, this->e.W, this->e.H, nullptr, coef, r0, p0, delta, const_cast<T*>(this->e.X[0]), L, this->cus, ctx);
+        return oc.solve(FlowMarchOp<T>{this->e.w_fit, this->e.w_reg}, this->e.W, this->e.H, nullptr, coef, r0, p0, delta, const_cast<T*>(this->e.X[0]), L, this->cus, ctx, lm);
     }
     bool onChipFailed() override { return oc.failedNow(); }
     std::string describe(int L, bool lmv) override { return oc.template describe<FlowMarchOp<T>>(this->e.W, this->e.H, this->cus, useMarch ? L : 0, lmv, "march_pcgIter"); }

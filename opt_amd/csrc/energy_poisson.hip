@@ -293,8 +293,8 @@ struct PoissonOps : EnergyOps<T> {
     OnchipMarch<T> oc;
     bool onChipWithoutPreconditioner() const override { return true; }
     bool pcgSolveOnChip(const T* r0, const T* p0, T* delta, int L, double* traceDev, const OnChipLm<T>* lm, LaunchCtx& ctx) override {
-        if (!singleKernel || lm || traceDev || this->slab.active) return false;
-        return oc.solve(PoissonMarchOp<T>{}, A.W, A.H, flags, nullptr, r0, p0, delta, const_cast<T*>(A.X), L, cus, ctx);
+        if (!singleKernel || traceDev || this->slab.active) return false;
+        return oc.solve(PoissonMarchOp<T>{}, A.W, A.H, flags, nullptr, r0, p0, delta, const_cast<T*>(A.X), L, cus, ctx, lm);
     }
     bool onChipFailed() override { return oc.failedNow(); }
     std::string describe(int L, bool lmv) override { return oc.template describe<PoissonMarchOp<T>>(A.W, A.H, cus, singleKernel ? L : 0, lmv, "march_pcgIter"); }
@@ -407,8 +407,8 @@ struct LaplacianOps : EnergyOps<float> {
     OnchipMarch<float> oc;      // the whole Gauss-Newton linear solve on chip (stencil_onchip.h)
     bool onChipWithoutPreconditioner() const override { return true; }
     bool pcgSolveOnChip(const float* r0, const float* p0, float* delta, int L, double* traceDev, const OnChipLm<float>* lm, LaunchCtx& ctx) override {
-        if (lm || traceDev || this->slab.active) return false;
-        return oc.solve(LaplacianMarchOp{}, A.W, A.H, nullptr, nullptr, r0, p0, delta, const_cast<float*>(A.X), L, cus, ctx);
+        if (traceDev || this->slab.active) return false;
+        return oc.solve(LaplacianMarchOp{}, A.W, A.H, nullptr, nullptr, r0, p0, delta, const_cast<float*>(A.X), L, cus, ctx, lm);
     }
     bool onChipFailed() override { return oc.failedNow(); }
     std::string describe(int L, bool lmv) override { return oc.describe<LaplacianMarchOp>(A.W, A.H, cus, L, lmv, "march_pcgIter"); }

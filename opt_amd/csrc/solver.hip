@@ -990,13 +990,15 @@ struct PcgSolver : SolverBase {
                 onChipOk = false; onChipFellBack = true; lastStepOnChip = false; unknownsUpdated = false;
                 if (lm) {      // the kernel produced no delta: the update above added nothing meaningful -- back to the saved unknowns, then the launch-per-iteration loop
                     imageOp(2);
-                    HIP_CHECK(hipMemsetAsync(delta, 0, nPad * sizeof(T), stream));      // (workgroups that had finished before the others gave up may have written theirs)
-                    if (!runSingleKernelLoopLM(preArg, T(0), q_tolerance)) { fprintf(stderr, "Opt(amd): the streaming LM loop refused the redo\n"); exit(1); }
+                    E->precompute(ctx);      // (workgroups that had finished before the others gave up may have written their delta: the update above was then not the identity)
+                    HIP_CHECK(hipMemsetAsync(delta, 0, nPad * sizeof(T), stream));
+                    // an energy whose LM loop is the generic one (no single-kernel LM iteration): the whole step again, from its PCGInit1, on the generic kernels
+                    if (!runSingleKernelLoopLM(preArg, T(0), q_tolerance)) return step(params);
                 } else {
                     // Gauss-Newton: nothing was applied (iw_applyDelta checks the flag -- in slab mode the all-reduced verdict, so no rank kept its update).
                     // The redone loop starts from delta = 0 as PCGInit1 left it: the ROWS = 16 variant accumulates delta in memory while it runs.
                     HIP_CHECK(hipMemsetAsync(delta, 0, nPad * sizeof(T), stream));
-                    if (!runSingleKernelLoop(preArg)) { fprintf(stderr, "Opt(amd): the streaming loop refused the redo\n"); exit(1); }
+                    if (!runSingleKernelLoop(preArg)) return step(params);      // (no single-kernel loop either: the whole step again on the generic kernels)
                 }
                 afterLinearSolve();
             }

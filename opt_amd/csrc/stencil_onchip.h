@@ -13,7 +13,10 @@
 //   sums    every workgroup posts its partial sums as tagged words and adds ALL workgroups' words in the same order: the same bits everywhere.
 // Every wait is bounded by the device's wall clock; a time-out raises `bad`, nothing is written to delta, the unknowns stay untouched (march_applyDelta checks the flag) and
 // the host redoes the linear solve with the marching kernels.  The grid must be co-resident (one workgroup per CU): the launcher checks workgroups <= CUs.
-// Gauss-Newton only (as the marching loop: the Levenberg-Marquardt loop of these energies keeps the generic kernels); not for Op::kSplit31 (intrinsic_image_decomposition).
+// Levenberg-Marquardt (LM = true): + CtC p (o.t:2076-2082; CtC as PCGFinalizeDiagonal left it, the start p_0 = M_LM r_0 comes from the solver, later z = r), a fifth sum --
+// sum r_0^2 in iteration 0, then Q_k = 1/2 sum delta . (r + b) (solver.t:483-485) formed where iteration k is applied and carried by the sums of iteration k + 1 -- and the
+// q early-out (:1093-1102) decided by every workgroup from the same totals; a residual reset before the last iteration (lIterations > residual_reset_period) keeps the solve
+// on the generic kernels.  Not for Op::kSplit31 (intrinsic_image_decomposition).
 #pragma once
 #include "stencil_march.h"
 #include "onchip_sync.h"
@@ -23,7 +26,7 @@ namespace {
 
 constexpr int kMoSpan = kWave - 2;            // pixels a wave owns per row (one DPP ring)
 constexpr int kMoMaxG = 256;                  // workgroups (one per CU)
-constexpr int kMoNS = 4, kMoNW = 2 * kMoNS;   // sums per iteration; tagged words per workgroup
+constexpr int kMoNSMax = 5, kMoNWMax = 2 * kMoNSMax;   // sums per iteration (Gauss-Newton 4, Levenberg-Marquardt 5); tagged words per workgroup
 
 template <class T>
 struct MoArgs {
@@ -35,13 +38,15 @@ struct MoArgs {
     oc_u64* slots;                          // [2][G][8]
     oc_u64* apBox;                          // [2][W * H * C * sizeof(T) / 4]
     int* bad; long long timeoutTicks; int failAt;
+    const T* CtC; T qTolerance; int* hostErr;      // LM: the clamped diagonal, q_tolerance, the pinned word a workgroup that gave up raises (the solver applies the update itself)
 };
 
 __device__ __forceinline__ float moFma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double moFma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-template <class T, class Op, int R, int WAVES>
+template <class T, class Op, int R, int WAVES, bool LM>
 __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T> K) {
+    constexpr int kMoNS = LM ? 5 : 4, kMoNW = 2 * kMoNS;
     static_assert(!Op::kSplit31, "one image of C channels per pixel");
     constexpr int C = Op::C, HR = R + 2, kBlk = WAVES * kWave, WPS = (int)sizeof(T) / 4;
     constexpr int kCoefN = Op::kCoef > 0 ? Op::kCoef : 1;
@@ -51,6 +56,7 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
     __shared__ unsigned W1[kMoMaxG * kMoNW];
     constexpr bool AP_LDS = C * sizeof(T) * R >= 128;      // where the registers are short, A p of the owned pixels waits in LDS between the stencil and the update: [row][channel][thread]
     __shared__ T apL[AP_LDS ? R * C * kBlk : 1];
+    __shared__ T bL[LM ? R * C * kBlk : 1];      // LM: b = r_0 of the owned pixels (for Q)
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = blockIdx.x;
     const int tile = g * WAVES + wave;
     const int sx = tile % K.stripsX, ty = tile / K.stripsX;
@@ -68,6 +74,7 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
     // ---- p_0, r_0, the flag bit and the operator coefficients of the held pixels (a pixel outside the image or switched off: zeros, off); delta = 0 ----------------
     Vec p[HR], r[HR], dl[R], ap[AP_LDS ? 1 : R];
     Coef cf[HR];
+    Vec ctc[LM ? R : 1];      // LM: CtC of the owned pixels
     unsigned onBits = 0;
 #pragma unroll
     for (int h = 0; h < HR; ++h) {
@@ -81,6 +88,10 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
 #pragma unroll
         for (int c = 0; c < kCoefN; ++c) cf[h].v[c] = Op::kCoef > 0 ? K.coef[i * kCoefN + c] : T(0);
         onBits |= on ? (1u << h) : 0u;
+        if (LM && h >= 1 && h <= R) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) { const T cv = K.CtC[i * C + c]; ctc[LM ? h - 1 : 0].v[c] = on ? cv : T(0); bL[((LM ? h - 1 : 0) * C + c) * kBlk + tid] = r[h].v[c]; }      // b = r_0 (solver.t:657)
+        }
     }
 #pragma unroll
     for (int i = 0; i < R; ++i)
@@ -90,6 +101,8 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
     const int pixBase = (yBase - 1) * K.W + xc;      // index of held row 0 of this lane's column (used only where the row exists)
     auto rowIn = [&](int h) { const int y = yBase - 1 + h; return xin && y >= 0 && y < K.H; };
     bool failed = false;
+    double accQ = 0;
+    T Q0 = 0;      // fetchQ before the loop (solver.t:1050): delta = 0, so exactly 0
     const size_t boxStride = (size_t)N * C * WPS;
 
     for (int k = 0; k < K.L; ++k) {
@@ -101,7 +114,7 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
         const bool first = k == 0;
 
         // ---- PCGStep1: A p_k on the owned pixels, with the four sums (march_pcgIter's expressions) --------------------------------------------------------------
-        double accDen = 0, accNum = 0, acc2 = 0, acc3 = 0;
+        double accDen = 0, accNum = 0, acc2 = 0, acc3 = 0, accX = 0;      // accX (LM): sum r_0^2 in iteration 0, the Q of the iteration before in the others
         if (!idle) {
 #pragma unroll
             for (int h = 1; h <= R; ++h) {
@@ -110,13 +123,14 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
                 Vec o = op.apply(p[h], pl, pr, p[h - 1], p[h + 1], hasL, hasR, y - 1 >= 0, y + 1 < K.H, cf[h]);
                 const bool on = (onBits >> h) & 1u;
 #pragma unroll
-                for (int c = 0; c < C; ++c) { o.v[c] = on ? o.v[c] : T(0); if (AP_LDS) apL[((AP_LDS ? h - 1 : 0) * C + c) * kBlk + tid] = o.v[c]; else ap[AP_LDS ? 0 : h - 1].v[c] = o.v[c]; }
+                for (int c = 0; c < C; ++c) { if (LM) o.v[c] += ctc[LM ? h - 1 : 0].v[c] * p[h].v[c]; o.v[c] = on ? o.v[c] : T(0); if (AP_LDS) apL[((AP_LDS ? h - 1 : 0) * C + c) * kBlk + tid] = o.v[c]; else ap[AP_LDS ? 0 : h - 1].v[c] = o.v[c]; }
                 if (writer && y < K.H) {
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
                         const double rr = (double)r[h].v[c], a = (double)o.v[c], pp = (double)p[h].v[c];
                         accNum += (first ? pp : rr) * rr;      // z_0 . r_0 is the reference's r_0 . p_0
                         accDen += pp * a; acc2 += rr * a; acc3 += a * a;
+                        if (LM && first) accX += rr * rr;
                     }
                     // the tile's outermost rows / columns: to the tagged image, for whoever holds them as ring
                     if (h == 1 || h == R || lane == 1 || lane == kMoSpan) {
@@ -134,7 +148,10 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
 
         // ---- the grid-wide sums; the ring's A p is collected inside the wait ------------------------------------------------------------------------------------
         {
-            double v4[kMoNS] = {accNum, accDen, acc2, acc3};
+            if (LM && !first) accX = accQ;
+            double v4[kMoNS];
+            v4[0] = accNum; v4[1] = accDen; v4[2] = acc2; v4[3] = acc3;
+            if constexpr (LM) v4[4] = accX;
 #pragma unroll
             for (int q = 0; q < kMoNS; ++q) { v4[q] = ocWaveSum63(v4[q]); if (lane == kWave - 1) red[q * WAVES + wave] = v4[q]; }
         }
@@ -230,33 +247,45 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
             __syncthreads();
             // every workgroup adds all workgroups' words in the same order: wave q takes sum q, a lane the workgroups lane, lane + 64, lane + 128, lane + 192 in that
             // order, then the wave's DPP tree -- the same association everywhere, so the same bits
-            if (wave < kMoNS) {
-                const int q = wave;
-                double sacc = 0;
 #pragma unroll
-                for (int c = 0; c < kMoMaxG / kWave; ++c) {
-                    const int m = lane + c * kWave;
-                    const double v = m < K.G ? ocJoin(W1[m * kMoNW + 2 * q], W1[m * kMoNW + 2 * q + 1]) : 0.0;
-                    sacc += v;
+            for (int pass = 0; pass < (kMoNS + WAVES - 1) / WAVES; ++pass) {      // (five sums on four waves: wave 0 takes the fifth as well)
+                const int q = wave + pass * WAVES;
+                if (q < kMoNS) {
+                    double sacc = 0;
+#pragma unroll
+                    for (int c = 0; c < kMoMaxG / kWave; ++c) {
+                        const int m = lane + c * kWave;
+                        const double v = m < K.G ? ocJoin(W1[m * kMoNW + 2 * q], W1[m * kMoNW + 2 * q + 1]) : 0.0;
+                        sacc += v;
+                    }
+                    sacc = ocWaveSum63(sacc);
+                    if (lane == kWave - 1) TOT[q] = sacc;
                 }
-                sacc = ocWaveSum63(sacc);
-                if (lane == kWave - 1) TOT[q] = sacc;
             }
             if (tid == 0) reinterpret_cast<int*>(TOT + kMoNS)[0] = __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
         }
         const double aNumD = TOT[0], aDenD = TOT[1], s2 = TOT[2], s3 = TOT[3];
         if (reinterpret_cast<const int*>(TOT + kMoNS)[0]) { failed = true; break; }      // uniform over the workgroup: a wait timed out somewhere
+        if constexpr (LM) {      // the q early-out of iteration k - 1 (solver.t:1093-1102): nothing of iteration k has been applied yet
+            if (!first) {
+                const T Q1 = (T)TOT[4];
+                const T zeta = T(k) * (Q1 - Q0) / Q1;
+                if (zeta < K.qTolerance) break;
+                Q0 = Q1;
+            }
+        }
         // the scalars of march_pcgIter's prologue (solver.t:456-459, 544-547 guards; beta numerator by expansion, clamped like the direct sum it replaces; the start-up
         // quirk: sum r_0^2 = 4 alphaNumerator_0, exact)
         const T aNum = (T)aNumD, aDen = (T)aDenD;
         const T alpha = (aDen > T(0)) ? aNum / aDen : T(0);
-        const double rr = first ? 4.0 * aNumD : aNumD;
+        const double rr = first ? (LM ? TOT[LM ? 4 : 0] : 4.0 * aNumD) : aNumD;      // (LM starts from the preconditioned r_0: sum r_0^2 is summed directly)
         const double bNumD = fmax(rr - 2.0 * (double)alpha * s2 + (double)alpha * (double)alpha * s3, 0.0);
         const T beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
         const bool last = k + 1 == K.L;
 
         // ---- PCGStep2 + PCGStep3 (z = r): delta += alpha p;  r -= alpha A p;  p = r + beta p -- on the owned pixels and, with the same fused operations, on the ring
+        accQ = 0;
 #pragma unroll
         for (int h = 0; h < HR; ++h) {
             const bool ownRow = h >= 1 && h <= R;
@@ -266,11 +295,13 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
                 if (ownRow) dl[ownRow ? h - 1 : 0].v[c] = moFma(alpha, p[h].v[c], dl[ownRow ? h - 1 : 0].v[c]);
                 if (!last) {
                     r[h].v[c] = moFma(-alpha, apv, r[h].v[c]);
+                    if (LM && ownRow && writer && yBase - 1 + h < K.H) accQ += (double)(T(0.5) * (dl[ownRow ? h - 1 : 0].v[c] * (r[h].v[c] + bL[((LM && ownRow ? h - 1 : 0) * C + c) * kBlk + tid])));      // solver.t:483-485
                     p[h].v[c] = moFma(beta, p[h].v[c], r[h].v[c]);
                 }
             }
         }
     }
+    if (failed && tid == 0 && K.hostErr) __hip_atomic_store(K.hostErr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (!failed && writer) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -311,10 +342,13 @@ struct OnchipMarch {
     }
     ~OnchipMarch() { if (slots) (void)hipFree(slots); if (box) (void)hipFree(box); if (bad) (void)hipFree(bad); if (hostErr) (void)hipHostFree(hostErr); }
     struct Variant { int rows, waves; const void* fn; };
-    template <class Op> static const std::vector<Variant>& variants() {
+    template <class Op, int R, int WV, bool LM> static constexpr size_t ldsBytes() {      // A p (where it waits in LDS) + b (LM) + the sums' staging
+        return (Op::C * sizeof(T) * R >= 128 ? (size_t)R * Op::C * sizeof(T) * WV * kWave : 0) + (LM ? (size_t)R * Op::C * sizeof(T) * WV * kWave : 0) + 12 * 1024;
+    }
+    template <class Op, bool LM> static const std::vector<Variant>& variants() {
         static const std::vector<Variant> v = [] {
             std::vector<Variant> o;
-#define MO_VARIANT(R, WV) o.push_back({R, WV, (const void*)march_onchipPcg<T, Op, R, WV>})
+#define MO_VARIANT(R, WV) if constexpr (ldsBytes<Op, R, WV, LM>() <= 150 * 1024) o.push_back({R, WV, (const void*)march_onchipPcg<T, Op, R, WV, LM>})
             MO_VARIANT(2, 4); MO_VARIANT(4, 4); MO_VARIANT(8, 4); MO_VARIANT(2, 8); MO_VARIANT(4, 8); MO_VARIANT(8, 8);
             if constexpr (Op::C * sizeof(T) <= 8) { MO_VARIANT(16, 4); MO_VARIANT(16, 8); }
 #undef MO_VARIANT
@@ -326,10 +360,10 @@ struct OnchipMarch {
         return v;
     }
     // among the variants whose workgroups fit one per CU: the least marching time per SIMD and iteration
-    template <class Op> const Variant* select(int W, int H, int cus, int& stripsX, int& tilesY, int& G) const {
+    template <class Op, bool LM = false> const Variant* select(int W, int H, int cus, int& stripsX, int& tilesY, int& G) const {
         stripsX = divUp(W, kMoSpan);
         const Variant* best = nullptr; int bestCost = 1 << 30;
-        for (const auto& v : variants<Op>()) {
+        for (const auto& v : variants<Op, LM>()) {
             if (forceRows && v.rows != forceRows) continue;
             if (forceWaves && v.waves != forceWaves) continue;
             const int ty = divUp(H, v.rows), g = divUp(stripsX * ty, v.waves);
@@ -340,14 +374,17 @@ struct OnchipMarch {
         return best;
     }
     // the whole linear solve + X += delta; false (nothing touched): not offered for this plan
-    template <class Op> bool solve(const Op& op, int W, int H, const uint8_t* flags, const T* coef, const T* r0, const T* p0, T* delta, T* X, int L, int cus, LaunchCtx& ctx) {
+    // lm: Levenberg-Marquardt (the solver applies the update itself and hears of a time-out through hostErr)
+    template <class Op> bool solve(const Op& op, int W, int H, const uint8_t* flags, const T* coef, const T* r0, const T* p0, T* delta, T* X, int L, int cus, LaunchCtx& ctx,
+                                   const OnChipLm<T>* lm = nullptr) {
         constexpr int C = Op::C;
         if (!enabled || failed || L <= 0 || (unsigned long long)W * H * C * sizeof(T) >= (1ull << 30)) return false;
+        if (lm && (!lm->CtC || lm->resetPeriod < L)) return false;      // a split residual reset before the last iteration: the generic kernels' business
         int stripsX = 0, tilesY = 0, G = 0;
-        const Variant* V = select<Op>(W, H, cus, stripsX, tilesY, G);
+        const Variant* V = lm ? select<Op, true>(W, H, cus, stripsX, tilesY, G) : select<Op, false>(W, H, cus, stripsX, tilesY, G);
         if (!V) return false;
         if (!slots) {      // sized for this plan's image once (the dimensions of a plan are fixed); zero = no tag
-            slotBytes = sizeof(oc_u64) * 2 * (size_t)kMoMaxG * kMoNW; boxBytes = sizeof(oc_u64) * 2 * (size_t)W * H * C * (sizeof(T) / 4);
+            slotBytes = sizeof(oc_u64) * 2 * (size_t)kMoMaxG * kMoNWMax; boxBytes = sizeof(oc_u64) * 2 * (size_t)W * H * C * (sizeof(T) / 4);
             HIP_CHECK(hipMalloc((void**)&slots, slotBytes)); HIP_CHECK(hipMalloc((void**)&box, boxBytes));
             HIP_CHECK(hipMalloc((void**)&bad, sizeof(int))); HIP_CHECK(hipHostMalloc((void**)&hostErr, 64)); *hostErr = 0;
             HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), ctx.stream));
@@ -357,7 +394,7 @@ struct OnchipMarch {
             HIP_CHECK(hipMemsetAsync(slots, 0, slotBytes, ctx.stream)); HIP_CHECK(hipMemsetAsync(box, 0, boxBytes, ctx.stream));
             seq = 2;
         }
-        MoArgs<T> K{W, H, r0, p0, delta, flags, coef, stripsX, tilesY, G, L, seq, slots, box, bad, timeoutTicks, failAt};
+        MoArgs<T> K{W, H, r0, p0, delta, flags, coef, stripsX, tilesY, G, L, seq, slots, box, bad, timeoutTicks, failAt, lm ? lm->CtC : nullptr, lm ? lm->qTolerance : T(0), lm ? hostErr : nullptr};
         {
             ScopedKernel k(ctx, "PCGSolveOnChip");
             Op opc = op;
@@ -365,7 +402,7 @@ struct OnchipMarch {
             if (hipLaunchKernel(V->fn, dim3(G), dim3(V->waves * kWave), kargs, 0, ctx.stream) != hipSuccess) { (void)hipGetLastError(); enabled = false; return false; }
         }
         seq += (unsigned)L;
-        {
+        if (!lm) {
             ScopedKernel k(ctx, "PCGLinearUpdate");
             const long n = (long)W * H * C;
             const int grid = (int)std::max<long>(1, std::min<long>((n + kBlock - 1) / kBlock, (long)cus * 8));
@@ -383,12 +420,12 @@ struct OnchipMarch {
     }
     template <class Op> std::string describe(int W, int H, int cus, int L, bool lmv, const char* marchName) const {
         int stripsX = 0, tilesY = 0, G = 0;
-        const Variant* V = (enabled && !failed && !lmv && L > 0) ? select<Op>(W, H, cus, stripsX, tilesY, G) : nullptr;
+        const Variant* V = (enabled && !failed && L > 0) ? (lmv ? select<Op, true>(W, H, cus, stripsX, tilesY, G) : select<Op, false>(W, H, cus, stripsX, tilesY, G)) : nullptr;
         char buf[500];
-        if (V) snprintf(buf, sizeof buf, "path=on-chip (march_onchipPcg); onchip_rows_per_wave=%d; waves_per_workgroup=%d; wave_tiles=%dx%d of 62 x %d pixels; workgroups=%d of %d CUs; fallback=one launch per PCG iteration (%s)",
-                        V->rows, V->waves, stripsX, tilesY, V->rows, G, cus, marchName);
+        if (V) snprintf(buf, sizeof buf, "path=on-chip (march_onchipPcg%s); onchip_rows_per_wave=%d; waves_per_workgroup=%d; wave_tiles=%dx%d of 62 x %d pixels; workgroups=%d of %d CUs; fallback=one launch per PCG iteration (%s)",
+                        lmv ? ", LM while lIterations <= residual_reset_period" : "", V->rows, V->waves, stripsX, tilesY, V->rows, G, cus, lmv ? "generic kernels" : marchName);
         else snprintf(buf, sizeof buf, "path=one launch per PCG iteration (%s); why_not_on_chip=%s", lmv ? "generic kernels, LM" : marchName,
-                      !enabled ? "switched off" : failed ? "a wait timed out earlier" : lmv ? "Gauss-Newton only" : "the wave tiles do not fit the CUs");
+                      !enabled ? "switched off" : failed ? "a wait timed out earlier" : "the wave tiles do not fit the CUs");
         return buf;
     }
 };

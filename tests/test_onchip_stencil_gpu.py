@@ -132,3 +132,78 @@ def test_config1_poisson_256_takes_the_onchip_solve(oracle_lib):
     d = g.describe()
     g.close()
     assert "on-chip" in d["path"], d
+
+
+# ---- Levenberg-Marquardt (march_onchipPcg<.., LM = true>): CtC, Q with the next iteration's sums, the early-out decided on chip ------------------------------------
+def _lm_side_by_side(oracle_lib, P, nsteps, liters, cost_tol, x_tol, radius_tol, expect_onchip=True, status=None, later_tol=None, **controls):
+    o = oracle_solver(oracle_lib, P, "LMGPU", nIterations=nsteps, lIterations=liters, **controls)
+    o.set_threads(4)
+    g = hip_solver(P, "LMGPU", timing=True, nIterations=nsteps, lIterations=liters, **controls)
+    dev = api.to_device(P)
+    Pref = P.clone()
+    o.init(Pref.params); g.init(dev)
+    scale = max(abs(o.cost()), 1e-300)
+    costs = [(o.cost(), g.cost())]
+    while True:
+        a, b = o.step(Pref.params), g.step(dev)
+        assert a == b, (a, b, costs)
+        costs.append((o.cost(), g.cost()))
+        tol = cost_tol if (later_tol is None or len(costs) <= 2) else later_tol
+        assert abs(g.cost() - o.cost()) <= tol * max(abs(o.cost()), 1e-9 * scale), costs
+        if later_tol is None or len(costs) <= 2:
+            assert abs(g.trust_region_radius() - o.trust_region_radius()) <= radius_tol * o.trust_region_radius(), costs
+        if not a:
+            break
+    assert ("PCGSolveOnChip" in g.kernel_timings()) == expect_onchip, g.kernel_timings().keys()
+    assert g.on_chip_status() == (status if status is not None else (1 if expect_onchip else 0))
+    if x_tol is not None:
+        assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < x_tol
+    g.close(); o.close()
+
+
+LM_SHAPES = [(7, 9), (61, 5), (62, 3), (63, 9), (300, 40), (64, 300), (517, 33)]
+
+
+@pytest.mark.parametrize("rows,waves", [(2, 4), (4, 4), (8, 4), (2, 8)])
+@pytest.mark.parametrize("mask", ["random", "none"])
+@pytest.mark.parametrize("W,H", LM_SHAPES)
+def test_lm_poisson_double(oracle_lib, monkeypatch, W, H, mask, rows, waves):
+    monkeypatch.setenv("OPT_AMD_ONCHIP_ROWS", str(rows)); monkeypatch.setenv("OPT_AMD_ONCHIP_WAVES", str(waves))
+    _lm_side_by_side(oracle_lib, _poisson(W, H, True, W * 3 + H, mask), 3, 10, 1e-10, 1e-9, 1e-8)
+
+
+@pytest.mark.parametrize("rows,waves", VARIANTS)
+@pytest.mark.parametrize("W,H", [(61, 5), (300, 40), (517, 33)])
+def test_lm_poisson_float(oracle_lib, monkeypatch, W, H, rows, waves):
+    monkeypatch.setenv("OPT_AMD_ONCHIP_ROWS", str(rows)); monkeypatch.setenv("OPT_AMD_ONCHIP_WAVES", str(waves))
+    _lm_side_by_side(oracle_lib, _poisson(W, H, False, W * 5 + H, "random"), 2, 10, 1e-5, None, 1e-3, later_tol=1e-3, q_tolerance=-1e9)
+
+
+@pytest.mark.parametrize("rows,waves", VARIANTS + [(16, 4), (16, 8)])
+@pytest.mark.parametrize("W,H", [(61, 5), (300, 40), (64, 300)])
+def test_lm_laplacian_float(oracle_lib, monkeypatch, W, H, rows, waves):
+    monkeypatch.setenv("OPT_AMD_ONCHIP_ROWS", str(rows)); monkeypatch.setenv("OPT_AMD_ONCHIP_WAVES", str(waves))
+    _lm_side_by_side(oracle_lib, wl.laplacian(W, H, seed=W + H), 2, 10, 1e-5, None, 1e-3, later_tol=1e-3, q_tolerance=-1e9)
+
+
+@pytest.mark.parametrize("rows,waves", [(2, 4), (4, 4), (8, 4), (2, 8), (4, 8)])
+@pytest.mark.parametrize("W,H", [(61, 5), (300, 40), (517, 33)])
+def test_lm_optical_flow_double(oracle_lib, monkeypatch, W, H, rows, waves):
+    monkeypatch.setenv("OPT_AMD_ONCHIP_ROWS", str(rows)); monkeypatch.setenv("OPT_AMD_ONCHIP_WAVES", str(waves))
+    _lm_side_by_side(oracle_lib, wl.optical_flow(W, H, double=True, seed=W + H, init_flow=1.2), 3, 10, 1e-10, 1e-9, 1e-8)
+
+
+@pytest.mark.parametrize("liters,period,onchip", [(10, 10, True), (9, 10, True), (12, 12, True), (12, 5, False), (6, 1, False)])
+def test_lm_residual_reset_inside_the_solve_stays_on_the_generic_kernels(oracle_lib, liters, period, onchip):
+    _lm_side_by_side(oracle_lib, _poisson(120, 70, True, 9, "random"), 3, liters, 1e-10, 1e-9, 1e-8, expect_onchip=onchip, residual_reset_period=period)
+
+
+@pytest.mark.parametrize("qtol", [0.5, 0.05, 5.0, 0.0])
+def test_lm_q_early_out_double(oracle_lib, qtol):
+    _lm_side_by_side(oracle_lib, _poisson(130, 90, True, 11, "random"), 4, 10, 1e-10, 1e-9, 1e-8, q_tolerance=qtol)
+
+
+@pytest.mark.parametrize("fail_at", [0, 2])
+def test_lm_timeout_path(oracle_lib, monkeypatch, fail_at):
+    monkeypatch.setenv("OPT_AMD_ONCHIP_FAIL_AT", str(fail_at))
+    _lm_side_by_side(oracle_lib, _poisson(130, 70, True, 3, "random"), 3, 10, 1e-10, 1e-9, 1e-8, expect_onchip=True, status=2, q_tolerance=-1e9)
