@@ -12,13 +12,16 @@ CASES = [("poisson 256^2 f32 GN 1x10 (config 1)", lambda: wl.poisson_image_editi
          ("optical_flow 512^2 f32 GN 3x50", lambda: wl.optical_flow(512, 512, seed=1), 3, 50),
          ("optical_flow 960x540 f32 GN 3x50", lambda: wl.optical_flow(960, 540, seed=1), 3, 50),
          ("optical_flow 1024^2 f32 GN 3x50", lambda: wl.optical_flow(1024, 1024, seed=1), 3, 50)]
-for name, make, nit, lit in CASES:
+CASES = [c + ("gaussNewtonGPU",) for c in CASES] + [("poisson 512^2 f32 LM 5x10", lambda: wl.poisson_image_editing(512, 512, seed=1), 5, 10, "LMGPU"),
+                                                   ("optical_flow 512^2 f32 LM 5x10", lambda: wl.optical_flow(512, 512, seed=1), 5, 10, "LMGPU"),
+                                                   ("laplacian 512^2 f32 LM 5x10", lambda: wl.laplacian(512, 512, seed=1), 5, 10, "LMGPU")]
+for name, make, nit, lit, kind in CASES:
     for flag in ("0", "1"):
         os.environ["OPT_AMD_ONCHIP"] = flag
         out = []
         for timing in (False, True):
             P = make()
-            g = api.Solver(api.energy_file(P.energy), "gaussNewtonGPU", P.dims, double=P.double, timing=timing)
+            g = api.Solver(api.energy_file(P.energy), kind, P.dims, double=P.double, timing=timing)
             g.set_parameter("nIterations", nit); g.set_parameter("lIterations", lit)
             dev = api.to_device(P); g.solve(dev)
             dev = api.to_device(P)
