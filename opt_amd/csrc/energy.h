@@ -144,6 +144,8 @@ struct EnergyOps {
     virtual bool pcgSolveOnChip(const T* /*r0*/, const T* /*p0*/, T* /*delta*/, int /*lIterations*/, double* /*traceDev*/, const OnChipLm<T>* /*lm*/, LaunchCtx&) { return false; }
     // an energy that does not precondition (UsePreconditioner(false): no preconditioner vector exists) but offers pcgSolveOnChip all the same
     virtual bool onChipWithoutPreconditioner() const { return false; }
+    // Gauss-Newton: did pcgSolveOnChip end with PCGLinearUpdate (X += delta) itself?  false: the solver applies delta as after any other linear solve
+    virtual bool onChipAppliedUpdate() const { return true; }
     // Row slabs: would pcgSolveOnChip run for this rank's slab right now (kernel variant fits, unit lattice, the communicator offers onChipPlan ...)?  The solver
     // makes the decision collective (all ranks or none) before anyone launches.  onChipPlan / onChipCtx: the communicator's entry (OptAmd_SlabCommExt), set by the solver.
     virtual bool slabOnChipAvailable(int /*lIterations*/) { return false; }

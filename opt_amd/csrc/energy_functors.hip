@@ -282,6 +282,24 @@ struct IntrinsicOps : StencilOps<T, IntrinsicE<T>> {
         return march.launch(IntrinsicMarchOp<T>{this->e.w_fit, this->e.w_regA, this->e.w_regS}, this->e.W, this->e.H, nullptr, this->cus, a, ctx, coef);
     }
     const T* pcgFinish(const T*, T* delta, LaunchCtx& ctx) override { return march.finish(delta, 4L * this->e.W * this->e.H, this->cus, ctx); }
+    // ---- the whole linear solve on chip (stencil_onchip.h); the operator's coefficients are repacked first, as for the marching loop ----
+    OnchipMarch<T> oc;
+    bool onChipWithoutPreconditioner() const override { return true; }
+    bool pcgSolveOnChip(const T* r0, const T* p0, T* delta, int L, double* traceDev, const OnChipLm<T>* lm, LaunchCtx& ctx) override {
+        if (!useMarch || traceDev || this->slab.active) return false;
+        using Op = IntrinsicMarchOp<T>;
+        int sx, ty, G;
+        if (!oc.enabled || oc.failed || (lm && (!lm->CtC || lm->resetPeriod < L)) ||
+            !(lm ? oc.template select<Op, true>(this->e.W, this->e.H, this->cus, sx, ty, G) : oc.template select<Op, false>(this->e.W, this->e.H, this->cus, sx, ty, G))) return false;
+        const long n = (long)this->e.W * this->e.H;
+        if (!coef) HIP_CHECK(hipMalloc((void**)&coef, (size_t)(4 * n) * sizeof(T)));
+        { ScopedKernel k(ctx, "operatorCoefficients"); intrinsic_coef<T><<<this->grid(), kBlock, 0, ctx.stream>>>(this->e.aux, coef, n); }
+        // (X += delta runs flat over the solver's layout: the two unknown images are consecutive there, but the CALLER's two arrays need not be -- the update stays with the solver)
+        return oc.solve(Op{this->e.w_fit, this->e.w_regA, this->e.w_regS}, this->e.W, this->e.H, nullptr, coef, r0, p0, delta, (T*)nullptr, L, this->cus, ctx, lm);
+    }
+    bool onChipAppliedUpdate() const override { return false; }
+    bool onChipFailed() override { return oc.failedNow(); }
+    std::string describe(int L, bool lmv) override { return oc.template describe<IntrinsicMarchOp<T>>(this->e.W, this->e.H, this->cus, useMarch ? L : 0, lmv, "march_pcgIter"); }
 };
 template <class T> EnergyOps<T>* makeIntrinsic(const unsigned* dims) { return new IntrinsicOps<T>(dims); }
 // OPT_AMD_VOLUMETRIC_ARAP=0: the functor engine; default: ARAP's kernel set on the lattice graph (graph_common.h makeVolumetricOnArap -- the same energy, 151 -> ... ms at 96^3)

@@ -586,7 +586,7 @@ struct PcgSolver : SolverBase {
                 tr = onChipTrace;
             }
             if (E->pcgSolveOnChip(r, p, delta, sp.lIterations, tr, nullptr, ctx)) {
-                usedOnChip = true; unknownsUpdated = true;
+                usedOnChip = true; unknownsUpdated = E->onChipAppliedUpdate();
                 if (traceEnabled) {
                     std::vector<double> h(4 * (size_t)sp.lIterations);
                     HIP_CHECK(hipMemcpyAsync(h.data(), onChipTrace, sizeof(double) * h.size(), hipMemcpyDeviceToHost, stream));

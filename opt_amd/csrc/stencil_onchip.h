@@ -1,4 +1,4 @@
-// 5-point stencils with C channels per pixel (the operators of stencil_march.h: poisson_image_editing, the minimal laplacian, optical_flow): the WHOLE PCG linear solve
+// 5-point stencils with C channels per pixel (the operators of stencil_march.h: poisson_image_editing, the minimal laplacian, optical_flow, intrinsic_image_decomposition): the WHOLE PCG linear solve
 // of a Gauss-Newton step as one persistent launch whose loop state never leaves the chip.
 //
 // What it replaces: the reference's loop `for lIter = 0, lIterations do PCGStep1; PCGStep2; PCGStep3 end` (solverGPUGaussNewton.t:1056-1092) -- one marching launch per
@@ -16,7 +16,7 @@
 // Levenberg-Marquardt (LM = true): + CtC p (o.t:2076-2082; CtC as PCGFinalizeDiagonal left it, the start p_0 = M_LM r_0 comes from the solver, later z = r), a fifth sum --
 // sum r_0^2 in iteration 0, then Q_k = 1/2 sum delta . (r + b) (solver.t:483-485) formed where iteration k is applied and carried by the sums of iteration k + 1 -- and the
 // q early-out (:1093-1102) decided by every workgroup from the same totals; a residual reset before the last iteration (lIterations > residual_reset_period) keeps the solve
-// on the generic kernels.  Not for Op::kSplit31 (intrinsic_image_decomposition).
+// on the generic kernels.  Op::kSplit31 (intrinsic_image_decomposition: two unknown images) only changes where a pixel's scalars sit in the solver's vectors.
 #pragma once
 #include "stencil_march.h"
 #include "onchip_sync.h"
@@ -47,7 +47,6 @@ __device__ __forceinline__ double moFma(double a, double b, double c) { return _
 template <class T, class Op, int R, int WAVES, bool LM>
 __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T> K) {
     constexpr int kMoNS = LM ? 5 : 4, kMoNW = 2 * kMoNS;
-    static_assert(!Op::kSplit31, "one image of C channels per pixel");
     constexpr int C = Op::C, HR = R + 2, kBlk = WAVES * kWave, WPS = (int)sizeof(T) / 4;
     constexpr int kCoefN = Op::kCoef > 0 ? Op::kCoef : 1;
     using Vec = MVec<T, C>; using Coef = MVec<T, kCoefN>;
@@ -70,6 +69,8 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
     const int N = K.W * K.H;
     int* const bad = K.bad;
     const long long to = K.timeoutTicks;
+    // scalar (pixel i, channel c) of a solver vector: C interleaved channels, or -- Op::kSplit31 -- a 3-channel image followed by a 1-channel image (energy.h)
+    auto at = [&](long i, int c) -> long { if constexpr (Op::kSplit31) return c < 3 ? i * 3 + c : 3L * N + i; else return i * C + c; };
 
     // ---- p_0, r_0, the flag bit and the operator coefficients of the held pixels (a pixel outside the image or switched off: zeros, off); delta = 0 ----------------
     Vec p[HR], r[HR], dl[R], ap[AP_LDS ? 1 : R];
@@ -84,13 +85,13 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
         bool on = in;
         if (Op::kMasked) on = on && (K.flags[i] & 1);
 #pragma unroll
-        for (int c = 0; c < C; ++c) { const T pv = K.p0[i * C + c], rv = K.r0[i * C + c]; p[h].v[c] = on ? pv : T(0); r[h].v[c] = on ? rv : T(0); }
+        for (int c = 0; c < C; ++c) { const T pv = K.p0[at(i, c)], rv = K.r0[at(i, c)]; p[h].v[c] = on ? pv : T(0); r[h].v[c] = on ? rv : T(0); }
 #pragma unroll
         for (int c = 0; c < kCoefN; ++c) cf[h].v[c] = Op::kCoef > 0 ? K.coef[i * kCoefN + c] : T(0);
         onBits |= on ? (1u << h) : 0u;
         if (LM && h >= 1 && h <= R) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) { const T cv = K.CtC[i * C + c]; ctc[LM ? h - 1 : 0].v[c] = on ? cv : T(0); bL[((LM ? h - 1 : 0) * C + c) * kBlk + tid] = r[h].v[c]; }      // b = r_0 (solver.t:657)
+            for (int c = 0; c < C; ++c) { const T cv = K.CtC[at(i, c)]; ctc[LM ? h - 1 : 0].v[c] = on ? cv : T(0); bL[((LM ? h - 1 : 0) * C + c) * kBlk + tid] = r[h].v[c]; }      // b = r_0 (solver.t:657)
         }
     }
 #pragma unroll
@@ -307,9 +308,9 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
         for (int i = 0; i < R; ++i) {
             const int y = yBase + i;
             if (y < K.H) {
-                const long e = ((long)y * K.W + x) * C;
+                const long e = (long)y * K.W + x;
 #pragma unroll
-                for (int c = 0; c < C; ++c) K.delta[e + c] = dl[i].v[c];
+                for (int c = 0; c < C; ++c) K.delta[at(e, c)] = dl[i].v[c];
             }
         }
     }
@@ -394,7 +395,7 @@ struct OnchipMarch {
             HIP_CHECK(hipMemsetAsync(slots, 0, slotBytes, ctx.stream)); HIP_CHECK(hipMemsetAsync(box, 0, boxBytes, ctx.stream));
             seq = 2;
         }
-        MoArgs<T> K{W, H, r0, p0, delta, flags, coef, stripsX, tilesY, G, L, seq, slots, box, bad, timeoutTicks, failAt, lm ? lm->CtC : nullptr, lm ? lm->qTolerance : T(0), lm ? hostErr : nullptr};
+        MoArgs<T> K{W, H, r0, p0, delta, flags, coef, stripsX, tilesY, G, L, seq, slots, box, bad, timeoutTicks, failAt, lm ? lm->CtC : nullptr, lm ? lm->qTolerance : T(0), (lm || !X) ? hostErr : nullptr};      // (no X: the solver applies the update itself, as for LM)
         {
             ScopedKernel k(ctx, "PCGSolveOnChip");
             Op opc = op;
@@ -402,7 +403,7 @@ struct OnchipMarch {
             if (hipLaunchKernel(V->fn, dim3(G), dim3(V->waves * kWave), kargs, 0, ctx.stream) != hipSuccess) { (void)hipGetLastError(); enabled = false; return false; }
         }
         seq += (unsigned)L;
-        if (!lm) {
+        if (!lm && X) {
             ScopedKernel k(ctx, "PCGLinearUpdate");
             const long n = (long)W * H * C;
             const int grid = (int)std::max<long>(1, std::min<long>((n + kBlock - 1) / kBlock, (long)cus * 8));

@@ -205,3 +205,44 @@ def test_lm_q_early_out_double(oracle_lib, qtol):
 def test_lm_timeout_path(oracle_lib, monkeypatch, fail_at):
     monkeypatch.setenv("OPT_AMD_ONCHIP_FAIL_AT", str(fail_at))
     _lm_side_by_side(oracle_lib, _poisson(130, 70, True, 3, "random"), 3, 10, 1e-10, 1e-9, 1e-8, expect_onchip=True, status=2, q_tolerance=-1e9)
+
+
+# ---- intrinsic_image_decomposition: two unknown images (3 + 1 channels per pixel: the solver's split layout), four operator coefficients per pixel; the update is
+# applied by the solver (the caller's two arrays need not be consecutive) ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("liters", [1, 3, 12])
+@pytest.mark.parametrize("rows,waves", [(2, 4), (4, 4), (2, 8)])
+@pytest.mark.parametrize("W,H", [(7, 9), (61, 5), (62, 3), (63, 9), (300, 40), (64, 300)])
+def test_intrinsic_double(oracle_lib, monkeypatch, W, H, rows, waves, liters):
+    """(ill-conditioned, unpreconditioned: 1e-8 / 1e-7 as in tests/test_stencil_march_gpu.py)"""
+    monkeypatch.setenv("OPT_AMD_ONCHIP_ROWS", str(rows)); monkeypatch.setenv("OPT_AMD_ONCHIP_WAVES", str(waves))
+    _pair(oracle_lib, wl.intrinsic_image_decomposition(W, H, double=True, seed=W + H + liters), 2, liters, 1e-8, 1e-7)
+
+
+@pytest.mark.parametrize("rows,waves", [(2, 4), (4, 4), (8, 4), (2, 8), (4, 8)])
+def test_intrinsic_float_variants_against_the_marching_kernels(monkeypatch, rows, waves):
+    """float: the trajectory of this energy is outside the 1e-5 contract for any two implementations (tests/golden/float_envelopes.json); the variants are pinned against the
+    marching loop on the same input after one Gauss-Newton step of 5 iterations"""
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("OPT_AMD_ONCHIP", flag); monkeypatch.setenv("OPT_AMD_ONCHIP_ROWS", str(rows)); monkeypatch.setenv("OPT_AMD_ONCHIP_WAVES", str(waves))
+        P = wl.intrinsic_image_decomposition(200, 120, double=False, seed=4)
+        g = hip_solver(P, "gaussNewtonGPU", timing=True, nIterations=1, lIterations=5)
+        dev = api.to_device(P)
+        g.solve(dev)
+        assert ("PCGSolveOnChip" in g.kernel_timings()) == (flag == "1")
+        res[flag] = (g.cost(), device_unknowns(P, dev))
+        g.close()
+    assert abs(res["1"][0] - res["0"][0]) <= 2e-4 * abs(res["0"][0])
+    assert rel_err(res["1"][1], res["0"][1]) < 1e-4
+
+
+@pytest.mark.parametrize("rows,waves", [(2, 4), (4, 4), (2, 8)])
+@pytest.mark.parametrize("W,H", [(61, 5), (300, 40)])
+def test_lm_intrinsic_double(oracle_lib, monkeypatch, W, H, rows, waves):
+    monkeypatch.setenv("OPT_AMD_ONCHIP_ROWS", str(rows)); monkeypatch.setenv("OPT_AMD_ONCHIP_WAVES", str(waves))
+    _lm_side_by_side(oracle_lib, wl.intrinsic_image_decomposition(W, H, double=True, seed=W + H), 3, 10, 1e-8, 1e-6, 1e-6)
+
+
+def test_intrinsic_timeout_path(oracle_lib, monkeypatch):
+    monkeypatch.setenv("OPT_AMD_ONCHIP_FAIL_AT", "1")
+    _pair(oracle_lib, wl.intrinsic_image_decomposition(200, 90, double=True, seed=3), 2, 10, 1e-8, 1e-7, status=2)
