@@ -55,6 +55,8 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
     __shared__ unsigned W1[kMoMaxG * kMoNW];
     constexpr bool AP_LDS = C * sizeof(T) * R >= 128;      // where the registers are short, A p of the owned pixels waits in LDS between the stencil and the update: [row][channel][thread]
     __shared__ T apL[AP_LDS ? R * C * kBlk : 1];
+    constexpr bool DL_LDS = AP_LDS && Op::kCoef >= 4 && (C + Op::kCoef) * sizeof(T) * R >= 256;      // ... and, for the fattest pixels (four channels + four coefficients), delta itself
+    __shared__ T dlL[DL_LDS ? R * C * kBlk : 1];
     __shared__ T bL[LM ? R * C * kBlk : 1];      // LM: b = r_0 of the owned pixels (for Q)
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = blockIdx.x;
     const int tile = g * WAVES + wave;
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
     auto at = [&](long i, int c) -> long { if constexpr (Op::kSplit31) return c < 3 ? i * 3 + c : 3L * N + i; else return i * C + c; };
 
     // ---- p_0, r_0, the flag bit and the operator coefficients of the held pixels (a pixel outside the image or switched off: zeros, off); delta = 0 ----------------
-    Vec p[HR], r[HR], dl[R], ap[AP_LDS ? 1 : R];
+    Vec p[HR], r[HR], dl[DL_LDS ? 1 : R], ap[AP_LDS ? 1 : R];
     Coef cf[HR];
     Vec ctc[LM ? R : 1];      // LM: CtC of the owned pixels
     unsigned onBits = 0;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
 #pragma unroll
     for (int i = 0; i < R; ++i)
 #pragma unroll
-        for (int c = 0; c < C; ++c) { dl[i].v[c] = 0; if (AP_LDS) apL[((AP_LDS ? i : 0) * C + c) * kBlk + tid] = 0; else ap[AP_LDS ? 0 : i].v[c] = 0; }
+        for (int c = 0; c < C; ++c) { if (DL_LDS) dlL[((DL_LDS ? i : 0) * C + c) * kBlk + tid] = 0; else dl[DL_LDS ? 0 : i].v[c] = 0; if (AP_LDS) apL[((AP_LDS ? i : 0) * C + c) * kBlk + tid] = 0; else ap[AP_LDS ? 0 : i].v[c] = 0; }
 
     const int pixBase = (yBase - 1) * K.W + xc;      // index of held row 0 of this lane's column (used only where the row exists)
     auto rowIn = [&](int h) { const int y = yBase - 1 + h; return xin && y >= 0 && y < K.H; };
@@ -293,10 +295,14 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const T apv = ownRow ? (writer ? (AP_LDS ? apL[((AP_LDS && ownRow ? h - 1 : 0) * C + c) * kBlk + tid] : ap[!AP_LDS && ownRow ? h - 1 : 0].v[c]) : ring[h].v[c]) : ring[h].v[c];
-                if (ownRow) dl[ownRow ? h - 1 : 0].v[c] = moFma(alpha, p[h].v[c], dl[ownRow ? h - 1 : 0].v[c]);
+                T dNew = 0;
+                if (ownRow) {
+                    dNew = moFma(alpha, p[h].v[c], DL_LDS ? dlL[((DL_LDS && ownRow ? h - 1 : 0) * C + c) * kBlk + tid] : dl[!DL_LDS && ownRow ? h - 1 : 0].v[c]);
+                    if (DL_LDS) dlL[((DL_LDS && ownRow ? h - 1 : 0) * C + c) * kBlk + tid] = dNew; else dl[!DL_LDS && ownRow ? h - 1 : 0].v[c] = dNew;
+                }
                 if (!last) {
                     r[h].v[c] = moFma(-alpha, apv, r[h].v[c]);
-                    if (LM && ownRow && writer && yBase - 1 + h < K.H) accQ += (double)(T(0.5) * (dl[ownRow ? h - 1 : 0].v[c] * (r[h].v[c] + bL[((LM && ownRow ? h - 1 : 0) * C + c) * kBlk + tid])));      // solver.t:483-485
+                    if (LM && ownRow && writer && yBase - 1 + h < K.H) accQ += (double)(T(0.5) * (dNew * (r[h].v[c] + bL[((LM && ownRow ? h - 1 : 0) * C + c) * kBlk + tid])));      // solver.t:483-485
                     p[h].v[c] = moFma(beta, p[h].v[c], r[h].v[c]);
                 }
             }
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
             if (y < K.H) {
                 const long e = (long)y * K.W + x;
 #pragma unroll
-                for (int c = 0; c < C; ++c) K.delta[at(e, c)] = dl[i].v[c];
+                for (int c = 0; c < C; ++c) K.delta[at(e, c)] = DL_LDS ? dlL[((DL_LDS ? i : 0) * C + c) * kBlk + tid] : dl[DL_LDS ? 0 : i].v[c];
             }
         }
     }
@@ -343,8 +349,10 @@ struct OnchipMarch {
     }
     ~OnchipMarch() { if (slots) (void)hipFree(slots); if (box) (void)hipFree(box); if (bad) (void)hipFree(bad); if (hostErr) (void)hipHostFree(hostErr); }
     struct Variant { int rows, waves; const void* fn; };
-    template <class Op, int R, int WV, bool LM> static constexpr size_t ldsBytes() {      // A p (where it waits in LDS) + b (LM) + the sums' staging
-        return (Op::C * sizeof(T) * R >= 128 ? (size_t)R * Op::C * sizeof(T) * WV * kWave : 0) + (LM ? (size_t)R * Op::C * sizeof(T) * WV * kWave : 0) + 12 * 1024;
+    template <class Op, int R, int WV, bool LM> static constexpr size_t ldsBytes() {      // A p and delta (where they wait in LDS) + b (LM) + the sums' staging
+        const size_t plane = (size_t)R * Op::C * sizeof(T) * WV * kWave;
+        const bool apLds = Op::C * sizeof(T) * R >= 128, dlLds = apLds && Op::kCoef >= 4 && (Op::C + Op::kCoef) * sizeof(T) * R >= 256;
+        return (apLds ? plane : 0) + (dlLds ? plane : 0) + (LM ? plane : 0) + 12 * 1024;
     }
     template <class Op, bool LM> static const std::vector<Variant>& variants() {
         static const std::vector<Variant> v = [] {

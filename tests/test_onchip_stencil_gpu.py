@@ -218,7 +218,7 @@ def test_intrinsic_double(oracle_lib, monkeypatch, W, H, rows, waves, liters):
     _pair(oracle_lib, wl.intrinsic_image_decomposition(W, H, double=True, seed=W + H + liters), 2, liters, 1e-8, 1e-7)
 
 
-@pytest.mark.parametrize("rows,waves", [(2, 4), (4, 4), (8, 4), (2, 8), (4, 8)])
+@pytest.mark.parametrize("rows,waves", VARIANTS)
 def test_intrinsic_float_variants_against_the_marching_kernels(monkeypatch, rows, waves):
     """float: the trajectory of this energy is outside the 1e-5 contract for any two implementations (tests/golden/float_envelopes.json); the variants are pinned against the
     marching loop on the same input after one Gauss-Newton step of 5 iterations"""

@@ -13,7 +13,7 @@ CASES = [("poisson 256^2 f32 GN 1x10 (config 1)", lambda: wl.poisson_image_editi
          ("optical_flow 960x540 f32 GN 3x50", lambda: wl.optical_flow(960, 540, seed=1), 3, 50),
          ("optical_flow 1024^2 f32 GN 3x50", lambda: wl.optical_flow(1024, 1024, seed=1), 3, 50),
          ("intrinsic 512^2 f32 GN 7x10", lambda: wl.intrinsic_image_decomposition(512, 512, seed=1), 7, 10),
-         ("intrinsic 700x700 f32 GN 7x10", lambda: wl.intrinsic_image_decomposition(700, 700, seed=1), 7, 10)]
+         ("intrinsic 1024^2 f32 GN 7x10", lambda: wl.intrinsic_image_decomposition(1024, 1024, seed=1), 7, 10)]
 CASES = [c + ("gaussNewtonGPU",) for c in CASES] + [("poisson 512^2 f32 LM 5x10", lambda: wl.poisson_image_editing(512, 512, seed=1), 5, 10, "LMGPU"),
                                                    ("optical_flow 512^2 f32 LM 5x10", lambda: wl.optical_flow(512, 512, seed=1), 5, 10, "LMGPU"),
                                                    ("laplacian 512^2 f32 LM 5x10", lambda: wl.laplacian(512, 512, seed=1), 5, 10, "LMGPU")]
