@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 5: phase profile of the on-chip shape_from_shading kernel (development variant libOpt_sfsprof.so)
 mkdir -p gpurun_out/r05s
+[ -f opt_amd/lib/libOpt_sfsprof.so ] || python -c 'from opt_amd import build; build.build_variant("sfsprof", ["SO_PROFILE=1"])' > /dev/null      # (the development variant is not kept in the tree)
 export OPT_AMD_LIB=$PWD/opt_amd/lib/libOpt_sfsprof.so OPT_AMD_ONCHIP_PROFILE=1
 timeout 300 python -u - > gpurun_out/r05s/prof.txt 2>&1 <<'PY'
 import os, sys
