@@ -277,6 +277,16 @@ struct ScopedEv {      // brackets a callback's launches with an event pair when
     PeerCtx* x; std::vector<std::pair<hipEvent_t, hipEvent_t>>* v; hipStream_t s; hipEvent_t b = nullptr;
     ScopedEv(PeerCtx* x_, std::vector<std::pair<hipEvent_t, hipEvent_t>>* v_, hipStream_t s_) : x(x_), v(v_), s(s_) {
         if (!x->timing) return;
+        // bounded: with timing left on for a long run the oldest pairs (long since completed) are folded into the totals instead of accumulating
+        if (v->size() >= 4096) {
+            double& ms = (v == &x->evAr) ? x->msAr : x->msHalo; long& n = (v == &x->evAr) ? x->nAr : x->nHalo;
+            for (size_t i = 0; i < 2048; ++i) {
+                auto& p = (*v)[i]; float t = 0;
+                if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) { ms += t; ++n; }
+                (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
+            }
+            v->erase(v->begin(), v->begin() + 2048);
+        }
         hipEvent_t a; if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { b = nullptr; return; }
         (void)hipEventRecord(a, s); v->push_back({a, b});
     }

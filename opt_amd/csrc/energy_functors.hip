@@ -306,11 +306,12 @@ template <class T> EnergyOps<T>* makeIntrinsic(const unsigned* dims) { return ne
 template <class T> EnergyOps<T>* makeVolumetric(const unsigned* dims) {
     const char* e = getenv("OPT_AMD_VOLUMETRIC_ARAP");
     // ARAP's kernel set holds, per voxel, 6 half-edges with 9 derivative columns, a 64-byte record, slots and CSR arrays -- about 400 (float) / 800 (double) bytes
-    // per voxel on the device plus two host index vectors of 6 |V| ints -- where the functor engine needs ~100: it is taken only while that fits a quarter of
-    // the free device memory (and 6 |V| half-edges fit 32-bit indices); larger volumes stay on the functor engine instead of failing in hipMalloc.
+    // per voxel on the device plus two host index vectors of 6 |V| ints -- where the functor engine needs ~100: it is taken only while that fits an eighth of
+    // the device's memory (and 6 |V| half-edges fit 32-bit indices); larger volumes stay on the functor engine instead of failing in hipMalloc.
     const unsigned long long nV = (unsigned long long)dims[0] * dims[1] * dims[2];
     size_t freeB = 0, totalB = 0;
-    const bool fits = hipMemGetInfo(&freeB, &totalB) == hipSuccess && nV * (sizeof(T) == 8 ? 800ull : 400ull) < freeB / 4;
+    // (decided from the device's TOTAL memory: the same problem takes the same kernel set whatever else is allocated -- ADVICE round 4)
+    const bool fits = hipMemGetInfo(&freeB, &totalB) == hipSuccess && nV * (sizeof(T) == 8 ? 800ull : 400ull) < totalB / 8;
     if ((!e || atoi(e) != 0) && nV < (1ull << 28) && fits) return makeVolumetricOnArap<T>(dims);
     return new StencilOps<T, VolumetricE<T>>(dims, true);
 }
