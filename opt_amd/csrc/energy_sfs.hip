@@ -641,6 +641,7 @@ struct SfsOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_ONCHIP_WAVES")) soForceWaves = std::max(0, atoi(e));
         if (const char* e = getenv("OPT_AMD_ONCHIP_FAIL_AT")) soFailAt = atoi(e);      // test hook: see SfsOcArgs::failAt
         if (const char* e = getenv("OPT_AMD_ONCHIP_TIMEOUT_MS")) soTimeoutTicks = std::max(1, atoi(e)) * 100000LL;
+        soReserve();
     }
     ~SfsOps() override { for (void* p : owned) (void)hipFree(p); if (soHostErr) (void)hipHostFree(soHostErr); }
     int grid() const { return (int)std::max<long>(1, std::min<long>(((long)A.W * A.H + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
@@ -784,6 +785,20 @@ struct SfsOps : EnergyOps<T> {
         }
         return best;
     }
+    // the buffers of the path, sized for the plan's image when the plan is made (so that its first linear solve does not pay for the allocations); zero = no tag
+    void soReserve() {
+        if (soSlots || !soEnabled || (unsigned long long)A.W * A.H * sizeof(T) >= (1ull << 30)) return;
+        soSlotBytes = sizeof(oc_u64) * 2 * (size_t)kSoMaxG * kSoNW; soBoxBytes = sizeof(oc_u64) * 2 * (size_t)A.W * A.H * (sizeof(T) / 4);
+        HIP_CHECK(hipMalloc((void**)&soSlots, soSlotBytes)); owned.push_back(soSlots);
+        HIP_CHECK(hipMalloc((void**)&soBox, soBoxBytes)); owned.push_back(soBox);
+        HIP_CHECK(hipMalloc((void**)&soBad, sizeof(int))); owned.push_back(soBad);
+        HIP_CHECK(hipHostMalloc((void**)&soHostErr, 64)); *soHostErr = 0;
+        HIP_CHECK(hipMemset(soBad, 0, sizeof(int))); HIP_CHECK(hipMemset(soSlots, 0, soSlotBytes)); HIP_CHECK(hipMemset(soBox, 0, soBoxBytes)); HIP_CHECK(hipStreamSynchronize(nullptr));      // (done before the plan's own stream sees the buffers)
+        soSeq = 2;
+#if SO_PROFILE
+        if (getenv("OPT_AMD_ONCHIP_PROFILE")) { HIP_CHECK(hipMalloc((void**)&soProf, sizeof(long long) * 8 * kSoMaxG)); owned.push_back(soProf); }
+#endif
+    }
     bool onChipWithoutPreconditioner() const override { return true; }
     bool pcgSolveOnChip(const T* r0, const T* p0, T* delta, int L, double* traceDev, const OnChipLm<T>* lmArgs, LaunchCtx& ctx) override {
         if (!soEnabled || soFailed || this->slab.active || traceDev || L <= 0 || (unsigned long long)A.W * A.H * sizeof(T) >= (1ull << 30)) return false;
@@ -791,18 +806,7 @@ struct SfsOps : EnergyOps<T> {
         int stripsX = 0, tilesY = 0, G = 0;
         const SoVariant* V = soSelect(stripsX, tilesY, G);
         if (!V) return false;
-        if (!soSlots) {      // sized for this plan's image once (the dimensions of a plan are fixed); zero = no tag
-            soSlotBytes = sizeof(oc_u64) * 2 * (size_t)kSoMaxG * kSoNW; soBoxBytes = sizeof(oc_u64) * 2 * (size_t)A.W * A.H * (sizeof(T) / 4);
-            HIP_CHECK(hipMalloc((void**)&soSlots, soSlotBytes)); owned.push_back(soSlots);
-            HIP_CHECK(hipMalloc((void**)&soBox, soBoxBytes)); owned.push_back(soBox);
-            HIP_CHECK(hipMalloc((void**)&soBad, sizeof(int))); owned.push_back(soBad);
-            HIP_CHECK(hipHostMalloc((void**)&soHostErr, 64)); *soHostErr = 0;
-            HIP_CHECK(hipMemsetAsync(soBad, 0, sizeof(int), ctx.stream));
-            soSeq = 0xE0000001u;      // forces the clearing below
-#if SO_PROFILE
-            if (getenv("OPT_AMD_ONCHIP_PROFILE")) { HIP_CHECK(hipMalloc((void**)&soProf, sizeof(long long) * 8 * kSoMaxG)); owned.push_back(soProf); }
-#endif
-        }
+        if (!soSlots) soReserve();
         if (soSeq > 0xE0000000u || soSeq + (unsigned)L > 0xE0000000u) {      // tags never repeat: start over on cleared buffers long before the counter wraps
             HIP_CHECK(hipMemsetAsync(soSlots, 0, soSlotBytes, ctx.stream)); HIP_CHECK(hipMemsetAsync(soBox, 0, soBoxBytes, ctx.stream));
             soSeq = 2;

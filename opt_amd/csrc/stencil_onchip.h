@@ -348,6 +348,16 @@ struct OnchipMarch {
         if (const char* e = getenv("OPT_AMD_ONCHIP_TIMEOUT_MS")) timeoutTicks = std::max(1, atoi(e)) * 100000LL;
     }
     ~OnchipMarch() { if (slots) (void)hipFree(slots); if (box) (void)hipFree(box); if (bad) (void)hipFree(bad); if (hostErr) (void)hipHostFree(hostErr); }
+    // The buffers of the path, sized for the plan's image (the dimensions of a plan are fixed).  Called when the plan is made (the kernel set's constructor), so that the
+    // first linear solve of a plan does not pay for four allocations; solve() calls it itself if nobody has.  zero = no tag.
+    void reserve(int W, int H, int C) {
+        if (slots || !enabled || (unsigned long long)W * H * C * sizeof(T) >= (1ull << 30)) return;
+        slotBytes = sizeof(oc_u64) * 2 * (size_t)kMoMaxG * kMoNWMax; boxBytes = sizeof(oc_u64) * 2 * (size_t)W * H * C * (sizeof(T) / 4);
+        HIP_CHECK(hipMalloc((void**)&slots, slotBytes)); HIP_CHECK(hipMalloc((void**)&box, boxBytes));
+        HIP_CHECK(hipMalloc((void**)&bad, sizeof(int))); HIP_CHECK(hipHostMalloc((void**)&hostErr, 64)); *hostErr = 0;
+        HIP_CHECK(hipMemset(bad, 0, sizeof(int))); HIP_CHECK(hipMemset(slots, 0, slotBytes)); HIP_CHECK(hipMemset(box, 0, boxBytes)); HIP_CHECK(hipStreamSynchronize(nullptr));      // (done before the plan's own stream sees the buffers)
+        seq = 2;
+    }
     struct Variant { int rows, waves; const void* fn; };
     template <class Op, int R, int WV, bool LM> static constexpr size_t ldsBytes() {      // A p and delta (where they wait in LDS) + b (LM) + the sums' staging
         const size_t plane = (size_t)R * Op::C * sizeof(T) * WV * kWave;
@@ -392,13 +402,7 @@ struct OnchipMarch {
         int stripsX = 0, tilesY = 0, G = 0;
         const Variant* V = lm ? select<Op, true>(W, H, cus, stripsX, tilesY, G) : select<Op, false>(W, H, cus, stripsX, tilesY, G);
         if (!V) return false;
-        if (!slots) {      // sized for this plan's image once (the dimensions of a plan are fixed); zero = no tag
-            slotBytes = sizeof(oc_u64) * 2 * (size_t)kMoMaxG * kMoNWMax; boxBytes = sizeof(oc_u64) * 2 * (size_t)W * H * C * (sizeof(T) / 4);
-            HIP_CHECK(hipMalloc((void**)&slots, slotBytes)); HIP_CHECK(hipMalloc((void**)&box, boxBytes));
-            HIP_CHECK(hipMalloc((void**)&bad, sizeof(int))); HIP_CHECK(hipHostMalloc((void**)&hostErr, 64)); *hostErr = 0;
-            HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), ctx.stream));
-            seq = 0xE0000001u;      // forces the clearing below
-        }
+        if (!slots) { reserve(W, H, C); HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), ctx.stream)); }
         if (seq > 0xE0000000u || seq + (unsigned)L > 0xE0000000u) {      // tags never repeat: start over on cleared buffers long before the counter wraps
             HIP_CHECK(hipMemsetAsync(slots, 0, slotBytes, ctx.stream)); HIP_CHECK(hipMemsetAsync(box, 0, boxBytes, ctx.stream));
             seq = 2;
