@@ -7,8 +7,9 @@
 //   tile    a WAVE holds 64 columns x (R + 4) rows of p and r in registers and owns the 60 x R pixels in the middle: the two-pixel ring around them is held as well
 //           and updated by the holder with the same alpha, beta and the same fused operations as by its owner, so the new search direction never travels;
 //   march   A p of the owned pixels is one pass over the R + 4 held rows with the expressions of sfs_pcgMarch (row values of the centres of row Y - 1, gather of
-//           row Y - 2; DPP shifts for the neighbouring columns); what is constant over the solve (dB_I / d{d0, d1, d2}, the flag word, CtC, b) is re-read per
-//           iteration through the caches (read-only, never written while the kernel runs);
+//           row Y - 2; DPP shifts for the neighbouring columns, the rows centred on the left / right neighbours summed by those lanes and shifted over as one partial sum per
+//           side); what is constant over the solve (dB_I / d{d0, d1, d2}, the flag word, CtC) is re-read per iteration through the caches (read-only, never written
+//           while the kernel runs), b sits in LDS;
 //   ring    the A p of a tile's two outermost rows / columns goes to a tagged image (one 8-byte {payload, tag} word per float, two per double; relaxed agent-scope
 //           stores, no fence), double-buffered by the parity of the iteration; the ring holders pick their pixels' words up INSIDE the wait for the sums;
 //   sums    five per iteration (alphaNum, alphaDen, s2, s3 and -- iteration 0 -- sum r^2 / -- later -- Q of the iteration before): every workgroup posts its
