@@ -788,6 +788,7 @@ struct SfsOps : EnergyOps<T> {
     // the buffers of the path, sized for the plan's image when the plan is made (so that its first linear solve does not pay for the allocations); zero = no tag
     void soReserve() {
         if (soSlots || !soEnabled || (unsigned long long)A.W * A.H * sizeof(T) >= (1ull << 30)) return;
+        { int sx, ty, g; if (!soSelect(sx, ty, g)) return; }      // (the image does not fit the chip: the path will never be taken)
         soSlotBytes = sizeof(oc_u64) * 2 * (size_t)kSoMaxG * kSoNW; soBoxBytes = sizeof(oc_u64) * 2 * (size_t)A.W * A.H * (sizeof(T) / 4);
         HIP_CHECK(hipMalloc((void**)&soSlots, soSlotBytes)); owned.push_back(soSlots);
         HIP_CHECK(hipMalloc((void**)&soBox, soBoxBytes)); owned.push_back(soBox);
@@ -806,7 +807,7 @@ struct SfsOps : EnergyOps<T> {
         int stripsX = 0, tilesY = 0, G = 0;
         const SoVariant* V = soSelect(stripsX, tilesY, G);
         if (!V) return false;
-        if (!soSlots) soReserve();
+        if (!soSlots) { soReserve(); if (!soSlots) return false; }
         if (soSeq > 0xE0000000u || soSeq + (unsigned)L > 0xE0000000u) {      // tags never repeat: start over on cleared buffers long before the counter wraps
             HIP_CHECK(hipMemsetAsync(soSlots, 0, soSlotBytes, ctx.stream)); HIP_CHECK(hipMemsetAsync(soBox, 0, soBoxBytes, ctx.stream));
             soSeq = 2;

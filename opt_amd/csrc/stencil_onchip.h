@@ -352,6 +352,7 @@ struct OnchipMarch {
     // first linear solve of a plan does not pay for four allocations; solve() calls it itself if nobody has.  zero = no tag.
     void reserve(int W, int H, int C) {
         if (slots || !enabled || (unsigned long long)W * H * C * sizeof(T) >= (1ull << 30)) return;
+        if ((long)W * H > (long)kMoMaxG * 8 * kMoSpan * 16 || divUp(W, kMoSpan) > kMoMaxG * 8) return;      // (more pixels than the largest variant holds on the largest grid: the path will never be taken)
         slotBytes = sizeof(oc_u64) * 2 * (size_t)kMoMaxG * kMoNWMax; boxBytes = sizeof(oc_u64) * 2 * (size_t)W * H * C * (sizeof(T) / 4);
         HIP_CHECK(hipMalloc((void**)&slots, slotBytes)); HIP_CHECK(hipMalloc((void**)&box, boxBytes));
         HIP_CHECK(hipMalloc((void**)&bad, sizeof(int))); HIP_CHECK(hipHostMalloc((void**)&hostErr, 64)); *hostErr = 0;
@@ -402,7 +403,7 @@ struct OnchipMarch {
         int stripsX = 0, tilesY = 0, G = 0;
         const Variant* V = lm ? select<Op, true>(W, H, cus, stripsX, tilesY, G) : select<Op, false>(W, H, cus, stripsX, tilesY, G);
         if (!V) return false;
-        if (!slots) { reserve(W, H, C); HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), ctx.stream)); }
+        if (!slots) { reserve(W, H, C); if (!slots) return false; HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), ctx.stream)); }
         if (seq > 0xE0000000u || seq + (unsigned)L > 0xE0000000u) {      // tags never repeat: start over on cleared buffers long before the counter wraps
             HIP_CHECK(hipMemsetAsync(slots, 0, slotBytes, ctx.stream)); HIP_CHECK(hipMemsetAsync(box, 0, boxBytes, ctx.stream));
             seq = 2;
