@@ -227,6 +227,62 @@ def reference_example_flows():
     return out
 
 
+def contract_loop_leg(api, wl, torch, W, H, liters):
+    """The reference-ordered loop as a product mode (Opt_SetSolverParameter "amd_reference_order" = 1: PCGStep1; PCGStep2; PCGStep3 per iteration as
+    solverGPUGaussNewton.t:1056-1092 runs them, r / z / A p in memory, the beta numerator summed directly) on the SAME workload as the headline: what parity at the
+    contract costs.  Timed like the headline (wall clock over whole Opt_ProblemSteps), then one more step with one hipEvent pair per run of equally named launches.
+    `frac` is a PHYSICAL fraction here: the loop moves the reference formulation's 180 B/pixel per iteration.  rel_err: cost after the first step and after
+    the metric's 8 x 400 solve against the frozen exact-order oracle of the fused-multiply-add build (the legal run this loop restates) and the plain build."""
+    P = wl.image_warping(W, H)
+    dev = api.to_device(P)
+    s = api.Solver(api.energy_file("image_warping"), "gaussNewtonGPU", (W, H))
+    s.set_parameter("amd_reference_order", 1)
+    s.set_parameter("nIterations", 8); s.set_parameter("lIterations", liters)
+    desc = s.describe()
+    s.init(dev)
+    costs = [s.cost()]
+    s.step(dev); costs.append(s.cost())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        s.step(dev); costs.append(s.cost())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    s.set_timing(2)
+    s.step(dev); costs.append(s.cost())
+    torch.cuda.synchronize()
+    kt = s.kernel_timings()
+    s.set_timing(False)
+    while s.step(dev):
+        costs.append(s.cost())
+    torch.cuda.synchronize()
+    on_chip = s.on_chip_status()
+    s.close()
+    del dev
+    loop_ms = sum(v[1] for k, v in kt.items() if k.startswith("PCGStep"))
+    achieved = ALGO_BYTES_PER_PIXEL * W * H / (loop_ms / liters * 1e-3) / 1e9 if loop_ms else None
+    out = {"what": f"image_warping {W}x{H} float, gaussNewtonGPU, {liters} PCG iterations per step, Opt_SetSolverParameter(amd_reference_order = 1)",
+           "plan": desc, "pcg_iters_per_s": liters / dt, "ms_per_step": dt * 1e3, "on_chip_status": on_chip,
+           "kernel_avg_ms": {k: v[1] / v[0] for k, v in kt.items()}, "kernel_ms_per_step": {k: v[1] for k, v in kt.items()},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                        "bytes_per_pixel": ALGO_BYTES_PER_PIXEL, "us_per_iteration": 1e3 * loop_ms / liters if loop_ms else None,
+                        "note": "SURVEY 8d's algorithmic bytes (PCGStep1 48 + PCGStep2 96 + PCGStep3 36 B/px) over the loop's own kernel time (PCGStep* launches of one step / "
+                                "lIterations): a physical fraction -- this loop reads and writes those vectors"},
+           "costs": costs}
+    try:
+        G = {"plain": json.load(open(os.path.join(ROOT, "tests", "golden", "horizon_costs.json"))), "fma": json.load(open(os.path.join(ROOT, "tests", "golden", "horizon_costs_fma.json")))}
+        for name, g in G.items():
+            e = g.get(f"solve8_{W}_float")
+            if e and liters == 400 and len(costs) == len(e["costs"]):
+                out[f"rel_err_vs_{name}_oracle"] = {"after_1_step_400_pcg": abs(costs[1] - e["costs"][1]) / abs(e["costs"][1]), "after_8_steps": abs(costs[-1] - e["costs"][-1]) / abs(e["costs"][-1]),
+                                                    "per_step": [abs(a - b) / abs(b) for a, b in zip(costs, e["costs"])]}
+        if "rel_err_vs_fma_oracle" in out:
+            out["within_contract_1e-5_of_fma_oracle"] = max(out["rel_err_vs_fma_oracle"]["per_step"]) <= 1e-5
+    except OSError:
+        pass
+    return out
+
+
 def box_info(torch):
     """Which box is this?  Boxes of the pool differ by ~10 % on the same binary (sclk / power behaviour): the line says what it ran on.  Static facts from rocm-smi
     (power cap, mclk, performance level), and -- because an idle GPU reports its sleep clocks -- a one-second copy loop during which sclk / mclk / power are sampled,
@@ -265,6 +321,14 @@ def box_info(torch):
     dt = time.perf_counter() - t0
     th.join()
     info["copy_gbs"] = 2.0 * n * 4 * reps / dt / 1e9
+    del a, b
+    torch.cuda.empty_cache()
+    # the ceiling as MI355X_MICROARCH.md measures it: a float4 grid-stride copy kernel (libOpt's own, OptAmd_MeasureCopyBandwidth), 2 GiB moved per launch, default and
+    # nontemporal accesses -- `copy_gbs` above is torch's copy_ (round 5's probe), kept for comparison between rounds
+    from opt_amd import api as _api
+    info["copy_gbs_float4"] = _api.lib().OptAmd_MeasureCopyBandwidth(2 << 30, 0, 40)
+    info["copy_gbs_float4_nontemporal"] = _api.lib().OptAmd_MeasureCopyBandwidth(2 << 30, 1, 40)
+    a = torch.empty(1 << 25, dtype=torch.float32, device="cuda"); b = torch.empty_like(a)
     # the same copy on a working set that stays in the 256 MiB Infinity Cache (64 MiB in + 64 MiB out): the ceiling a streaming kernel can reach on the cache-resident
     # working sets of configs 3 and 4 (SFS 1024^2 double: 132 MB; ARAP 500 k vertices: 239 MB) -- measured, not quoted
     m = 1 << 24
@@ -281,7 +345,7 @@ def box_info(torch):
     info["mclk_mhz_under_load"] = grab(txt, r"mclk clock level: \S+ \(([0-9.]+)Mhz\)")
     info["power_w_under_load"] = grab(txt, r"Current Socket Graphics Package Power \(W\): ([0-9.]+)")
     info["device"] = torch.cuda.get_device_name(0)
-    info["kind"] = f"copy {info['copy_gbs'] / 1e3:.2f} TB/s, sclk {info['sclk_mhz_under_load']} MHz under load, cap {info['power_cap_w']} W"
+    info["kind"] = f"copy {info['copy_gbs'] / 1e3:.2f} TB/s (torch copy_), float4 kernel {info['copy_gbs_float4'] / 1e3:.2f} / nontemporal {info['copy_gbs_float4_nontemporal'] / 1e3:.2f} TB/s, sclk {info['sclk_mhz_under_load']} MHz under load, cap {info['power_cap_w']} W"
     del a, b
     return info
 
@@ -637,7 +701,16 @@ def main():
         flows = reference_example_flows()
         if flows is not None:
             flows["parity_vs_frozen_reference_runs"] = flow_parity(flows)
+    contract = None
+    if not distributed and not args.no_extras:
+        contract = contract_loop_leg(api, wl, torch, W, H, args.liters)
+        contract["headline_over_contract_loop"] = value / contract["pcg_iters_per_s"]
     box = box_info(torch) if (rank == 0 and not args.share_gpu) else None
+    if box and roofline and box.get("copy_gbs_float4"):
+        best = max(box["copy_gbs_float4"], box["copy_gbs_float4_nontemporal"])
+        roofline["frac_of_box_copy_float4"] = (roofline.get("hbm_achieved") or roofline["achieved"]) / best
+        roofline["frac_of_box_copy_note"] = ("counter traffic (else model bytes) per launch / launch time over the better of this box's two float4 copy-kernel rates (box.copy_gbs_float4*): "
+                                             "what a perfect streaming kernel reaches HERE")
 
     # ---- CPU leg last: the GPU work sits at the front of the run in one block ------------------------------------------------------------
     cpu = None
@@ -679,7 +752,7 @@ def main():
                "gn_solve": solve, "gn_solve_ms": solve["gn_solve_ms"] if solve else None,
                "cost_initial": costs[0], "cost_final": cost_final, "parity": parity, "comm_ranks": comm_ranks, "preflight": preflight, "rccl_leg": rccl_leg,
                "per_iteration_ms": dt / args.steps / args.liters * 1e3,
-               "kernel_src_sha16": sha, "box": box, "roofline": roofline, "general_urshape": general, "onchip": onchip, "reference_example_flows": flows, "cpu_baseline": cpu}
+               "kernel_src_sha16": sha, "box": box, "roofline": roofline, "contract_loop": contract, "general_urshape": general, "onchip": onchip, "reference_example_flows": flows, "cpu_baseline": cpu}
         print(json.dumps(out))
     if distributed:
         job.close()

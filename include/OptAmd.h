@@ -84,6 +84,23 @@ int OptAmd_PlanOnChipStatus(Opt_Plan* plan);
  * communicator's fast paths.  Uses the solver parameters set so far (lIterations).  `bench.py --gpus N --dry` prints it per rank without running a step. */
 int OptAmd_PlanDescribe(Opt_Plan* plan, char* out, int outLen);
 
+/* Solver parameters of this build, set through the reference's own Opt_SetSolverParameter (a reference build only warns about names it does not know,
+ * solverGPUGaussNewton.t:1205-1221, so a caller that sets them stays portable); both are `int*`:
+ *   "amd_reference_order"  1: every PCG iteration runs the reference's own sequence PCGStep1; PCGStep2; PCGStep3 (solverGPUGaussNewton.t:1056-1092) on kernels that keep
+ *                          r, z and A p in memory and form the three sums as the reference does (beta numerator = r.z directly).  This is the loop that meets the 1e-5
+ *                          (float) contract against the oracle at every horizon tested (400 PCG iterations included); it moves the reference formulation's 180 B/pixel
+ *                          per iteration where the default single-kernel iteration moves 53 and it never runs on chip.  0 (default): the fused loops.
+ *   "amd_onchip"           0: never take the on-chip (persistent) linear solve; 1 (default): take it where the problem fits the chip.
+ * OptAmd_PlanDescribe reports the choice.  (The environment switches OPT_AMD_ONEKERNEL / OPT_AMD_ONCHIP remain as process-wide development overrides.) */
+
+/* The float4 copy rate of this box in GB/s: `bytes` moved in total per repetition (half read, half written; device memory allocated and freed inside the call),
+ * default (0) or nontemporal (1) accesses, `reps` timed repetitions after three warm-up launches.  bench.py reports it next to its roofline fraction: boxes of the
+ * pool differ by ~10 % and MI355X_MICROARCH.md's copy ceiling (6.29 TB/s) is a measurement of this kind.  0.0 if the buffers cannot be allocated. */
+double OptAmd_MeasureCopyBandwidth(long bytes, int nontemporal, int reps);
+/* Test hook: `workgroups` one-wave workgroups that spin for `milliseconds` (<= 5000) on `stream` (a hipStream_t) -- a stand-in for a foreign tenant holding CUs while a
+ * plan's persistent kernel is launched (tests/test_coresidency_gpu.py).  Returns 1 if launched. */
+int OptAmd_DebugOccupy(int workgroups, double milliseconds, void* stream);
+
 /* hipEvent timing of one kernel name since the last Opt_ProblemInit (requires
  * collectPerKernelTimingInfo).  Returns 0 if the name was never launched. */
 int OptAmd_PlanKernelTiming(Opt_Plan* plan, const char* kernel, long* count, double* total_ms);

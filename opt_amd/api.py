@@ -23,7 +23,8 @@ OPT_SYMBOLS = ["Opt_NewState", "Opt_ProblemDefine", "Opt_ProblemDelete", "Opt_Pr
 OPTAMD_SYMBOLS = ["OptAmd_Version", "OptAmd_EnergyCount", "OptAmd_EnergyName", "OptAmd_PlanNumUnknownScalars", "OptAmd_PlanVector",
                   "OptAmd_EvalJTF", "OptAmd_ApplyJTJ", "OptAmd_EvalCost", "OptAmd_PlanEnableTrace", "OptAmd_PlanTraceRows",
                   "OptAmd_PlanGetTrace", "OptAmd_PlanTrustRegionRadius", "OptAmd_PlanKernelTiming", "OptAmd_PlanSetTiming", "OptAmd_PlanKernelCount",
-                  "OptAmd_PlanKernelName", "OptAmd_PlanOnChipStatus", "OptAmd_PlanDescribe", "OptAmd_PlanSetSlab", "OptAmd_PlanSetSlabExt", "OptAmd_CheckProblemFile", "OptAmd_ProblemFileHash"]
+                  "OptAmd_PlanKernelName", "OptAmd_PlanOnChipStatus", "OptAmd_PlanDescribe", "OptAmd_PlanSetSlab", "OptAmd_PlanSetSlabExt", "OptAmd_CheckProblemFile", "OptAmd_ProblemFileHash",
+                  "OptAmd_MeasureCopyBandwidth", "OptAmd_DebugOccupy"]
 
 
 class Opt_InitializationParameters(ctypes.Structure):
@@ -87,6 +88,8 @@ def lib():
     L.OptAmd_PlanKernelName.restype = cp; L.OptAmd_PlanKernelName.argtypes = [vp, ci]
     L.OptAmd_PlanSetSlab.restype = ci; L.OptAmd_PlanSetSlab.argtypes = [vp, cl, cl, cl, ctypes.POINTER(OptAmd_SlabComm)]
     L.OptAmd_PlanSetSlabExt.restype = ci; L.OptAmd_PlanSetSlabExt.argtypes = [vp, ctypes.POINTER(OptAmd_SlabCommExt)]
+    L.OptAmd_MeasureCopyBandwidth.restype = cd; L.OptAmd_MeasureCopyBandwidth.argtypes = [cl, ci, ci]
+    L.OptAmd_DebugOccupy.restype = ci; L.OptAmd_DebugOccupy.argtypes = [ci, cd, vp]
     L.OptAmd_CheckProblemFile.restype = ci; L.OptAmd_CheckProblemFile.argtypes = [cp, cp, ci]
     _lib = L
     return L
@@ -99,7 +102,7 @@ def check_problem_file(path):
     return bool(ok), buf.value.decode()
 
 
-_INT_PARAMS = {"nIterations", "lIterations", "residual_reset_period", "nIter", "patchIterations", "patchSize"}
+_INT_PARAMS = {"nIterations", "lIterations", "residual_reset_period", "nIter", "patchIterations", "patchSize", "amd_reference_order", "amd_onchip"}
 
 
 def energy_file(stem):

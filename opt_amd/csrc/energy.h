@@ -161,6 +161,9 @@ struct EnergyOps {
     // After the stream has drained: did a wait inside the last on-chip solve time out (another tenant on the GPU kept its workgroups from being co-resident)?
     // Then the unknowns were left untouched, the kernel set has switched the path off for this plan, and the caller redoes the linear solve.
     virtual bool onChipFailed() { return false; }
+    // The solver's back-off after such a failure is over: clear the failure state (device word, pinned word, the path's own off switch) so that the next
+    // pcgSolveOnChip launches again.  Stream-ordered.
+    virtual void onChipRearm(LaunchCtx&) {}
     // Slab mode, before the loop: will pcgIteration accept the launches?  (The solver refreshes the ghost rows of r_0, p_0 and M for that loop only: the
     // three-kernel loop relies on r being 0 on ghost rows -- its flat sums run over them.)
     virtual bool slabIterationAvailable() const { return true; }

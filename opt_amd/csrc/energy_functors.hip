@@ -236,6 +236,7 @@ struct OpticalFlowOps : StencilOps<T, OpticalFlowE<T>> {
         return oc.solve(FlowMarchOp<T>{this->e.w_fit, this->e.w_reg}, this->e.W, this->e.H, nullptr, coef, r0, p0, delta, const_cast<T*>(this->e.X[0]), L, this->cus, ctx, lm);
     }
     bool onChipFailed() override { return oc.failedNow(); }
+    void onChipRearm(LaunchCtx& ctx) override { oc.rearm(ctx); }
     std::string describe(int L, bool lmv) override { return oc.template describe<FlowMarchOp<T>>(this->e.W, this->e.H, this->cus, useMarch ? L : 0, lmv, "march_pcgIter"); }
 };
 template <class T> EnergyOps<T>* makeFlow(const unsigned* dims) { return new OpticalFlowOps<T>(dims); }
@@ -299,6 +300,7 @@ struct IntrinsicOps : StencilOps<T, IntrinsicE<T>> {
     }
     bool onChipAppliedUpdate() const override { return false; }
     bool onChipFailed() override { return oc.failedNow(); }
+    void onChipRearm(LaunchCtx& ctx) override { oc.rearm(ctx); }
     std::string describe(int L, bool lmv) override { return oc.template describe<IntrinsicMarchOp<T>>(this->e.W, this->e.H, this->cus, useMarch ? L : 0, lmv, "march_pcgIter"); }
 };
 template <class T> EnergyOps<T>* makeIntrinsic(const unsigned* dims) { return new IntrinsicOps<T>(dims); }

@@ -373,7 +373,7 @@ struct ImageWarpingOps : EnergyOps<T> {
     struct OcVariant { int rows; bool apLds, deltaGlb; const void* fn; size_t lds; int occ; };
     std::vector<OcVariant> ocVariants, ocVariantsLM;
     bool ocEnabled = true, ocFailed = false, ocLaunched = false;
-    int ocForceRows = 0, ocFlatMax = 256, ocFailAt = -1; long long* ocProf = nullptr; long long ocTimeoutTicks = 2000LL * 100000;      // 2 s of the 100 MHz wall clock
+    int ocForceRows = 0, ocFlatMax = 256, ocFailAt = -1; long long* ocProf = nullptr; long long ocTimeoutTicks = 0;      // 0: onchip_sync.h ocTimeouts() decides; OPT_AMD_ONCHIP_TIMEOUT_MS overrides
     OnchipSync ocS{}; unsigned ocSeq = 1; size_t ocInboxBytes = 0, ocSlotBytes = 0, ocGroupBytes = 0;
     void ocInit() {
         if (!ocVariants.empty()) return;
@@ -460,8 +460,9 @@ struct ImageWarpingOps : EnergyOps<T> {
             links.seq0 = Lk.seq0; links.edgeSendUp = Lk.edgeSendUp; links.edgeSendDown = Lk.edgeSendDown; links.edgeRecvUp = Lk.edgeRecvUp; links.edgeRecvDown = Lk.edgeRecvDown;
             links.edgeParityStride = Lk.edgeParityStride;
         }
+        const OcTimeouts tmo = ocTimeouts(ocTimeoutTicks, L, slabMode);
         OnchipArgs<T> K{A.W, A.H, tX, tY, G, A.yBegin, A.yEnd, links, r0, p0, A.Angle, A.flags, delta, A.w_fit, A.w_reg, L, ocSeq, G <= ocFlatMax ? 1 : 0, ocS, traceDev,
-                        ocTimeoutTicks, ocProf, ocFailAt, T(0), T(0), T(0), T(0), 1};
+                        tmo.later, tmo.first, ocProf, ocFailAt, T(0), T(0), T(0), T(0), 1};
         if (lmArgs) { K.lmRadius = lmArgs->radius; K.lmMin = lmArgs->minLm; K.lmMax = lmArgs->maxLm; K.qTolerance = lmArgs->qTolerance; K.resetPeriod = lmArgs->resetPeriod; }
         ocSeq += nTags;
         {
@@ -543,6 +544,11 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (__atomic_load_n(ocS.hostErr, __ATOMIC_ACQUIRE) == 0) return false;
         ocFailed = true;
         return true;
+    }
+    void onChipRearm(LaunchCtx& ctx) override {
+        if (!ocS.bad) return;
+        ocFailed = false; __atomic_store_n(ocS.hostErr, 0, __ATOMIC_RELEASE);
+        HIP_CHECK(hipMemsetAsync(ocS.bad, 0, sizeof(int), ctx.stream));
     }
 };
 

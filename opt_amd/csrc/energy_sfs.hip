@@ -756,7 +756,7 @@ struct SfsOps : EnergyOps<T> {
     // every variant on small images); OPT_AMD_ONCHIP_FAIL_AT / _TIMEOUT_MS: the time-out path's test hooks.
     struct SoVariant { int rows, waves; const void* gn; const void* lm; };
     bool soEnabled = true, soFailed = false, soLaunched = false;
-    int soForceRows = 0, soForceWaves = 0, soFailAt = -1; long long soTimeoutTicks = 2000LL * 100000;      // 2 s of the 100 MHz wall clock
+    int soForceRows = 0, soForceWaves = 0, soFailAt = -1; long long soTimeoutTicks = 0;      // 0: onchip_sync.h ocTimeouts() decides; OPT_AMD_ONCHIP_TIMEOUT_MS overrides
     long long* soProf = nullptr;
     oc_u64 *soSlots = nullptr, *soBox = nullptr; int *soBad = nullptr, *soHostErr = nullptr; unsigned soSeq = 0; size_t soSlotBytes = 0, soBoxBytes = 0;
     static const std::vector<SoVariant>& soVariants() {
@@ -812,7 +812,8 @@ struct SfsOps : EnergyOps<T> {
             HIP_CHECK(hipMemsetAsync(soSlots, 0, soSlotBytes, ctx.stream)); HIP_CHECK(hipMemsetAsync(soBox, 0, soBoxBytes, ctx.stream));
             soSeq = 2;
         }
-        SfsOcArgs<T> K{A, r0, p0, lmArgs ? lmArgs->CtC : nullptr, delta, stripsX, tilesY, G, L, soSeq, soSlots, soBox, soBad, soTimeoutTicks, soFailAt, lmArgs ? lmArgs->qTolerance : T(0), lmArgs ? soHostErr : nullptr, soProf};
+        const OcTimeouts tmo = ocTimeouts(soTimeoutTicks, L, false);
+        SfsOcArgs<T> K{A, r0, p0, lmArgs ? lmArgs->CtC : nullptr, delta, stripsX, tilesY, G, L, soSeq, soSlots, soBox, soBad, tmo.later, soFailAt, tmo.first, lmArgs ? lmArgs->qTolerance : T(0), lmArgs ? soHostErr : nullptr, soProf};
         soSeq += (unsigned)L;
         {
             ScopedKernel k(ctx, "PCGSolveOnChip");
@@ -853,6 +854,11 @@ struct SfsOps : EnergyOps<T> {
         if (__atomic_load_n(soHostErr, __ATOMIC_ACQUIRE) == 0) return false;
         soFailed = true;
         return true;
+    }
+    void onChipRearm(LaunchCtx& ctx) override {
+        if (!soBad) return;
+        soFailed = false; __atomic_store_n(soHostErr, 0, __ATOMIC_RELEASE);
+        HIP_CHECK(hipMemsetAsync(soBad, 0, sizeof(int), ctx.stream));
     }
     std::string describe(int L, bool lmv) override {      // ("key=value; ..." -- no ';' inside a value)
         int stripsX = 0, tilesY = 0, G = 0;

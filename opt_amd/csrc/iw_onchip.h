@@ -60,6 +60,8 @@ struct OnchipArgs {
     OnchipSync S;
     double* trace;                      // [L][4] = alphaNum, alphaDen, s2, s3 of every iteration (written by workgroup 0), or nullptr
     long long timeoutTicks;
+    long long firstTicks;               // bound of the waits of the FIRST phase: passing it proves that every workgroup of the grid is resident (each has posted its words), so it is the
+                                        // co-residency check -- short (10 ms), before anything has been written; row slabs: = timeoutTicks (the first sum waits for the other ranks' launches)
     long long* prof;                    // OC_PROFILE builds: [G][8] ticks per phase, else nullptr
     int failAt;                         // test hook (OPT_AMD_ONCHIP_FAIL_AT): workgroup 0 raises `bad` in this iteration as a timed-out wait would; -1: never
     // Levenberg-Marquardt variants (LMV): the scalars of PCGFinalizeDiagonal (solver.t:631-664), the q early-out and the residual reset period (:1077-1102)
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
     const bool xin = x < K.W;
     const T w2 = K.w_reg * K.w_reg, wf2 = K.w_fit * K.w_fit;
     int* const bad = K.S.bad;
-    const long long to = K.timeoutTicks;
+    long long to = K.firstTicks;      // the first phase's waits double as the co-residency check (OnchipArgs::firstTicks); K.timeoutTicks afterwards
 
     if (tid < 15) {      // the table of iw_pcgIter2: same accumulation order as iw_evalJTF, so the entries are the solver's preconditioner values bit for bit
         const int t = tid, cnt = t < 10 ? t % 5 : t - 10;
@@ -563,6 +565,7 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
             if constexpr (LMV) v4[4] = accQ;
             gridWait(v4, tag, par, boxPar, k, rtag, rpar, at, ab, as);
         }
+        to = K.timeoutTicks;      // every workgroup has been heard from: the grid is resident
         if constexpr (LMV) { ++phase; accQ = 0; }
         // With delta in memory (ROWS = 16) it is read in chunks of CH rows, two chunks ahead of the update: the first request goes out HERE, behind the wait for
         // the sums, and returns (lines this lane wrote one iteration ago, still in its XCD's L2) while the halo copies are updated.  (All 48 values requested

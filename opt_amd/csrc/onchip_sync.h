@@ -1,4 +1,4 @@
-// Grid-wide hand-off primitives of the persistent ("on-chip") solver kernels: iw_onchip.h (image_warping) and arap_onchip.h (arap_mesh_deformation).
+// Grid-wide hand-off primitives of the persistent ("on-chip") solver kernels: iw_onchip.h (image_warping), sfs_onchip.h, stencil_onchip.h.
 //
 // Everything that crosses workgroups inside such a kernel travels as naturally aligned 8-byte words {payload, tag}: ONE relaxed agent-scope store each (global_store sc1:
 // written through, no fence, no cache write-back) and relaxed agent-scope loads on the polling side (MI355X_MICROARCH.md "handoff-1to1" / granule "R2"; measured in
@@ -11,6 +11,20 @@ namespace optamd {
 namespace {
 
 typedef unsigned long long oc_u64;
+
+// Bounds of the waits inside a persistent kernel, in ticks of the device's 100 MHz wall clock.  `first`: the waits of the first phase -- every workgroup posts its words
+// before it waits, so passing them proves the whole grid resident; a grid that is NOT co-resident (a foreign tenant holds CUs, another plan's persistent kernel) gives up
+// there after 10 ms, before anything has been written, and the solver redoes the step on the streaming kernels.  `later`: once resident, a word is microseconds away; the
+// bound only ends a hang (a peer that faulted) and scales with the solve: 100 ms + 100 us per PCG iteration.  Kernels whose first sum waits for OTHER PROCESSES' launches
+// (row slabs: the rank hop) keep 2 s for both.  OPT_AMD_ONCHIP_TIMEOUT_MS (tests of the time-out path) overrides `later` and caps `first`.
+struct OcTimeouts { long long first, later; };
+inline OcTimeouts ocTimeouts(long long overrideTicks, int lIterations, bool waitsForOtherProcesses) {
+    OcTimeouts t;
+    t.later = waitsForOtherProcesses ? 2000LL * 100000 : (100LL + lIterations / 10) * 100000;
+    t.first = waitsForOtherProcesses ? t.later : 10LL * 100000;
+    if (overrideTicks > 0) { t.later = overrideTicks; t.first = std::min(t.first, overrideTicks); }
+    return t;
+}
 
 // SYS: words that cross GPUs (the peer window: uncached memory, system scope); else agent scope
 template <bool SYS = false> __device__ __forceinline__ oc_u64 ocLoad(const oc_u64* p) {

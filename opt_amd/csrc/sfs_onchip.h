@@ -42,6 +42,7 @@ struct SfsOcArgs {
     oc_u64* slots;                      // [2][G][10]
     oc_u64* apBox;                      // [2][W * H * sizeof(T) / 4]
     int* bad; long long timeoutTicks; int failAt;
+    long long firstTicks;      // bound of the FIRST iteration's wait: the co-residency check (every workgroup has posted its words once it passes), before anything is written
     T qTolerance;
     int* hostErr;                       // LM (the solver applies the update itself): pinned host word a workgroup that gave up raises on its way out; GN: nullptr (sfs_applyDelta tells the host)
     long long* prof;                    // SO_PROFILE builds: [G][8] ticks per phase (wave 0 of every workgroup), else nullptr
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
                     if (check()) break;
                     if ((++spins & 31u) == 0) {
                         if (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                        if (wall_clock64() - t0 > to) { __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        if (wall_clock64() - t0 > (k == 0 ? K.firstTicks : to)) { __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                     }
                 }
             }

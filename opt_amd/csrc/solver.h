@@ -22,6 +22,11 @@ struct SolverParameters {
     int lIterations = 10;
     int patchIterations = 16;     // kind "patchGaussNewtonGPU" only: inner PCG iterations per patch and sweep (reference CUDAPatchSolverWarping.cpp:19)
     int patchSize = 32;           // 16 (the reference's PATCH_SIZE) or 32
+    // Path selection (OptAmd.h "Solver parameters of this build"; reference callers never set them -- unknown names only warn there too, solver.t:1205-1221):
+    int amd_reference_order = 0;  // 1: the reference's own sequence PCGStep1; PCGStep2; PCGStep3 per PCG iteration (solverGPUGaussNewton.t:1056-1092) on the generic kernels --
+                                  // three sums per iteration as the reference forms them (r.z directly, no expansion; r, z, A p in memory).  The loop that meets the 1e-5 contract at
+                                  // any horizon; ~3x the bytes of the default single-kernel iteration and never on chip.
+    int amd_onchip = 1;           // 0: never take the on-chip (persistent) linear solve; 1: take it where the problem fits (default)
 };
 
 struct SolverBase {

@@ -12,6 +12,8 @@
 //  * alphaNumerator <- betaNumerator (a D2D memcpy per iteration in the reference, :1091) is a two-slot
 //    rotation written by workgroup 0 of Step3.
 #include "solver.h"
+#include <chrono>
+#include <mutex>
 #include <cmath>
 #include <cstddef>
 #include <cstring>
@@ -366,6 +368,7 @@ struct PcgSolver : SolverBase {
     }
     ~PcgSolver() override {
         (void)hipStreamSynchronize(stream);
+        dropLease();
         for (void* a : allocs) (void)hipFree(a);
         if (hostBuf) (void)hipHostFree(hostBuf);
         if (redQ.partials) (void)hipHostFree(redQ.partials);
@@ -379,6 +382,21 @@ struct PcgSolver : SolverBase {
         (void)hipStreamDestroy(stream);
     }
 
+    // ---- co-residency of the persistent kernels (EnergyOps::pcgSolveOnChip): their workgroups wait for each other, so the whole grid has to be resident ----
+    // (i)  Two plans of ONE process stepped from two host threads would interleave two such grids on the CUs: a process-wide lease per device serialises the
+    //      on-chip launches -- taken before the launch, dropped when this step has drained the stream; a plan that cannot get it within 50 ms runs this step
+    //      on the streaming kernels.
+    // (ii) A foreign tenant (another process, another library's long kernel) is caught by the kernel itself: the waits of its FIRST phase are bounded by
+    //      10 ms (firstTicks) -- every workgroup posts its words before it waits, so passing that wait proves the grid resident; nothing has been written by then.
+    // (iii) After a time-out the step is redone by the streaming kernels and the plan stays on them for `onChipBackoff` clean steps (8, then 16, 32 ... 1024), then
+    //      tries the chip again (EnergyOps::onChipRearm): a tenant that has left does not cost the plan its fast path for life.
+    static std::timed_mutex& chipLease() { static std::timed_mutex m[64]; int dev = 0; (void)hipGetDevice(&dev); return m[(unsigned)dev % 64u]; }
+    bool leaseHeld = false;
+    bool takeLease() { if (leaseHeld) return true; leaseHeld = chipLease().try_lock_for(std::chrono::milliseconds(50)); return leaseHeld; }
+    void dropLease() { if (leaseHeld) { chipLease().unlock(); leaseHeld = false; } }
+    int onChipFailures = 0, onChipBackoff = 0, onChipCleanSteps = 0;
+    bool onChipAllowed() const { return onChipOk && sp.amd_onchip != 0 && sp.amd_reference_order == 0; }
+    bool singleKernelAllowed() const { return oneKernel && sp.amd_reference_order == 0; }
     bool onChipOk = true, usedOnChip = false, onChipFellBack = false, lastStepOnChip = false; double* onChipTrace = nullptr; int onChipTraceCap = 0;      // EnergyOps::pcgSolveOnChip
     // true iff `mine` holds on every rank: one all-reduce of a count and one read-back (once per Gauss-Newton step in slab mode)
     bool allRanksAgree(bool mine) {
@@ -562,9 +580,10 @@ struct PcgSolver : SolverBase {
         // Row slabs: the on-chip solve runs on ALL ranks or on none (their kernels wait for each other): every rank says whether it could, the communicator adds it up.
         bool slabOnChip = false;
         if (distributed) {
-            slabOnChip = allRanksAgree(onChipOk && preArg && sp.lIterations > 0 && !traceEnabled && E->slabOnChipAvailable(sp.lIterations));
+            slabOnChip = allRanksAgree(onChipAllowed() && preArg && sp.lIterations > 0 && !traceEnabled && E->slabOnChipAvailable(sp.lIterations));
             if (!slabOnChip && !E->slabIterationAvailable()) return false;      // (before anything is exchanged: the three-kernel loop needs r = 0 on ghost rows)
             if (slabOnChip) {      // the kernel reads r_0, p_0 of its halo rows from the ghost rows
+                (void)takeLease();      // (agreed collectively: this rank launches whether or not another plan of this process holds the chip)
                 exchangeVector(r); exchangeVector(p);
                 // A rank whose kernel set refuses after the vote (it should not: the vote covers the communicator's capacity and error state) launches nothing; its
                 // peers' waits then time out, and the verdict below makes every rank redo the step with the streaming loop -- a library does not exit().
@@ -579,7 +598,7 @@ struct PcgSolver : SolverBase {
         }
         // The whole linear solve as one persistent launch with the loop state on chip, if the kernel set has one and the problem fits (iw_onchip.h);
         // it ends with PCGLinearUpdate.  A traced solve gets its per-iteration scalars from the kernel (beta numerator by expansion, as below).
-        if (!distributed && (preArg || E->onChipWithoutPreconditioner()) && onChipOk && sp.lIterations > 0) {
+        if (!distributed && (preArg || E->onChipWithoutPreconditioner()) && onChipAllowed() && sp.lIterations > 0 && takeLease()) {
             double* tr = nullptr;
             if (traceEnabled) {
                 if (onChipTraceCap < sp.lIterations) { if (onChipTrace) HIP_CHECK(hipFree(onChipTrace)); onChipTraceCap = sp.lIterations; HIP_CHECK(hipMalloc((void**)&onChipTrace, sizeof(double) * 4 * onChipTraceCap)); }
@@ -600,6 +619,7 @@ struct PcgSolver : SolverBase {
                 }
                 return true;
             }
+            dropLease();
         }
         Reduction prev[4] = {redC, Reduction{}, Reduction{}, Reduction{}};   // alphaNum_0 = sum r.p from PCGInit1
         if (distributed) {   // ghost rows of r_0, M and p_0 (written as 0 by evalJTF / PCGInit1_Finish) come from the slab neighbours once
@@ -678,9 +698,10 @@ struct PcgSolver : SolverBase {
         if (distributed || traceEnabled || keepReferenceP) return false;
         // The whole LM linear solve as one persistent launch (iw_onchip.h, LMV): CtC, the q early-out and the split residual reset happen on chip, the host
         // sees only delta.  (A listening caller -- verbosity > 0 -- wants the "breaking at iteration" message: the launch-per-iteration loop prints it.)
-        if (onChipOk && (preArg || E->onChipWithoutPreconditioner()) && sp.lIterations > 0 && verbosity == 0 && Q0 == T(0)) {
+        if (onChipAllowed() && (preArg || E->onChipWithoutPreconditioner()) && sp.lIterations > 0 && verbosity == 0 && Q0 == T(0) && takeLease()) {
             const OnChipLm<T> la{trust_region_radius, min_lm_diagonal, max_lm_diagonal, q_tolerance, sp.residual_reset_period, CtC};
             if (E->pcgSolveOnChip(r, p, delta, sp.lIterations, nullptr, &la, ctx)) { usedOnChip = true; return true; }
+            dropLease();
         }
         if (!delta2) delta2 = allocVec();                       // zero-filled like delta; every launch that updates delta rewrites all of it
         Reduction prev[4] = {redC, Reduction{}, Reduction{}, Reduction{}};
@@ -832,7 +853,7 @@ struct PcgSolver : SolverBase {
         // PCGInit1 [+ _Graph + _Finish]: the energy produces r = -J^T F and raw diag(J^T J) (parked in CtC) -- or, for the Gauss-Newton single-kernel loop on
         // one GPU, r, p = M r, delta = 0 and the partial sums of r.p directly (EnergyOps::evalJTFInit)
         unknownsUpdated = false;
-        const bool fusedInit = !lm && !distributed && oneKernel && r2 && sp.lIterations > 0 && E->evalJTFInit(r, p, delta, nPad, redC, ctx);
+        const bool fusedInit = !lm && !distributed && singleKernelAllowed() && r2 && sp.lIterations > 0 && E->evalJTFInit(r, p, delta, nPad, redC, ctx);
         bool fusedInitLM = false;
         if (lm && !distributed) {
             LmInitArgs<T> la{CtC, SSq, r, delta, preconditioner, b, p, trust_region_radius, min_lm_diagonal, max_lm_diagonal, sp.nIter == 0 ? 1 : 0, &redC, &redQ};
@@ -864,8 +885,14 @@ struct PcgSolver : SolverBase {
         // feeds the next Step1; after the last iteration p is dead).
         bool pendingStep3 = false;
         Reduction bNum;
-        const bool single = oneKernel && r2 && (lm ? (oneKernelLM && runSingleKernelLoopLM(preArg, Q0, q_tolerance)) : runSingleKernelLoop(preArg));
-        if (fusedInit && !single) { fprintf(stderr, "Opt(amd): the kernel set accepted evalJTFInit but refused the single-kernel loop\n"); exit(1); }
+        const bool single = singleKernelAllowed() && r2 && (lm ? (oneKernelLM && runSingleKernelLoopLM(preArg, Q0, q_tolerance)) : runSingleKernelLoop(preArg));
+        if (fusedInit && !single) {      // the kernel set accepted evalJTFInit but refused the loop (it should not): PCGInit1 again for the generic loop -- a library does not exit()
+            fprintf(stderr, "Opt(amd): the kernel set accepted evalJTFInit but refused the single-kernel loop; this step runs on the generic kernels\n");
+            E->evalJTF(r, CtC, ctx);
+            ScopedKernel k(ctx, "PCGInit1_Finish");
+            k_initFinish<T><<<streamGrid, kBlock, 0, stream>>>(r, CtC, preconditioner, p, delta, nPacks, E->usePreconditioner ? 1 : 0, E->usesGraph ? 1 : 0, redC.partials);
+            redC.n = streamGrid;
+        }
         if (!single) finalizeTo(redC, scal + aSlot);   // alphaNumerator = sum r.p as one device scalar (the single-kernel loops sum the partials in their first launch)
         // Step3 of the previous iteration (when pending) and Step1 of the next one.  None of it touches what survives a q early-out
         // (delta, and p only through the very Step3 the reference also runs before its q test), so in LM it is enqueued BEFORE the
@@ -984,9 +1011,12 @@ struct PcgSolver : SolverBase {
         if (usedOnChip) {      // (the stream has drained: the cost was read)
             usedOnChip = false;
             bool ocFailedNow = E->onChipFailed();
+            dropLease();      // the launch has left the chip
             if (ocFailedNow) {
-                fprintf(stderr, "Opt(amd): a wait inside the on-chip PCG kernel timed out (its workgroups were not co-resident: is the GPU shared?); "
-                                "this linear solve is redone with the streaming kernels and the plan stays on them\n");
+                ++onChipFailures; onChipCleanSteps = 0; onChipBackoff = std::min(8 << std::min(onChipFailures - 1, 7), 1024);
+                if (onChipFailures <= 3)
+                    fprintf(stderr, "Opt(amd): a wait inside the on-chip PCG kernel timed out (its workgroups were not co-resident: is the GPU shared?); this linear solve is redone "
+                                    "with the streaming kernels and the plan stays on them for %d steps before it tries the chip again\n", onChipBackoff);
                 onChipOk = false; onChipFellBack = true; lastStepOnChip = false; unknownsUpdated = false;
                 if (lm) {      // the kernel produced no delta: the update above added nothing meaningful -- back to the saved unknowns, then the launch-per-iteration loop
                     imageOp(2);
@@ -1038,6 +1068,10 @@ struct PcgSolver : SolverBase {
             prevCost = newCost;
         }
         sp.nIter += 1;
+        if (!onChipOk && onChipFailures > 0 && ++onChipCleanSteps >= onChipBackoff) {      // back-off over: the next step tries the chip again
+            onChipOk = true; onChipFellBack = false;
+            E->onChipRearm(ctx);
+        }
         return 1;
     }
 
@@ -1052,7 +1086,11 @@ struct PcgSolver : SolverBase {
     double trustRegionRadius() const override { return (double)trust_region_radius; }
     int onChipStatus() const override { return onChipFellBack ? 2 : lastStepOnChip ? 1 : 0; }
     std::string describe() override {
-        std::string d = E->describe(sp.lIterations, lm);
+        std::string d = sp.amd_reference_order ? std::string("path=reference-order (PCGStep1 [+ the previous PCGStep3] and PCGStep2 per PCG iteration, r / z / A p in memory); amd_reference_order=1")
+                                               : E->describe(sp.lIterations, lm);
+        if (!sp.amd_reference_order && !sp.amd_onchip) d += "; amd_onchip=0";
+        if (!sp.amd_reference_order && !oneKernel) d += "; OPT_AMD_ONEKERNEL=0 (reference-order loop by environment)";
+        if (onChipFailures) d += "; onchip_fallbacks=" + std::to_string(onChipFailures) + "; onchip_backoff_steps_left=" + std::to_string(onChipOk ? 0 : onChipBackoff - onChipCleanSteps);
         d += std::string("; solver=") + (lm ? "LM" : "GN") + "; distributed=" + (distributed ? "yes" : "no") + "; comm_world=" + std::to_string(distributed ? comm.world : 1) +
              "; comm_ext=" + (commExt.onChipPlan ? "onChipPlan " : "") + (commExt.allReducePost ? "allReducePost " : "") + (commExt.allReducePartials ? "allReducePartials" : "");
         return d;
@@ -1122,6 +1160,7 @@ bool SolverBase::setParameter(const char* name, const void* value) {   // solver
     PF(min_relative_decrease) PF(min_trust_region_radius) PF(max_trust_region_radius) PF(q_tolerance) PF(function_tolerance)
     PF(trust_region_radius) PF(radius_decrease_factor) PF(min_lm_diagonal) PF(max_lm_diagonal)
     PI(residual_reset_period) PI(nIter) PI(nIterations) PI(lIterations) PI(patchIterations) PI(patchSize)
+    PI(amd_reference_order) PI(amd_onchip)
 #undef PF
 #undef PI
     return false;

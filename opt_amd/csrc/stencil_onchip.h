@@ -38,6 +38,7 @@ struct MoArgs {
     oc_u64* slots;                          // [2][G][8]
     oc_u64* apBox;                          // [2][W * H * C * sizeof(T) / 4]
     int* bad; long long timeoutTicks; int failAt;
+    long long firstTicks;      // bound of the FIRST iteration's wait: the co-residency check (every workgroup has posted its words once it passes), before anything is written
     const T* CtC; T qTolerance; int* hostErr;      // LM: the clamped diagonal, q_tolerance, the pinned word a workgroup that gave up raises (the solver applies the update itself)
 };
 
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
                     if (check()) break;
                     if ((++spins & 31u) == 0) {
                         if (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                        if (wall_clock64() - t0 > to) { __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        if (wall_clock64() - t0 > (k == 0 ? K.firstTicks : to)) { __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                     }
                 }
             }
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void march_applyDelta(T* __restrict__ X, co
 template <class T>
 struct OnchipMarch {
     bool enabled = true, failed = false, launched = false;
-    int forceRows = 0, forceWaves = 0, failAt = -1; long long timeoutTicks = 2000LL * 100000;      // 2 s of the 100 MHz wall clock
+    int forceRows = 0, forceWaves = 0, failAt = -1; long long timeoutTicks = 0;      // 0: onchip_sync.h ocTimeouts() decides; OPT_AMD_ONCHIP_TIMEOUT_MS overrides
     oc_u64 *slots = nullptr, *box = nullptr; int *bad = nullptr, *hostErr = nullptr; unsigned seq = 0; size_t slotBytes = 0, boxBytes = 0;
     int lastRows = 0, lastWaves = 0, lastG = 0;
     OnchipMarch() {
@@ -408,7 +409,8 @@ struct OnchipMarch {
             HIP_CHECK(hipMemsetAsync(slots, 0, slotBytes, ctx.stream)); HIP_CHECK(hipMemsetAsync(box, 0, boxBytes, ctx.stream));
             seq = 2;
         }
-        MoArgs<T> K{W, H, r0, p0, delta, flags, coef, stripsX, tilesY, G, L, seq, slots, box, bad, timeoutTicks, failAt, lm ? lm->CtC : nullptr, lm ? lm->qTolerance : T(0), (lm || !X) ? hostErr : nullptr};      // (no X: the solver applies the update itself, as for LM)
+        const OcTimeouts tmo = ocTimeouts(timeoutTicks, L, false);
+        MoArgs<T> K{W, H, r0, p0, delta, flags, coef, stripsX, tilesY, G, L, seq, slots, box, bad, tmo.later, failAt, tmo.first, lm ? lm->CtC : nullptr, lm ? lm->qTolerance : T(0), (lm || !X) ? hostErr : nullptr};      // (no X: the solver applies the update itself, as for LM)
         {
             ScopedKernel k(ctx, "PCGSolveOnChip");
             Op opc = op;
@@ -431,6 +433,11 @@ struct OnchipMarch {
         if (__atomic_load_n(hostErr, __ATOMIC_ACQUIRE) == 0) return false;
         failed = true;
         return true;
+    }
+    void rearm(LaunchCtx& ctx) {      // EnergyOps::onChipRearm
+        if (!bad) return;
+        failed = false; __atomic_store_n(hostErr, 0, __ATOMIC_RELEASE);
+        HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), ctx.stream));
     }
     template <class Op> std::string describe(int W, int H, int cus, int L, bool lmv, const char* marchName) const {
         int stripsX = 0, tilesY = 0, G = 0;

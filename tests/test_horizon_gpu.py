@@ -61,18 +61,25 @@ def table():
 HORIZONS = [20, 50, 100, 200, 400]
 
 
-@pytest.mark.parametrize("family,precision", [("horizon", "double"), ("adversarial", "float"), ("adversarial", "double")])
+@pytest.mark.parametrize("family,precision", [("horizon", "float"), ("horizon", "double"), ("adversarial", "float"), ("adversarial", "double")])
 @pytest.mark.parametrize("liters", HORIZONS)
 def test_every_loop_within_the_reference_spread(table, family, precision, liters):
-    """One yardstick -- max(contract, diameter of the frozen legal runs) -- and no allowance on top of it (round 4 multiplied by two).  The benchmark family in float is
-    measured with the physical yardstick below instead (test_horizon_float_in_iterations_of_progress): its diameter is a diameter of scalar-noise runs."""
+    """One yardstick -- max(contract, diameter of the frozen legal runs) -- and no allowance on top of it (round 4 multiplied by two), asserted WITH and WITHOUT the
+    synthetic 1-ulp sin / cos runs in the set of legal runs (they change no diameter today; the smaller of the two is the bar).  All four families are in (round 5 had
+    moved the benchmark family in float to the iterations-of-progress test below, which stays as a diagnostic): the reference-ordered loop holds the yardstick everywhere;
+    the r-free / on-chip loops miss it at ONE point -- horizon float L = 50, 3.7e-3 against 3.08e-3 = 1.21 yardsticks (profiles/r05_horizon_parity.md; the horizon ends
+    inside a near-breakdown of the solve's ~5.5-iteration cycle, profiles/r05_l50_bisect.md) -- reported as XFAIL with the measured ratio, and a hard failure above 1.5."""
     r = table.get((family, precision, liters))
     assert r is not None, "no frozen oracle value for this case"
     assert r["legal_runs"] >= 5, r                      # exact-order plain + fma, reference-order seeds
-    yard = r["yardstick"]
+    size = 2048 if family == "horizon" else 1024
+    yard = min(r["yardstick"], rs.yardstick(f"{family}_{size}_{precision}_{liters}", precision, trig=False))
     assert yard >= FLOOR[precision] and rs.FACTOR == 1.0
-    for loop in ("ref-order", "r-free", "on-chip"):      # (on-chip: where the image fits -- the 1024^2 family; at 2048^2 the streaming loop again)
-        assert r[loop + "_rel"] <= yard, (loop, r[loop + "_rel"], yard, r)
+    assert r["ref-order_rel"] <= yard, ("ref-order", r["ref-order_rel"], yard, r)
+    worst = max(r["r-free_rel"], r["on-chip_rel"])      # (on-chip: where the image fits -- the 1024^2 family; at 2048^2 the streaming loop again)
+    if (family, precision, liters) == ("horizon", "float", 50) and yard < worst <= 1.5 * yard:
+        pytest.xfail(f"r-free / on-chip loop at L = 50: {worst:.2e} = {worst / yard:.2f} yardsticks ({yard:.2e}); the reference-ordered loop is at {r['ref-order_rel'] / yard:.2f}")
+    assert worst <= yard, (worst, yard, r)
 
 
 @pytest.mark.parametrize("liters", HORIZONS)
@@ -83,7 +90,8 @@ def test_horizon_float_in_iterations_of_progress(table, liters):
     profiles/r05_l50_bisect.md: the solve has a ~5.5-iteration cycle of near-breakdowns that amplifies 1e-7 differences 1e5-fold for two iterations at a time, and its cost
     still falls 0.46 % per iteration at L = 50 -- so a cost at a fixed horizon is known to a fraction of an iteration, not to 1e-5.  Measured (profiles/r05_horizon_parity.md):
     the reference-ordered loop 0.12 iterations outside the hull at L = 50 and inside it everywhere else; the r-free / on-chip loops at most 0.64 (L = 50) and 1.45 (L = 100,
-    worst launch geometry).  Bars: 0.25 and 2 iterations."""
+    worst launch geometry).  Bars: 0.25 and 2 iterations.  A DIAGNOSTIC beside test_every_loop_within_the_reference_spread (which asserts the diameter yardstick for this family
+    too), not a replacement for it."""
     r = table[("horizon", "float", liters)]
     its = {loop: rs.iterations_from_hull("horizon", 2048, "float", liters, r[loop]) for loop in ("ref-order", "r-free", "on-chip")}
     assert all(v is not None for v in its.values()), "neighbouring horizons not frozen (tests/golden/make_horizon_costs.py --horizons)"

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 from opt_amd import api, workloads as wl
-from helpers import device_unknowns, flat_unknowns, hip_solver, oracle_solver, rel_err
+from helpers import assert_close, device_unknowns, flat_unknowns, hip_solver, oracle_solver, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -32,12 +32,12 @@ def _side_by_side(oracle_lib, P, nsteps, liters, cost_tol, x_tol, radius_tol, **
         a, b = o.step(Pref.params), g.step(dev)
         assert a == b, (a, b, costs)
         costs.append((o.cost(), g.cost()))
-        assert abs(g.cost() - o.cost()) <= cost_tol * max(abs(o.cost()), 1e-12 * scale), costs
-        assert abs(g.trust_region_radius() - o.trust_region_radius()) <= radius_tol * o.trust_region_radius(), costs
+        assert_close("cost" if len(costs) <= 2 else "cost_later", g.cost(), o.cost(), cost_tol, floor=1e-12 * scale, double=P.double, step=len(costs) - 1)
+        assert_close("radius", g.trust_region_radius(), o.trust_region_radius(), radius_tol, double=P.double)
         if not a:
             break
     if x_tol is not None:
-        assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < x_tol
+        assert_close("x", rel_err(device_unknowns(P, dev), flat_unknowns(Pref)), 0.0, x_tol, absolute=True, double=P.double)
     g.close(); o.close()
     return costs
 

@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 
 from opt_amd import api, workloads as wl
-from helpers import device_unknowns, flat_unknowns, hip_solver, oracle_solver, rel_err
+from helpers import assert_close, device_unknowns, flat_unknowns, hip_solver, oracle_solver, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -41,12 +41,12 @@ def _pair(oracle_lib, P, nsteps, liters, cost_tol, x_tol, expect_onchip=True):
     while True:
         a, b = o.step(Pref.params), g.step(dev)
         assert a == b
-        assert abs(g.cost() - o.cost()) <= cost_tol * max(abs(o.cost()), 1e-12 * scale), (g.cost(), o.cost())
+        assert_close("cost", g.cost(), o.cost(), cost_tol, floor=1e-12 * scale, double=P.double)
         if not a:
             break
     assert _ran_onchip(g) == expect_onchip, g.kernel_timings().keys()
     if x_tol is not None:
-        assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < x_tol
+        assert_close("x", rel_err(device_unknowns(P, dev), flat_unknowns(Pref)), 0.0, x_tol, absolute=True, double=P.double)
     g.close(); o.close()
 
 
@@ -146,8 +146,8 @@ def test_a_timed_out_wait_leaves_the_unknowns_alone_and_the_step_is_redone(oracl
     g.solve(dev)
     t = g.kernel_timings()
     assert t["PCGSolveOnChip"][0] == 1 and "PCGIteration" in t          # tried once, then the streaming loop for the rest of the plan
-    assert abs(g.cost() - o.cost()) <= 1e-10 * abs(o.cost())
-    assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < 1e-9
+    assert_close("cost", g.cost(), o.cost(), 1e-10, double=True)
+    assert_close("x", rel_err(device_unknowns(P, dev), flat_unknowns(Pref)), 0.0, 1e-9, absolute=True, double=True)
     assert "timed out" in capfd.readouterr().err
     g.close(); o.close()
 

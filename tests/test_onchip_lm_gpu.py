@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 from opt_amd import api, workloads as wl
-from helpers import device_unknowns, flat_unknowns, hip_solver, oracle_solver, rel_err
+from helpers import assert_close, device_unknowns, flat_unknowns, hip_solver, oracle_solver, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -39,15 +39,15 @@ def _side_by_side(oracle_lib, P, nsteps, liters, cost_tol, x_tol, radius_tol, ex
         assert a == b, (a, b, costs)
         costs.append((o.cost(), g.cost()))
         tol = cost_tol if (later_tol is None or len(costs) <= 2) else later_tol      # later_tol: outer steps after the first (float runs, see test_variants_float)
-        assert abs(g.cost() - o.cost()) <= tol * max(abs(o.cost()), 1e-12 * scale), costs
+        assert_close("cost" if len(costs) <= 2 else "cost_later", g.cost(), o.cost(), tol, floor=1e-12 * scale, double=P.double, step=len(costs) - 1)
         if later_tol is None or len(costs) <= 2:
-            assert abs(g.trust_region_radius() - o.trust_region_radius()) <= radius_tol * o.trust_region_radius(), costs
+            assert_close("radius", g.trust_region_radius(), o.trust_region_radius(), radius_tol, double=P.double)
         if not a:
             break
     assert _ran_onchip(g) == expect_onchip, g.kernel_timings().keys()
     assert g.on_chip_status() in ((1,) if expect_onchip else (0,))
     if x_tol is not None:
-        assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < x_tol
+        assert_close("x", rel_err(device_unknowns(P, dev), flat_unknowns(Pref)), 0.0, x_tol, absolute=True, double=P.double)
     g.close(); o.close()
     return costs
 
@@ -142,8 +142,8 @@ def test_a_timed_out_wait_is_taken_back_and_the_step_is_redone(oracle_lib, monke
     t = g.kernel_timings()
     assert t["PCGSolveOnChip"][0] == 1 and "PCGIteration" in t          # tried once, then the launch-per-iteration loop for the rest of the plan
     assert g.on_chip_status() == 2
-    assert abs(g.cost() - o.cost()) <= 1e-10 * abs(o.cost())
-    assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < 1e-9
+    assert_close("cost", g.cost(), o.cost(), 1e-10, double=True)
+    assert_close("x", rel_err(device_unknowns(P, dev), flat_unknowns(Pref)), 0.0, 1e-9, absolute=True, double=True)
     assert "timed out" in capfd.readouterr().err
     g.close(); o.close()
 

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from opt_amd import api, workloads as wl
-from helpers import device_unknowns, flat_unknowns, hip_solver, oracle_solver, rel_err
+from helpers import assert_close, device_unknowns, flat_unknowns, hip_solver, oracle_solver, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -49,13 +49,13 @@ def _pair(oracle_lib, P, nsteps, liters, cost_tol, x_tol, status=1):
     while True:
         a, b = o.step(Pref.params), g.step(dev)
         assert a == b
-        assert abs(g.cost() - o.cost()) <= cost_tol * max(abs(o.cost()), 1e-9 * scale), (g.cost(), o.cost())
+        assert_close("cost", g.cost(), o.cost(), cost_tol, floor=1e-9 * scale, double=P.double)
         if not a:
             break
     kt = g.kernel_timings()
     assert "PCGSolveOnChip" in kt and ("PCGIteration" in kt) == (status == 2), kt.keys()
     assert g.on_chip_status() == status
-    assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < x_tol
+    assert_close("x", rel_err(device_unknowns(P, dev), flat_unknowns(Pref)), 0.0, x_tol, absolute=True, double=P.double)
     g.close(); o.close()
 
 
@@ -147,15 +147,15 @@ def _lm_side_by_side(oracle_lib, P, nsteps, liters, cost_tol, x_tol, radius_tol,
         assert a == b, (a, b, costs)
         costs.append((o.cost(), g.cost()))
         tol = cost_tol if (later_tol is None or len(costs) <= 2) else later_tol
-        assert abs(g.cost() - o.cost()) <= tol * max(abs(o.cost()), 1e-9 * scale), costs
+        assert_close("cost" if len(costs) <= 2 else "cost_later", g.cost(), o.cost(), tol, floor=1e-9 * scale, double=P.double, step=len(costs) - 1)
         if later_tol is None or len(costs) <= 2:
-            assert abs(g.trust_region_radius() - o.trust_region_radius()) <= radius_tol * o.trust_region_radius(), costs
+            assert_close("radius", g.trust_region_radius(), o.trust_region_radius(), radius_tol, double=P.double)
         if not a:
             break
     assert ("PCGSolveOnChip" in g.kernel_timings()) == expect_onchip, g.kernel_timings().keys()
     assert g.on_chip_status() == (status if status is not None else (1 if expect_onchip else 0))
     if x_tol is not None:
-        assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < x_tol
+        assert_close("x", rel_err(device_unknowns(P, dev), flat_unknowns(Pref)), 0.0, x_tol, absolute=True, double=P.double)
     g.close(); o.close()
 
 

@@ -1,0 +1,97 @@
+"""GPU parity tests (-m gpu) of the reference-ordered loop as a PRODUCT MODE: Opt_SetSolverParameter(..., "amd_reference_order", int* 1).
+
+The reference runs PCGStep1; PCGStep2; PCGStep3 per PCG iteration with r, z, A p in memory and the beta numerator summed directly (solverGPUGaussNewton.t:1056-1092).
+The default HIP loops fuse that into one launch per iteration (or one per linear solve) and obtain the beta numerator by expansion: faster, but outside the 1e-5 float
+contract from ~50 iterations on (profiles/r05_horizon_parity.md).  The reference-ordered loop is the one that meets the contract at the metric's own horizon; round 5
+could only reach it through an environment variable.  Here:
+  * the parameter selects it per plan (two plans of one process take different loops), OptAmd_PlanDescribe says so, it never runs on chip;
+  * it is the same loop bit for bit as the old environment switch;
+  * it holds the contract against the oracle on every energy family the fused loops cover (image_warping GN / LM, shape_from_shading, poisson, optical_flow, ARAP);
+  * "amd_onchip" = 0 keeps a small image on the launch-per-iteration kernels.
+The long-horizon statement (400 iterations, 5e-7 from the exact-order fma oracle) is tests/test_horizon_gpu.py's; bench.py times the mode (`contract_loop`).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from opt_amd import api, workloads as wl
+from helpers import assert_close, device_unknowns, flat_unknowns, hip_solver, oracle_solver, rel_err
+
+pytestmark = pytest.mark.gpu
+THREADS = max(1, min(os.cpu_count() or 1, 64))
+
+
+def _run(P, kind, nsteps, liters, **params):
+    g = hip_solver(P, kind, timing=True, nIterations=nsteps, lIterations=liters, **params)
+    dev = api.to_device(P)
+    g.init(dev)
+    costs = [g.cost()]
+    while g.step(dev):
+        costs.append(g.cost())
+    out = (costs, device_unknowns(P, dev), set(g.kernel_timings().keys()), g.describe(), g.on_chip_status())
+    g.close()
+    return out
+
+
+def test_parameter_selects_the_three_kernel_loop_per_plan():
+    P = wl.image_warping(300, 200, random_state=3, mask_fraction=0.05, perturb=0.3)
+    c_ref, x_ref, k_ref, d_ref, st_ref = _run(P, "gaussNewtonGPU", 2, 12, amd_reference_order=1)
+    c_def, x_def, k_def, d_def, st_def = _run(P, "gaussNewtonGPU", 2, 12)
+    assert "reference-order" in d_ref["path"] and "PCGStep2" in k_ref and "PCGSolveOnChip" not in k_ref and "PCGIteration" not in k_ref and st_ref == 0
+    assert "on-chip" in d_def["path"] and "PCGSolveOnChip" in k_def and st_def == 1      # the default plan of the same process is untouched by the other plan's choice
+    np.testing.assert_allclose(c_ref, c_def, rtol=1e-5)
+
+
+def test_same_bits_as_the_environment_switch(monkeypatch):
+    P = wl.image_warping(300, 200, random_state=5, mask_fraction=0.05, perturb=0.3)
+    a = _run(P, "gaussNewtonGPU", 2, 25, amd_reference_order=1)
+    monkeypatch.setenv("OPT_AMD_ONEKERNEL", "0"); monkeypatch.setenv("OPT_AMD_ONCHIP", "0")
+    b = _run(P, "gaussNewtonGPU", 2, 25)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+
+
+def test_amd_onchip_zero_keeps_the_launch_per_iteration_kernels():
+    P = wl.image_warping(300, 200, random_state=7, perturb=0.3)
+    c, x, k, d, st = _run(P, "gaussNewtonGPU", 2, 9, amd_onchip=0)
+    assert "PCGIteration" in k and "PCGSolveOnChip" not in k and st == 0 and d.get("amd_onchip") == "0"
+
+
+CASES = [
+    ("image_warping GN float", lambda: wl.image_warping(517, 133, random_state=11, mask_fraction=0.05, perturb=0.3), "gaussNewtonGPU", 2, 25),
+    ("image_warping LM float", lambda: wl.image_warping(300, 210, random_state=12, mask_fraction=0.05, perturb=0.3), "LMGPU", 3, 10),
+    ("image_warping GN double", lambda: wl.image_warping(260, 131, double=True, random_state=13, mask_fraction=0.05, perturb=0.3), "gaussNewtonGPU", 2, 25),
+    ("image_warping LM double", lambda: wl.image_warping(260, 131, double=True, random_state=14, mask_fraction=0.05, perturb=0.3), "LMGPU", 3, 12),
+    ("shape_from_shading LM double", lambda: wl.shape_from_shading(123, 70, double=True, seed=3, holes=True), "LMGPU", 3, 10),
+    ("shape_from_shading GN float", lambda: wl.shape_from_shading(123, 70, double=False, seed=4, holes=True), "gaussNewtonGPU", 2, 10),
+    ("poisson GN float", lambda: wl.poisson_image_editing(130, 90, seed=5), "gaussNewtonGPU", 1, 20),
+    ("optical_flow GN double", lambda: wl.optical_flow(96, 64, double=True, seed=6, init_flow=1.2), "gaussNewtonGPU", 2, 15),
+    ("arap GN float", lambda: wl.arap_mesh_deformation(40, 31, perturb=0.01), "gaussNewtonGPU", 2, 20),
+    ("arap LM double", lambda: wl.arap_mesh_deformation(40, 31, double=True, perturb=0.01), "LMGPU", 3, 10),
+]
+
+
+@pytest.mark.parametrize("name,make,kind,nsteps,liters", CASES, ids=[c[0].replace(" ", "_") for c in CASES])
+def test_reference_order_against_the_oracle(oracle_lib, name, make, kind, nsteps, liters):
+    """Side by side with the oracle after every outer step; double runs at the bars of tests/golden/parity_bars.json (1e-12 where the measured error allows it)."""
+    P = make()
+    o = oracle_solver(oracle_lib, P, kind, nIterations=nsteps, lIterations=liters)
+    g = hip_solver(P, kind, nIterations=nsteps, lIterations=liters, amd_reference_order=1)
+    dev = api.to_device(P)
+    Pref = P.clone()
+    o.init(Pref.params); g.init(dev)
+    scale = max(abs(o.cost()), 1e-300)
+    assert_close("cost0", g.cost(), o.cost(), 1e-12 if P.double else 1e-5, double=P.double)
+    step = 0
+    while True:
+        a, b = o.step(Pref.params), g.step(dev)
+        assert a == b
+        step += 1
+        assert_close("cost", g.cost(), o.cost(), 1e-10 if P.double else 1e-5, floor=1e-12 * scale, double=P.double, step=step)
+        if kind == "LMGPU":
+            assert_close("radius", g.trust_region_radius(), o.trust_region_radius(), 1e-8 if P.double else 1e-3, double=P.double, step=step)
+        if not a:
+            break
+    assert g.on_chip_status() == 0
+    assert_close("x", rel_err(device_unknowns(P, dev), flat_unknowns(Pref)), 0.0, 1e-9 if P.double else 2e-5, absolute=True, double=P.double)
+    g.close(); o.close()

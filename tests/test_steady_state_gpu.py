@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 
 from opt_amd import api, workloads as wl
-from helpers import device_unknowns, flat_unknowns, hip_solver, oracle_solver, rel_err
+from helpers import assert_close, device_unknowns, flat_unknowns, hip_solver, oracle_solver, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -43,17 +43,17 @@ def _pair(oracle_lib, P, kind, nsteps, liters, cost_tol, x_tol, radius_tol=None,
     Pref = P.clone()
     o.init(Pref.params); g.init(dev)
     scale = max(abs(o.cost()), 1e-300)
-    assert abs(g.cost() - o.cost()) <= cost_tol * scale
+    assert_close("cost0", g.cost(), o.cost(), cost_tol, floor=scale, double=P.double)
     while True:
         a, b = o.step(Pref.params), g.step(dev)
         assert a == b
-        assert abs(g.cost() - o.cost()) <= cost_tol * max(abs(o.cost()), 1e-12 * scale), (g.cost(), o.cost())
+        assert_close("cost", g.cost(), o.cost(), cost_tol, floor=1e-12 * scale, double=P.double)
         if radius_tol is not None:
-            assert abs(g.trust_region_radius() - o.trust_region_radius()) <= radius_tol * o.trust_region_radius()
+            assert_close("radius", g.trust_region_radius(), o.trust_region_radius(), radius_tol, double=P.double)
         if not a:
             break
     if x_tol is not None:
-        assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < x_tol
+        assert_close("x", rel_err(device_unknowns(P, dev), flat_unknowns(Pref)), 0.0, x_tol, absolute=True, double=P.double)
     g.close(); o.close()
 
 

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from opt_amd import api, workloads as wl
-from helpers import device_unknowns, flat_unknowns, hip_solver, oracle_solver, rel_err
+from helpers import assert_close, device_unknowns, flat_unknowns, hip_solver, oracle_solver, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -51,11 +51,11 @@ def _pair(oracle_lib, P, nsteps, liters, cost_tol, x_tol):
     while True:
         a, b = o.step(Pref.params), g.step(dev)
         assert a == b
-        assert abs(g.cost() - o.cost()) <= cost_tol * max(abs(o.cost()), 1e-9 * scale), (g.cost(), o.cost())
+        assert_close("cost", g.cost(), o.cost(), cost_tol, floor=1e-9 * scale, double=P.double)
         if not a:
             break
     assert "PCGIteration" in g.kernel_timings() and "PCGStep1" not in g.kernel_timings()
-    assert rel_err(device_unknowns(P, dev), flat_unknowns(Pref)) < x_tol
+    assert_close("x", rel_err(device_unknowns(P, dev), flat_unknowns(Pref)), 0.0, x_tol, absolute=True, double=P.double)
     g.close(); o.close()
 
 

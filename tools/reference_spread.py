@@ -64,8 +64,10 @@ def _exact(key, name):
     return _load(name).get(key)
 
 
-def legal_runs(key, step=1):
-    """[(label, cost after `step` Gauss-Newton steps)] of every frozen run of workload `key` (e.g. "horizon_2048_float_400", "solve8_2048_float", "bench_4096_float_400x2")."""
+def legal_runs(key, step=1, trig=True):
+    """[(label, cost after `step` Gauss-Newton steps)] of every frozen run of workload `key` (e.g. "horizon_2048_float_400", "solve8_2048_float", "bench_4096_float_400x2").
+    trig=False leaves out the runs with the seeded 1-ulp float sin / cos stand-in (`_trig`, `_trig_fma`): a SYNTHETIC perturbation, not an arithmetic the reference is known
+    to take -- tests assert their bars with and without it."""
     runs = []
     for label, name in (("exact-order plain", "horizon_costs.json"), ("exact-order fma", "horizon_costs_fma.json")):
         e = _exact(key, name)
@@ -78,6 +80,8 @@ def legal_runs(key, step=1):
         keys.append((f"solve8_{size}_{prec}", " (8 x 400 solve)"))
     for k, note in keys:
         for sfx, tag in VARIANTS:
+            if not trig and "trig" in tag:
+                continue
             for seed, costs in sorted(R.get(k + sfx, {}).get("costs_by_seed", {}).items(), key=lambda kv: int(kv[0])):
                 if len(costs) > step:
                     runs.append((f"reference-order {tag} seed {seed}{note}", costs[step]))
@@ -89,9 +93,9 @@ def anchor(key, step=1):
     return e["costs"][step] if e and len(e["costs"]) > step else None
 
 
-def spread(key, step=1):
+def spread(key, step=1, trig=True):
     """Diameter of the legal runs relative to the anchor; None without at least two runs."""
-    runs = [c for _, c in legal_runs(key, step)]
+    runs = [c for _, c in legal_runs(key, step, trig)]
     a = anchor(key, step)
     if len(runs) < 2 or a is None:
         return None
@@ -106,8 +110,8 @@ def seed_spread(key, step=1):
     return (max(v) - min(v)) / abs(a) if len(v) >= 2 and a else None
 
 
-def yardstick(key, precision, step=1):
-    s = spread(key, step)
+def yardstick(key, precision, step=1, trig=True):
+    s = spread(key, step, trig)
     return max(FLOOR[precision], s or 0.0)
 
 
