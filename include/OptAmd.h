@@ -72,12 +72,14 @@ void OptAmd_PlanGetTrace(Opt_Plan* plan, double* rows6);
 /* Current LM trust-region radius (reference pd.parameters.trust_region_radius). */
 double OptAmd_PlanTrustRegionRadius(Opt_Plan* plan);
 
-/* Which linear-solve path the plan's last step took and whether the plan has given the on-chip path up:
- *   0  launch-per-iteration kernels (the problem does not fit the chip, the kernel set has no on-chip solve, or it is switched off);
+/* Which linear-solve path the plan's last step took:
+ *   0  launch-per-iteration kernels (the problem does not fit the chip, the kernel set has no on-chip solve, or it is switched off: "amd_onchip" / "amd_reference_order");
  *   1  the whole linear solve of the last step ran as one persistent on-chip launch;
- *   2  a wait inside an on-chip launch timed out at some step (workgroups not co-resident: a shared GPU); that step was redone by the streaming kernels and
- *      the plan stays on them for the rest of its life (also reported once on stderr).  The two paths round differently: a caller that compares runs should
- *      check this. */
+ *   2  the plan is in its back-off after a failed on-chip launch: the waits of a launch's first phase are bounded by 10 ms (passing them proves the whole grid resident;
+ *      a foreign tenant holding CUs makes the launch give up there, before anything has been written), the step was redone by the streaming kernels (reported on stderr the
+ *      first three times) and the plan stays on them for 8 (then 16, 32 ... 1024) steps before it tries the chip again.  OptAmd_PlanDescribe carries `onchip_fallbacks` and
+ *      `onchip_backoff_steps_left`.  Plans of one process stepped from several host threads take turns on the chip (a per-device lease around each on-chip launch).
+ *      The two paths round differently: a caller that compares runs should check this. */
 int OptAmd_PlanOnChipStatus(Opt_Plan* plan);
 /* What the plan WOULD do at its next step, as "key=value; ..." text (truncated to outLen - 1 characters; returns the full length): the linear-solve path of its kernel
  * set for the plan's dimensions and slab (on chip or one launch per iteration, and why), tiles, LDS, ghost depth, bytes that cross ranks per PCG iteration, the
@@ -97,7 +99,8 @@ int OptAmd_PlanDescribe(Opt_Plan* plan, char* out, int outLen);
  * default (0) or nontemporal (1) accesses, `reps` timed repetitions after three warm-up launches.  bench.py reports it next to its roofline fraction: boxes of the
  * pool differ by ~10 % and MI355X_MICROARCH.md's copy ceiling (6.29 TB/s) is a measurement of this kind.  0.0 if the buffers cannot be allocated. */
 double OptAmd_MeasureCopyBandwidth(long bytes, int nontemporal, int reps);
-/* Test hook: `workgroups` one-wave workgroups that spin for `milliseconds` (<= 5000) on `stream` (a hipStream_t) -- a stand-in for a foreign tenant holding CUs while a
+/* Test hook: `workgroups` one-wave workgroups, each holding 150 KB of LDS (at most one per CU), that spin for `milliseconds` (<= 5000) on `stream` (a hipStream_t) -- a
+ * stand-in for a foreign tenant holding that many CUs while a
  * plan's persistent kernel is launched (tests/test_coresidency_gpu.py).  Returns 1 if launched. */
 int OptAmd_DebugOccupy(int workgroups, double milliseconds, void* stream);
 

@@ -17,6 +17,25 @@ OBJDIR = os.path.join(HERE, "build")
 # v_mov packing (and, in the row-marching kernels, with copies of not-yet-arrived loads); measured 1-3 % slower.
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-Wno-misleading-indentation"]
+# every device object is compiled with the kernel-resource-usage remarks on (free: an analysis pass the back end runs anyway); they are kept next to the object as
+# <source>.remarks and read by tests/test_kernel_resources.py (VGPRs, scratch, occupancy, LDS of every kernel in the library -- the "no scratch in an offered variant" rule)
+REMARKS = ["-Rpass-analysis=kernel-resource-usage"]
+
+
+def kernel_resources():
+    """{demangled kernel name: {"vgprs", "agprs", "scratch", "occupancy", "lds", "sgprs", "file"}} of every kernel of libOpt.so, from the remarks of the last build."""
+    import re
+    out = {}
+    for path in sorted(glob.glob(os.path.join(OBJDIR, "*.remarks"))):
+        txt = open(path, errors="replace").read()
+        rows = [m.groups() for m in re.finditer(r"Function Name: (\S+).*?SGPRs: (\d+).*?VGPRs: (\d+).*?AGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+).*?LDS Size \[bytes/block\]: (\d+)", txt, re.S)]
+        if not rows:
+            continue
+        names = subprocess.run(["c++filt"] + [r[0] for r in rows], capture_output=True, text=True).stdout.splitlines()
+        for r, n in zip(rows, names):
+            n = re.sub(r"\(.*", "", n.replace("optamd::(anonymous namespace)::", "").replace("void ", ""))
+            out[n] = {"sgprs": int(r[1]), "vgprs": int(r[2]), "agprs": int(r[3]), "scratch": int(r[4]), "occupancy": int(r[5]), "lds": int(r[6]), "file": os.path.basename(path)[:-len(".o.remarks")]}
+    return out
 
 
 def sources():
@@ -56,12 +75,19 @@ def build(force=False, verbose=False):
     for src in sources():
         obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m):
-            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
+        is_hip = src.endswith(".hip")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m) or (is_hip and not os.path.exists(obj + ".remarks")):
+            cmd = [HIPCC] + FLAGS + (REMARKS + ["-x", "hip"] if is_hip else []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
-            procs.append((src, subprocess.Popen(cmd)))
-    failed = [s for s, p in procs if p.wait() != 0]
+            procs.append((src, subprocess.Popen(cmd, stderr=open(obj + ".remarks", "w") if is_hip else None), obj + ".remarks" if is_hip else None))
+    failed = []
+    for src, p, rem in procs:
+        if p.wait() != 0:
+            failed.append(src)
+            if rem:      # the compiler's messages went to the remarks file: show what is not a remark
+                sys.stderr.write("".join(l for l in open(rem, errors="replace") if "remark:" not in l))
+                os.remove(rem)
     if failed:
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
     if procs or not os.path.exists(LIB):

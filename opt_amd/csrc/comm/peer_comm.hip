@@ -55,6 +55,7 @@ constexpr size_t kEdgeBytes = 2 * 2 * kEdgeWords * sizeof(u64);
 
 struct PeerCtx {
     int rank, world;
+    int said = 0;                  // the error-state message has been printed for THIS communicator
     Window* win[kMaxWorld];        // win[rank] = my own window, others IPC-mapped
     char* stage[kMaxWorld];        // staging area behind each window
     u64* edge[kMaxWorld];          // edge boxes behind each staging area
@@ -268,8 +269,7 @@ void fail(PeerCtx* x, int code) { if (!*x->hostErr) *x->hostErr = code; }
 bool failed(PeerCtx* x, const char* where) {
     const int e = *x->hostErr;
     if (!e) return false;
-    static int said = 0;
-    if (!said++) fprintf(stderr, "OptComm(peer) rank %d: communicator in error state at %s (code %d: 1 = all-reduce timed out, 2 = halo ack, 3 = halo rows, 4 = posted all-reduce polled by the "
+    if (!x->said++) fprintf(stderr, "OptComm(peer) rank %d: communicator in error state at %s (code %d: 1 = all-reduce timed out, 2 = halo ack, 3 = halo rows, 4 = posted all-reduce polled by the "
                                   "iteration kernel, 5 = oversize exchange, 6 = too many values, 7 = HIP error) -- a rank died or fell out of step; further collectives are skipped\n", x->rank, where, e);
     return true;
 }

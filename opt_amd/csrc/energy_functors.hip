@@ -183,6 +183,10 @@ struct VolumetricE {
 template <class T>
 struct FlowMarchOp {
     static constexpr int C = 2, kCoef = 2; static constexpr bool kMasked = false, kSplit31 = false;
+    // variants that would spill are not instantiated (tests/test_kernel_resources.py reads the compiler's resource remarks): the widest marching workgroup, and the
+    // on-chip (rows, waves, LM) combinations whose loop state does not fit 256 VGPRs
+    static constexpr int kMaxBlock = 768;
+    template <int R, int WV, bool LM> static constexpr bool spills() { return LM && WV == 8 && (sizeof(T) == 4 ? R == 16 : R == 8); }
     using Vec = MVec<T, 2>;
     T w_fit, w_reg;
     __device__ __forceinline__ Vec apply(const Vec& pc, const Vec& pl, const Vec& pr, const Vec& pu, const Vec& pd, bool hasL, bool hasR, bool hasU, bool hasD, const MVec<T, 2>& g) const {
@@ -248,6 +252,8 @@ template <class T> EnergyOps<T>* makeFlow(const unsigned* dims) { return new Opt
 template <class T>
 struct IntrinsicMarchOp {
     static constexpr int C = 4, kCoef = 4; static constexpr bool kMasked = false, kSplit31 = true;
+    static constexpr int kMaxBlock = sizeof(T) == 8 ? 256 : 768;      // (double: 512 / 768 threads spill 76 / 428 B)
+    template <int R, int WV, bool LM> static constexpr bool spills() { return sizeof(T) == 8 && !LM && R == 4 && WV == 8; }
     using Vec = MVec<T, 4>;
     T w_fit, w_regA, w_regS;
     __device__ __forceinline__ Vec apply(const Vec& pc, const Vec& pl, const Vec& pr, const Vec& pu, const Vec& pd, bool hasL, bool hasR, bool hasU, bool hasD, const MVec<T, 4>& w) const {

@@ -588,20 +588,35 @@ __global__ __launch_bounds__(kBlock) void arap_applySym(ArapArgs<T> A, const int
 
 // PCGStep2 + PCGStep3 in one flat pass for the record path: a workgroup takes 256 consecutive vertices = 3 * 256 / NP 16-byte packs of the Offset half and as many of the Angle
 // half (N a multiple of 4: both halves start on a pack boundary), updates delta, r, p pack by pack, and passes the new p through LDS to the thread that owns the vertex's record.
-template <class T>
+// LM (Levenberg-Marquardt, round 6): the same pass with the reference's LM extras -- delta goes to deltaOut (the solver enqueues the next launch before it has read Q:
+// an early-out must still find the old delta), Q_{k-1} = 1/2 sum delta . (r + b) (solver.t:483-485) leaves as per-workgroup partials (tagged words if qTag != 0), and
+// after a split residual reset (L.afterReset: delta and r are already the new ones, solver.t:1077-1083) the pass only forms p = M r + beta p with beta = sum bNum / sum bDen.
+struct ArapLmStep { const void* b; void* deltaOut; double* q; unsigned qTag; int afterReset; const double* bNumP; int nbNum; const double* bDenP; int nbDen; };
+template <class T, bool LM>
 __global__ __launch_bounds__(kBlock) void arap_flatStepRec(T* __restrict__ delta, const T* __restrict__ pOld, const T* __restrict__ rOld, const T* __restrict__ Ap, const T* __restrict__ M,
                                                            T* __restrict__ rNew, T* __restrict__ pNew, ArapRec<T>* __restrict__ rec, long N, const double* aNumP, int nNum, const double* aDenP, int nDen,
-                                                           const double* s2P, int n2, const double* s3P, int n3) {
+                                                           const double* s2P, int n2, const double* s3P, int n3, ArapLmStep L) {
     __shared__ double scratch[4 * (kBlock / kWave + 1)];
     constexpr int NP = 16 / sizeof(T), PACKS = 3 * kBlock / NP;
     typedef T VP __attribute__((ext_vector_type(NP)));
     __shared__ T tile[2][3 * kBlock];
-    const double* const ps[4] = {aNumP, aDenP, s2P, s3P}; const int ns[4] = {nNum, nDen, n2, n3}; double o4[4];
-    sumPartialsN<4>(ps, ns, scratch, o4);
-    const T aNum = (T)o4[0], aDen = (T)o4[1];
-    const T alpha = (aDen > T(0)) ? aNum / aDen : T(0);                                  // solver.t:456-459
-    const double bNumD = fmax(o4[0] - 2.0 * (double)alpha * o4[2] + (double)alpha * (double)alpha * o4[3], 0.0);
-    const T beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);                               // solver.t:544-547
+    T alpha, beta;
+    const bool restart = LM && L.afterReset;
+    if (restart) {
+        const double* const ps[2] = {L.bNumP, L.bDenP}; const int ns[2] = {L.nbNum, L.nbDen}; double o2[2];
+        sumPartialsN<2>(ps, ns, scratch, o2);
+        const T bNum = (T)o2[0], bDen = (T)o2[1];
+        alpha = T(0); beta = (bDen > T(0)) ? bNum / bDen : T(0);                            // PCGStep3's guard (solver.t:544-547)
+    } else {
+        const double* const ps[4] = {aNumP, aDenP, s2P, s3P}; const int ns[4] = {nNum, nDen, n2, n3}; double o4[4];
+        sumPartialsN<4>(ps, ns, scratch, o4);
+        const T aNum = (T)o4[0], aDen = (T)o4[1];
+        alpha = (aDen > T(0)) ? aNum / aDen : T(0);                                          // solver.t:456-459
+        const double bNumD = fmax(o4[0] - 2.0 * (double)alpha * o4[2] + (double)alpha * (double)alpha * o4[3], 0.0);
+        beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);                                       // solver.t:544-547
+    }
+    const T* const bV = (const T*)L.b; T* const dOut = LM ? (T*)L.deltaOut : delta;
+    double accQ = 0;
     const long offA = 3 * N, nTiles = (N + kBlock - 1) / kBlock, packsPerHalf = 3 * N / NP;
     for (long t = blockIdx.x; t < nTiles; t += gridDim.x) {
         __syncthreads();
@@ -610,18 +625,28 @@ __global__ __launch_bounds__(kBlock) void arap_flatStepRec(T* __restrict__ delta
             const long pk = t * PACKS + j;
             if (pk < packsPerHalf) {
                 const long base = (half ? offA : 0) + pk * NP;
-                VP d = *(const VP*)(delta + base);
-                const VP p = *(const VP*)(pOld + base), r = *(const VP*)(rOld + base), a = *(const VP*)(Ap + base), m = *(const VP*)(M + base);
+                const VP p = *(const VP*)(pOld + base), r = *(const VP*)(rOld + base), m = *(const VP*)(M + base);
                 VP rn, pn;
+                if (restart) {
 #pragma unroll
-                for (int k = 0; k < NP; ++k) {
-                    d[k] = d[k] + alpha * p[k];
-                    rn[k] = r[k] - alpha * a[k];
-                    const T z = m[k] * rn[k];
-                    pn[k] = z + beta * p[k];
-                    tile[half][j * NP + k] = pn[k];
+                    for (int k = 0; k < NP; ++k) { rn[k] = r[k]; pn[k] = m[k] * r[k] + beta * p[k]; tile[half][j * NP + k] = pn[k]; }
+                } else {
+                    VP d = *(const VP*)(delta + base);
+                    const VP a = *(const VP*)(Ap + base);
+                    VP bb;
+                    if (LM) bb = *(const VP*)(bV + base);
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        d[k] = d[k] + alpha * p[k];
+                        rn[k] = r[k] - alpha * a[k];
+                        const T z = m[k] * rn[k];
+                        pn[k] = z + beta * p[k];
+                        tile[half][j * NP + k] = pn[k];
+                        if (LM) accQ += (double)(T(0.5) * (d[k] * (rn[k] + bb[k])));
+                    }
+                    *(VP*)(dOut + base) = d;
                 }
-                *(VP*)(delta + base) = d; *(VP*)(rNew + base) = rn; *(VP*)(pNew + base) = pn;
+                *(VP*)(rNew + base) = rn; *(VP*)(pNew + base) = pn;
             }
         }
         __syncthreads();
@@ -631,6 +656,11 @@ __global__ __launch_bounds__(kBlock) void arap_flatStepRec(T* __restrict__ delta
             rr.px = tile[0][3 * threadIdx.x]; rr.py = tile[0][3 * threadIdx.x + 1]; rr.pz = tile[0][3 * threadIdx.x + 2];
             rr.ax = tile[1][3 * threadIdx.x]; rr.ay = tile[1][3 * threadIdx.x + 1]; rr.az = tile[1][3 * threadIdx.x + 2];
         }
+    }
+    if (LM && L.q && !restart) {
+        __syncthreads();
+        const double tq = blockReduceSum(accQ, scratch);
+        if (threadIdx.x == 0) { if (L.qTag) storeTaggedPartial(L.q, blockIdx.x, tq, L.qTag); else L.q[blockIdx.x] = tq; }
     }
 }
 
@@ -887,22 +917,30 @@ struct ArapOps : EnergyOps<T> {
     // kernels per iteration.)  On the edge-list gather of asymmetric graphs the same fusion lost in three formulations (profiles/NOTES.md) and is not offered.
     int fusedIterEnv = -1;
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
-        if (symPath() && fusedIterEnv != 0 && !a.CtC && a.pre && !this->slab.active && A.N % 4 == 0 &&
-            ((uintptr_t)a.delta | (uintptr_t)a.pOld | (uintptr_t)a.rOld | (uintptr_t)a.ApOld | (uintptr_t)a.pre | (uintptr_t)a.rNew | (uintptr_t)a.pNew) % 16 == 0) {
+        // Gauss-Newton and (round 6) Levenberg-Marquardt: a.CtC adds CtC p to the gather, the flat pass carries b, Q and the restart after a residual reset (ArapLmStep)
+        const bool lmv = a.CtC != nullptr;
+        if (symPath() && fusedIterEnv != 0 && a.pre && !this->slab.active && A.N % 4 == 0 && (!lmv || (a.b && a.q)) &&
+            ((uintptr_t)a.delta | (uintptr_t)a.pOld | (uintptr_t)a.rOld | (uintptr_t)a.ApOld | (uintptr_t)a.pre | (uintptr_t)a.rNew | (uintptr_t)a.pNew | (uintptr_t)a.deltaOut | (uintptr_t)a.b) % 16 == 0) {
             const long n = 6 * A.N, nPad = (n + 3) / 4 * 4;
+            const int g = (int)std::max<long>(1, std::min<long>((A.N + kBlock - 1) / kBlock, (long)cus * 8));
             if (a.first) {      // the solver adopts rNew / pNew after every launch: the start state moves there unchanged
                 HIP_CHECK(hipMemcpyAsync(a.rNew, a.rOld, nPad * sizeof(T), hipMemcpyDeviceToDevice, ctx.stream));
                 HIP_CHECK(hipMemcpyAsync(a.pNew, a.pOld, nPad * sizeof(T), hipMemcpyDeviceToDevice, ctx.stream));
                 ScopedKernel k(ctx, "packVertexRecords"); arap_packRec<T><<<vgrid(), kBlock, 0, ctx.stream>>>(a.pNew, rec, A.N);
+            } else if (lmv) {
+                ScopedKernel k(ctx, "PCGStep2+PCGStep3");
+                const ArapLmStep L{a.b, a.deltaOut ? a.deltaOut : a.delta, a.q->partials, a.qTag, a.afterReset, a.betaNum.partials, a.betaNum.n, a.betaDen.partials, a.betaDen.n};
+                arap_flatStepRec<T, true><<<g, kBlock, 0, ctx.stream>>>(a.delta, a.pOld, a.rOld, a.ApOld, a.pre, a.rNew, a.pNew, rec, A.N, a.aNumPrev.partials, a.aNumPrev.n, a.aDenPrev.partials, a.aDenPrev.n,
+                                                                       a.s2Prev.partials, a.s2Prev.n, a.s3Prev.partials, a.s3Prev.n, L);
+                if (!a.afterReset) a.q->n = g;
             } else {
                 ScopedKernel k(ctx, "PCGStep2+PCGStep3");
-                const int g = (int)std::max<long>(1, std::min<long>((A.N + kBlock - 1) / kBlock, (long)cus * 8));
-                arap_flatStepRec<T><<<g, kBlock, 0, ctx.stream>>>(a.delta, a.pOld, a.rOld, a.ApOld, a.pre, a.rNew, a.pNew, rec, A.N, a.aNumPrev.partials, a.aNumPrev.n, a.aDenPrev.partials, a.aDenPrev.n,
-                                                                 a.s2Prev.partials, a.s2Prev.n, a.s3Prev.partials, a.s3Prev.n);
+                arap_flatStepRec<T, false><<<g, kBlock, 0, ctx.stream>>>(a.delta, a.pOld, a.rOld, a.ApOld, a.pre, a.rNew, a.pNew, rec, A.N, a.aNumPrev.partials, a.aNumPrev.n, a.aDenPrev.partials, a.aDenPrev.n,
+                                                                        a.s2Prev.partials, a.s2Prev.n, a.s3Prev.partials, a.s3Prev.n, ArapLmStep{});
             }
             ScopedKernel k(ctx, "PCGStep1");
-            const int g = launchSym(a.pNew, a.ApNew, nullptr, a.aDen, ctx, ArapIterSums{a.rNew, a.pre, a.aNum->partials, a.s2->partials, a.s3->partials});
-            a.aNum->n = a.aDen->n = a.s2->n = a.s3->n = g;
+            const int gs = launchSym(a.pNew, a.ApNew, a.CtC, a.aDen, ctx, ArapIterSums{a.rNew, a.pre, a.aNum->partials, a.s2->partials, a.s3->partials});
+            a.aNum->n = a.aDen->n = a.s2->n = a.s3->n = gs;
             return true;
         }
         return false;

@@ -122,6 +122,9 @@ __global__ __launch_bounds__(kBlock) void poisson_applyJTJ(PArgs<T> A, const T* 
 template <class T>
 struct PoissonMarchOp {
     static constexpr int C = 4, kCoef = 0; static constexpr bool kMasked = true, kSplit31 = false;
+    // variants that would spill are not instantiated (tests/test_kernel_resources.py): double4 pixels at 768 threads (156 B), on chip 8 rows x 8 waves (528 B) / LM 4 x 8 (52 B)
+    static constexpr int kMaxBlock = sizeof(T) == 8 ? 512 : 768;
+    template <int R, int WV, bool LM> static constexpr bool spills() { return sizeof(T) == 8 && WV == 8 && (LM ? R == 4 : R == 8); }
     using Vec = MVec<T, 4>;
     __device__ __forceinline__ Vec apply(const Vec& pc, const Vec& pl, const Vec& pr, const Vec& pu, const Vec& pd, bool hasL, bool hasR, bool hasU, bool hasD, const MVec<T, 1>&) const {
         Vec o;
@@ -140,6 +143,8 @@ struct PoissonMarchOp {
 // laplacian: 0.2^2 p_c + sum over in-bounds neighbours of (p_c - p_n), order as in lap_applyJTJ
 struct LaplacianMarchOp {
     static constexpr int C = 1, kCoef = 0; static constexpr bool kMasked = false, kSplit31 = false;
+    static constexpr int kMaxBlock = 768;
+    template <int R, int WV, bool LM> static constexpr bool spills() { return false; }
     using Vec = MVec<float, 1>;
     __device__ __forceinline__ Vec apply(const Vec& pc, const Vec& pl, const Vec& pr, const Vec& pu, const Vec& pd, bool hasL, bool hasR, bool hasU, bool hasD, const MVec<float, 1>&) const {
         float o = 0.2f * 0.2f * pc.v[0];

@@ -145,7 +145,12 @@ template <class T> struct OcLds {
     static constexpr size_t tail() { return (kOcSumsMax * kOcWaves + kOcGroup * kOcSumsMax + 8) * sizeof(double) + (kOcMaxTiles * 2 * kOcSumsMax + kOcGroup * 8) * sizeof(unsigned) + 32 * sizeof(T) + 16; }
     // Levenberg-Marquardt: b = r_0 of the lane's pixels ([row][component][thread], like apL), delta of the halo rows and of the halo columns
     static constexpr size_t lm(int rows) { return ap(rows, true) + row() + side(rows); }
-    static constexpr size_t total(int rows, bool apLds, bool lmv = false) { return ap(rows, apLds) + rows3(apLds) + 5 * side(rows) + tail() + (lmv ? lm(rows) : 0); }
+    // cos / sin of the lane's LAST csRows rows live in LDS instead of registers where that relieves a variant that spills and the LDS has the room: the LM ROWS = 8 variant
+    // (round 6: 124 -> 68 B of scratch per lane; a row's pair is read back once per stencil pass): [row][cos, sin][thread], behind everything else.  (ROWS = 16 has no room: its
+    // A p fills 96 of the CU's 160 KB and the rest is taken to within 6 KB; its 40-64 B of scratch stay -- ~13 scratch operations per iteration of ~2000 VALU instructions.)
+    static constexpr int csRows(int rows, bool apLds, bool lmv) { return (sizeof(T) == 4 && rows == 8 && lmv && !apLds) ? 8 : 0; }
+    static constexpr size_t base(int rows, bool apLds, bool lmv) { return ap(rows, apLds) + rows3(apLds) + 5 * side(rows) + tail() + (lmv ? lm(rows) : 0); }
+    static constexpr size_t total(int rows, bool apLds, bool lmv = false) { return base(rows, apLds, lmv) + (size_t)csRows(rows, apLds, lmv) * 2 * kOcBlock * sizeof(T); }
 };
 
 // Development builds (opt_amd/build.py build_variant with OC_PROFILE=1; tools/onchip_bench.py under OPT_AMD_ONCHIP_PROFILE=1): thread 0 of every workgroup
@@ -242,7 +247,9 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
     };
 
     // ---- the lane's ROWS pixels, the halo rows above and below them, and (lane = side * ROWS + row) the halo columns of the wave ---------------------
-    T p[ROWS][3], r[ROWS][3], cs[ROWS][2];
+    constexpr int CSL = OcLds<T>::csRows(ROWS, AP_LDS, LMV), CSR = ROWS - CSL;      // rows whose cos / sin live in LDS / in registers
+    T* const myCs = reinterpret_cast<T*>(ocLds + OcLds<T>::base(ROWS, AP_LDS, LMV)) + tid;      // + ((row - CSR) * 2 + {0: cos, 1: sin}) * 512
+    T p[ROWS][3], r[ROWS][3], cs[CSR > 0 ? CSR : 1][2];
     T dl[DELTA_GLB ? 1 : ROWS][3], ap[AP_LDS ? 1 : ROWS][3];
     unsigned fl[(ROWS + 3) / 4];
     T* const myB = bL + tid;      // LM: + (row * 3 + component) * 512
@@ -251,7 +258,10 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
         unsigned f; T on;
-        loadPixel(x, yBase + j, p[j], r[j], cs[j][0], cs[j][1], on, f, true);
+        T cj, sj;
+        loadPixel(x, yBase + j, p[j], r[j], cj, sj, on, f, true);
+        if (j < CSR) { cs[j < CSR ? j : 0][0] = cj; cs[j < CSR ? j : 0][1] = sj; }
+        else { myCs[((j - CSR) * 2 + 0) * kOcBlock] = cj; myCs[((j - CSR) * 2 + 1) * kOcBlock] = sj; }
         fl[j >> 2] |= f << (8 * (j & 3));
         if (!DELTA_GLB) { dl[DELTA_GLB ? 0 : j][0] = 0; dl[DELTA_GLB ? 0 : j][1] = 0; dl[DELTA_GLB ? 0 : j][2] = 0; }
         if (LMV) { myB[(j * 3 + 0) * kOcBlock] = r[j][0]; myB[(j * 3 + 1) * kOcBlock] = r[j][1]; myB[(j * 3 + 2) * kOcBlock] = r[j][2]; }      // b = r_0 (solver.t:657)
@@ -291,7 +301,7 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
     auto rowQ = [&](const T (&v)[ROWS][3], int j) {
         Q<T> q{};
         const unsigned f = flagOf(j);
-        q.ox = v[j][0]; q.oy = v[j][1]; q.a = v[j][2]; q.c = cs[j][0]; q.s = cs[j][1];
+        q.ox = v[j][0]; q.oy = v[j][1]; q.a = v[j][2]; q.c = j < CSR ? cs[j < CSR ? j : 0][0] : myCs[((j - CSR) * 2 + 0) * kOcBlock]; q.s = j < CSR ? cs[j < CSR ? j : 0][1] : myCs[((j - CSR) * 2 + 1) * kOcBlock];
         q.on = (f & kActive) ? T(1) : T(0); q.fw = (f & kFit) ? wf2 : T(0);
         return q;
     };

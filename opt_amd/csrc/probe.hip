@@ -2,7 +2,7 @@
 //  * OptAmd_MeasureCopyBandwidth: the float4 copy ceiling of THIS box (the roofline's second denominator: MI355X_MICROARCH.md measures 6.29 TB/s this way, boxes of
 //    the pool differ) -- a grid-stride 16-byte-per-lane copy kernel, default or nontemporal accesses, timed with hipEvents on its own stream.
 //  * OptAmd_DebugOccupy: a test hook that holds CUs the way a foreign tenant would (tests/test_coresidency_gpu.py): `workgroups` single-wave workgroups spin on the
-//    device's wall clock for `milliseconds`; while they run, no 512-thread workgroup of a persistent solver kernel that needs a whole CU's registers can share those CUs.
+//    device's wall clock for `milliseconds`, each holding 150 KB of its CU's LDS; while they run, no workgroup of a persistent solver kernel fits on those CUs.
 #include "common.h"
 #include "../../include/OptAmd.h"
 
@@ -50,6 +50,11 @@ extern "C" double OptAmd_MeasureCopyBandwidth(long bytes, int nontemporal, int r
 
 extern "C" int OptAmd_DebugOccupy(int workgroups, double milliseconds, void* stream) {
     if (workgroups < 1 || milliseconds <= 0 || milliseconds > 5000.0) return 0;
-    k_probeOccupy<<<workgroups, kWave, 0, (hipStream_t)stream>>>((long long)(milliseconds * 1e5), nullptr);
+    // each workgroup is one wave that holds 150 of its CU's 160 KB of LDS: at most one per CU, and no workgroup of a persistent solver kernel (tens of KB of LDS each)
+    // fits beside it -- a small-register tenant alone would share the CU with the 105-VGPR variants
+    constexpr int kLds = 150 * 1024;
+    static bool once = false;
+    if (!once) { if (hipFuncSetAttribute((const void*)k_probeOccupy, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) { (void)hipGetLastError(); return 0; } once = true; }
+    k_probeOccupy<<<workgroups, kWave, kLds, (hipStream_t)stream>>>((long long)(milliseconds * 1e5), nullptr);
     return hipGetLastError() == hipSuccess ? 1 : 0;
 }

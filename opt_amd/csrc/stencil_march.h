@@ -258,8 +258,8 @@ struct MarchLoop {
         // (1024^2: optical_flow 21.4 / 21.8 / 25.2 us for 512 / 768 / 256, intrinsic 28.2 / 32.5 / 30.9; poisson 256^2 11.9 / 13.6 / 13.0); 32-byte pixels
         // (double4: 206 VGPRs) run 256 threads
         const int blk = forceBlock ? forceBlock : (Op::C * sizeof(T) <= 16 ? (W >= 1536 ? 768 : 512) : 256);
-        if (blk == 768) return launchB<Op, 768>(op, W, H, flags, cus, a, ctx, coef);
-        if (blk == 512) return launchB<Op, 512>(op, W, H, flags, cus, a, ctx, coef);
+        if constexpr (Op::kMaxBlock >= 768) { if (blk == 768) return launchB<Op, 768>(op, W, H, flags, cus, a, ctx, coef); }      // (Op::kMaxBlock: wider workgroups would spill and are not instantiated)
+        if constexpr (Op::kMaxBlock >= 512) { if (blk >= 512) return launchB<Op, 512>(op, W, H, flags, cus, a, ctx, coef); }
         return launchB<Op, 256>(op, W, H, flags, cus, a, ctx, coef);
     }
     template <class Op, int blk>

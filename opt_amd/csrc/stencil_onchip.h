@@ -369,11 +369,12 @@ struct OnchipMarch {
     template <class Op, bool LM> static const std::vector<Variant>& variants() {
         static const std::vector<Variant> v = [] {
             std::vector<Variant> o;
-#define MO_VARIANT(R, WV) if constexpr (ldsBytes<Op, R, WV, LM>() <= 150 * 1024) o.push_back({R, WV, (const void*)march_onchipPcg<T, Op, R, WV, LM>})
+#define MO_VARIANT(R, WV) if constexpr (ldsBytes<Op, R, WV, LM>() <= 150 * 1024 && !Op::template spills<R, WV, LM>()) o.push_back({R, WV, (const void*)march_onchipPcg<T, Op, R, WV, LM>})
             MO_VARIANT(2, 4); MO_VARIANT(4, 4); MO_VARIANT(8, 4); MO_VARIANT(2, 8); MO_VARIANT(4, 8); MO_VARIANT(8, 8);
             if constexpr (Op::C * sizeof(T) <= 8) { MO_VARIANT(16, 4); MO_VARIANT(16, 8); }
 #undef MO_VARIANT
-            // a variant whose registers do not hold its loop state (16- and 32-byte pixels at 8 rows) is not offered: no scratch in a kernel that is all latency
+            // a variant whose registers do not hold its loop state is not instantiated (Op::spills, from the compiler's resource remarks); should a compiler upgrade make another one
+            // spill it is still not offered: no scratch in a kernel that is all latency
             std::vector<Variant> ok;
             for (const auto& v : o) { hipFuncAttributes fa{}; if (hipFuncGetAttributes(&fa, v.fn) == hipSuccess && fa.localSizeBytes == 0) ok.push_back(v); else (void)hipGetLastError(); }
             return ok;

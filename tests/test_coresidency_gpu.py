@@ -7,7 +7,7 @@ The on-chip linear solves (iw_onchipPcg, sfs_onchipPcg, march_onchipPcg) wait fo
         holds CUs makes the launch give up there, the step is redone by the streaming kernels;
   (iii) after such a fall-back the plan returns to the chip after 8 (16, 32 ...) clean steps.
 Checked here: two plans (image_warping 512^2 GN and shape_from_shading 640x480 double LM) stepped concurrently from two threads give, each, exactly the costs they give
-alone, stay on chip, and no step stalls; a plan stepped while a foreign kernel holds 128 CUs for 0.3 s falls back ONCE (status 2, oracle-correct cost, stall << 50 ms
+alone, stay on chip, and no step stalls; a plan stepped while a foreign kernel holds 240 of the 256 CUs for 0.3 s falls back ONCE (status 2, oracle-correct cost, stall << 50 ms
 beyond its own work) and is back on chip (status 1) after its back-off.
 """
 import ctypes
@@ -82,10 +82,11 @@ def test_foreign_tenant_makes_the_launch_fall_back_once_and_the_plan_returns(ora
     g.step(dev)                                      # step 1 alone: on chip
     assert g.on_chip_status() == 1
     side = torch.cuda.Stream()
-    assert api.lib().OptAmd_DebugOccupy(128, ctypes.c_double(300.0), ctypes.c_void_p(side.cuda_stream)) == 1
+    # 240 one-wave workgroups with 150 KB of LDS each: 240 CUs closed to the plan's 256 workgroups (53 KB of LDS, 105 VGPRs: the 16 free CUs take two each)
+    assert api.lib().OptAmd_DebugOccupy(240, ctypes.c_double(300.0), ctypes.c_void_p(side.cuda_stream)) == 1
     time.sleep(0.02)                                 # the tenant is running
     t0 = time.perf_counter()
-    g.step(dev)                                      # step 2 while 128 CUs are held: first-phase wait gives up after 10 ms, redone on the streaming kernels
+    g.step(dev)                                      # step 2 while 240 CUs are held: first-phase wait gives up after 10 ms, redone on the streaming kernels
     dt = time.perf_counter() - t0
     assert g.on_chip_status() == 2, g.describe()
     assert dt < 0.06, dt                             # 10 ms bound + the streaming redo; the old 2 s time-out would show here

@@ -90,6 +90,28 @@ def test_poisson_generic_lm_loop_controls(oracle_lib, period, qtol, liters):
     _side_by_side(oracle_lib, P, 3, liters, 1e-5, None, 1e-3, **kw)
 
 
+@pytest.mark.parametrize("double", [True, False])
+@pytest.mark.parametrize("period,qtol,liters", [(1, None, 6), (2, None, 10), (3, 0.5, 10), (10, None, 10), (10, 0.05, 12), (4, 0.0, 9), (7, None, 23), (5, 5.0, 10)])
+def test_arap_two_kernel_lm_iteration_controls(oracle_lib, period, qtol, liters, double):
+    """arap_mesh_deformation, Levenberg-Marquardt on the record gather (round 6: arap_flatStepRec<.., LM> + arap_applySym with CtC -- two kernels per PCG iteration where
+    the generic loop runs three; reference shape: examples/arap_mesh_deformation/src/main.cpp:81-99): CtC in the gather, b / Q / deltaOut in the flat pass, the restart
+    launch after a split residual reset, early-outs on and next to a reset iteration.  The two-kernel loop must actually be the one that ran (kernel names)."""
+    P = wl.arap_mesh_deformation(36, 29, double=double, perturb=0.01)
+    kw = dict(residual_reset_period=period)
+    if qtol is not None:
+        kw["q_tolerance"] = qtol
+    if double:
+        _side_by_side(oracle_lib, P, 4, liters, 1e-10, 1e-9, 1e-8, **kw)
+    else:
+        _side_by_side(oracle_lib, P, 3, liters, 1e-5, None, 1e-3, **kw)
+    g = hip_solver(P, "LMGPU", timing=True, nIterations=1, lIterations=max(liters, 3), residual_reset_period=period)
+    dev = api.to_device(P)
+    g.init(dev); g.step(dev)
+    kt = g.kernel_timings()
+    g.close()
+    assert "PCGStep2+PCGStep3" in kt and "PCGStep3" not in kt, kt.keys()
+
+
 def test_verbose_run_takes_the_listening_path(oracle_lib, capfd):
     """verbosity > 0 keeps the reference's last fetchQ (its only effect is the "breaking at iteration" message): same costs as the silent run."""
     P = wl.image_warping(48, 40, double=True, random_state=3, perturb=0.3)

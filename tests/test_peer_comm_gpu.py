@@ -218,6 +218,10 @@ def test_bench_two_ranks_is_self_describing():
     assert ck["allreduce_launches"] > 0 and ck["allreduce_us_per_iteration"] > 0 and ck["halo_exchanges"] > 0
     assert out["per_iteration_ms"] > 0 and out["roofline"]["per_iteration_ms"] > 0
     assert "needs distinct devices" in out["rccl_leg"]["skipped"]
+    # round 6: the smoke solve before the timed region -- one Gauss-Newton step of 12 PCG iterations through the solver's kernels on every rank, verdict collective
+    sm = out["smoke"]
+    assert sm["ok"] and sm["comm"] == "peer" and len(sm["ranks"]) == 2 and "fallback" not in sm
+    assert all(r["comm_error"] == 0 and r["exception"] is None for r in sm["ranks"]) and sm["ranks"][0]["cost"] == sm["ranks"][1]["cost"]
 
 
 @pytest.mark.parametrize("world,W,rows_per_rank,ghost,double,onchip_rows", [(2, 600, 64, 8, False, 4), (2, 300, 32, 2, True, 4), (4, 520, 32, 8, False, 8), (2, 260, 64, 4, False, 16), (3, 257, 24, 2, True, 4)])
