@@ -664,13 +664,10 @@ __global__ __launch_bounds__(kBlock) void arap_flatStepRec(T* __restrict__ delta
     }
 }
 
-#ifdef OPT_AMD_ARAP_ONCHIP      // development builds only: the persistent ARAP iteration of round 5 (measured slower than the two-kernel loop: profiles/r05_arap_onchip_experiment.md)
-}  // namespace
-}  // namespace optamd
-#include "../../tools/round5/arap_onchip_experiment/arap_onchip.h"
-namespace optamd {
-namespace {
-#endif
+// (The persistent ARAP iteration of round 5 -- built, parity-green, break-even at 56.7 us -- is kept as a record under tools/round5/arap_onchip_experiment/ with its numbers in
+// profiles/r05_arap_onchip_experiment.md; it is no longer wired into the library.  Round 6 measured what bounds the two kernels of an iteration with SQ / TCC / TCP counters and
+// tried the record layout {p, M = sum_k p_a[k] dR/da_k, U} with id-only slots -- 25 % fewer VALU instructions and 21 % fewer HBM reads in the gather, same time; 38 MB more in the
+// flat pass, 8 us slower: profiles/r06_arap_counters.md, tools/round6/arap_v2_pMU_records.patch.)
 
 // ---- the same for J^T F and diag(J^T J) (once per Gauss-Newton iteration) ---------------------------------------------------------
 // Edge pass: rotation-derivative columns into the D planes (as arap_edges<2>) and one 9-scalar record per half-edge,
@@ -749,9 +746,6 @@ struct ArapOps : EnergyOps<T> {
         if (nbr) (void)hipFree(nbr);
         for (void* q : {(void*)slots, (void*)rec, (void*)dNotSym}) if (q) (void)hipFree(q);
         for (void* q : {(void*)A.D, (void*)outOff, (void*)outIdx, (void*)inOff, (void*)inIdx, (void*)cursors, (void*)Jp, scanTemp, (void*)dChecksum}) if (q) (void)hipFree(q);
-#ifdef OPT_AMD_ARAP_ONCHIP
-        aoFree();
-#endif
     }
     void ensureCsr(LaunchCtx& ctx) {
         hipStream_t st = ctx.stream;
@@ -801,9 +795,6 @@ struct ArapOps : EnergyOps<T> {
             }
         }
         csrV0 = A.v0; csrV1 = A.v1; csrNE = A.nE; csrSum = sum; csrValid = true;
-#ifdef OPT_AMD_ARAP_ONCHIP
-        ++csrGen;
-#endif
     }
     ArapOps(const unsigned* dims) {
         A.N = dims[0];
@@ -815,12 +806,6 @@ struct ArapOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_ARAP_SYM")) useSym = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ARAP_SYM_XCD")) symXcd = atoi(e);
         if (const char* e = getenv("OPT_AMD_ARAP_VGRID")) symGridCap = atoi(e);
-#ifdef OPT_AMD_ARAP_ONCHIP
-        if (const char* e = getenv("OPT_AMD_ONCHIP")) aoEnabled = atoi(e) != 0;
-        if (const char* e = getenv("OPT_AMD_ONCHIP_FAIL_AT")) aoFailAt = atoi(e);
-        if (const char* e = getenv("OPT_AMD_ONCHIP_TIMEOUT_MS")) aoTimeoutTicks = std::max(1, atoi(e)) * 100000LL;
-        if (getenv("OPT_AMD_ONCHIP_PROFILE")) HIP_CHECK(hipMalloc((void**)&aoProf, sizeof(long long) * 8 * 256));
-#endif
     }
     void bind(void** p, LaunchCtx& ctx) override {
         A.w_fit = (T) * (const float*)p[0]; A.w_reg = (T) * (const float*)p[1];
@@ -847,9 +832,6 @@ struct ArapOps : EnergyOps<T> {
         out.n = gv + ge;
     }
     void evalJTF(T* r, T* diag, LaunchCtx& ctx) override {
-#ifdef OPT_AMD_ARAP_ONCHIP
-        aoDiag = diag;
-#endif
         { ScopedKernel k(ctx, "PCGInit1"); arap_vertices<T, 2><<<vgrid(), kBlock, 0, ctx.stream>>>(A, nullptr, r, diag, nullptr, nullptr); }
         if (useGather) {
             GraphCsr G{outOff, outIdx, inOff, inIdx};
@@ -945,9 +927,6 @@ struct ArapOps : EnergyOps<T> {
         }
         return false;
     }
-#ifdef OPT_AMD_ARAP_ONCHIP
-#include "../../tools/round5/arap_onchip_experiment/host_side.inc"
-#endif
     void evalModelCost(const T* delta, Reduction& out, LaunchCtx& ctx) override {
         const int gv = vgrid(), ge = edgeGrid(A.nE, cus);
         { ScopedKernel k(ctx, "computeModelCost"); arap_vertices<T, 1><<<gv, kBlock, 0, ctx.stream>>>(A, delta, nullptr, nullptr, nullptr, out.partials); }
