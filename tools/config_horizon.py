@@ -77,11 +77,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--configs", type=int, nargs="+", default=[3, 4])
+    ap.add_argument("--from-json", default=None, help="take the measurements from an earlier --out file (a run on the GPU box) instead of running: --from-json X --freeze")
     ap.add_argument("--freeze", action="store_true", help="write tests/golden/config_horizon_bars.json: per path and step, max(contract, 10 x measured)")
     args = ap.parse_args()
     G = json.load(open(GOLD))
-    res = {}
-    for c in args.configs:
+    res = json.load(open(args.from_json)) if args.from_json else {}
+    for c in ([] if args.from_json else args.configs):
         if CASES[c][0] not in G:
             print(f"config {c}: not frozen yet", file=sys.stderr)
             continue
