@@ -7,10 +7,13 @@
 // the edge kernel then accumulates on top (solver.t:1032-1036, 1062-1065).
 //
 // MI355X design: no atomics.  The edge lists are turned into per-vertex out- / in-lists once per graph (ensureCsr), and J^T J p is a GATHER:
-//   * symmetric graphs (every mesh: OptGraph.h:64-76 emits both directions of every edge; checked per vertex by csr_symmetric): one walk of a vertex's out-list serves
-//     both edge directions, a neighbour is ONE 64-byte record {p, p_a, sin / cos of its angles}, the slot of a half-edge 16 bytes {U_v - U_u, u} (arap_applySym), and a
-//     Gauss-Newton PCG iteration is two kernels -- the flat PCGStep2 + PCGStep3 pass that also rewrites the records (arap_flatStepRec) and the gather with the
-//     sums of the expanded beta numerator; vertices are dealt to the XCDs in contiguous eighths so that a record's readers share one L2;
+//   * symmetric graphs whose longest out-list has at most 16 entries (every mesh: OptGraph.h:64-76 emits both directions of every edge; checked per vertex by csr_symmetric):
+//     one walk of a vertex's out-list serves both edge directions.  Round 6 layout: what a half-edge needs of its neighbour lives in 16-byte SoA PLANES (D0 / D1: p and its Angle
+//     part, rewritten every PCG iteration; T0 / T1: sines / cosines; U0: rest position) and the out-lists in ELL order, one lane per vertex (arap_applyEll) -- the gathers of a
+//     wave touch 16 cache lines instead of 64 (the vector L1's line rate bound the 64-byte-record gather of rounds 3-5: profiles/r06_arap_counters.md).  A Gauss-Newton or
+//     Levenberg-Marquardt PCG iteration is two kernels -- the flat PCGStep2 + PCGStep3 pass that also rewrites the dynamic planes (arap_flatStepPlanes) and the gather with the
+//     sums of the expanded beta numerator; both walk the SAME eighth of the vertices per XCD, the gather forward, the flat pass backward (XcdWalk): 58 -> 47 us per iteration
+//     at 500 k vertices, config 4 116.9 -> 95.6 ms;
 //   * any other graph: the edge-list gather arap_applyFused (36-byte derivative rows per half-edge) in the reference's three-kernel loop.
 // The same inputs give the same bits (fixed summation order per vertex).  The scatter with wave-aggregated atomics (arap_vertices<3> + arap_edges<3>: runs of lanes
 // that target the same head vertex folded by a segmented shuffle reduction into one hardware f32 / f64 atomic) is what cost, model cost and curveFitting still use,
@@ -307,7 +310,7 @@ template <class T>
 __global__ __launch_bounds__(kBlock) void arap_packD(const T* __restrict__ D, T* __restrict__ D9, long nE) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < 9 * nE; i += (long)gridDim.x * blockDim.x) D9[i] = D[(i % 9) * nE + i / 9];
 }
-// S.r != nullptr (round 3): the launch is the Step1 half of a TWO-kernel PCG iteration (arap_flatStepRec + arap_applySym; EnergyOps::pcgIteration).  Besides p . A p it then sums, at the
+// S.r != nullptr (round 3): the launch is the Step1 half of a TWO-kernel PCG iteration (arap_flatStepPlanes + arap_applyEll; EnergyOps::pcgIteration).  Besides p . A p it then sums, at the
 // lane that owns the vertex, what the expanded beta numerator of the next flat pass needs -- sum M r^2, sum M r . A p, sum M (A p)^2, every term from M, r, A p themselves in double
 // (exact products of floats; see energy_image_warping.hip dprod3) -- so that PCGStep2 and PCGStep3 become one flat pass without a reduction between them.
 template <class T> __device__ __forceinline__ double arap_dprod3(T m, T a, T b) { return ((double)m * (double)a) * (double)b; }
@@ -397,8 +400,19 @@ __global__ __launch_bounds__(kBlock) void arap_applyFused(ArapArgs<T> A, GraphCs
 // 36-byte row -- is ONE 64-byte record (one cache line); the slot itself is 16 contiguous bytes {U_v - U_u, u}.  Per half-edge pair: 80 B in two lines instead of ~190 B in
 // seven.  The expressions are arap_edges<3>'s / arap_rot's (same association: J p = w (p_v0 - p_v1) - w (D_0 pa.x + D_1 pa.y + D_2 pa.z)), the in-edge terms are summed in
 // out-list order.
-template <class T> struct alignas(16) ArapSlot { T ux, uy, uz; int nbr; };
-template <class T> struct alignas(16) ArapRec { T px, py, pz, ax, ay, az, sa, ca, sb, cb, sg, cg, pad0, pad1, pad2, pad3; };
+// ---- symmetric-graph path, round 6 layout: 16-byte SoA PLANES + ELL out-lists, one lane per vertex ---------------------------------------------------------
+// What a half-edge's arithmetic needs of its neighbour u -- p_u, the Angle part of p_u, the sines / cosines of u's angles, u's rest position -- used to be one 64-byte
+// record per vertex, gathered with 16-byte loads: every lane of a gather touched a cache line of its own, four times over, and the vector L1's line rate (one line per clock
+// per CU: 10.9 M line accesses = 17.8 us of a 29 us launch) bound the kernel together with its issue slots (profiles/r06_arap_counters.md).  Now every group of four scalars
+// is a PLANE of N 16-byte entries: the neighbours of consecutive vertices of a mesh are consecutive vertices, so the 64 lanes of a gather touch 16 lines instead of 64.
+//   D0 = {p.x, p.y, p.z, pa.x}   D1 = {pa.y, pa.z, -, -}      dynamic: rewritten by the flat pass of every PCG iteration (two coalesced 16-byte stores per vertex)
+//   T0 = {sa, ca, sb, cb}        T1 = {sg, cg, -, -}           per Gauss-Newton step (arap_buildStatic)
+//   U0 = {U.x, U.y, U.z, -}                                     rest positions (rebuilt with T0 / T1: UrShape is an input of the solve)
+// and the out-lists are stored ELL-wise: ell[j * N + v] = the j-th out-neighbour of v (v itself beyond its degree, weight 0), so slot j of consecutive vertices is contiguous.
+// A vertex with more than kEllMax neighbours sends the graph to the edge-list gather (arap_applyFused), like an asymmetric one.
+constexpr int kEllMax = 16;
+template <class T> struct alignas(16) Q4 { T a, b, c, d; };
+template <class T> struct ArapPlanes { Q4<T>* D0; Q4<T>* D1; Q4<T>* T0; Q4<T>* T1; Q4<T>* U0; const int* ell; const int* deg; int K; };
 template <class T> struct ArapCoef { T a0, a1, a2, a3, a4, a5, b0, b1, b2, b3, b4, b5, b6, b7, b8, c0, c1, c2, c3, c4, c5; };
 // the non-zero entries of dR3/d alpha, d beta, d gamma (arap_rot's coefficients, same products)
 template <class T>
@@ -420,6 +434,8 @@ __device__ __forceinline__ void arap_cols(const ArapCoef<T>& c, const V3<T>& u, 
     D1.x = c.b0 * u.x + c.b1 * u.y + c.b2 * u.z; D1.y = c.b3 * u.x + c.b4 * u.y + c.b5 * u.z; D1.z = c.b6 * u.x + c.b7 * u.y + c.b8 * u.z;
     D2.x = c.c0 * u.x + c.c1 * u.y + c.c2 * u.z; D2.y = c.c3 * u.x + c.c4 * u.y + c.c5 * u.z; D2.z = 0;
 }
+template <class T> __device__ __forceinline__ V3<T> ldv3(const T* p, long i) { return reinterpret_cast<const V3<T>*>(p)[i]; }      // one 12 / 24-byte load
+template <class T> __device__ __forceinline__ void stv3(T* p, long i, const V3<T>& v) { reinterpret_cast<V3<T>*>(p)[i] = v; }
 // per vertex: is the multiset of out-neighbours the multiset of in-neighbours?  (quadratic in the degree; lists longer than 64 are declared asymmetric)
 __global__ __launch_bounds__(kBlock) void csr_symmetric(long N, const int* __restrict__ outOff, const int* __restrict__ outNbr, const int* __restrict__ inOff, const int* __restrict__ inNbr,
                                                         int* __restrict__ notSym) {
@@ -436,41 +452,44 @@ __global__ __launch_bounds__(kBlock) void csr_symmetric(long N, const int* __res
         if (bad) *notSym = 1;
     }
 }
-template <class T>
-__global__ __launch_bounds__(kBlock) void arap_buildSlots(ArapArgs<T> A, const int* __restrict__ outIdx, ArapSlot<T>* __restrict__ slots) {
-    for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < A.nE; k += (long)gridDim.x * blockDim.x) {
-        const int e = outIdx[k];
-        const long a0 = A.v0[e], a1 = A.v1[e];
-        const V3<T> U0 = ld3(A.UrShape, a0), U1 = ld3(A.UrShape, a1);
-        slots[k] = ArapSlot<T>{U0.x - U1.x, U0.y - U1.y, U0.z - U1.z, (int)a1};
+// out-lists in ELL order (once per graph): ell[j * N + v], padded with v itself; deg[v]; *maxDeg (a vertex beyond kEllMax sends the graph to the edge-list gather)
+__global__ __launch_bounds__(kBlock) void arap_buildEll(long N, const int* __restrict__ outOff, const int* __restrict__ outNbr, int K, int* __restrict__ ell, int* __restrict__ deg) {
+    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < N; v += (long)gridDim.x * blockDim.x) {
+        const int b = outOff[v], d = outOff[v + 1] - b;
+        deg[v] = d;
+        for (int j = 0; j < K; ++j) ell[(long)j * N + v] = j < d ? outNbr[b + j] : (int)v;
     }
 }
-// once per Gauss-Newton iteration: the sines and cosines of every vertex's angles (the p part of the record is written by arap_packRec / arap_step3Rec)
+__global__ __launch_bounds__(kBlock) void csr_maxDegree(long N, const int* __restrict__ outOff, int* __restrict__ out) {
+    int m = 0;
+    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < N; v += (long)gridDim.x * blockDim.x) m = max(m, outOff[v + 1] - outOff[v]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_down(m, o, kWave));
+    if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(out, m);
+}
+// once per Gauss-Newton iteration: the sines and cosines of every vertex's angles and its rest position
 template <class T>
-__global__ __launch_bounds__(kBlock) void arap_buildRecTrig(ArapArgs<T> A, ArapRec<T>* __restrict__ rec) {
+__global__ __launch_bounds__(kBlock) void arap_buildStatic(ArapArgs<T> A, ArapPlanes<T> P) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < A.N; i += (long)gridDim.x * blockDim.x) {
-        const V3<T> a = ld3(A.Angle, i);
+        const V3<T> a = ldv3(A.Angle, i), U = ldv3(A.UrShape, i);
         T sa, ca, sb, cb, sg, cg;
         sincosT(a.x, &sa, &ca); sincosT(a.y, &sb, &cb); sincosT(a.z, &sg, &cg);
-        ArapRec<T>& r = rec[i];
-        r.sa = sa; r.ca = ca; r.sb = sb; r.cb = cb; r.sg = sg; r.cg = cg; r.pad0 = r.pad1 = r.pad2 = r.pad3 = 0;
+        P.T0[i] = Q4<T>{sa, ca, sb, cb}; P.T1[i] = Q4<T>{sg, cg, T(0), T(0)}; P.U0[i] = Q4<T>{U.x, U.y, U.z, T(0)};
     }
 }
+// the dynamic planes from a solver vector (the first launch of a loop, probes, the A delta of LM's residual reset)
 template <class T>
-__global__ __launch_bounds__(kBlock) void arap_packRec(const T* __restrict__ v, ArapRec<T>* __restrict__ rec, long N) {
+__global__ __launch_bounds__(kBlock) void arap_packPlanes(const T* __restrict__ v, ArapPlanes<T> P, long N) {
     const long offA = 3 * N;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
-        const V3<T> p = ld3(v, i), pa = ld3(v + offA, i);
-        ArapRec<T>& r = rec[i];
-        r.px = p.x; r.py = p.y; r.pz = p.z; r.ax = pa.x; r.ay = pa.y; r.az = pa.z;
+        const V3<T> p = ldv3(v, i), pa = ldv3(v + offA, i);
+        P.D0[i] = Q4<T>{p.x, p.y, p.z, pa.x}; P.D1[i] = Q4<T>{pa.y, pa.z, T(0), T(0)};
     }
 }
-// PCGStep3 (k_step3 in solver.hip: solver.t:537-550) writing the new search direction to the solver's vector AND to the records.  21 us at 500 k vertices against 13 us for the
-// generic pass: the 24-byte record pieces at a 64-byte stride are what costs -- four vertices per thread with 16-byte vector accesses (23 us), coalesced packs staged through LDS
-// to the thread that owns the record (21 us) and records whose p half fills a 32-byte sector of its own (21 us, gather 45 -> 49 us) were measured and dropped.
+// PCGStep3 (k_step3 in solver.hip: solver.t:537-550) writing the new search direction to the solver's vector AND to the dynamic planes (the reference-ordered loop and the
+// generic Levenberg-Marquardt loop: EnergyOps::applyJTJFused)
 template <class T>
-__global__ __launch_bounds__(kBlock) void arap_step3Rec(const T* __restrict__ z, const T* __restrict__ pOld, T* __restrict__ pNew, ArapRec<T>* __restrict__ rec, long N,
-                                                        const double* __restrict__ bNumPartials, int nB, const double* __restrict__ aNumOld, double* __restrict__ aNumNext) {
+__global__ __launch_bounds__(kBlock) void arap_step3Planes(const T* __restrict__ z, const T* __restrict__ pOld, T* __restrict__ pNew, ArapPlanes<T> P, long N,
+                                                           const double* __restrict__ bNumPartials, int nB, const double* __restrict__ aNumOld, double* __restrict__ aNumNext) {
     __shared__ double scratch[kBlock / kWave + 1];
     const double bSum = sumPartials(bNumPartials, nB, scratch);
     const T rDotzNew = (T)bSum, rDotzOld = (T)aNumOld[0];
@@ -478,97 +497,98 @@ __global__ __launch_bounds__(kBlock) void arap_step3Rec(const T* __restrict__ z,
     if (blockIdx.x == 0 && threadIdx.x == 0) aNumNext[0] = bSum;
     const long offA = 3 * N;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
-        const V3<T> zo = ld3(z, i), za = ld3(z + offA, i), po = ld3(pOld, i), pa = ld3(pOld + offA, i);
+        const V3<T> zo = ldv3(z, i), za = ldv3(z + offA, i), po = ldv3(pOld, i), pa = ldv3(pOld + offA, i);
         const V3<T> no{zo.x + beta * po.x, zo.y + beta * po.y, zo.z + beta * po.z}, na{za.x + beta * pa.x, za.y + beta * pa.y, za.z + beta * pa.z};
-        pNew[3 * i] = no.x; pNew[3 * i + 1] = no.y; pNew[3 * i + 2] = no.z;
-        pNew[offA + 3 * i] = na.x; pNew[offA + 3 * i + 1] = na.y; pNew[offA + 3 * i + 2] = na.z;
-        ArapRec<T>& r = rec[i];
-        r.px = no.x; r.py = no.y; r.pz = no.z; r.ax = na.x; r.ay = na.y; r.az = na.z;
+        stv3(pNew, i, no); stv3(pNew + offA, i, na);
+        P.D0[i] = Q4<T>{no.x, no.y, no.z, na.x}; P.D1[i] = Q4<T>{na.y, na.z, T(0), T(0)};
     }
 }
-// LANES lanes share a vertex (each walks every LANES-th slot of its out-list); the kernel is bound by its arithmetic (two sets of derivative columns per slot), so fewer
-// lanes per vertex -- less of a wave spent on the per-vertex part and on idle lanes of short lists -- is faster as long as the lists' slots still arrive coalesced.
-#ifndef ARAP_SYM_LANES
-#define ARAP_SYM_LANES 2
+// XCD-aware, cache-friendly order of the two kernels of an iteration.  Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MB L2, and a vertex's plane entries
+// are read by the vertex and by its ~6 neighbours -- which in a mesh's vertex order sit a row of vertices apart: XCD x walks the x-th eighth of the vertex groups, so the copies
+// meet in one L2 (xcd != 0; the grid is a multiple of 8).  The gather walks its eighth FORWARD, the flat pass that follows it BACKWARD over the SAME eighth: what one kernel
+// touched last (the gather's A p, the flat pass's planes and vectors) is what the next one touches first, while it is still in that XCD's L2 / the Infinity Cache.
+struct XcdWalk {
+    long first, step, count;
+    __device__ __forceinline__ XcdWalk(long nGroups, int xcd) {
+        const long perXcd = (nGroups + 7) / 8, wgPerXcd = gridDim.x / 8;
+        first = xcd ? (long)(blockIdx.x % 8) * perXcd + blockIdx.x / 8 : blockIdx.x;
+        step = xcd ? wgPerXcd : gridDim.x;
+        const long end = xcd ? min(nGroups, (long)(blockIdx.x % 8 + 1) * perXcd) : nGroups;
+        count = end > first ? (end - first + step - 1) / step : 0;
+    }
+    __device__ __forceinline__ long group(long t, bool backward) const { return first + (backward ? count - 1 - t : t) * step; }
+};
+// J^T J p as a gather over the vertex's out-list (symmetric graphs), ONE lane per vertex.  BATCH neighbours of a lane are in flight together: their ids (coalesced: ELL),
+// then their five plane entries each, then the arithmetic -- both edge directions of a half-edge pair from one walk, as arap_edges<3> would compute them.
+#ifndef ARAP_ELL_BATCH
+#define ARAP_ELL_BATCH 3
 #endif
-template <class T, int LANES, int BATCH>
-__global__ __launch_bounds__(kBlock) void arap_applySym(ArapArgs<T> A, const int* __restrict__ outOff, const ArapSlot<T>* __restrict__ slots, const ArapRec<T>* __restrict__ rec,
-                                                        const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ CtC, double* __restrict__ partials, int xcd, ArapIterSums S) {
+template <class T, int BATCH>
+__global__ __launch_bounds__(kBlock) void arap_applyEll(ArapArgs<T> A, ArapPlanes<T> P, const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ CtC, double* __restrict__ partials,
+                                                        int xcd, ArapIterSums S) {
     __shared__ double scratch[4 * (kBlock / kWave + 1)];
     double acc = 0, accNum = 0, acc2 = 0, acc3 = 0;      // S.r != nullptr: the Step1 half of a two-kernel PCG iteration, see arap_applyFused
     const T* rv = (const T*)S.r; const T* Mv = (const T*)S.M;
-    const long offA = 3 * A.N;
-    const int sub = threadIdx.x % LANES;
-    const long nGroups = (A.N + (kBlock / LANES) - 1) / (kBlock / LANES);
-    // XCD-aware order (xcd != 0; the grid is a multiple of 8): workgroups are dealt round-robin to the 8 XCDs, each with its own L2, and a record is read by its vertex and by
-    // its ~6 neighbours -- which in a mesh's vertex order sit a row of vertices apart.  With consecutive groups on consecutive workgroups every XCD fetches its own copy of most
-    // records (157 MB of L2 misses per launch where slots + records + outputs are 100 MB); here XCD x walks the x-th eighth of the vertices, so the copies meet in one L2.
-    const long perXcd = (nGroups + 7) / 8, wgPerXcd = gridDim.x / 8;
-    const long gFirst = xcd ? (long)(blockIdx.x % 8) * perXcd + blockIdx.x / 8 : blockIdx.x, gStep = xcd ? wgPerXcd : gridDim.x;
-    const long gEnd = xcd ? min(nGroups, (long)(blockIdx.x % 8 + 1) * perXcd) : nGroups;
-    for (long g = gFirst; g < gEnd; g += gStep) {       // (trip counts differ between workgroups only: the shuffles below need whole waves, not whole grids)
-        const long i = g * (kBlock / LANES) + threadIdx.x / LANES;
-        const bool ok = i < A.N;
+    const long N = A.N, offA = 3 * N;
+    const XcdWalk walk((N + kBlock - 1) / kBlock, xcd);
+    const T w = A.w_reg;
+    for (long t = 0; t < walk.count; ++t) {       // (trip counts differ between workgroups only: the wave-wide maximum below needs whole waves, not whole grids)
+        const long g = walk.group(t, false);
+        const long i = g * kBlock + threadIdx.x;
+        const bool ok = i < N;
         const long iv = ok ? i : 0;
-        const T w = A.w_reg;
-        ArapRec<T> me = rec[iv];
-        const int bo = outOff[iv], eo = ok ? outOff[iv + 1] : bo;
+        const Q4<T> d0 = P.D0[iv], d1 = P.D1[iv], t0 = P.T0[iv], t1 = P.T1[iv], u0 = P.U0[iv];
+        const int deg = ok ? P.deg[iv] : 0;
+        int dmax = deg;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o, kWave));      // the wave walks as many slots as its longest list
         V3<T> rO{0, 0, 0}, rA{0, 0, 0}, mO{0, 0, 0}, mA{0, 0, 0};
-        if (rv && sub == 0) { rO = ld3(rv, iv); rA = ld3(rv + offA, iv); mO = ld3(Mv, iv); mA = ld3(Mv + offA, iv); }      // requested before the walk: known from the vertex index alone
-        const V3<T> pv{me.px, me.py, me.pz}, pav{me.ax, me.ay, me.az};
-        const ArapCoef<T> cv = arap_coef(me.sa, me.ca, me.sb, me.cb, me.sg, me.cg);
+        if (rv) { rO = ldv3(rv, iv); rA = ldv3(rv + offA, iv); mO = ldv3(Mv, iv); mA = ldv3(Mv + offA, iv); }      // requested before the walk: known from the vertex index alone
+        const V3<T> pv{d0.a, d0.b, d0.c}, pav{d0.d, d1.a, d1.b};
+        const ArapCoef<T> cv = arap_coef(t0.a, t0.b, t0.c, t0.d, t1.a, t1.b);
         T s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
-        // BATCH slots of a lane are requested together, then their BATCH records, then the arithmetic: the slot -> record chain is two memory round trips, and a lane that
-        // walks its three slots one after the other pays them three times (a slot past the end of the list repeats the last valid one with weight 0)
-        for (int k0 = bo + sub; k0 < eo; k0 += LANES * BATCH) {
-            ArapSlot<T> sl[BATCH]; ArapRec<T> nbs[BATCH]; T wm[BATCH];
+        for (int j0 = 0; j0 < dmax; j0 += BATCH) {
+            int nid[BATCH]; T wm[BATCH];
+            Q4<T> nd0[BATCH], nd1[BATCH], nt0[BATCH], nt1[BATCH], nu0[BATCH];
 #pragma unroll
-            for (int j = 0; j < BATCH; ++j) { const int kk = k0 + j * LANES; wm[j] = kk < eo ? w : T(0); sl[j] = slots[min(kk, eo - 1)]; }
+            for (int j = 0; j < BATCH; ++j) { const int jj = j0 + j; wm[j] = jj < deg ? w : T(0); nid[j] = P.ell[(long)min(jj, P.K - 1) * N + iv]; }
 #pragma unroll
-            for (int j = 0; j < BATCH; ++j) {
-                nbs[j] = rec[sl[j].nbr];
-            }
+            for (int j = 0; j < BATCH; ++j) { nd0[j] = P.D0[nid[j]]; nd1[j] = P.D1[nid[j]]; nt0[j] = P.T0[nid[j]]; nt1[j] = P.T1[nid[j]]; nu0[j] = P.U0[nid[j]]; }
 #pragma unroll
             for (int j = 0; j < BATCH; ++j) {
-                const ArapRec<T>& nb = nbs[j];
                 const T wj = wm[j];
-                const V3<T> u{sl[j].ux, sl[j].uy, sl[j].uz}, un{-sl[j].ux, -sl[j].uy, -sl[j].uz};
+                const V3<T> np{nd0[j].a, nd0[j].b, nd0[j].c}, npa{nd0[j].d, nd1[j].a, nd1[j].b};
+                const V3<T> u{u0.a - nu0[j].a, u0.b - nu0[j].b, u0.c - nu0[j].c}, un{-u.x, -u.y, -u.z};      // U_v - U_u: the subtraction the slots of rounds 3-5 stored
                 V3<T> D0, D1, D2;
                 arap_cols(cv, u, D0, D1, D2);
                 {   // out-edge (v -> u): J p and D_k . J p  (arap_edges<3> with v0 = v)
-                    const T jx = w * (pv.x - nb.px) - w * (D0.x * pav.x + D1.x * pav.y + D2.x * pav.z);
-                    const T jy = w * (pv.y - nb.py) - w * (D0.y * pav.x + D1.y * pav.y + D2.y * pav.z);
-                    const T jz = w * (pv.z - nb.pz) - w * (D0.z * pav.x + D1.z * pav.y + D2.z * pav.z);
+                    const T jx = w * (pv.x - np.x) - w * (D0.x * pav.x + D1.x * pav.y + D2.x * pav.z);
+                    const T jy = w * (pv.y - np.y) - w * (D0.y * pav.x + D1.y * pav.y + D2.y * pav.z);
+                    const T jz = w * (pv.z - np.z) - w * (D0.z * pav.x + D1.z * pav.y + D2.z * pav.z);
                     s0 += wj * jx; s1 += wj * jy; s2 += wj * jz;
                     s3 -= wj * (D0.x * jx + D0.y * jy + D0.z * jz); s4 -= wj * (D1.x * jx + D1.y * jy + D1.z * jz); s5 -= wj * (D2.x * jx + D2.y * jy + D2.z * jz);
                     if (wj != T(0)) acc += (double)(jx * jx + jy * jy + jz * jz);              // sum_u p_u (J^T J p)_u of this edge = |J p|^2 (o.t:2117-2122)
                 }
                 {   // its reverse (u -> v): only its J p reaches this vertex's Offset row
-                    const ArapCoef<T> cu = arap_coef(nb.sa, nb.ca, nb.sb, nb.cb, nb.sg, nb.cg);
+                    const ArapCoef<T> cu = arap_coef(nt0[j].a, nt0[j].b, nt0[j].c, nt0[j].d, nt1[j].a, nt1[j].b);
                     V3<T> E0, E1, E2;
                     arap_cols(cu, un, E0, E1, E2);
-                    const T jx = w * (nb.px - pv.x) - w * (E0.x * nb.ax + E1.x * nb.ay + E2.x * nb.az);
-                    const T jy = w * (nb.py - pv.y) - w * (E0.y * nb.ax + E1.y * nb.ay + E2.y * nb.az);
-                    const T jz = w * (nb.pz - pv.z) - w * (E0.z * nb.ax + E1.z * nb.ay + E2.z * nb.az);
+                    const T jx = w * (np.x - pv.x) - w * (E0.x * npa.x + E1.x * npa.y + E2.x * npa.z);
+                    const T jy = w * (np.y - pv.y) - w * (E0.y * npa.x + E1.y * npa.y + E2.y * npa.z);
+                    const T jz = w * (np.z - pv.z) - w * (E0.z * npa.x + E1.z * npa.y + E2.z * npa.z);
                     s0 -= wj * jx; s1 -= wj * jy; s2 -= wj * jz;
                 }
             }
         }
-#pragma unroll
-        for (int m = 1; m < LANES; m <<= 1) {
-            s0 += __shfl_xor(s0, m, kWave); s1 += __shfl_xor(s1, m, kWave); s2 += __shfl_xor(s2, m, kWave);
-            s3 += __shfl_xor(s3, m, kWave); s4 += __shfl_xor(s4, m, kWave); s5 += __shfl_xor(s5, m, kWave);
-        }
-        if (ok && sub == 0) {
+        if (ok) {
             // per-vertex ("centred") part: fitting term and, for LM, CtC p  -- what arap_vertices<3> computes
             const bool valid = A.Constraints[3 * i] >= T(-999999.9);
             const T wf = valid ? A.w_fit : T(0);
             V3<T> q{wf * wf * pv.x, wf * wf * pv.y, wf * wf * pv.z}, qa{0, 0, 0};
-            if (CtC) { const V3<T> cO = ld3(CtC, i), cA = ld3(CtC + offA, i); q.x += cO.x * pv.x; q.y += cO.y * pv.y; q.z += cO.z * pv.z; qa.x = cA.x * pav.x; qa.y = cA.y * pav.y; qa.z = cA.z * pav.z; }
+            if (CtC) { const V3<T> cO = ldv3(CtC, i), cA = ldv3(CtC + offA, i); q.x += cO.x * pv.x; q.y += cO.y * pv.y; q.z += cO.z * pv.z; qa.x = cA.x * pav.x; qa.y = cA.y * pav.y; qa.z = cA.z * pav.z; }
             acc += (double)(dot3(pv, q) + dot3(pav, qa));
             const V3<T> oO{q.x + s0, q.y + s1, q.z + s2}, oA{qa.x + s3, qa.y + s4, qa.z + s5};
-            out[3 * i] = oO.x; out[3 * i + 1] = oO.y; out[3 * i + 2] = oO.z;
-            out[offA + 3 * i] = oA.x; out[offA + 3 * i + 1] = oA.y; out[offA + 3 * i + 2] = oA.z;
+            stv3(out, i, oO); stv3(out + offA, i, oA);
             if (rv) {
                 accNum += arap_dprod3(mO.x, rO.x, rO.x) + arap_dprod3(mO.y, rO.y, rO.y) + arap_dprod3(mO.z, rO.z, rO.z) + arap_dprod3(mA.x, rA.x, rA.x) + arap_dprod3(mA.y, rA.y, rA.y) + arap_dprod3(mA.z, rA.z, rA.z);
                 acc2 += arap_dprod3(mO.x, rO.x, oO.x) + arap_dprod3(mO.y, rO.y, oO.y) + arap_dprod3(mO.z, rO.z, oO.z) + arap_dprod3(mA.x, rA.x, oA.x) + arap_dprod3(mA.y, rA.y, oA.y) + arap_dprod3(mA.z, rA.z, oA.z);
@@ -586,20 +606,18 @@ __global__ __launch_bounds__(kBlock) void arap_applySym(ArapArgs<T> A, const int
     if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
 }
 
-// PCGStep2 + PCGStep3 in one flat pass for the record path: a workgroup takes 256 consecutive vertices = 3 * 256 / NP 16-byte packs of the Offset half and as many of the Angle
-// half (N a multiple of 4: both halves start on a pack boundary), updates delta, r, p pack by pack, and passes the new p through LDS to the thread that owns the vertex's record.
+// PCGStep2 + PCGStep3 in one flat pass for the plane path, one thread per vertex: 12-byte (24-byte) loads of the vertex's Offset and Angle parts of delta, p, r, A p, M, the
+// updates, and the vertex's dynamic planes in two coalesced 16-byte stores (rounds 3-5 moved 16-byte packs and passed the new p through LDS to a thread that wrote 24 B
+// of a 64 B record with six dword stores -- 41 % of the launch stalled on issue).
 // LM (Levenberg-Marquardt, round 6): the same pass with the reference's LM extras -- delta goes to deltaOut (the solver enqueues the next launch before it has read Q:
 // an early-out must still find the old delta), Q_{k-1} = 1/2 sum delta . (r + b) (solver.t:483-485) leaves as per-workgroup partials (tagged words if qTag != 0), and
 // after a split residual reset (L.afterReset: delta and r are already the new ones, solver.t:1077-1083) the pass only forms p = M r + beta p with beta = sum bNum / sum bDen.
 struct ArapLmStep { const void* b; void* deltaOut; double* q; unsigned qTag; int afterReset; const double* bNumP; int nbNum; const double* bDenP; int nbDen; };
 template <class T, bool LM>
-__global__ __launch_bounds__(kBlock) void arap_flatStepRec(T* __restrict__ delta, const T* __restrict__ pOld, const T* __restrict__ rOld, const T* __restrict__ Ap, const T* __restrict__ M,
-                                                           T* __restrict__ rNew, T* __restrict__ pNew, ArapRec<T>* __restrict__ rec, long N, const double* aNumP, int nNum, const double* aDenP, int nDen,
-                                                           const double* s2P, int n2, const double* s3P, int n3, ArapLmStep L) {
+__global__ __launch_bounds__(kBlock) void arap_flatStepPlanes(ArapPlanes<T> P, long N, T* __restrict__ delta, const T* __restrict__ pOld, const T* __restrict__ rOld, const T* __restrict__ Ap,
+                                                              const T* __restrict__ M, T* __restrict__ rNew, T* __restrict__ pNew,
+                                                              const double* aNumP, int nNum, const double* aDenP, int nDen, const double* s2P, int n2, const double* s3P, int n3, ArapLmStep L, int xcd, int backward) {
     __shared__ double scratch[4 * (kBlock / kWave + 1)];
-    constexpr int NP = 16 / sizeof(T), PACKS = 3 * kBlock / NP;
-    typedef T VP __attribute__((ext_vector_type(NP)));
-    __shared__ T tile[2][3 * kBlock];
     T alpha, beta;
     const bool restart = LM && L.afterReset;
     if (restart) {
@@ -617,48 +635,34 @@ __global__ __launch_bounds__(kBlock) void arap_flatStepRec(T* __restrict__ delta
     }
     const T* const bV = (const T*)L.b; T* const dOut = LM ? (T*)L.deltaOut : delta;
     double accQ = 0;
-    const long offA = 3 * N, nTiles = (N + kBlock - 1) / kBlock, packsPerHalf = 3 * N / NP;
-    for (long t = blockIdx.x; t < nTiles; t += gridDim.x) {
-        __syncthreads();
-        for (int q = threadIdx.x; q < 2 * PACKS; q += kBlock) {
-            const int half = q >= PACKS, j = half ? q - PACKS : q;
-            const long pk = t * PACKS + j;
-            if (pk < packsPerHalf) {
-                const long base = (half ? offA : 0) + pk * NP;
-                const VP p = *(const VP*)(pOld + base), r = *(const VP*)(rOld + base), m = *(const VP*)(M + base);
-                VP rn, pn;
-                if (restart) {
+    const long offA = 3 * N;
+    const XcdWalk walk((N + kBlock - 1) / kBlock, xcd);
+    for (long t = 0; t < walk.count; ++t) {      // the gather's eighths, walked backward (XcdWalk)
+        const long i = walk.group(t, backward != 0) * kBlock + threadIdx.x;
+        if (i >= N) continue;
+        V3<T> pn[2];
 #pragma unroll
-                    for (int k = 0; k < NP; ++k) { rn[k] = r[k]; pn[k] = m[k] * r[k] + beta * p[k]; tile[half][j * NP + k] = pn[k]; }
-                } else {
-                    VP d = *(const VP*)(delta + base);
-                    const VP a = *(const VP*)(Ap + base);
-                    VP bb;
-                    if (LM) bb = *(const VP*)(bV + base);
-#pragma unroll
-                    for (int k = 0; k < NP; ++k) {
-                        d[k] = d[k] + alpha * p[k];
-                        rn[k] = r[k] - alpha * a[k];
-                        const T z = m[k] * rn[k];
-                        pn[k] = z + beta * p[k];
-                        tile[half][j * NP + k] = pn[k];
-                        if (LM) accQ += (double)(T(0.5) * (d[k] * (rn[k] + bb[k])));
-                    }
-                    *(VP*)(dOut + base) = d;
-                }
-                *(VP*)(rNew + base) = rn; *(VP*)(pNew + base) = pn;
+        for (int h = 0; h < 2; ++h) {
+            const long o = h ? offA : 0;
+            const V3<T> p = ldv3(pOld + o, i), r = ldv3(rOld + o, i), m = ldv3(M + o, i);
+            V3<T> rn;
+            if (restart) {
+                rn = r;
+                pn[h] = V3<T>{m.x * r.x + beta * p.x, m.y * r.y + beta * p.y, m.z * r.z + beta * p.z};
+            } else {
+                const V3<T> d0 = ldv3(delta + o, i), a = ldv3(Ap + o, i);
+                const V3<T> d{d0.x + alpha * p.x, d0.y + alpha * p.y, d0.z + alpha * p.z};
+                rn = V3<T>{r.x - alpha * a.x, r.y - alpha * a.y, r.z - alpha * a.z};
+                const V3<T> z{m.x * rn.x, m.y * rn.y, m.z * rn.z};
+                pn[h] = V3<T>{z.x + beta * p.x, z.y + beta * p.y, z.z + beta * p.z};
+                if (LM) { const V3<T> bb = ldv3(bV + o, i); accQ += (double)(T(0.5) * (d.x * (rn.x + bb.x))) + (double)(T(0.5) * (d.y * (rn.y + bb.y))) + (double)(T(0.5) * (d.z * (rn.z + bb.z))); }
+                stv3(dOut + o, i, d);
             }
+            stv3(rNew + o, i, rn); stv3(pNew + o, i, pn[h]);
         }
-        __syncthreads();
-        const long i = t * kBlock + threadIdx.x;
-        if (i < N) {
-            ArapRec<T>& rr = rec[i];
-            rr.px = tile[0][3 * threadIdx.x]; rr.py = tile[0][3 * threadIdx.x + 1]; rr.pz = tile[0][3 * threadIdx.x + 2];
-            rr.ax = tile[1][3 * threadIdx.x]; rr.ay = tile[1][3 * threadIdx.x + 1]; rr.az = tile[1][3 * threadIdx.x + 2];
-        }
+        P.D0[i] = Q4<T>{pn[0].x, pn[0].y, pn[0].z, pn[1].x}; P.D1[i] = Q4<T>{pn[1].y, pn[1].z, T(0), T(0)};
     }
     if (LM && L.q && !restart) {
-        __syncthreads();
         const double tq = blockReduceSum(accQ, scratch);
         if (threadIdx.x == 0) { if (L.qTag) storeTaggedPartial(L.q, blockIdx.x, tq, L.qTag); else L.q[blockIdx.x] = tq; }
     }
@@ -667,7 +671,7 @@ __global__ __launch_bounds__(kBlock) void arap_flatStepRec(T* __restrict__ delta
 // (The persistent ARAP iteration of round 5 -- built, parity-green, break-even at 56.7 us -- is kept as a record under tools/round5/arap_onchip_experiment/ with its numbers in
 // profiles/r05_arap_onchip_experiment.md; it is no longer wired into the library.  Round 6 measured what bounds the two kernels of an iteration with SQ / TCC / TCP counters and
 // tried the record layout {p, M = sum_k p_a[k] dR/da_k, U} with id-only slots -- 25 % fewer VALU instructions and 21 % fewer HBM reads in the gather, same time; 38 MB more in the
-// flat pass, 8 us slower: profiles/r06_arap_counters.md, tools/round6/arap_v2_pMU_records.patch.)
+// flat pass, 8 us slower: profiles/r06_arap_counters.md, tools/round6/arap_v2_pMU_records.patch -- before the plane layout above.)
 
 // ---- the same for J^T F and diag(J^T J) (once per Gauss-Newton iteration) ---------------------------------------------------------
 // Edge pass: rotation-derivative columns into the D planes (as arap_edges<2>) and one 9-scalar record per half-edge,
@@ -737,14 +741,14 @@ struct ArapOps : EnergyOps<T> {
     const int *csrV0 = nullptr, *csrV1 = nullptr; int csrNE = -1; unsigned long long csrSum = 0; bool csrValid = false;
     bool useGather = true;   // (development builds: OPT_AMD_ARAP_GATHER=0 scatters with wave-aggregated atomics instead)
     T* D9 = nullptr; long d9Capacity = 0; int* nbr = nullptr;
-    // symmetric-graph path (arap_applySym): out-list slots {U_v - U_u, u}, one record per vertex; OPT_AMD_ARAP_SYM=0 keeps arap_applyFused
+    // symmetric-graph path (arap_applyEll): 16-byte planes D0, D1 (dynamic), T0, T1, U0 (per Gauss-Newton step) and the out-lists in ELL order; OPT_AMD_ARAP_SYM=0 keeps arap_applyFused
     bool useSym = true, symGraph = false;
-    ArapSlot<T>* slots = nullptr; ArapRec<T>* rec = nullptr; int* dNotSym = nullptr;
+    ArapPlanes<T> planes{}; void* planeMem = nullptr; int* ellMem = nullptr; int* dNotSym = nullptr;
     bool symPath() const { return useGather && useSym && symGraph; }
     ~ArapOps() override {
         if (D9) (void)hipFree(D9);
         if (nbr) (void)hipFree(nbr);
-        for (void* q : {(void*)slots, (void*)rec, (void*)dNotSym}) if (q) (void)hipFree(q);
+        for (void* q : {planeMem, (void*)ellMem, (void*)dNotSym}) if (q) (void)hipFree(q);
         for (void* q : {(void*)A.D, (void*)outOff, (void*)outIdx, (void*)inOff, (void*)inIdx, (void*)cursors, (void*)Jp, scanTemp, (void*)dChecksum}) if (q) (void)hipFree(q);
     }
     void ensureCsr(LaunchCtx& ctx) {
@@ -786,12 +790,23 @@ struct ArapOps : EnergyOps<T> {
             int bad = 1;
             HIP_CHECK(hipMemcpyAsync(&bad, dNotSym, 4, hipMemcpyDeviceToHost, st)); HIP_CHECK(hipStreamSynchronize(st));
             symGraph = bad == 0;
-            for (void* q : {(void*)slots, (void*)rec}) if (q) HIP_CHECK(hipFree(q));
-            slots = nullptr; rec = nullptr;
-            if (symGraph) {
-                HIP_CHECK(hipMalloc((void**)&slots, (size_t)std::max(1, A.nE) * sizeof(ArapSlot<T>)));
-                HIP_CHECK(hipMalloc((void**)&rec, (size_t)std::max<long>(1, A.N) * sizeof(ArapRec<T>)));
-                HIP_CHECK(hipMemsetAsync(rec, 0, (size_t)std::max<long>(1, A.N) * sizeof(ArapRec<T>), st));
+            for (void* q : {planeMem, (void*)ellMem}) if (q) HIP_CHECK(hipFree(q));
+            planeMem = nullptr; ellMem = nullptr; planes = ArapPlanes<T>{};
+            if (symGraph) {      // the longest out-list decides the ELL width; a vertex beyond kEllMax sends the graph to the edge-list gather
+                HIP_CHECK(hipMemsetAsync(dNotSym, 0, 4, st));
+                csr_maxDegree<<<vgrid(), kBlock, 0, st>>>(A.N, outOff, dNotSym);
+                int K = 0;
+                HIP_CHECK(hipMemcpyAsync(&K, dNotSym, 4, hipMemcpyDeviceToHost, st)); HIP_CHECK(hipStreamSynchronize(st));
+                if (K > kEllMax) symGraph = false;
+                else {
+                    K = std::max(K, 1);
+                    const size_t n = (size_t)std::max<long>(1, A.N);
+                    HIP_CHECK(hipMalloc(&planeMem, 5 * n * sizeof(Q4<T>))); HIP_CHECK(hipMemsetAsync(planeMem, 0, 5 * n * sizeof(Q4<T>), st));
+                    HIP_CHECK(hipMalloc((void**)&ellMem, ((size_t)K + 1) * n * sizeof(int)));
+                    Q4<T>* q = (Q4<T>*)planeMem;
+                    planes = ArapPlanes<T>{q, q + n, q + 2 * n, q + 3 * n, q + 4 * n, ellMem, ellMem + (size_t)K * n, K};
+                    arap_buildEll<<<vgrid(), kBlock, 0, st>>>(A.N, outOff, nbr, K, ellMem, ellMem + (size_t)K * n);
+                }
             }
         }
         csrV0 = A.v0; csrV1 = A.v1; csrNE = A.nE; csrSum = sum; csrValid = true;
@@ -806,6 +821,7 @@ struct ArapOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_ARAP_SYM")) useSym = atoi(e) != 0;
         if (const char* e = getenv("OPT_AMD_ARAP_SYM_XCD")) symXcd = atoi(e);
         if (const char* e = getenv("OPT_AMD_ARAP_VGRID")) symGridCap = atoi(e);
+        if (const char* e = getenv("OPT_AMD_ARAP_WALK")) flatBackward = atoi(e);
     }
     void bind(void** p, LaunchCtx& ctx) override {
         A.w_fit = (T) * (const float*)p[0]; A.w_reg = (T) * (const float*)p[1];
@@ -817,11 +833,7 @@ struct ArapOps : EnergyOps<T> {
             HIP_CHECK(hipMalloc((void**)&A.D, (size_t)9 * dCapacity * sizeof(T)));
             HIP_CHECK(hipMemset(A.D, 0, (size_t)9 * dCapacity * sizeof(T)));
         }
-        if (useGather) ensureCsr(ctx);
-        if (symPath()) {      // UrShape is an input of the solve: the slots' U_v - U_u are rebuilt whenever the parameters are (re)bound
-            ScopedKernel k(ctx, "buildEdgeSlots");
-            arap_buildSlots<T><<<edgeGrid(A.nE, cus), kBlock, 0, ctx.stream>>>(A, outIdx, slots);
-        }
+        if (useGather) ensureCsr(ctx);      // (UrShape is an input of the solve: arap_buildStatic reads it afresh in every Gauss-Newton step)
     }
     T* unknownPtr(int img) const override { return const_cast<T*>(img == 0 ? A.Offset : A.Angle); }
     int vgrid() const { static const int cap = getenv("OPT_AMD_ARAP_VGRID") ? atoi(getenv("OPT_AMD_ARAP_VGRID")) : kMaxPartials / 2; return (int)std::max<long>(1, std::min<long>((A.N + kBlock - 1) / kBlock, cap)); }
@@ -837,9 +849,9 @@ struct ArapOps : EnergyOps<T> {
             GraphCsr G{outOff, outIdx, inOff, inIdx};
             { ScopedKernel k(ctx, "PCGInit1_Graph"); arap_edgeJTF<T><<<edgeGrid(A.nE, cus), kBlock, 0, ctx.stream>>>(A, Jp); }
             { ScopedKernel k(ctx, "PCGInit1_Gather"); arap_vertexGatherJTF<T><<<vgrid(), kBlock, 0, ctx.stream>>>(A, G, Jp, r, diag); }
-            if (symPath()) {    // the sines / cosines of this Gauss-Newton iteration's angles, one record per vertex, for arap_applySym
+            if (symPath()) {    // the sines / cosines of this Gauss-Newton iteration's angles and the rest positions as planes, for arap_applyEll
                 ScopedKernel k(ctx, "vertexRecords");
-                arap_buildRecTrig<T><<<vgrid(), kBlock, 0, ctx.stream>>>(A, rec);
+                arap_buildStatic<T><<<vgrid(), kBlock, 0, ctx.stream>>>(A, planes);
             }
             if (!symPath()) {     // the derivative columns of this Gauss-Newton iteration as 36-byte rows for arap_applyFused
                 if (A.nE > d9Capacity) { if (D9) HIP_CHECK(hipFree(D9)); d9Capacity = A.nE; HIP_CHECK(hipMalloc((void**)&D9, (size_t)9 * std::max<long>(1, d9Capacity) * sizeof(T))); }
@@ -851,7 +863,7 @@ struct ArapOps : EnergyOps<T> {
     void applyJTJ(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) override {
         const int gv = vgrid(), ge = edgeGrid(A.nE, cus);
         if (symPath()) {
-            { ScopedKernel k(ctx, "packVertexRecords"); arap_packRec<T><<<gv, kBlock, 0, ctx.stream>>>(v, rec, A.N); }
+            { ScopedKernel k(ctx, "packVertexRecords"); arap_packPlanes<T><<<gv, kBlock, 0, ctx.stream>>>(v, planes, A.N); }
             ScopedKernel k(ctx, "PCGStep1");
             launchSym(v, out, CtC, dot, ctx);
             return;
@@ -869,56 +881,62 @@ struct ArapOps : EnergyOps<T> {
         }
         if (dot) dot->n = gv + ge;
     }
-    int symGrid() const {               // all workgroups resident at once (4 per CU): a second, partial round of workgroups costs more than the longer grid-stride loops
+    int symOcc = 0;
+    int symGrid() {                     // one lane per vertex; all workgroups resident at once (what the gather's registers allow per CU: a second, partial round of workgroups costs
+                                        // more than the longer walks -- 768 workgroups 26.5 us, 1952 31.5 us at 500 k vertices); a multiple of 8 for the XCD-aware order
+        if (symOcc == 0) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&symOcc, arap_applyEll<T, ARAP_ELL_BATCH>, kBlock, 0) != hipSuccess) { (void)hipGetLastError(); symOcc = 2; }
+            symOcc = std::max(1, std::min(symOcc, 8));
+        }
         const int cap = symGridCap;
-        const long groups = (A.N + kBlock / ARAP_SYM_LANES - 1) / (kBlock / ARAP_SYM_LANES);
-        return (int)std::max<long>(1, std::min<long>(groups, cap > 0 ? cap : std::min<long>(4L * cus, kMaxPartials / 2)));
+        const long groups = (A.N + kBlock - 1) / kBlock;
+        long g = std::max<long>(1, std::min<long>(groups, cap > 0 ? cap : std::min<long>((long)symOcc * cus, kMaxPartials / 2)));
+        if (g >= 8) g -= g % 8;
+        return (int)g;
     }
     int symGridCap = 0;                 // OPT_AMD_ARAP_VGRID (read per plan)
-    int symXcd = 1;                     // OPT_AMD_ARAP_SYM_XCD=0: consecutive vertex groups on consecutive workgroups (A/B switch, see arap_applySym)
-    // slots a lane requests together: 4 for the plain J^T J p (a mesh vertex has ~6 neighbours, 3 per lane at two lanes per vertex: measured 31.0 / 34.9 / 32.6 / 29.3 us for 1 .. 4),
-    // 1 with the expansion sums of the two-kernel iteration in the same kernel (more live registers: 30.5 against 34.7 us)
+    int flatBackward = 1;               // OPT_AMD_ARAP_WALK=0: the flat pass walks its eighths forward like the gather (A/B switch, see XcdWalk)
+    int symXcd = 1;                     // OPT_AMD_ARAP_SYM_XCD=0: consecutive vertex groups on consecutive workgroups (A/B switch, see arap_applyEll)
     int launchSym(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx, const ArapIterSums& S = ArapIterSums{nullptr, nullptr, nullptr, nullptr, nullptr}) {
         const int g = symGrid();
         double* part = dot ? dot->partials : nullptr;
-        if (S.r) arap_applySym<T, ARAP_SYM_LANES, 1><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part, symXcd && g % 8 == 0, S);
-        else arap_applySym<T, ARAP_SYM_LANES, 4><<<g, kBlock, 0, ctx.stream>>>(A, outOff, slots, rec, v, out, CtC, part, symXcd && g % 8 == 0, S);
+        arap_applyEll<T, ARAP_ELL_BATCH><<<g, kBlock, 0, ctx.stream>>>(A, planes, v, out, CtC, part, symXcd && g % 8 == 0, S);
         if (dot) dot->n = g;
         return g;
     }
     // PCGStep3 of the previous iteration + PCGStep1 (symmetric-graph path): the flat pass that forms p = z + beta p also writes it into the vertex records the gather reads
     bool applyJTJFused(const T* pOld, const T* z, T* pNew, T* out, const T* CtC, Reduction* dot, const Reduction& bNum, const double* aNumOld, double* aNumNext, LaunchCtx& ctx) override {
         if (!symPath()) return false;
-        { ScopedKernel k(ctx, "PCGStep3"); arap_step3Rec<T><<<vgrid(), kBlock, 0, ctx.stream>>>(z, pOld, pNew, rec, A.N, bNum.partials, bNum.n, aNumOld, aNumNext); }
+        { ScopedKernel k(ctx, "PCGStep3"); arap_step3Planes<T><<<vgrid(), kBlock, 0, ctx.stream>>>(z, pOld, pNew, planes, A.N, bNum.partials, bNum.n, aNumOld, aNumNext); }
         ScopedKernel k(ctx, "PCGStep1");
         launchSym(pNew, out, CtC, dot, ctx);
         return true;
     }
     // ---- two kernels per Gauss-Newton PCG iteration instead of three on the symmetric-graph path: [PCGStep2 + PCGStep3 of iteration k-1 as one flat pass that also rewrites the
-    // records: arap_flatStepRec] + [PCGStep1 of iteration k with the sums of the expanded beta numerator: arap_applySym].  (Development builds: OPT_AMD_ARAP_ITER=0 keeps the reference's three
+    // planes: arap_flatStepPlanes] + [PCGStep1 of iteration k with the sums of the expanded beta numerator: arap_applyEll].  (Development builds: OPT_AMD_ARAP_ITER=0 keeps the reference's three
     // kernels per iteration.)  On the edge-list gather of asymmetric graphs the same fusion lost in three formulations (profiles/NOTES.md) and is not offered.
     int fusedIterEnv = -1;
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
         // Gauss-Newton and (round 6) Levenberg-Marquardt: a.CtC adds CtC p to the gather, the flat pass carries b, Q and the restart after a residual reset (ArapLmStep)
         const bool lmv = a.CtC != nullptr;
-        if (symPath() && fusedIterEnv != 0 && a.pre && !this->slab.active && A.N % 4 == 0 && (!lmv || (a.b && a.q)) &&
-            ((uintptr_t)a.delta | (uintptr_t)a.pOld | (uintptr_t)a.rOld | (uintptr_t)a.ApOld | (uintptr_t)a.pre | (uintptr_t)a.rNew | (uintptr_t)a.pNew | (uintptr_t)a.deltaOut | (uintptr_t)a.b) % 16 == 0) {
+        if (symPath() && fusedIterEnv != 0 && a.pre && !this->slab.active && (!lmv || (a.b && a.q))) {
             const long n = 6 * A.N, nPad = (n + 3) / 4 * 4;
-            const int g = (int)std::max<long>(1, std::min<long>((A.N + kBlock - 1) / kBlock, (long)cus * 8));
+            const int g = symGrid();      // the gather's grid and vertex -> XCD mapping (XcdWalk)
+            const int fx = symXcd && g % 8 == 0;
             if (a.first) {      // the solver adopts rNew / pNew after every launch: the start state moves there unchanged
                 HIP_CHECK(hipMemcpyAsync(a.rNew, a.rOld, nPad * sizeof(T), hipMemcpyDeviceToDevice, ctx.stream));
                 HIP_CHECK(hipMemcpyAsync(a.pNew, a.pOld, nPad * sizeof(T), hipMemcpyDeviceToDevice, ctx.stream));
-                ScopedKernel k(ctx, "packVertexRecords"); arap_packRec<T><<<vgrid(), kBlock, 0, ctx.stream>>>(a.pNew, rec, A.N);
+                ScopedKernel k(ctx, "packVertexRecords"); arap_packPlanes<T><<<vgrid(), kBlock, 0, ctx.stream>>>(a.pNew, planes, A.N);
             } else if (lmv) {
                 ScopedKernel k(ctx, "PCGStep2+PCGStep3");
                 const ArapLmStep L{a.b, a.deltaOut ? a.deltaOut : a.delta, a.q->partials, a.qTag, a.afterReset, a.betaNum.partials, a.betaNum.n, a.betaDen.partials, a.betaDen.n};
-                arap_flatStepRec<T, true><<<g, kBlock, 0, ctx.stream>>>(a.delta, a.pOld, a.rOld, a.ApOld, a.pre, a.rNew, a.pNew, rec, A.N, a.aNumPrev.partials, a.aNumPrev.n, a.aDenPrev.partials, a.aDenPrev.n,
-                                                                       a.s2Prev.partials, a.s2Prev.n, a.s3Prev.partials, a.s3Prev.n, L);
+                arap_flatStepPlanes<T, true><<<g, kBlock, 0, ctx.stream>>>(planes, A.N, a.delta, a.pOld, a.rOld, a.ApOld, a.pre, a.rNew, a.pNew, a.aNumPrev.partials, a.aNumPrev.n, a.aDenPrev.partials, a.aDenPrev.n,
+                                                                       a.s2Prev.partials, a.s2Prev.n, a.s3Prev.partials, a.s3Prev.n, L, fx, flatBackward);
                 if (!a.afterReset) a.q->n = g;
             } else {
                 ScopedKernel k(ctx, "PCGStep2+PCGStep3");
-                arap_flatStepRec<T, false><<<g, kBlock, 0, ctx.stream>>>(a.delta, a.pOld, a.rOld, a.ApOld, a.pre, a.rNew, a.pNew, rec, A.N, a.aNumPrev.partials, a.aNumPrev.n, a.aDenPrev.partials, a.aDenPrev.n,
-                                                                        a.s2Prev.partials, a.s2Prev.n, a.s3Prev.partials, a.s3Prev.n, ArapLmStep{});
+                arap_flatStepPlanes<T, false><<<g, kBlock, 0, ctx.stream>>>(planes, A.N, a.delta, a.pOld, a.rOld, a.ApOld, a.pre, a.rNew, a.pNew, a.aNumPrev.partials, a.aNumPrev.n, a.aDenPrev.partials, a.aDenPrev.n,
+                                                                        a.s2Prev.partials, a.s2Prev.n, a.s3Prev.partials, a.s3Prev.n, ArapLmStep{}, fx, flatBackward);
             }
             ScopedKernel k(ctx, "PCGStep1");
             const int gs = launchSym(a.pNew, a.ApNew, a.CtC, a.aDen, ctx, ArapIterSums{a.rNew, a.pre, a.aNum->partials, a.s2->partials, a.s3->partials});
@@ -937,7 +955,7 @@ struct ArapOps : EnergyOps<T> {
 
 // volumetric_mesh_deformation (examples/volumetric_mesh_deformation/volumetric_mesh_deformation.t:1-20) on ARAP's kernels: every in-bounds lattice neighbour n of voxel c, in the
 // .t's stencil order (+x, -x, +y, -y, +z, -z), is the half-edge (c -> n) -- Select(InBounds(0,0,0), Select(InBounds(n), edge, 0), 0) keeps exactly the edges between existing voxels --
-// and the parameter slots are those of the volumetric .t re-ordered into ARAP's.  The lattice graph is symmetric, so J^T J p runs on the record gather (arap_applySym).
+// and the parameter slots are those of the volumetric .t re-ordered into ARAP's.  The lattice graph is symmetric (six neighbours), so J^T J p runs on the plane gather (arap_applyEll).
 template <class T>
 struct VolumetricArapOps : ArapOps<T> {
     int* dv0 = nullptr; int* dv1 = nullptr; int nEdges = 0;
