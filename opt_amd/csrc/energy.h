@@ -77,7 +77,9 @@ struct LmInitArgs {
 
 // Levenberg-Marquardt controls of EnergyOps::pcgSolveOnChip: the scalars of PCGFinalizeDiagonal (solver.t:631-664), q_tolerance and residual_reset_period (:1077-1102).
 template <class T>
-struct OnChipLm { T radius, minLm, maxLm, qTolerance; int resetPeriod; const T* CtC = nullptr; };      // CtC: the clamped diagonal PCGFinalizeDiagonal has just written (energies whose kernel does not rebuild it from a table)
+struct OnChipLm { T radius, minLm, maxLm, qTolerance; int resetPeriod; const T* CtC = nullptr;
+                  double* breakInfo = nullptr; };      // pinned, 2 doubles: workgroup 0 leaves {iteration of the q early-out + 1, zeta} there (0: the loop ran to its end) -- the solver prints the
+                                                       // reference's "breaking at iteration" message from it when someone listens (verbosity > 0)      // CtC: the clamped diagonal PCGFinalizeDiagonal has just written (energies whose kernel does not rebuild it from a table)
 
 // Everything the solver needs from an energy.  T = opt_float (float or double).
 // Contract shared by all implementations:
@@ -146,6 +148,10 @@ struct EnergyOps {
     virtual bool onChipWithoutPreconditioner() const { return false; }
     // Gauss-Newton: did pcgSolveOnChip end with PCGLinearUpdate (X += delta) itself?  false: the solver applies delta as after any other linear solve
     virtual bool onChipAppliedUpdate() const { return true; }
+    // ... and if it did not: PCGLinearUpdate X += delta applied by the kernel set itself, GUARDED by the launch's failure word (a workgroup that gave up in the last wait only
+    // raises the flag while the others have already written their delta: an unguarded update would add a partial delta that Gauss-Newton -- no saved unknowns -- cannot take
+    // back).  false: no such kernel, the solver applies delta itself (Levenberg-Marquardt restores the saved unknowns on a failure).
+    virtual bool onChipGuardedUpdate(const T* /*delta*/, LaunchCtx&) { return false; }
     // Row slabs: would pcgSolveOnChip run for this rank's slab right now (kernel variant fits, unit lattice, the communicator offers onChipPlan ...)?  The solver
     // makes the decision collective (all ranks or none) before anyone launches.  onChipPlan / onChipCtx: the communicator's entry (OptAmd_SlabCommExt), set by the solver.
     virtual bool slabOnChipAvailable(int /*lIterations*/) { return false; }
@@ -161,6 +167,8 @@ struct EnergyOps {
     // After the stream has drained: did a wait inside the last on-chip solve time out (another tenant on the GPU kept its workgroups from being co-resident)?
     // Then the unknowns were left untouched, the kernel set has switched the path off for this plan, and the caller redoes the linear solve.
     virtual bool onChipFailed() { return false; }
+    // the same question without consuming the answer (the solver prints an on-chip LM solve's "breaking at iteration" message only for a launch that did not fail)
+    virtual bool onChipFailedPeek() { return false; }
     // The solver's back-off after such a failure is over: clear the failure state (device word, pinned word, the path's own off switch) so that the next
     // pcgSolveOnChip launches again.  Stream-ordered.
     virtual void onChipRearm(LaunchCtx&) {}

@@ -240,6 +240,7 @@ struct OpticalFlowOps : StencilOps<T, OpticalFlowE<T>> {
         return oc.solve(FlowMarchOp<T>{this->e.w_fit, this->e.w_reg}, this->e.W, this->e.H, nullptr, coef, r0, p0, delta, const_cast<T*>(this->e.X[0]), L, this->cus, ctx, lm);
     }
     bool onChipFailed() override { return oc.failedNow(); }
+    bool onChipFailedPeek() override { return oc.failedPeek(); }
     void onChipRearm(LaunchCtx& ctx) override { oc.rearm(ctx); }
     std::string describe(int L, bool lmv) override { return oc.template describe<FlowMarchOp<T>>(this->e.W, this->e.H, this->cus, useMarch ? L : 0, lmv, "march_pcgIter"); }
 };
@@ -305,7 +306,19 @@ struct IntrinsicOps : StencilOps<T, IntrinsicE<T>> {
         return oc.solve(Op{this->e.w_fit, this->e.w_regA, this->e.w_regS}, this->e.W, this->e.H, nullptr, coef, r0, p0, delta, (T*)nullptr, L, this->cus, ctx, lm);
     }
     bool onChipAppliedUpdate() const override { return false; }
+    bool onChipGuardedUpdate(const T* delta, LaunchCtx& ctx) override {      // X += delta per unknown image, unless the launch raised its failure word
+        if (!oc.bad || !oc.launched) return false;
+        ScopedKernel k(ctx, "PCGLinearUpdate");
+        for (size_t i = 0; i < this->unknowns.size(); ++i) {
+            const auto& u = this->unknowns[i];
+            const long cnt = u.elems * u.channels;
+            const int grid = (int)std::max<long>(1, std::min<long>((cnt + kBlock - 1) / kBlock, 4096));
+            march_applyDelta<T><<<grid, kBlock, 0, ctx.stream>>>(this->unknownPtr((int)i), delta + u.offset, cnt, oc.bad, oc.hostErr);
+        }
+        return true;
+    }
     bool onChipFailed() override { return oc.failedNow(); }
+    bool onChipFailedPeek() override { return oc.failedPeek(); }
     void onChipRearm(LaunchCtx& ctx) override { oc.rearm(ctx); }
     std::string describe(int L, bool lmv) override { return oc.template describe<IntrinsicMarchOp<T>>(this->e.W, this->e.H, this->cus, useMarch ? L : 0, lmv, "march_pcgIter"); }
 };

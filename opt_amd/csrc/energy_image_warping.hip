@@ -461,7 +461,7 @@ struct ImageWarpingOps : EnergyOps<T> {
             links.edgeParityStride = Lk.edgeParityStride;
         }
         const OcTimeouts tmo = ocTimeouts(ocTimeoutTicks, L, slabMode);
-        OnchipArgs<T> K{A.W, A.H, tX, tY, G, A.yBegin, A.yEnd, links, r0, p0, A.Angle, A.flags, delta, A.w_fit, A.w_reg, L, ocSeq, G <= ocFlatMax ? 1 : 0, ocS, traceDev,
+        OnchipArgs<T> K{A.W, A.H, tX, tY, G, A.yBegin, A.yEnd, links, r0, p0, A.Angle, A.flags, delta, A.w_fit, A.w_reg, L, ocSeq, G <= ocFlatMax ? 1 : 0, ocS, lmArgs ? lmArgs->breakInfo : traceDev,
                         tmo.later, tmo.first, ocProf, ocFailAt, T(0), T(0), T(0), T(0), 1};
         if (lmArgs) { K.lmRadius = lmArgs->radius; K.lmMin = lmArgs->minLm; K.lmMax = lmArgs->maxLm; K.qTolerance = lmArgs->qTolerance; K.resetPeriod = lmArgs->resetPeriod; }
         ocSeq += nTags;
@@ -545,6 +545,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         ocFailed = true;
         return true;
     }
+    bool onChipFailedPeek() override { return ocLaunched && ocS.hostErr && __atomic_load_n(ocS.hostErr, __ATOMIC_ACQUIRE) != 0; }
     void onChipRearm(LaunchCtx& ctx) override {
         if (!ocS.bad) return;
         ocFailed = false; __atomic_store_n(ocS.hostErr, 0, __ATOMIC_RELEASE);

@@ -303,6 +303,7 @@ struct PoissonOps : EnergyOps<T> {
         return oc.solve(PoissonMarchOp<T>{}, A.W, A.H, flags, nullptr, r0, p0, delta, const_cast<T*>(A.X), L, cus, ctx, lm);
     }
     bool onChipFailed() override { return oc.failedNow(); }
+    bool onChipFailedPeek() override { return oc.failedPeek(); }
     void onChipRearm(LaunchCtx& ctx) override { oc.rearm(ctx); }
     std::string describe(int L, bool lmv) override { return oc.template describe<PoissonMarchOp<T>>(A.W, A.H, cus, singleKernel ? L : 0, lmv, "march_pcgIter"); }
     // ---- patch solver: ping-pong between the caller's X and a scratch copy; patchFinish leaves the result in the caller's buffer
@@ -419,6 +420,7 @@ struct LaplacianOps : EnergyOps<float> {
         return oc.solve(LaplacianMarchOp{}, A.W, A.H, nullptr, nullptr, r0, p0, delta, const_cast<float*>(A.X), L, cus, ctx, lm);
     }
     bool onChipFailed() override { return oc.failedNow(); }
+    bool onChipFailedPeek() override { return oc.failedPeek(); }
     void onChipRearm(LaunchCtx& ctx) override { oc.rearm(ctx); }
     std::string describe(int L, bool lmv) override { return oc.describe<LaplacianMarchOp>(A.W, A.H, cus, L, lmv, "march_pcgIter"); }
 };

@@ -813,7 +813,7 @@ struct SfsOps : EnergyOps<T> {
             soSeq = 2;
         }
         const OcTimeouts tmo = ocTimeouts(soTimeoutTicks, L, false);
-        SfsOcArgs<T> K{A, r0, p0, lmArgs ? lmArgs->CtC : nullptr, delta, stripsX, tilesY, G, L, soSeq, soSlots, soBox, soBad, tmo.later, soFailAt, tmo.first, lmArgs ? lmArgs->qTolerance : T(0), lmArgs ? soHostErr : nullptr, soProf};
+        SfsOcArgs<T> K{A, r0, p0, lmArgs ? lmArgs->CtC : nullptr, delta, stripsX, tilesY, G, L, soSeq, soSlots, soBox, soBad, tmo.later, soFailAt, tmo.first, lmArgs ? lmArgs->qTolerance : T(0), lmArgs ? soHostErr : nullptr, soProf, lmArgs ? lmArgs->breakInfo : nullptr};
         soSeq += (unsigned)L;
         {
             ScopedKernel k(ctx, "PCGSolveOnChip");
@@ -855,6 +855,7 @@ struct SfsOps : EnergyOps<T> {
         soFailed = true;
         return true;
     }
+    bool onChipFailedPeek() override { return soLaunched && soHostErr && __atomic_load_n(soHostErr, __ATOMIC_ACQUIRE) != 0; }
     void onChipRearm(LaunchCtx& ctx) override {
         if (!soBad) return;
         soFailed = false; __atomic_store_n(soHostErr, 0, __ATOMIC_RELEASE);

@@ -65,7 +65,7 @@ struct OnchipArgs {
     long long* prof;                    // OC_PROFILE builds: [G][8] ticks per phase, else nullptr
     int failAt;                         // test hook (OPT_AMD_ONCHIP_FAIL_AT): workgroup 0 raises `bad` in this iteration as a timed-out wait would; -1: never
     // Levenberg-Marquardt variants (LMV): the scalars of PCGFinalizeDiagonal (solver.t:631-664), the q early-out and the residual reset period (:1077-1102)
-    T lmRadius, lmMin, lmMax, qTolerance; int resetPeriod;
+    T lmRadius, lmMin, lmMax, qTolerance; int resetPeriod;      // (LMV: `trace` is the pinned {iteration + 1, zeta} word of the q early-out instead, OnChipLm::breakInfo -- the LM variants are never traced)
 };
 
 // one scalar of the halo as tagged words: a float is one word, a double two
@@ -146,7 +146,7 @@ template <class T> struct OcLds {
     // Levenberg-Marquardt: b = r_0 of the lane's pixels ([row][component][thread], like apL), delta of the halo rows and of the halo columns
     static constexpr size_t lm(int rows) { return ap(rows, true) + row() + side(rows); }
     // cos / sin of the lane's LAST csRows rows live in LDS instead of registers where that relieves a variant that spills and the LDS has the room: the LM ROWS = 8 variant
-    // (round 6: 124 -> 68 B of scratch per lane; a row's pair is read back once per stencil pass): [row][cos, sin][thread], behind everything else.  (ROWS = 16 has no room: its
+    // (round 6: 124 -> 68-76 B of scratch per lane; a row's pair is read back once per stencil pass): [row][cos, sin][thread], behind everything else.  (ROWS = 16 has no room: its
     // A p fills 96 of the CU's 160 KB and the rest is taken to within 6 KB; its 40-64 B of scratch stay -- ~13 scratch operations per iteration of ~2000 VALU instructions.)
     static constexpr int csRows(int rows, bool apLds, bool lmv) { return (sizeof(T) == 4 && rows == 8 && lmv && !apLds) ? 8 : 0; }
     static constexpr size_t base(int rows, bool apLds, bool lmv) { return ap(rows, apLds) + rows3(apLds) + 5 * side(rows) + tail() + (lmv ? lm(rows) : 0); }
@@ -598,12 +598,12 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
         OC_MARK(6);      // delta requests
         const double aNumD = TOT[0], aDenD = TOT[1], s2 = TOT[2], s3 = TOT[3];
         if (reinterpret_cast<const int*>(TOT + 6)[0]) { failed = true; break; }      // uniform over the workgroup: a wait timed out somewhere
-        if (K.trace && g == 0 && tid == 0) { K.trace[4 * k] = aNumD; K.trace[4 * k + 1] = aDenD; K.trace[4 * k + 2] = s2; K.trace[4 * k + 3] = s3; }
+        if (!LMV && K.trace && g == 0 && tid == 0) { K.trace[4 * k] = aNumD; K.trace[4 * k + 1] = aDenD; K.trace[4 * k + 2] = s2; K.trace[4 * k + 3] = s3; }
         if constexpr (LMV) {      // the q early-out of iteration k - 1 (solver.t:1093-1102): nothing of iteration k has been applied yet
             if (qPending) {
                 const T Q1 = (T)TOT[4];
                 const T zeta = T(k) * (Q1 - Q0) / Q1;
-                if (zeta < K.qTolerance) break;
+                if (zeta < K.qTolerance) { if (K.trace && g == 0 && tid == 0) { K.trace[1] = (double)zeta; K.trace[0] = (double)(k + 1); } break; }
                 Q0 = Q1;
             }
         }
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
                 {      // the q test of THIS iteration (the split step delivers Q directly)
                     const T Q1 = (T)TOT[4];
                     const T zeta = T(k + 1) * (Q1 - Q0) / Q1;
-                    if (zeta < K.qTolerance) break;
+                    if (zeta < K.qTolerance) { if (K.trace && g == 0 && tid == 0) { K.trace[1] = (double)zeta; K.trace[0] = (double)(k + 2); } break; }
                     Q0 = Q1;
                 }
                 qPending = false;

@@ -46,6 +46,7 @@ struct SfsOcArgs {
     T qTolerance;
     int* hostErr;                       // LM (the solver applies the update itself): pinned host word a workgroup that gave up raises on its way out; GN: nullptr (sfs_applyDelta tells the host)
     long long* prof;                    // SO_PROFILE builds: [G][8] ticks per phase (wave 0 of every workgroup), else nullptr
+    double* lmBreak;                    // pinned {iteration + 1, zeta} of the q early-out (OnChipLm::breakInfo), or nullptr
 };
 
 // Development builds (opt_amd/build.py build_variant with SO_PROFILE=1; OPT_AMD_ONCHIP_PROFILE=1): thread 0 of every workgroup accumulates the wall-clock ticks
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(WAVES * kWave) void sfs_onchipPcg(SfsOcArgs<T> K) {
         if (LM && !first) {      // the q early-out of iteration k - 1 (solver.t:1093-1102): nothing of iteration k has been applied yet
             const T Q1 = (T)xD;
             const T zeta = T(k) * (Q1 - Q0) / Q1;
-            if (zeta < K.qTolerance) break;
+            if (zeta < K.qTolerance) { if (K.lmBreak && blockIdx.x == 0 && tid == 0) { K.lmBreak[1] = (double)zeta; K.lmBreak[0] = (double)(k + 1); } break; }
             Q0 = Q1;
         }
         // the scalars of sfs_pcgMarch's prologue (solver.t:456-459, 544-547 guards; beta numerator by expansion, clamped like the direct sum it replaces)

@@ -376,6 +376,7 @@ struct PcgSolver : SolverBase {
         if (redMH.partials) (void)hipHostFree(redMH.partials);
         if (redQR.partials) (void)hipHostFree(redQR.partials);
         if (stampFlag) (void)hipHostFree(stampFlag);
+        if (lmBreak) (void)hipHostFree(lmBreak);
         if (onChipTrace) (void)hipFree(onChipTrace);
         if (redCH.partials) (void)hipHostFree(redCH.partials);
         if (hostBufQ) { (void)hipHostFree(hostBufQ); (void)hipEventDestroy(qEvent); }
@@ -397,6 +398,7 @@ struct PcgSolver : SolverBase {
     int onChipFailures = 0, onChipBackoff = 0, onChipCleanSteps = 0;
     bool onChipAllowed() const { return onChipOk && sp.amd_onchip != 0 && sp.amd_reference_order == 0; }
     bool singleKernelAllowed() const { return oneKernel && sp.amd_reference_order == 0; }
+    double* lmBreak = nullptr;          // pinned: {iteration + 1, zeta} of an on-chip LM solve's q early-out (OnChipLm::breakInfo)
     bool onChipOk = true, usedOnChip = false, onChipFellBack = false, lastStepOnChip = false; double* onChipTrace = nullptr; int onChipTraceCap = 0;      // EnergyOps::pcgSolveOnChip
     // true iff `mine` holds on every rank: one all-reduce of a count and one read-back (once per Gauss-Newton step in slab mode)
     bool allRanksAgree(bool mine) {
@@ -697,9 +699,14 @@ struct PcgSolver : SolverBase {
     bool runSingleKernelLoopLM(const T* preArg, T Q0, T q_tolerance) {
         if (distributed || traceEnabled || keepReferenceP) return false;
         // The whole LM linear solve as one persistent launch (iw_onchip.h, LMV): CtC, the q early-out and the split residual reset happen on chip, the host
-        // sees only delta.  (A listening caller -- verbosity > 0 -- wants the "breaking at iteration" message: the launch-per-iteration loop prints it.)
-        if (onChipAllowed() && (preArg || E->onChipWithoutPreconditioner()) && sp.lIterations > 0 && verbosity == 0 && Q0 == T(0) && takeLease()) {
-            const OnChipLm<T> la{trust_region_radius, min_lm_diagonal, max_lm_diagonal, q_tolerance, sp.residual_reset_period, CtC};
+        // sees only delta -- and, for a listening caller (verbosity > 0), the iteration and zeta of the early-out in a pinned word, from which the reference's "breaking at
+        // iteration" message is printed once the step has drained (round 6: verbose and silent runs take the SAME path).  Not reproduced there: the message of
+        // an early-out decided after the LAST iteration (its test is dead -- the loop has ended -- and the on-chip kernels do not form it).
+        if (onChipAllowed() && (preArg || E->onChipWithoutPreconditioner()) && sp.lIterations > 0 && Q0 == T(0) && takeLease()) {
+            if (!lmBreak) { HIP_CHECK(hipHostMalloc((void**)&lmBreak, 64)); }
+            lmBreak[0] = 0.0; lmBreak[1] = 0.0;
+            OnChipLm<T> la{trust_region_radius, min_lm_diagonal, max_lm_diagonal, q_tolerance, sp.residual_reset_period, CtC};
+            la.breakInfo = verbosity > 0 ? lmBreak : nullptr;
             if (E->pcgSolveOnChip(r, p, delta, sp.lIterations, nullptr, &la, ctx)) { usedOnChip = true; return true; }
             dropLease();
         }
@@ -981,12 +988,15 @@ struct PcgSolver : SolverBase {
                 exchangeVector(delta);
                 E->evalModelCost(delta, distributed ? redA : redMH, ctx);   // (its own partials buffer: the value is read together with the new cost below)
                 imageOp(3);   // savePreviousUnknowns + PCGLinearUpdate
-            } else if (!unknownsUpdated) imageOp(0);   // PCGLinearUpdate
+            } else if (!unknownsUpdated) {   // PCGLinearUpdate (behind an on-chip solve that left the update to the solver: guarded by the launch's failure word where the kernel set can)
+                if (!(usedOnChip && E->onChipGuardedUpdate(delta, ctx))) imageOp(0);
+            }
             exchangeUnknowns();
             E->precompute(ctx);
             if (lm && !distributed) {
                 E->evalCost(redCH, ctx);                   // both sets of partials are written straight to pinned memory: one drain, no copy kernels
                 drain();
+                if (usedOnChip && verbosity > 0 && lmBreak && lmBreak[0] > 0.0 && !E->onChipFailedPeek()) { printf("zeta=%.18g, breaking at iteration: %d\n", lmBreak[1], (int)lmBreak[0] - 1); lmBreak[0] = 0.0; }
                 double sm = 0, sc = 0;
                 for (int i = 0; i < redMH.n; ++i) sm += redMH.partials[i];
                 for (int i = 0; i < redCH.n; ++i) sc += redCH.partials[i];

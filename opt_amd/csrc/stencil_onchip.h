@@ -40,6 +40,7 @@ struct MoArgs {
     int* bad; long long timeoutTicks; int failAt;
     long long firstTicks;      // bound of the FIRST iteration's wait: the co-residency check (every workgroup has posted its words once it passes), before anything is written
     const T* CtC; T qTolerance; int* hostErr;      // LM: the clamped diagonal, q_tolerance, the pinned word a workgroup that gave up raises (the solver applies the update itself)
+    double* lmBreak;                               // pinned {iteration + 1, zeta} of the q early-out (OnChipLm::breakInfo), or nullptr
 };
 
 __device__ __forceinline__ float moFma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(WAVES * kWave) void march_onchipPcg(Op op, MoArgs<T
             if (!first) {
                 const T Q1 = (T)TOT[4];
                 const T zeta = T(k) * (Q1 - Q0) / Q1;
-                if (zeta < K.qTolerance) break;
+                if (zeta < K.qTolerance) { if (K.lmBreak && blockIdx.x == 0 && tid == 0) { K.lmBreak[1] = (double)zeta; K.lmBreak[0] = (double)(k + 1); } break; }
                 Q0 = Q1;
             }
         }
@@ -411,7 +412,7 @@ struct OnchipMarch {
             seq = 2;
         }
         const OcTimeouts tmo = ocTimeouts(timeoutTicks, L, false);
-        MoArgs<T> K{W, H, r0, p0, delta, flags, coef, stripsX, tilesY, G, L, seq, slots, box, bad, tmo.later, failAt, tmo.first, lm ? lm->CtC : nullptr, lm ? lm->qTolerance : T(0), (lm || !X) ? hostErr : nullptr};      // (no X: the solver applies the update itself, as for LM)
+        MoArgs<T> K{W, H, r0, p0, delta, flags, coef, stripsX, tilesY, G, L, seq, slots, box, bad, tmo.later, failAt, tmo.first, lm ? lm->CtC : nullptr, lm ? lm->qTolerance : T(0), (lm || !X) ? hostErr : nullptr, lm ? lm->breakInfo : nullptr};      // (no X: the solver applies the update itself, as for LM)
         {
             ScopedKernel k(ctx, "PCGSolveOnChip");
             Op opc = op;
@@ -435,6 +436,7 @@ struct OnchipMarch {
         failed = true;
         return true;
     }
+    bool failedPeek() const { return launched && hostErr && __atomic_load_n(hostErr, __ATOMIC_ACQUIRE) != 0; }      // EnergyOps::onChipFailedPeek
     void rearm(LaunchCtx& ctx) {      // EnergyOps::onChipRearm
         if (!bad) return;
         failed = false; __atomic_store_n(hostErr, 0, __ATOMIC_RELEASE);
