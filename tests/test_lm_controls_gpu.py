@@ -127,6 +127,8 @@ def test_verbose_run_takes_the_same_path_as_the_silent_one(oracle_lib, capfd):
         costs.append(g.cost())
     assert g.on_chip_status() == 1
     g.close()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)      # the library prints through C stdio
     out = capfd.readouterr().out
     assert costs == [c[1] for c in silent][:len(costs)], (costs, silent)
     assert "breaking at iteration" in out, out[-2000:]
