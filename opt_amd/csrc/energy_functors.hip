@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void flow_coef(OpticalFlowE<T> e, T* __rest
 template <class T>
 struct OpticalFlowOps : StencilOps<T, OpticalFlowE<T>> {
     MarchLoop<T> march; T* coef = nullptr; bool useMarch = true;
-    OpticalFlowOps(const unsigned* dims) : StencilOps<T, OpticalFlowE<T>>(dims, false) { if (const char* e = getenv("OPT_AMD_FLOW_MARCH")) useMarch = atoi(e) != 0; if (useMarch) oc.reserve(this->e.W, this->e.H, 2); }
+    OpticalFlowOps(const unsigned* dims) : StencilOps<T, OpticalFlowE<T>>(dims, false) { if (const char* e = getenv("OPT_AMD_FLOW_MARCH")) useMarch = atoi(e) != 0; if (useMarch) oc.template reserveFor<FlowMarchOp<T>>(this->e.W, this->e.H, this->cus); }
     ~OpticalFlowOps() override { if (coef) (void)hipFree(coef); }
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
         if (!useMarch || a.pre || a.CtC) return false;      // Gauss-Newton only
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void intrinsic_coef(const T* __restrict__ a
 template <class T>
 struct IntrinsicOps : StencilOps<T, IntrinsicE<T>> {
     MarchLoop<T> march; T* coef = nullptr; bool useMarch = true;
-    IntrinsicOps(const unsigned* dims) : StencilOps<T, IntrinsicE<T>>(dims, false) { if (const char* e = getenv("OPT_AMD_INTRINSIC_MARCH")) useMarch = atoi(e) != 0; if (useMarch) oc.reserve(this->e.W, this->e.H, 4); }
+    IntrinsicOps(const unsigned* dims) : StencilOps<T, IntrinsicE<T>>(dims, false) { if (const char* e = getenv("OPT_AMD_INTRINSIC_MARCH")) useMarch = atoi(e) != 0; if (useMarch) oc.template reserveFor<IntrinsicMarchOp<T>>(this->e.W, this->e.H, this->cus); }
     ~IntrinsicOps() override { if (coef) (void)hipFree(coef); }
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
         if (!useMarch || a.pre || a.CtC) return false;      // Gauss-Newton only

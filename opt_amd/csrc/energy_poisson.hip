@@ -267,7 +267,7 @@ struct PoissonOps : EnergyOps<T> {
         this->addUnknown(0, (long)A.W * A.H, 4);
         int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (const char* e = getenv("OPT_AMD_POISSON_ONEKERNEL")) singleKernel = atoi(e) != 0;
-        if (singleKernel) oc.reserve(A.W, A.H, 4);
+        if (singleKernel) oc.template reserveFor<PoissonMarchOp<T>>(A.W, A.H, cus);
     }
     int grid() const { return (int)std::max<long>(1, std::min<long>(((long)A.W * A.H + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
     void bind(void** p, LaunchCtx& ctx) override {
@@ -391,7 +391,7 @@ struct LaplacianOps : EnergyOps<float> {
         this->usePreconditioner = false;                       // no UsePreconditioner call in laplacian.t (default o.t:214)
         this->addUnknown(0, (long)A.W * A.H, 1);
         int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        oc.reserve(A.W, A.H, 1);
+        oc.template reserveFor<LaplacianMarchOp>(A.W, A.H, cus);
     }
     int grid() const { return (int)std::max<long>(1, std::min<long>(((long)A.W * A.H + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
     void bind(void** p, LaunchCtx&) override { A.X = (const float*)p[0]; A.Aim = (const float*)p[1]; }

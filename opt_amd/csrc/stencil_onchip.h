@@ -352,6 +352,12 @@ struct OnchipMarch {
     ~OnchipMarch() { if (slots) (void)hipFree(slots); if (box) (void)hipFree(box); if (bad) (void)hipFree(bad); if (hostErr) (void)hipHostFree(hostErr); }
     // The buffers of the path, sized for the plan's image (the dimensions of a plan are fixed).  Called when the plan is made (the kernel set's constructor), so that the
     // first linear solve of a plan does not pay for four allocations; solve() calls it itself if nobody has.  zero = no tag.
+    // ... only for plans that can take the path at all: some variant of THIS operator fits THIS device's CUs for the image (a 4-channel double image of
+    // 1-2 M pixels used to allocate ~256 MB of tagged box it could never use)
+    template <class Op> void reserveFor(int W, int H, int cus) {
+        int sx, ty, G;
+        if (select<Op, false>(W, H, cus, sx, ty, G) || select<Op, true>(W, H, cus, sx, ty, G)) reserve(W, H, Op::C);
+    }
     void reserve(int W, int H, int C) {
         if (slots || !enabled || (unsigned long long)W * H * C * sizeof(T) >= (1ull << 30)) return;
         if ((long)W * H > (long)kMoMaxG * 8 * kMoSpan * 16 || divUp(W, kMoSpan) > kMoMaxG * 8) return;      // (more pixels than the largest variant holds on the largest grid: the path will never be taken)
