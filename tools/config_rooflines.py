@@ -22,8 +22,8 @@ MODELS = {
     "poisson_image_editing 2048": [("PCGIteration", "march_pcgIter", 65.0 * 2048 * 2048, "poisson marching iteration: 65 B/px (DESIGN 3.5)")],
     "config2": [("PCGIteration", "iw_pcgIter2", 53.0 * 2048 * 2048, "image_warping iteration: 53 B/px (DESIGN 3.1)")],
     "config3": [("PCGIteration", "sfs_pcgMarch", 126.0 * 1024 * 1024, "SFS double LM iteration: ~126 B/px (DESIGN 3.5); working set 132 MB: Infinity-Cache-resident")],
-    "config4": [("PCGStep1", "arap_applySym", 125e6, "ARAP record gather: slots + records + outputs 125 MB (DESIGN 3.5); working set 239 MB: Infinity-Cache-resident"),
-                ("PCGStep2+PCGStep3", "arap_flatStepRec", 114e6, "ARAP flat PCGStep2 + PCGStep3 + record rewrite: 114 MB")],
+    "config4": [("PCGStep1", "arap_applyEll", 180.0 * 500556, "ARAP plane gather (round 6): own planes 80 + r, M 48 + ELL ids 28 + A p 24 = 180 B per vertex = 90 MB (gathered plane entries are the same arrays: L2 / Infinity-Cache hits)"),
+                ("PCGStep2+PCGStep3", "arap_flatStepPlanes", 224.0 * 500556, "ARAP flat PCGStep2 + PCGStep3 + dynamic planes: delta, p, r, A p, M in (120) + delta, r, p (72) + D0, D1 (32) out = 224 B per vertex = 112 MB")],
 }
 
 
@@ -106,6 +106,9 @@ def main(src, out):
                 o = {"kernel": f"{kname} = {needle}", "avg_us": us, "bound": "hbm", "model_bytes_per_launch": model, "model": what, "achieved": ach, "unit": "GB/s",
                      "peak": HBM_PEAK, "frac": ach / HBM_PEAK, "traffic": t["total"] if t else None, "traffic_read_write": t,
                      "hbm_achieved": t["total"] / (us * 1e-6) / 1e9 if t else None}
+                if box and box.get("copy_gbs_float4_nontemporal"):      # round 6: what a float4 copy kernel reaches on THIS box (OptAmd_MeasureCopyBandwidth)
+                    best = max(box.get("copy_gbs_float4") or 0.0, box["copy_gbs_float4_nontemporal"])
+                    o.update({"box_copy_float4_gbs": best, "frac_of_box_copy_float4": (o["hbm_achieved"] or ach) / best})
                 if "Infinity-Cache-resident" in what and cache_peak:
                     o.update({"cache_resident_peak_measured": cache_peak, "frac_of_cache_resident_peak": ach / cache_peak,
                               "note": "the working set sits in the 256 MiB Infinity Cache: HBM sees only part of the bytes (traffic < model); the honest ceiling is the box's own copy rate on a 128 MiB working set"})
