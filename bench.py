@@ -23,6 +23,11 @@ The same JSON line carries
                  N > 1: after the timed steps the same job runs two more steps with per-kernel hipEvents switched on (OptAmd_PlanSetTiming); rank 0 reports
                  its own slab's kernel (model bytes of its rows / its launch time) and `per_iteration_ms`: the difference is the communicator (all-reduce
                  every iteration, halo exchange every 7th) plus launch gaps -- on a real multi-GPU box that is the xGMI cost per iteration.
+  contract_loop: the reference-ordered loop as a product mode (Opt_SetSolverParameter "amd_reference_order" = 1: PCGStep1; PCGStep2; PCGStep3 per iteration, r / z / A p in
+                 memory) on the same workload: PCG iterations/s, per-kernel times, `frac` against the reference formulation's 180 B/pixel and `frac_physical` against the 149 it
+                 moves, relative error per step against the frozen exact-order oracle builds -- what parity at the contract costs.
+  smoke        : N > 1 only: a Gauss-Newton step of 12 PCG iterations through the real kernels on every rank BEFORE the timed region, verdict collective; a peer communicator
+                 that fails it is replaced by RCCL on every rank and the line says so.
   cpu_baseline : the CPU oracle (a port, not the reference) timed on a bounded sample on the host cores (rank 0, N = 1 only).
   parity       : cost after the first step next to the frozen oracle value for this workload (tests/golden/bench_costs.json).
   box          : what the line ran on -- power cap, clocks and power sampled under load, the box's own measured copy bandwidth (boxes of the pool differ by ~10 %).
@@ -100,7 +105,21 @@ def cpu_baseline(size, liters):
     from oracle.binding import OracleSolver
     from opt_amd import workloads as wl
     cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 128))
+    phys = None
+    try:      # physical cores = distinct (socket, core) pairs: SMT siblings buy the memory-bound row bands nothing, so one thread per physical core (at most 128)
+        ids, cur = set(), {}
+        for ln in open("/proc/cpuinfo"):
+            if ":" in ln:
+                k, v = [t.strip() for t in ln.split(":", 1)]
+                cur[k] = v
+            elif cur:
+                ids.add((cur.get("physical id"), cur.get("core id"))); cur = {}
+        if cur:
+            ids.add((cur.get("physical id"), cur.get("core id")))
+        phys = len(ids) if len(ids) > 1 else None
+    except OSError:
+        pass
+    threads = max(1, min(phys or cores, 128))
     P = wl.image_warping(size, size)
     s = OracleSolver("image_warping", "gaussNewtonGPU", False, P.dims)
     s.set_threads(threads)
@@ -113,7 +132,8 @@ def cpu_baseline(size, liters):
     return {"value": rate, "unit": "PCG iters/s", "cores": threads, "kind": "port",
             "sample": f"oracle (C++ port of solverGPUGaussNewton.t: generic dual-number residuals scattered per thread band, {threads} OpenMP threads), "
                       f"image_warping {size}x{size} float, 1 GN step x {liters} PCG iterations, {dt:.1f} s wall incl. the step's evalJTF/update/cost; "
-                      f"host has {cores} logical cores.  A stated baseline, not a tuned CPU solver: no speed-up claim is made from it"}
+                      f"host has {cores} logical / {phys or '?'} physical cores: one thread per physical core (SMT siblings do not help the memory-bound row bands), capped at 128.  "
+                      "A stated baseline, not a tuned CPU solver: no speed-up claim is made from it"}
 
 
 def golden_cost(size, liters):

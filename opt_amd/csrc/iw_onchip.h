@@ -147,7 +147,7 @@ template <class T> struct OcLds {
     static constexpr size_t lm(int rows) { return ap(rows, true) + row() + side(rows); }
     // cos / sin of the lane's LAST csRows rows live in LDS instead of registers where that relieves a variant that spills and the LDS has the room: the LM ROWS = 8 variant
     // (round 6: 124 -> 68-76 B of scratch per lane; a row's pair is read back once per stencil pass): [row][cos, sin][thread], behind everything else.  (ROWS = 16 has no room: its
-    // A p fills 96 of the CU's 160 KB and the rest is taken to within 6 KB; its 40-64 B of scratch stay -- ~13 scratch operations per iteration of ~2000 VALU instructions.)
+    // A p fills 96 of the CU's 160 KB and the rest is taken to within 6 KB; its 40 B of scratch stay -- ~13 scratch operations per iteration of ~2000 VALU instructions.)
     static constexpr int csRows(int rows, bool apLds, bool lmv) { return (sizeof(T) == 4 && rows == 8 && lmv && !apLds) ? 8 : 0; }
     static constexpr size_t base(int rows, bool apLds, bool lmv) { return ap(rows, apLds) + rows3(apLds) + 5 * side(rows) + tail() + (lmv ? lm(rows) : 0); }
     static constexpr size_t total(int rows, bool apLds, bool lmv = false) { return base(rows, apLds, lmv) + (size_t)csRows(rows, apLds, lmv) * 2 * kOcBlock * sizeof(T); }
@@ -215,7 +215,6 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
     const bool xin = x < K.W;
     const T w2 = K.w_reg * K.w_reg, wf2 = K.w_fit * K.w_fit;
     int* const bad = K.S.bad;
-    long long to = K.firstTicks;      // the first phase's waits double as the co-residency check (OnchipArgs::firstTicks); K.timeoutTicks afterwards
 
     if (tid < 15) {      // the table of iw_pcgIter2: same accumulation order as iw_evalJTF, so the entries are the solver's preconditioner values bit for bit
         const int t = tid, cnt = t < 10 ? t % 5 : t - 10;
@@ -412,6 +411,8 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
     // column and of the halo pixel this lane looks after.  k: the PCG iteration (the rank hop of row slabs numbers its mailbox slots by it).
     auto gridWait = [&](double (&v4)[NS], unsigned tag, int par, oc_u64* boxPar, int k, unsigned rtag, int rpar, T (&at)[3], T (&ab)[3], T (&as)[3]) {
         auto box = [&](int tile, int sd) { return boxPar + ((long)tile * 4 + sd) * K.S.stride; };
+        // the FIRST phase's waits double as the co-residency check (OnchipArgs::firstTicks: every workgroup posts before it waits, so passing them proves the grid resident)
+        const long long to = tag == K.tag0 ? K.firstTicks : K.timeoutTicks;
         int tq = tid;      // (opaque per iteration, like fl / pix0: the addresses below are recomputed, not kept in registers across the whole loop)
         asm volatile("" : "+v"(tq));
 #pragma unroll
@@ -575,7 +576,6 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
             if constexpr (LMV) v4[4] = accQ;
             gridWait(v4, tag, par, boxPar, k, rtag, rpar, at, ab, as);
         }
-        to = K.timeoutTicks;      // every workgroup has been heard from: the grid is resident
         if constexpr (LMV) { ++phase; accQ = 0; }
         // With delta in memory (ROWS = 16) it is read in chunks of CH rows, two chunks ahead of the update: the first request goes out HERE, behind the wait for
         // the sums, and returns (lines this lane wrote one iteration ago, still in its XCD's L2) while the halo copies are updated.  (All 48 values requested

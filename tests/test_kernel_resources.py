@@ -22,7 +22,7 @@ def resources(opt_lib):
 
 # kernels that still hold scratch, with the ceiling asserted here: {regex on the demangled name: (max bytes per lane, why)}
 KNOWN = {
-    r"^iw_onchipPcg<float, 16, true, true, false>$": (64, "the 4096x512 slab variant: p, r, cos / sin of 16 rows = 132 persistent VGPRs, A p fills 96 of the 160 KB of LDS and the rest is "
+    r"^iw_onchipPcg<float, 16, true, true, false>$": (40, "the 4096x512 slab variant: p, r, cos / sin of 16 rows = 132 persistent VGPRs, A p fills 96 of the 160 KB of LDS and the rest is "
                                                           "taken to within 6 KB, delta is streamed through L2 -- ~13 scratch operations per iteration of ~2000 VALU instructions"),
     r"^iw_onchipPcg<float, 8, false, false, true>$": (76, "Levenberg-Marquardt, 8 rows: p, r, delta, A p of 8 rows in registers; cos / sin moved to LDS in round 6 (124 -> 68 B; 76 with the early-out report for verbose callers), b already there; "
                                                           "the LDS is full"),
