@@ -204,3 +204,11 @@ def test_config3_sfs_1024_double_lm_step_vs_oracle(oracle_lib):
 def test_config4_arap_500k_step_vs_oracle(oracle_lib):
     P = wl.arap_mesh_deformation(708, 707, perturb=0.01)
     _pair(oracle_lib, P, "gaussNewtonGPU", 1, 10, 1e-5, 1e-5)
+
+
+def test_config4_arap_500k_lm_steps_vs_oracle(oracle_lib):
+    """The same mesh under Levenberg-Marquardt (the reference's performance run of this example is GN and LM, arap_mesh_deformation/src/main.cpp:81-99): two outer steps of 12
+    iterations on the two-kernel iteration of round 6 -- CtC in the plane gather, b / Q / delta-out in the flat pass, one split residual reset (period 10) with its restart
+    launch -- at full size (500 556 vertices: 768 workgroups walking their XCD eighths)."""
+    P = wl.arap_mesh_deformation(708, 707, perturb=0.01)
+    _pair(oracle_lib, P, "LMGPU", 2, 12, 1e-5, 1e-5, radius_tol=1e-3)
