@@ -24,8 +24,8 @@ The same JSON line carries
                  its own slab's kernel (model bytes of its rows / its launch time) and `per_iteration_ms`: the difference is the communicator (all-reduce
                  every iteration, halo exchange every 7th) plus launch gaps -- on a real multi-GPU box that is the xGMI cost per iteration.
   contract_loop: the reference-ordered loop as a product mode (Opt_SetSolverParameter "amd_reference_order" = 1: PCGStep1; PCGStep2; PCGStep3 per iteration, r / z / A p in
-                 memory) on the same workload: PCG iterations/s, per-kernel times, `frac` against the reference formulation's 180 B/pixel and `frac_physical` against the 149 it
-                 moves, relative error per step against the frozen exact-order oracle builds -- what parity at the contract costs.
+                 memory) on the same workload: PCG iterations/s, per-kernel times, `frac` against the reference formulation's 180 B/pixel and `frac_physical` against the 168.8 it
+                 moves (PMC-measured), relative error per step against the frozen exact-order oracle builds -- what parity at the contract costs.
   smoke        : N > 1 only: a Gauss-Newton step of 12 PCG iterations through the real kernels on every rank BEFORE the timed region, verdict collective; a peer communicator
                  that fails it is replaced by RCCL on every rank and the line says so.
   cpu_baseline : the CPU oracle (a port, not the reference) timed on a bounded sample on the host cores (rank 0, N = 1 only).
@@ -53,6 +53,7 @@ ALGO_BYTES_PER_PIXEL = 48 + 96 + 36   # PCGStep1 + PCGStep2 + PCGStep3 of the re
 # p_k 12 out, angle 4, flags 1 = 41; every second launch additionally delta 12 in / 12 out = 24 -> 12 on average; general UrShape: + U 8 + M_a 4
 MODEL_BYTES_PER_PIXEL = {"lattice": 41 + 12, "general": 41 + 12 + 8}      # general UrShape: + U 8 (M_O from the flag byte; M_a rebuilt from the pairs the stencil evaluates, round 4)
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CONTRACT_LOOP_TRAFFIC_B_PER_PX = 168.8      # reference-ordered loop, PMC-measured per PCG iteration at 4096^2 (profiles/r06_contract_loop_traffic.txt): k_step2 96.0 + iw_applyJTJ<fused> 72.8
 KERNEL_SOURCES = ["opt_amd/csrc/energy_image_warping.hip", "opt_amd/csrc/iw_device.h", "opt_amd/csrc/iw_iter.h", "opt_amd/csrc/iw_step.h", "opt_amd/csrc/iw_onchip.h", "opt_amd/csrc/solver.hip", "opt_amd/csrc/common.h", "opt_amd/csrc/energy.h", "opt_amd/build.py"]
 
 
@@ -286,11 +287,12 @@ def contract_loop_leg(api, wl, torch, W, H, liters):
            "kernel_avg_ms": {k: v[1] / v[0] for k, v in kt.items()}, "kernel_ms_per_step": {k: v[1] for k, v in kt.items()},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
                         "bytes_per_pixel": ALGO_BYTES_PER_PIXEL, "us_per_iteration": 1e3 * loop_ms / liters if loop_ms else None,
-                        "physical_bytes_per_pixel": 96 + 53, "frac_physical": (achieved * (96 + 53) / ALGO_BYTES_PER_PIXEL / HBM_PEAK_GBS) if achieved else None,
+                        "physical_bytes_per_pixel": CONTRACT_LOOP_TRAFFIC_B_PER_PX, "frac_physical": (achieved * CONTRACT_LOOP_TRAFFIC_B_PER_PX / ALGO_BYTES_PER_PIXEL / HBM_PEAK_GBS) if achieved else None,
                         "note": "SURVEY 8d's algorithmic bytes (PCGStep1 48 + PCGStep2 96 + PCGStep3 36 B/px) over the loop's own kernel time (PCGStep* launches of one step / "
                                 "lIterations).  The loop keeps r, z, A p and p in memory and sums as the reference does; the one fusion left is PCGStep3 into the next PCGStep1 "
-                                "(p is not written and re-read in between: z 12 + p 12 in, p 12 + A p 12 out, angle 4, flags 1 = 53 B/px for the pair instead of 84), so the bytes "
-                                "that physically move are 149 B/px: frac_physical"},
+                                "(p is not written and re-read in between).  The bytes that physically move were measured with rocprofv3 FETCH_SIZE / WRITE_SIZE passes "
+                                "(profiles/r06_contract_loop_traffic.txt, 4096^2): PCGStep2 96.0 B/px (= its model), PCGStep3+PCGStep1 72.8 B/px (model 53 + the cos / sin table 8 + "
+                                "stencil halo re-reads) = 168.8 B/px: frac_physical"},
            "costs": costs}
     try:
         G = {"plain": json.load(open(os.path.join(ROOT, "tests", "golden", "horizon_costs.json"))), "fma": json.load(open(os.path.join(ROOT, "tests", "golden", "horizon_costs_fma.json")))}
