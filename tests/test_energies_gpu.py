@@ -275,6 +275,43 @@ def test_arap_asymmetric_graph_keeps_the_edge_list_path(oracle_lib, double):
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("hub,expect_planes", [(16, True), (17, False), (40, False)])
+def test_arap_high_valence_vertex_and_the_ell_width(oracle_lib, hub, expect_planes):
+    """Round 6: the symmetric-graph path stores the out-lists ELL-wise, one column per neighbour of the longest list (kEllMax = 16).  A mesh plus one hub vertex joined to
+    `hub` others (both directions): 16 neighbours still take the plane gather (ELL width 16, most vertices use 4-6 columns of it), 17 or 40 send the graph to the edge-list
+    gather.  Either way J^T J p and a 2 x 12 trajectory against the oracle."""
+    import torch
+    P = wl.arap_mesh_deformation(19, 13, double=True, seed=5, perturb=0.01)
+    heads, tails = list(P.params[7]), list(P.params[8])
+    n = 19 * 13
+    h = 7 * 19 + 9                                   # an interior vertex
+    have = {t for a, t in zip(heads, tails) if a == h}
+    extra = [v for v in range(0, n, 3) if v != h and v not in have][:hub - len(have)]
+    for v in extra:
+        heads += [h, v]; tails += [v, h]
+    P.params[7] = np.ascontiguousarray(np.array(heads, dtype=np.int32)); P.params[8] = np.ascontiguousarray(np.array(tails, dtype=np.int32))
+    P.params[6] = np.array(len(heads), dtype=np.int32)
+    assert sum(1 for a in heads if a == h) == hub
+    o = oracle_solver(oracle_lib, P); g = hip_solver(P, timing=True)
+    dev = api.to_device(P)
+    v = np.random.default_rng(5).standard_normal(o.n).astype(o.dtype)
+    Av_gpu, _ = g.apply_jtj(dev, torch.from_numpy(v).cuda())
+    assert rel_err(Av_gpu.cpu().numpy(), o.apply_jtj(P.params, v)) < 1e-11
+    assert ("packVertexRecords" in g.kernel_timings()) == expect_planes, g.kernel_timings().keys()
+    g.close(); o.close()
+    kw = dict(nIterations=2, lIterations=12)
+    o = oracle_solver(oracle_lib, P, "gaussNewtonGPU", **kw); g = hip_solver(P, "gaussNewtonGPU", **kw)
+    Pref = P.clone(); dev = api.to_device(P)
+    o.init(Pref.params); g.init(dev)
+    while True:
+        a, b = o.step(Pref.params), g.step(dev)
+        assert a == b
+        assert_close("cost", g.cost(), o.cost(), 1e-10, double=True)
+        if not a:
+            break
+    g.close(); o.close()
+
+
 @pytest.mark.parametrize("mode", ["0", "1"])
 @pytest.mark.parametrize("double", [False, True])
 def test_volumetric_on_both_kernel_sets(oracle_lib, double, mode, monkeypatch):
