@@ -848,8 +848,17 @@ struct PcgSolver : SolverBase {
     }
 
     // ---- step (solver.t:1016-1177) --------------------------------------------------------------------
+    // A step whose on-chip linear solve failed on an energy without a launch-per-iteration loop of its own is run again from its PCGInit1 on the generic kernels (the on-chip
+    // path is off by then): a loop, not a recursion.
     int step(void** params) override {
         if (patch) return stepPatch(params);
+        for (int attempt = 0;; ++attempt) {
+            bool again = false;
+            const int rc = stepOnce(params, again);
+            if (!again || attempt >= 1) return rc;
+        }
+    }
+    int stepOnce(void** params, bool& again) {
         const T min_relative_decrease = (T)sp.min_relative_decrease, min_trust_region_radius = (T)sp.min_trust_region_radius;
         const T max_trust_region_radius = (T)sp.max_trust_region_radius, q_tolerance = (T)sp.q_tolerance, function_tolerance = (T)sp.function_tolerance;
         T Q0 = 0, Q1 = 0;
@@ -1033,12 +1042,12 @@ struct PcgSolver : SolverBase {
                     E->precompute(ctx);      // (workgroups that had finished before the others gave up may have written their delta: the update above was then not the identity)
                     HIP_CHECK(hipMemsetAsync(delta, 0, nPad * sizeof(T), stream));
                     // an energy whose LM loop is the generic one (no single-kernel LM iteration): the whole step again, from its PCGInit1, on the generic kernels
-                    if (!runSingleKernelLoopLM(preArg, T(0), q_tolerance)) return step(params);
+                    if (!runSingleKernelLoopLM(preArg, T(0), q_tolerance)) { again = true; return 1; }
                 } else {
                     // Gauss-Newton: nothing was applied (iw_applyDelta checks the flag -- in slab mode the all-reduced verdict, so no rank kept its update).
                     // The redone loop starts from delta = 0 as PCGInit1 left it: the ROWS = 16 variant accumulates delta in memory while it runs.
                     HIP_CHECK(hipMemsetAsync(delta, 0, nPad * sizeof(T), stream));
-                    if (!runSingleKernelLoop(preArg)) return step(params);      // (no single-kernel loop either: the whole step again on the generic kernels)
+                    if (!runSingleKernelLoop(preArg)) { again = true; return 1; }      // (no single-kernel loop either: the whole step again on the generic kernels)
                 }
                 afterLinearSolve();
             }
