@@ -109,6 +109,10 @@ struct EnergyOps {
     // util.initParameters (reference util.t:664-692): re-read every pointer and host scalar; also refresh
     // any per-solve auxiliary arrays derived from the inputs (validity flags ...).
     virtual void bind(void** params, LaunchCtx& ctx) = 0;
+    // Inside Opt_ProblemSolve (Init + Steps with no caller code in between) the reference re-reads the same pointers and host scalars before every step (util.t:664-692): a
+    // kernel set whose bind() derives device-side auxiliaries ONLY from inputs that are not unknowns (flag images, edge lists ...) may say so here, and the solver binds once
+    // per solve instead of once per step.  Opt_ProblemStep called by itself always binds.
+    virtual bool bindInvariantDuringSolve() const { return false; }
     virtual T* unknownPtr(int img) const = 0;
     virtual void precompute(LaunchCtx&) {}                                   // ComputedArrays (solver.t:607-614)
     // partial sums of 1/2 sum r^2 over non-excluded, owned elements (solver.t:580-592, 715-725)

@@ -823,6 +823,7 @@ struct ArapOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_ARAP_VGRID")) symGridCap = atoi(e);
         if (const char* e = getenv("OPT_AMD_ARAP_WALK")) flatBackward = atoi(e);
     }
+    bool bindInvariantDuringSolve() const override { return true; }      // the edge lists (and their checksum + read-back) depend on the graph arrays only
     void bind(void** p, LaunchCtx& ctx) override {
         A.w_fit = (T) * (const float*)p[0]; A.w_reg = (T) * (const float*)p[1];
         A.Offset = (const T*)p[2]; A.Angle = (const T*)p[3]; A.UrShape = (const T*)p[4]; A.Constraints = (const T*)p[5];

@@ -69,6 +69,7 @@ struct ImageWarpingOps : EnergyOps<T> {
 
     // ---- bind: flag bytes + is UrShape the unit lattice? (the reference example always passes the pixel grid, CombinedSolver.h:161-172) ---------------------
     int* hNotLattice = nullptr; int* dNotLattice = nullptr; hipEvent_t bindEvent = nullptr; bool verdictPending = false, lattice = false;
+    bool bindInvariantDuringSolve() const override { return true; }      // the flag bytes and the lattice verdict depend on Mask, Constraints and UrShape only
     void bind(void** p, LaunchCtx& ctx) override {
         A.Offset = (const T*)p[0]; A.Angle = (const T*)p[1]; A.UrShape = (const T*)p[2]; A.Constraints = (const T*)p[3]; A.Mask = (const T*)p[4];
         A.w_fit = (T) * (const float*)p[5]; A.w_reg = (T) * (const float*)p[6];   // Param(..., float, ...) stays float in double mode (:7-8)

@@ -34,6 +34,7 @@ struct SolverBase {
     KernelTimer timer;
     int verbosity = 0;
     bool traceEnabled = false;
+    bool insideSolve = false;    // set by Opt_ProblemSolve around its Init + Step loop: no caller code runs between those steps, so inputs other than the unknowns cannot change
     std::vector<double> trace;   // rows of 6
     virtual ~SolverBase() {}
     virtual void init(void** params) = 0;

@@ -396,6 +396,7 @@ struct PcgSolver : SolverBase {
     bool takeLease() { if (leaseHeld) return true; leaseHeld = chipLease().try_lock_for(std::chrono::milliseconds(50)); return leaseHeld; }
     void dropLease() { if (leaseHeld) { chipLease().unlock(); leaseHeld = false; } }
     int onChipFailures = 0, onChipBackoff = 0, onChipCleanSteps = 0;
+    bool boundForSolve = false;      // bind() has run inside the current Opt_ProblemSolve (SolverBase::insideSolve)
     bool onChipAllowed() const { return onChipOk && sp.amd_onchip != 0 && sp.amd_reference_order == 0; }
     bool singleKernelAllowed() const { return oneKernel && sp.amd_reference_order == 0; }
     double* lmBreak = nullptr;          // pinned: {iteration + 1, zeta} of an on-chip LM solve's q early-out (OnChipLm::breakInfo)
@@ -805,6 +806,7 @@ struct PcgSolver : SolverBase {
         if (overallOpen) { timer.pool.push_back(overallStart); overallOpen = false; }
         if (timer.enabled) { overallStart = timer.get(); HIP_CHECK(hipEventRecord(overallStart, stream)); overallOpen = true; }   // "overall": init -> cleanup (solver.t:959, 1011)
         E->bind(params, ctx);
+        boundForSolve = insideSolve;
         sp.nIter = 0; patchSweep = 0;
         if (lm) {
             trust_region_radius = (T)sp.trust_region_radius; radius_decrease_factor = (T)sp.radius_decrease_factor;
@@ -862,7 +864,7 @@ struct PcgSolver : SolverBase {
         const T min_relative_decrease = (T)sp.min_relative_decrease, min_trust_region_radius = (T)sp.min_trust_region_radius;
         const T max_trust_region_radius = (T)sp.max_trust_region_radius, q_tolerance = (T)sp.q_tolerance, function_tolerance = (T)sp.function_tolerance;
         T Q0 = 0, Q1 = 0;
-        E->bind(params, ctx);
+        if (!(insideSolve && boundForSolve && E->bindInvariantDuringSolve())) E->bind(params, ctx);      // (EnergyOps::bindInvariantDuringSolve: once per Opt_ProblemSolve where nothing bind() derives can have changed)
         if (sp.nIter >= sp.nIterations) { cleanup(); return 0; }
         const T* preArg = E->usePreconditioner ? preconditioner : nullptr;   // solver.t:467-470: pre = 1 unless the energy preconditions
 

@@ -95,3 +95,26 @@ def test_reference_order_against_the_oracle(oracle_lib, name, make, kind, nsteps
     assert g.on_chip_status() == 0
     assert_close("x", rel_err(device_unknowns(P, dev), flat_unknowns(Pref)), 0.0, 1e-9 if P.double else 2e-5, absolute=True, double=P.double)
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("energy", ["image_warping", "arap"])
+def test_solve_binds_once_and_gives_the_bits_of_step_by_step(energy):
+    """Opt_ProblemSolve binds once where the kernel set says its bind() derives nothing from the unknowns (round 6: flag bytes / lattice verdict of image_warping, edge lists and
+    their checksum read-back of ARAP): no caller code runs between the steps of that loop.  Same bits as Init + Step by Step (which binds before every step), fewer launches."""
+    P = wl.image_warping(300, 200, random_state=9, mask_fraction=0.05, perturb=0.3) if energy == "image_warping" else wl.arap_mesh_deformation(40, 31, perturb=0.01)
+    res = []
+    for whole in (False, True):
+        g = hip_solver(P, "gaussNewtonGPU", timing=True, nIterations=5, lIterations=10)
+        dev = api.to_device(P)
+        if whole:
+            g.solve(dev)
+        else:
+            g.init(dev)
+            while g.step(dev):
+                pass
+        kt = g.kernel_timings()
+        res.append((g.cost(), device_unknowns(P, dev), kt.get("bindFlags", kt.get("buildEdgeLists", (0, 0.0)))[0]))
+        g.close()
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
+    if energy == "image_warping":
+        assert res[1][2] == 1 and res[0][2] >= 6, (res[0][2], res[1][2])      # one bindFlags launch per solve against one per Init / Step
