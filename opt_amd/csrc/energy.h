@@ -131,6 +131,9 @@ struct EnergyOps {
     // preconditioner, delta = 0, aNum0 = partial sums of r.p -- for a kernel set whose pcgIteration needs neither the diag nor the preconditioner vector.
     // Returning true promises that pcgIteration will accept the loop that follows.  false: the solver runs evalJTF + its own flat pass.
     virtual bool evalJTFInit(T* /*r*/, T* /*p*/, T* /*delta*/, long /*nPad*/, Reduction& /*aNum0*/, LaunchCtx&) { return false; }
+    // computeCost of the step that has just updated the unknowns and evalJTFInit of the next step in one pass over them (both read the same X; the cost's partial sums
+    // are those of evalCost: same grid, same expressions).  Only asked for inside Opt_ProblemSolve, where no caller code runs between the two steps.
+    virtual bool evalCostAndJTFInit(Reduction& /*cost*/, T* /*r*/, T* /*p*/, T* /*delta*/, long /*nPad*/, Reduction& /*aNum0*/, LaunchCtx&) { return false; }
     // Optional (Levenberg-Marquardt, single GPU): PCGInit1 and everything k_finalizeDiagonal<T, true> does after it, in the energy's own J^T F kernel -- r = -J^T F,
     // CtC = clamped diag(J^T J) / radius, the LM preconditioner, b = r, p = M r, delta = 0, SSq (first outer iteration), partial sums of r . p.  false: the solver
     // runs evalJTF and its flat pass.

@@ -118,7 +118,7 @@ struct ImageWarpingOps : EnergyOps<T> {
     int occMarch = 0;
     void marchGrid(int rows, int& gx, int& gy, int& rowsPerGroup) {
         if (occMarch == 0) {      // 256-thread workgroups, ~60 VGPRs: the co-resident count of the widest of the marching kernels
-            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occMarch, (const void*)iw_jtfMarch<T, false>, kBlock, 0));
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occMarch, (const void*)iw_jtfMarch<T, false, false>, kBlock, 0));
             occMarch = std::max(1, std::min(occMarch, 8));
         }
         gx = divUp(A.W, kStrip);
@@ -139,11 +139,15 @@ struct ImageWarpingOps : EnergyOps<T> {
         return !this->slab.active && (unsigned long long)A.W * A.H * 3ull * sizeof(T) < (1ull << 32);
     }
     T *initR = nullptr, *initP = nullptr; Reduction* initRed = nullptr; bool initHint = false, initPending = false, deltaZero = false;
-    void launchJtf(bool lat, LaunchCtx& ctx) {
-        ScopedKernel k(ctx, "PCGInit1");
+    void launchJtf(bool lat, LaunchCtx& ctx, Reduction* cost = nullptr) {
+        ScopedKernel k(ctx, cost ? "computeCost+PCGInit1" : "PCGInit1");
         int gx, gy, rpg; marchGrid(A.yEnd - A.yBegin, gx, gy, rpg);
-        if (lat) iw_jtfMarch<T, true><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, initRed->partials, rpg, gx, gy);
-        else iw_jtfMarch<T, false><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, initRed->partials, rpg, gx, gy);
+        if (cost) {
+            if (lat) iw_jtfMarch<T, true, true><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, initRed->partials, cost->partials, rpg, gx, gy);
+            else iw_jtfMarch<T, false, true><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, initRed->partials, cost->partials, rpg, gx, gy);
+            cost->n = gx * gy;
+        } else if (lat) iw_jtfMarch<T, true, false><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, initRed->partials, nullptr, rpg, gx, gy);
+        else iw_jtfMarch<T, false, false><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, initRed->partials, nullptr, rpg, gx, gy);
         initRed->n = gx * gy;
     }
     // PCGInit1 + PCGInit1_Finish for the Gauss-Newton loops: r = -J^T F, p = M r, partial sums of r.p -- one marching kernel (no cos/sin table, no diag /
@@ -154,6 +158,15 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (!fastGN()) return false;
         initR = r; initP = p; initRed = &aNum0; initHint = lattice;
         launchJtf(initHint, ctx);
+        deltaZero = true; initPending = true;
+        return true;
+    }
+    // The cost of the step that has just finished and PCGInit1 of the next one, one march (inside Opt_ProblemSolve: solver.hip).  The lattice verdict is resolved here -- the
+    // cost needs it anyway -- so the variant launched is final and nothing is left pending.
+    bool evalCostAndJTFInit(Reduction& cost, T* r, T* p, T* /*delta*/, long /*nPad*/, Reduction& aNum0, LaunchCtx& ctx) override {
+        if (!fastGN()) return false;
+        initR = r; initP = p; initRed = &aNum0; initHint = resolveLattice();
+        launchJtf(initHint, ctx, &cost);
         deltaZero = true; initPending = true;
         return true;
     }

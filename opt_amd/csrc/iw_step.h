@@ -395,15 +395,18 @@ __global__ __launch_bounds__(kBlock) void iw_bindMarch(IWArgs<T> A, int* __restr
 }
 
 // r = -J^T F, p = guardedInvert(diag J^T J) r, partial sums of r.p (the iteration kernels rebuild M themselves: no preconditioner vector is written)
-template <class T, bool LATTICE>
-__global__ __launch_bounds__(kBlock) void iw_jtfMarch(IWArgs<T> A, T* __restrict__ r, T* __restrict__ p, double* __restrict__ partials,
+// COST: the same pass also sums computeCost's 1/2 r^2 (iw_costMarch's expressions, operand for operand, on the same grid: the same partial sums) -- the end of one
+// Gauss-Newton step and the PCGInit1 of the next read the same unknowns, so inside Opt_ProblemSolve the two marches are one (PcgSolver: costAndJTFInit).
+template <class T, bool LATTICE, bool COST>
+__global__ __launch_bounds__(kBlock) void iw_jtfMarch(IWArgs<T> A, T* __restrict__ r, T* __restrict__ p, double* __restrict__ partials, double* __restrict__ costPartials,
                                                       int rowsPerGroup, int gx, int gy) {
     __shared__ double scratch[kBlock / kWave + 1];
     const MarchGeo g = marchGeo(A, rowsPerGroup, gx, gy);
     const long N = (long)A.W * A.H;
     V2<T>* rO = (V2<T>*)r; T* ra = r + 2 * N; V2<T>* pO = (V2<T>*)p; T* pa = p + 2 * N;
     const T w = A.w_reg;
-    double acc = 0;
+    double acc = 0, accCost = 0;
+    T e = 0;
     MPx<T> up = iw_marchCombine<T, LATTICE>(iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, g.yb - 1));
     MRaw<T> rawCur = iw_marchLoad<T, LATTICE, true>(A, g.xok, g.x, g.yb);
     MPx<T> cur = iw_marchCombine<T, LATTICE>(rawCur);
@@ -416,6 +419,7 @@ __global__ __launch_bounds__(kBlock) void iw_jtfMarch(IWArgs<T> A, T* __restrict
         const T ey = w * ((c.oy - n.oy) - (c.s * ux + c.c * uy));
         const T hx = w * ((n.ox - c.ox) + (n.c * ux - n.s * uy));
         const T hy = w * ((n.oy - c.oy) + (n.s * ux + n.c * uy));
+        if (COST) e += ex * ex + ey * ey;
         Fx += w * ex - w * hx; Fy += w * ey - w * hy;
         const T Dx = -c.s * ux - c.c * uy, Dy = c.c * ux - c.s * uy;
         Fa += -(w * Dx) * ex - (w * Dy) * ey;
@@ -425,15 +429,18 @@ __global__ __launch_bounds__(kBlock) void iw_jtfMarch(IWArgs<T> A, T* __restrict
     auto row = [&](int y, const MRaw<T>& rdn, bool live) {
         const MPx<T> dn = iw_marchCombine<T, LATTICE>(rdn);
         const MPx<T> lf = dppShiftM<true, LATTICE>(cur), rt = dppShiftM<false, LATTICE>(cur);
-        Fx = 0; Fy = 0; Fa = 0; Pxy = 0; Pa = 0;
+        Fx = 0; Fy = 0; Fa = 0; Pxy = 0; Pa = 0; e = 0;
         if (cur.f & kActive) {
             pair(cur, rt, T(-1), T(0)); pair(cur, lf, T(1), T(0)); pair(cur, dn, T(0), T(-1)); pair(cur, up, T(0), T(1));
             if (cur.f & kFit) {
-                Fx += A.w_fit * (A.w_fit * (cur.ox - ccCur.x)); Fy += A.w_fit * (A.w_fit * (cur.oy - ccCur.y));
+                const T fx = A.w_fit * (cur.ox - ccCur.x), fy = A.w_fit * (cur.oy - ccCur.y);
+                if (COST) e += fx * fx + fy * fy;
+                Fx += A.w_fit * fx; Fy += A.w_fit * fy;
                 Pxy += A.w_fit * A.w_fit;
             }
         }
         if (g.writer && live) {
+            if (COST) accCost += (double)(T(0.5) * e);
             const long i = (long)y * A.W + g.x;
             const T r0 = -Fx, r1 = -Fy, r2 = -Fa;
             const T sO = T(1) + sqrt(Pxy), sA = T(1) + sqrt(Pa);
@@ -455,6 +462,11 @@ __global__ __launch_bounds__(kBlock) void iw_jtfMarch(IWArgs<T> A, T* __restrict
     }
     const double t = blockReduceSum(acc, scratch);
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
+    if (COST) {
+        __syncthreads();
+        const double tc = blockReduceSum(accCost, scratch);
+        if (threadIdx.x == 0) costPartials[blockIdx.x] = tc;
+    }
 }
 
 // 1/2 sum r^2 over the non-excluded pixels of the workgroup's rows (iw_cost's expressions)

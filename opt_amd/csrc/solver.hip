@@ -397,6 +397,7 @@ struct PcgSolver : SolverBase {
     void dropLease() { if (leaseHeld) { chipLease().unlock(); leaseHeld = false; } }
     int onChipFailures = 0, onChipBackoff = 0, onChipCleanSteps = 0;
     bool boundForSolve = false;      // bind() has run inside the current Opt_ProblemSolve (SolverBase::insideSolve)
+    bool jtfReady = false;           // the pass that computed the last step's cost also ran this step's PCGInit1 (EnergyOps::evalCostAndJTFInit; only inside Opt_ProblemSolve)
     bool onChipAllowed() const { return onChipOk && sp.amd_onchip != 0 && sp.amd_reference_order == 0; }
     bool singleKernelAllowed() const { return oneKernel && sp.amd_reference_order == 0; }
     double* lmBreak = nullptr;          // pinned: {iteration + 1, zeta} of an on-chip LM solve's q early-out (OnChipLm::breakInfo)
@@ -814,7 +815,11 @@ struct PcgSolver : SolverBase {
         }
         exchangeUnknowns();
         E->precompute(ctx);
-        prevCost = computeCost();
+        // (inside Opt_ProblemSolve the first step follows at once on the same unknowns: its PCGInit1 rides on this cost pass where the kernel set can -- see stepOnce)
+        jtfReady = false;
+        if (!lm && !distributed && insideSolve && E->bindInvariantDuringSolve() && sp.nIterations > 0 && singleKernelAllowed() && r2 && sp.lIterations > 0 &&
+            E->evalCostAndJTFInit(redCH, r, p, delta, nPad, redC, ctx)) { jtfReady = true; prevCost = (T)hostSum(redCH); }
+        else prevCost = computeCost();
     }
     void cleanup() {   // solver.t:1009-1014
         if (verbosity > 0) printf("final cost=%f\n", (double)prevCost);
@@ -871,7 +876,9 @@ struct PcgSolver : SolverBase {
         // PCGInit1 [+ _Graph + _Finish]: the energy produces r = -J^T F and raw diag(J^T J) (parked in CtC) -- or, for the Gauss-Newton single-kernel loop on
         // one GPU, r, p = M r, delta = 0 and the partial sums of r.p directly (EnergyOps::evalJTFInit)
         unknownsUpdated = false;
-        const bool fusedInit = !lm && !distributed && singleKernelAllowed() && r2 && sp.lIterations > 0 && E->evalJTFInit(r, p, delta, nPad, redC, ctx);
+        const bool jtfCarried = jtfReady && insideSolve;      // r, p and the partial sums of r.p are already there: the previous step's cost pass wrote them from these very unknowns
+        jtfReady = false;
+        const bool fusedInit = !lm && !distributed && singleKernelAllowed() && r2 && sp.lIterations > 0 && (jtfCarried || E->evalJTFInit(r, p, delta, nPad, redC, ctx));
         bool fusedInitLM = false;
         if (lm && !distributed) {
             LmInitArgs<T> la{CtC, SSq, r, delta, preconditioner, b, p, trust_region_radius, min_lm_diagonal, max_lm_diagonal, sp.nIter == 0 ? 1 : 0, &redC, &redQ};
@@ -1023,7 +1030,13 @@ struct PcgSolver : SolverBase {
                     model_cost_change = prevCost - model_cost;
                     if (verbosity > 0) printf(" model_cost_change=%f \n", (double)model_cost_change);
                 }
-                newCost = computeCost();
+                // Gauss-Newton inside Opt_ProblemSolve with another step to come: that step's PCGInit1 reads the unknowns this cost reads, and no caller code runs in
+                // between -- one pass does both where the kernel set can (same cost bits: same grid, same expressions).  A step on the generic kernels (back-off after
+                // an on-chip time-out included) does not ask.
+                const bool carry = !lm && !distributed && insideSolve && boundForSolve && E->bindInvariantDuringSolve() && sp.nIter + 1 < sp.nIterations &&
+                                   singleKernelAllowed() && r2 && sp.lIterations > 0;
+                if (carry && E->evalCostAndJTFInit(redCH, r, p, delta, nPad, redC, ctx)) { jtfReady = true; newCost = (T)hostSum(redCH); }
+                else newCost = computeCost();
             }
         };
         afterLinearSolve();

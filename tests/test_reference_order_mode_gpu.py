@@ -97,15 +97,31 @@ def test_reference_order_against_the_oracle(oracle_lib, name, make, kind, nsteps
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("energy", ["image_warping", "arap"])
-def test_solve_binds_once_and_gives_the_bits_of_step_by_step(energy):
+def _c_stdout(capfd):
+    import ctypes
+    ctypes.CDLL(None).fflush(None)      # the library prints through C stdio
+    return capfd.readouterr().out
+
+
+@pytest.mark.parametrize("energy", ["image_warping", "image_warping_double", "image_warping_streaming", "image_warping_general_urshape", "arap"])
+def test_solve_binds_once_and_gives_the_bits_of_step_by_step(energy, capfd):
     """Opt_ProblemSolve binds once where the kernel set says its bind() derives nothing from the unknowns (round 6: flag bytes / lattice verdict of image_warping, edge lists and
-    their checksum read-back of ARAP): no caller code runs between the steps of that loop.  Same bits as Init + Step by Step (which binds before every step), fewer launches."""
-    P = wl.image_warping(300, 200, random_state=9, mask_fraction=0.05, perturb=0.3) if energy == "image_warping" else wl.arap_mesh_deformation(40, 31, perturb=0.01)
+    their checksum read-back of ARAP): no caller code runs between the steps of that loop.  Same bits as Init + Step by Step (which binds before every step), fewer launches.
+    image_warping, Gauss-Newton: the cost pass at the end of a step is also the next step's PCGInit1 (iw_jtfMarch<.., COST>: both read the same unknowns) -- 2 n + 1 marches
+    become n + 1, every printed cost is the one the separate kernel gives (same grid, same expressions) and the unknowns are the same bits."""
+    if energy == "arap":
+        P = wl.arap_mesh_deformation(40, 31, perturb=0.01)
+    elif energy == "image_warping_streaming":
+        P = wl.image_warping(1600, 1400, random_state=9, mask_fraction=0.05, perturb=0.3)      # 2.2 M pixels: past the on-chip range, the one-launch-per-iteration loop
+    elif energy == "image_warping_general_urshape":
+        P = wl.image_warping(300, 200, random_state=9, mask_fraction=0.05, perturb=0.3, jitter_urshape=0.05)      # not the unit lattice: the general-UrShape variants
+    else:
+        P = wl.image_warping(300, 200, double=energy.endswith("double"), random_state=9, mask_fraction=0.05, perturb=0.3)
     res = []
     for whole in (False, True):
-        g = hip_solver(P, "gaussNewtonGPU", timing=True, nIterations=5, lIterations=10)
+        g = hip_solver(P, "gaussNewtonGPU", timing=True, verbosity=1, nIterations=5, lIterations=10)
         dev = api.to_device(P)
+        capfd.readouterr()
         if whole:
             g.solve(dev)
         else:
@@ -113,8 +129,13 @@ def test_solve_binds_once_and_gives_the_bits_of_step_by_step(energy):
             while g.step(dev):
                 pass
         kt = g.kernel_timings()
-        res.append((g.cost(), device_unknowns(P, dev), kt.get("bindFlags", kt.get("buildEdgeLists", (0, 0.0)))[0]))
+        out = [ln for ln in _c_stdout(capfd).splitlines() if ln.startswith("cost:") or ln.startswith("final cost")]
+        res.append((g.cost(), device_unknowns(P, dev), kt.get("bindFlags", kt.get("buildEdgeLists", (0, 0.0)))[0], out, {k: v[0] for k, v in kt.items()}))
         g.close()
     assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
-    if energy == "image_warping":
+    assert len(res[0][3]) == 6 and res[0][3] == res[1][3], (res[0][3], res[1][3])      # "cost: a -> b" of every step and the final cost, to the printed digits
+    if energy.startswith("image_warping"):
         assert res[1][2] == 1 and res[0][2] >= 6, (res[0][2], res[1][2])      # one bindFlags launch per solve against one per Init / Step
+        steps, whole = res[0][4], res[1][4]
+        assert steps.get("PCGInit1") == 5 and steps.get("computeCost") == 6 and "computeCost+PCGInit1" not in steps, steps
+        assert whole.get("computeCost+PCGInit1") == 5 and whole.get("computeCost") == 1 and "PCGInit1" not in whole, whole
