@@ -54,6 +54,7 @@ struct PcgIterArgs {
     const T* CtC = nullptr; const T* b = nullptr; Reduction* q = nullptr;
     unsigned qTag = 0;                                   // != 0: q is host-visible and its partials are written as tagged word pairs (common.h storeTaggedPartial)
     int afterReset = 0; Reduction betaNum, betaDen;
+    double qInit = 0;                                    // afterReset: Q as the reset's direct sum gave it (a kernel set that carries Q forward by the CG recurrence starts again from it)
     T lmRadius = 0, lmMinDiag = 0, lmMaxDiag = 0;        // the scalars of PCGFinalizeDiagonal (solver.t:631-664): an energy whose diag(J^T J) is a known
                                                          // function of per-pixel flags can rebuild CtC and the LM preconditioner from them instead of reading both
     // Slab mode with a communicator that posts its all-reduces (OptAmd_SlabCommExt.allReducePost): the four sums of the previous launch are not in
@@ -113,6 +114,8 @@ struct EnergyOps {
     // kernel set whose bind() derives device-side auxiliaries ONLY from inputs that are not unknowns (flag images, edge lists ...) may say so here, and the solver binds once
     // per solve instead of once per step.  Opt_ProblemStep called by itself always binds.
     virtual bool bindInvariantDuringSolve() const { return false; }
+    // pcgIteration kept the search directions in buffers of its own: where p of the launch issued last lives (nullptr: in the caller's pNew)
+    virtual const T* iterCurrentP() const { return nullptr; }
     virtual T* unknownPtr(int img) const = 0;
     virtual void precompute(LaunchCtx&) {}                                   // ComputedArrays (solver.t:607-614)
     // partial sums of 1/2 sum r^2 over non-excluded, owned elements (solver.t:580-592, 715-725)

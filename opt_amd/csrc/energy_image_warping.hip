@@ -64,6 +64,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         (void)hipHostFree(hNotLattice); (void)hipEventDestroy(bindEvent);
         for (T* b : ring) if (b) (void)hipFree(b);
         (void)hipFree(A.flags); (void)hipFree(A.cs); if (alphaSlots) (void)hipFree(alphaSlots); (void)hipFree(dNotLattice);
+        if (lmQState) (void)hipFree(lmQState);
     }
     int flatGrid(long n) const { return (int)std::max<long>(1, std::min<long>((n + kBlock - 1) / kBlock, std::min<long>(kMaxPartials, (long)cus * 8))); }
 
@@ -247,7 +248,7 @@ struct ImageWarpingOps : EnergyOps<T> {
     static int iterBlock(bool lat, bool lmLoop) { return sizeof(T) == 8 ? 256 : lat ? 768 : lmLoop ? 512 : 768; }      // IterBlk<T, LATTICE, PRE, LM>::value of iterKernel's choice
     int occIter[4] = {0, 0, 0, 0};
     int iterFlip = 0, sinceExchange = 0, iterIndex = 0;
-    bool deferredTerm = false, lastLoopRfree = false;
+    bool deferredTerm = false, lastLoopRfree = false, lastLoopLmRing = false; int sinceTrueR = 0, lmPrN = 0; double* lmQState = nullptr;
     T* ring[3] = {nullptr, nullptr, nullptr}; const T* r0Ptr = nullptr; T* alphaSlots = nullptr;
     // What the loops do before their first launch: this bind's lattice verdict (the marching bind does not block for it); a PCGInit1 that ran on the previous
     // verdict and guessed "lattice" for an input that is none is redone.
@@ -289,29 +290,40 @@ struct ImageWarpingOps : EnergyOps<T> {
         int gy, rowsPerGroup;
         splitRows(Ax.yEnd - Ax.yBegin, gx, cus * occIter[L], gy, rowsPerGroup);
         // Gauss-Newton: delta every second launch, and no residual vector -- the state is a ring of three p buffers (ring[j % 3] holds p_j; the first two
-        // launches read the solver's r_0).  LM keeps r in memory and updates delta in every launch (Q needs it).
-        const bool gn = !lmLoop;
+        // launches read the solver's r_0).  LM on a unit lattice (round 6) runs on the same ring -- the two launches behind PCGInit1 or a split residual reset read the true r the
+        // solver holds -- and takes Q from the CG recurrence (iw_iter.h), so neither r nor b moves; delta is updated in every launch (an early-out must find it complete).
+        // LM with a general UrShape keeps r, CtC, M and b in memory.
+        const bool gn = !lmLoop, lmRing = lmLoop && lattice;
         const T *rOldPtr = a.rOld, *pOldPtr = a.pOld; T* pNewPtr = a.pNew; int rfreeFlag = 0, deltaMode = 0; const T* alphaIn = nullptr; T* alphaOut = nullptr;
-        if (gn) {
+        if (gn || lmRing) {
             const size_t bytes = ((size_t)A.W * A.H * 3 + 3) / 4 * 4 * sizeof(T);      // padded like the solver's vectors: its flat kernels read whole 16-byte packs of the last p
             for (int j = 0; j < 3; ++j) if (!ring[j]) { HIP_CHECK(hipMalloc((void**)&ring[j], bytes)); HIP_CHECK(hipMemsetAsync(ring[j], 0, bytes, ctx.stream)); }
-            if (a.first) r0Ptr = a.rOld;                       // the solver swaps its r buffers after every launch; this one keeps r_0 until launch 1 has read it
+            if (a.first || a.afterReset) { r0Ptr = a.rOld; sinceTrueR = 0; }      // the solver swaps its r buffers after every launch; this one keeps the true r until the second launch has read it
             const int k = iterIndex;
             pOldPtr = k == 0 ? a.pOld : ring[(k - 1) % 3];
-            rOldPtr = k <= 1 ? r0Ptr : ring[(k - 2) % 3];
+            rOldPtr = sinceTrueR <= 1 ? r0Ptr : ring[(k - 2) % 3];
             pNewPtr = ring[k % 3];
-            rfreeFlag = k <= 1 ? 2 : 1;
+            rfreeFlag = sinceTrueR <= 1 ? 2 : 1;
+            ++sinceTrueR;
             if (!alphaSlots) { HIP_CHECK(hipMalloc((void**)&alphaSlots, 4 * sizeof(T))); HIP_CHECK(hipMemsetAsync(alphaSlots, 0, 4 * sizeof(T), ctx.stream)); }   // [0,1] alpha, [2,3] beta, ping-pong
-            deltaMode = (k >= 2 && k % 2 == 0) ? 1 : 2;           // launch 0 has nothing to apply; odd launches defer
+            if (gn) deltaMode = (k >= 2 && k % 2 == 0) ? 1 : 2;           // launch 0 has nothing to apply; odd launches defer
             alphaOut = alphaSlots + (k & 1); alphaIn = alphaSlots + ((k & 1) ^ 1);
         }
-        lastLoopRfree = gn;
+        if (lmRing && !lmQState) {      // the running Q and the two sets of p . r partials (this launch's / the previous launch's)
+            HIP_CHECK(hipMalloc((void**)&lmQState, sizeof(double) * (1 + 2 * (size_t)kMaxPartials)));
+            HIP_CHECK(hipMemsetAsync(lmQState, 0, sizeof(double) * (1 + 2 * (size_t)kMaxPartials), ctx.stream));
+        }
+        lastLoopRfree = gn; lastLoopLmRing = lmRing;
         deferredTerm = gn && iterIndex >= 1 && iterIndex % 2 == 1;            // after an odd launch alpha_{k-1} p_{k-1} is still owed (pcgFinish / finishUpdate)
         IterK<T> K{};
         K.rOld = rOldPtr; K.pOld = pOldPtr; K.rNew = a.rNew; K.pNew = pNewPtr; K.delta = a.delta; K.deltaOut = a.deltaOut ? a.deltaOut : a.delta;
         K.pre = a.pre; K.first = a.first; K.deltaMode = deltaMode; K.alphaIn = alphaIn; K.alphaOut = alphaOut; K.rfree = rfreeFlag;
         K.CtC = a.CtC; K.b = a.b; K.q = a.q ? a.q->partials : nullptr; K.qTag = a.qTag; K.afterReset = a.afterReset;
         K.betaNum = a.betaNum.partials; K.nBetaNum = a.betaNum.n; K.betaDen = a.betaDen.partials; K.nBetaDen = a.betaDen.n;
+        if (lmRing) {
+            K.qState = lmQState; K.qInit = a.qInit;
+            K.pr = lmQState + 1 + (size_t)(iterIndex & 1) * kMaxPartials; K.prPrev = lmQState + 1 + (size_t)((iterIndex & 1) ^ 1) * kMaxPartials; K.nPr = lmPrN;
+        }
         K.lmRadius = a.lmRadius; K.lmMin = a.lmMinDiag; K.lmMax = a.lmMaxDiag;
         K.aNumPrev = a.aNumPrev.partials; K.aDenPrev = a.aDenPrev.partials; K.s2Prev = a.s2Prev.partials; K.s3Prev = a.s3Prev.partials;
         K.nNum = a.aNumPrev.n; K.nDen = a.aDenPrev.n; K.n2 = a.s2Prev.n; K.n3 = a.s3Prev.n;
@@ -333,9 +345,12 @@ struct ImageWarpingOps : EnergyOps<T> {
         iterFlip ^= 1;      // successive launches sweep top-down / bottom-up: a launch starts on the rows the previous one left in the caches
         ++iterIndex;
         a.aNum->n = a.aDen->n = a.s2->n = a.s3->n = gx * gy;
-        if (a.q) a.q->n = gx * gy;
+        if (a.q) a.q->n = lmRing ? 1 : gx * gy;      // (the recurrence's Q is one value, published by workgroup 0)
+        lmPrN = gx * gy;
         return true;
     }
+    // Where p of the last launch lives when the loop keeps its own buffers (the LM loop's reset and tail kernels read it)
+    const T* iterCurrentP() const override { return lastLoopLmRing && iterIndex >= 1 ? ring[(iterIndex - 1) % 3] : nullptr; }
     // Slab mode, after launch iterIndex - 1: the vectors whose ghost rows the neighbours must refresh -- the two newest search directions of the ring.
     int iterExchangeVectors(T** out) override {
         if (!lastLoopRfree || iterIndex < 1) return 0;

@@ -15,7 +15,14 @@
 // 64 pixels and produces the inner 60); three raw row buffers are requested three rows ahead and rotated by name; rows are addressed through buffer
 // descriptors (soffset = row, voffset = lane constant: no address VALU); successive launches sweep top-down / bottom-up (FLIP) so that a launch starts on the
 // rows the previous one left in the caches; MODE compiles the launch-to-launch state of the Gauss-Newton steady state in (1: odd launch, 2: even launch).
-// LM = true: A = J^T J + diag(CtC), the Q sums, r in memory, and the restart launch after a split residual reset (energy.h PcgIterArgs).
+// LM = true: A = J^T J + diag(CtC), the restart launch after a split residual reset (energy.h PcgIterArgs), and
+//   * general UrShape (PRE == 1): r, CtC, the preconditioner and b in memory, Q = 1/2 sum delta . (r + b) summed where delta is updated (solver.t:483-485);
+//   * unit lattice (PRE == 3, round 6): no residual vector either -- the ring of three p buffers as in Gauss-Newton (1 / M is the table's own denominator), true r only in
+//     the two launches behind PCGInit1 or a reset -- and no b: one CG step changes Q(delta) = b . delta - 1/2 delta^T A delta by alpha (p . r) - 1/2 alpha^2 (p . A p), and
+//     every launch sums p_k . r_k beside its four other sums (in exact arithmetic it equals alphaNum_k; summed directly it also holds behind a reset, whose fresh r is not
+//     orthogonal to the old p), so Q_k = Q_{k-1} + alpha_k (p_k . r_k - 1/2 alpha_k alphaDen_k) in the prologue of the launch that applies alpha_k.
+//     Thread 0 of workgroup 0 keeps the running Q (IterK::qState) and publishes it where the host's early-out test polls (one tagged word pair instead of one per
+//     workgroup, and at the START of the launch).  A reset re-anchors it to the host's direct sum (IterK::qInit).  89 -> 65 B/pixel.
 #pragma once
 #include "iw_device.h"
 
@@ -44,6 +51,8 @@ struct IterK {             // kernel argument block
     int deltaMode; const T* alphaIn; T* alphaOut;      // alpha_{k-2}, beta_{k-2} written by the previous launch ([0], [2]) / where this launch leaves its own
     int rfree;             // 0: r in memory (LM);  1: rOld holds p_{k-2}, r rebuilt;  2: first two launches -- rOld holds the solver's r_0, r is not written either
     const T* CtC; const T* b; double* q; unsigned qTag; int afterReset; const double* betaNum; int nBetaNum; const double* betaDen; int nBetaDen;      // LM
+    double* qState; double qInit;      // LM on a unit lattice (r-free): the running Q of the recurrence (one device double) / its value after a split residual reset (the host's direct sum)
+    const double* prPrev; int nPr; double* pr;      // ... and the partial sums of p . r the previous launch left / this launch leaves (device memory, the energy's own)
     T lmRadius, lmMin, lmMax;      // PRE == 3 with LM: CtC and the LM preconditioner are rebuilt from the flag byte
     const double *aNumPrev, *aDenPrev, *s2Prev, *s3Prev; int nNum, nDen, n2, n3;
     double *aNum, *aDen, *s2, *s3;
@@ -102,9 +111,10 @@ struct NewRow {            // one row of iteration k: p_k, r_k, M, and the shift
 
 template <class T, bool LATTICE, int PRE, bool FLIP, bool LM = false, int MODE = 0>
 __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), 1) void iw_pcgIter2(IWArgs<T> A, IterK<T> K, int rowsPerGroup, int gx, int gy) {
-    static_assert(MODE == 0 || !LM, "steady-state specialisations are Gauss-Newton only");
+    static_assert(MODE == 0 || !LM, "steady-state specialisations are Gauss-Newton only");      // (an LM steady-state variant was measured in round 6: 62.0 -> 62.7 us at 2048^2, not kept)
     static_assert(PRE >= 1 && PRE <= 3, "image_warping always preconditions (image_warping.t:10)");
     const int kDeltaMode = MODE == 1 ? 2 : MODE == 2 ? 1 : K.deltaMode, kRfree = MODE ? 1 : K.rfree;
+    constexpr bool LMRF = LM && PRE == 3;      // Levenberg-Marquardt without r and b in memory (see the header)
     constexpr int kBlk = IterBlk<T, LATTICE, PRE, LM>::value, kStripW = (kBlk / kWave) * kSpan2;
     __shared__ double scratch[5 * (kBlk / kWave + 1)];
     const long N = (long)A.W * A.H;
@@ -136,22 +146,32 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), 1) void iw_p
         const T bNum = (T)o2[0], bDen = (T)o2[1];
         beta = (bDen > T(0)) ? bNum / bDen : T(0);     // solver.t:544-547
     } else if (!first) {
-        const double* const ps[4] = {K.aNumPrev, K.aDenPrev, K.s2Prev, K.s3Prev}; const int ns[4] = {K.nNum, K.nDen, K.n2, K.n3}; double o4[4];
+        const double* const ps[4] = {K.aNumPrev, K.aDenPrev, K.s2Prev, K.s3Prev}; const int ns[4] = {K.nNum, K.nDen, K.n2, K.n3}; double o4[4]; double prD = 0;
         if (!LM && K.mail.words) {                     // slab mode: the sums were posted to this rank's mailbox by every rank and may still be in flight
             __shared__ double mailScr[4 + 1 + 64];
             pollMailSums<4>(K.mail, mailScr, o4);
+        } else if constexpr (LMRF) {                   // ... and p . r of the previous launch for the Q recurrence
+            const double* const ps5[5] = {K.aNumPrev, K.aDenPrev, K.s2Prev, K.s3Prev, K.prPrev}; const int ns5[5] = {K.nNum, K.nDen, K.n2, K.n3, K.nPr}; double o5[5];
+            sumPartialsN<5>(ps5, ns5, scratch, o5);
+            o4[0] = o5[0]; o4[1] = o5[1]; o4[2] = o5[2]; o4[3] = o5[3]; prD = o5[4];
         } else sumPartialsN<4>(ps, ns, scratch, o4);   // the four sums of the previous launch, loads in flight together
         const double aNumD = o4[0], aDenD = o4[1], s2 = o4[2], s3 = o4[3];
         const T aNum = (T)aNumD, aDen = (T)aDenD;
         alpha = (aDen > T(0)) ? aNum / aDen : T(0);
+        if (LMRF && blockIdx.x == 0 && threadIdx.x == 0) {      // Q of the iteration this launch applies, by the recurrence (header); the host polls word pair 0
+            const double qNow = K.qState[0] + (double)alpha * (prD - 0.5 * (double)alpha * aDenD);
+            K.qState[0] = qNow;
+            if (K.qTag) storeTaggedPartial(K.q, 0, qNow, K.qTag); else K.q[0] = qNow;
+        }
         // betaNumerator = sum M r_k^2 by expansion (energy.h); the reference's direct sum cannot be negative, so cancellation
         // noise below zero (residual dropping by >~1e3 in one iteration) is clamped away
         const double bNumD = fmax(aNumD - 2.0 * (double)alpha * s2 + (double)alpha * (double)alpha * s3, 0.0);
         beta = (aNum > T(0)) ? (T)bNumD / aNum : T(0);
     }
     if (K.alphaOut && blockIdx.x == 0 && threadIdx.x == 0) { K.alphaOut[0] = alpha; K.alphaOut[2] = beta; }
+    if (LMRF && (first || restart) && blockIdx.x == 0 && threadIdx.x == 0) K.qState[0] = first ? 0.0 : K.qInit;      // Q_0 = 0 (delta = 0) / the direct sum of the reset
     const T alpha2 = (kDeltaMode == 1) ? K.alphaIn[0] : T(0);
-    const bool reconR = !LM && kRfree == 1;
+    const bool reconR = (!LM || LMRF) && kRfree == 1;
     const T betaOlder = reconR ? K.alphaIn[2] : T(0);      // the beta of the previous launch: p_{k-1} = M r_{k-1} + betaOlder p_{k-2}
     auto phys = [&](int y) { return FLIP ? A.H - 1 - y : y; };   // sweep row -> image row
     const T w2 = A.w_reg * A.w_reg, wf2 = A.w_fit * A.w_fit;
@@ -173,7 +193,7 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), 1) void iw_p
             if (LM) {   // k_finalizeDiagonal (solver.t:631-664) on the table: SSq is the first outer iteration's guardedInvert(diag), and diag does not change
                 const T radius = K.lmRadius, unclamped = d * (T(1) / radius), clampMul = (T(1) / gi) / radius;
                 const T c = fmin(fmax(unclamped, K.lmMin * clampMul), K.lmMax * clampMul);
-                cTab[t] = c; mTab[t] = T(1) / (c + radius * unclamped);
+                cTab[t] = c; mTab[t] = T(1) / (c + radius * unclamped); iTab[t] = c + radius * unclamped;
             } else { mTab[t] = gi; iTab[t] = sq * sq; }
         }
         __syncthreads();
@@ -199,7 +219,7 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), 1) void iw_p
         if (PRE == 3) {
             o.mx = o.my = mTab[io]; o.ma = mTab[10 + cnt];
             if (LM) { o.cx = o.cy = cTab[io]; o.ca = cTab[10 + cnt]; }
-            else if (reconR) { ix = iy = iTab[io]; ia = iTab[10 + cnt]; }
+            if (reconR) { ix = iy = iTab[io]; ia = iTab[10 + cnt]; }
         } else if (PRE == 2) {      // M_a follows from the pairs of the row's first stencil evaluation (trip): until then the Angle part of a rebuilt r stays unscaled
             o.mx = o.my = mTab[io]; o.ma = 0;
             if (!LM && reconR) { ix = iy = iTab[io]; ia = T(1); }
@@ -208,7 +228,7 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), 1) void iw_p
             if (!LM && reconR) { ix = T(1) / o.mx; iy = T(1) / o.my; ia = T(1) / o.ma; }
         }
         if (!LM && LATTICE && kRfree) { o.p2x = w.ro.x; o.p2y = w.ro.y; o.p2a = w.ra; }      // (the general-UrShape kernel has no registers to spare: it reads p_{k-2} again)
-        if (!LM && reconR) {      // r_{k-1} = (p_{k-1} - beta p_{k-2}) / M: w.ro / w.ra were loaded from the p_{k-2} buffer
+        if (reconR) {      // r_{k-1} = (p_{k-1} - beta p_{k-2}) / M: w.ro / w.ra were loaded from the p_{k-2} buffer
             o.rx = (o.q.ox - betaOlder * w.ro.x) * ix; o.ry = (o.q.oy - betaOlder * w.ro.y) * iy; o.ra = (o.q.a - betaOlder * w.ra) * ia;
         }
     };
@@ -296,12 +316,12 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), 1) void iw_p
                 }
                 d.x += alpha * oB.q.ox; d.y += alpha * oB.q.oy; da += alpha * oB.q.a;
                 bufSt2(Bf.deltaOut, Bf.x2, s2, d.x, d.y); bufSt1(Bf.deltaOut, Bf.x1, s1a, da);
-                if (LM) {   // Q = 1/2 sum delta . (r + b) with the updated delta and r (solver.t:483-485)
+                if (LM && !LMRF) {   // Q = 1/2 sum delta . (r + b) with the updated delta and r (solver.t:483-485)
                     const V2<T> bo = bufLd2(Bf.b, Bf.x2, s2, tag); const T ba = bufLd1(Bf.b, Bf.x1, s1a, tag);
                     accQ += (double)(T(0.5) * (d.x * (rx + bo.x))) + (double)(T(0.5) * (d.y * (ry + bo.y))) + (double)(T(0.5) * (da * (ra + ba)));
                 }
             }
-            if (LM || !kRfree) { bufSt2(Bf.rNew, Bf.x2, s2, rx, ry); bufSt1(Bf.rNew, Bf.x1, s1a, ra); }
+            if (!kRfree) { bufSt2(Bf.rNew, Bf.x2, s2, rx, ry); bufSt1(Bf.rNew, Bf.x1, s1a, ra); }
             bufSt2(Bf.pNew, Bf.x2, s2, nC.q.ox, nC.q.oy); bufSt1(Bf.pNew, Bf.x1, s1a, nC.q.a);
         }
         Q<T> l2 = nB.lf, r2 = nB.rt;
@@ -311,6 +331,7 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), 1) void iw_p
         if (LM) { ox += nB.cx * nB.q.ox; oy += nB.cy * nB.q.oy; oa += nB.ca * nB.q.a; }
         if (live && writer && y >= yb && phys(y) >= K.ownBegin && phys(y) < K.ownEnd) {
             accDen += (double)(nB.q.ox * ox + nB.q.oy * oy + nB.q.a * oa);
+            if (LMRF) accQ += (double)nB.q.ox * (double)nB.rx + (double)nB.q.oy * (double)nB.ry + (double)nB.q.a * (double)nB.ra;      // p_k . r_k, exact products
             // sum M r^2, sum M r Ap, sum M Ap^2 of this row from shared double factors.  The expansion of the beta numerator cancels to as many digits as the residual
             // loses in one iteration, so every term is formed from the same M, r, A p in double, where a product of two floats is exact.
             const double mx = (double)nB.mx, my = (double)nB.my, ma = (double)nB.ma;
@@ -339,7 +360,8 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), 1) void iw_p
     blockReduceSumN<5>(v, scratch);
     if (threadIdx.x == 0) {
         K.aDen[blockIdx.x] = v[0]; K.aNum[blockIdx.x] = v[1]; K.s2[blockIdx.x] = v[2]; K.s3[blockIdx.x] = v[3];
-        if (LM) { if (K.qTag) storeTaggedPartial(K.q, blockIdx.x, v[4], K.qTag); else K.q[blockIdx.x] = v[4]; }
+        if (LMRF) K.pr[blockIdx.x] = v[4];
+        else if (LM) { if (K.qTag) storeTaggedPartial(K.q, blockIdx.x, v[4], K.qTag); else K.q[blockIdx.x] = v[4]; }
     }
     if (!LM && K.post.world) {      // slab mode: the last workgroup to finish posts the four sums (order of the consumer's poll: aNum, aDen, s2, s3) to every rank's mailbox
         double* const parts[4] = {K.aNum, K.aDen, K.s2, K.s3};

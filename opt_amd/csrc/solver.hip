@@ -717,14 +717,16 @@ struct PcgSolver : SolverBase {
         int cur = 0;
         bool afterReset = false, deltaOwed = false, issued = false, issuedRestart = false;
         Reduction bNumDirect{}, bDenDirect{};
+        double qDirect = 0;                                         // Q as the last split residual reset summed it (PcgIterArgs::qInit of the restart launch)
         unsigned tagOf[2] = {0, 0};                                 // tag of the Q partials in redQ / redQ2
+        auto pNow = [&]() -> const T* { const T* own = E->iterCurrentP(); return own ? own : p; };      // p of the launch adopted last (a kernel set may keep the directions in buffers of its own)
         // One launch from the current state into the alternate buffers (r2, p2, delta2, setS[cur]); adopted later by pointer swaps.
         auto issue = [&](int k, bool restart) -> bool {
             PcgIterArgs<T> a{};
             a.rOld = r; a.ApOld = Ap_X; a.pOld = p; a.rNew = r2; a.ApNew = Ap2; a.pNew = p2; a.delta = delta; a.deltaOut = delta2; a.pre = preArg; a.first = k == 0;
             a.aNumPrev = prev[0]; a.aDenPrev = prev[1]; a.s2Prev = prev[2]; a.s3Prev = prev[3];
             a.aNum = &setS[cur][0]; a.aDen = &setS[cur][1]; a.s2 = &setS[cur][2]; a.s3 = &setS[cur][3];
-            a.CtC = CtC; a.b = b; a.q = (k & 1) ? &redQ2 : &redQ; a.afterReset = restart ? 1 : 0; a.betaNum = bNumDirect; a.betaDen = bDenDirect;
+            a.CtC = CtC; a.b = b; a.q = (k & 1) ? &redQ2 : &redQ; a.afterReset = restart ? 1 : 0; a.betaNum = bNumDirect; a.betaDen = bDenDirect; a.qInit = qDirect;
             if (taggedQ) { if (++launchTag == 0) ++launchTag; a.qTag = tagOf[k & 1] = launchTag; } else tagOf[k & 1] = 0;      // (0: this launch writes plain partials)
             a.lmRadius = trust_region_radius; a.lmMinDiag = min_lm_diagonal; a.lmMaxDiag = max_lm_diagonal;
             issuedRestart = restart;
@@ -747,7 +749,7 @@ struct PcgSolver : SolverBase {
             const bool lastAndSilent = lIter + 1 >= sp.lIterations && verbosity == 0;
             auto resetKernels = [&](T* deltaOut) {
                 { ScopedKernel k(ctx, "PCGStep2_1stHalf");
-                  k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, deltaOut, p, nPacks, nullptr, prev[0].partials, prev[0].n, prev[1].partials, prev[1].n); }
+                  k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, deltaOut, pNow(), nPacks, nullptr, prev[0].partials, prev[0].n, prev[1].partials, prev[1].n); }
                 if (lastAndSilent) return;
                 E->applyJTJ(deltaOut, Adelta, CtC, nullptr, ctx);             // computeAdelta
                 { ScopedKernel k(ctx, "PCGStep2_2ndHalf");
@@ -779,7 +781,8 @@ struct PcgSolver : SolverBase {
                 // fetchQ (solver.t:1098).  After the last iteration its only effect is the message below: the loop ends either way, so the blocking
                 // read (one drain of the stream per outer iteration when residual_reset_period == lIterations, the default) happens only when someone is listening.
                 if (!lastAndSilent) {
-                    const T Q1 = (T)hostSum(redQR);
+                    qDirect = hostSum(redQR);
+                    const T Q1 = (T)qDirect;
                     const T zeta = T(lIter + 1) * (Q1 - Q0) / Q1;
                     if (zeta < q_tolerance) { if (verbosity > 0) printf("zeta=%.18g, breaking at iteration: %d\n", (double)zeta, lIter + 1); return true; }
                     Q0 = Q1;
@@ -789,7 +792,7 @@ struct PcgSolver : SolverBase {
         }
         if (deltaOwed) {   // the last iteration's delta += alpha p; its r, z, p and Q are dead (the reference's last fetchQ can only break a finished loop)
             ScopedKernel k(ctx, "PCGStep2_delta");
-            k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, delta, p, nPacks, nullptr, prev[0].partials, prev[0].n, prev[1].partials, prev[1].n);
+            k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, delta, pNow(), nPacks, nullptr, prev[0].partials, prev[0].n, prev[1].partials, prev[1].n);
         }
         return true;
     }

@@ -20,9 +20,9 @@ from helpers import assert_close, device_unknowns, flat_unknowns, hip_solver, or
 pytestmark = pytest.mark.gpu
 
 
-def _side_by_side(oracle_lib, P, nsteps, liters, cost_tol, x_tol, radius_tol, **controls):
+def _side_by_side(oracle_lib, P, nsteps, liters, cost_tol, x_tol, radius_tol, hip_only=None, **controls):
     o = oracle_solver(oracle_lib, P, "LMGPU", nIterations=nsteps, lIterations=liters, **controls)
-    g = hip_solver(P, "LMGPU", nIterations=nsteps, lIterations=liters, **controls)
+    g = hip_solver(P, "LMGPU", nIterations=nsteps, lIterations=liters, **controls, **(hip_only or {}))
     dev = api.to_device(P)
     Pref = P.clone()
     o.init(Pref.params); g.init(dev)
@@ -70,6 +70,30 @@ def test_image_warping_float_controls(oracle_lib, period, qtol):
     if qtol is not None:
         kw["q_tolerance"] = qtol
     _side_by_side(oracle_lib, P, 3, 10, 1e-5, None, 1e-3, **kw)
+
+
+@pytest.mark.parametrize("double", [True, False])
+@pytest.mark.parametrize("period,qtol,liters", [(1, None, 6), (2, None, 10), (3, None, 12), (3, 0.5, 10), (10, None, 25), (10, 0.05, 12), (4, 0.0, 9), (7, None, 23), (5, 5.0, 10),
+                                                (10, 0.01, 40), (6, 0.002, 60)])
+def test_image_warping_launch_per_iteration_loop_controls(oracle_lib, period, qtol, liters, double):
+    """The same controls on the launch-per-iteration LM loop ("amd_onchip" = 0: what images past the on-chip range run on -- the reference's LM-only large-image case,
+    examples/image_warping/src/main.cpp:121-129).  Round 6: on a unit lattice that loop keeps no residual vector (ring of three p buffers; true r only behind PCGInit1 and
+    behind a reset) and takes Q from the CG recurrence Q_k = Q_{k-1} + alpha_k (p_k . r_k - 1/2 alpha_k p_k . A p_k) instead of summing 1/2 delta . (r + b); a reset
+    re-anchors it to the direct sum.  Early-outs on, next to and between resets, restarts, long solves -- step for step beside the oracle, which sums Q directly."""
+    P = wl.image_warping(61, 47, double=double, random_state=5, mask_fraction=0.05, perturb=0.4)
+    kw = dict(residual_reset_period=period)
+    if qtol is not None:
+        kw["q_tolerance"] = qtol
+    if double:
+        _side_by_side(oracle_lib, P, 4, liters, 1e-10, 1e-9, 1e-8, hip_only=dict(amd_onchip=0), **kw)
+    else:
+        _side_by_side(oracle_lib, P, 3, liters, 1e-5, None, 1e-3, hip_only=dict(amd_onchip=0), **kw)
+    g = hip_solver(P, "LMGPU", timing=True, nIterations=1, lIterations=liters, amd_onchip=0, **kw)
+    dev = api.to_device(P)
+    g.init(dev); g.step(dev)
+    kt = g.kernel_timings()
+    g.close()
+    assert "PCGIteration" in kt and "PCGSolveOnChip" not in kt, kt.keys()
 
 
 @pytest.mark.parametrize("period,qtol,liters", [(1, None, 6), (2, None, 10), (3, 0.5, 10), (10, None, 10), (10, 0.05, 12), (4, 0.0, 9), (5, 5.0, 10)])
