@@ -116,6 +116,10 @@ struct EnergyOps {
     virtual bool bindInvariantDuringSolve() const { return false; }
     // pcgIteration kept the search directions in buffers of its own: where p of the launch issued last lives (nullptr: in the caller's pNew)
     virtual const T* iterCurrentP() const { return nullptr; }
+    // LM loop: did the launch issued last write deltaOut (a kernel set that pairs its delta updates writes it every second launch) ...
+    virtual bool iterWroteDelta() const { return true; }
+    // ... and the term such a launch left owed, added to `delta` in place (issuedBeyond: launches issued after the one meant -- the solver's speculative next launch)
+    virtual void iterFlushDelta(T* /*delta*/, int /*issuedBeyond*/, LaunchCtx&) {}
     virtual T* unknownPtr(int img) const = 0;
     virtual void precompute(LaunchCtx&) {}                                   // ComputedArrays (solver.t:607-614)
     // partial sums of 1/2 sum r^2 over non-excluded, owned elements (solver.t:580-592, 715-725)

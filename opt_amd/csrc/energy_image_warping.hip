@@ -240,7 +240,7 @@ struct ImageWarpingOps : EnergyOps<T> {
     // ---- one launch per PCG iteration (iw_iter.h) ---------------------------------------------------------------------------------------------------------------------
     static const void* iterKernel(bool lat, bool lmLoop, bool flip, int mode) {      // mode: 0 launch state from the arguments, 1 / 2 steady state of the Gauss-Newton loop (odd / even launch)
 #define IWK(LAT, PRE, LMV, MODE) (flip ? (const void*)iw_pcgIter2<T, LAT, PRE, true, LMV, MODE> : (const void*)iw_pcgIter2<T, LAT, PRE, false, LMV, MODE>)
-        if (lmLoop) return lat ? IWK(true, 3, true, 0) : IWK(false, 1, true, 0);
+        if (lmLoop) return lat ? (mode == 1 ? IWK(true, 3, true, 1) : mode == 2 ? IWK(true, 3, true, 2) : IWK(true, 3, true, 0)) : IWK(false, 1, true, 0);
         if (lat) return mode == 1 ? IWK(true, 3, false, 1) : mode == 2 ? IWK(true, 3, false, 2) : IWK(true, 3, false, 0);
         return mode == 1 ? IWK(false, 2, false, 1) : mode == 2 ? IWK(false, 2, false, 2) : IWK(false, 2, false, 0);
 #undef IWK
@@ -248,7 +248,8 @@ struct ImageWarpingOps : EnergyOps<T> {
     static int iterBlock(bool lat, bool lmLoop) { return sizeof(T) == 8 ? 256 : lat ? 768 : lmLoop ? 512 : 768; }      // IterBlk<T, LATTICE, PRE, LM>::value of iterKernel's choice
     int occIter[4] = {0, 0, 0, 0};
     int iterFlip = 0, sinceExchange = 0, iterIndex = 0;
-    bool deferredTerm = false, lastLoopRfree = false, lastLoopLmRing = false; int sinceTrueR = 0, lmPrN = 0; double* lmQState = nullptr;
+    bool deferredTerm = false, lastLoopRfree = false, lastLoopLmRing = false, lastWroteDelta = true; int sinceTrueR = 0, lmPrN = 0; double* lmQState = nullptr;
+    const T* owedP[2] = {nullptr, nullptr};
     T* ring[3] = {nullptr, nullptr, nullptr}; const T* r0Ptr = nullptr; T* alphaSlots = nullptr;
     // What the loops do before their first launch: this bind's lattice verdict (the marching bind does not block for it); a PCGInit1 that ran on the previous
     // verdict and guessed "lattice" for an input that is none is redone.
@@ -304,15 +305,18 @@ struct ImageWarpingOps : EnergyOps<T> {
             rOldPtr = sinceTrueR <= 1 ? r0Ptr : ring[(k - 2) % 3];
             pNewPtr = ring[k % 3];
             rfreeFlag = sinceTrueR <= 1 ? 2 : 1;
-            ++sinceTrueR;
             if (!alphaSlots) { HIP_CHECK(hipMalloc((void**)&alphaSlots, 4 * sizeof(T))); HIP_CHECK(hipMemsetAsync(alphaSlots, 0, 4 * sizeof(T), ctx.stream)); }   // [0,1] alpha, [2,3] beta, ping-pong
-            if (gn) deltaMode = (k >= 2 && k % 2 == 0) ? 1 : 2;           // launch 0 has nothing to apply; odd launches defer
+            deltaMode = (sinceTrueR >= 2 && sinceTrueR % 2 == 0) ? 1 : 2;      // the launch behind PCGInit1 / a reset has nothing to apply; odd launches defer
+            // what this launch leaves owed to delta (LM: the solver has it added before a reset, an early-out or the end of the loop -- iterFlushDelta)
+            owedP[k & 1] = (lmRing && sinceTrueR % 2 == 1) ? pOldPtr : nullptr; lastWroteDelta = !lmRing || deltaMode == 1;
+            ++sinceTrueR;
             alphaOut = alphaSlots + (k & 1); alphaIn = alphaSlots + ((k & 1) ^ 1);
         }
         if (lmRing && !lmQState) {      // the running Q and the two sets of p . r partials (this launch's / the previous launch's)
             HIP_CHECK(hipMalloc((void**)&lmQState, sizeof(double) * (1 + 2 * (size_t)kMaxPartials)));
             HIP_CHECK(hipMemsetAsync(lmQState, 0, sizeof(double) * (1 + 2 * (size_t)kMaxPartials), ctx.stream));
         }
+        if (!gn && !lmRing) lastWroteDelta = true;
         lastLoopRfree = gn; lastLoopLmRing = lmRing;
         deferredTerm = gn && iterIndex >= 1 && iterIndex % 2 == 1;            // after an odd launch alpha_{k-1} p_{k-1} is still owed (pcgFinish / finishUpdate)
         IterK<T> K{};
@@ -339,7 +343,7 @@ struct ImageWarpingOps : EnergyOps<T> {
             int rpg = rowsPerGroup, gxa = gx, gya = gy;
             void* kargs[] = {(void*)&Ax, (void*)&K, (void*)&rpg, (void*)&gxa, (void*)&gya};
             // from the third launch of a Gauss-Newton solve on the launch state alternates between two values: compiled in
-            const int mode = (gn && rfreeFlag == 1 && !a.first && !K.deltaZero) ? (deltaMode == 2 ? 1 : 2) : 0;
+            const int mode = ((gn || lmRing) && rfreeFlag == 1 && !a.first && !a.afterReset && !K.deltaZero) ? (deltaMode == 2 ? 1 : 2) : 0;
             HIP_CHECK(hipLaunchKernel(iterKernel(lattice, lmLoop, iterFlip != 0, mode), dim3(gx * gy), dim3(blk), kargs, 0, ctx.stream));
         }
         iterFlip ^= 1;      // successive launches sweep top-down / bottom-up: a launch starts on the rows the previous one left in the caches
@@ -351,6 +355,15 @@ struct ImageWarpingOps : EnergyOps<T> {
     }
     // Where p of the last launch lives when the loop keeps its own buffers (the LM loop's reset and tail kernels read it)
     const T* iterCurrentP() const override { return lastLoopLmRing && iterIndex >= 1 ? ring[(iterIndex - 1) % 3] : nullptr; }
+    bool iterWroteDelta() const override { return lastWroteDelta; }
+    // delta += the term the launch `issuedBeyond` before the one issued last left owed (a deferring launch of the paired LM loop), if any
+    void iterFlushDelta(T* delta, int issuedBeyond, LaunchCtx& ctx) override {
+        const int idx = iterIndex - 1 - issuedBeyond;
+        if (!lastLoopLmRing || idx < 0 || !owedP[idx & 1]) return;
+        ScopedKernel k(ctx, "PCGStep2_delta");
+        const long n = 3L * A.W * A.H;
+        iw_axpyDeferred<T><<<flatGrid(n), kBlock, 0, ctx.stream>>>(delta, owedP[idx & 1], alphaSlots + (idx & 1), n);
+    }
     // Slab mode, after launch iterIndex - 1: the vectors whose ghost rows the neighbours must refresh -- the two newest search directions of the ring.
     int iterExchangeVectors(T** out) override {
         if (!lastLoopRfree || iterIndex < 1) return 0;

@@ -22,7 +22,9 @@
 //     every launch sums p_k . r_k beside its four other sums (in exact arithmetic it equals alphaNum_k; summed directly it also holds behind a reset, whose fresh r is not
 //     orthogonal to the old p), so Q_k = Q_{k-1} + alpha_k (p_k . r_k - 1/2 alpha_k alphaDen_k) in the prologue of the launch that applies alpha_k.
 //     Thread 0 of workgroup 0 keeps the running Q (IterK::qState) and publishes it where the host's early-out test polls (one tagged word pair instead of one per
-//     workgroup, and at the START of the launch).  A reset re-anchors it to the host's direct sum (IterK::qInit).  89 -> 65 B/pixel.
+//     workgroup, and at the START of the launch).  A reset re-anchors it to the host's direct sum (IterK::qInit).  With Q off delta's back, delta is paired as in
+//     Gauss-Newton (written by every second launch into the other buffer, so an early-out still finds the old one; the term a deferring launch owes is added by
+//     the solver before a reset, an early-out or the end of the loop: EnergyOps::iterFlushDelta).  89 -> 53 B/pixel.
 #pragma once
 #include "iw_device.h"
 
@@ -111,7 +113,7 @@ struct NewRow {            // one row of iteration k: p_k, r_k, M, and the shift
 
 template <class T, bool LATTICE, int PRE, bool FLIP, bool LM = false, int MODE = 0>
 __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), 1) void iw_pcgIter2(IWArgs<T> A, IterK<T> K, int rowsPerGroup, int gx, int gy) {
-    static_assert(MODE == 0 || !LM, "steady-state specialisations are Gauss-Newton only");      // (an LM steady-state variant was measured in round 6: 62.0 -> 62.7 us at 2048^2, not kept)
+    static_assert(MODE == 0 || !LM || PRE == 3, "steady-state specialisations: the r-free loops (Gauss-Newton; Levenberg-Marquardt on a unit lattice)");
     static_assert(PRE >= 1 && PRE <= 3, "image_warping always preconditions (image_warping.t:10)");
     const int kDeltaMode = MODE == 1 ? 2 : MODE == 2 ? 1 : K.deltaMode, kRfree = MODE ? 1 : K.rfree;
     constexpr bool LMRF = LM && PRE == 3;      // Levenberg-Marquardt without r and b in memory (see the header)
@@ -139,7 +141,7 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), 1) void iw_p
     IterRaw<T> rwA = loadRow(yb), rwB = loadRow(yb + 1), rwC = loadRow(yb + 2);
     T alpha = 0, beta = 0;
     const bool first = MODE ? false : K.first != 0;
-    const bool restart = LM && K.afterReset != 0;      // r and delta are already those of this iteration (split residual reset)
+    const bool restart = LM && MODE == 0 && K.afterReset != 0;      // r and delta are already those of this iteration (split residual reset)
     if (restart) {
         const double* const ps[2] = {K.betaNum, K.betaDen}; const int ns[2] = {K.nBetaNum, K.nBetaDen}; double o2[2];
         sumPartialsN<2>(ps, ns, scratch, o2);
@@ -227,7 +229,7 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), 1) void iw_p
             o.mx = w.mo.x; o.my = w.mo.y; o.ma = w.ma;
             if (!LM && reconR) { ix = T(1) / o.mx; iy = T(1) / o.my; ia = T(1) / o.ma; }
         }
-        if (!LM && LATTICE && kRfree) { o.p2x = w.ro.x; o.p2y = w.ro.y; o.p2a = w.ra; }      // (the general-UrShape kernel has no registers to spare: it reads p_{k-2} again)
+        if ((!LM || LMRF) && LATTICE && kRfree) { o.p2x = w.ro.x; o.p2y = w.ro.y; o.p2a = w.ra; }      // (the general-UrShape kernel has no registers to spare: it reads p_{k-2} again)
         if (reconR) {      // r_{k-1} = (p_{k-1} - beta p_{k-2}) / M: w.ro / w.ra were loaded from the p_{k-2} buffer
             o.rx = (o.q.ox - betaOlder * w.ro.x) * ix; o.ry = (o.q.oy - betaOlder * w.ro.y) * iy; o.ra = (o.q.a - betaOlder * w.ra) * ia;
         }
@@ -257,9 +259,9 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), 1) void iw_p
     T vOldM = 0, unusedM = 0;                     // ... and, for M_a, the neighbour-side term of the p_{k-1} stream's vertical pair
     // The delta of the row a trip updates (y + 1) is requested one trip ahead, before that trip's prefetch of a raw row: by the time it is used a whole trip
     // has passed and the wait leaves the younger requests in flight, where a request at the point of use is the newest one and its wait (vmcnt(0)) drains
-    // the whole queue once per row.  Every launch of the LM loop and the even launches of the Gauss-Newton steady state (MODE 2) update delta in every
+    // the whole queue once per row.  Every launch of the general-UrShape LM loop and the even launches of the r-free steady states (MODE 2) update delta in every
     // trip and take this form; the others read it where they use it.
-    constexpr bool kDeltaEarly = MODE == 2 || LM;
+    constexpr bool kDeltaEarly = MODE == 2 || (LM && !LMRF);
     struct DeltaPre { V2<T> o; T a; };
     auto loadDelta = [&](int y1) {
         DeltaPre d{V2<T>{0, 0}, 0};
@@ -307,9 +309,9 @@ __global__ __launch_bounds__((IterBlk<T, LATTICE, PRE, LM>::value), 1) void iw_p
                 else { d = bufLd2(Bf.delta, Bf.x2, s2, tag); da = bufLd1(Bf.delta, Bf.x1, s1a, tag); }
                 if (MODE == 0 && K.deltaZero) { d.x = 0; d.y = 0; da = 0; }      // first delta update of a linear solve whose PCGInit1 left the buffer untouched
                 if (kDeltaMode == 1) {
-                    if (!LM && LATTICE && kRfree == 1) { d.x += alpha2 * oB.p2x; d.y += alpha2 * oB.p2y; da += alpha2 * oB.p2a; }      // p_{k-2} kept from the load: exact
+                    if ((!LM || LMRF) && LATTICE && kRfree == 1) { d.x += alpha2 * oB.p2x; d.y += alpha2 * oB.p2y; da += alpha2 * oB.p2a; }      // p_{k-2} kept from the load: exact
                     else {      // p_{k-2} from memory: the buffer read through rOld (r-free ring), or the p buffer about to be overwritten
-                        const __amdgpu_buffer_rsrc_t qb = (!LM && kRfree) ? Bf.rOld : Bf.pNew;
+                        const __amdgpu_buffer_rsrc_t qb = ((!LM || LMRF) && kRfree) ? Bf.rOld : Bf.pNew;
                         const V2<T> q = bufLd2(qb, Bf.x2, s2, tag); const T qa = bufLd1(qb, Bf.x1, s1a, tag);
                         d.x += alpha2 * q.x; d.y += alpha2 * q.y; da += alpha2 * qa;
                     }

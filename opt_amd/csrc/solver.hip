@@ -738,7 +738,9 @@ struct PcgSolver : SolverBase {
             // adopt launch lIter
             const bool appliedStep2 = lIter > 0 && !issuedRestart;    // it finished iteration lIter-1 (delta, r, z, p) and summed Q_{lIter-1}
             std::swap(r, r2); std::swap(p, p2); std::swap(Ap_X, Ap2);
-            if (appliedStep2) std::swap(delta, delta2);
+            if (appliedStep2 && E->iterWroteDelta()) std::swap(delta, delta2);      // (a kernel set that pairs its delta updates writes every second launch; what a deferring launch owes: flushOwed)
+            bool owedFlushed = false;
+            auto flushOwed = [&](int issuedBeyond) { if (!owedFlushed && appliedStep2) { E->iterFlushDelta(delta, issuedBeyond, ctx); owedFlushed = true; } };
             for (int i = 0; i < 4; ++i) prev[i] = setS[cur][i];
             cur ^= 1;
             afterReset = false;
@@ -748,6 +750,7 @@ struct PcgSolver : SolverBase {
             // reference's computeAdelta and second half are not run then.
             const bool lastAndSilent = lIter + 1 >= sp.lIterations && verbosity == 0;
             auto resetKernels = [&](T* deltaOut) {
+                flushOwed(0);      // delta complete through iteration lIter - 1 (also what an early-out decided below must find)
                 { ScopedKernel k(ctx, "PCGStep2_1stHalf");
                   k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, deltaOut, pNow(), nPacks, nullptr, prev[0].partials, prev[0].n, prev[1].partials, prev[1].n); }
                 if (lastAndSilent) return;
@@ -770,7 +773,11 @@ struct PcgSolver : SolverBase {
                     taggedQ = false; //  plan reads Q through the stream (beginHostSum / endHostSum) from here on, so the later early-out tests are real again
                 } else {
                     const T zeta = T(lIter) * (Q1 - Q0) / Q1;
-                    if (zeta < q_tolerance) { if (verbosity > 0) printf("zeta=%.18g, breaking at iteration: %d\n", (double)zeta, lIter); return true; }
+                    if (zeta < q_tolerance) {
+                        if (verbosity > 0) printf("zeta=%.18g, breaking at iteration: %d\n", (double)zeta, lIter);
+                        flushOwed(issued ? 1 : 0);
+                        return true;
+                    }
                     Q0 = Q1;
                 }
             }
@@ -791,6 +798,7 @@ struct PcgSolver : SolverBase {
             }
         }
         if (deltaOwed) {   // the last iteration's delta += alpha p; its r, z, p and Q are dead (the reference's last fetchQ can only break a finished loop)
+            E->iterFlushDelta(delta, 0, ctx);      // (... behind the term a deferring last launch left owed)
             ScopedKernel k(ctx, "PCGStep2_delta");
             k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, delta, pNow(), nPacks, nullptr, prev[0].partials, prev[0].n, prev[1].partials, prev[1].n);
         }
