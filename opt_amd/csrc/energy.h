@@ -120,6 +120,8 @@ struct EnergyOps {
     virtual bool iterWroteDelta() const { return true; }
     // ... and the term such a launch left owed, added to `delta` in place (issuedBeyond: launches issued after the one meant -- the solver's speculative next launch)
     virtual void iterFlushDelta(T* /*delta*/, int /*issuedBeyond*/, LaunchCtx&) {}
+    // ... or handed to a solver kernel that adds it in its own pass: *p, *alpha[0] (false: nothing owed)
+    virtual bool iterOwedTerm(int /*issuedBeyond*/, const T** /*p*/, const T** /*alpha*/) const { return false; }
     virtual T* unknownPtr(int img) const = 0;
     virtual void precompute(LaunchCtx&) {}                                   // ComputedArrays (solver.t:607-614)
     // partial sums of 1/2 sum r^2 over non-excluded, owned elements (solver.t:580-592, 715-725)
@@ -145,6 +147,9 @@ struct EnergyOps {
     // CtC = clamped diag(J^T J) / radius, the LM preconditioner, b = r, p = M r, delta = 0, SSq (first outer iteration), partial sums of r . p.  false: the solver
     // runs evalJTF and its flat pass.
     virtual bool evalJTFInitLM(const LmInitArgs<T>& /*args*/, LaunchCtx&) { return false; }
+    // LM's split residual reset behind delta += alpha p (solver.t:1079-1083): Adelta = (J^T J + CtC) delta and r = b - Adelta, z = M r, the partial sums of r . z and of
+    // Q = 1/2 delta . (r + b) -- in one pass where the kernel set can (false: applyJTJ + the solver's k_step2SecondHalf)
+    virtual bool applyJTJResetLM(const T* /*delta*/, T* /*r*/, const T* /*b*/, const T* /*pre*/, T* /*z*/, const T* /*CtC*/, Reduction& /*bNum*/, Reduction& /*q*/, LaunchCtx&) { return false; }
     // Optional: the end of a single-kernel Gauss-Newton loop in one pass over the unknowns -- whatever pcgFinish would still add to delta, the last iteration's
     // delta += alpha p (alpha = sum aNum / sum aDen, guarded) and PCGLinearUpdate X += delta.  delta itself is dead afterwards and need not be written.
     // true: the unknowns are updated (the solver skips pcgFinish, the last PCGStep2 and PCGLinearUpdate).

@@ -230,6 +230,24 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (this->slab.active) iw_zeroGhost<T><<<divUp(A.W, kBlock), kBlock, 0, ctx.stream>>>(A, out);
     }
     void applyJTJ(const T* v, T* out, const T* CtC, Reduction* dot, LaunchCtx& ctx) override { launchApply(v, out, CtC, dot, ctx, nullptr); }
+    // computeAdelta + PCGStep2_2ndHalf of LM's split residual reset (solver.t:1079-1083) in one march: A delta is consumed where it is formed (single GPU)
+    int occReset = 0;
+    bool applyJTJResetLM(const T* delta, T* r, const T* b, const T* pre, T* z, const T* CtC, Reduction& bNum, Reduction& q, LaunchCtx& ctx) override {
+        if (this->slab.active || !pre || !CtC) return false;
+        if (occReset == 0) {
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occReset, (const void*)iw_applyJTJ<T, true, false, true>, kBlock, 0));
+            occReset = std::max(1, std::min(occReset, 8));
+        }
+        const int gx = divUp(A.W, kStrip);
+        int gy, rowsPerGroup;
+        splitRows(A.yEnd - A.yBegin, gx, cus * occReset, gy, rowsPerGroup);
+        FuseArgs<T> F{};
+        F.resetB = b; F.resetPre = pre; F.resetR = r; F.resetZ = z; F.resetBNum = bNum.partials; F.resetQ = q.partials;
+        ScopedKernel k(ctx, "PCGStep1+PCGStep2_2ndHalf");
+        iw_applyJTJ<T, true, false, true><<<gx * gy, kBlock, 0, ctx.stream>>>(A, delta, nullptr, CtC, nullptr, rowsPerGroup, gx, gy, F);
+        bNum.n = gx * gy; q.n = gx * gy;
+        return true;
+    }
     bool applyJTJFused(const T* pOld, const T* z, T* pNew, T* out, const T* CtC, Reduction* dot, const Reduction& bNum, const double* aNumOld,
                        double* aNumNext, LaunchCtx& ctx) override {
         FuseArgs<T> F{z, pNew, bNum.partials, bNum.n, aNumOld, aNumNext};
@@ -357,12 +375,18 @@ struct ImageWarpingOps : EnergyOps<T> {
     const T* iterCurrentP() const override { return lastLoopLmRing && iterIndex >= 1 ? ring[(iterIndex - 1) % 3] : nullptr; }
     bool iterWroteDelta() const override { return lastWroteDelta; }
     // delta += the term the launch `issuedBeyond` before the one issued last left owed (a deferring launch of the paired LM loop), if any
-    void iterFlushDelta(T* delta, int issuedBeyond, LaunchCtx& ctx) override {
+    bool iterOwedTerm(int issuedBeyond, const T** p, const T** alpha) const override {
         const int idx = iterIndex - 1 - issuedBeyond;
-        if (!lastLoopLmRing || idx < 0 || !owedP[idx & 1]) return;
+        if (!lastLoopLmRing || idx < 0 || !owedP[idx & 1]) return false;
+        *p = owedP[idx & 1]; *alpha = alphaSlots + (idx & 1);
+        return true;
+    }
+    void iterFlushDelta(T* delta, int issuedBeyond, LaunchCtx& ctx) override {
+        const T *p = nullptr, *alpha = nullptr;
+        if (!iterOwedTerm(issuedBeyond, &p, &alpha)) return;
         ScopedKernel k(ctx, "PCGStep2_delta");
         const long n = 3L * A.W * A.H;
-        iw_axpyDeferred<T><<<flatGrid(n), kBlock, 0, ctx.stream>>>(delta, owedP[idx & 1], alphaSlots + (idx & 1), n);
+        iw_axpyDeferred<T><<<flatGrid(n), kBlock, 0, ctx.stream>>>(delta, p, alpha, n);
     }
     // Slab mode, after launch iterIndex - 1: the vectors whose ghost rows the neighbours must refresh -- the two newest search directions of the ring.
     int iterExchangeVectors(T** out) override {

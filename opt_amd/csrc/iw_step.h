@@ -165,6 +165,8 @@ struct FuseArgs {            // the PCGStep3 inputs when fused (see k_step3 in s
     const T* z; T* vNew;
     const double* bNumPartials; int nB;
     const double* aNumOld; double* aNumNext;
+    // RESET (the tail of LM's split residual reset in the same pass, solver.hip k_step2SecondHalf): r = b - A v, z = M r, partial sums of r . z and of 1/2 v . (r + b)
+    const T* resetB = nullptr; const T* resetPre = nullptr; T* resetR = nullptr; T* resetZ = nullptr; double* resetBNum = nullptr; double* resetQ = nullptr;
 };
 
 template <class T, bool FUSE>
@@ -206,9 +208,12 @@ __device__ __forceinline__ void iw_pair(const Px<T>& c, const Px<T>& n, T& accOx
 constexpr int kSpan = kWave - 2;                    // output pixels per wave per row
 constexpr int kStrip = (kBlock / kWave) * kSpan;    // output pixels per workgroup per row (248)
 
-template <class T, bool LM, bool FUSE>
+// RESET (LM, not FUSE): v = delta; instead of storing A v the pass finishes the split residual reset (solver.t:505-534) -- what k_step2SecondHalf would do in a second pass
+// over five vectors.
+template <class T, bool LM, bool FUSE, bool RESET = false>
 __global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ CtC,
                                                       double* __restrict__ partials, int rowsPerGroup, int gx, int gy, FuseArgs<T> F) {
+    static_assert(!RESET || (LM && !FUSE), "the reset tail belongs to the LM loop's plain J^T J pass");
     __shared__ double scratch[kBlock / kWave + 1];
     const int bx = blockIdx.x % gx, by = blockIdx.x / gx;
     const bool idle = by >= gy;
@@ -217,6 +222,10 @@ __global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __re
     const V2<T>* zO = (const V2<T>*)F.z; const T* za = F.z + 2 * N;
     V2<T>* nO = (V2<T>*)F.vNew; T* na = F.vNew + 2 * N;
     V2<T>* outO = (V2<T>*)out; T* outA = out + 2 * N;
+    const V2<T>* bO = (const V2<T>*)F.resetB; const T* bA = RESET ? F.resetB + 2 * N : nullptr;
+    const V2<T>* mO = (const V2<T>*)F.resetPre; const T* mA = RESET ? F.resetPre + 2 * N : nullptr;
+    V2<T>* rsO = (V2<T>*)F.resetR; T* rsA = RESET ? F.resetR + 2 * N : nullptr; V2<T>* zO2 = (V2<T>*)F.resetZ; T* zA2 = RESET ? F.resetZ + 2 * N : nullptr;
+    double accQ = 0;
     T beta = 0;
     if (FUSE) {   // solver.t:541-547
         const double bSum = sumPartials(F.bNumPartials, F.nB, scratch);
@@ -246,6 +255,11 @@ __global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __re
         const long i = (long)y * A.W + x;
         if (FUSE && writer && live && y + 1 < A.H && (y + 1 < ye || y + 1 == A.yEnd)) { const long j = i + A.W; nO[j] = V2<T>{dn.ox, dn.oy}; na[j] = dn.a; }
         const Px<T> lf = dppShiftPx<true>(cur), rt = dppShiftPx<false>(cur);
+        V2<T> bo{0, 0}, mo{0, 0}; T ba = 0, ma = 0;
+        if (RESET) {      // requested before the row's arithmetic, used behind it
+            const long ir = (writer && live) ? i : 0;
+            bo = bO[ir]; ba = bA[ir]; mo = mO[ir]; ma = mA[ir];
+        }
         T ax = 0, ay = 0, aa = 0;
         iw_pair(cur, rt, ax, ay, aa);
         iw_pair(cur, lf, ax, ay, aa);
@@ -261,7 +275,15 @@ __global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __re
         }
         const bool act = (cur.f & kActive) != 0;       // excluded / non-existent centre: row of J^T J is 0 (solver.t:424)
         rx = act ? rx : T(0); ry = act ? ry : T(0); ra = act ? ra : T(0);
-        if (writer && live) {
+        if (RESET) {
+            if (writer && live) {
+                const T r0 = bo.x - rx, r1 = bo.y - ry, r2 = ba - ra;       // r = b - A delta
+                const T z0 = mo.x * r0, z1 = mo.y * r1, z2 = ma * r2;       // z = M r
+                rsO[i] = V2<T>{r0, r1}; rsA[i] = r2; zO2[i] = V2<T>{z0, z1}; zA2[i] = z2;
+                acc += (double)(z0 * r0) + (double)(z1 * r1) + (double)(z2 * r2);
+                accQ += (double)(T(0.5) * (cur.ox * (r0 + bo.x))) + (double)(T(0.5) * (cur.oy * (r1 + bo.y))) + (double)(T(0.5) * (cur.a * (r2 + ba)));
+            }
+        } else if (writer && live) {
             acc += (double)(cur.ox * rx + cur.oy * ry + cur.a * ra);
             outO[i] = V2<T>{rx, ry}; outA[i] = ra;
         }
@@ -279,7 +301,12 @@ __global__ __launch_bounds__(kBlock) void iw_applyJTJ(IWArgs<T> A, const T* __re
         row(y + 1, rB, y + 1 < ye);
     }
     double t = blockReduceSum(acc, scratch);
-    if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
+    if (RESET) {
+        if (threadIdx.x == 0) F.resetBNum[blockIdx.x] = t;
+        __syncthreads();
+        const double tq = blockReduceSum(accQ, scratch);
+        if (threadIdx.x == 0) F.resetQ[blockIdx.x] = tq;
+    } else if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
 }
 
 // ---- the once-per-Gauss-Newton-step passes as row-marching kernels (round 3) ------------------------------------------------------

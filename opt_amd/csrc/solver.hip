@@ -162,16 +162,25 @@ __global__ __launch_bounds__(kBlock) void k_step2(T* __restrict__ delta, const T
 // deltaOut may be delta (in place) or another vector (the caller then decides later which of the two it keeps).  alphaNumerator is either a
 // finished total (aNumTotal, nNum == 0) or partial sums this kernel adds up itself -- the same sumPartials over kBlock threads as
 // k_finalizeSum, so the same bits, one launch less.
+// pOwed / alphaOwed (may be null): a term alphaOwed[0] * pOwed that an earlier launch left owed to delta (EnergyOps::iterOwedTerm) is added first -- the reference's
+// order of additions, one pass instead of two.
 template <class T>
 __global__ __launch_bounds__(kBlock) void k_step2FirstHalf(const T* delta, T* deltaOut, const T* __restrict__ p, long nPacks, const double* __restrict__ aNumTotal,
-                                                           const double* __restrict__ aNumPartials, int nNum, const double* __restrict__ aDenPartials, int nDen) {
+                                                           const double* __restrict__ aNumPartials, int nNum, const double* __restrict__ aDenPartials, int nDen,
+                                                           const T* __restrict__ pOwed = nullptr, const T* __restrict__ alphaOwed = nullptr) {
     __shared__ double scratch[kBlock / kWave + 1];
     constexpr int N = PackN<T>::N;
     const T aDen = (T)sumPartials(aDenPartials, nDen, scratch);
     const T aNum = nNum > 0 ? (T)sumPartials(aNumPartials, nNum, scratch) : (T)aNumTotal[0];
     const T alpha = (aDen > T(0)) ? aNum / aDen : T(0);
+    const T a2 = pOwed ? alphaOwed[0] : T(0);
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nPacks; i += (long)gridDim.x * blockDim.x) {
         Pack<T> D = ((const Pack<T>*)delta)[i], P = ((const Pack<T>*)p)[i];
+        if (pOwed) {
+            const Pack<T> P2 = ((const Pack<T>*)pOwed)[i];
+#pragma unroll
+            for (int k = 0; k < N; ++k) D.v[k] = D.v[k] + a2 * P2.v[k];
+        }
 #pragma unroll
         for (int k = 0; k < N; ++k) D.v[k] = D.v[k] + alpha * P.v[k];
         ((Pack<T>*)deltaOut)[i] = D;
@@ -750,10 +759,13 @@ struct PcgSolver : SolverBase {
             // reference's computeAdelta and second half are not run then.
             const bool lastAndSilent = lIter + 1 >= sp.lIterations && verbosity == 0;
             auto resetKernels = [&](T* deltaOut) {
-                flushOwed(0);      // delta complete through iteration lIter - 1 (also what an early-out decided below must find)
+                // (a term the adopted launch left owed goes in first, in the same pass; `delta` itself stays as it is: an early-out decided below flushes it there)
+                const T *pOwed = nullptr, *aOwed = nullptr;
+                if (appliedStep2 && !owedFlushed) (void)E->iterOwedTerm(0, &pOwed, &aOwed);
                 { ScopedKernel k(ctx, "PCGStep2_1stHalf");
-                  k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, deltaOut, pNow(), nPacks, nullptr, prev[0].partials, prev[0].n, prev[1].partials, prev[1].n); }
+                  k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, deltaOut, pNow(), nPacks, nullptr, prev[0].partials, prev[0].n, prev[1].partials, prev[1].n, pOwed, aOwed); }
                 if (lastAndSilent) return;
+                if (E->applyJTJResetLM(deltaOut, r, b, preArg, z, CtC, redB, redQR, ctx)) return;      // computeAdelta + the second half in one pass
                 E->applyJTJ(deltaOut, Adelta, CtC, nullptr, ctx);             // computeAdelta
                 { ScopedKernel k(ctx, "PCGStep2_2ndHalf");
                   k_step2SecondHalf<T><<<streamGrid, kBlock, 0, stream>>>(deltaOut, r, Adelta, b, preArg, z, nPacks, redB.partials, redQR.partials); }
@@ -798,9 +810,10 @@ struct PcgSolver : SolverBase {
             }
         }
         if (deltaOwed) {   // the last iteration's delta += alpha p; its r, z, p and Q are dead (the reference's last fetchQ can only break a finished loop)
-            E->iterFlushDelta(delta, 0, ctx);      // (... behind the term a deferring last launch left owed)
+            const T *pOwed = nullptr, *aOwed = nullptr;
+            (void)E->iterOwedTerm(0, &pOwed, &aOwed);      // (... behind the term a deferring last launch left owed)
             ScopedKernel k(ctx, "PCGStep2_delta");
-            k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, delta, pNow(), nPacks, nullptr, prev[0].partials, prev[0].n, prev[1].partials, prev[1].n);
+            k_step2FirstHalf<T><<<streamGrid, kBlock, 0, stream>>>(delta, delta, pNow(), nPacks, nullptr, prev[0].partials, prev[0].n, prev[1].partials, prev[1].n, pOwed, aOwed);
         }
         return true;
     }
