@@ -109,6 +109,17 @@ def test_2048_float_20_iterations(oracle_lib, monkeypatch, rows):
     _pair(oracle_lib, P, "gaussNewtonGPU", 1, 20, 1e-5, 1e-5)
 
 
+def test_2048_float_lm_25_iterations(oracle_lib):
+    """The same image under Levenberg-Marquardt on the launch-per-iteration loop of round 6 (no residual vector, Q by the CG recurrence, paired delta): two outer
+    steps of 25 PCG iterations -- two split residual resets with their restart launches and re-anchored Q, an odd number of launches (the tail adds an owed delta term) -- at the
+    size the reference's LM-only large-image mode is for (examples/image_warping/src/main.cpp:121-129), natural grid: costs and the trust-region radius at the float bars."""
+    P = wl.image_warping(2048, 2048)
+    rng = np.random.default_rng(2)
+    P.params[0] += (0.3 * rng.standard_normal(P.params[0].shape)).astype(np.float32)
+    P.params[1] += (0.1 * rng.standard_normal(P.params[1].shape)).astype(np.float32)
+    _pair(oracle_lib, P, "LMGPU", 2, 25, 1e-5, 1e-5, radius_tol=1e-3)
+
+
 # ---- (d) the benchmark workload against its frozen oracle trajectory ----------------------------------------------------------------
 def _golden():
     with open(os.path.join(HERE, "golden", "bench_costs.json")) as f:
