@@ -48,10 +48,10 @@ struct IterK {             // kernel argument block
     const T *rOld, *pOld; T *rNew, *pNew; T* delta; T* deltaOut;      // deltaOut == delta: in place
     const T* pre;          // the solver's 3-channel Jacobi preconditioner (PRE == 1)
     int first;             // first launch of a linear solve: alpha = beta = 0, r as given
-    // deltaMode 0: delta += alpha_{k-1} p_{k-1} in every launch (LM).  Paired (Gauss-Newton): 2 = this launch leaves delta alone, 1 = this launch applies the two
+    // deltaMode 0: delta += alpha_{k-1} p_{k-1} in every launch (LM with a general UrShape).  Paired (the r-free loops): 2 = this launch leaves delta alone, 1 = this launch applies the two
     // pending terms alpha_{k-2} p_{k-2} + alpha_{k-1} p_{k-1} in the reference's order -- 24 B/px every second launch instead of every launch.
     int deltaMode; const T* alphaIn; T* alphaOut;      // alpha_{k-2}, beta_{k-2} written by the previous launch ([0], [2]) / where this launch leaves its own
-    int rfree;             // 0: r in memory (LM);  1: rOld holds p_{k-2}, r rebuilt;  2: first two launches -- rOld holds the solver's r_0, r is not written either
+    int rfree;             // 0: r in memory (LM with a general UrShape);  1: rOld holds p_{k-2}, r rebuilt;  2: the two launches behind PCGInit1 / a reset -- rOld holds the solver's true r, r is not written either
     const T* CtC; const T* b; double* q; unsigned qTag; int afterReset; const double* betaNum; int nBetaNum; const double* betaDen; int nBetaDen;      // LM
     double* qState; double qInit;      // LM on a unit lattice (r-free): the running Q of the recurrence (one device double) / its value after a split residual reset (the host's direct sum)
     const double* prPrev; int nPr; double* pr;      // ... and the partial sums of p . r the previous launch left / this launch leaves (device memory, the energy's own)
