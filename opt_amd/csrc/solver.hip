@@ -753,7 +753,7 @@ struct PcgSolver : SolverBase {
             for (int i = 0; i < 4; ++i) prev[i] = setS[cur][i];
             cur ^= 1;
             afterReset = false;
-            const bool resetNow = ((lIter + 1) % sp.residual_reset_period) == 0;
+            const bool resetNow = sp.residual_reset_period > 0 && ((lIter + 1) % sp.residual_reset_period) == 0;      // (a period of 0: never -- Lua's x % 0 is nan, solver.t:1077)
             // The split residual reset (solver.t:1077-1083) of this iteration: delta += alpha p, then r = b - (J^T J + CtC) delta afresh.
             // After the last iteration only delta survives (r, z, the beta numerator and -- unless someone listens for the message -- Q are dead), so the
             // reference's computeAdelta and second half are not run then.
@@ -970,7 +970,7 @@ struct PcgSolver : SolverBase {
         const bool speculate = !traceEnabled;
         if (!single && sp.lIterations > 0) stepThreeAndOne();     // Step1 of iteration 0
         for (int lIter = 0; !single && lIter < sp.lIterations; ++lIter) {
-            const bool reset = lm && ((lIter + 1) % sp.residual_reset_period) == 0;
+            const bool reset = lm && sp.residual_reset_period > 0 && ((lIter + 1) % sp.residual_reset_period) == 0;
             // After the last iteration only delta survives: r, z, the beta numerator and (unless someone listens for the "breaking" message) Q are dead, so the
             // last PCGStep2 -- or the last split residual reset -- shrinks to its delta += alpha p.
             const bool deltaOnly = lIter + 1 >= sp.lIterations && !traceEnabled && !keepReferenceP && (!lm || verbosity == 0);

@@ -74,7 +74,7 @@ def test_image_warping_float_controls(oracle_lib, period, qtol):
 
 @pytest.mark.parametrize("double", [True, False])
 @pytest.mark.parametrize("period,qtol,liters", [(1, None, 6), (2, None, 10), (3, None, 12), (3, 0.5, 10), (10, None, 25), (10, 0.05, 12), (4, 0.0, 9), (7, None, 23), (5, 5.0, 10),
-                                                (10, 0.01, 40), (6, 0.002, 60)])
+                                                (10, 0.01, 40), (6, 0.002, 60), (10, None, 1), (10, None, 2), (10, None, 3), (2, None, 3), (1, None, 1), (1, None, 2), (3, 5.0, 4)])
 def test_image_warping_launch_per_iteration_loop_controls(oracle_lib, period, qtol, liters, double):
     """The same controls on the launch-per-iteration LM loop ("amd_onchip" = 0: what images past the on-chip range run on -- the reference's LM-only large-image case,
     examples/image_warping/src/main.cpp:121-129).  Round 6: on a unit lattice that loop keeps no residual vector (ring of three p buffers; true r only behind PCGInit1 and
