@@ -191,6 +191,13 @@ struct EnergyOps {
     // The solver's back-off after such a failure is over: clear the failure state (device word, pinned word, the path's own off switch) so that the next
     // pcgSolveOnChip launches again.  Stream-ordered.
     virtual void onChipRearm(LaunchCtx&) {}
+    // Opt_ProblemSolve may enqueue several Gauss-Newton steps before it reads anything back (PcgSolver: deferred steps).  A kernel set that supports it gives every such
+    // step's guarded update a word of its own (slot >= 0; -1: none), so that the host can tell afterwards WHICH step's on-chip solve gave up -- from that step on nothing was
+    // applied (the failure flag is sticky until onChipRearm) and the solver goes back to it.
+    virtual bool supportsDeferredSteps() const { return false; }
+    virtual void onChipStepSlot(int /*slot*/) {}
+    virtual bool onChipStepFailed(int /*slot*/) { return false; }
+    virtual void onChipClearStepSlots() {}
     // Slab mode, before the loop: will pcgIteration accept the launches?  (The solver refreshes the ghost rows of r_0, p_0 and M for that loop only: the
     // three-kernel loop relies on r being 0 on ghost rows -- its flat sums run over them.)
     virtual bool slabIterationAvailable() const { return true; }

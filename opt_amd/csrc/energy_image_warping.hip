@@ -53,6 +53,7 @@ struct ImageWarpingOps : EnergyOps<T> {
         if (const char* e = getenv("OPT_AMD_ONCHIP_ROWS")) ocForceRows = std::max(0, atoi(e));
         if (const char* e = getenv("OPT_AMD_ONCHIP_FLAT")) ocFlatMax = std::max(0, atoi(e));
         if (const char* e = getenv("OPT_AMD_ONCHIP_FAIL_AT")) ocFailAt = atoi(e);      // test hook: see OnchipArgs::failAt
+        if (const char* e = getenv("OPT_AMD_ONCHIP_FAIL_LAUNCH")) ocFailLaunch = atoi(e);      // ... in the n-th on-chip launch of the plan only (default: in every one)
         if (const char* e = getenv("OPT_AMD_ONCHIP_TIMEOUT_MS")) ocTimeoutTicks = std::max(1, atoi(e)) * 100000LL;
         HIP_CHECK(hipMalloc((void**)&dNotLattice, sizeof(int)));
         HIP_CHECK(hipHostMalloc((void**)&hNotLattice, 64)); *hNotLattice = 0;
@@ -439,7 +440,7 @@ struct ImageWarpingOps : EnergyOps<T> {
     struct OcVariant { int rows; bool apLds, deltaGlb; const void* fn; size_t lds; int occ; };
     std::vector<OcVariant> ocVariants, ocVariantsLM;
     bool ocEnabled = true, ocFailed = false, ocLaunched = false;
-    int ocForceRows = 0, ocFlatMax = 256, ocFailAt = -1; long long* ocProf = nullptr; long long ocTimeoutTicks = 0;      // 0: onchip_sync.h ocTimeouts() decides; OPT_AMD_ONCHIP_TIMEOUT_MS overrides
+    int ocForceRows = 0, ocFlatMax = 256, ocFailAt = -1, ocFailLaunch = -1, ocLaunchCount = 0; long long* ocProf = nullptr; long long ocTimeoutTicks = 0;      // 0: onchip_sync.h ocTimeouts() decides; OPT_AMD_ONCHIP_TIMEOUT_MS overrides
     OnchipSync ocS{}; unsigned ocSeq = 1; size_t ocInboxBytes = 0, ocSlotBytes = 0, ocGroupBytes = 0;
     void ocInit() {
         if (!ocVariants.empty()) return;
@@ -505,7 +506,7 @@ struct ImageWarpingOps : EnergyOps<T> {
             ocSlotBytes = sizeof(oc_u64) * 2 * (size_t)gMax * 2 * kOcSumsMax; ocGroupBytes = sizeof(oc_u64) * 2 * (size_t)divUp(gMax, kOcGroup) * 8;
             ocInboxBytes = sizeof(oc_u64) * 2 * (size_t)gMax * 4 * (size_t)ocS.stride;
             HIP_CHECK(hipMalloc((void**)&ocS.slots, ocSlotBytes)); HIP_CHECK(hipMalloc((void**)&ocS.groupSlots, ocGroupBytes)); HIP_CHECK(hipMalloc((void**)&ocS.inbox, ocInboxBytes));
-            if (!ocS.bad) { HIP_CHECK(hipMalloc((void**)&ocS.bad, sizeof(int))); HIP_CHECK(hipHostMalloc((void**)&ocS.hostErr, 64)); *ocS.hostErr = 0; HIP_CHECK(hipMemsetAsync(ocS.bad, 0, sizeof(int), ctx.stream)); }
+            if (!ocS.bad) { HIP_CHECK(hipMalloc((void**)&ocS.bad, sizeof(int))); HIP_CHECK(hipHostMalloc((void**)&ocS.hostErr, 64)); for (int w_ = 0; w_ < 16; ++w_) ocS.hostErr[w_] = 0; HIP_CHECK(hipMemsetAsync(ocS.bad, 0, sizeof(int), ctx.stream)); }
             ocSeq = 0xE0000001u;      // forces the clearing below
 #if OC_PROFILE
             if (getenv("OPT_AMD_ONCHIP_PROFILE")) { HIP_CHECK(hipMalloc((void**)&ocProf, sizeof(long long) * kOcWaves * 16 * kOcMaxTiles)); }
@@ -528,7 +529,8 @@ struct ImageWarpingOps : EnergyOps<T> {
         }
         const OcTimeouts tmo = ocTimeouts(ocTimeoutTicks, L, slabMode);
         OnchipArgs<T> K{A.W, A.H, tX, tY, G, A.yBegin, A.yEnd, links, r0, p0, A.Angle, A.flags, delta, A.w_fit, A.w_reg, L, ocSeq, G <= ocFlatMax ? 1 : 0, ocS, lmArgs ? lmArgs->breakInfo : traceDev,
-                        tmo.later, tmo.first, ocProf, ocFailAt, T(0), T(0), T(0), T(0), 1};
+                        tmo.later, tmo.first, ocProf, (ocFailLaunch < 0 || ocLaunchCount == ocFailLaunch) ? ocFailAt : -1, T(0), T(0), T(0), T(0), 1};
+        ++ocLaunchCount;
         if (lmArgs) { K.lmRadius = lmArgs->radius; K.lmMin = lmArgs->minLm; K.lmMax = lmArgs->maxLm; K.qTolerance = lmArgs->qTolerance; K.resetPeriod = lmArgs->resetPeriod; }
         ocSeq += nTags;
         {
@@ -565,13 +567,14 @@ struct ImageWarpingOps : EnergyOps<T> {
     // PCGLinearUpdate behind the on-chip Gauss-Newton solve.  verdict (row slabs): device scalar, the number of ranks whose kernel failed -- all ranks apply or none.
     // refused: this rank launched no kernel at all (its peers will time out): its contribution to the verdict is "failed".
     void onChipVerdict(double* out, bool refused, LaunchCtx& ctx) override {
-        if (!ocS.bad) { HIP_CHECK(hipMalloc((void**)&ocS.bad, sizeof(int))); HIP_CHECK(hipHostMalloc((void**)&ocS.hostErr, 64)); *ocS.hostErr = 0; HIP_CHECK(hipMemsetAsync(ocS.bad, 0, sizeof(int), ctx.stream)); }
+        if (!ocS.bad) { HIP_CHECK(hipMalloc((void**)&ocS.bad, sizeof(int))); HIP_CHECK(hipHostMalloc((void**)&ocS.hostErr, 64)); for (int w_ = 0; w_ < 16; ++w_) ocS.hostErr[w_] = 0; HIP_CHECK(hipMemsetAsync(ocS.bad, 0, sizeof(int), ctx.stream)); }
         iw_badToScalar<<<1, kWave, 0, ctx.stream>>>(ocS.bad, refused ? 1 : 0, out);
     }
     void onChipApply(const T* delta, const double* verdict, bool /*refused*/, LaunchCtx& ctx) override {
         ScopedKernel k(ctx, "PCGLinearUpdate");
         const long N = (long)A.W * A.H;
-        iw_applyDelta<T><<<flatGrid(N), kBlock, 0, ctx.stream>>>(const_cast<T*>(A.Offset), const_cast<T*>(A.Angle), delta, N, ocS.bad, verdict, ocS.hostErr);
+        iw_applyDelta<T><<<flatGrid(N), kBlock, 0, ctx.stream>>>(const_cast<T*>(A.Offset), const_cast<T*>(A.Angle), delta, N, ocS.bad, verdict, ocS.hostErr,
+                                                                 ocStepSlot >= 0 ? ocS.hostErr + 1 + ocStepSlot : nullptr);
         ocLaunched = true;
     }
     std::string describe(int L, bool lmv) override {      // ("key=value; ..." -- no ';' inside a value)
@@ -612,8 +615,14 @@ struct ImageWarpingOps : EnergyOps<T> {
         return true;
     }
     bool onChipFailedPeek() override { return ocLaunched && ocS.hostErr && __atomic_load_n(ocS.hostErr, __ATOMIC_ACQUIRE) != 0; }
+    int ocStepSlot = -1;      // (hostErr is 16 ints: word 0 "some launch failed", words 1 .. 15 one per deferred step)
+    bool supportsDeferredSteps() const override { return !this->slab.active; }
+    void onChipStepSlot(int slot) override { ocStepSlot = (slot >= 0 && slot < 15) ? slot : -1; }
+    bool onChipStepFailed(int slot) override { return ocS.hostErr && slot >= 0 && slot < 15 && __atomic_load_n(ocS.hostErr + 1 + slot, __ATOMIC_ACQUIRE) != 0; }
+    void onChipClearStepSlots() override { if (ocS.hostErr) for (int i = 1; i < 16; ++i) __atomic_store_n(ocS.hostErr + i, 0, __ATOMIC_RELEASE); }
     void onChipRearm(LaunchCtx& ctx) override {
         if (!ocS.bad) return;
+        onChipClearStepSlots();
         ocFailed = false; __atomic_store_n(ocS.hostErr, 0, __ATOMIC_RELEASE);
         HIP_CHECK(hipMemsetAsync(ocS.bad, 0, sizeof(int), ctx.stream));
     }

@@ -215,6 +215,9 @@ __global__ __launch_bounds__(kOcBlock, 2) void iw_onchipPcg(OnchipArgs<T> K) {
     const bool xin = x < K.W;
     const T w2 = K.w_reg * K.w_reg, wf2 = K.w_fit * K.w_fit;
     int* const bad = K.S.bad;
+    // A launch enqueued behind one whose wait timed out (Opt_ProblemSolve enqueues several Gauss-Newton steps before it reads anything back): nothing to do -- the flag is
+    // sticky until the host re-arms the path, PCGLinearUpdate checks it too, and waiting for peers again would cost the first-phase bound per launch.
+    if (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
 
     if (tid < 15) {      // the table of iw_pcgIter2: same accumulation order as iw_evalJTF, so the entries are the solver's preconditioner values bit for bit
         const int t = tid, cnt = t < 10 ? t % 5 : t - 10;
@@ -785,10 +788,13 @@ __global__ void iw_relayBad(const int* __restrict__ bad, int* hostErr) {
 // either every rank applies its delta or none does.
 template <class T>
 __global__ __launch_bounds__(kBlock) void iw_applyDelta(T* __restrict__ XO, T* __restrict__ XA, const T* __restrict__ delta, long N, const int* __restrict__ bad,
-                                                        const double* __restrict__ verdict, int* hostErr) {
+                                                        const double* __restrict__ verdict, int* hostErr, int* stepErr = nullptr) {
     const bool fail = verdict ? verdict[0] != 0.0 : __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     if (fail) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(hostErr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            __hip_atomic_store(hostErr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (stepErr) __hip_atomic_store(stepErr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (EnergyOps::onChipStepSlot: which of several enqueued steps this was)
+        }
         return;
     }
     V2<T>* xO = (V2<T>*)XO; const V2<T>* dO = (const V2<T>*)delta;

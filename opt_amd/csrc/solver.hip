@@ -388,6 +388,7 @@ struct PcgSolver : SolverBase {
         if (lmBreak) (void)hipHostFree(lmBreak);
         if (onChipTrace) (void)hipFree(onChipTrace);
         if (redCH.partials) (void)hipHostFree(redCH.partials);
+        for (Reduction& R : costRing) if (R.partials) (void)hipHostFree(R.partials);
         if (hostBufQ) { (void)hipHostFree(hostBufQ); (void)hipEventDestroy(qEvent); }
         (void)hipStreamDestroy(stream);
     }
@@ -407,6 +408,12 @@ struct PcgSolver : SolverBase {
     int onChipFailures = 0, onChipBackoff = 0, onChipCleanSteps = 0;
     bool boundForSolve = false;      // bind() has run inside the current Opt_ProblemSolve (SolverBase::insideSolve)
     bool jtfReady = false;           // the pass that computed the last step's cost also ran this step's PCGInit1 (EnergyOps::evalCostAndJTFInit; only inside Opt_ProblemSolve)
+    // Deferred Gauss-Newton steps (inside Opt_ProblemSolve, kernel sets with evalCostAndJTFInit): nothing a step computes steers the next one -- the cost is only reported --
+    // so up to kDefer - 1 steps are enqueued back to back and their costs (one pinned partials buffer each) and on-chip verdicts (one word each) are read at the next drain.
+    static constexpr int kDefer = 8;
+    struct PendingStep { int slot, step; bool onChip; };
+    std::vector<PendingStep> pendingSteps;
+    Reduction costRing[kDefer];
     bool onChipAllowed() const { return onChipOk && sp.amd_onchip != 0 && sp.amd_reference_order == 0; }
     bool singleKernelAllowed() const { return oneKernel && sp.amd_reference_order == 0; }
     double* lmBreak = nullptr;          // pinned: {iteration + 1, zeta} of an on-chip LM solve's q early-out (OnChipLm::breakInfo)
@@ -840,7 +847,7 @@ struct PcgSolver : SolverBase {
         exchangeUnknowns();
         E->precompute(ctx);
         // (inside Opt_ProblemSolve the first step follows at once on the same unknowns: its PCGInit1 rides on this cost pass where the kernel set can -- see stepOnce)
-        jtfReady = false;
+        jtfReady = false; pendingSteps.clear(); E->onChipStepSlot(-1);
         if (!lm && !distributed && insideSolve && E->bindInvariantDuringSolve() && sp.nIterations > 0 && singleKernelAllowed() && r2 && sp.lIterations > 0 &&
             E->evalCostAndJTFInit(redCH, r, p, delta, nPad, redC, ctx)) { jtfReady = true; prevCost = (T)hostSum(redCH); }
         else prevCost = computeCost();
@@ -889,12 +896,46 @@ struct PcgSolver : SolverBase {
             if (!again || attempt >= 1) return rc;
         }
     }
+    // Behind a drain: the costs of the deferred steps in order (printed as the reference prints them), and the first step whose on-chip solve gave up, or -1.
+    int settlePending() {
+        int failed = -1;
+        for (const PendingStep& ps : pendingSteps) {
+            if (ps.onChip && E->onChipStepFailed(ps.slot)) { failed = ps.step; break; }
+            double c = 0; for (int i = 0; i < costRing[ps.slot].n; ++i) c += costRing[ps.slot].partials[i];
+            if (verbosity > 0) printf("cost: %f -> %f\n", (double)prevCost, (double)(T)c);
+            prevCost = (T)c; lastStepOnChip = ps.onChip;
+        }
+        pendingSteps.clear();
+        E->onChipClearStepSlots();
+        return failed;
+    }
+    // The deferred step `f` found its on-chip solve timed out: nothing has been applied from it on (the flag is sticky: later launches return at once and every guarded
+    // update is skipped), so the solve goes back to step f on the streaming kernels.  r, p of the newest cost + PCGInit1 pass belong to exactly those unknowns.
+    void rewindTo(int f) {
+        (void)E->onChipFailed();      // (consumes the launch's failure word)
+        dropLease();
+        ++onChipFailures; onChipCleanSteps = 0; onChipBackoff = std::min(8 << std::min(onChipFailures - 1, 7), 1024);
+        if (onChipFailures <= 3)
+            fprintf(stderr, "Opt(amd): a wait inside the on-chip PCG kernel timed out (its workgroups were not co-resident: is the GPU shared?); the solve goes back to that step "
+                            "with the streaming kernels and the plan stays on them for %d steps before it tries the chip again\n", onChipBackoff);
+        onChipOk = false; onChipFellBack = true; lastStepOnChip = false; usedOnChip = false;
+        sp.nIter = f;
+    }
     int stepOnce(void** params, bool& again) {
         const T min_relative_decrease = (T)sp.min_relative_decrease, min_trust_region_radius = (T)sp.min_trust_region_radius;
         const T max_trust_region_radius = (T)sp.max_trust_region_radius, q_tolerance = (T)sp.q_tolerance, function_tolerance = (T)sp.function_tolerance;
         T Q0 = 0, Q1 = 0;
         if (!(insideSolve && boundForSolve && E->bindInvariantDuringSolve())) E->bind(params, ctx);      // (EnergyOps::bindInvariantDuringSolve: once per Opt_ProblemSolve where nothing bind() derives can have changed)
+        const bool mayDefer = !lm && !distributed && insideSolve && !traceEnabled && E->supportsDeferredSteps();
+        if (!pendingSteps.empty() && (!mayDefer || sp.nIter >= sp.nIterations)) {      // (cannot happen: the last step of a solve is never deferred -- kept so that no cost is ever lost)
+            drain();
+            const int f = settlePending();
+            if (f >= 0) { rewindTo(f); jtfReady = false; }
+        }
         if (sp.nIter >= sp.nIterations) { cleanup(); return 0; }
+        const int deferSlot = mayDefer ? (int)pendingSteps.size() : -1;
+        E->onChipStepSlot(deferSlot);
+        bool deferredNow = false;
         const T* preArg = E->usePreconditioner ? preconditioner : nullptr;   // solver.t:467-470: pre = 1 unless the energy preconditions
 
         // PCGInit1 [+ _Graph + _Finish]: the energy produces r = -J^T F and raw diag(J^T J) (parked in CtC) -- or, for the Gauss-Newton single-kernel loop on
@@ -1059,12 +1100,40 @@ struct PcgSolver : SolverBase {
                 // an on-chip time-out included) does not ask.
                 const bool carry = !lm && !distributed && insideSolve && boundForSolve && E->bindInvariantDuringSolve() && sp.nIter + 1 < sp.nIterations &&
                                    singleKernelAllowed() && r2 && sp.lIterations > 0;
-                if (carry && E->evalCostAndJTFInit(redCH, r, p, delta, nPad, redC, ctx)) { jtfReady = true; newCost = (T)hostSum(redCH); }
-                else newCost = computeCost();
+                Reduction& costR = deferSlot >= 0 ? costRing[deferSlot] : redCH;
+                if (deferSlot >= 0 && !costR.partials) { HIP_CHECK(hipHostMalloc((void**)&costR.partials, 2 * kMaxPartials * sizeof(double))); costR.hostVisible = true; }
+                if (carry && E->evalCostAndJTFInit(costR, r, p, delta, nPad, redC, ctx)) {
+                    jtfReady = true;
+                    if (deferSlot >= 0 && deferSlot + 1 < kDefer) deferredNow = true;      // nothing is read back now: the next step is enqueued behind this one
+                    else newCost = (T)hostSum(costR);
+                } else newCost = computeCost();
             }
         };
         afterLinearSolve();
 
+        if (deferredNow) {      // (the lease stays with this plan until the steps are settled)
+            pendingSteps.push_back({deferSlot, sp.nIter, usedOnChip});
+            usedOnChip = false;
+            sp.nIter += 1;
+            if (!onChipOk && onChipFailures > 0 && ++onChipCleanSteps >= onChipBackoff) {      // back-off over (these were streaming steps): the next step tries the chip again
+                onChipOk = true; onChipFellBack = false;
+                E->onChipRearm(ctx);
+            }
+            return 1;
+        }
+        if (!pendingSteps.empty()) {      // the stream has drained (this step's cost was read): what the deferred steps before it left
+            const bool thisOnChip = usedOnChip;
+            const int f = settlePending();
+            if (f >= 0) {
+                // from step f on nothing was applied -- unless THIS step ran on the streaming kernels (it cannot while the path is armed; if it did, it was a valid step from
+                // the unknowns of step f and counts as that step)
+                rewindTo(f);
+                if (!thisOnChip) { if (verbosity > 0) printf("cost: %f -> %f\n", (double)prevCost, (double)newCost); prevCost = newCost; sp.nIter = f + 1; }
+                else if (!jtfReady) { /* the last step of the solve carried no PCGInit1: the next step runs its own */ }
+                return 1;
+            }
+            if (!usedOnChip) dropLease();
+        }
         lastStepOnChip = usedOnChip;
         if (usedOnChip) {      // (the stream has drained: the cost was read)
             usedOnChip = false;
