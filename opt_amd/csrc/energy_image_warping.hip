@@ -141,13 +141,16 @@ struct ImageWarpingOps : EnergyOps<T> {
         return !this->slab.active && (unsigned long long)A.W * A.H * 3ull * sizeof(T) < (1ull << 32);
     }
     T *initR = nullptr, *initP = nullptr; Reduction* initRed = nullptr; bool initHint = false, initPending = false, deltaZero = false;
-    void launchJtf(bool lat, LaunchCtx& ctx, Reduction* cost = nullptr) {
+    void launchJtf(bool lat, LaunchCtx& ctx, Reduction* cost = nullptr, const JtfLm<T>* lmInit = nullptr) {
         ScopedKernel k(ctx, cost ? "computeCost+PCGInit1" : "PCGInit1");
         int gx, gy, rpg; marchGrid(A.yEnd - A.yBegin, gx, gy, rpg);
         if (cost) {
             if (lat) iw_jtfMarch<T, true, true><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, initRed->partials, cost->partials, rpg, gx, gy);
             else iw_jtfMarch<T, false, true><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, initRed->partials, cost->partials, rpg, gx, gy);
             cost->n = gx * gy;
+        } else if (lmInit) {
+            if (lat) iw_jtfMarch<T, true, false, true><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, initRed->partials, nullptr, rpg, gx, gy, *lmInit);
+            else iw_jtfMarch<T, false, false, true><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, initRed->partials, nullptr, rpg, gx, gy, *lmInit);
         } else if (lat) iw_jtfMarch<T, true, false><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, initRed->partials, nullptr, rpg, gx, gy);
         else iw_jtfMarch<T, false, false><<<gx * gy, kBlock, 0, ctx.stream>>>(A, initR, initP, initRed->partials, nullptr, rpg, gx, gy);
         initRed->n = gx * gy;
@@ -170,6 +173,18 @@ struct ImageWarpingOps : EnergyOps<T> {
         initR = r; initP = p; initRed = &aNum0; initHint = resolveLattice();
         launchJtf(initHint, ctx, &cost);
         deltaZero = true; initPending = true;
+        return true;
+    }
+    // Levenberg-Marquardt's PCGInit1 + PCGSaveSSq + PCGFinalizeDiagonal as one march (iw_jtfMarch<.., LMINIT>; single GPU).  The cost of this Init / Step has been read by
+    // now, so the lattice verdict is known and the variant launched is final.
+    bool evalJTFInitLM(const LmInitArgs<T>& a, LaunchCtx& ctx) override {
+        if (!fastGN()) return false;
+        const bool lat = resolveLattice();
+        initR = a.r; initP = a.p; initRed = a.rDotP; initHint = lat; initPending = false;
+        const JtfLm<T> L{a.CtC, a.SSq, a.delta, a.pre, a.b, a.radius, a.minLm, a.maxLm, a.saveSSq, a.q->partials};
+        launchJtf(lat, ctx, nullptr, &L);
+        a.q->n = a.rDotP->n;
+        deltaZero = false;      // (this pass writes delta = 0 itself: the LM loops read it)
         return true;
     }
     void evalCost(Reduction& out, LaunchCtx& ctx) override {

@@ -424,9 +424,14 @@ __global__ __launch_bounds__(kBlock) void iw_bindMarch(IWArgs<T> A, int* __restr
 // r = -J^T F, p = guardedInvert(diag J^T J) r, partial sums of r.p (the iteration kernels rebuild M themselves: no preconditioner vector is written)
 // COST: the same pass also sums computeCost's 1/2 r^2 (iw_costMarch's expressions, operand for operand, on the same grid: the same partial sums) -- the end of one
 // Gauss-Newton step and the PCGInit1 of the next read the same unknowns, so inside Opt_ProblemSolve the two marches are one (PcgSolver: costAndJTFInit).
-template <class T, bool LATTICE, bool COST>
+// LMINIT: the pass is Levenberg-Marquardt's PCGInit1 + PCGSaveSSq + PCGFinalizeDiagonal (solver.t:361-419, 624-664; solver.hip k_finalizeDiagonal<T, true>, expression for
+// expression, on the diagonal this pass has just formed): CtC, the LM preconditioner, b = r, p = M r, delta = 0 and -- first outer iteration -- SSq, instead of a cos / sin
+// table pass, a gathering J^T F pass that parks diag J^T J in memory and a flat pass that reads it back.
+template <class T>
+struct JtfLm { T *CtC, *SSq, *delta, *pre, *b; T radius, minLm, maxLm; int saveSSq; double* qPartials; };
+template <class T, bool LATTICE, bool COST, bool LMINIT = false>
 __global__ __launch_bounds__(kBlock) void iw_jtfMarch(IWArgs<T> A, T* __restrict__ r, T* __restrict__ p, double* __restrict__ partials, double* __restrict__ costPartials,
-                                                      int rowsPerGroup, int gx, int gy) {
+                                                      int rowsPerGroup, int gx, int gy, JtfLm<T> L = JtfLm<T>{}) {
     __shared__ double scratch[kBlock / kWave + 1];
     const MarchGeo g = marchGeo(A, rowsPerGroup, gx, gy);
     const long N = (long)A.W * A.H;
@@ -471,7 +476,26 @@ __global__ __launch_bounds__(kBlock) void iw_jtfMarch(IWArgs<T> A, T* __restrict
             const long i = (long)y * A.W + g.x;
             const T r0 = -Fx, r1 = -Fy, r2 = -Fa;
             const T sO = T(1) + sqrt(Pxy), sA = T(1) + sqrt(Pa);
-            const T mO = T(1) / (sO * sO), mA = T(1) / (sA * sA);         // solver.hip guardedInvert (solver.t:323-332)
+            T mO = T(1) / (sO * sO), mA = T(1) / (sA * sA);         // solver.hip guardedInvert (solver.t:323-332)
+            if (LMINIT) {
+                T sso = mO, ssa = mA;      // PCGSaveSSq: the first outer iteration's guardedInvert(diag)
+                V2<T>* ssO = (V2<T>*)L.SSq; T* ssA = L.SSq + 2 * N;
+                if (L.saveSSq) { ssO[i] = V2<T>{sso, sso}; ssA[i] = ssa; } else { const V2<T> so = ssO[i]; sso = so.x; ssa = ssA[i]; }      // (diag's two Offset components are one value, so SSq's are too)
+                const T invRadius = T(1) / L.radius;
+                auto fin = [&](T diag, T S, T& c, T& m) {
+                    const T unclamped = diag * invRadius;                 // computeCtC: diag(J^T J) / radius (o.t:2277-2279)
+                    const T invS = T(1) / S, clampMul = invS / L.radius;
+                    c = fmin(fmax(unclamped, L.minLm * clampMul), L.maxLm * clampMul);
+                    m = T(1) / (c + L.radius * unclamped);
+                };
+                T cO, cA;
+                fin(Pxy, sso, cO, mO); fin(Pa, ssa, cA, mA);
+                ((V2<T>*)L.CtC)[i] = V2<T>{cO, cO}; L.CtC[2 * N + i] = cA;
+                ((V2<T>*)L.pre)[i] = V2<T>{mO, mO}; L.pre[2 * N + i] = mA;
+                ((V2<T>*)L.b)[i] = V2<T>{r0, r1}; L.b[2 * N + i] = r2;
+                ((V2<T>*)L.delta)[i] = V2<T>{0, 0}; L.delta[2 * N + i] = 0;
+                ((V2<T>*)A.cs)[i] = V2<T>{cur.c, cur.s};      // the cos / sin table the LM step's other passes read (model cost, the reset's J^T J pass): iw_cossin's values
+            }
             const T p0 = mO * r0, p1 = mO * r1, p2 = mA * r2;
             rO[i] = V2<T>{r0, r1}; ra[i] = r2;
             pO[i] = V2<T>{p0, p1}; pa[i] = p2;
@@ -494,6 +518,7 @@ __global__ __launch_bounds__(kBlock) void iw_jtfMarch(IWArgs<T> A, T* __restrict
         const double tc = blockReduceSum(accCost, scratch);
         if (threadIdx.x == 0) costPartials[blockIdx.x] = tc;
     }
+    if (LMINIT && threadIdx.x == 0) L.qPartials[blockIdx.x] = 0.0;      // Q_0 = 1/2 sum delta . (r + b) with delta = 0
 }
 
 // 1/2 sum r^2 over the non-excluded pixels of the workgroup's rows (iw_cost's expressions)

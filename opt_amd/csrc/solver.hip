@@ -1129,8 +1129,7 @@ struct PcgSolver : SolverBase {
                 // the unknowns of step f and counts as that step)
                 rewindTo(f);
                 if (!thisOnChip) { if (verbosity > 0) printf("cost: %f -> %f\n", (double)prevCost, (double)newCost); prevCost = newCost; sp.nIter = f + 1; }
-                else if (!jtfReady) { /* the last step of the solve carried no PCGInit1: the next step runs its own */ }
-                return 1;
+                return 1;      // (jtfReady says whether this step's cost pass carried a PCGInit1 for the unknowns as they stand; the last step of a solve carries none)
             }
             if (!usedOnChip) dropLease();
         }
