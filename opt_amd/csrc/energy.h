@@ -194,6 +194,8 @@ struct EnergyOps {
     // Opt_ProblemSolve may enqueue several Gauss-Newton steps before it reads anything back (PcgSolver: deferred steps).  A kernel set that supports it gives every such
     // step's guarded update a word of its own (slot >= 0; -1: none), so that the host can tell afterwards WHICH step's on-chip solve gave up -- from that step on nothing was
     // applied (the failure flag is sticky until onChipRearm) and the solver goes back to it.
+    // pcgIteration takes delta from its arguments at every launch and keeps no pointer to it: the solver may move the vector between two launches (PcgSolver::deltaTrial)
+    virtual bool deltaMovable() const { return false; }
     virtual bool supportsDeferredSteps() const { return false; }
     virtual void onChipStepSlot(int /*slot*/) {}
     virtual bool onChipStepFailed(int /*slot*/) { return false; }

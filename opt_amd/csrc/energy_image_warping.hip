@@ -632,6 +632,7 @@ struct ImageWarpingOps : EnergyOps<T> {
     bool onChipFailedPeek() override { return ocLaunched && ocS.hostErr && __atomic_load_n(ocS.hostErr, __ATOMIC_ACQUIRE) != 0; }
     int ocStepSlot = -1;      // (hostErr is 16 ints: word 0 "some launch failed", words 1 .. 15 one per deferred step)
     bool supportsDeferredSteps() const override { return !this->slab.active; }
+    bool deltaMovable() const override { return !this->slab.active; }
     void onChipStepSlot(int slot) override { ocStepSlot = (slot >= 0 && slot < 15) ? slot : -1; }
     bool onChipStepFailed(int slot) override { return ocS.hostErr && slot >= 0 && slot < 15 && __atomic_load_n(ocS.hostErr + 1 + slot, __ATOMIC_ACQUIRE) != 0; }
     void onChipClearStepSlots() override { if (ocS.hostErr) for (int i = 1; i < 16; ++i) __atomic_store_n(ocS.hostErr + i, 0, __ATOMIC_RELEASE); }

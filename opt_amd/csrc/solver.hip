@@ -361,6 +361,7 @@ struct PcgSolver : SolverBase {
         if (lm) { b = allocVec(); Adelta = allocVec(); SSq = allocVec(); prevX = allocVec(); }
         p2 = allocVec();
         if (const char* e = getenv("OPT_AMD_ONEKERNEL")) oneKernel = atoi(e) != 0;
+        if (const char* e = getenv("OPT_AMD_DELTA_TRIAL")) trialMode = atoi(e);
         if (const char* e = getenv("OPT_AMD_ONEKERNEL_LM")) oneKernelLM = atoi(e) != 0;
         r2 = allocVec(); Ap2 = allocVec();                // second r / A p buffers of the single-kernel iterations (kernels that keep A p in memory read the old one on a halo)
         for (auto& st : setS) for (auto& R : st) R = allocRed();
@@ -389,6 +390,7 @@ struct PcgSolver : SolverBase {
         if (onChipTrace) (void)hipFree(onChipTrace);
         if (redCH.partials) (void)hipHostFree(redCH.partials);
         for (Reduction& R : costRing) if (R.partials) (void)hipHostFree(R.partials);
+        for (hipEvent_t e : trialEv) if (e) (void)hipEventDestroy(e);
         if (hostBufQ) { (void)hipHostFree(hostBufQ); (void)hipEventDestroy(qEvent); }
         (void)hipStreamDestroy(stream);
     }
@@ -410,6 +412,50 @@ struct PcgSolver : SolverBase {
     bool jtfReady = false;           // the pass that computed the last step's cost also ran this step's PCGInit1 (EnergyOps::evalCostAndJTFInit; only inside Opt_ProblemSolve)
     // Deferred Gauss-Newton steps (inside Opt_ProblemSolve, kernel sets with evalCostAndJTFInit): nothing a step computes steers the next one -- the cost is only reported --
     // so up to kDefer - 1 steps are enqueued back to back and their costs (one pinned partials buffer each) and on-chip verdicts (one word each) are read at the next drain.
+    // Where delta lives (round 6).  delta is the one vector the Gauss-Newton loop reads AND writes, and the time of a launch follows the region the allocator put it in
+    // (profiles/NOTES.md: 173 / 176 / 191 us at 4096^2 for the same binary in one process, region by region; the ring, the flag bytes and the caller's arrays do not matter).
+    // The first long linear solve of a large single-GPU plan therefore tries kTrialCands allocations of it: after launch kTrialFirst delta is copied into a fresh vector
+    // every kTrialWindow launches (a copy: no bit changes), each window is timed with one event pair, the loop goes on in the fastest and the others are freed.
+    // OPT_AMD_DELTA_TRIAL=0: off, 2: report on stderr.
+    static constexpr int kTrialCands = 4, kTrialWindow = 6, kTrialFirst = 4;
+    int trialMode = 1, trialPhase = 0, trialAttempts = 0; std::vector<T*> trialVecs; std::vector<float> trialMs; hipEvent_t trialEv[2] = {nullptr, nullptr};
+    void trialDrop(T* keep) {      // free every trial vector but `keep`
+        for (T* v : trialVecs) if (v != keep) { for (auto it = allocs.begin(); it != allocs.end(); ++it) if (*it == (void*)v) { allocs.erase(it); break; } (void)hipFree(v); }
+        trialVecs.clear(); trialMs.clear();
+    }
+    void deltaTrial(int lIter) {
+        if (lIter == 0) {
+            if (trialPhase == 1) { trialDrop(delta); trialPhase = 0; }      // the last solve ended inside the trial: it stayed where it had got to
+            if (trialPhase == 0 && trialAttempts < 2 && sp.lIterations > kTrialFirst + kTrialCands * kTrialWindow) { trialPhase = 1; ++trialAttempts; trialVecs.assign(1, delta); trialMs.clear(); }
+        }
+        if (trialPhase != 1 || lIter < kTrialFirst || (lIter - kTrialFirst) % kTrialWindow != 0) return;
+        const int w = (lIter - kTrialFirst) / kTrialWindow;      // the window about to start
+        if (!trialEv[0]) { HIP_CHECK(hipEventCreate(&trialEv[0])); HIP_CHECK(hipEventCreate(&trialEv[1])); }
+        if (w > 0) {
+            float ms = 0;
+            HIP_CHECK(hipEventRecord(trialEv[1], stream)); HIP_CHECK(hipEventSynchronize(trialEv[1])); HIP_CHECK(hipEventElapsedTime(&ms, trialEv[0], trialEv[1]));
+            trialMs.push_back(ms);
+        }
+        auto moveTo = [&](T* to) { if (to != delta) { HIP_CHECK(hipMemcpyAsync(to, delta, nPad * sizeof(T), hipMemcpyDeviceToDevice, stream)); delta = to; } };
+        if (w == 0) { HIP_CHECK(hipEventRecord(trialEv[0], stream)); return; }
+        if (w < kTrialCands) {
+            T* v = nullptr;
+            if (hipMalloc((void**)&v, nPad * sizeof(T)) == hipSuccess) {
+                allocs.push_back(v); trialVecs.push_back(v);
+                moveTo(v);
+                HIP_CHECK(hipEventRecord(trialEv[0], stream));
+                return;
+            }
+            (void)hipGetLastError();      // (no room for another: decide among those timed so far)
+        }
+        int best = 0;
+        for (int i = 1; i < (int)trialMs.size(); ++i) if (trialMs[i] < trialMs[best]) best = i;
+        if (trialMode > 1) { fprintf(stderr, "Opt(amd): delta placement trial, ms per %d launches:", kTrialWindow); for (float m : trialMs) fprintf(stderr, " %.3f", m); fprintf(stderr, " -> %d\n", best); }
+        moveTo(trialVecs[(size_t)best]);
+        HIP_CHECK(hipStreamSynchronize(stream));      // (the copy out of a vector about to be freed has finished)
+        trialDrop(delta);
+        trialPhase = 2;
+    }
     static constexpr int kDefer = 8;
     struct PendingStep { int slot, step; bool onChip; };
     std::vector<PendingStep> pendingSteps;
@@ -660,6 +706,7 @@ struct PcgSolver : SolverBase {
             if (distributed && commExt.allReducePlan && lIter + 1 < sp.lIterations && !traceEnabled && E->iterPostsItself(false))
                 planned = commExt.allReducePlan(comm.ctx, 4, &a.post, &nextMail) != 0;
             if (distributed && lIter > 0 && !E->iterStateExchange) exchangeVector(Ap_X);   // kernel with Ap in memory: r and p ghost rows are kept current by the kernel itself
+            if (!distributed && !traceEnabled && trialMode && trialPhase != 2 && nPad * sizeof(T) >= ((size_t)64 << 20) && E->deltaMovable()) { deltaTrial(lIter); a.delta = delta; }
             if (!E->pcgIteration(a, ctx)) { if (lIter == 0) return false; fprintf(stderr, "pcgIteration refused mid-loop\n"); exit(1); }
             std::swap(r, r2); std::swap(Ap_X, Ap2); std::swap(p, p2);
             if (distributed && E->iterStateExchange && E->iterExchangeDue) {   // Ap-free kernel: the neighbours' edge rows of r_k and p_k, one grouped exchange

@@ -223,3 +223,35 @@ def test_config4_arap_500k_lm_steps_vs_oracle(oracle_lib):
     launch -- at full size (500 556 vertices: 768 workgroups walking their XCD eighths)."""
     P = wl.arap_mesh_deformation(708, 707, perturb=0.01)
     _pair(oracle_lib, P, "LMGPU", 2, 12, 1e-5, 1e-5, radius_tol=1e-3)
+
+
+def test_delta_placement_trial_changes_no_bit(monkeypatch, capfd):
+    """Round 6: delta is the one vector the Gauss-Newton loop reads and writes, and the time of a launch follows the region the allocator put it in (profiles/NOTES.md).  The
+    first long linear solve of a large single-GPU plan copies delta into a fresh vector every six launches (four candidates, each window timed) and goes on in the fastest
+    (PcgSolver::deltaTrial).  A copy is a copy: unknowns and costs are the bits of a run with the trial switched off; the trial does run (its report names four timings) and a
+    second solve on the same plan does not repeat it; a solve too short for four windows leaves everything as it is."""
+    P = wl.image_warping(2400, 2400, random_state=6, perturb=0.3)
+    res = []
+    for trial in ("0", "2"):
+        monkeypatch.setenv("OPT_AMD_DELTA_TRIAL", trial)
+        g = hip_solver(P, "gaussNewtonGPU", nIterations=3, lIterations=40)
+        dev = api.to_device(P)
+        capfd.readouterr()
+        g.init(dev)
+        costs = [g.cost()]
+        while g.step(dev):
+            costs.append(g.cost())
+        costs.append(g.cost())
+        err = capfd.readouterr().err
+        res.append((costs, device_unknowns(P, dev), err))
+        g.close()
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
+    assert "delta placement trial" not in res[0][2]
+    assert res[1][2].count("delta placement trial") == 1 and len(res[1][2].split("launches:")[1].split("->")[0].split()) == 4, res[1][2]
+    monkeypatch.setenv("OPT_AMD_DELTA_TRIAL", "2")
+    g = hip_solver(P, "gaussNewtonGPU", nIterations=2, lIterations=20)      # 20 < 4 + 4 x 6 launches: no trial
+    dev = api.to_device(P)
+    capfd.readouterr()
+    g.solve(dev)
+    assert "delta placement trial" not in capfd.readouterr().err
+    g.close()
