@@ -218,6 +218,7 @@ struct OpticalFlowOps : StencilOps<T, OpticalFlowE<T>> {
     MarchLoop<T> march; T* coef = nullptr; bool useMarch = true;
     OpticalFlowOps(const unsigned* dims) : StencilOps<T, OpticalFlowE<T>>(dims, false) { if (const char* e = getenv("OPT_AMD_FLOW_MARCH")) useMarch = atoi(e) != 0; if (useMarch) oc.template reserveFor<FlowMarchOp<T>>(this->e.W, this->e.H, this->cus); }
     ~OpticalFlowOps() override { if (coef) (void)hipFree(coef); }
+    bool deltaMovable() const override { return useMarch && !this->slab.active; }      // (PcgSolver::deltaTrial)
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
         if (!useMarch || a.pre || a.CtC) return false;      // Gauss-Newton only
         const long n = (long)this->e.W * this->e.H;
@@ -282,6 +283,7 @@ struct IntrinsicOps : StencilOps<T, IntrinsicE<T>> {
     MarchLoop<T> march; T* coef = nullptr; bool useMarch = true;
     IntrinsicOps(const unsigned* dims) : StencilOps<T, IntrinsicE<T>>(dims, false) { if (const char* e = getenv("OPT_AMD_INTRINSIC_MARCH")) useMarch = atoi(e) != 0; if (useMarch) oc.template reserveFor<IntrinsicMarchOp<T>>(this->e.W, this->e.H, this->cus); }
     ~IntrinsicOps() override { if (coef) (void)hipFree(coef); }
+    bool deltaMovable() const override { return useMarch && !this->slab.active; }      // (PcgSolver::deltaTrial)
     bool pcgIteration(const PcgIterArgs<T>& a, LaunchCtx& ctx) override {
         if (!useMarch || a.pre || a.CtC) return false;      // Gauss-Newton only
         const long n = (long)this->e.W * this->e.H;

@@ -295,6 +295,7 @@ struct PoissonOps : EnergyOps<T> {
         return march.launch(PoissonMarchOp<T>{}, A.W, A.H, flags, cus, a, ctx);
     }
     const T* pcgFinish(const T*, T* delta, LaunchCtx& ctx) override { return march.finish(delta, 4L * A.W * A.H, cus, ctx); }
+    bool deltaMovable() const override { return !this->slab.active; }      // (the march takes delta from its arguments at every launch: PcgSolver::deltaTrial)
     // ---- the whole Gauss-Newton linear solve on chip (stencil_onchip.h) ----
     OnchipMarch<T> oc;
     bool onChipWithoutPreconditioner() const override { return true; }
@@ -413,6 +414,7 @@ struct LaplacianOps : EnergyOps<float> {
         return march.launch(LaplacianMarchOp{}, A.W, A.H, nullptr, cus, a, ctx);
     }
     const float* pcgFinish(const float*, float* delta, LaunchCtx& ctx) override { return march.finish(delta, (long)A.W * A.H, cus, ctx); }
+    bool deltaMovable() const override { return !this->slab.active; }
     OnchipMarch<float> oc;      // the whole Gauss-Newton linear solve on chip (stencil_onchip.h)
     bool onChipWithoutPreconditioner() const override { return true; }
     bool pcgSolveOnChip(const float* r0, const float* p0, float* delta, int L, double* traceDev, const OnChipLm<float>* lm, LaunchCtx& ctx) override {

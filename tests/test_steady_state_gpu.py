@@ -255,3 +255,19 @@ def test_delta_placement_trial_changes_no_bit(monkeypatch, capfd):
     g.solve(dev)
     assert "delta placement trial" not in capfd.readouterr().err
     g.close()
+
+
+def test_delta_placement_trial_on_the_march_template_changes_no_bit(monkeypatch, capfd):
+    """The same trial on the marching template's Gauss-Newton loop (poisson_image_editing 2048^2: 64 MiB vectors, the smallest the trial looks at)."""
+    P = wl.poisson_image_editing(2048, 2048, seed=3)
+    res = []
+    for trial in ("0", "2"):
+        monkeypatch.setenv("OPT_AMD_DELTA_TRIAL", trial)
+        g = hip_solver(P, "gaussNewtonGPU", nIterations=2, lIterations=40)
+        dev = api.to_device(P)
+        capfd.readouterr()
+        g.solve(dev)
+        res.append((g.cost(), device_unknowns(P, dev), capfd.readouterr().err))
+        g.close()
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
+    assert "delta placement trial" not in res[0][2] and res[1][2].count("delta placement trial") == 1, res[1][2]
