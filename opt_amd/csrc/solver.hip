@@ -1264,6 +1264,10 @@ struct PcgSolver : SolverBase {
         if (!sp.amd_reference_order && !sp.amd_onchip) d += "; amd_onchip=0";
         if (!sp.amd_reference_order && !oneKernel) d += "; OPT_AMD_ONEKERNEL=0 (reference-order loop by environment)";
         if (onChipFailures) d += "; onchip_fallbacks=" + std::to_string(onChipFailures) + "; onchip_backoff_steps_left=" + std::to_string(onChipOk ? 0 : onChipBackoff - onChipCleanSteps);
+        // what Opt_ProblemSolve does beyond Init + Step by Step on this plan, and where the trial over delta's placement stands
+        if (!lm && !distributed && E->supportsDeferredSteps()) d += "; solve_enqueues_steps_back_to_back=up to " + std::to_string(kDefer - 1);
+        if (!lm && !distributed && E->deltaMovable() && nPad * sizeof(T) >= ((size_t)64 << 20))
+            d += std::string("; delta_placement_trial=") + (!trialMode ? "off" : trialPhase == 2 ? "done" : trialPhase == 1 ? "running" : "before the first linear solve of more than 28 launches");
         d += std::string("; solver=") + (lm ? "LM" : "GN") + "; distributed=" + (distributed ? "yes" : "no") + "; comm_world=" + std::to_string(distributed ? comm.world : 1) +
              "; comm_ext=" + (commExt.onChipPlan ? "onChipPlan " : "") + (commExt.allReducePost ? "allReducePost " : "") + (commExt.allReducePartials ? "allReducePartials" : "");
         return d;

@@ -244,6 +244,7 @@ def test_delta_placement_trial_changes_no_bit(monkeypatch, capfd):
         costs.append(g.cost())
         err = capfd.readouterr().err
         res.append((costs, device_unknowns(P, dev), err))
+        assert g.describe().get("delta_placement_trial") == ("off" if trial == "0" else "done"), g.describe()      # (OptAmd_PlanDescribe says where the trial stands)
         g.close()
     assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
     assert "delta placement trial" not in res[0][2]
